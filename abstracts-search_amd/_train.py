@@ -1,0 +1,116 @@
+"""IndexIVFPQ.train (setup; reference Makefile:39 `index train`): k-means for
+the nlist coarse centroids and for the M sub-quantiser codebooks.
+
+Not on the timed path.  The assignment steps -- the only
+heavy part -- run on the library's own kernels through the C ABI
+(``mi_ip_assign``: exact-f32 MFMA GEMM + arg max; ``mi_pq_encode``: nearest
+codeword per sub-vector).  The centroid means are torch scatter-adds on the
+device (plumbing).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_void_p
+
+import numpy as np
+
+
+def _lib():
+    from .faiss import _Lib
+    return _Lib.get()
+
+
+def _check(rc):
+    from .faiss import _check as c
+    c(rc)
+
+
+def _to_device_sample(x, nmax: int, seed: int, device: int):
+    """Random subsample (faiss: max_points_per_centroid * k) -> CUDA f32 tensor."""
+    import torch
+    dev = torch.device("cuda", device)
+    n = x.shape[0]
+    if n > nmax:
+        rng = np.random.default_rng(seed)
+        sel = np.sort(rng.choice(n, nmax, replace=False))
+        if type(x).__module__.startswith("torch"):
+            x = x[torch.as_tensor(sel, device=x.device)]
+        else:
+            x = x[sel]
+    if type(x).__module__.startswith("torch"):
+        return x.to(dev, torch.float32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+
+
+def _assign_ip(x, c, device):
+    import torch
+    n = x.shape[0]
+    a = torch.empty(n, dtype=torch.int32, device=x.device)
+    stream = c_void_p(torch.cuda.current_stream().cuda_stream)
+    _check(_lib().mi_ip_assign(device, n, c_void_p(x.data_ptr()), c.shape[0], c_void_p(c.data_ptr()),
+                               x.shape[1], c_void_p(a.data_ptr()), c_void_p(0), stream))
+    return a.long()
+
+
+def kmeans_l2(x, k: int, niter: int, seed: int, device: int, verbose: bool = False):
+    """Lloyd k-means, L2.  arg min ||x-c||^2 = arg max (<x,c> - ||c||^2/2), evaluated
+    by the inner-product kernel on vectors augmented with 4 columns
+    ([x, 1, 0, 0, 0] . [c, -||c||^2/2, 0, 0, 0])."""
+    import torch
+    n, d = x.shape
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    perm = torch.randperm(n, generator=g)[:k].to(x.device)
+    c = x[perm].clone()
+    if n <= k:  # degenerate: fewer points than centroids
+        c = torch.cat([c, c[torch.randint(0, max(n, 1), (k - c.shape[0],), generator=g).to(x.device)]])
+    xa = torch.cat([x, torch.ones(n, 1, device=x.device), torch.zeros(n, 3, device=x.device)], 1).contiguous()
+    for it in range(niter):
+        ca = torch.cat([c, -0.5 * (c * c).sum(1, keepdim=True), torch.zeros(k, 3, device=x.device)], 1).contiguous()
+        a = _assign_ip(xa, ca, device)
+        sums = torch.zeros(k, d, device=x.device).index_add_(0, a, x)
+        cnt = torch.bincount(a, minlength=k).to(torch.float32)
+        empty = cnt == 0
+        c = sums / cnt.clamp(min=1).unsqueeze(1)
+        ne = int(empty.sum())
+        if ne:  # re-seed empty clusters from random points
+            idx = torch.randint(0, n, (ne,), generator=g).to(x.device)
+            c[empty] = x[idx]
+        if verbose:
+            print(f"  kmeans iter {it}: {ne} empty clusters")
+    return c.contiguous()
+
+
+def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbose: bool = False):
+    import torch
+    d = x.shape[1]
+    dsub = d // M
+    # coarse centroids
+    xs = _to_device_sample(x, cp.max_points_per_centroid * nlist, cp.seed, device)
+    if verbose:
+        print(f"train: coarse k-means on {xs.shape[0]} points, k={nlist}")
+    cent = kmeans_l2(xs, nlist, cp.niter, cp.seed, device, verbose)
+    # PQ codebooks on (residual) sub-vectors
+    xp = _to_device_sample(x, cp.max_points_per_centroid * 256, cp.seed + 1, device)
+    if by_residual:
+        a = _assign_ip(xp, cent, device)
+        xp = (xp - cent[a]).contiguous()
+    n = xp.shape[0]
+    g = torch.Generator(device="cpu").manual_seed(cp.seed + 2)
+    init = torch.randperm(n, generator=g)[:256]
+    if init.numel() < 256:
+        init = torch.cat([init, torch.randint(0, n, (256 - init.numel(),), generator=g)])
+    cb = xp[init.to(xp.device)].view(256, M, dsub).permute(1, 0, 2).contiguous()  # [M,256,dsub]
+    codes = torch.empty(n, M, dtype=torch.uint8, device=xp.device)
+    stream = lambda: c_void_p(torch.cuda.current_stream().cuda_stream)
+    offs = (torch.arange(M, device=xp.device) * 256).unsqueeze(0)
+    for it in range(cp.niter):
+        _check(_lib().mi_pq_encode(device, n, c_void_p(xp.data_ptr()), d, M, c_void_p(cb.data_ptr()),
+                                   c_void_p(codes.data_ptr()), stream()))
+        idx = (codes.long() + offs).reshape(-1)
+        sums = torch.zeros(M * 256, dsub, device=xp.device).index_add_(0, idx, xp.view(n * M, dsub))
+        cnt = torch.bincount(idx, minlength=M * 256).to(torch.float32)
+        new = sums / cnt.clamp(min=1).unsqueeze(1)
+        keep = (cnt == 0).unsqueeze(1)
+        cb = torch.where(keep, cb.view(M * 256, dsub), new).view(M, 256, dsub).contiguous()
+    torch.cuda.synchronize()
+    return cent, cb

@@ -1,0 +1,108 @@
+// common.h -- host-side plumbing shared by the C-ABI translation units:
+// error capture (no exception crosses the ABI), grow-only device buffers,
+// host/device pointer classification.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace mi {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+inline std::string &last_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+#define MI_HIP(expr)                                                                  \
+    do {                                                                              \
+        hipError_t mi_e_ = (expr);                                                    \
+        if (mi_e_ != hipSuccess)                                                      \
+            throw mi::Error(std::string(#expr) + " failed: " + hipGetErrorString(mi_e_)); \
+    } while (0)
+
+#define MI_REQUIRE(cond, msg)                         \
+    do {                                              \
+        if (!(cond)) throw mi::Error(std::string(msg)); \
+    } while (0)
+
+template <class F>
+int guard(F &&f) {
+    try {
+        f();
+        last_error().clear();
+        return 0;
+    } catch (const std::exception &e) {
+        last_error() = e.what();
+        return 1;
+    } catch (...) {
+        last_error() = "unknown error";
+        return 1;
+    }
+}
+
+// Grow-only device allocation.  hipFree synchronises the device, so growing a
+// workspace that an in-flight kernel still reads is safe (just slow): sizes
+// settle after the first call of a given shape.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    void *reserve(size_t bytes) {
+        if (bytes > cap) {
+            release();
+            size_t want = bytes + bytes / 8 + 256;
+            MI_HIP(hipMalloc(&p, want));
+            cap = want;
+        }
+        return p;
+    }
+    template <class T>
+    T *as(size_t count) {
+        return static_cast<T *>(reserve(count * sizeof(T)));
+    }
+    template <class T>
+    T *get() const {
+        return static_cast<T *>(p);
+    }
+};
+
+// true if `ptr` is dereferenceable by a kernel on the current device.
+inline bool is_device_ptr(const void *ptr) {
+    if (!ptr) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'd host memory: not an error for us
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+struct DeviceGuard {
+    int prev = 0;
+    explicit DeviceGuard(int dev) {
+        MI_HIP(hipGetDevice(&prev));
+        if (dev != prev) MI_HIP(hipSetDevice(dev));
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace mi

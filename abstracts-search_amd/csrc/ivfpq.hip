@@ -1,0 +1,814 @@
+// ivfpq.hip -- C ABI (include/mi_ivfpq.h) over the gfx950 kernels of
+// ivfpq_kernels.h.  Host orchestration only: no arithmetic of the hot path
+// happens on the CPU here, and there is no CPU fallback -- without a HIP
+// device every entry point fails with an error.
+#include "../../include/mi_ivfpq.h"
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <utility>
+#include <vector>
+
+#include "common.h"
+#include "ivfpq_kernels.h"
+
+using namespace mi;
+
+namespace {
+
+hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ------------------------------------------------------------------
+// kernel launch helpers
+// ------------------------------------------------------------------
+
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+void launch_gemm_cfg(const float *A, int na, const float *B, int nb, int d, float *S, int64_t ldS,
+                     hipStream_t st) {
+    constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
+    int tiles_m = (na + BM - 1) / BM, tiles_n = (nb + BN - 1) / BN;
+    int64_t grid = (int64_t)8 * tiles_m * ((tiles_n + 7) / 8);
+    MI_REQUIRE(grid < (int64_t)1 << 31, "ip_gemm: grid too large");
+    hipLaunchKernelGGL((ip_gemm_kernel<WM, WN, WAVES_M, WAVES_N>), dim3((unsigned)grid),
+                       dim3(WAVES_M * WAVES_N * 64), 0, st, A, na, B, nb, d, S, ldS, tiles_m,
+                       tiles_n);
+    MI_HIP(hipGetLastError());
+}
+
+// S[na][nb] = A . B^T (exact f32).  Tile shape by the number of A rows: small
+// query batches get many small tiles (one 16x16 MFMA tile per wave, so that a
+// 64 x 4096 problem still fills all 1024 SIMDs), big batches get 128x128.
+void launch_gemm(const float *A, int64_t na, const float *B, int64_t nb, int d, float *S,
+                 int64_t ldS, hipStream_t st) {
+    MI_REQUIRE(d % 4 == 0, "d must be a multiple of 4");
+    MI_REQUIRE(na > 0 && nb > 0, "empty gemm");
+    MI_REQUIRE(na < ((int64_t)1 << 31) && nb < ((int64_t)1 << 31), "gemm dims exceed int32");
+    if (na <= 16) launch_gemm_cfg<1, 1, 1, 4>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    else if (na <= 128) launch_gemm_cfg<1, 1, 4, 1>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    else if (na <= 512) launch_gemm_cfg<2, 2, 2, 2>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    else launch_gemm_cfg<4, 4, 2, 2>(A, (int)na, B, (int)nb, d, S, ldS, st);
+}
+
+void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int32_t *oi32,
+                   int64_t *oi64, float *os, hipStream_t st) {
+    MI_REQUIRE(K >= 1, "select: K < 1");
+    hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(256), 0, st, S, ldS, n, K, oi32,
+                       oi64, os);
+    MI_HIP(hipGetLastError());
+}
+
+void launch_lut(const float *q, int nq, int d, int M, const float *cb, float *lut, hipStream_t st) {
+    const int dsub = d / M;
+    const int qtile = 8;
+    dim3 grid(M, (nq + qtile - 1) / qtile), block(256);
+    switch (dsub) {
+#define MI_LUT_CASE(DS)                                                                      \
+    case DS:                                                                                 \
+        hipLaunchKernelGGL((lut_kernel<DS>), grid, block, 0, st, q, nq, d, M, cb, lut, qtile); \
+        break;
+        MI_LUT_CASE(1)
+        MI_LUT_CASE(2)
+        MI_LUT_CASE(4)
+        MI_LUT_CASE(8)
+        MI_LUT_CASE(16)
+        MI_LUT_CASE(32)
+        MI_LUT_CASE(64)
+#undef MI_LUT_CASE
+        default:
+            throw Error("unsupported d/M (sub-vector length must be 1,2,4,8,16,32 or 64)");
+    }
+    MI_HIP(hipGetLastError());
+}
+
+void launch_pq_encode(const float *x, int64_t n, int d, int M, const float *cb, const float *cent,
+                      const int32_t *assign, uint8_t *codes, hipStream_t st) {
+    const int dsub = d / M;
+    dim3 grid((unsigned)((n + 255) / 256), M), block(256);
+    switch (dsub) {
+#define MI_ENC_CASE(DS)                                                                        \
+    case DS:                                                                                   \
+        hipLaunchKernelGGL((pq_encode_kernel<DS>), grid, block, 0, st, x, n, d, M, cb, cent, assign, \
+                           codes);                                                             \
+        break;
+        MI_ENC_CASE(1)
+        MI_ENC_CASE(2)
+        MI_ENC_CASE(4)
+        MI_ENC_CASE(8)
+        MI_ENC_CASE(16)
+        MI_ENC_CASE(32)
+        MI_ENC_CASE(64)
+#undef MI_ENC_CASE
+        default:
+            throw Error("unsupported d/M (sub-vector length must be 1,2,4,8,16,32 or 64)");
+    }
+    MI_HIP(hipGetLastError());
+}
+
+template <int M>
+void launch_scan_m(const ScanArgs &a, size_t smem, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<M>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((scan_kernel<M>), dim3((unsigned)((int64_t)a.nq * a.nslice)), dim3(512), smem,
+                       st, a);
+    MI_HIP(hipGetLastError());
+}
+
+bool scan_supports_M(int M) {
+    switch (M) {
+        case 4: case 8: case 16: case 32: case 48: case 64: case 96: case 128: return true;
+        default: return false;
+    }
+}
+
+void launch_scan(int M, const ScanArgs &a, hipStream_t st) {
+    size_t smem = scan_smem_bytes(M, a.nprobe);
+    MI_REQUIRE(smem <= 160 * 1024, "nprobe too large for the LDS probe tables");
+    switch (M) {
+        case 4: launch_scan_m<4>(a, smem, st); break;
+        case 8: launch_scan_m<8>(a, smem, st); break;
+        case 16: launch_scan_m<16>(a, smem, st); break;
+        case 32: launch_scan_m<32>(a, smem, st); break;
+        case 48: launch_scan_m<48>(a, smem, st); break;
+        case 64: launch_scan_m<64>(a, smem, st); break;
+        case 96: launch_scan_m<96>(a, smem, st); break;
+        case 128: launch_scan_m<128>(a, smem, st); break;
+        default: throw Error("unsupported M (PQ sub-quantisers: 4,8,16,32,48,64,96,128)");
+    }
+}
+
+void launch_merge(const float *ps, const int64_t *pid, int nparts, int64_t stride_p,
+                  int64_t stride_q, int64_t nq, int k, float *D, int64_t *I, int64_t ldo,
+                  int out_off, float *bs, int64_t *bid, hipStream_t st) {
+    size_t smem = merge_smem_bytes(nparts, k);
+    MI_REQUIRE(smem <= 64 * 1024, "merge: nparts*k too large");
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), smem, st, ps, pid, nparts,
+                       stride_p, stride_q, k, D, I, ldo, out_off, bs, bid);
+    MI_HIP(hipGetLastError());
+}
+
+// copy `bytes` to the device if `src` is a host pointer; returns a device pointer.
+const void *to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t st) {
+    if (is_device_ptr(src)) return src;
+    void *dst = stage.reserve(bytes);
+    MI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    return dst;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------
+
+struct mi_index {
+    int d = 0, nlist = 0, M = 0, dsub = 0, metric = 0, by_residual = 1, device = 0;
+    bool has_coarse = false, has_codebook = false;
+    DevBuf centroids, codebook;
+    // master copy of the inverted lists (insertion order, row-major codes)
+    std::vector<std::vector<uint8_t>> h_codes;
+    std::vector<std::vector<int64_t>> h_ids;
+    int64_t ntotal = 0;
+    bool dirty = true;
+    // device image (group-interleaved, see ivfpq_kernels.h)
+    DevBuf d_codes, d_ids, d_goff, d_len;
+    int64_t ngroups = 0;
+    // workspaces
+    DevBuf ws_q, ws_scores, ws_cidx, ws_cdis, ws_lut, ws_ps, ws_pid, ws_bs, ws_bid, ws_D, ws_I;
+    DevBuf ws_x, ws_assign, ws_codes, ws_ids, ws_count;
+    // scan-kernel timing
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    int64_t last_scan_bytes = 0;
+
+    int nch() const { return (M + 15) / 16; }
+    ~mi_index() {
+        for (auto &e : evs) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+    }
+};
+
+struct mi_flat {
+    int d = 0, device = 0;
+    int64_t ntotal = 0;
+    DevBuf base;
+    DevBuf ws_q, ws_scores, ws_D, ws_I;
+};
+
+namespace {
+
+void require_trained(mi_index *h) {
+    MI_REQUIRE(h->has_coarse && h->has_codebook, "index is not trained (set_coarse/set_codebook)");
+}
+
+// rebuild the device image of the inverted lists from the host master copy
+void sync_lists(mi_index *h) {
+    if (!h->dirty) return;
+    const int nlist = h->nlist, M = h->M, NCH = h->nch();
+    std::vector<int32_t> goff(nlist + 1, 0), len(nlist, 0);
+    int64_t g = 0;
+    for (int l = 0; l < nlist; ++l) {
+        goff[l] = (int32_t)g;
+        int64_t n = (int64_t)h->h_ids[l].size();
+        MI_REQUIRE(n < ((int64_t)1 << 31), "list too long");
+        len[l] = (int32_t)n;
+        g += (n + 63) / 64;
+        MI_REQUIRE(g * 64 < ((int64_t)1 << 32), "more than 2^32 padded codes on one device");
+    }
+    goff[nlist] = (int32_t)g;
+    h->ngroups = g;
+    const size_t gbytes = (size_t)NCH * 1024;
+    std::vector<uint8_t> codes((size_t)std::max<int64_t>(g, 1) * gbytes, 0);
+    std::vector<int64_t> ids((size_t)std::max<int64_t>(g, 1) * 64, -1);
+    for (int l = 0; l < nlist; ++l) {
+        const uint8_t *src = h->h_codes[l].data();
+        const int64_t n = len[l];
+        for (int64_t e = 0; e < n; ++e) {
+            const size_t grp = (size_t)goff[l] + (size_t)(e >> 6);
+            const int lane = (int)(e & 63);
+            uint8_t *dst = codes.data() + grp * gbytes + (size_t)lane * 16;
+            const uint8_t *c = src + (size_t)e * M;
+            for (int ch = 0; ch < NCH; ++ch)
+                std::memcpy(dst + (size_t)ch * 1024, c + ch * 16, (size_t)std::min(16, M - ch * 16));
+            ids[grp * 64 + lane] = h->h_ids[l][e];
+        }
+    }
+    MI_HIP(hipMemcpy(h->d_codes.reserve(codes.size()), codes.data(), codes.size(), hipMemcpyHostToDevice));
+    MI_HIP(hipMemcpy(h->d_ids.reserve(ids.size() * 8), ids.data(), ids.size() * 8, hipMemcpyHostToDevice));
+    MI_HIP(hipMemcpy(h->d_goff.reserve(goff.size() * 4), goff.data(), goff.size() * 4, hipMemcpyHostToDevice));
+    MI_HIP(hipMemcpy(h->d_len.reserve(len.size() * 4), len.data(), len.size() * 4, hipMemcpyHostToDevice));
+    h->dirty = false;
+}
+
+// coarse assign + PQ encode of n vectors (device pointer xdev); results stay in
+// ws_assign / ws_codes on the device.
+void encode_chunk(mi_index *h, const float *xdev, int64_t n, hipStream_t st) {
+    float *scores = h->ws_scores.as<float>((size_t)n * h->nlist);
+    int32_t *assign = h->ws_assign.as<int32_t>((size_t)n);
+    uint8_t *codes = h->ws_codes.as<uint8_t>((size_t)n * h->M);
+    launch_gemm(xdev, n, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st);
+    launch_select(scores, h->nlist, n, h->nlist, 1, assign, nullptr, nullptr, st);
+    launch_pq_encode(xdev, n, h->d, h->M, h->codebook.get<float>(),
+                     h->by_residual ? h->centroids.get<float>() : nullptr, assign, codes, st);
+}
+
+int64_t add_chunk_size(const mi_index *h) {
+    int64_t c = ((int64_t)1 << 28) / std::max(1, h->nlist);  // <= 1 GiB of scores
+    return std::min<int64_t>(std::max<int64_t>(c, 256), 65536);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------
+
+extern "C" {
+
+const char *mi_last_error(void) { return last_error().c_str(); }
+
+int mi_device_count(int *count) {
+    return guard([&] {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            n = 0;
+        }
+        *count = n;
+    });
+}
+
+int mi_index_create(int d, int nlist, int M, int nbits, int metric, int by_residual, int device,
+                    mi_index **out) {
+    return guard([&] {
+        MI_REQUIRE(out != nullptr, "out is null");
+        MI_REQUIRE(metric == MI_METRIC_INNER_PRODUCT,
+                   "only METRIC_INNER_PRODUCT is implemented on the MI355X path");
+        MI_REQUIRE(nbits == 8, "only nbits == 8 is implemented");
+        MI_REQUIRE(d > 0 && M > 0 && d % M == 0, "d must be a positive multiple of M");
+        MI_REQUIRE(d % 4 == 0, "d must be a multiple of 4");
+        MI_REQUIRE(nlist > 0, "nlist must be positive");
+        MI_REQUIRE(scan_supports_M(M), "unsupported M (PQ sub-quantisers: 4,8,16,32,48,64,96,128)");
+        int dsub = d / M;
+        MI_REQUIRE(dsub == 1 || dsub == 2 || dsub == 4 || dsub == 8 || dsub == 16 || dsub == 32 ||
+                       dsub == 64,
+                   "unsupported d/M (sub-vector length must be 1,2,4,8,16,32 or 64)");
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0) {
+            (void)hipGetLastError();
+            throw Error("no HIP device available: the MI355X index has no CPU fallback");
+        }
+        MI_REQUIRE(device >= 0 && device < ndev, "invalid device ordinal");
+        auto h = std::make_unique<mi_index>();
+        h->d = d; h->nlist = nlist; h->M = M; h->dsub = dsub; h->metric = metric;
+        h->by_residual = by_residual ? 1 : 0; h->device = device;
+        h->h_codes.resize(nlist);
+        h->h_ids.resize(nlist);
+        *out = h.release();
+    });
+}
+
+int mi_index_destroy(mi_index *h) {
+    return guard([&] {
+        if (!h) return;
+        DeviceGuard dg(h->device);
+        delete h;
+    });
+}
+
+int mi_index_set_coarse(mi_index *h, const float *centroids) {
+    return guard([&] {
+        MI_REQUIRE(h && centroids, "null argument");
+        DeviceGuard dg(h->device);
+        size_t bytes = (size_t)h->nlist * h->d * sizeof(float);
+        MI_HIP(hipMemcpy(h->centroids.reserve(bytes), centroids, bytes, hipMemcpyDefault));
+        h->has_coarse = true;
+    });
+}
+
+int mi_index_set_codebook(mi_index *h, const float *codebook) {
+    return guard([&] {
+        MI_REQUIRE(h && codebook, "null argument");
+        DeviceGuard dg(h->device);
+        size_t bytes = (size_t)h->M * 256 * h->dsub * sizeof(float);
+        MI_HIP(hipMemcpy(h->codebook.reserve(bytes), codebook, bytes, hipMemcpyDefault));
+        h->has_codebook = true;
+    });
+}
+
+int mi_index_get_coarse(mi_index *h, float *out) {
+    return guard([&] {
+        MI_REQUIRE(h && out, "null argument");
+        MI_REQUIRE(h->has_coarse, "no coarse centroids set");
+        DeviceGuard dg(h->device);
+        MI_HIP(hipMemcpy(out, h->centroids.p, (size_t)h->nlist * h->d * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int mi_index_get_codebook(mi_index *h, float *out) {
+    return guard([&] {
+        MI_REQUIRE(h && out, "null argument");
+        MI_REQUIRE(h->has_codebook, "no codebook set");
+        DeviceGuard dg(h->device);
+        MI_HIP(hipMemcpy(out, h->codebook.p, (size_t)h->M * 256 * h->dsub * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int mi_index_is_trained(mi_index *h, int *out) {
+    return guard([&] {
+        MI_REQUIRE(h && out, "null argument");
+        *out = (h->has_coarse && h->has_codebook) ? 1 : 0;
+    });
+}
+
+int mi_index_ntotal(mi_index *h, int64_t *out) {
+    return guard([&] {
+        MI_REQUIRE(h && out, "null argument");
+        *out = h->ntotal;
+    });
+}
+
+int mi_index_reset(mi_index *h) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        for (auto &v : h->h_codes) std::vector<uint8_t>().swap(v);
+        for (auto &v : h->h_ids) std::vector<int64_t>().swap(v);
+        h->ntotal = 0;
+        h->dirty = true;
+    });
+}
+
+int mi_index_encode(mi_index *h, int64_t n, const float *x, int32_t *list_no, uint8_t *codes) {
+    return guard([&] {
+        MI_REQUIRE(h && (n == 0 || x), "null argument");
+        require_trained(h);
+        DeviceGuard dg(h->device);
+        const int64_t chunk = add_chunk_size(h);
+        const bool xdev = is_device_ptr(x);
+        for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+            int64_t m = std::min(chunk, n - c0);
+            const float *xs = x + (size_t)c0 * h->d;
+            if (!xdev) {
+                float *stage = h->ws_x.as<float>((size_t)m * h->d);
+                MI_HIP(hipMemcpy(stage, xs, (size_t)m * h->d * 4, hipMemcpyHostToDevice));
+                xs = stage;
+            }
+            encode_chunk(h, xs, m, nullptr);
+            if (list_no) MI_HIP(hipMemcpy(list_no + c0, h->ws_assign.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+            if (codes) MI_HIP(hipMemcpy(codes + (size_t)c0 * h->M, h->ws_codes.p, (size_t)m * h->M, hipMemcpyDeviceToHost));
+        }
+    });
+}
+
+int mi_index_add_codes(mi_index *h, int64_t n, const int32_t *list_no, const uint8_t *codes,
+                       const int64_t *ids) {
+    return guard([&] {
+        MI_REQUIRE(h && (n == 0 || (list_no && codes)), "null argument");
+        for (int64_t i = 0; i < n; ++i)
+            MI_REQUIRE(list_no[i] >= 0 && list_no[i] < h->nlist, "list number out of range");
+        for (int64_t i = 0; i < n; ++i) {
+            int l = list_no[i];
+            h->h_codes[l].insert(h->h_codes[l].end(), codes + (size_t)i * h->M, codes + (size_t)(i + 1) * h->M);
+            h->h_ids[l].push_back(ids ? ids[i] : h->ntotal + i);
+        }
+        h->ntotal += n;
+        h->dirty = true;
+    });
+}
+
+int mi_index_add(mi_index *h, int64_t n, const float *x, const int64_t *ids) {
+    return guard([&] {
+        MI_REQUIRE(h && (n == 0 || x), "null argument");
+        require_trained(h);
+        DeviceGuard dg(h->device);
+        std::vector<int64_t> ids_host;
+        if (ids && is_device_ptr(ids)) {
+            ids_host.resize((size_t)n);
+            MI_HIP(hipMemcpy(ids_host.data(), ids, (size_t)n * 8, hipMemcpyDeviceToHost));
+            ids = ids_host.data();
+        }
+        const int64_t chunk = add_chunk_size(h);
+        const bool xdev = is_device_ptr(x);
+        std::vector<int32_t> a_host;
+        std::vector<uint8_t> c_host;
+        for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+            int64_t m = std::min(chunk, n - c0);
+            const float *xs = x + (size_t)c0 * h->d;
+            if (!xdev) {
+                float *stage = h->ws_x.as<float>((size_t)m * h->d);
+                MI_HIP(hipMemcpy(stage, xs, (size_t)m * h->d * 4, hipMemcpyHostToDevice));
+                xs = stage;
+            }
+            encode_chunk(h, xs, m, nullptr);
+            a_host.resize((size_t)m);
+            c_host.resize((size_t)m * h->M);
+            MI_HIP(hipMemcpy(a_host.data(), h->ws_assign.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+            MI_HIP(hipMemcpy(c_host.data(), h->ws_codes.p, (size_t)m * h->M, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < m; ++i) {
+                int l = a_host[i];
+                MI_REQUIRE(l >= 0 && l < h->nlist, "internal: bad list assignment");
+                h->h_codes[l].insert(h->h_codes[l].end(), c_host.begin() + (size_t)i * h->M,
+                                     c_host.begin() + (size_t)(i + 1) * h->M);
+                h->h_ids[l].push_back(ids ? ids[c0 + i] : h->ntotal + c0 + i);
+            }
+        }
+        h->ntotal += n;
+        h->dirty = true;
+    });
+}
+
+int mi_index_list_size(mi_index *h, int list_no, int64_t *out) {
+    return guard([&] {
+        MI_REQUIRE(h && out, "null argument");
+        MI_REQUIRE(list_no >= 0 && list_no < h->nlist, "list number out of range");
+        *out = (int64_t)h->h_ids[list_no].size();
+    });
+}
+
+int mi_index_get_list(mi_index *h, int list_no, uint8_t *codes, int64_t *ids) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        MI_REQUIRE(list_no >= 0 && list_no < h->nlist, "list number out of range");
+        if (codes) std::memcpy(codes, h->h_codes[list_no].data(), h->h_codes[list_no].size());
+        if (ids) std::memcpy(ids, h->h_ids[list_no].data(), h->h_ids[list_no].size() * 8);
+    });
+}
+
+int mi_index_profile_enable(mi_index *h, int on) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        h->prof = on != 0;
+    });
+}
+
+int mi_index_profile_read(mi_index *h, double *scan_ms_avg, int64_t *launches, int64_t *last_bytes) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        DeviceGuard dg(h->device);
+        double tot = 0.0;
+        int64_t n = 0;
+        for (auto &e : h->evs) {
+            MI_HIP(hipEventSynchronize(e.second));
+            float ms = 0.f;
+            MI_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+            tot += ms;
+            ++n;
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        h->evs.clear();
+        if (h->ws_count.p) {
+            unsigned long long c = 0;
+            MI_HIP(hipMemcpy(&c, h->ws_count.p, 8, hipMemcpyDeviceToHost));
+            h->last_scan_bytes = (int64_t)c * (h->M + 8);
+        }
+        if (scan_ms_avg) *scan_ms_avg = n ? tot / (double)n : 0.0;
+        if (launches) *launches = n;
+        if (last_bytes) *last_bytes = h->last_scan_bytes;
+    });
+}
+
+// Number of (query, slice) workgroups: enough to fill 2 x 256 CUs, but never
+// fewer than ~8 code groups (one per wave) of expected work per slice.
+static int choose_nslice(const mi_index *h, int64_t nq, int nprobe) {
+    double avg_groups = h->nlist > 0 ? (double)h->ngroups / h->nlist : 0.0;
+    double per_query = avg_groups * nprobe;
+    int64_t by_fill = (1024 + nq - 1) / nq;
+    int64_t by_work = (int64_t)(per_query / 8.0);
+    int64_t s = std::min(by_fill, by_work);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(s, 32));
+}
+
+static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int nprobe, float *Ddev,
+                         int64_t *Idev, hipStream_t st, int32_t *cI_out, float *cD_out,
+                         float *lut_out, bool stop_after_lut) {
+    const int M = h->M;
+    float *scores = h->ws_scores.as<float>((size_t)nq * h->nlist);
+    int32_t *cidx = h->ws_cidx.as<int32_t>((size_t)nq * nprobe);
+    float *cdis = h->ws_cdis.as<float>((size_t)nq * nprobe);
+    float *lut = h->ws_lut.as<float>((size_t)nq * M * 256);
+    launch_gemm(qdev, nq, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st);
+    launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st);
+    launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
+    if (cI_out) MI_HIP(hipMemcpyAsync(cI_out, cidx, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
+    if (cD_out) MI_HIP(hipMemcpyAsync(cD_out, cdis, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
+    if (lut_out) MI_HIP(hipMemcpyAsync(lut_out, lut, (size_t)nq * M * 256 * 4, hipMemcpyDeviceToHost, st));
+    if (stop_after_lut) return;
+
+    const int nslice = choose_nslice(h, nq, nprobe);
+    const int npass = (k + 63) / 64;
+    float *ps = h->ws_ps.as<float>((size_t)nq * nslice * 64);
+    int64_t *pid = h->ws_pid.as<int64_t>((size_t)nq * nslice * 64);
+    float *bs = nullptr;
+    int64_t *bid = nullptr;
+    if (npass > 1) {
+        bs = h->ws_bs.as<float>((size_t)nq);
+        bid = h->ws_bid.as<int64_t>((size_t)nq);
+    }
+    if (h->prof) {
+        unsigned long long *cnt = h->ws_count.as<unsigned long long>(1);
+        MI_HIP(hipMemsetAsync(cnt, 0, 8, st));
+        int64_t n = nq * nprobe;
+        hipLaunchKernelGGL(count_codes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           cidx, n, h->d_len.get<int32_t>(), cnt);
+        MI_HIP(hipGetLastError());
+    }
+    for (int pass = 0; pass < npass; ++pass) {
+        const int kp = std::min(64, k - pass * 64);
+        ScanArgs a;
+        a.lut = lut; a.coarse_idx = cidx; a.coarse_dis = cdis;
+        a.list_goff = h->d_goff.get<int32_t>(); a.list_len = h->d_len.get<int32_t>();
+        a.codes = h->d_codes.get<uint8_t>(); a.ids = h->d_ids.get<int64_t>();
+        a.part_s = ps; a.part_id = pid;
+        a.bound_s = pass ? bs : nullptr; a.bound_id = pass ? bid : nullptr;
+        a.nq = (int)nq; a.nprobe = nprobe; a.nslice = nslice; a.k = kp; a.by_residual = h->by_residual;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->prof) {
+            MI_HIP(hipEventCreate(&e0));
+            MI_HIP(hipEventCreate(&e1));
+            MI_HIP(hipEventRecord(e0, st));
+        }
+        launch_scan(M, a, st);
+        if (h->prof) {
+            MI_HIP(hipEventRecord(e1, st));
+            h->evs.emplace_back(e0, e1);
+        }
+        launch_merge(ps, pid, nslice, kp, (int64_t)nslice * kp, nq, kp, Ddev, Idev, k, pass * 64,
+                     npass > 1 ? bs : nullptr, npass > 1 ? bid : nullptr, st);
+    }
+}
+
+static int64_t query_chunk_size(const mi_index *h) {
+    int64_t c = ((int64_t)1 << 28) / std::max(1, h->nlist);  // scores <= 1 GiB
+    c = std::min<int64_t>(c, 4096);                          // LUT <= 4096 * M KiB
+    return std::max<int64_t>(c, 64);
+}
+
+int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe, float *D, int64_t *I,
+                    void *stream) {
+    return guard([&] {
+        MI_REQUIRE(h && (nq == 0 || (q && D && I)), "null argument");
+        MI_REQUIRE(k >= 1 && k <= 1024, "k must be in [1, 1024]");
+        MI_REQUIRE(nprobe >= 1, "nprobe must be >= 1");
+        require_trained(h);
+        if (nq == 0) return;
+        DeviceGuard dg(h->device);
+        hipStream_t st = as_stream(stream);
+        nprobe = std::min(nprobe, h->nlist);
+        sync_lists(h);
+        const bool qd = is_device_ptr(q), Dd = is_device_ptr(D), Id = is_device_ptr(I);
+        const int64_t chunk = query_chunk_size(h);
+        for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
+            const int64_t m = std::min(chunk, nq - c0);
+            const float *qs = q + (size_t)c0 * h->d;
+            if (!qd) qs = static_cast<const float *>(to_device(qs, (size_t)m * h->d * 4, h->ws_q, st));
+            float *Dc = Dd ? D + (size_t)c0 * k : h->ws_D.as<float>((size_t)m * k);
+            int64_t *Ic = Id ? I + (size_t)c0 * k : h->ws_I.as<int64_t>((size_t)m * k);
+            search_chunk(h, m, qs, k, nprobe, Dc, Ic, st, nullptr, nullptr, nullptr, false);
+            if (!Dd) MI_HIP(hipMemcpyAsync(D + (size_t)c0 * k, Dc, (size_t)m * k * 4, hipMemcpyDeviceToHost, st));
+            if (!Id) MI_HIP(hipMemcpyAsync(I + (size_t)c0 * k, Ic, (size_t)m * k * 8, hipMemcpyDeviceToHost, st));
+            if (!qd || !Dd || !Id) MI_HIP(hipStreamSynchronize(st));
+        }
+    });
+}
+
+int mi_index_coarse_lut(mi_index *h, int64_t nq, const float *q, int nprobe, int32_t *cI, float *cD,
+                        float *lut) {
+    return guard([&] {
+        MI_REQUIRE(h && (nq == 0 || q), "null argument");
+        MI_REQUIRE(nprobe >= 1, "nprobe must be >= 1");
+        require_trained(h);
+        if (nq == 0) return;
+        DeviceGuard dg(h->device);
+        nprobe = std::min(nprobe, h->nlist);
+        const int64_t chunk = query_chunk_size(h);
+        const bool qd = is_device_ptr(q);
+        for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
+            const int64_t m = std::min(chunk, nq - c0);
+            const float *qs = q + (size_t)c0 * h->d;
+            if (!qd) qs = static_cast<const float *>(to_device(qs, (size_t)m * h->d * 4, h->ws_q, nullptr));
+            search_chunk(h, m, qs, 1, nprobe, nullptr, nullptr, nullptr,
+                         cI ? cI + (size_t)c0 * nprobe : nullptr, cD ? cD + (size_t)c0 * nprobe : nullptr,
+                         lut ? lut + (size_t)c0 * h->M * 256 : nullptr, true);
+            MI_HIP(hipStreamSynchronize(nullptr));
+        }
+    });
+}
+
+int mi_merge_topk(int device, int nparts, int64_t nq, int k, const float *D_parts,
+                  const int64_t *I_parts, float *D, int64_t *I, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(nparts >= 1 && k >= 1 && nq >= 0, "bad sizes");
+        MI_REQUIRE(D_parts && I_parts && D && I, "null argument");
+        if (nq == 0) return;
+        DeviceGuard dg(device);
+        hipStream_t st = as_stream(stream);
+        const bool all_dev = is_device_ptr(D_parts) && is_device_ptr(I_parts) && is_device_ptr(D) && is_device_ptr(I);
+        const size_t n_in = (size_t)nparts * nq * k, n_out = (size_t)nq * k;
+        if (all_dev) {
+            launch_merge(D_parts, I_parts, nparts, nq * k, k, nq, k, D, I, k, 0, nullptr, nullptr, st);
+            return;
+        }
+        MI_REQUIRE(!is_device_ptr(D_parts) && !is_device_ptr(I_parts) && !is_device_ptr(D) && !is_device_ptr(I),
+                   "mi_merge_topk: pointers must be all host or all device");
+        DevBuf dD, dI, oD, oI;
+        MI_HIP(hipMemcpyAsync(dD.reserve(n_in * 4), D_parts, n_in * 4, hipMemcpyHostToDevice, st));
+        MI_HIP(hipMemcpyAsync(dI.reserve(n_in * 8), I_parts, n_in * 8, hipMemcpyHostToDevice, st));
+        launch_merge(dD.get<float>(), dI.get<int64_t>(), nparts, nq * k, k, nq, k,
+                     oD.as<float>(n_out), oI.as<int64_t>(n_out), k, 0, nullptr, nullptr, st);
+        MI_HIP(hipMemcpyAsync(D, oD.p, n_out * 4, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipMemcpyAsync(I, oI.p, n_out * 8, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
+    });
+}
+
+// ---- IndexFlatIP -----------------------------------------------------
+
+int mi_flat_create(int d, int device, mi_flat **out) {
+    return guard([&] {
+        MI_REQUIRE(out != nullptr, "out is null");
+        MI_REQUIRE(d > 0 && d % 4 == 0, "d must be a positive multiple of 4");
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0) {
+            (void)hipGetLastError();
+            throw Error("no HIP device available: the MI355X index has no CPU fallback");
+        }
+        MI_REQUIRE(device >= 0 && device < ndev, "invalid device ordinal");
+        auto h = std::make_unique<mi_flat>();
+        h->d = d;
+        h->device = device;
+        *out = h.release();
+    });
+}
+
+int mi_flat_destroy(mi_flat *h) {
+    return guard([&] {
+        if (!h) return;
+        DeviceGuard dg(h->device);
+        delete h;
+    });
+}
+
+int mi_flat_add(mi_flat *h, int64_t n, const float *x) {
+    return guard([&] {
+        MI_REQUIRE(h && (n == 0 || x), "null argument");
+        if (n == 0) return;
+        DeviceGuard dg(h->device);
+        size_t old_bytes = (size_t)h->ntotal * h->d * 4, add_bytes = (size_t)n * h->d * 4;
+        if (old_bytes + add_bytes > h->base.cap) {
+            DevBuf nb;
+            nb.reserve((old_bytes + add_bytes) * 3 / 2);
+            if (old_bytes) MI_HIP(hipMemcpy(nb.p, h->base.p, old_bytes, hipMemcpyDeviceToDevice));
+            std::swap(nb.p, h->base.p);
+            std::swap(nb.cap, h->base.cap);
+        }
+        MI_HIP(hipMemcpy(static_cast<char *>(h->base.p) + old_bytes, x, add_bytes, hipMemcpyDefault));
+        h->ntotal += n;
+    });
+}
+
+int mi_flat_ntotal(mi_flat *h, int64_t *out) {
+    return guard([&] {
+        MI_REQUIRE(h && out, "null argument");
+        *out = h->ntotal;
+    });
+}
+
+int mi_flat_reset(mi_flat *h) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        h->ntotal = 0;
+    });
+}
+
+int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int64_t *I, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(h && (nq == 0 || (q && D && I)), "null argument");
+        MI_REQUIRE(k >= 1 && k <= 1024, "k must be in [1, 1024]");
+        if (nq == 0) return;
+        DeviceGuard dg(h->device);
+        hipStream_t st = as_stream(stream);
+        const bool qd = is_device_ptr(q), Dd = is_device_ptr(D), Id = is_device_ptr(I);
+        if (h->ntotal == 0) {  // faiss: all -1
+            MI_REQUIRE(!Dd && !Id, "empty flat index: host outputs only");
+            for (int64_t i = 0; i < nq * k; ++i) {
+                D[i] = -FLT_MAX;
+                I[i] = -1;
+            }
+            return;
+        }
+        int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(4096, ((int64_t)1 << 28) / h->ntotal));
+        for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
+            const int64_t m = std::min(chunk, nq - c0);
+            const float *qs = q + (size_t)c0 * h->d;
+            if (!qd) qs = static_cast<const float *>(to_device(qs, (size_t)m * h->d * 4, h->ws_q, st));
+            float *scores = h->ws_scores.as<float>((size_t)m * h->ntotal);
+            float *Dc = Dd ? D + (size_t)c0 * k : h->ws_D.as<float>((size_t)m * k);
+            int64_t *Ic = Id ? I + (size_t)c0 * k : h->ws_I.as<int64_t>((size_t)m * k);
+            launch_gemm(qs, m, h->base.get<float>(), h->ntotal, h->d, scores, h->ntotal, st);
+            launch_select(scores, h->ntotal, m, (int)h->ntotal, k, nullptr, Ic, Dc, st);
+            if (!Dd) MI_HIP(hipMemcpyAsync(D + (size_t)c0 * k, Dc, (size_t)m * k * 4, hipMemcpyDeviceToHost, st));
+            if (!Id) MI_HIP(hipMemcpyAsync(I + (size_t)c0 * k, Ic, (size_t)m * k * 8, hipMemcpyDeviceToHost, st));
+            if (!qd || !Dd || !Id) MI_HIP(hipStreamSynchronize(st));
+        }
+    });
+}
+
+// ---- building blocks for train() --------------------------------------
+
+int mi_ip_assign(int device, int64_t n, const float *x, int64_t nc, const float *c, int d,
+                 int32_t *assign, float *score, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(x && c && assign, "null argument");
+        MI_REQUIRE(n > 0 && nc > 0, "empty input");
+        DeviceGuard dg(device);
+        hipStream_t st = as_stream(stream);
+        MI_REQUIRE(is_device_ptr(x) && is_device_ptr(c), "mi_ip_assign: x and c must be device pointers");
+        const bool ad = is_device_ptr(assign), sd = score ? is_device_ptr(score) : true;
+        DevBuf scores, da, ds;
+        int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(65536, ((int64_t)1 << 28) / nc));
+        scores.reserve((size_t)std::min(chunk, n) * nc * 4);
+        if (!ad) da.reserve((size_t)n * 4);
+        if (score && !sd) ds.reserve((size_t)n * 4);
+        int32_t *ap = ad ? assign : da.get<int32_t>();
+        float *sp = score ? (sd ? score : ds.get<float>()) : nullptr;
+        for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+            int64_t m = std::min(chunk, n - c0);
+            launch_gemm(x + (size_t)c0 * d, m, c, nc, d, scores.get<float>(), nc, st);
+            launch_select(scores.get<float>(), nc, m, (int)nc, 1, ap + c0, nullptr, sp ? sp + c0 : nullptr, st);
+        }
+        if (!ad) MI_HIP(hipMemcpyAsync(assign, ap, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        if (score && !sd) MI_HIP(hipMemcpyAsync(score, sp, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));  // scratch buffers die with this scope
+    });
+}
+
+int mi_pq_encode(int device, int64_t n, const float *x, int d, int M, const float *codebook,
+                 uint8_t *codes, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(x && codebook && codes, "null argument");
+        MI_REQUIRE(n > 0 && d > 0 && M > 0 && d % M == 0, "bad sizes");
+        DeviceGuard dg(device);
+        hipStream_t st = as_stream(stream);
+        MI_REQUIRE(is_device_ptr(x) && is_device_ptr(codebook), "mi_pq_encode: x and codebook must be device pointers");
+        if (is_device_ptr(codes)) {
+            launch_pq_encode(x, n, d, M, codebook, nullptr, nullptr, codes, st);
+            return;
+        }
+        DevBuf dc;
+        launch_pq_encode(x, n, d, M, codebook, nullptr, nullptr, dc.as<uint8_t>((size_t)n * M), st);
+        MI_HIP(hipMemcpyAsync(codes, dc.p, (size_t)n * M, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,684 @@
+// ivfpq_kernels.h -- gfx950 (CDNA4, wave64) kernels of the IVF-PQ search path.
+//
+// Stages of IndexIVFPQ.search (reference call sites: Makefile:32 `index tune`,
+// README.md:28 query-time app; arithmetic restated in oracle/ivfpq_oracle.c):
+//
+//   ip_gemm_kernel   S = Q . C^T, exact f32 on v_mfma_f32_16x16x4_f32
+//                    (bitwise an ascending-k fmaf chain = the oracle's dot)
+//   select_kernel    best-K of each row of S under (score desc, index asc)
+//   lut_kernel       LUT[q][m][j] = <q_m, codebook[m][j]>
+//   scan_kernel      stream PQ codes of the probed lists, 64 LDS table
+//                    look-ups per code, per-wave register top-k       (HBM/LDS bound)
+//   merge_kernel     k-way merge of per-slice / per-shard partial top-k
+//   pq_encode_kernel Index.add: residual + nearest codeword per sub-vector
+//
+// Inverted-list layout in HBM ("group-interleaved"): a list is padded to
+// groups of 64 codes; group g is NCH = ceil(M/16) chunks of 1 KiB, chunk c
+// holding bytes [16c, 16c+16) of the 64 codes, 16 B per code, so that lane j
+// of a wave reads code j with NCH perfectly coalesced global_load_dwordx4
+// (64 lanes x 16 B = 1 KiB per instruction).  ids[group*64 + lane] is int64.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+namespace mi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned EMPTY_POS = 0xFFFFFFFFu;
+constexpr int64_t EMPTY_ID = INT64_MAX;
+#define MI_NEG_INF (-__builtin_huge_valf())
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ unsigned readlane_u(unsigned v, int l) {
+    return (unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniform_f(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+// order-preserving float <-> unsigned map (for LDS atomicMax on scores)
+__device__ __forceinline__ unsigned f2o(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float o2f(unsigned o) {
+    unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+// ---------------------------------------------------------------------
+// S[na][nb] = A[na][d] . B[nb][d]^T, exact f32.
+// Workgroup tile BM x BN, K chunk 32, double-buffered through LDS in k-major
+// order so that lane (i = lane&15, g = lane>>4) reads A[k0+g][i]: the MFMA
+// then consumes k in ascending order and every output is an ascending-k fmaf
+// chain from +0.  LDS row stride == 16 (mod 32) keeps the four k-rows of one
+// operand fetch on disjoint banks.
+// Grid: 8 * tiles_m * ceil(tiles_n/8); block b runs on XCD b%8, and all
+// blocks of one XCD walk the M tiles of the same B strip (L2 reuse of B).
+// ---------------------------------------------------------------------
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
+    ip_gemm_kernel(const float *__restrict__ A, int na, const float *__restrict__ B, int nb,
+                   int d, float *__restrict__ S, int64_t ldS, int tiles_m, int tiles_n) {
+    constexpr int BM = 16 * WM * WAVES_M;
+    constexpr int BN = 16 * WN * WAVES_N;
+    constexpr int BK = 32;
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int SA = (BM % 32 == 16) ? BM : BM + 16;
+    constexpr int SB = (BN % 32 == 16) ? BN : BN + 16;
+    constexpr int CA = (BM * 8 + NT - 1) / NT;
+    constexpr int CB = (BN * 8 + NT - 1) / NT;
+    __shared__ float smem[2 * BK * (SA + SB)];
+    float *As = smem;                 // [2][BK][SA]
+    float *Bs = smem + 2 * BK * SA;   // [2][BK][SB]
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, jb = bid >> 3;
+    const int tm = jb % tiles_m;
+    const int tn = (jb / tiles_m) * 8 + xcd;
+    if (tn >= tiles_n) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int wmi = w % WAVES_M, wni = w / WAVES_M;
+    const int li = lane & 15, lg = lane >> 4;
+
+    float4 ra[CA], rb[CB];
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int x = 0; x < WM; ++x)
+#pragma unroll
+        for (int y = 0; y < WN; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < CA; ++u) {
+            int idx = tid + u * NT;
+            if ((BM * 8) % NT == 0 || idx < BM * 8) {
+                int row = ((idx >> 7) << 4) | (idx & 15);
+                int k = k0 + ((idx >> 4) & 7) * 4;
+                int gr = min(m0 + row, na - 1);
+                ra[u] = (k < d) ? *reinterpret_cast<const float4 *>(A + (size_t)gr * d + k)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            int idx = tid + u * NT;
+            if ((BN * 8) % NT == 0 || idx < BN * 8) {
+                int row = ((idx >> 7) << 4) | (idx & 15);
+                int k = k0 + ((idx >> 4) & 7) * 4;
+                int gr = min(n0 + row, nb - 1);
+                rb[u] = (k < d) ? *reinterpret_cast<const float4 *>(B + (size_t)gr * d + k)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < CA; ++u) {
+            int idx = tid + u * NT;
+            if ((BM * 8) % NT == 0 || idx < BM * 8) {
+                int row = ((idx >> 7) << 4) | (idx & 15);
+                float *p = As + buf * BK * SA + (((idx >> 4) & 7) * 4) * SA + row;
+                p[0] = ra[u].x;
+                p[SA] = ra[u].y;
+                p[2 * SA] = ra[u].z;
+                p[3 * SA] = ra[u].w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            int idx = tid + u * NT;
+            if ((BN * 8) % NT == 0 || idx < BN * 8) {
+                int row = ((idx >> 7) << 4) | (idx & 15);
+                float *p = Bs + buf * BK * SB + (((idx >> 4) & 7) * 4) * SB + row;
+                p[0] = rb[u].x;
+                p[SB] = rb[u].y;
+                p[2 * SB] = rb[u].z;
+                p[3 * SB] = rb[u].w;
+            }
+        }
+    };
+
+    const int nk = (d + BK - 1) / BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) gload((t + 1) * BK);
+        const float *ab = As + (t & 1) * BK * SA + lg * SA + wmi * WM * 16 + li;
+        const float *bb = Bs + (t & 1) * BK * SB + lg * SB + wni * WN * 16 + li;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            float a[WM], b[WN];
+#pragma unroll
+            for (int x = 0; x < WM; ++x) a[x] = ab[kk * 4 * SA + x * 16];
+#pragma unroll
+            for (int y = 0; y < WN; ++y) b[y] = bb[kk * 4 * SB + y * 16];
+#pragma unroll
+            for (int x = 0; x < WM; ++x)
+#pragma unroll
+                for (int y = 0; y < WN; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+        if (t + 1 < nk) sstore((t + 1) & 1);
+        __syncthreads();
+    }
+    // D layout of 16x16x4: lane holds rows (lane>>4)*4 + r, column lane&15
+#pragma unroll
+    for (int x = 0; x < WM; ++x)
+#pragma unroll
+        for (int y = 0; y < WN; ++y) {
+            int col = n0 + (wni * WN + y) * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = m0 + (wmi * WM + x) * 16 + lg * 4 + r;
+                if (row < na && col < nb) S[(size_t)row * ldS + col] = acc[x][y][r];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------
+// wave-level sorted list, one entry per lane, best first (lane 0 = best).
+// insert keeps the list sorted; entries pushed past lane 63 are dropped.
+// ---------------------------------------------------------------------
+__device__ __forceinline__ void wave_insert_i32(float &ls, int &li, int lane, int k, float cs, int ci) {
+    bool before = (ls > cs) || (ls == cs && li < ci);
+    int r = __popcll(__ballot(before));
+    if (r >= k) return;  // wave-uniform
+    float us = __shfl_up(ls, 1);
+    int ui = __shfl_up(li, 1);
+    if (lane > r) {
+        ls = us;
+        li = ui;
+    } else if (lane == r) {
+        ls = cs;
+        li = ci;
+    }
+}
+
+// ---------------------------------------------------------------------
+// Best K entries of each row of S under (score desc, column asc); one
+// 256-thread workgroup per row.  K > 64 is extracted 64 at a time: pass p
+// keeps the best 64 among entries strictly after the last entry of pass p-1.
+// Unfilled: index -1, score -FLT_MAX.  out_i32 / out_i64 / out_s may be null.
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    select_kernel(const float *__restrict__ S, int64_t ldS, int n, int K, int32_t *__restrict__ out_i32,
+                  int64_t *__restrict__ out_i64, float *__restrict__ out_s) {
+    __shared__ float m_s[256];
+    __shared__ int m_i[256];
+    __shared__ float o_s[64];
+    __shared__ int o_i[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = uniform_i(tid >> 6);
+    const int64_t row = blockIdx.x;
+    const float *r = S + row * ldS;
+    bool has_bound = false;
+    float bs = 0.f;
+    int bi = 0;
+    for (int p0 = 0; p0 < K; p0 += 64) {
+        const int kp = min(64, K - p0);
+        float ls = MI_NEG_INF, thr = MI_NEG_INF;
+        int li = INT_MAX;
+        for (int base = w * 64; base < n; base += 256) {
+            int c = base + lane;
+            bool valid = c < n;
+            float s = valid ? r[c] : 0.f;
+            bool pf = valid && (s >= thr);
+            if (has_bound) pf = pf && (s < bs || (s == bs && c > bi));
+            unsigned long long mask = __ballot(pf);
+            while (mask) {
+                int src = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                float cs = readlane_f(s, src);
+                if (!(cs >= thr)) continue;
+                wave_insert_i32(ls, li, lane, kp, cs, base + src);
+                thr = readlane_f(ls, kp - 1);
+            }
+        }
+        m_s[tid] = ls;
+        m_i[tid] = li;
+        if (tid < 64) {
+            o_s[tid] = MI_NEG_INF;
+            o_i[tid] = INT_MAX;
+        }
+        __syncthreads();
+        if (lane < kp && li != INT_MAX) {
+            int rank = 0;
+            for (int ww = 0; ww < 4; ++ww)
+                for (int j = 0; j < kp; ++j) {
+                    float js = m_s[ww * 64 + j];
+                    int ji = m_i[ww * 64 + j];
+                    rank += (js > ls) || (js == ls && ji < li);
+                }
+            if (rank < kp) {
+                o_s[rank] = ls;
+                o_i[rank] = li;
+            }
+        }
+        __syncthreads();
+        if (tid < kp) {
+            int oi = o_i[tid];
+            float os = o_s[tid];
+            size_t o = (size_t)row * K + p0 + tid;
+            if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi;
+            if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi;
+            if (out_s) out_s[o] = oi == INT_MAX ? -FLT_MAX : os;
+        }
+        has_bound = true;
+        bs = o_s[kp - 1];
+        bi = o_i[kp - 1];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------
+// LUT[q][m][j] = <q_m, codebook[m][j]>  (ascending-t fmaf chain from +0).
+// grid (M, ceil(nq/qtile)), 256 threads: thread j holds codeword j of
+// sub-quantiser m in registers and walks `qtile` queries.
+// ---------------------------------------------------------------------
+template <int DSUB>
+__global__ void __launch_bounds__(256)
+    lut_kernel(const float *__restrict__ q, int nq, int d, int M, const float *__restrict__ codebook,
+               float *__restrict__ lut, int qtile) {
+    const int m = blockIdx.x, j = threadIdx.x;
+    const int q0 = blockIdx.y * qtile;
+    const int q1 = min(nq, q0 + qtile);
+    float cb[DSUB];
+    const float *cp = codebook + ((size_t)m * 256 + j) * DSUB;
+#pragma unroll
+    for (int t = 0; t < DSUB; ++t) cb[t] = cp[t];
+    for (int qi = q0; qi < q1; ++qi) {
+        const float *qs = q + (size_t)qi * d + m * DSUB;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < DSUB; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
+        lut[((size_t)qi * M + m) * 256 + j] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------
+// PQ-code scan + per-slice top-k.
+// ---------------------------------------------------------------------
+struct ScanArgs {
+    const float *lut;          // [nq][M*256]
+    const int32_t *coarse_idx; // [nq][nprobe], -1 = none
+    const float *coarse_dis;   // [nq][nprobe]
+    const int32_t *list_goff;  // [nlist+1] first group of each list
+    const int32_t *list_len;   // [nlist]
+    const uint8_t *codes;      // group-interleaved
+    const int64_t *ids;        // [ngroups*64]
+    float *part_s;             // [nq][nslice][k]
+    int64_t *part_id;          // [nq][nslice][k]
+    const float *bound_s;      // [nq] or null: only entries strictly after
+    const int64_t *bound_id;   //      (bound_s, bound_id) are eligible
+    int nq, nprobe, nslice, k, by_residual;
+};
+
+// LDS carve: [ LUT M*1024 B | prefix | p_goff | p_len | p_dis | wg_thr ]
+// (the LUT region is reused for the end-of-scan merge, so it is at least
+// 16 KiB).
+__host__ __device__ inline size_t scan_lut_bytes(int M) {
+    size_t b = (size_t)M * 1024;
+    return b < 16384 ? 16384 : b;
+}
+__host__ __device__ inline int scan_tab_stride(int nprobe) { return (nprobe + 1 + 3) & ~3; }
+__host__ __device__ inline size_t scan_smem_bytes(int M, int nprobe) {
+    return scan_lut_bytes(M) + (size_t)scan_tab_stride(nprobe) * 4 * 4 + 16;
+}
+
+template <int M>
+__global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
+    constexpr int NCH = (M + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *lut_s = reinterpret_cast<float *>(smem);
+    const int TS = scan_tab_stride(a.nprobe);
+    int *prefix = reinterpret_cast<int *>(smem + scan_lut_bytes(M));
+    int *p_goff = prefix + TS;
+    int *p_len = p_goff + TS;
+    float *p_dis = reinterpret_cast<float *>(p_len + TS);
+    unsigned *wg_thr = reinterpret_cast<unsigned *>(p_dis + TS);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = uniform_i(tid >> 6);
+    const int nw = blockDim.x >> 6;
+    const int q = blockIdx.x / a.nslice, slice = blockIdx.x % a.nslice;
+    const int nprobe = a.nprobe, k = a.k;
+
+    // ---- stage the query's LUT (M KiB) and the probe tables
+    {
+        const float4 *lg = reinterpret_cast<const float4 *>(a.lut + (size_t)q * M * 256);
+        float4 *ls4 = reinterpret_cast<float4 *>(lut_s);
+        for (int i = tid; i < M * 64; i += blockDim.x) ls4[i] = lg[i];
+    }
+    for (int p = tid; p < nprobe; p += blockDim.x) {
+        int l = a.coarse_idx[(size_t)q * nprobe + p];
+        int g0 = 0, ng = 0, len = 0;
+        if (l >= 0) {
+            g0 = a.list_goff[l];
+            ng = a.list_goff[l + 1] - g0;
+            len = a.list_len[l];
+        }
+        prefix[p + 1] = ng;
+        p_goff[p] = g0;
+        p_len[p] = len;
+        p_dis[p] = a.by_residual ? a.coarse_dis[(size_t)q * nprobe + p] : 0.0f;
+    }
+    if (tid == 0) {
+        prefix[0] = 0;
+        *wg_thr = f2o(MI_NEG_INF);
+    }
+    __syncthreads();
+    if (w == 0) {  // inclusive scan of group counts, chunked over the lanes of wave 0
+        int per = (nprobe + 63) / 64;
+        int b = lane * per;
+        int sum = 0;
+        for (int i = 0; i < per; ++i)
+            if (b + i < nprobe) sum += prefix[b + i + 1];
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        int run = incl - sum;
+        for (int i = 0; i < per; ++i)
+            if (b + i < nprobe) {
+                run += prefix[b + i + 1];
+                prefix[b + i + 1] = run;
+            }
+    }
+    __syncthreads();
+
+    const int G = prefix[nprobe];
+    const int beg = (int)(((int64_t)G * slice) / a.nslice);
+    const int end = (int)(((int64_t)G * (slice + 1)) / a.nslice);
+
+    const bool has_bound = a.bound_s != nullptr;
+    float bs = 0.f;
+    int64_t bid = 0;
+    if (has_bound) {
+        bs = a.bound_s[q];
+        bid = a.bound_id[q];
+    }
+
+    float ls = MI_NEG_INF, thr = MI_NEG_INF;
+    unsigned lp = EMPTY_POS;
+
+    // work items = 64-code groups [beg, end) of the concatenated probed lists,
+    // dealt round-robin to the waves
+    int t = beg + w;
+    int p = 0;
+    if (t < end) {  // smallest p with prefix[p+1] > t
+        int lo = 0, hi = nprobe - 1;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (uniform_i(prefix[mid + 1]) > t) hi = mid;
+            else lo = mid + 1;
+        }
+        p = lo;
+    }
+    uint4 cur[NCH];
+    int c_gg = 0, c_nvalid = 0;
+    float c_dis0 = 0.f;
+    auto locate_and_load = [&](int tt, uint4(&buf)[NCH], int &gg, int &nvalid, float &dis0) {
+        while (uniform_i(prefix[p + 1]) <= tt) ++p;
+        int gi = tt - uniform_i(prefix[p]);
+        gg = uniform_i(p_goff[p]) + gi;
+        nvalid = min(64, uniform_i(p_len[p]) - gi * 64);
+        dis0 = uniform_f(p_dis[p]);
+        const uint4 *gp = reinterpret_cast<const uint4 *>(a.codes + (size_t)gg * (NCH * 1024)) + lane;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) buf[ch] = gp[ch * 64];
+    };
+    if (t < end) locate_and_load(t, cur, c_gg, c_nvalid, c_dis0);
+
+    while (t < end) {
+        const int tn = t + nw;
+        uint4 nxt[NCH];
+        int n_gg = 0, n_nvalid = 0;
+        float n_dis0 = 0.f;
+        if (tn < end) locate_and_load(tn, nxt, n_gg, n_nvalid, n_dis0);
+
+        // 64 table look-ups, m ascending, f32 adds in that order (= the oracle)
+        float acc = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const unsigned wd[4] = {cur[ch].x, cur[ch].y, cur[ch].z, cur[ch].w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int m = ch * 16 + j;
+                if (m < M) {
+                    unsigned byte = (wd[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+                    acc += lut_s[m * 256 + byte];
+                }
+            }
+        }
+        const float s = c_dis0 + acc;
+
+        const float wthr = o2f(*reinterpret_cast<volatile unsigned *>(wg_thr));
+        float thr_eff = fmaxf(thr, wthr);
+        bool pf = (lane < c_nvalid) && (s >= thr_eff);
+        if (has_bound) pf = pf && (s <= bs);
+        unsigned long long mask = __ballot(pf);
+        if (mask) {
+            bool changed = false;
+            while (mask) {
+                const int src = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float cs = readlane_f(s, src);
+                if (!(cs >= thr_eff)) continue;
+                const unsigned cp = (unsigned)c_gg * 64u + (unsigned)src;
+                if (has_bound && cs == bs) {
+                    if (a.ids[cp] <= bid) continue;
+                }
+                const bool gt = ls > cs;
+                const bool eq = (ls == cs) && (lp != EMPTY_POS);
+                bool before = gt;
+                if (__ballot(eq)) {  // exact score tie: order by id (rare)
+                    int64_t cid = a.ids[cp];
+                    int64_t mine = eq ? a.ids[lp] : 0;
+                    before = gt || (eq && mine < cid);
+                }
+                const int r = __popcll(__ballot(before));
+                if (r >= k) continue;
+                float us = __shfl_up(ls, 1);
+                unsigned up = __shfl_up(lp, 1);
+                if (lane > r) {
+                    ls = us;
+                    lp = up;
+                } else if (lane == r) {
+                    ls = cs;
+                    lp = cp;
+                }
+                thr = readlane_f(ls, k - 1);
+                thr_eff = fmaxf(thr, wthr);
+                changed = true;
+            }
+            if (changed && thr > wthr && lane == 0) atomicMax(wg_thr, f2o(thr));
+        }
+
+        t = tn;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) cur[ch] = nxt[ch];
+        c_gg = n_gg;
+        c_nvalid = n_nvalid;
+        c_dis0 = n_dis0;
+    }
+
+    // ---- merge the waves' lists by rank counting (LUT region reused)
+    __syncthreads();
+    float *m_s = lut_s;                                         // [nw][64]
+    unsigned *m_p = reinterpret_cast<unsigned *>(lut_s) + 1024; // [nw][64], nw <= 16
+    float *o_s = lut_s + 2048;                                  // [64]
+    unsigned *o_p = reinterpret_cast<unsigned *>(lut_s) + 2048 + 64;
+    m_s[tid] = ls;
+    m_p[tid] = lp;
+    if (tid < 64) {
+        o_s[tid] = MI_NEG_INF;
+        o_p[tid] = EMPTY_POS;
+    }
+    __syncthreads();
+    if (lane < k && lp != EMPTY_POS) {
+        int rank = 0;
+        int64_t myid = 0;
+        bool have_id = false;
+        for (int ww = 0; ww < nw; ++ww)
+            for (int j = 0; j < k; ++j) {
+                float js = m_s[ww * 64 + j];
+                unsigned jp = m_p[ww * 64 + j];
+                if (js > ls) {
+                    ++rank;
+                } else if (js == ls && jp != EMPTY_POS && jp != lp) {
+                    if (!have_id) {
+                        myid = a.ids[lp];
+                        have_id = true;
+                    }
+                    int64_t jid = a.ids[jp];
+                    rank += (jid < myid) || (jid == myid && jp < lp);
+                }
+            }
+        if (rank < k) {
+            o_s[rank] = ls;
+            o_p[rank] = lp;
+        }
+    }
+    __syncthreads();
+    if (tid < k) {
+        unsigned pp = o_p[tid];
+        size_t o = ((size_t)q * a.nslice + slice) * k + tid;
+        a.part_s[o] = o_s[tid];
+        a.part_id[o] = pp == EMPTY_POS ? EMPTY_ID : a.ids[pp];
+    }
+}
+
+// ---------------------------------------------------------------------
+// Merge `nparts` partial top-k lists per query into the final k under
+// (score desc, id asc).  Entry (p, q, j) is at p*stride_p + q*stride_q + j.
+// Empty entries: id == EMPTY_ID or id < 0.  Writes D/I at
+// [q*ldo + out_off + rank]; unfilled -FLT_MAX / -1.  Optionally records the
+// last kept entry per query (bound for the next extraction pass).
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    merge_kernel(const float *__restrict__ ps, const int64_t *__restrict__ pid, int nparts,
+                 int64_t stride_p, int64_t stride_q, int k, float *__restrict__ D,
+                 int64_t *__restrict__ I, int64_t ldo, int out_off, float *__restrict__ bound_s,
+                 int64_t *__restrict__ bound_id) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = nparts * k;
+    int64_t *e_id = reinterpret_cast<int64_t *>(smem);            // [n]
+    float *e_s = reinterpret_cast<float *>(e_id + n);             // [n]
+    float *o_s = e_s + n;                                         // [k]
+    int64_t *o_id = reinterpret_cast<int64_t *>(smem + (((size_t)n * 12 + (size_t)k * 4 + 7) & ~(size_t)7));
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    for (int e = tid; e < n; e += blockDim.x) {
+        int p = e / k, j = e - p * k;
+        size_t o = (size_t)p * stride_p + (size_t)q * stride_q + j;
+        int64_t id = pid[o];
+        e_id[e] = id < 0 ? EMPTY_ID : id;
+        e_s[e] = id < 0 ? MI_NEG_INF : ps[o];
+    }
+    for (int j = tid; j < k; j += blockDim.x) {
+        o_s[j] = MI_NEG_INF;
+        o_id[j] = EMPTY_ID;
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += blockDim.x) {
+        const int64_t mi_ = e_id[e];
+        if (mi_ == EMPTY_ID) continue;
+        const float ms = e_s[e];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            float js = e_s[j];
+            int64_t ji = e_id[j];
+            rank += (js > ms) || (js == ms && (ji < mi_ || (ji == mi_ && j < e)));
+        }
+        if (rank < k) {
+            o_s[rank] = ms;
+            o_id[rank] = mi_;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < k; j += blockDim.x) {
+        int64_t id = o_id[j];
+        D[q * ldo + out_off + j] = id == EMPTY_ID ? -FLT_MAX : o_s[j];
+        I[q * ldo + out_off + j] = id == EMPTY_ID ? (int64_t)-1 : id;
+    }
+    if (bound_s && tid == 0) {
+        bound_s[q] = o_s[k - 1];
+        bound_id[q] = o_id[k - 1];
+    }
+}
+__host__ inline size_t merge_smem_bytes(int nparts, int k) {
+    size_t n = (size_t)nparts * k;
+    return ((n * 12 + (size_t)k * 4 + 7) & ~(size_t)7) + (size_t)k * 8;
+}
+
+// ---------------------------------------------------------------------
+// Index.add arithmetic: r = x - centroid[assign] (if by_residual), then for
+// sub-quantiser m the index of the L2-nearest codeword (ties: smallest).
+// grid (ceil(n/256), M); the sub-codebook (256 x DSUB f32) sits in LDS and is
+// read with wave-uniform (broadcast) addresses.
+// ---------------------------------------------------------------------
+template <int DSUB>
+__global__ void __launch_bounds__(256)
+    pq_encode_kernel(const float *__restrict__ x, int64_t n, int d, int M,
+                     const float *__restrict__ codebook, const float *__restrict__ centroids,
+                     const int32_t *__restrict__ assign, uint8_t *__restrict__ codes) {
+    __shared__ float cb[256 * DSUB];
+    const int m = blockIdx.y, tid = threadIdx.x;
+    const float *cg = codebook + (size_t)m * 256 * DSUB;
+    for (int i = tid; i < 256 * DSUB; i += 256) cb[i] = cg[i];
+    __syncthreads();
+    const int64_t v = (int64_t)blockIdx.x * 256 + tid;
+    if (v >= n) return;
+    float r[DSUB];
+    const float *xp = x + (size_t)v * d + m * DSUB;
+#pragma unroll
+    for (int t = 0; t < DSUB; ++t) r[t] = xp[t];
+    if (centroids) {
+        const float *cp = centroids + (size_t)assign[v] * d + m * DSUB;
+#pragma unroll
+        for (int t = 0; t < DSUB; ++t) r[t] = r[t] - cp[t];
+    }
+    int best = 0;
+    float bd = 0.f;
+    for (int j = 0; j < 256; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < DSUB; ++t) {
+            float df = r[t] - cb[j * DSUB + t];
+            acc = __builtin_fmaf(df, df, acc);
+        }
+        if (j == 0 || acc < bd) {
+            bd = acc;
+            best = j;
+        }
+    }
+    codes[(size_t)v * M + m] = (uint8_t)best;
+}
+
+// Σ over (q, probe) of the probed list lengths (profiling only).
+__global__ void count_codes_kernel(const int32_t *__restrict__ coarse_idx, int64_t n,
+                                   const int32_t *__restrict__ list_len,
+                                   unsigned long long *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (i < n) {
+        int l = coarse_idx[i];
+        if (l >= 0) v = (unsigned long long)list_len[l];
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+}  // namespace mi

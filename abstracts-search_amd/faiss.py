@@ -1,0 +1,517 @@
+"""faiss-shaped Python mirror of the MI355X IVF-PQ index.
+
+Drop-in for the subset of the faiss Python API that the reference reaches
+through ``sidecar-search index train|fill|tune`` (reference Makefile:39,
+Makefile:25, Makefile:32) and its query-time ``app.py`` (reference
+README.md:28): ``index_factory``, ``IndexIVFPQ.{train,add,add_with_ids,search,
+reset}``, ``nprobe``, ``ntotal``, ``is_trained``, ``IndexFlatIP``,
+``write_index`` / ``read_index`` (own container format), ``ParameterSpace``.
+
+Everything numeric happens in HIP kernels behind the C ABI of
+``include/mi_ivfpq.h``; this file only checks arguments, moves pointers and
+raises Python exceptions from C status codes.  There is no CPU fallback.
+
+``search``/``add`` take float32 C-contiguous numpy arrays like faiss (results
+are fresh numpy arrays), or torch CUDA tensors (results are CUDA tensors and
+the call only enqueues work on the current stream -- the path bench.py times).
+"""
+from __future__ import annotations
+
+import ctypes
+import re
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+
+import numpy as np
+
+from . import _native
+
+METRIC_INNER_PRODUCT = 0
+METRIC_L2 = 1
+
+_c_f32p = POINTER(c_float)
+
+
+class _Lib:
+    """Lazy binding of libmi_ivfpq.so (one per process)."""
+
+    _lib = None
+
+    @classmethod
+    def get(cls):
+        if cls._lib is None:
+            lib = _native.load("ivfpq")
+            lib.mi_last_error.restype = c_char_p
+            v = c_void_p
+            sigs = {
+                "mi_device_count": [POINTER(c_int)],
+                "mi_index_create": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(v)],
+                "mi_index_destroy": [v],
+                "mi_index_set_coarse": [v, v],
+                "mi_index_set_codebook": [v, v],
+                "mi_index_get_coarse": [v, v],
+                "mi_index_get_codebook": [v, v],
+                "mi_index_is_trained": [v, POINTER(c_int)],
+                "mi_index_ntotal": [v, POINTER(c_int64)],
+                "mi_index_reset": [v],
+                "mi_index_add": [v, c_int64, v, v],
+                "mi_index_encode": [v, c_int64, v, v, v],
+                "mi_index_add_codes": [v, c_int64, v, v, v],
+                "mi_index_list_size": [v, c_int, POINTER(c_int64)],
+                "mi_index_get_list": [v, c_int, v, v],
+                "mi_index_search": [v, c_int64, v, c_int, c_int, v, v, v],
+                "mi_index_coarse_lut": [v, c_int64, v, c_int, v, v, v],
+                "mi_index_profile_enable": [v, c_int],
+                "mi_index_profile_read": [v, POINTER(c_double), POINTER(c_int64), POINTER(c_int64)],
+                "mi_merge_topk": [c_int, c_int, c_int64, c_int, v, v, v, v, v],
+                "mi_flat_create": [c_int, c_int, POINTER(v)],
+                "mi_flat_destroy": [v],
+                "mi_flat_add": [v, c_int64, v],
+                "mi_flat_ntotal": [v, POINTER(c_int64)],
+                "mi_flat_reset": [v],
+                "mi_flat_search": [v, c_int64, v, c_int, v, v, v],
+                "mi_ip_assign": [c_int, c_int64, v, c_int64, v, c_int, v, v, v],
+                "mi_pq_encode": [c_int, c_int64, v, c_int, c_int, v, v, v],
+            }
+            for name, args in sigs.items():
+                fn = getattr(lib, name)
+                fn.argtypes = args
+                fn.restype = c_int
+            cls._lib = lib
+        return cls._lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise RuntimeError("mi_ivfpq: " + _Lib.get().mi_last_error().decode())
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _as_f32(x, d: int, what: str = "x"):
+    """faiss semantics: 2-D, second dim == d (assert), converted to C-contiguous float32."""
+    if _is_torch(x):
+        import torch
+        assert x.dim() == 2, f"{what} must be 2-D"
+        assert x.shape[1] == d, f"{what}.shape[1] ({x.shape[1]}) != index.d ({d})"
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.to(torch.float32).contiguous()
+        return x
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    assert x.ndim == 2, f"{what} must be 2-D"
+    assert x.shape[1] == d, f"{what}.shape[1] ({x.shape[1]}) != index.d ({d})"
+    return x
+
+
+def _ptr(x):
+    if x is None:
+        return c_void_p(0)
+    if _is_torch(x):
+        return c_void_p(x.data_ptr())
+    return c_void_p(x.ctypes.data)
+
+
+def get_num_gpus() -> int:
+    n = c_int(0)
+    _check(_Lib.get().mi_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def omp_set_num_threads(n: int) -> None:  # API compatibility; the index runs on the GPU
+    pass
+
+
+# ----------------------------------------------------------------------
+# IndexFlatIP
+# ----------------------------------------------------------------------
+
+class IndexFlatIP:
+    """faiss.IndexFlatIP: exact inner-product search (config #1's plumbing
+    index; the same GEMM + top-k kernels as the coarse quantiser)."""
+
+    metric_type = METRIC_INNER_PRODUCT
+    is_trained = True
+
+    def __init__(self, d: int, device: int = 0):
+        self.d = int(d)
+        self.device = int(device)
+        self._h = c_void_p()
+        _check(_Lib.get().mi_flat_create(self.d, self.device, ctypes.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _Lib.get().mi_flat_destroy(h)
+            except Exception:
+                pass
+
+    @property
+    def ntotal(self) -> int:
+        n = c_int64(0)
+        _check(_Lib.get().mi_flat_ntotal(self._h, ctypes.byref(n)))
+        return n.value
+
+    def train(self, x):
+        pass
+
+    def add(self, x):
+        x = _as_f32(x, self.d)
+        _check(_Lib.get().mi_flat_add(self._h, x.shape[0], _ptr(x)))
+
+    def reset(self):
+        _check(_Lib.get().mi_flat_reset(self._h))
+
+    def search(self, x, k: int):
+        x = _as_f32(x, self.d)
+        assert k > 0
+        nq = x.shape[0]
+        if _is_torch(x) and x.is_cuda:
+            import torch
+            D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+            _check(_Lib.get().mi_flat_search(self._h, nq, _ptr(x), k, _ptr(D), _ptr(I), _current_stream()))
+            return D, I
+        if _is_torch(x):
+            x = x.numpy()
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        _check(_Lib.get().mi_flat_search(self._h, nq, _ptr(x), k, _ptr(D), _ptr(I), c_void_p(0)))
+        return D, I
+
+
+class IndexFlat(IndexFlatIP):
+    def __init__(self, d: int, metric: int = METRIC_L2, device: int = 0):
+        if metric != METRIC_INNER_PRODUCT:
+            raise NotImplementedError("only METRIC_INNER_PRODUCT is implemented on the MI355X path")
+        super().__init__(d, device)
+
+
+# ----------------------------------------------------------------------
+# IndexIVFPQ
+# ----------------------------------------------------------------------
+
+class _PQ:
+    """index.pq: ProductQuantizer parameters (read-only view)."""
+
+    def __init__(self, d, M, nbits):
+        self.d, self.M, self.nbits = d, M, nbits
+        self.ksub = 1 << nbits
+        self.dsub = d // M
+        self.code_size = M
+
+
+class ClusteringParameters:
+    """faiss.ClusteringParameters subset used by train()."""
+
+    def __init__(self):
+        self.niter = 25
+        self.max_points_per_centroid = 256
+        self.min_points_per_centroid = 39
+        self.seed = 1234
+        self.verbose = False
+
+
+class IndexIVFPQ:
+    """faiss.IndexIVFPQ (inner product, 8-bit codes) on one MI355X.
+
+    Same call surface as faiss: ``train(x)``, ``add(x)``, ``add_with_ids(x, ids)``,
+    ``search(x, k) -> (D, I)``, ``reset()``, attributes ``d ntotal is_trained
+    nprobe nlist metric_type by_residual pq``.
+    """
+
+    def __init__(self, d: int, nlist: int, M: int, nbits: int = 8,
+                 metric: int = METRIC_INNER_PRODUCT, by_residual: bool = True, device: int = 0):
+        self.d, self.nlist, self.device = int(d), int(nlist), int(device)
+        self.metric_type = int(metric)
+        self.by_residual = bool(by_residual)
+        self.nprobe = 1
+        self.pq = _PQ(self.d, int(M), int(nbits))
+        self.cp = ClusteringParameters()
+        self.verbose = False
+        self._h = c_void_p()
+        _check(_Lib.get().mi_index_create(self.d, self.nlist, int(M), int(nbits), self.metric_type,
+                                          int(self.by_residual), self.device, ctypes.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _Lib.get().mi_index_destroy(h)
+            except Exception:
+                pass
+
+    # -- state ---------------------------------------------------------
+    @property
+    def ntotal(self) -> int:
+        n = c_int64(0)
+        _check(_Lib.get().mi_index_ntotal(self._h, ctypes.byref(n)))
+        return n.value
+
+    @property
+    def is_trained(self) -> bool:
+        t = c_int(0)
+        _check(_Lib.get().mi_index_is_trained(self._h, ctypes.byref(t)))
+        return bool(t.value)
+
+    @property
+    def code_size(self) -> int:
+        return self.pq.M
+
+    def set_centroids(self, centroids):
+        """Coarse centroids [nlist, d] (what faiss keeps in index.quantizer)."""
+        c = np.ascontiguousarray(centroids, np.float32) if not _is_torch(centroids) else centroids.contiguous()
+        assert tuple(c.shape) == (self.nlist, self.d)
+        _check(_Lib.get().mi_index_set_coarse(self._h, _ptr(c)))
+
+    def set_codebook(self, codebook):
+        """PQ codebook [M, 256, d/M] (faiss: index.pq.centroids)."""
+        c = np.ascontiguousarray(codebook, np.float32) if not _is_torch(codebook) else codebook.contiguous()
+        assert tuple(c.shape) == (self.pq.M, self.pq.ksub, self.pq.dsub)
+        _check(_Lib.get().mi_index_set_codebook(self._h, _ptr(c)))
+
+    def get_centroids(self) -> np.ndarray:
+        out = np.empty((self.nlist, self.d), np.float32)
+        _check(_Lib.get().mi_index_get_coarse(self._h, _ptr(out)))
+        return out
+
+    def get_codebook(self) -> np.ndarray:
+        out = np.empty((self.pq.M, self.pq.ksub, self.pq.dsub), np.float32)
+        _check(_Lib.get().mi_index_get_codebook(self._h, _ptr(out)))
+        return out
+
+    # -- train (setup, not on the timed path) ---------------------------
+    def train(self, x):
+        """k-means for the coarse centroids, then k-means per sub-quantiser on
+        the residuals (faiss IndexIVFPQ.train; reference Makefile:39).  The
+        assignment steps run on the HIP kernels (mi_ip_assign / mi_pq_encode);
+        the centroid means are torch scatter-adds on the device."""
+        from . import _train
+        x = _as_f32(x, self.d)
+        cent, cb = _train.train_ivfpq(x, self.nlist, self.pq.M, self.by_residual, self.cp,
+                                      self.device, self.verbose)
+        self.set_centroids(cent)
+        self.set_codebook(cb)
+
+    # -- add -------------------------------------------------------------
+    def add(self, x):
+        self.add_with_ids(x, None)
+
+    def add_with_ids(self, x, ids):
+        x = _as_f32(x, self.d)
+        n = x.shape[0]
+        if ids is not None:
+            if _is_torch(ids):
+                import torch
+                ids = ids.to(torch.int64).contiguous()
+            else:
+                ids = np.ascontiguousarray(ids, np.int64)
+            assert ids.shape == (n,)
+        if _is_torch(x) and not x.is_cuda:
+            x = x.numpy()
+        _check(_Lib.get().mi_index_add(self._h, n, _ptr(x), _ptr(ids)))
+
+    def add_codes(self, list_no, codes, ids=None):
+        """Append pre-encoded entries (read_index path)."""
+        list_no = np.ascontiguousarray(list_no, np.int32)
+        codes = np.ascontiguousarray(codes, np.uint8)
+        n = list_no.shape[0]
+        assert codes.shape == (n, self.pq.M)
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, np.int64)
+        _check(_Lib.get().mi_index_add_codes(self._h, n, _ptr(list_no), _ptr(codes), _ptr(ids)))
+
+    def encode(self, x):
+        """(list_no[n] int32, codes[n, M] uint8): the arithmetic of add()."""
+        x = _as_f32(x, self.d)
+        if _is_torch(x) and not x.is_cuda:
+            x = x.numpy()
+        n = x.shape[0]
+        list_no = np.empty(n, np.int32)
+        codes = np.empty((n, self.pq.M), np.uint8)
+        _check(_Lib.get().mi_index_encode(self._h, n, _ptr(x), _ptr(list_no), _ptr(codes)))
+        return list_no, codes
+
+    def reset(self):
+        _check(_Lib.get().mi_index_reset(self._h))
+
+    def list_size(self, list_no: int) -> int:
+        n = c_int64(0)
+        _check(_Lib.get().mi_index_list_size(self._h, int(list_no), ctypes.byref(n)))
+        return n.value
+
+    def get_list(self, list_no: int):
+        n = self.list_size(list_no)
+        codes = np.empty((n, self.pq.M), np.uint8)
+        ids = np.empty(n, np.int64)
+        _check(_Lib.get().mi_index_get_list(self._h, int(list_no), _ptr(codes), _ptr(ids)))
+        return codes, ids
+
+    # -- search ------------------------------------------------------------
+    def search(self, x, k: int, nprobe: int | None = None):
+        x = _as_f32(x, self.d)
+        assert k > 0
+        nprobe = int(self.nprobe if nprobe is None else nprobe)
+        nq = x.shape[0]
+        if _is_torch(x) and x.is_cuda:
+            import torch
+            D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+            _check(_Lib.get().mi_index_search(self._h, nq, _ptr(x), k, nprobe, _ptr(D), _ptr(I),
+                                              _current_stream()))
+            return D, I
+        if _is_torch(x):
+            x = x.numpy()
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        _check(_Lib.get().mi_index_search(self._h, nq, _ptr(x), k, nprobe, _ptr(D), _ptr(I), c_void_p(0)))
+        return D, I
+
+    def search_into(self, x, k: int, D, I, nprobe: int | None = None):
+        """search() into caller-owned CUDA tensors (no allocation; what a
+        captured / steady-state serving loop uses)."""
+        nprobe = int(self.nprobe if nprobe is None else nprobe)
+        _check(_Lib.get().mi_index_search(self._h, x.shape[0], _ptr(x), k, nprobe, _ptr(D), _ptr(I),
+                                          _current_stream()))
+
+    def coarse_and_lut(self, x, nprobe: int | None = None, want_lut: bool = True):
+        """Steps 1-2 of search for parity tests: (coarse_I, coarse_D, lut)."""
+        x = _as_f32(x, self.d)
+        if _is_torch(x) and not x.is_cuda:
+            x = x.numpy()
+        nprobe = min(int(self.nprobe if nprobe is None else nprobe), self.nlist)
+        nq = x.shape[0]
+        cI = np.empty((nq, nprobe), np.int32)
+        cD = np.empty((nq, nprobe), np.float32)
+        lut = np.empty((nq, self.pq.M, self.pq.ksub), np.float32) if want_lut else None
+        _check(_Lib.get().mi_index_coarse_lut(self._h, nq, _ptr(x), nprobe, _ptr(cI), _ptr(cD), _ptr(lut)))
+        return cI, cD, lut
+
+    # -- scan-kernel timing (HIP events on the launch stream) ------------
+    def profile(self, on: bool = True):
+        _check(_Lib.get().mi_index_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms, n, b = c_double(0), c_int64(0), c_int64(0)
+        _check(_Lib.get().mi_index_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)))
+        return {"scan_ms_avg": ms.value, "launches": n.value, "last_scan_bytes": b.value}
+
+
+def merge_topk(D_parts, I_parts, device: int = 0):
+    """k-way merge of per-shard results [nparts, nq, k] -> (D, I)  (the
+    arithmetic after the all-gather; faiss IndexShards' merge)."""
+    nparts, nq, k = D_parts.shape
+    if _is_torch(D_parts) and D_parts.is_cuda:
+        import torch
+        D_parts, I_parts = D_parts.contiguous(), I_parts.contiguous()
+        D = torch.empty((nq, k), dtype=torch.float32, device=D_parts.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=D_parts.device)
+        _check(_Lib.get().mi_merge_topk(D_parts.device.index or 0, nparts, nq, k, _ptr(D_parts),
+                                        _ptr(I_parts), _ptr(D), _ptr(I), _current_stream()))
+        return D, I
+    D_parts = np.ascontiguousarray(D_parts, np.float32)
+    I_parts = np.ascontiguousarray(I_parts, np.int64)
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    _check(_Lib.get().mi_merge_topk(device, nparts, nq, k, _ptr(D_parts), _ptr(I_parts), _ptr(D),
+                                    _ptr(I), c_void_p(0)))
+    return D, I
+
+
+# ----------------------------------------------------------------------
+# module-level faiss functions
+# ----------------------------------------------------------------------
+
+_FACTORY_RE = re.compile(r"^IVF(\d+)(?:_HNSW\d+)?,PQ(\d+)(?:x(\d+))?$")
+
+
+def index_factory(d: int, description: str, metric: int = METRIC_L2, device: int = 0):
+    """faiss.index_factory for the strings this path uses: "IVF{nlist},PQ{M}"
+    (optionally "PQ{M}x8") and "Flat".  Like faiss the default metric is L2,
+    which this path rejects: pass METRIC_INNER_PRODUCT."""
+    description = description.replace(" ", "")
+    if description == "Flat":
+        return IndexFlat(d, metric, device)
+    m = _FACTORY_RE.match(description)
+    if not m:
+        raise ValueError(f"index_factory: unsupported description {description!r} "
+                         "(supported: 'Flat', 'IVF<nlist>,PQ<M>[x8]')")
+    if metric != METRIC_INNER_PRODUCT:
+        raise NotImplementedError("only METRIC_INNER_PRODUCT is implemented on the MI355X path")
+    nlist, M, nbits = int(m.group(1)), int(m.group(2)), int(m.group(3) or 8)
+    return IndexIVFPQ(d, nlist, M, nbits, metric, device=device)
+
+
+def extract_index_ivf(index):
+    return index
+
+
+def downcast_index(index):
+    return index
+
+
+class ParameterSpace:
+    """faiss.ParameterSpace subset (what an autotune sweep sets)."""
+
+    def set_index_parameter(self, index, name: str, value):
+        if name != "nprobe":
+            raise ValueError(f"unknown parameter {name!r}")
+        index.nprobe = int(value)
+
+    def set_index_parameters(self, index, description: str):
+        for tok in description.split(","):
+            if tok:
+                k, v = tok.split("=")
+                self.set_index_parameter(index, k, float(v))
+
+
+_MAGIC = "mi355x-ivfpq-v1"
+
+
+def write_index(index, fname: str) -> None:
+    """Own container (numpy .npz): parameters, centroids, codebook, and the
+    inverted lists as (list_no, codes, ids).  The faiss on-disk format
+    (index.faiss + ondisk.ivfdata, reference Makefile:11) is a SURVEY 8(f)
+    "next" row."""
+    if isinstance(index, IndexFlatIP):
+        raise NotImplementedError("write_index: IndexFlatIP is not serialised")
+    sizes = np.array([index.list_size(l) for l in range(index.nlist)], np.int64)
+    codes = np.empty((int(sizes.sum()), index.pq.M), np.uint8)
+    ids = np.empty(int(sizes.sum()), np.int64)
+    o = 0
+    for l in range(index.nlist):
+        if sizes[l]:
+            c, i = index.get_list(l)
+            codes[o:o + sizes[l]] = c
+            ids[o:o + sizes[l]] = i
+            o += sizes[l]
+    trained = index.is_trained
+    with open(fname, "wb") as f:
+        np.savez(f, magic=np.array(_MAGIC),
+                 params=np.array([index.d, index.nlist, index.pq.M, index.pq.nbits, index.metric_type,
+                                  int(index.by_residual), index.nprobe, int(trained)], np.int64),
+                 centroids=index.get_centroids() if trained else np.zeros((0,), np.float32),
+                 codebook=index.get_codebook() if trained else np.zeros((0,), np.float32),
+                 sizes=sizes, codes=codes, ids=ids)
+
+
+def read_index(fname: str, device: int = 0):
+    z = np.load(fname, allow_pickle=False)
+    if str(z["magic"]) != _MAGIC:
+        raise ValueError(f"{fname}: not a {_MAGIC} file")
+    d, nlist, M, nbits, metric, by_res, nprobe, trained = (int(v) for v in z["params"])
+    index = IndexIVFPQ(d, nlist, M, nbits, metric, bool(by_res), device)
+    index.nprobe = nprobe
+    if trained:
+        index.set_centroids(z["centroids"])
+        index.set_codebook(z["codebook"])
+    sizes = z["sizes"]
+    if sizes.sum():
+        index.add_codes(np.repeat(np.arange(nlist, dtype=np.int32), sizes), z["codes"], z["ids"])
+    return index

@@ -1,0 +1,139 @@
+/*
+ * mi_ivfpq.h -- C ABI of the MI355X-native IVF-PQ index (search hot path).
+ *
+ * This is the drop-in boundary for the index half of the hot path.  The
+ * reference has no in-repo FFI for it: it reaches the arithmetic through the
+ * `sidecar-search index` CLI (reference Makefile:39 train, Makefile:25 fill,
+ * Makefile:32 tune, README.md:28 query-time app), which calls the Python faiss
+ * API.  Each entry point below names the faiss call it replaces; the Python
+ * mirror of that API is abstracts-search_amd/faiss.py, which binds exactly
+ * these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     in mi_last_error() (thread-local).  No C++ exception crosses the ABI.
+ *   - plain pointers and sizes only.  A data pointer may be a host pointer or
+ *     a HIP device pointer on the index's device (e.g. torch.Tensor.data_ptr());
+ *     the library detects which.  With device pointers for all inputs and
+ *     outputs, mi_index_search() only enqueues work on `stream` and returns
+ *     without synchronising; with host pointers it stages and synchronises.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - metric: MI_METRIC_INNER_PRODUCT only in this round (the metric the
+ *     reference's normalised stella embeddings use); MI_METRIC_L2 is rejected.
+ *   - nbits == 8 only (one byte per sub-quantiser, ksub = 256).
+ *   - handles are opaque, freed only by *_destroy; one handle per device.
+ *   - search is safe for concurrent readers on different streams only if each
+ *     uses its own handle; add/train-type calls are exclusive.
+ *   - result semantics (faiss): best first; unfilled slots I = -1,
+ *     D = -FLT_MAX.  Exact score ties are ordered by ascending id.
+ */
+#ifndef MI_IVFPQ_H
+#define MI_IVFPQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_METRIC_INNER_PRODUCT 0 /* faiss.METRIC_INNER_PRODUCT */
+#define MI_METRIC_L2 1            /* faiss.METRIC_L2 (not implemented) */
+
+typedef struct mi_index mi_index; /* faiss.IndexIVFPQ */
+typedef struct mi_flat mi_flat;   /* faiss.IndexFlatIP */
+
+/* Last error message of the calling thread ("" if none). */
+const char *mi_last_error(void);
+
+/* Number of visible HIP devices (faiss.get_num_gpus). */
+int mi_device_count(int *count);
+
+/* ---- IndexIVFPQ ---------------------------------------------------- */
+
+/* faiss.index_factory(d, "IVF{nlist},PQ{M}", metric) / IndexIVFPQ ctor. */
+int mi_index_create(int d, int nlist, int M, int nbits, int metric, int by_residual,
+                    int device, mi_index **out);
+int mi_index_destroy(mi_index *h);
+
+/* Result of IndexIVFPQ.train: coarse centroids [nlist][d] and PQ codebook
+ * [M][256][d/M], float32.  (faiss: quantizer.add(centroids); pq.centroids.) */
+int mi_index_set_coarse(mi_index *h, const float *centroids);
+int mi_index_set_codebook(mi_index *h, const float *codebook);
+int mi_index_get_coarse(mi_index *h, float *centroids_host);
+int mi_index_get_codebook(mi_index *h, float *codebook_host);
+int mi_index_is_trained(mi_index *h, int *out);
+
+/* IndexIVFPQ.ntotal / .reset() */
+int mi_index_ntotal(mi_index *h, int64_t *out);
+int mi_index_reset(mi_index *h);
+
+/* IndexIVFPQ.add (ids == NULL: sequential from ntotal) / add_with_ids.
+ * x: float32 [n][d]. */
+int mi_index_add(mi_index *h, int64_t n, const float *x, const int64_t *ids);
+
+/* The arithmetic of add without the append (IndexIVFPQ.encode_multiple +
+ * quantizer.assign): list_no[n] int32, codes[n][M] uint8, host outputs. */
+int mi_index_encode(mi_index *h, int64_t n, const float *x, int32_t *list_no_host,
+                    uint8_t *codes_host);
+
+/* Append pre-encoded entries (read_index path; InvertedLists.add_entries). */
+int mi_index_add_codes(mi_index *h, int64_t n, const int32_t *list_no_host,
+                       const uint8_t *codes_host, const int64_t *ids_host);
+
+/* InvertedLists.list_size / get_codes+get_ids (host outputs, insertion order). */
+int mi_index_list_size(mi_index *h, int list_no, int64_t *out);
+int mi_index_get_list(mi_index *h, int list_no, uint8_t *codes_host, int64_t *ids_host);
+
+/* IndexIVFPQ.search with index.nprobe = nprobe.
+ * q float32 [nq][d]; D float32 [nq][k]; I int64 [nq][k].  1 <= k <= 1024. */
+int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe,
+                    float *D, int64_t *I, void *stream);
+
+/* Steps 1-2 of search exposed for parity tests: quantizer.search(q, nprobe)
+ * -> coarse_I int32 [nq][nprobe], coarse_D float32 [nq][nprobe] (host), and the
+ * ADC table pq.compute_inner_prod_tables -> lut float32 [nq][M][256] (host).
+ * Any output may be NULL. */
+int mi_index_coarse_lut(mi_index *h, int64_t nq, const float *q, int nprobe,
+                        int32_t *coarse_I_host, float *coarse_D_host, float *lut_host);
+
+/* Average device time (ms) of the PQ-code scan kernel over the launches since
+ * the last call, measured with HIP events on the stream the kernel ran on;
+ * also returns the number of launches and the algorithmic bytes
+ * (codes scanned x (M + 8)) of the last launch.  Timing is off until enabled. */
+int mi_index_profile_enable(mi_index *h, int on);
+int mi_index_profile_read(mi_index *h, double *scan_ms_avg, int64_t *launches,
+                          int64_t *last_scan_bytes);
+
+/* ---- exchange step ------------------------------------------------- */
+
+/* Merge nparts per-shard results (faiss IndexShards merge): D_parts/I_parts are
+ * [nparts][nq][k] (what an all-gather of per-shard (D, I) produces). */
+int mi_merge_topk(int device, int nparts, int64_t nq, int k, const float *D_parts,
+                  const int64_t *I_parts, float *D, int64_t *I, void *stream);
+
+/* ---- IndexFlatIP (config #1; also the coarse quantiser's arithmetic) ---- */
+
+int mi_flat_create(int d, int device, mi_flat **out);
+int mi_flat_destroy(mi_flat *h);
+int mi_flat_add(mi_flat *h, int64_t n, const float *x);
+int mi_flat_ntotal(mi_flat *h, int64_t *out);
+int mi_flat_reset(mi_flat *h);
+int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int64_t *I,
+                   void *stream);
+
+/* ---- building blocks used by train() in the Python mirror ---------- */
+
+/* arg max_j <x_i, c_j> (ties: smallest j) -> assign int32 [n], score float32 [n]
+ * (host or device outputs; score may be NULL).  Clustering assignment step. */
+int mi_ip_assign(int device, int64_t n, const float *x, int64_t nc, const float *c, int d,
+                 int32_t *assign, float *score, void *stream);
+
+/* ProductQuantizer.compute_codes: codes uint8 [n][M] (host or device output),
+ * codebook float32 [M][256][d/M]. */
+int mi_pq_encode(int device, int64_t n, const float *x, int d, int M, const float *codebook,
+                 uint8_t *codes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_IVFPQ_H */

@@ -1,0 +1,292 @@
+/*
+ * oracle/ivfpq_oracle.c -- CPU restatement of the IVF-PQ half of the hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (abstracts-search_amd/)
+ * may import, link or call this file.  It is the checker used by tests/,
+ * __graft_entry__.smoke() and the cpu_baseline leg of bench.py.
+ *
+ * PARITY UNPINNED.  The reference (/root/reference) holds none of this
+ * arithmetic: it only *invokes* it through `sidecar-search index train|fill|tune`
+ * (reference Makefile:39, Makefile:25, Makefile:32) and the query-time app
+ * (reference README.md:28).  The arithmetic lives in faiss, an un-vendored,
+ * un-pinned transitive dependency of sidecar-search@0.3.0
+ * (reference requirements.txt:1).  faiss is not importable in the build
+ * container, the reference ships no tests and no golden vectors, so this file
+ * restates the *published* algorithm (Jegou, Douze, Schmid: "Product
+ * quantization for nearest neighbor search", PAMI 2011, the IVFADC scheme)
+ * with faiss's documented IndexIVFPQ search semantics:
+ *
+ *   - coarse quantiser = flat inner-product search over the nlist centroids,
+ *     best `nprobe` kept                                  (IndexIVF::search)
+ *   - by_residual: the vector stored in list c is PQ-encoded as (x - c)
+ *                                                        (IndexIVFPQ::encode)
+ *   - PQ encode: sub-vector m -> index of the L2-nearest codeword of
+ *     codebook[m]                                 (ProductQuantizer::compute_code)
+ *   - ADC, inner product: LUT[m][j] = <q_m, codebook[m][j]>;
+ *     score(code) = <q, c> (if by_residual) + sum_{m ascending} LUT[m][code[m]]
+ *                                         (IVFPQScanner, METRIC_INNER_PRODUCT)
+ *   - keep the k best, best first; unfilled slots are I = -1 and
+ *     D = -FLT_MAX (the neutral element of faiss's CMin heap).
+ *
+ * Where faiss leaves the floating-point evaluation order to its BLAS / SIMD
+ * build, this restatement fixes ONE order so that "bit-exact" is a meaningful
+ * statement between this file and the HIP kernels:
+ *
+ *   dot(a, b, n)  = fmaf chain, k ascending, accumulator starts at +0.0f
+ *                   (this is bit-for-bit what gfx950's v_mfma_f32_16x16x4_f32
+ *                   computes, see MI355X guide "FP32-input MFMA")
+ *   l2sqr(a,b,n)  = t = a[k]-b[k]; acc = fmaf(t, t, acc), k ascending
+ *   ADC sum       = acc = 0; acc += LUT[m][code[m]] for m ascending;
+ *                   score = coarse_term + acc
+ *   ties          = total order (score descending, then id ascending); for the
+ *                   coarse quantiser the "id" is the list number.  faiss breaks
+ *                   exact ties by heap insertion order, which depends on its
+ *                   threading/scan order; a total order makes the result
+ *                   independent of scan order and of how the index is sharded.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -mavx2 -mfma -ffp-contract=off -fopenmp).
+ * -ffp-contract=off matters: every fused multiply-add below is an explicit
+ * fmaf(); nothing else may be contracted.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* elementary arithmetic, fixed evaluation order                      */
+/* ------------------------------------------------------------------ */
+
+static inline float dot_chain(const float *a, const float *b, int n) {
+    float acc = 0.0f;
+    for (int k = 0; k < n; ++k) acc = fmaf(a[k], b[k], acc);
+    return acc;
+}
+
+static inline float l2sqr_chain(const float *a, const float *b, int n) {
+    float acc = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        float t = a[k] - b[k];
+        acc = fmaf(t, t, acc);
+    }
+    return acc;
+}
+
+/* 8 independent ascending-k chains at once: same bits as dot_chain, but the
+ * chains pipeline instead of serialising on fma latency. */
+static inline void dot_chain_x8(const float *q, const float *rows, int ld, int n,
+                                float out[8]) {
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    const float *r0 = rows, *r1 = rows + ld, *r2 = rows + 2 * (size_t)ld,
+                *r3 = rows + 3 * (size_t)ld, *r4 = rows + 4 * (size_t)ld,
+                *r5 = rows + 5 * (size_t)ld, *r6 = rows + 6 * (size_t)ld,
+                *r7 = rows + 7 * (size_t)ld;
+    for (int k = 0; k < n; ++k) {
+        float x = q[k];
+        a0 = fmaf(x, r0[k], a0);
+        a1 = fmaf(x, r1[k], a1);
+        a2 = fmaf(x, r2[k], a2);
+        a3 = fmaf(x, r3[k], a3);
+        a4 = fmaf(x, r4[k], a4);
+        a5 = fmaf(x, r5[k], a5);
+        a6 = fmaf(x, r6[k], a6);
+        a7 = fmaf(x, r7[k], a7);
+    }
+    out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+    out[4] = a4; out[5] = a5; out[6] = a6; out[7] = a7;
+}
+
+/* all inner products of one query against n rows */
+static void ip_row(const float *q, const float *rows, int64_t n, int d, float *out) {
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) dot_chain_x8(q, rows + i * d, d, d, out + i);
+    for (; i < n; ++i) out[i] = dot_chain(q, rows + i * d, d);
+}
+
+/* ------------------------------------------------------------------ */
+/* top-k under the total order (score desc, id asc)                   */
+/* ------------------------------------------------------------------ */
+
+typedef struct { float s; int64_t id; } cand_t;
+
+static inline int better(float sa, int64_t ia, float sb, int64_t ib) {
+    return (sa > sb) || (sa == sb && ia < ib);
+}
+
+/* sorted insertion list, best first; n = current fill, k = capacity */
+static inline void topk_push(cand_t *L, int *n, int k, float s, int64_t id) {
+    if (s != s) return; /* NaN never enters (faiss: comparison false) */
+    if (*n == k && !better(s, id, L[k - 1].s, L[k - 1].id)) return;
+    int pos = (*n < k) ? *n : k - 1;
+    while (pos > 0 && better(s, id, L[pos - 1].s, L[pos - 1].id)) {
+        L[pos] = L[pos - 1];
+        --pos;
+    }
+    L[pos].s = s;
+    L[pos].id = id;
+    if (*n < k) ++*n;
+}
+
+/* ------------------------------------------------------------------ */
+/* exported entry points                                              */
+/* ------------------------------------------------------------------ */
+
+ORACLE_API int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* Flat inner-product top-k: the coarse quantiser (IndexFlatIP::search), also
+ * config #1's IndexFlatIP.  idx is int64 (faiss idx_t); unfilled = -1/-FLT_MAX. */
+ORACLE_API void oracle_flat_ip(int64_t nq, int d, const float *q, int64_t nb,
+                               const float *base, int k, float *D, int64_t *I) {
+#pragma omp parallel
+    {
+        float *row = (float *)malloc(sizeof(float) * (size_t)(nb > 0 ? nb : 1));
+        cand_t *L = (cand_t *)malloc(sizeof(cand_t) * (size_t)k);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t qi = 0; qi < nq; ++qi) {
+            ip_row(q + qi * d, base, nb, d, row);
+            int n = 0;
+            for (int64_t i = 0; i < nb; ++i) topk_push(L, &n, k, row[i], i);
+            for (int j = 0; j < k; ++j) {
+                D[qi * k + j] = j < n ? L[j].s : -FLT_MAX;
+                I[qi * k + j] = j < n ? L[j].id : -1;
+            }
+        }
+        free(row);
+        free(L);
+    }
+}
+
+/* ADC look-up table for one query: lut[m*ksub + j] = <q_m, codebook[m][j]> */
+ORACLE_API void oracle_lut(int d, int M, int ksub, const float *q,
+                           const float *codebook, float *lut) {
+    int dsub = d / M;
+    for (int m = 0; m < M; ++m)
+        for (int j = 0; j < ksub; ++j)
+            lut[m * ksub + j] = dot_chain(
+                q + m * dsub, codebook + ((size_t)m * ksub + j) * dsub, dsub);
+}
+
+/* Index.add(): coarse assign (arg max inner product, ties -> smallest list
+ * number) + PQ encode of the residual (or of x itself if !by_residual).
+ * ksub <= 256, one byte per sub-quantiser. */
+ORACLE_API void oracle_encode(int64_t n, int d, const float *x, int nlist,
+                              const float *centroids, int M, int ksub,
+                              const float *codebook, int by_residual,
+                              int32_t *list_no, uint8_t *codes) {
+    int dsub = d / M;
+#pragma omp parallel
+    {
+        float *row = (float *)malloc(sizeof(float) * (size_t)nlist);
+        float *r = (float *)malloc(sizeof(float) * (size_t)d);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t i = 0; i < n; ++i) {
+            const float *xi = x + i * d;
+            ip_row(xi, centroids, nlist, d, row);
+            int best = 0;
+            for (int c = 1; c < nlist; ++c)
+                if (row[c] > row[best]) best = c;
+            list_no[i] = best;
+            const float *cen = centroids + (size_t)best * d;
+            for (int t = 0; t < d; ++t) r[t] = by_residual ? xi[t] - cen[t] : xi[t];
+            for (int m = 0; m < M; ++m) {
+                int bj = 0;
+                float bd = l2sqr_chain(r + m * dsub, codebook + (size_t)m * ksub * dsub, dsub);
+                for (int j = 1; j < ksub; ++j) {
+                    float dj = l2sqr_chain(
+                        r + m * dsub, codebook + ((size_t)m * ksub + j) * dsub, dsub);
+                    if (dj < bd) { bd = dj; bj = j; }
+                }
+                codes[i * M + m] = (uint8_t)bj;
+            }
+        }
+        free(row);
+        free(r);
+    }
+}
+
+/* Index.search() over inverted lists in CSR form:
+ *   list l holds codes[list_off[l] .. list_off[l+1]) (M bytes each, row-major)
+ *   and ids[...] in the same order.
+ * Returns the coarse result too (coarse_I/coarse_D may be NULL). */
+ORACLE_API void oracle_search(int64_t nq, int d, const float *q, int nlist,
+                              const float *centroids, int M, int ksub,
+                              const float *codebook, int by_residual,
+                              const int64_t *list_off, const uint8_t *codes,
+                              const int64_t *ids, int nprobe, int k, float *D,
+                              int64_t *I, int32_t *coarse_I, float *coarse_D) {
+    if (nprobe > nlist) nprobe = nlist;
+#pragma omp parallel
+    {
+        float *row = (float *)malloc(sizeof(float) * (size_t)nlist);
+        float *lut = (float *)malloc(sizeof(float) * (size_t)M * ksub);
+        cand_t *P = (cand_t *)malloc(sizeof(cand_t) * (size_t)nprobe);
+        cand_t *L = (cand_t *)malloc(sizeof(cand_t) * (size_t)k);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t qi = 0; qi < nq; ++qi) {
+            const float *qv = q + qi * d;
+            /* step 1: coarse quantise */
+            ip_row(qv, centroids, nlist, d, row);
+            int np = 0;
+            for (int c = 0; c < nlist; ++c) topk_push(P, &np, nprobe, row[c], c);
+            /* step 2: distance LUT */
+            oracle_lut(d, M, ksub, qv, codebook, lut);
+            /* step 3+4: scan the probed lists, keep the k best */
+            int n = 0;
+            for (int p = 0; p < np; ++p) {
+                int64_t l = P[p].id;
+                float dis0 = by_residual ? P[p].s : 0.0f;
+                for (int64_t e = list_off[l]; e < list_off[l + 1]; ++e) {
+                    const uint8_t *c = codes + e * M;
+                    float acc = 0.0f;
+                    for (int m = 0; m < M; ++m) acc += lut[m * ksub + c[m]];
+                    topk_push(L, &n, k, dis0 + acc, ids[e]);
+                }
+            }
+            for (int j = 0; j < k; ++j) {
+                D[qi * k + j] = j < n ? L[j].s : -FLT_MAX;
+                I[qi * k + j] = j < n ? L[j].id : -1;
+            }
+            if (coarse_I)
+                for (int p = 0; p < nprobe; ++p) coarse_I[qi * nprobe + p] = p < np ? (int32_t)P[p].id : -1;
+            if (coarse_D)
+                for (int p = 0; p < nprobe; ++p) coarse_D[qi * nprobe + p] = p < np ? P[p].s : -FLT_MAX;
+        }
+        free(row);
+        free(lut);
+        free(P);
+        free(L);
+    }
+}
+
+/* Merge `nparts` per-shard top-k lists ([part][q][k], best first, -1 padded)
+ * into one, under the same total order.  This is the exchange step's
+ * arithmetic (faiss: IndexShards / merge_knn_results). */
+ORACLE_API void oracle_merge(int nparts, int64_t nq, int k, const float *Dp,
+                             const int64_t *Ip, float *D, int64_t *I) {
+    cand_t *L = (cand_t *)malloc(sizeof(cand_t) * (size_t)k);
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        int n = 0;
+        for (int p = 0; p < nparts; ++p)
+            for (int j = 0; j < k; ++j) {
+                size_t o = ((size_t)p * nq + qi) * k + j;
+                if (Ip[o] >= 0) topk_push(L, &n, k, Dp[o], Ip[o]);
+            }
+        for (int j = 0; j < k; ++j) {
+            D[qi * k + j] = j < n ? L[j].s : -FLT_MAX;
+            I[qi * k + j] = j < n ? L[j].id : -1;
+        }
+    }
+    free(L);
+}

@@ -1,0 +1,269 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the oracle, bit-exact
+for codes / indices / f32 scores, on golden fixtures, seeded random indexes
+and edge cases."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def faiss():
+    import abstracts_search_amd.faiss as f
+    assert f.get_num_gpus() >= 1
+    return f
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "ivfpq_tiny.npz"))
+
+
+def make_index(faiss, cent, cb, by_residual=True):
+    idx = faiss.IndexIVFPQ(cent.shape[1], cent.shape[0], cb.shape[0], 8, faiss.METRIC_INNER_PRODUCT,
+                           by_residual=by_residual)
+    assert not idx.is_trained
+    idx.set_centroids(cent)
+    idx.set_codebook(cb)
+    assert idx.is_trained
+    return idx
+
+
+def random_problem(seed, d, M, nlist, n, nq, scale=0.3):
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((nlist, d)).astype(np.float32)
+    cb = (scale * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+    x = (cent[rng.integers(0, nlist, n)] + scale * rng.standard_normal((n, d))).astype(np.float32)
+    q = (x[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    return cent, cb, x, q
+
+
+def test_golden_fixture(faiss, gold):
+    cent, cb, x, q, ids = gold["centroids"], gold["codebook"], gold["x"], gold["q"], gold["ids"]
+    k = int(gold["k"])
+    idx = make_index(faiss, cent, cb)
+    ln, codes = idx.encode(x)
+    assert np.array_equal(ln, gold["list_no"])
+    assert np.array_equal(codes, gold["codes"])
+    idx.add_with_ids(x, ids)
+    assert idx.ntotal == x.shape[0]
+    _, _, lut = idx.coarse_and_lut(q[:1], 1)
+    assert np.array_equal(bits(lut[0]), bits(gold["lut_q0"]))
+    for nprobe in (1, 4, 16):
+        cI, cD, _ = idx.coarse_and_lut(q, nprobe, want_lut=False)
+        assert np.array_equal(cI, gold[f"cI_np{nprobe}"])
+        assert np.array_equal(bits(cD), bits(gold[f"cD_np{nprobe}"]))
+        idx.nprobe = nprobe
+        D, I = idx.search(q, k)
+        assert np.array_equal(I, gold[f"I_np{nprobe}"])
+        assert np.array_equal(bits(D), bits(gold[f"D_np{nprobe}"]))
+    flat = faiss.IndexFlatIP(x.shape[1])
+    flat.add(x)
+    D, I = flat.search(q, k)
+    assert np.array_equal(I, gold["flat_I"])
+    assert np.array_equal(bits(D), bits(gold["flat_D"]))
+
+
+@pytest.mark.parametrize("d,M,nlist,n,nq", [
+    (64, 8, 16, 3000, 33),       # small, ragged nq
+    (128, 16, 64, 20000, 130),   # second GEMM tile config (nq > 128)
+    (256, 64, 32, 5000, 17),     # M = 64, dsub = 4
+    (1024, 64, 256, 30000, 64),  # the north-star shape (d=1024, PQ64), reduced N
+    (96, 4, 7, 900, 5),          # odd nlist, M = 4, dsub = 24 -> unsupported? (d/M must be pow2)
+])
+@pytest.mark.parametrize("by_residual", [True, False])
+def test_search_matches_oracle(faiss, oracle, d, M, nlist, n, nq, by_residual):
+    if (d // M) not in (1, 2, 4, 8, 16, 32, 64):
+        with pytest.raises(RuntimeError, match="unsupported d/M"):
+            faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT)
+        return
+    cent, cb, x, q = random_problem(d * 7 + M, d, M, nlist, n, nq)
+    idx = make_index(faiss, cent, cb, by_residual)
+    idx.add(x[: n // 2])
+    idx.add(x[n // 2:])          # two add() calls: sequential ids continue from ntotal
+    assert idx.ntotal == n
+    ln, codes = oracle.encode(x, cent, cb, by_residual)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(n), nlist)
+    # inverted lists hold exactly the oracle's codes in insertion order
+    for l in (0, nlist // 2, nlist - 1):
+        c, i = idx.get_list(l)
+        assert np.array_equal(c, lc[off[l]:off[l + 1]]) and np.array_equal(i, li[off[l]:off[l + 1]])
+    for nprobe, k in ((1, 10), (5, 10), (nlist, 1), (min(nlist, 33), 64)):
+        idx.nprobe = nprobe
+        D, I = idx.search(q, k)
+        De, Ie, cIe, cDe = oracle.search(q, cent, cb, off, lc, li, nprobe, k, by_residual, return_coarse=True)
+        cI, cD, _ = idx.coarse_and_lut(q, nprobe, want_lut=False)
+        assert np.array_equal(cI, cIe)
+        assert np.array_equal(bits(cD), bits(cDe))
+        assert np.array_equal(I, Ie), (nprobe, k, np.argwhere(I != Ie)[:5])
+        assert np.array_equal(bits(D), bits(De))
+
+
+def test_lut_matches_oracle(faiss, oracle):
+    cent, cb, x, q = random_problem(3, 1024, 64, 8, 64, 9)
+    idx = make_index(faiss, cent, cb)
+    _, _, lut = idx.coarse_and_lut(q, 1)
+    for i in range(q.shape[0]):
+        assert np.array_equal(bits(lut[i]), bits(oracle.lut(q[i], cb)))
+
+
+def test_gemm_tile_configs_bit_exact(faiss, oracle):
+    """every ip_gemm tile configuration (chosen by nq) gives the oracle's fmaf chain"""
+    rng = np.random.default_rng(11)
+    d, nb = 1024, 777
+    base = rng.standard_normal((nb, d)).astype(np.float32)
+    flat = faiss.IndexFlatIP(d)
+    flat.add(base)
+    for nq in (1, 16, 17, 128, 129, 512, 513, 700):
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+        D, I = flat.search(q, 5)
+        De, Ie = oracle.flat_ip(q, base, 5)
+        assert np.array_equal(I, Ie), nq
+        assert np.array_equal(bits(D), bits(De)), nq
+
+
+def test_large_k_multipass(faiss, oracle):
+    cent, cb, x, q = random_problem(21, 64, 8, 8, 4000, 12)
+    idx = make_index(faiss, cent, cb)
+    idx.add(x)
+    ln, codes = oracle.encode(x, cent, cb)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(len(x)), 8)
+    for k, nprobe in ((65, 8), (200, 3), (1000, 8)):
+        idx.nprobe = nprobe
+        D, I = idx.search(q, k)
+        De, Ie = oracle.search(q, cent, cb, off, lc, li, nprobe, k)
+        assert np.array_equal(I, Ie), k
+        assert np.array_equal(bits(D), bits(De)), k
+    # flat index / coarse quantiser with K > 64
+    flat = faiss.IndexFlatIP(64)
+    flat.add(x)
+    D, I = flat.search(q, 130)
+    De, Ie = oracle.flat_ip(q, x, 130)
+    assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De))
+    idx.nprobe = 8
+    cI, cD, _ = idx.coarse_and_lut(q, 8, want_lut=False)
+    assert cI.shape == (12, 8)
+
+
+def test_edge_cases(faiss, oracle):
+    cent, cb, x, q = random_problem(4, 64, 8, 16, 40, 6)
+    idx = make_index(faiss, cent, cb)
+    # empty index: all -1
+    D, I = idx.search(q, 5)
+    assert (I == -1).all() and (D == -np.finfo(np.float32).max).all()
+    ids = np.arange(40, dtype=np.int64)[::-1] * 3 + 5     # descending ids
+    idx.add_with_ids(x, ids)
+    # k > ntotal -> tail padded with -1 / -FLT_MAX; nprobe > nlist clamps
+    idx.nprobe = 1000
+    D, I = idx.search(q, 50)
+    assert (I[:, 40:] == -1).all() and (D[:, 40:] == -np.finfo(np.float32).max).all()
+    assert all(sorted(r[:40].tolist()) == sorted(ids.tolist()) for r in I)
+    ln, codes = oracle.encode(x, cent, cb)
+    off, lc, li = oracle.build_lists(ln, codes, ids, 16)
+    De, Ie = oracle.search(q, cent, cb, off, lc, li, 16, 50)
+    assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De))
+    # exact duplicates -> ties broken by ascending id, regardless of storage order
+    idx.add_with_ids(x[:10], np.arange(10, dtype=np.int64) + 1)
+    ids2 = np.concatenate([ids, np.arange(10) + 1])
+    x2 = np.concatenate([x, x[:10]])
+    ln, codes = oracle.encode(x2, cent, cb)
+    off, lc, li = oracle.build_lists(ln, codes, ids2, 16)
+    D, I = idx.search(x[:10], 4)
+    De, Ie = oracle.search(x[:10], cent, cb, off, lc, li, 16, 4)
+    assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De))
+    # reset
+    idx.reset()
+    assert idx.ntotal == 0
+    D, I = idx.search(q, 3)
+    assert (I == -1).all()
+    # argument errors surface as Python exceptions
+    with pytest.raises(AssertionError):
+        idx.search(q[:, :32], 3)
+    with pytest.raises(RuntimeError):
+        idx.search(q, 5000)
+    untrained = faiss.IndexIVFPQ(64, 16, 8, 8, faiss.METRIC_INNER_PRODUCT)
+    with pytest.raises(RuntimeError, match="not trained"):
+        untrained.add(x)
+    with pytest.raises(RuntimeError):
+        faiss.IndexIVFPQ(64, 16, 8, 8, faiss.METRIC_L2)
+
+
+def test_torch_device_path_equals_host_path(faiss):
+    import torch
+    cent, cb, x, q = random_problem(8, 128, 16, 32, 8000, 70)
+    idx = make_index(faiss, cent, cb)
+    idx.add(torch.from_numpy(x).cuda())        # device-pointer add
+    idx.nprobe = 6
+    D, I = idx.search(q, 10)
+    Dt, It = idx.search(torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    assert np.array_equal(I, It.cpu().numpy()) and np.array_equal(bits(D), bits(Dt.cpu().numpy()))
+    # determinism: same call twice, bit-identical
+    Dt2, It2 = idx.search(torch.from_numpy(q).cuda(), 10)
+    assert torch.equal(It, It2) and torch.equal(Dt, Dt2)
+
+
+def test_merge_topk_and_shard_invariance(faiss, oracle):
+    cent, cb, x, q = random_problem(9, 64, 8, 16, 6000, 40)
+    n = len(x)
+    whole = make_index(faiss, cent, cb)
+    whole.add(x)
+    whole.nprobe = 5
+    D, I = whole.search(q, 10)
+    for nshard in (2, 3, 8):
+        Dp, Ip = [], []
+        for s in range(nshard):                       # shard s holds rows i = s (mod nshard)
+            sh = make_index(faiss, cent, cb)
+            sh.add_with_ids(x[s::nshard], np.arange(n, dtype=np.int64)[s::nshard])
+            sh.nprobe = 5
+            d_, i_ = sh.search(q, 10)
+            Dp.append(d_), Ip.append(i_)
+        Dp, Ip = np.stack(Dp), np.stack(Ip)
+        Dm, Im = faiss.merge_topk(Dp, Ip)
+        assert np.array_equal(Im, I) and np.array_equal(bits(Dm), bits(D))
+        Do, Io = oracle.merge(Dp, Ip)
+        assert np.array_equal(Im, Io) and np.array_equal(bits(Dm), bits(Do))
+        perm = np.random.default_rng(nshard).permutation(nshard)
+        Dm2, Im2 = faiss.merge_topk(Dp[perm], Ip[perm])
+        assert np.array_equal(Im2, Im)
+
+
+def test_write_read_roundtrip(faiss, tmp_path):
+    cent, cb, x, q = random_problem(10, 64, 8, 16, 2000, 20)
+    idx = make_index(faiss, cent, cb)
+    idx.add_with_ids(x, np.arange(2000, dtype=np.int64) + 77)
+    idx.nprobe = 4
+    D, I = idx.search(q, 10)
+    f = str(tmp_path / "index.mi")
+    faiss.write_index(idx, f)
+    idx2 = faiss.read_index(f)
+    assert idx2.ntotal == 2000 and idx2.nprobe == 4 and idx2.is_trained
+    D2, I2 = idx2.search(q, 10)
+    assert np.array_equal(I, I2) and np.array_equal(bits(D), bits(D2))
+
+
+def test_train_builds_a_usable_index(faiss):
+    """train() is setup (not bit-pinned): check it yields a working quantiser
+    with good recall on clustered data."""
+    import abstracts_search_amd.synth as synth
+    x = synth.corpus_rows(0, 20000, d=64, ncentres=64, cos=0.8)
+    q = synth.queries_from(x, 50, cos=0.8)
+    idx = faiss.index_factory(64, "IVF32,PQ16", faiss.METRIC_INNER_PRODUCT)
+    idx.cp.niter = 8
+    idx.train(x)
+    assert idx.is_trained
+    idx.add(x)
+    idx.nprobe = 8
+    D, I = idx.search(q, 10)
+    flat = faiss.IndexFlatIP(64)
+    flat.add(x)
+    Df, If = flat.search(q, 10)
+    recall = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(I, If)])
+    assert recall > 0.5, recall
+    assert (D[:, :-1] >= D[:, 1:]).all()

@@ -1,0 +1,115 @@
+"""CPU tests of the oracle itself: C restatement vs the committed golden
+vectors, vs the independent numpy brute force, and algebraic properties.
+(PARITY UNPINNED -- SURVEY.md 8(c): no reference tests / golden vectors exist.)"""
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "ivfpq_tiny.npz"))
+
+
+def test_oracle_matches_golden(oracle, gold):
+    cent, cb, x, q, ids = gold["centroids"], gold["codebook"], gold["x"], gold["q"], gold["ids"]
+    k = int(gold["k"])
+    list_no, codes = oracle.encode(x, cent, cb, True)
+    assert np.array_equal(list_no, gold["list_no"])
+    assert np.array_equal(codes, gold["codes"])
+    assert np.array_equal(oracle.lut(q[0], cb), gold["lut_q0"])
+    off, lc, li = oracle.build_lists(list_no, codes, ids, cent.shape[0])
+    for nprobe in (1, 4, 16):
+        D, I, cI, cD = oracle.search(q, cent, cb, off, lc, li, nprobe, k, True, return_coarse=True)
+        assert np.array_equal(I, gold[f"I_np{nprobe}"])
+        assert np.array_equal(D.view(np.uint32), gold[f"D_np{nprobe}"].view(np.uint32))
+        assert np.array_equal(cI, gold[f"cI_np{nprobe}"])
+        assert np.array_equal(cD.view(np.uint32), gold[f"cD_np{nprobe}"].view(np.uint32))
+    D, I = oracle.flat_ip(q, x, k)
+    assert np.array_equal(I, gold["flat_I"])
+    assert np.array_equal(D.view(np.uint32), gold["flat_D"].view(np.uint32))
+
+
+def test_golden_ties_ordered_by_id(gold):
+    # rows 500..511 duplicate rows 0..11: equal scores must appear in ascending id order
+    D, I = gold["D_np16"], gold["I_np16"]
+    for d_row, i_row in zip(D, I):
+        for a in range(len(d_row) - 1):
+            if d_row[a] == d_row[a + 1] and i_row[a + 1] >= 0:
+                assert i_row[a] < i_row[a + 1]
+    assert (D[:, :-1] >= D[:, 1:]).all()
+
+
+def _random_index(rng, d, M, nlist, n):
+    cent = rng.standard_normal((nlist, d)).astype(np.float32)
+    cb = (0.3 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+    x = (cent[rng.integers(0, nlist, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+    return cent, cb, x
+
+
+@pytest.mark.parametrize("by_residual", [True, False])
+def test_oracle_vs_numpy_bruteforce(oracle, by_residual):
+    rng = np.random.default_rng(5)
+    d, M, nlist, n, nq, k = 32, 4, 12, 700, 24, 7
+    cent, cb, x = _random_index(rng, d, M, nlist, n)
+    q = x[:nq] + 0.05 * rng.standard_normal((nq, d)).astype(np.float32)
+    ln, codes = oracle.encode(x, cent, cb, by_residual)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(n), nlist)
+    for nprobe in (1, 3, 12, 40):
+        D, I = oracle.search(q, cent, cb, off, lc, li, nprobe, k, by_residual)
+        D2, I2 = oracle.brute_force_search(q, cent, cb, off, lc, li, nprobe, k, by_residual)
+        assert np.array_equal(I >= 0, I2 >= 0)
+        m = I >= 0
+        assert np.allclose(D[m], D2[m], atol=1e-4, rtol=0)
+        assert (I[m] == I2[m]).mean() > 0.98  # float64 may reorder near-ties only
+
+
+def test_oracle_edge_cases(oracle):
+    rng = np.random.default_rng(6)
+    d, M, nlist, n = 16, 4, 8, 5
+    cent, cb, x = _random_index(rng, d, M, nlist, n)
+    ln, codes = oracle.encode(x, cent, cb)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(n) + 10, nlist)
+    # k larger than the number of stored vectors -> -1 / -FLT_MAX padding
+    D, I = oracle.search(x[:2], cent, cb, off, lc, li, nlist, 9)
+    assert (I[:, n:] == -1).all() and (D[:, n:] == -oracle.FLT_MAX).all()
+    assert sorted(I[0, :n].tolist()) == list(range(10, 10 + n))
+    # empty index
+    off0 = np.zeros(nlist + 1, np.int64)
+    D, I = oracle.search(x[:2], cent, cb, off0, lc[:0], li[:0], 3, 4)
+    assert (I == -1).all()
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(1, 4), st.integers(1, 6), st.integers(1, 8), st.integers(0, 2 ** 31 - 1))
+def test_merge_equals_global_topk(nparts, nq, k, seed):
+    from oracle import ivfpq_oracle as O
+    rng = np.random.default_rng(seed)
+    # unique ids across parts, some duplicated scores, some -1 padding
+    D = np.round(rng.standard_normal((nparts, nq, k)), 1).astype(np.float32)
+    I = rng.permutation(nparts * nq * k).reshape(nparts, nq, k).astype(np.int64)
+    D = -np.sort(-D, axis=2)
+    pad = rng.random((nparts, nq, k)) < 0.2
+    pad = np.maximum.accumulate(pad, axis=2)  # padding only at the tail
+    D[pad], I[pad] = -O.FLT_MAX, -1
+    # each part must itself be sorted under (score desc, id asc)
+    for p in range(nparts):
+        for qi in range(nq):
+            o = np.lexsort((I[p, qi], -D[p, qi]))
+            keep = I[p, qi][o] >= 0
+            oo = np.concatenate([o[keep], o[~keep]])
+            D[p, qi], I[p, qi] = D[p, qi][oo], I[p, qi][oo]
+    Dm, Im = O.merge(D, I)
+    for qi in range(nq):
+        s, i = D[:, qi].ravel(), I[:, qi].ravel()
+        v = i >= 0
+        o = np.lexsort((i[v], -s[v]))[:k]
+        exp_i = np.full(k, -1, np.int64)
+        exp_i[:len(o)] = i[v][o]
+        assert np.array_equal(Im[qi], exp_i)
+    # permuting the parts does not change the result
+    perm = rng.permutation(nparts)
+    Dm2, Im2 = O.merge(D[perm], I[perm])
+    assert np.array_equal(Im, Im2) and np.array_equal(Dm, Dm2)
