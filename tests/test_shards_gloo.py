@@ -1,0 +1,83 @@
+"""world_size-2/3 gloo tests (CPU) of the multi-GPU plumbing: vector sharding +
+query all-gather + top-k all-gather + merge reproduces the unsharded result.
+The local search / merge are injected from the oracle (allowed in tests); on
+the GPU box the same ShardedIndex runs the HIP paths (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    rng = np.random.default_rng(3)
+    d, M, nlist, n = 32, 4, 8, 1500
+    cent = rng.standard_normal((nlist, d)).astype(np.float32)
+    cb = (0.3 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+    x = (cent[rng.integers(0, nlist, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+    x[n - 20:] = x[:20]       # duplicates: ties must resolve identically when sharded
+    return cent, cb, x
+
+
+def _worker(rank, world, port, mode, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import ivfpq_oracle as O
+    from abstracts_search_amd.shards import ShardedIndex, shard_rows
+    cent, cb, x = _problem()
+    n, nlist, nprobe, k, b = len(x), len(cent), 3, 10, 6
+    rows = np.fromiter(shard_rows(n, rank, world), np.int64)
+    ln, codes = O.encode(x[rows], cent, cb)
+    off, lc, li = O.build_lists(ln, codes, rows, nlist)            # global ids
+
+    def local_search(q, kk):
+        D, I = O.search(q.numpy(), cent, cb, off, lc, li, nprobe, kk)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def merge(Dp, Ip):
+        D, I = O.merge(Dp.numpy(), Ip.numpy())
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    sh = ShardedIndex(index=None, local_search=local_search, merge=merge)
+    rng = np.random.default_rng(100)
+    qall = (x[rng.integers(0, n, world * b)] + 0.01 * rng.standard_normal((world * b, x.shape[1]))).astype(np.float32)
+    if mode == "own":
+        D, I = sh.search(torch.from_numpy(qall[rank * b:(rank + 1) * b]), k)
+        qs = qall[rank * b:(rank + 1) * b]
+    else:
+        D, I = sh.search_replicated(torch.from_numpy(qall), k)
+        qs = qall
+    # unsharded expectation
+    ln, codes = O.encode(x, cent, cb)
+    off, lc, li = O.build_lists(ln, codes, np.arange(n), nlist)
+    De, Ie = O.search(qs, cent, cb, off, lc, li, nprobe, k)
+    ok = np.array_equal(I.numpy(), Ie) and np.array_equal(D.numpy().view(np.uint32), De.view(np.uint32))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "own"), (2, "replicated"), (3, "own")])
+def test_sharded_equals_unsharded(world, mode):
+    from oracle import ivfpq_oracle as O
+    O.build()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), mode, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
