@@ -5,6 +5,7 @@
 #include "../../include/mi_ivfpq.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <utility>
@@ -23,14 +24,14 @@ hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 // kernel launch helpers
 // ------------------------------------------------------------------
 
-template <int WM, int WN, int WAVES_M, int WAVES_N>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK>
 void launch_gemm_cfg(const float *A, int na, const float *B, int nb, int d, float *S, int64_t ldS,
                      hipStream_t st) {
     constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
     int tiles_m = (na + BM - 1) / BM, tiles_n = (nb + BN - 1) / BN;
     int64_t grid = (int64_t)8 * tiles_m * ((tiles_n + 7) / 8);
     MI_REQUIRE(grid < (int64_t)1 << 31, "ip_gemm: grid too large");
-    hipLaunchKernelGGL((ip_gemm_kernel<WM, WN, WAVES_M, WAVES_N>), dim3((unsigned)grid),
+    hipLaunchKernelGGL((ip_gemm_kernel<WM, WN, WAVES_M, WAVES_N, BK>), dim3((unsigned)grid),
                        dim3(WAVES_M * WAVES_N * 64), 0, st, A, na, B, nb, d, S, ldS, tiles_m,
                        tiles_n);
     MI_HIP(hipGetLastError());
@@ -44,17 +45,17 @@ void launch_gemm(const float *A, int64_t na, const float *B, int64_t nb, int d, 
     MI_REQUIRE(d % 4 == 0, "d must be a multiple of 4");
     MI_REQUIRE(na > 0 && nb > 0, "empty gemm");
     MI_REQUIRE(na < ((int64_t)1 << 31) && nb < ((int64_t)1 << 31), "gemm dims exceed int32");
-    if (na <= 16) launch_gemm_cfg<1, 1, 1, 4>(A, (int)na, B, (int)nb, d, S, ldS, st);
-    else if (na <= 128) launch_gemm_cfg<1, 1, 4, 1>(A, (int)na, B, (int)nb, d, S, ldS, st);
-    else if (na <= 512) launch_gemm_cfg<2, 2, 2, 2>(A, (int)na, B, (int)nb, d, S, ldS, st);
-    else launch_gemm_cfg<4, 4, 2, 2>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    if (na <= 16) launch_gemm_cfg<1, 1, 1, 4, 128>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    else if (na <= 128) launch_gemm_cfg<1, 1, 4, 1, 128>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    else if (na <= 512) launch_gemm_cfg<2, 2, 2, 2, 32>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    else launch_gemm_cfg<4, 4, 2, 2, 32>(A, (int)na, B, (int)nb, d, S, ldS, st);
 }
 
 void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int32_t *oi32,
-                   int64_t *oi64, float *os, hipStream_t st) {
+                   int64_t *oi64, float *os, hipStream_t st, ProbeTables pt = ProbeTables{}) {
     MI_REQUIRE(K >= 1, "select: K < 1");
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(256), 0, st, S, ldS, n, K, oi32,
-                       oi64, os);
+                       oi64, os, pt);
     MI_HIP(hipGetLastError());
 }
 
@@ -144,10 +145,13 @@ void launch_scan(int M, const ScanArgs &a, hipStream_t st) {
 void launch_merge(const float *ps, const int64_t *pid, int nparts, int64_t stride_p,
                   int64_t stride_q, int64_t nq, int k, float *D, int64_t *I, int64_t ldo,
                   int out_off, float *bs, int64_t *bid, hipStream_t st) {
-    size_t smem = merge_smem_bytes(nparts, k);
-    MI_REQUIRE(smem <= 64 * 1024, "merge: nparts*k too large");
-    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), smem, st, ps, pid, nparts,
-                       stride_p, stride_q, k, D, I, ldo, out_off, bs, bid);
+    const size_t per_wave = merge_wave_bytes(nparts, k);
+    MI_REQUIRE(per_wave <= 64 * 1024, "merge: nparts*k too large");
+    int qpb = (int)std::min<size_t>(4, (64 * 1024) / per_wave);   // queries (waves) per workgroup
+    if (qpb == 3) qpb = 2;
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((nq + qpb - 1) / qpb)), dim3(64 * qpb),
+                       per_wave * qpb, st, ps, pid, nparts, stride_p, stride_q, nq, k, D, I, ldo,
+                       out_off, bs, bid);
     MI_HIP(hipGetLastError());
 }
 
@@ -179,6 +183,7 @@ struct mi_index {
     int64_t ngroups = 0;
     // workspaces
     DevBuf ws_q, ws_scores, ws_cidx, ws_cdis, ws_lut, ws_ps, ws_pid, ws_bs, ws_bid, ws_D, ws_I;
+    DevBuf ws_pgoff, ws_plen, ws_pprefix;
     DevBuf ws_x, ws_assign, ws_codes, ws_ids, ws_count;
     // scan-kernel timing
     bool prof = false;
@@ -524,6 +529,7 @@ static int choose_nslice(const mi_index *h, int64_t nq, int nprobe) {
     int64_t by_fill = (1024 + nq - 1) / nq;
     int64_t by_work = (int64_t)(per_query / 8.0);
     int64_t s = std::min(by_fill, by_work);
+    if (const char *e = std::getenv("MI_NSLICE")) s = std::atoi(e);  // tuning knob
     return (int)std::max<int64_t>(1, std::min<int64_t>(s, 32));
 }
 
@@ -536,7 +542,15 @@ static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int 
     float *cdis = h->ws_cdis.as<float>((size_t)nq * nprobe);
     float *lut = h->ws_lut.as<float>((size_t)nq * M * 256);
     launch_gemm(qdev, nq, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st);
-    launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st);
+    ProbeTables pt{};
+    if (!stop_after_lut) {
+        pt.list_goff = h->d_goff.get<int32_t>();
+        pt.list_len = h->d_len.get<int32_t>();
+        pt.p_goff = h->ws_pgoff.as<int32_t>((size_t)nq * nprobe);
+        pt.p_len = h->ws_plen.as<int32_t>((size_t)nq * nprobe);
+        pt.p_prefix = h->ws_pprefix.as<int32_t>((size_t)nq * (nprobe + 1));
+    }
+    launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st, pt);
     launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
     if (cI_out) MI_HIP(hipMemcpyAsync(cI_out, cidx, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (cD_out) MI_HIP(hipMemcpyAsync(cD_out, cdis, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
@@ -564,12 +578,14 @@ static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int 
     for (int pass = 0; pass < npass; ++pass) {
         const int kp = std::min(64, k - pass * 64);
         ScanArgs a;
-        a.lut = lut; a.coarse_idx = cidx; a.coarse_dis = cdis;
-        a.list_goff = h->d_goff.get<int32_t>(); a.list_len = h->d_len.get<int32_t>();
+        a.lut = lut; a.coarse_dis = cdis;
+        a.p_goff = pt.p_goff; a.p_len = pt.p_len; a.p_prefix = pt.p_prefix;
         a.codes = h->d_codes.get<uint8_t>(); a.ids = h->d_ids.get<int64_t>();
         a.part_s = ps; a.part_id = pid;
         a.bound_s = pass ? bs : nullptr; a.bound_id = pass ? bid : nullptr;
         a.nq = (int)nq; a.nprobe = nprobe; a.nslice = nslice; a.k = kp; a.by_residual = h->by_residual;
+        a.debug = 0;
+        if (const char *e = std::getenv("MI_SCAN_DEBUG")) a.debug = std::atoi(e);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->prof) {
             MI_HIP(hipEventCreate(&e0));

@@ -41,6 +41,14 @@ __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfi
 __device__ __forceinline__ float uniform_f(float v) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
+// lane i <- lane i-1 (lane 0 keeps its own value): one v_mov_b32_dpp wave_shr:1
+// instead of a ds_bpermute round trip through the LDS crossbar.
+__device__ __forceinline__ int wave_shr1_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float wave_shr1_f(float v) {
+    return __int_as_float(wave_shr1_i(__float_as_int(v)));
+}
 // order-preserving float <-> unsigned map (for LDS atomicMax on scores)
 __device__ __forceinline__ unsigned f2o(float f) {
     unsigned u = __float_as_uint(f);
@@ -53,7 +61,7 @@ __device__ __forceinline__ float o2f(unsigned o) {
 
 // ---------------------------------------------------------------------
 // S[na][nb] = A[na][d] . B[nb][d]^T, exact f32.
-// Workgroup tile BM x BN, K chunk 32, double-buffered through LDS in k-major
+// Workgroup tile BM x BN, K chunk BK (32 or 128), double-buffered through LDS in k-major
 // order so that lane (i = lane&15, g = lane>>4) reads A[k0+g][i]: the MFMA
 // then consumes k in ascending order and every output is an ascending-k fmaf
 // chain from +0.  LDS row stride == 16 (mod 32) keeps the four k-rows of one
@@ -61,18 +69,18 @@ __device__ __forceinline__ float o2f(unsigned o) {
 // Grid: 8 * tiles_m * ceil(tiles_n/8); block b runs on XCD b%8, and all
 // blocks of one XCD walk the M tiles of the same B strip (L2 reuse of B).
 // ---------------------------------------------------------------------
-template <int WM, int WN, int WAVES_M, int WAVES_N>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
     ip_gemm_kernel(const float *__restrict__ A, int na, const float *__restrict__ B, int nb,
                    int d, float *__restrict__ S, int64_t ldS, int tiles_m, int tiles_n) {
     constexpr int BM = 16 * WM * WAVES_M;
     constexpr int BN = 16 * WN * WAVES_N;
-    constexpr int BK = 32;
+    constexpr int KQ = BK / 4;  // float4 per tile row
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int SA = (BM % 32 == 16) ? BM : BM + 16;
     constexpr int SB = (BN % 32 == 16) ? BN : BN + 16;
-    constexpr int CA = (BM * 8 + NT - 1) / NT;
-    constexpr int CB = (BN * 8 + NT - 1) / NT;
+    constexpr int CA = (BM * KQ + NT - 1) / NT;
+    constexpr int CB = (BN * KQ + NT - 1) / NT;
     __shared__ float smem[2 * BK * (SA + SB)];
     float *As = smem;                 // [2][BK][SA]
     float *Bs = smem + 2 * BK * SA;   // [2][BK][SB]
@@ -100,9 +108,9 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
 #pragma unroll
         for (int u = 0; u < CA; ++u) {
             int idx = tid + u * NT;
-            if ((BM * 8) % NT == 0 || idx < BM * 8) {
-                int row = ((idx >> 7) << 4) | (idx & 15);
-                int k = k0 + ((idx >> 4) & 7) * 4;
+            if ((BM * KQ) % NT == 0 || idx < BM * KQ) {
+                int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
+                int k = k0 + ((idx >> 4) & (KQ - 1)) * 4;
                 int gr = min(m0 + row, na - 1);
                 ra[u] = (k < d) ? *reinterpret_cast<const float4 *>(A + (size_t)gr * d + k)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -111,9 +119,9 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
             int idx = tid + u * NT;
-            if ((BN * 8) % NT == 0 || idx < BN * 8) {
-                int row = ((idx >> 7) << 4) | (idx & 15);
-                int k = k0 + ((idx >> 4) & 7) * 4;
+            if ((BN * KQ) % NT == 0 || idx < BN * KQ) {
+                int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
+                int k = k0 + ((idx >> 4) & (KQ - 1)) * 4;
                 int gr = min(n0 + row, nb - 1);
                 rb[u] = (k < d) ? *reinterpret_cast<const float4 *>(B + (size_t)gr * d + k)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -124,9 +132,9 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
 #pragma unroll
         for (int u = 0; u < CA; ++u) {
             int idx = tid + u * NT;
-            if ((BM * 8) % NT == 0 || idx < BM * 8) {
-                int row = ((idx >> 7) << 4) | (idx & 15);
-                float *p = As + buf * BK * SA + (((idx >> 4) & 7) * 4) * SA + row;
+            if ((BM * KQ) % NT == 0 || idx < BM * KQ) {
+                int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
+                float *p = As + buf * BK * SA + (((idx >> 4) & (KQ - 1)) * 4) * SA + row;
                 p[0] = ra[u].x;
                 p[SA] = ra[u].y;
                 p[2 * SA] = ra[u].z;
@@ -136,9 +144,9 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
             int idx = tid + u * NT;
-            if ((BN * 8) % NT == 0 || idx < BN * 8) {
-                int row = ((idx >> 7) << 4) | (idx & 15);
-                float *p = Bs + buf * BK * SB + (((idx >> 4) & 7) * 4) * SB + row;
+            if ((BN * KQ) % NT == 0 || idx < BN * KQ) {
+                int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
+                float *p = Bs + buf * BK * SB + (((idx >> 4) & (KQ - 1)) * 4) * SB + row;
                 p[0] = rb[u].x;
                 p[SB] = rb[u].y;
                 p[2 * SB] = rb[u].z;
@@ -193,8 +201,8 @@ __device__ __forceinline__ void wave_insert_i32(float &ls, int &li, int lane, in
     bool before = (ls > cs) || (ls == cs && li < ci);
     int r = __popcll(__ballot(before));
     if (r >= k) return;  // wave-uniform
-    float us = __shfl_up(ls, 1);
-    int ui = __shfl_up(li, 1);
+    float us = wave_shr1_f(ls);
+    int ui = wave_shr1_i(li);
     if (lane > r) {
         ls = us;
         li = ui;
@@ -209,11 +217,23 @@ __device__ __forceinline__ void wave_insert_i32(float &ls, int &li, int lane, in
 // 256-thread workgroup per row.  K > 64 is extracted 64 at a time: pass p
 // keeps the best 64 among entries strictly after the last entry of pass p-1.
 // Unfilled: index -1, score -FLT_MAX.  out_i32 / out_i64 / out_s may be null.
+// With list tables (coarse quantiser of a search): also emits, per row, the
+// probe tables the scan kernel walks -- first group and length of every
+// probed list and the exclusive prefix sum of their group counts.
 // ---------------------------------------------------------------------
+struct ProbeTables {
+    const int32_t *list_goff;  // [nlist+1] in, null = no tables
+    const int32_t *list_len;   // [nlist]   in
+    int32_t *p_goff;           // [rows][K]   out
+    int32_t *p_len;            // [rows][K]   out
+    int32_t *p_prefix;         // [rows][K+1] out
+};
+
 __global__ void __launch_bounds__(256)
     select_kernel(const float *__restrict__ S, int64_t ldS, int n, int K, int32_t *__restrict__ out_i32,
-                  int64_t *__restrict__ out_i64, float *__restrict__ out_s) {
+                  int64_t *__restrict__ out_i64, float *__restrict__ out_s, ProbeTables pt) {
     __shared__ float m_s[256];
+    __shared__ int wtot[4];
     __shared__ int m_i[256];
     __shared__ float o_s[64];
     __shared__ int o_i[64];
@@ -278,6 +298,41 @@ __global__ void __launch_bounds__(256)
         bi = o_i[kp - 1];
         __syncthreads();
     }
+    if (pt.list_goff) {  // probe tables (out_i32 is non-null on this path; written by this block)
+        const int per = (K + 255) / 256;
+        const int b = tid * per;
+        int sum = 0;
+        for (int i = 0; i < per; ++i)
+            if (b + i < K) {
+                int l = out_i32[(size_t)row * K + b + i];
+                if (l >= 0) sum += pt.list_goff[l + 1] - pt.list_goff[l];
+            }
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads();
+        int run = incl - sum;
+        for (int ww = 0; ww < w; ++ww) run += wtot[ww];
+        for (int i = 0; i < per; ++i)
+            if (b + i < K) {
+                int l = out_i32[(size_t)row * K + b + i];
+                int g0 = 0, ng = 0, len = 0;
+                if (l >= 0) {
+                    g0 = pt.list_goff[l];
+                    ng = pt.list_goff[l + 1] - g0;
+                    len = pt.list_len[l];
+                }
+                pt.p_goff[(size_t)row * K + b + i] = g0;
+                pt.p_len[(size_t)row * K + b + i] = len;
+                pt.p_prefix[(size_t)row * (K + 1) + b + i] = run;
+                run += ng;
+                if (b + i == K - 1) pt.p_prefix[(size_t)row * (K + 1) + K] = run;
+            }
+    }
 }
 
 // ---------------------------------------------------------------------
@@ -310,10 +365,10 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------
 struct ScanArgs {
     const float *lut;          // [nq][M*256]
-    const int32_t *coarse_idx; // [nq][nprobe], -1 = none
     const float *coarse_dis;   // [nq][nprobe]
-    const int32_t *list_goff;  // [nlist+1] first group of each list
-    const int32_t *list_len;   // [nlist]
+    const int32_t *p_goff;     // [nq][nprobe]   first group of each probed list
+    const int32_t *p_len;      // [nq][nprobe]   its length in codes
+    const int32_t *p_prefix;   // [nq][nprobe+1] exclusive prefix of group counts
     const uint8_t *codes;      // group-interleaved
     const int64_t *ids;        // [ngroups*64]
     float *part_s;             // [nq][nslice][k]
@@ -321,6 +376,7 @@ struct ScanArgs {
     const float *bound_s;      // [nq] or null: only entries strictly after
     const int64_t *bound_id;   //      (bound_s, bound_id) are eligible
     int nq, nprobe, nslice, k, by_residual;
+    int debug;  // ablation switches for tools/scan_ablate.py (0 in production)
 };
 
 // LDS carve: [ LUT M*1024 B | prefix | p_goff | p_len | p_dis | wg_thr ]
@@ -357,44 +413,19 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
     {
         const float4 *lg = reinterpret_cast<const float4 *>(a.lut + (size_t)q * M * 256);
         float4 *ls4 = reinterpret_cast<float4 *>(lut_s);
-        for (int i = tid; i < M * 64; i += blockDim.x) ls4[i] = lg[i];
+        if (!(a.debug & 8))
+            for (int i = tid; i < M * 64; i += blockDim.x) ls4[i] = lg[i];
     }
     for (int p = tid; p < nprobe; p += blockDim.x) {
-        int l = a.coarse_idx[(size_t)q * nprobe + p];
-        int g0 = 0, ng = 0, len = 0;
-        if (l >= 0) {
-            g0 = a.list_goff[l];
-            ng = a.list_goff[l + 1] - g0;
-            len = a.list_len[l];
-        }
-        prefix[p + 1] = ng;
-        p_goff[p] = g0;
-        p_len[p] = len;
-        p_dis[p] = a.by_residual ? a.coarse_dis[(size_t)q * nprobe + p] : 0.0f;
+        const size_t o = (size_t)q * nprobe + p;
+        prefix[p] = a.p_prefix[(size_t)q * (nprobe + 1) + p];
+        p_goff[p] = a.p_goff[o];
+        p_len[p] = a.p_len[o];
+        p_dis[p] = a.by_residual ? a.coarse_dis[o] : 0.0f;
     }
     if (tid == 0) {
-        prefix[0] = 0;
+        prefix[nprobe] = a.p_prefix[(size_t)q * (nprobe + 1) + nprobe];
         *wg_thr = f2o(MI_NEG_INF);
-    }
-    __syncthreads();
-    if (w == 0) {  // inclusive scan of group counts, chunked over the lanes of wave 0
-        int per = (nprobe + 63) / 64;
-        int b = lane * per;
-        int sum = 0;
-        for (int i = 0; i < per; ++i)
-            if (b + i < nprobe) sum += prefix[b + i + 1];
-        int incl = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        int run = incl - sum;
-        for (int i = 0; i < per; ++i)
-            if (b + i < nprobe) {
-                run += prefix[b + i + 1];
-                prefix[b + i + 1] = run;
-            }
     }
     __syncthreads();
 
@@ -458,7 +489,8 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
                 const int m = ch * 16 + j;
                 if (m < M) {
                     unsigned byte = (wd[j >> 2] >> ((j & 3) * 8)) & 0xffu;
-                    acc += lut_s[m * 256 + byte];
+                    if (a.debug & 4) acc += __uint_as_float(byte);
+                    else acc += lut_s[m * 256 + byte];
                 }
             }
         }
@@ -469,6 +501,7 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         bool pf = (lane < c_nvalid) && (s >= thr_eff);
         if (has_bound) pf = pf && (s <= bs);
         unsigned long long mask = __ballot(pf);
+        if (a.debug & 1) mask &= 1ull;
         if (mask) {
             bool changed = false;
             while (mask) {
@@ -490,8 +523,8 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
                 }
                 const int r = __popcll(__ballot(before));
                 if (r >= k) continue;
-                float us = __shfl_up(ls, 1);
-                unsigned up = __shfl_up(lp, 1);
+                float us = wave_shr1_f(ls);
+                unsigned up = (unsigned)wave_shr1_i((int)lp);
                 if (lane > r) {
                     ls = us;
                     lp = up;
@@ -527,7 +560,7 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         o_p[tid] = EMPTY_POS;
     }
     __syncthreads();
-    if (lane < k && lp != EMPTY_POS) {
+    if (lane < k && lp != EMPTY_POS && !(a.debug & 2)) {
         int rank = 0;
         int64_t myid = 0;
         bool have_id = false;
@@ -566,61 +599,72 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
 // Empty entries: id == EMPTY_ID or id < 0.  Writes D/I at
 // [q*ldo + out_off + rank]; unfilled -FLT_MAX / -1.  Optionally records the
 // last kept entry per query (bound for the next extraction pass).
+// One wave per query, QPB = blockDim/64 queries per workgroup; rank by
+// counting over the n = nparts*k candidates staged in LDS.
 // ---------------------------------------------------------------------
+__host__ __device__ inline size_t merge_wave_bytes(int nparts, int k) {
+    size_t n = (size_t)nparts * k;
+    return ((n * 12 + 7) & ~(size_t)7) + (size_t)k * 16;   // e_id[n] e_s[n] | o_id[k] o_s[k](+pad)
+}
+
 __global__ void __launch_bounds__(256)
     merge_kernel(const float *__restrict__ ps, const int64_t *__restrict__ pid, int nparts,
-                 int64_t stride_p, int64_t stride_q, int k, float *__restrict__ D,
+                 int64_t stride_p, int64_t stride_q, int64_t nq, int k, float *__restrict__ D,
                  int64_t *__restrict__ I, int64_t ldo, int out_off, float *__restrict__ bound_s,
                  int64_t *__restrict__ bound_id) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = nparts * k;
-    int64_t *e_id = reinterpret_cast<int64_t *>(smem);            // [n]
-    float *e_s = reinterpret_cast<float *>(e_id + n);             // [n]
-    float *o_s = e_s + n;                                         // [k]
-    int64_t *o_id = reinterpret_cast<int64_t *>(smem + (((size_t)n * 12 + (size_t)k * 4 + 7) & ~(size_t)7));
-    const int tid = threadIdx.x;
-    const int64_t q = blockIdx.x;
-    for (int e = tid; e < n; e += blockDim.x) {
-        int p = e / k, j = e - p * k;
-        size_t o = (size_t)p * stride_p + (size_t)q * stride_q + j;
-        int64_t id = pid[o];
-        e_id[e] = id < 0 ? EMPTY_ID : id;
-        e_s[e] = id < 0 ? MI_NEG_INF : ps[o];
-    }
-    for (int j = tid; j < k; j += blockDim.x) {
-        o_s[j] = MI_NEG_INF;
-        o_id[j] = EMPTY_ID;
-    }
-    __syncthreads();
-    for (int e = tid; e < n; e += blockDim.x) {
-        const int64_t mi_ = e_id[e];
-        if (mi_ == EMPTY_ID) continue;
-        const float ms = e_s[e];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            float js = e_s[j];
-            int64_t ji = e_id[j];
-            rank += (js > ms) || (js == ms && (ji < mi_ || (ji == mi_ && j < e)));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, qpb = blockDim.x >> 6;
+    unsigned char *base = smem + (size_t)w * merge_wave_bytes(nparts, k);
+    int64_t *e_id = reinterpret_cast<int64_t *>(base);                                   // [n]
+    float *e_s = reinterpret_cast<float *>(e_id + n);                                    // [n]
+    int64_t *o_id = reinterpret_cast<int64_t *>(base + (((size_t)n * 12 + 7) & ~(size_t)7)); // [k]
+    float *o_s = reinterpret_cast<float *>(o_id + k);                                    // [k]
+    const int64_t q = (int64_t)blockIdx.x * qpb + w;
+    const bool live = q < nq;
+    if (live) {
+        for (int e = lane; e < n; e += 64) {
+            int p = e / k, j = e - p * k;
+            size_t o = (size_t)p * stride_p + (size_t)q * stride_q + j;
+            int64_t id = pid[o];
+            e_id[e] = id < 0 ? EMPTY_ID : id;
+            e_s[e] = id < 0 ? MI_NEG_INF : ps[o];
         }
-        if (rank < k) {
-            o_s[rank] = ms;
-            o_id[rank] = mi_;
+        for (int j = lane; j < k; j += 64) {
+            o_s[j] = MI_NEG_INF;
+            o_id[j] = EMPTY_ID;
         }
     }
     __syncthreads();
-    for (int j = tid; j < k; j += blockDim.x) {
-        int64_t id = o_id[j];
-        D[q * ldo + out_off + j] = id == EMPTY_ID ? -FLT_MAX : o_s[j];
-        I[q * ldo + out_off + j] = id == EMPTY_ID ? (int64_t)-1 : id;
+    if (live) {
+        for (int e = lane; e < n; e += 64) {
+            const int64_t mi_ = e_id[e];
+            if (mi_ == EMPTY_ID) continue;
+            const float ms = e_s[e];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                float js = e_s[j];
+                int64_t ji = e_id[j];
+                rank += (js > ms) || (js == ms && (ji < mi_ || (ji == mi_ && j < e)));
+            }
+            if (rank < k) {
+                o_s[rank] = ms;
+                o_id[rank] = mi_;
+            }
+        }
     }
-    if (bound_s && tid == 0) {
-        bound_s[q] = o_s[k - 1];
-        bound_id[q] = o_id[k - 1];
+    __syncthreads();
+    if (live) {
+        for (int j = lane; j < k; j += 64) {
+            int64_t id = o_id[j];
+            D[q * ldo + out_off + j] = id == EMPTY_ID ? -FLT_MAX : o_s[j];
+            I[q * ldo + out_off + j] = id == EMPTY_ID ? (int64_t)-1 : id;
+        }
+        if (bound_s && lane == 0) {
+            bound_s[q] = o_s[k - 1];
+            bound_id[q] = o_id[k - 1];
+        }
     }
-}
-__host__ inline size_t merge_smem_bytes(int nparts, int k) {
-    size_t n = (size_t)nparts * k;
-    return ((n * 12 + (size_t)k * 4 + 7) & ~(size_t)7) + (size_t)k * 8;
 }
 
 // ---------------------------------------------------------------------
