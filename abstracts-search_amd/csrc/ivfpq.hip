@@ -183,15 +183,24 @@ struct mi_index {
     int64_t ngroups = 0;
     // workspaces
     DevBuf ws_q, ws_scores, ws_cidx, ws_cdis, ws_lut, ws_ps, ws_pid, ws_bs, ws_bid, ws_D, ws_I;
-    DevBuf ws_pgoff, ws_plen, ws_pprefix;
+    DevBuf ws_pgoff, ws_plen, ws_pprefix, ws_counters;
+    size_t counters_zeroed = 0;  // bytes of ws_counters known to be zero
     DevBuf ws_x, ws_assign, ws_codes, ws_ids, ws_count;
     // scan-kernel timing
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
     int64_t last_scan_bytes = 0;
 
+    // side stream: the LUT kernel is independent of coarse GEMM + select and
+    // runs beside them (fork/join with events; capturable in a hipGraph)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
     int nch() const { return (M + 15) / 16; }
     ~mi_index() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
         for (auto &e : evs) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
@@ -541,6 +550,18 @@ static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int 
     int32_t *cidx = h->ws_cidx.as<int32_t>((size_t)nq * nprobe);
     float *cdis = h->ws_cdis.as<float>((size_t)nq * nprobe);
     float *lut = h->ws_lut.as<float>((size_t)nq * M * 256);
+    const bool fork = std::getenv("MI_SIDE_STREAM") != nullptr;  // measured slower in eager mode: opt-in
+    if (fork) {
+        if (!h->side) {
+            MI_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+            MI_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            MI_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+        MI_HIP(hipEventRecord(h->ev_fork, st));
+        MI_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, h->side);
+        MI_HIP(hipEventRecord(h->ev_join, h->side));
+    }
     launch_gemm(qdev, nq, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st);
     ProbeTables pt{};
     if (!stop_after_lut) {
@@ -551,7 +572,8 @@ static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int 
         pt.p_prefix = h->ws_pprefix.as<int32_t>((size_t)nq * (nprobe + 1));
     }
     launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st, pt);
-    launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
+    if (fork) MI_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    else launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
     if (cI_out) MI_HIP(hipMemcpyAsync(cI_out, cidx, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (cD_out) MI_HIP(hipMemcpyAsync(cD_out, cdis, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (lut_out) MI_HIP(hipMemcpyAsync(lut_out, lut, (size_t)nq * M * 256 * 4, hipMemcpyDeviceToHost, st));
@@ -592,13 +614,30 @@ static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int 
             MI_HIP(hipEventCreate(&e1));
             MI_HIP(hipEventRecord(e0, st));
         }
+        // the last slice of each query merges the partial lists in-kernel when
+        // they fit in the LUT's LDS region; otherwise a separate merge kernel
+        const bool fuse = scan_fused_merge_bytes(nslice, kp) <= scan_lut_bytes(M) &&
+                          !std::getenv("MI_NO_FUSED_MERGE");
+        a.counters = nullptr; a.D = Ddev; a.I = Idev; a.ldo = k; a.out_off = pass * 64;
+        a.next_bound_s = npass > 1 ? bs : nullptr; a.next_bound_id = npass > 1 ? bid : nullptr;
+        if (fuse) {
+            const size_t cb = (size_t)nq * sizeof(unsigned);
+            unsigned *cnt = h->ws_counters.as<unsigned>((size_t)nq);
+            if (h->counters_zeroed < h->ws_counters.cap) {  // fresh allocation: zero it once
+                MI_HIP(hipMemsetAsync(h->ws_counters.p, 0, h->ws_counters.cap, st));
+                h->counters_zeroed = h->ws_counters.cap;
+            }
+            (void)cb;
+            a.counters = cnt;
+        }
         launch_scan(M, a, st);
         if (h->prof) {
             MI_HIP(hipEventRecord(e1, st));
             h->evs.emplace_back(e0, e1);
         }
-        launch_merge(ps, pid, nslice, kp, (int64_t)nslice * kp, nq, kp, Ddev, Idev, k, pass * 64,
-                     npass > 1 ? bs : nullptr, npass > 1 ? bid : nullptr, st);
+        if (!fuse)
+            launch_merge(ps, pid, nslice, kp, (int64_t)nslice * kp, nq, kp, Ddev, Idev, k, pass * 64,
+                         npass > 1 ? bs : nullptr, npass > 1 ? bid : nullptr, st);
     }
 }
 

@@ -49,6 +49,11 @@ __device__ __forceinline__ int wave_shr1_i(int v) {
 __device__ __forceinline__ float wave_shr1_f(float v) {
     return __int_as_float(wave_shr1_i(__float_as_int(v)));
 }
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int lane_prefix_count(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
 // order-preserving float <-> unsigned map (for LDS atomicMax on scores)
 __device__ __forceinline__ unsigned f2o(float f) {
     unsigned u = __float_as_uint(f);
@@ -229,74 +234,181 @@ struct ProbeTables {
     int32_t *p_prefix;         // [rows][K+1] out
 };
 
+constexpr int SEL_CAP = 1024;  // survivor slots of the fast path
+
 __global__ void __launch_bounds__(256)
     select_kernel(const float *__restrict__ S, int64_t ldS, int n, int K, int32_t *__restrict__ out_i32,
                   int64_t *__restrict__ out_i64, float *__restrict__ out_s, ProbeTables pt) {
-    __shared__ float m_s[256];
+    __shared__ float c_s[SEL_CAP];   // survivors (fast path) / wave lists (fallback: first 256)
+    __shared__ int c_i[SEL_CAP];
+    __shared__ int c_rank[SEL_CAP];
+    __shared__ unsigned gkey[256];
+    __shared__ float o_s[256];
+    __shared__ int o_i[256];
     __shared__ int wtot[4];
-    __shared__ int m_i[256];
-    __shared__ float o_s[64];
-    __shared__ int o_i[64];
+    __shared__ int c_cnt;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = uniform_i(tid >> 6);
     const int64_t row = blockIdx.x;
     const float *r = S + row * ldS;
-    bool has_bound = false;
-    float bs = 0.f;
-    int bi = 0;
-    for (int p0 = 0; p0 < K; p0 += 64) {
-        const int kp = min(64, K - p0);
-        float ls = MI_NEG_INF, thr = MI_NEG_INF;
-        int li = INT_MAX;
-        for (int base = w * 64; base < n; base += 256) {
-            int c = base + lane;
-            bool valid = c < n;
-            float s = valid ? r[c] : 0.f;
-            bool pf = valid && (s >= thr);
-            if (has_bound) pf = pf && (s < bs || (s == bs && c > bi));
-            unsigned long long mask = __ballot(pf);
-            while (mask) {
-                int src = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                float cs = readlane_f(s, src);
-                if (!(cs >= thr)) continue;
-                wave_insert_i32(ls, li, lane, kp, cs, base + src);
-                thr = readlane_f(ls, kp - 1);
-            }
+
+    // ---- fast path (K <= 256): the K-th largest of the 256 per-thread maxima
+    // is a lower bound of the K-th largest element, so everything below it is
+    // dropped with one compare; the few survivors are ranked by counting.
+    bool done = false;
+    if (K <= 256) {
+        unsigned lmax = 0;
+#pragma unroll 8
+        for (int c = tid; c < n; c += 256) {
+            const float v = r[c];
+            const unsigned key = (v == v) ? f2o(v) : 0u;
+            lmax = max(lmax, key);
         }
-        m_s[tid] = ls;
-        m_i[tid] = li;
-        if (tid < 64) {
-            o_s[tid] = MI_NEG_INF;
-            o_i[tid] = INT_MAX;
-        }
+        gkey[tid] = lmax;
+        o_s[tid] = MI_NEG_INF;
+        o_i[tid] = INT_MAX;
+        if (tid == 0) c_cnt = 0;
         __syncthreads();
-        if (lane < kp && li != INT_MAX) {
-            int rank = 0;
-            for (int ww = 0; ww < 4; ++ww)
-                for (int j = 0; j < kp; ++j) {
-                    float js = m_s[ww * 64 + j];
-                    int ji = m_i[ww * 64 + j];
-                    rank += (js > ls) || (js == ls && ji < li);
+        const unsigned k0 = gkey[lane], k1 = gkey[lane + 64], k2 = gkey[lane + 128], k3 = gkey[lane + 192];
+        unsigned T0 = 0;
+#pragma unroll 4
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned t = T0 | (1u << bit);
+            const int c = __popcll(__ballot(k0 >= t)) + __popcll(__ballot(k1 >= t)) +
+                          __popcll(__ballot(k2 >= t)) + __popcll(__ballot(k3 >= t));
+            if (c >= K) T0 = t;
+        }
+        // survivors: key >= T0 (NaN has key 0 and never survives)
+        for (int base = 0; base < n; base += 256) {
+            const int c = base + tid;
+            float v = 0.f;
+            unsigned key = 0;
+            if (c < n) {
+                v = r[c];
+                key = (v == v) ? f2o(v) : 0u;
+            }
+            const bool pf = key != 0u && key >= T0;
+            const unsigned long long mask = __ballot(pf);
+            if (mask) {
+                int o = 0;
+                if (lane == 0) o = atomicAdd(&c_cnt, __popcll(mask));
+                o = uniform_i(o) + lane_prefix_count(mask);
+                if (pf && o < SEL_CAP) {
+                    c_s[o] = v;
+                    c_i[o] = c;
                 }
-            if (rank < kp) {
-                o_s[rank] = ls;
-                o_i[rank] = li;
             }
         }
         __syncthreads();
-        if (tid < kp) {
-            int oi = o_i[tid];
-            float os = o_s[tid];
-            size_t o = (size_t)row * K + p0 + tid;
-            if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi;
-            if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi;
-            if (out_s) out_s[o] = oi == INT_MAX ? -FLT_MAX : os;
+        const int Sn = c_cnt;
+        if (Sn <= SEL_CAP) {
+            for (int e = tid; e < Sn; e += 256) c_rank[e] = 0;
+            __syncthreads();
+            if (Sn > 0) {
+                const int P = max(1, 256 / Sn);  // thread groups sharing the j range (Sn < 256)
+                for (int e0 = 0; e0 < Sn; e0 += 256) {
+                    const int part = (Sn < 256) ? tid / Sn : 0;
+                    const int e = (Sn < 256) ? tid - part * Sn : e0 + tid;
+                    if (part < P && e < Sn) {
+                        const float es = c_s[e];
+                        const int ei = c_i[e];
+                        const int j0 = (Sn * part) / P, j1 = (Sn * (part + 1)) / P;
+                        int rk = 0;
+#pragma unroll 8
+                        for (int j = j0; j < j1; ++j) {
+                            const float js = c_s[j];
+                            const int ji = c_i[j];
+                            rk += (js > es) || (js == es && ji < ei);
+                        }
+                        if (rk) atomicAdd(&c_rank[e], rk);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < Sn; e += 256) {
+                const int rk = c_rank[e];
+                if (rk < K) {
+                    o_s[rk] = c_s[e];
+                    o_i[rk] = c_i[e];
+                }
+            }
+            __syncthreads();
+            if (tid < K) {
+                const int oi = o_i[tid];
+                const float os = o_s[tid];
+                const size_t o = (size_t)row * K + tid;
+                if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi;
+                if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi;
+                if (out_s) out_s[o] = oi == INT_MAX ? -FLT_MAX : os;
+            }
+            __syncthreads();
+            done = true;
         }
-        has_bound = true;
-        bs = o_s[kp - 1];
-        bi = o_i[kp - 1];
-        __syncthreads();
+    }
+
+    // ---- general path (K > 256, or a pathological row with > SEL_CAP ties):
+    // per-wave sorted lists with serial insertion, 64 results per pass.
+    if (!done) {
+        float *m_s = c_s;
+        int *m_i = c_i;
+        bool has_bound = false;
+        float bs = 0.f;
+        int bi = 0;
+        for (int p0 = 0; p0 < K; p0 += 64) {
+            const int kp = min(64, K - p0);
+            float ls = MI_NEG_INF, thr = MI_NEG_INF;
+            int li = INT_MAX;
+            for (int base = w * 64; base < n; base += 256) {
+                int c = base + lane;
+                bool valid = c < n;
+                float s = valid ? r[c] : 0.f;
+                bool pf = valid && (s >= thr);
+                if (has_bound) pf = pf && (s < bs || (s == bs && c > bi));
+                unsigned long long mask = __ballot(pf);
+                while (mask) {
+                    int src = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    float cs = readlane_f(s, src);
+                    if (!(cs >= thr)) continue;
+                    wave_insert_i32(ls, li, lane, kp, cs, base + src);
+                    thr = readlane_f(ls, kp - 1);
+                }
+            }
+            m_s[tid] = ls;
+            m_i[tid] = li;
+            if (tid < 64) {
+                o_s[tid] = MI_NEG_INF;
+                o_i[tid] = INT_MAX;
+            }
+            __syncthreads();
+            if (lane < kp && li != INT_MAX) {
+                int rank = 0;
+                for (int ww = 0; ww < 4; ++ww)
+#pragma unroll 8
+                    for (int j = 0; j < kp; ++j) {
+                        float js = m_s[ww * 64 + j];
+                        int ji = m_i[ww * 64 + j];
+                        rank += (js > ls) || (js == ls && ji < li);
+                    }
+                if (rank < kp) {
+                    o_s[rank] = ls;
+                    o_i[rank] = li;
+                }
+            }
+            __syncthreads();
+            if (tid < kp) {
+                int oi = o_i[tid];
+                float os = o_s[tid];
+                size_t o = (size_t)row * K + p0 + tid;
+                if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi;
+                if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi;
+                if (out_s) out_s[o] = oi == INT_MAX ? -FLT_MAX : os;
+            }
+            has_bound = true;
+            bs = o_s[kp - 1];
+            bi = o_i[kp - 1];
+            __syncthreads();
+        }
     }
     if (pt.list_goff) {  // probe tables (out_i32 is non-null on this path; written by this block)
         const int per = (K + 255) / 256;
@@ -362,6 +474,24 @@ __global__ void __launch_bounds__(256)
 
 // ---------------------------------------------------------------------
 // PQ-code scan + per-slice top-k.
+//
+// One 512-thread workgroup per (query, slice).  The slice's work items are
+// the 64-code groups of the query's probed lists (concatenated, dealt
+// round-robin to the 8 waves); lane j of a wave owns code j of the group:
+// NCH coalesced 16-byte loads (+ one 8-byte id load), then M look-ups
+// LUT[m][code[m]] from LDS added in ascending m (the oracle's order).
+//
+// Selection is threshold-filtered and latency-free on the common path:
+//   - a score below the running threshold is dropped by one compare + ballot;
+//   - survivors are appended to a 128-entry per-wave LDS buffer;
+//   - when the buffer passes 64 entries it is compressed to the wave's exact
+//     top-k by a 32-step bitwise descent on order-preserving keys (ballot +
+//     popcount only: no shuffles, no serial insertion), which also tightens
+//     the threshold; the threshold is shared across the workgroup's waves
+//     through one LDS word (atomicMax);
+//   - exact score ties at the cut are resolved by ascending id.
+// At the end the waves' survivors (<= 8k) are ranked by parallel counting
+// and written as the slice's sorted partial top-k.
 // ---------------------------------------------------------------------
 struct ScanArgs {
     const float *lut;          // [nq][M*256]
@@ -377,18 +507,87 @@ struct ScanArgs {
     const int64_t *bound_id;   //      (bound_s, bound_id) are eligible
     int nq, nprobe, nslice, k, by_residual;
     int debug;  // ablation switches for tools/scan_ablate.py (0 in production)
+    // fused final merge (the last slice of a query to finish merges all of the
+    // query's partial lists; counters must be zero on entry and are left zero)
+    unsigned *counters;        // [nq] or null = separate merge kernel
+    float *D;                  // [nq][ldo]
+    int64_t *I;                // [nq][ldo]
+    float *next_bound_s;       // [nq] or null: last kept entry (next extraction pass)
+    int64_t *next_bound_id;
+    int64_t ldo;
+    int out_off;
 };
 
-// LDS carve: [ LUT M*1024 B | prefix | p_goff | p_len | p_dis | wg_thr ]
-// (the LUT region is reused for the end-of-scan merge, so it is at least
-// 16 KiB).
+// LDS bytes the fused final merge needs inside the LUT region
+__host__ __device__ inline size_t scan_fused_merge_bytes(int nslice, int k) {
+    return (size_t)nslice * k * 16 + 1024;
+}
+
+constexpr int SCAN_NW = 8;        // waves per workgroup
+constexpr int SCAN_WBUF = 128;    // candidate slots per wave
+
+// LDS carve: [ LUT M KiB (>= 10 KiB, reused by the final merge) | wave buffers
+//              8 x 128 x (8+4) B | prefix | p_goff | p_len | p_dis | misc 16 B ]
 __host__ __device__ inline size_t scan_lut_bytes(int M) {
     size_t b = (size_t)M * 1024;
-    return b < 16384 ? 16384 : b;
+    return b < 10240 ? 10240 : b;
 }
 __host__ __device__ inline int scan_tab_stride(int nprobe) { return (nprobe + 1 + 3) & ~3; }
 __host__ __device__ inline size_t scan_smem_bytes(int M, int nprobe) {
-    return scan_lut_bytes(M) + (size_t)scan_tab_stride(nprobe) * 4 * 4 + 16;
+    return scan_lut_bytes(M) + (size_t)SCAN_NW * SCAN_WBUF * 12 + (size_t)scan_tab_stride(nprobe) * 4 * 4 + 16;
+}
+
+// k-th largest of up to 128 order-preserving keys held two per lane (0 = empty)
+__device__ __forceinline__ unsigned wave_kth_largest(unsigned ka, unsigned kb, int k) {
+    unsigned prefix = 0;
+#pragma unroll 4
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned t = prefix | (1u << bit);
+        const int c = __popcll(__ballot(ka >= t)) + __popcll(__ballot(kb >= t));
+        if (c >= k) prefix = t;
+    }
+    return prefix;
+}
+
+// Reduce a wave's candidate buffer (cnt <= 128 entries) to its exact top-k
+// under (score desc, id asc); returns the new count and the k-th score.
+__device__ __forceinline__ void wave_compress(float *buf_s, int64_t *buf_id, int lane, int k, int &cnt,
+                                              float &thr) {
+    const bool va = lane < cnt, vb = lane + 64 < cnt;
+    const float sa = va ? buf_s[lane] : 0.f, sb = vb ? buf_s[lane + 64] : 0.f;
+    const int64_t ia = va ? buf_id[lane] : 0, ib = vb ? buf_id[lane + 64] : 0;
+    const unsigned ka = va ? f2o(sa) : 0u, kb = vb ? f2o(sb) : 0u;
+    const unsigned T = wave_kth_largest(ka, kb, k);
+    const bool ga = ka > T, gb = kb > T;
+    const bool ea = (ka == T) && (T != 0u), eb = (kb == T) && (T != 0u);
+    const int need = k - (__popcll(__ballot(ga)) + __popcll(__ballot(gb)));
+    const int ties = __popcll(__ballot(ea)) + __popcll(__ballot(eb));
+    bool keep_a = ga || ea, keep_b = gb || eb;
+    if (ties > need) {  // rare: keep the `need` smallest ids among the tied entries
+        const unsigned long long ua = (unsigned long long)ia ^ (1ull << 63), ub = (unsigned long long)ib ^ (1ull << 63);
+        unsigned long long pref = 0;
+        for (int bit = 63; bit >= 0; --bit) {
+            const unsigned long long t = pref | (1ull << bit);
+            const int c = __popcll(__ballot(ea && ua < t)) + __popcll(__ballot(eb && ub < t));
+            if (c < need) pref = t;
+        }
+        keep_a = ga || (ea && ua <= pref);
+        keep_b = gb || (eb && ub <= pref);
+    }
+    const unsigned long long ma = __ballot(keep_a), mb = __ballot(keep_b);
+    const int na = __popcll(ma);
+    if (keep_a) {
+        const int pa = lane_prefix_count(ma);
+        buf_s[pa] = sa;
+        buf_id[pa] = ia;
+    }
+    if (keep_b) {
+        const int pb = na + lane_prefix_count(mb);
+        buf_s[pb] = sb;
+        buf_id[pb] = ib;
+    }
+    cnt = na + __popcll(mb);
+    thr = (cnt >= k && T != 0u) ? o2f(T) : MI_NEG_INF;
 }
 
 template <int M>
@@ -396,27 +595,32 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
     constexpr int NCH = (M + 15) / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *lut_s = reinterpret_cast<float *>(smem);
+    unsigned char *wb = smem + scan_lut_bytes(M);
     const int TS = scan_tab_stride(a.nprobe);
-    int *prefix = reinterpret_cast<int *>(smem + scan_lut_bytes(M));
+    int *prefix = reinterpret_cast<int *>(wb + (size_t)SCAN_NW * SCAN_WBUF * 12);
     int *p_goff = prefix + TS;
     int *p_len = p_goff + TS;
     float *p_dis = reinterpret_cast<float *>(p_len + TS);
     unsigned *wg_thr = reinterpret_cast<unsigned *>(p_dis + TS);
+    int *c_total = reinterpret_cast<int *>(wg_thr + 1);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = uniform_i(tid >> 6);
-    const int nw = blockDim.x >> 6;
     const int q = blockIdx.x / a.nslice, slice = blockIdx.x % a.nslice;
     const int nprobe = a.nprobe, k = a.k;
+    int64_t *buf_id = reinterpret_cast<int64_t *>(wb) + w * SCAN_WBUF;                          // [8][128]
+    float *buf_s = reinterpret_cast<float *>(wb + (size_t)SCAN_NW * SCAN_WBUF * 8) + w * SCAN_WBUF;  // [8][128]
 
-    // ---- stage the query's LUT (M KiB) and the probe tables
-    {
-        const float4 *lg = reinterpret_cast<const float4 *>(a.lut + (size_t)q * M * 256);
-        float4 *ls4 = reinterpret_cast<float4 *>(lut_s);
-        if (!(a.debug & 8))
-            for (int i = tid; i < M * 64; i += blockDim.x) ls4[i] = lg[i];
+    // ---- stage the query's LUT: row m (1 KiB) by one global_load_lds_dwordx4
+    // per wave (LDS-DMA: wave-uniform LDS base + lane*16, no VGPR round trip)
+    if (!(a.debug & 8)) {
+        const float *lg = a.lut + (size_t)q * M * 256 + lane * 4;
+        for (int m = w; m < M; m += SCAN_NW)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(lg + m * 256),
+                (__attribute__((address_space(3))) void *)(lut_s + m * 256), 16, 0, 0);
     }
-    for (int p = tid; p < nprobe; p += blockDim.x) {
+    for (int p = tid; p < nprobe; p += 512) {
         const size_t o = (size_t)q * nprobe + p;
         prefix[p] = a.p_prefix[(size_t)q * (nprobe + 1) + p];
         p_goff[p] = a.p_goff[o];
@@ -426,8 +630,9 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
     if (tid == 0) {
         prefix[nprobe] = a.p_prefix[(size_t)q * (nprobe + 1) + nprobe];
         *wg_thr = f2o(MI_NEG_INF);
+        *c_total = 0;
     }
-    __syncthreads();
+    __syncthreads();  // LUT (DMA drained by the barrier's vmcnt(0)) and tables visible
 
     const int G = prefix[nprobe];
     const int beg = (int)(((int64_t)G * slice) / a.nslice);
@@ -441,11 +646,10 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         bid = a.bound_id[q];
     }
 
-    float ls = MI_NEG_INF, thr = MI_NEG_INF;
-    unsigned lp = EMPTY_POS;
+    int cnt = 0;
+    float thr = MI_NEG_INF;
 
-    // work items = 64-code groups [beg, end) of the concatenated probed lists,
-    // dealt round-robin to the waves
+    // work items = 64-code groups [beg, end), dealt round-robin to the waves
     int t = beg + w;
     int p = 0;
     if (t < end) {  // smallest p with prefix[p+1] > t
@@ -458,28 +662,31 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         p = lo;
     }
     uint4 cur[NCH];
-    int c_gg = 0, c_nvalid = 0;
+    int64_t c_id = 0;
+    int c_nvalid = 0;
     float c_dis0 = 0.f;
-    auto locate_and_load = [&](int tt, uint4(&buf)[NCH], int &gg, int &nvalid, float &dis0) {
+    auto locate_and_load = [&](int tt, uint4(&buf)[NCH], int64_t &id, int &nvalid, float &dis0) {
         while (uniform_i(prefix[p + 1]) <= tt) ++p;
-        int gi = tt - uniform_i(prefix[p]);
-        gg = uniform_i(p_goff[p]) + gi;
+        const int gi = tt - uniform_i(prefix[p]);
+        const int gg = uniform_i(p_goff[p]) + gi;
         nvalid = min(64, uniform_i(p_len[p]) - gi * 64);
         dis0 = uniform_f(p_dis[p]);
         const uint4 *gp = reinterpret_cast<const uint4 *>(a.codes + (size_t)gg * (NCH * 1024)) + lane;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) buf[ch] = gp[ch * 64];
+        id = a.ids[(size_t)gg * 64 + lane];
     };
-    if (t < end) locate_and_load(t, cur, c_gg, c_nvalid, c_dis0);
+    if (t < end) locate_and_load(t, cur, c_id, c_nvalid, c_dis0);
 
     while (t < end) {
-        const int tn = t + nw;
+        const int tn = t + SCAN_NW;
         uint4 nxt[NCH];
-        int n_gg = 0, n_nvalid = 0;
+        int64_t n_id = 0;
+        int n_nvalid = 0;
         float n_dis0 = 0.f;
-        if (tn < end) locate_and_load(tn, nxt, n_gg, n_nvalid, n_dis0);
+        if (tn < end) locate_and_load(tn, nxt, n_id, n_nvalid, n_dis0);
 
-        // 64 table look-ups, m ascending, f32 adds in that order (= the oracle)
+        // M table look-ups, m ascending, f32 adds in that order (= the oracle)
         float acc = 0.f;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
@@ -489,107 +696,169 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
                 const int m = ch * 16 + j;
                 if (m < M) {
                     unsigned byte = (wd[j >> 2] >> ((j & 3) * 8)) & 0xffu;
-                    if (a.debug & 4) acc += __uint_as_float(byte);
-                    else acc += lut_s[m * 256 + byte];
+                    acc += lut_s[m * 256 + byte];
                 }
             }
         }
         const float s = c_dis0 + acc;
 
         const float wthr = o2f(*reinterpret_cast<volatile unsigned *>(wg_thr));
-        float thr_eff = fmaxf(thr, wthr);
+        const float thr_eff = fmaxf(thr, wthr);
         bool pf = (lane < c_nvalid) && (s >= thr_eff);
-        if (has_bound) pf = pf && (s <= bs);
+        if (has_bound) pf = pf && (s < bs || (s == bs && c_id > bid));
         unsigned long long mask = __ballot(pf);
-        if (a.debug & 1) mask &= 1ull;
+        if (a.debug & 1) mask = 0;
         if (mask) {
-            bool changed = false;
-            while (mask) {
-                const int src = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const float cs = readlane_f(s, src);
-                if (!(cs >= thr_eff)) continue;
-                const unsigned cp = (unsigned)c_gg * 64u + (unsigned)src;
-                if (has_bound && cs == bs) {
-                    if (a.ids[cp] <= bid) continue;
-                }
-                const bool gt = ls > cs;
-                const bool eq = (ls == cs) && (lp != EMPTY_POS);
-                bool before = gt;
-                if (__ballot(eq)) {  // exact score tie: order by id (rare)
-                    int64_t cid = a.ids[cp];
-                    int64_t mine = eq ? a.ids[lp] : 0;
-                    before = gt || (eq && mine < cid);
-                }
-                const int r = __popcll(__ballot(before));
-                if (r >= k) continue;
-                float us = wave_shr1_f(ls);
-                unsigned up = (unsigned)wave_shr1_i((int)lp);
-                if (lane > r) {
-                    ls = us;
-                    lp = up;
-                } else if (lane == r) {
-                    ls = cs;
-                    lp = cp;
-                }
-                thr = readlane_f(ls, k - 1);
-                thr_eff = fmaxf(thr, wthr);
-                changed = true;
+            if (pf) {
+                const int o = cnt + lane_prefix_count(mask);
+                buf_s[o] = s;
+                buf_id[o] = c_id;
             }
-            if (changed && thr > wthr && lane == 0) atomicMax(wg_thr, f2o(thr));
+            cnt += __popcll(mask);
+            if (cnt > 64) {
+                wave_compress(buf_s, buf_id, lane, k, cnt, thr);
+                if (thr > wthr && lane == 0) atomicMax(wg_thr, f2o(thr));
+            }
         }
 
         t = tn;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) cur[ch] = nxt[ch];
-        c_gg = n_gg;
+        c_id = n_id;
         c_nvalid = n_nvalid;
         c_dis0 = n_dis0;
     }
+    if (cnt > k) wave_compress(buf_s, buf_id, lane, k, cnt, thr);
 
-    // ---- merge the waves' lists by rank counting (LUT region reused)
-    __syncthreads();
-    float *m_s = lut_s;                                         // [nw][64]
-    unsigned *m_p = reinterpret_cast<unsigned *>(lut_s) + 1024; // [nw][64], nw <= 16
-    float *o_s = lut_s + 2048;                                  // [64]
-    unsigned *o_p = reinterpret_cast<unsigned *>(lut_s) + 2048 + 64;
-    m_s[tid] = ls;
-    m_p[tid] = lp;
+    // ---- gather the waves' survivors (<= 8k) and rank them by counting
+    __syncthreads();  // every wave is done with the LUT: its LDS is reused below
+    int64_t *g_id = reinterpret_cast<int64_t *>(lut_s);          // [512]
+    float *g_s = lut_s + 1024;                                   // [512]
+    int *g_rank = reinterpret_cast<int *>(lut_s) + 1536;         // [512]
+    int64_t *o_id = reinterpret_cast<int64_t *>(lut_s + 2048);   // [64]
+    float *o_s = lut_s + 2048 + 128;                             // [64]
+    int woff = 0;
+    if (lane == 0 && cnt > 0) woff = atomicAdd(c_total, cnt);
+    woff = uniform_i(woff);
+    if (lane < cnt) {
+        g_s[woff + lane] = buf_s[lane];
+        g_id[woff + lane] = buf_id[lane];
+    }
+    g_rank[tid] = 0;
     if (tid < 64) {
         o_s[tid] = MI_NEG_INF;
-        o_p[tid] = EMPTY_POS;
+        o_id[tid] = EMPTY_ID;
     }
     __syncthreads();
-    if (lane < k && lp != EMPTY_POS && !(a.debug & 2)) {
-        int rank = 0;
-        int64_t myid = 0;
-        bool have_id = false;
-        for (int ww = 0; ww < nw; ++ww)
-            for (int j = 0; j < k; ++j) {
-                float js = m_s[ww * 64 + j];
-                unsigned jp = m_p[ww * 64 + j];
-                if (js > ls) {
-                    ++rank;
-                } else if (js == ls && jp != EMPTY_POS && jp != lp) {
-                    if (!have_id) {
-                        myid = a.ids[lp];
-                        have_id = true;
-                    }
-                    int64_t jid = a.ids[jp];
-                    rank += (jid < myid) || (jid == myid && jp < lp);
-                }
+    const int C = *c_total;  // <= 8 * 64
+    if (C > 0 && !(a.debug & 2)) {
+        const int P = max(1, 512 / C);          // thread groups sharing the j range
+        const int part = tid / C, e = tid - part * C;
+        if (part < P) {
+            const float es = g_s[e];
+            const int64_t eid = g_id[e];
+            const int j0 = (C * part) / P, j1 = (C * (part + 1)) / P;
+            int r = 0;
+#pragma unroll 4
+            for (int j = j0; j < j1; ++j) {
+                const float js = g_s[j];
+                const int64_t jid = g_id[j];
+                r += (js > es) || (js == es && (jid < eid || (jid == eid && j < e)));
             }
-        if (rank < k) {
-            o_s[rank] = ls;
-            o_p[rank] = lp;
+            if (r) atomicAdd(&g_rank[e], r);
+        }
+    }
+    __syncthreads();
+    if (tid < C) {
+        const int r = g_rank[tid];
+        if (r < k) {
+            o_s[r] = g_s[tid];
+            o_id[r] = g_id[tid];
         }
     }
     __syncthreads();
     if (tid < k) {
-        unsigned pp = o_p[tid];
-        size_t o = ((size_t)q * a.nslice + slice) * k + tid;
+        const size_t o = ((size_t)q * a.nslice + slice) * k + tid;
         a.part_s[o] = o_s[tid];
-        a.part_id[o] = pp == EMPTY_POS ? EMPTY_ID : a.ids[pp];
+        a.part_id[o] = o_id[tid];
+    }
+    if (!a.counters) return;
+
+    // ---- fused final merge: publish this slice's partial list (agent-scope
+    // release), take a ticket; the last arriver acquires and merges.  Correct
+    // for any placement of the slices on CUs / XCDs (guide section 6, G16).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket =
+            __hip_atomic_fetch_add(a.counters + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == (unsigned)(a.nslice - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(a.counters + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *c_total = last;
+    }
+    __syncthreads();
+    if (!*c_total) return;
+    const int n = a.nslice * k;                                   // <= 32 * 64
+    int64_t *e_id = reinterpret_cast<int64_t *>(lut_s);           // [n]
+    float *e_s = reinterpret_cast<float *>(e_id + n);             // [n]
+    int *e_rank = reinterpret_cast<int *>(e_s + n);               // [n]
+    int64_t *f_id = reinterpret_cast<int64_t *>(smem + (size_t)n * 16);  // [64]
+    float *f_s = reinterpret_cast<float *>(f_id + 64);            // [64]
+    for (int e = tid; e < n; e += 512) {
+        const size_t o = (size_t)q * n + e;
+        e_id[e] = a.part_id[o];
+        e_s[e] = a.part_s[o];
+        e_rank[e] = 0;
+    }
+    if (tid < 64) {
+        f_s[tid] = MI_NEG_INF;
+        f_id[tid] = EMPTY_ID;
+    }
+    __syncthreads();
+    {
+        const int P = n < 512 ? max(1, 512 / n) : 1;
+        for (int e0 = 0; e0 < n; e0 += 512) {
+            const int part = n < 512 ? tid / n : 0;
+            const int e = n < 512 ? tid - part * n : e0 + tid;
+            if (part < P && e < n) {
+                const int64_t eid = e_id[e];
+                if (eid != EMPTY_ID) {
+                    const float es = e_s[e];
+                    const int j0 = (n * part) / P, j1 = (n * (part + 1)) / P;
+                    int r = 0;
+#pragma unroll 4
+                    for (int j = j0; j < j1; ++j) {
+                        const float js = e_s[j];
+                        const int64_t jid = e_id[j];
+                        r += (js > es) || (js == es && (jid < eid || (jid == eid && j < e)));
+                    }
+                    if (r) atomicAdd(&e_rank[e], r);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += 512) {
+        const int r = e_rank[e];
+        if (e_id[e] != EMPTY_ID && r < k) {
+            f_s[r] = e_s[e];
+            f_id[r] = e_id[e];
+        }
+    }
+    __syncthreads();
+    if (tid < k) {
+        const int64_t id = f_id[tid];
+        a.D[(size_t)q * a.ldo + a.out_off + tid] = id == EMPTY_ID ? -FLT_MAX : f_s[tid];
+        a.I[(size_t)q * a.ldo + a.out_off + tid] = id == EMPTY_ID ? (int64_t)-1 : id;
+    }
+    if (a.next_bound_s && tid == 0) {
+        a.next_bound_s[q] = f_s[k - 1];
+        a.next_bound_id[q] = f_id[k - 1];
     }
 }
 
@@ -642,6 +911,7 @@ __global__ void __launch_bounds__(256)
             if (mi_ == EMPTY_ID) continue;
             const float ms = e_s[e];
             int rank = 0;
+#pragma unroll 8
             for (int j = 0; j < n; ++j) {
                 float js = e_s[j];
                 int64_t ji = e_id[j];

@@ -151,6 +151,38 @@ def test_large_k_multipass(faiss, oracle):
     assert cI.shape == (12, 8)
 
 
+def test_select_paths(faiss, oracle):
+    """flat search exercises select_kernel: threshold fast path (K <= 256), the
+    insertion path (K > 256) and the tie-overflow fallback (> 1024 equal scores)."""
+    rng = np.random.default_rng(77)
+    d = 32
+    base = rng.standard_normal((5000, d)).astype(np.float32)
+    q = rng.standard_normal((9, d)).astype(np.float32)
+    flat = faiss.IndexFlatIP(d)
+    flat.add(base)
+    for k in (1, 10, 64, 200, 256, 257, 300, 1000):
+        D, I = flat.search(q, k)
+        De, Ie = oracle.flat_ip(q, base, k)
+        assert np.array_equal(I, Ie), k
+        assert np.array_equal(bits(D), bits(De)), k
+    # 3000 identical vectors + a few distinct ones: every score ties
+    dup = np.repeat(base[:1], 3000, axis=0)
+    dup = np.concatenate([dup, base[1:40]])
+    flat2 = faiss.IndexFlatIP(d)
+    flat2.add(dup)
+    for k in (5, 100, 300):
+        D, I = flat2.search(q, k)
+        De, Ie = oracle.flat_ip(q, dup, k)
+        assert np.array_equal(I, Ie), k
+        assert np.array_equal(bits(D), bits(De)), k
+    # fewer rows than k, NaN-free tiny inputs
+    flat3 = faiss.IndexFlatIP(d)
+    flat3.add(base[:7])
+    D, I = flat3.search(q, 12)
+    De, Ie = oracle.flat_ip(q, base[:7], 12)
+    assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De))
+
+
 def test_edge_cases(faiss, oracle):
     cent, cb, x, q = random_problem(4, 64, 8, 16, 40, 6)
     idx = make_index(faiss, cent, cb)
