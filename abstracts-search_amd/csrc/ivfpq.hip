@@ -186,10 +186,11 @@ struct mi_index {
     DevBuf ws_pgoff, ws_plen, ws_pprefix, ws_counters;
     size_t counters_zeroed = 0;  // bytes of ws_counters known to be zero
     DevBuf ws_x, ws_assign, ws_codes, ws_ids, ws_count;
-    // scan-kernel timing
-    bool prof = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
-    int64_t last_scan_bytes = 0;
+    // most recent scan launch (mi_index_profile_scan replays it)
+    ScanArgs last_scan{};
+    bool have_last_scan = false;
+    int64_t last_nq = 0;
+    int last_nprobe = 0;
 
     // side stream: the LUT kernel is independent of coarse GEMM + select and
     // runs beside them (fork/join with events; capturable in a hipGraph)
@@ -201,10 +202,6 @@ struct mi_index {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (side) (void)hipStreamDestroy(side);
-        for (auto &e : evs) {
-            (void)hipEventDestroy(e.first);
-            (void)hipEventDestroy(e.second);
-        }
     }
 };
 
@@ -496,37 +493,35 @@ int mi_index_get_list(mi_index *h, int list_no, uint8_t *codes, int64_t *ids) {
     });
 }
 
-int mi_index_profile_enable(mi_index *h, int on) {
+int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_avg, int64_t *scan_bytes) {
     return guard([&] {
-        MI_REQUIRE(h, "null argument");
-        h->prof = on != 0;
-    });
-}
-
-int mi_index_profile_read(mi_index *h, double *scan_ms_avg, int64_t *launches, int64_t *last_bytes) {
-    return guard([&] {
-        MI_REQUIRE(h, "null argument");
+        MI_REQUIRE(h && reps >= 1, "bad argument");
+        MI_REQUIRE(h->have_last_scan, "mi_index_profile_scan: no search has run yet");
         DeviceGuard dg(h->device);
-        double tot = 0.0;
-        int64_t n = 0;
-        for (auto &e : h->evs) {
-            MI_HIP(hipEventSynchronize(e.second));
-            float ms = 0.f;
-            MI_HIP(hipEventElapsedTime(&ms, e.first, e.second));
-            tot += ms;
-            ++n;
-            (void)hipEventDestroy(e.first);
-            (void)hipEventDestroy(e.second);
-        }
-        h->evs.clear();
-        if (h->ws_count.p) {
-            unsigned long long c = 0;
-            MI_HIP(hipMemcpy(&c, h->ws_count.p, 8, hipMemcpyDeviceToHost));
-            h->last_scan_bytes = (int64_t)c * (h->M + 8);
-        }
-        if (scan_ms_avg) *scan_ms_avg = n ? tot / (double)n : 0.0;
-        if (launches) *launches = n;
-        if (last_bytes) *last_bytes = h->last_scan_bytes;
+        hipStream_t st = as_stream(stream);
+        // algorithmic bytes of the launch: sum of the probed list lengths x (M + 8)
+        unsigned long long *cnt = h->ws_count.as<unsigned long long>(1);
+        MI_HIP(hipMemsetAsync(cnt, 0, 8, st));
+        const int64_t n = h->last_nq * h->last_nprobe;
+        hipLaunchKernelGGL(count_codes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           h->ws_cidx.get<int32_t>(), n, h->d_len.get<int32_t>(), cnt);
+        MI_HIP(hipGetLastError());
+        hipEvent_t e0, e1;
+        MI_HIP(hipEventCreate(&e0));
+        MI_HIP(hipEventCreate(&e1));
+        launch_scan(h->M, h->last_scan, st);  // warm
+        MI_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch_scan(h->M, h->last_scan, st);
+        MI_HIP(hipEventRecord(e1, st));
+        MI_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        MI_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        unsigned long long c = 0;
+        MI_HIP(hipMemcpy(&c, cnt, 8, hipMemcpyDeviceToHost));
+        if (scan_ms_avg) *scan_ms_avg = (double)ms / reps;
+        if (scan_bytes) *scan_bytes = (int64_t)c * (h->M + 8);
     });
 }
 
@@ -589,14 +584,6 @@ static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int 
         bs = h->ws_bs.as<float>((size_t)nq);
         bid = h->ws_bid.as<int64_t>((size_t)nq);
     }
-    if (h->prof) {
-        unsigned long long *cnt = h->ws_count.as<unsigned long long>(1);
-        MI_HIP(hipMemsetAsync(cnt, 0, 8, st));
-        int64_t n = nq * nprobe;
-        hipLaunchKernelGGL(count_codes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           cidx, n, h->d_len.get<int32_t>(), cnt);
-        MI_HIP(hipGetLastError());
-    }
     for (int pass = 0; pass < npass; ++pass) {
         const int kp = std::min(64, k - pass * 64);
         ScanArgs a;
@@ -608,12 +595,6 @@ static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int 
         a.nq = (int)nq; a.nprobe = nprobe; a.nslice = nslice; a.k = kp; a.by_residual = h->by_residual;
         a.debug = 0;
         if (const char *e = std::getenv("MI_SCAN_DEBUG")) a.debug = std::atoi(e);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->prof) {
-            MI_HIP(hipEventCreate(&e0));
-            MI_HIP(hipEventCreate(&e1));
-            MI_HIP(hipEventRecord(e0, st));
-        }
         // the last slice of each query merges the partial lists in-kernel when
         // they fit in the LUT's LDS region; otherwise a separate merge kernel
         const bool fuse = scan_fused_merge_bytes(nslice, kp) <= scan_lut_bytes(M) &&
@@ -631,9 +612,11 @@ static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int 
             a.counters = cnt;
         }
         launch_scan(M, a, st);
-        if (h->prof) {
-            MI_HIP(hipEventRecord(e1, st));
-            h->evs.emplace_back(e0, e1);
+        if (pass == 0) {
+            h->last_scan = a;
+            h->have_last_scan = true;
+            h->last_nq = nq;
+            h->last_nprobe = nprobe;
         }
         if (!fuse)
             launch_merge(ps, pid, nslice, kp, (int64_t)nslice * kp, nq, kp, Ddev, Idev, k, pass * 64,

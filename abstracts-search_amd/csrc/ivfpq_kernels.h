@@ -242,7 +242,8 @@ __global__ void __launch_bounds__(256)
     __shared__ float c_s[SEL_CAP];   // survivors (fast path) / wave lists (fallback: first 256)
     __shared__ int c_i[SEL_CAP];
     __shared__ int c_rank[SEL_CAP];
-    __shared__ unsigned gkey[256];
+    __shared__ unsigned gkey4[1024];
+    unsigned *gkey = gkey4;
     __shared__ float o_s[256];
     __shared__ int o_i[256];
     __shared__ int wtot[4];
@@ -257,26 +258,51 @@ __global__ void __launch_bounds__(256)
     // dropped with one compare; the few survivors are ranked by counting.
     bool done = false;
     if (K <= 256) {
-        unsigned lmax = 0;
-#pragma unroll 8
-        for (int c = tid; c < n; c += 256) {
-            const float v = r[c];
-            const unsigned key = (v == v) ? f2o(v) : 0u;
-            lmax = max(lmax, key);
+        // thread t owns 4 interleaved groups: elements c with c%256 == t, (c/256)%4 == g.
+        // K <= 64 uses the 256 per-thread maxima, larger K the 1024 group maxima
+        // (the bound is only tight when there are several times more groups than K).
+        unsigned gm[4] = {0u, 0u, 0u, 0u};
+        for (int c0 = tid; c0 < n; c0 += 1024) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = c0 + g * 256;
+                if (c < n) {
+                    const float v = r[c];
+                    const unsigned key = (v == v) ? f2o(v) : 0u;
+                    gm[g] = max(gm[g], key);
+                }
+            }
         }
-        gkey[tid] = lmax;
         o_s[tid] = MI_NEG_INF;
         o_i[tid] = INT_MAX;
         if (tid == 0) c_cnt = 0;
-        __syncthreads();
-        const unsigned k0 = gkey[lane], k1 = gkey[lane + 64], k2 = gkey[lane + 128], k3 = gkey[lane + 192];
         unsigned T0 = 0;
+        if (K <= 64) {
+            gkey[tid] = max(max(gm[0], gm[1]), max(gm[2], gm[3]));
+            __syncthreads();
+            const unsigned k0 = gkey[lane], k1 = gkey[lane + 64], k2 = gkey[lane + 128], k3 = gkey[lane + 192];
 #pragma unroll 4
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned t = T0 | (1u << bit);
-            const int c = __popcll(__ballot(k0 >= t)) + __popcll(__ballot(k1 >= t)) +
-                          __popcll(__ballot(k2 >= t)) + __popcll(__ballot(k3 >= t));
-            if (c >= K) T0 = t;
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned t = T0 | (1u << bit);
+                const int c = __popcll(__ballot(k0 >= t)) + __popcll(__ballot(k1 >= t)) +
+                              __popcll(__ballot(k2 >= t)) + __popcll(__ballot(k3 >= t));
+                if (c >= K) T0 = t;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gkey4[g * 256 + tid] = gm[g];
+            __syncthreads();
+            unsigned kk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kk[i] = gkey4[i * 64 + lane];
+#pragma unroll 2
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned t = T0 | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) c += __popcll(__ballot(kk[i] >= t));
+                if (c >= K) T0 = t;
+            }
         }
         // survivors: key >= T0 (NaN has key 0 and never survives)
         for (int base = 0; base < n; base += 256) {

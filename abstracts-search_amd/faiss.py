@@ -60,8 +60,7 @@ class _Lib:
                 "mi_index_get_list": [v, c_int, v, v],
                 "mi_index_search": [v, c_int64, v, c_int, c_int, v, v, v],
                 "mi_index_coarse_lut": [v, c_int64, v, c_int, v, v, v],
-                "mi_index_profile_enable": [v, c_int],
-                "mi_index_profile_read": [v, POINTER(c_double), POINTER(c_int64), POINTER(c_int64)],
+                "mi_index_profile_scan": [v, c_int, v, POINTER(c_double), POINTER(c_int64)],
                 "mi_merge_topk": [c_int, c_int, c_int64, c_int, v, v, v, v, v],
                 "mi_flat_create": [c_int, c_int, POINTER(v)],
                 "mi_flat_destroy": [v],
@@ -394,13 +393,13 @@ class IndexIVFPQ:
         return cI, cD, lut
 
     # -- scan-kernel timing (HIP events on the launch stream) ------------
-    def profile(self, on: bool = True):
-        _check(_Lib.get().mi_index_profile_enable(self._h, int(on)))
-
-    def profile_read(self):
-        ms, n, b = c_double(0), c_int64(0), c_int64(0)
-        _check(_Lib.get().mi_index_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)))
-        return {"scan_ms_avg": ms.value, "launches": n.value, "last_scan_bytes": b.value}
+    def profile_scan(self, reps: int = 50):
+        """Replays the scan kernel of the last search `reps` times between two
+        HIP events on the current stream -> {"scan_ms_avg", "scan_bytes"}."""
+        ms, b = c_double(0), c_int64(0)
+        _check(_Lib.get().mi_index_profile_scan(self._h, int(reps), _current_stream(),
+                                                ctypes.byref(ms), ctypes.byref(b)))
+        return {"scan_ms_avg": ms.value, "scan_bytes": b.value}
 
 
 def merge_topk(D_parts, I_parts, device: int = 0):

@@ -48,7 +48,8 @@ def main():
     ap.add_argument("--train-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
-    ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="replay the step from a captured hipGraph (measured slower than eager: off)")
     args = ap.parse_args()
 
     import numpy as np
@@ -147,21 +148,19 @@ def main():
     total_queries = args.steps * args.batch * world
     qps = total_queries / dt
 
-    # ---- roofline of the dominant kernel (PQ-code scan): HIP events recorded
-    # by the library on the launch stream, eager launches of the same step
-    index.profile(True)
-    for i in range(args.steps):
-        step(args.warmup + i)
+    # ---- roofline of the dominant kernel (PQ-code scan): the library re-launches
+    # the scan of the last step K times back to back between two HIP events
+    # recorded on the launch stream (per-launch events cost more than the kernel)
+    step(args.warmup)
     torch.cuda.synchronize()
-    prof = index.profile_read()
-    index.profile(False)
+    prof = index.profile_scan(args.steps)
     scan_ms = prof["scan_ms_avg"]
-    scan_bytes = prof["last_scan_bytes"]
+    scan_bytes = prof["scan_bytes"]
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     roofline = {"kernel": "scan_kernel<64>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
                 "bytes_per_launch": int(scan_bytes), "avg_launch_ms": round(scan_ms, 5),
-                "launches": int(prof["launches"])}
+                "launches": args.steps}
 
     out = None
     if rank == 0:

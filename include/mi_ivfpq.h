@@ -96,13 +96,13 @@ int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe,
 int mi_index_coarse_lut(mi_index *h, int64_t nq, const float *q, int nprobe,
                         int32_t *coarse_I_host, float *coarse_D_host, float *lut_host);
 
-/* Average device time (ms) of the PQ-code scan kernel over the launches since
- * the last call, measured with HIP events on the stream the kernel ran on;
- * also returns the number of launches and the algorithmic bytes
- * (codes scanned x (M + 8)) of the last launch.  Timing is off until enabled. */
-int mi_index_profile_enable(mi_index *h, int on);
-int mi_index_profile_read(mi_index *h, double *scan_ms_avg, int64_t *launches,
-                          int64_t *last_scan_bytes);
+/* Timing of the dominant kernel for the roofline: re-launches the PQ-code scan
+ * kernel of the most recent mi_index_search() call (same arguments, idempotent)
+ * `reps` times back to back on `stream`, bracketed by two HIP events recorded on
+ * that stream, and returns the average duration per launch in ms together with
+ * the algorithmic bytes of one launch (codes scanned x (M + 8)). */
+int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_avg,
+                          int64_t *scan_bytes);
 
 /* ---- exchange step ------------------------------------------------- */
 

@@ -18,14 +18,13 @@ def run(env):
     for k_, v in env.items(): os.environ[k_] = str(v)
     for b in range(8): idx.search_into(q[b], 10, D, I)
     torch.cuda.synchronize()
-    idx.profile(True)
     t0 = time.perf_counter()
     for b in range(64): idx.search_into(q[b % 8], 10, D, I)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 64
-    p = idx.profile_read(); idx.profile(False)
+    p = idx.profile_scan(20)
     for k_ in env: os.environ.pop(k_)
-    gbs = p["last_scan_bytes"] / (p["scan_ms_avg"] * 1e-3) / 1e9
+    gbs = p["scan_bytes"] / (p["scan_ms_avg"] * 1e-3) / 1e9
     print(f"{env!s:45s} scan {p['scan_ms_avg']*1e3:8.1f} us  {gbs:8.1f} GB/s   step {dt*1e6:8.1f} us", flush=True)
 
 for ns in (2, 4, 6, 8, 12):
