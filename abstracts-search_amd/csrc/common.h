@@ -56,6 +56,10 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) {
+        o.p = nullptr;
+        o.cap = 0;
+    }
     ~DevBuf() { release(); }
     void release() {
         if (p) (void)hipFree(p);

@@ -1,0 +1,485 @@
+// encoder.hip -- C ABI (include/mi_encoder.h) over the gfx950 kernels of
+// encoder_kernels.h.  Host orchestration only; no CPU fallback.
+#include "../../include/mi_encoder.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "encoder_kernels.h"
+
+using namespace mi;
+using namespace mienc;
+
+namespace {
+
+hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+struct LayerW {
+    DevBuf wqkv, bqkv, wo, wgu, wd, ln1, ln2;
+};
+
+void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
+    MI_REQUIRE(g.K % 64 == 0, "encoder GEMM: K must be a multiple of 64");
+    MI_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "encoder GEMM: leading dimensions must be multiples of 8");
+    g.tiles_m = (g.M + 127) / 128;
+    g.tiles_n = (g.N + 127) / 128;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int per = (ntiles + 7) / 8;
+    dim3 grid(8 * per), block(256);
+    switch (epi) {
+        case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_STORE>), grid, block, 0, st, g); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_RESID>), grid, block, 0, st, g); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_QKV>), grid, block, 0, st, g); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_SWIGLU>), grid, block, 0, st, g); break;
+        default: throw Error("bad epilogue");
+    }
+    MI_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+struct mi_encoder {
+    mi_encoder_cfg cfg{};
+    int device = 0;
+    int qk_cols = 0, v_cols = 0, q_cols = 0;
+    DevBuf embed, norm_w, dense_w, dense_b, rope_cos, rope_sin;
+    std::vector<LayerW> layers;
+    std::map<std::string, bool> loaded;
+    // workspaces
+    DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_ids, ws_pos, ws_meta, ws_out, ws_stage;
+    size_t vt_zeroed = 0;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    double prof_flops = 0.0;
+    ~mi_encoder() {
+        for (auto &e : evs) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+    }
+};
+
+namespace {
+
+void register_params(mi_encoder *h) {
+    auto &L = h->loaded;
+    L["embed_tokens.weight"] = false;
+    L["norm.weight"] = false;
+    for (int l = 0; l < h->cfg.n_layers; ++l) {
+        std::string p = "layers." + std::to_string(l) + ".";
+        for (const char *n : {"input_layernorm.weight", "post_attention_layernorm.weight",
+                              "self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight",
+                              "self_attn.k_proj.bias", "self_attn.v_proj.weight", "self_attn.v_proj.bias",
+                              "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
+                              "mlp.down_proj.weight"})
+            L[p + n] = false;
+    }
+    if (h->cfg.dense_out) {
+        L["dense.weight"] = false;
+        if (h->cfg.dense_bias) L["dense.bias"] = false;
+    }
+}
+
+// copy a tensor into its internal slot: bf16 (dst) or f32 (dst_f32), rows remapped
+void import_tensor(mi_encoder *h, const void *data, int dtype, int64_t rows, int64_t cols, int64_t blk,
+                   int64_t stride, int64_t off, bf16_t *dst, float *dst_f32) {
+    const size_t esz = dtype == MI_DTYPE_F32 ? 4 : 2;
+    const void *src = data;
+    if (!is_device_ptr(data)) {
+        void *stg = h->ws_stage.reserve((size_t)rows * cols * esz);
+        MI_HIP(hipMemcpy(stg, data, (size_t)rows * cols * esz, hipMemcpyHostToDevice));
+        src = stg;
+    }
+    const int64_t n = rows * cols;
+    hipLaunchKernelGGL(import_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, src, dtype,
+                       rows, cols, blk, stride, off, dst, dst_f32);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipDeviceSynchronize());
+}
+
+struct Batch {
+    int nseq = 0, T_real = 0, T_pad = 0, Lmax = 0, nwork = 0;
+    // device pointers into ws_meta
+    int32_t *seq_start = nullptr, *seq_len = nullptr, *work_seq = nullptr, *work_q0 = nullptr, *tok_map = nullptr;
+};
+
+// Build the padded-packed layout (every sequence starts at a multiple of 8
+// tokens, T_pad a multiple of 128) and upload ids / positions / work lists.
+Batch prepare_batch(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu, hipStream_t st) {
+    MI_REQUIRE(nseq > 0, "encode: nseq must be positive");
+    std::vector<int32_t> cu_h((size_t)nseq + 1);
+    if (is_device_ptr(cu)) MI_HIP(hipMemcpy(cu_h.data(), cu, cu_h.size() * 4, hipMemcpyDeviceToHost));
+    else std::memcpy(cu_h.data(), cu, cu_h.size() * 4);
+    MI_REQUIRE(cu_h[0] == 0, "encode: cu_seqlens[0] must be 0");
+    const int T_real = cu_h[nseq];
+    std::vector<int32_t> ids_h((size_t)T_real);
+    if (is_device_ptr(ids)) MI_HIP(hipMemcpy(ids_h.data(), ids, ids_h.size() * 4, hipMemcpyDeviceToHost));
+    else std::memcpy(ids_h.data(), ids, ids_h.size() * 4);
+    Batch b;
+    b.nseq = nseq;
+    b.T_real = T_real;
+    std::vector<int32_t> start(nseq), len(nseq), wseq, wq0, tok_map((size_t)T_real);
+    int cur = 0;
+    for (int i = 0; i < nseq; ++i) {
+        const int L = cu_h[i + 1] - cu_h[i];
+        MI_REQUIRE(L >= 1, "encode: empty sequence");
+        MI_REQUIRE(L <= h->cfg.max_seq_len, "encode: sequence longer than max_seq_len");
+        start[i] = cur;
+        len[i] = L;
+        b.Lmax = std::max(b.Lmax, L);
+        for (int q0 = 0; q0 < L; q0 += 64) {
+            wseq.push_back(i);
+            wq0.push_back(q0);
+        }
+        cur += (L + 7) & ~7;
+    }
+    b.T_pad = (cur + 127) & ~127;
+    b.nwork = (int)wseq.size();
+    std::vector<int32_t> ids_pad((size_t)b.T_pad, 0), pos((size_t)b.T_pad, 0);
+    for (int i = 0; i < nseq; ++i)
+        for (int t = 0; t < len[i]; ++t) {
+            const int32_t id = ids_h[(size_t)cu_h[i] + t];
+            MI_REQUIRE(id >= 0 && id < h->cfg.vocab_size, "encode: token id out of range");
+            ids_pad[(size_t)start[i] + t] = id;
+            pos[(size_t)start[i] + t] = t;
+            tok_map[(size_t)cu_h[i] + t] = start[i] + t;
+        }
+    int32_t *d_ids = h->ws_ids.as<int32_t>((size_t)b.T_pad);
+    int32_t *d_pos = h->ws_pos.as<int32_t>((size_t)b.T_pad);
+    const size_t meta_n = (size_t)nseq * 2 + (size_t)b.nwork * 2 + (size_t)T_real;
+    int32_t *d_meta = h->ws_meta.as<int32_t>(meta_n);
+    std::vector<int32_t> meta;
+    meta.reserve(meta_n);
+    meta.insert(meta.end(), start.begin(), start.end());
+    meta.insert(meta.end(), len.begin(), len.end());
+    meta.insert(meta.end(), wseq.begin(), wseq.end());
+    meta.insert(meta.end(), wq0.begin(), wq0.end());
+    meta.insert(meta.end(), tok_map.begin(), tok_map.end());
+    MI_HIP(hipMemcpyAsync(d_ids, ids_pad.data(), ids_pad.size() * 4, hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st));
+    MI_HIP(hipStreamSynchronize(st));  // the host vectors die with this scope
+    b.seq_start = d_meta;
+    b.seq_len = d_meta + nseq;
+    b.work_seq = d_meta + 2 * (size_t)nseq;
+    b.work_q0 = b.work_seq + b.nwork;
+    b.tok_map = b.work_q0 + b.nwork;
+    return b;
+}
+
+void timed_gemm(mi_encoder *h, int epi, const GemmArgs &g, hipStream_t st) {
+    if (!h->prof) {
+        launch_gemm(epi, g, st);
+        return;
+    }
+    hipEvent_t e0, e1;
+    MI_HIP(hipEventCreate(&e0));
+    MI_HIP(hipEventCreate(&e1));
+    MI_HIP(hipEventRecord(e0, st));
+    launch_gemm(epi, g, st);
+    MI_HIP(hipEventRecord(e1, st));
+    h->evs.emplace_back(e0, e1);
+    h->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
+}
+
+// the decoder stack: leaves the residual stream (before the final norm) in ws_x
+void run_stack(mi_encoder *h, const Batch &b, hipStream_t st) {
+    const mi_encoder_cfg &c = h->cfg;
+    for (auto &kv : h->loaded) MI_REQUIRE(kv.second, std::string("encoder parameter not loaded: ") + kv.first);
+    const int H = c.hidden, I = c.intermediate, T = b.T_pad, hd = c.head_dim;
+    const int ldvt = T + 64;
+    float *x = h->ws_x.as<float>((size_t)T * H);
+    bf16_t *xn = h->ws_xn.as<bf16_t>((size_t)T * H);
+    bf16_t *qk = h->ws_qk.as<bf16_t>((size_t)T * h->qk_cols);
+    const size_t vt_bytes = (size_t)h->v_cols * ldvt * 2;
+    bf16_t *vt = static_cast<bf16_t *>(h->ws_vt.reserve(vt_bytes));
+    if (h->vt_zeroed != h->ws_vt.cap) {  // fresh allocation: the 64-token slack must hold finite values
+        MI_HIP(hipMemsetAsync(h->ws_vt.p, 0, h->ws_vt.cap, st));
+        h->vt_zeroed = h->ws_vt.cap;
+    }
+    bf16_t *att = h->ws_att.as<bf16_t>((size_t)T * h->q_cols);
+    bf16_t *hb = h->ws_h.as<bf16_t>((size_t)T * I);
+
+    hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, st, h->ws_ids.get<int32_t>(),
+                       h->embed.get<bf16_t>(), H, T, x);
+    MI_HIP(hipGetLastError());
+    for (int l = 0; l < c.n_layers; ++l) {
+        LayerW &w = h->layers[l];
+        hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln1.get<float>(), H, T,
+                           c.rms_eps, xn);
+        GemmArgs g{};
+        g.A = xn; g.lda = H; g.W = w.wqkv.get<bf16_t>(); g.ldw = H; g.M = T; g.N = h->qk_cols + h->v_cols; g.K = H;
+        g.bias = w.bqkv.get<float>(); g.C = qk; g.ldc = h->qk_cols; g.Vt = vt; g.ldvt = ldvt; g.qk_cols = h->qk_cols;
+        timed_gemm(h, EPI_QKV, g, st);
+        {
+            const int nh_qk = c.n_heads + c.n_kv_heads;
+            const int64_t n = (int64_t)T * nh_qk * (hd / 16);
+            hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, qk, h->qk_cols,
+                               nh_qk, hd, h->ws_pos.get<int32_t>(), h->rope_cos.get<float>(),
+                               h->rope_sin.get<float>(), T);
+        }
+        AttnArgs a{};
+        a.QK = qk; a.Vt = vt; a.O = att; a.work_seq = b.work_seq; a.work_q0 = b.work_q0;
+        a.seq_start = b.seq_start; a.seq_len = b.seq_len; a.ldqk = h->qk_cols; a.ldvt = ldvt;
+        a.n_heads = c.n_heads; a.n_kv = c.n_kv_heads; a.causal = c.causal;
+        a.scale = 1.0f / std::sqrt((float)hd);
+        if (hd == 128) hipLaunchKernelGGL((attn_kernel<128>), dim3(b.nwork, c.n_heads), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_kernel<64>), dim3(b.nwork, c.n_heads), dim3(256), 0, st, a);
+        MI_HIP(hipGetLastError());
+        GemmArgs o{};
+        o.A = att; o.lda = h->q_cols; o.W = w.wo.get<bf16_t>(); o.ldw = h->q_cols; o.M = T; o.N = H; o.K = h->q_cols;
+        o.X = x; o.ldc = H;
+        timed_gemm(h, EPI_RESID, o, st);
+        hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln2.get<float>(), H, T,
+                           c.rms_eps, xn);
+        GemmArgs u{};
+        u.A = xn; u.lda = H; u.W = w.wgu.get<bf16_t>(); u.ldw = H; u.M = T; u.N = 2 * I; u.K = H; u.C = hb; u.ldc = I;
+        timed_gemm(h, EPI_SWIGLU, u, st);
+        GemmArgs d{};
+        d.A = hb; d.lda = I; d.W = w.wd.get<bf16_t>(); d.ldw = I; d.M = T; d.N = H; d.K = I; d.X = x; d.ldc = H;
+        timed_gemm(h, EPI_RESID, d, st);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mi_enc_last_error(void) { return last_error().c_str(); }
+
+int mi_encoder_create(const mi_encoder_cfg *cfg, int device, mi_encoder **out) {
+    return guard([&] {
+        MI_REQUIRE(cfg && out, "null argument");
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0) {
+            (void)hipGetLastError();
+            throw Error("no HIP device available: the MI355X encoder has no CPU fallback");
+        }
+        MI_REQUIRE(device >= 0 && device < ndev, "invalid device ordinal");
+        const mi_encoder_cfg &c = *cfg;
+        MI_REQUIRE(c.head_dim == 64 || c.head_dim == 128, "head_dim must be 64 or 128");
+        MI_REQUIRE(c.hidden > 0 && c.hidden % 64 == 0, "hidden must be a multiple of 64");
+        MI_REQUIRE(c.intermediate > 0 && c.intermediate % 64 == 0, "intermediate must be a multiple of 64");
+        MI_REQUIRE((c.n_heads * c.head_dim) % 64 == 0, "n_heads*head_dim must be a multiple of 64");
+        MI_REQUIRE(c.n_kv_heads > 0 && c.n_heads % c.n_kv_heads == 0, "n_heads must be a multiple of n_kv_heads");
+        MI_REQUIRE(c.n_layers > 0 && c.vocab_size > 0 && c.max_seq_len > 0, "bad config");
+        MI_REQUIRE(c.dense_out >= 0, "bad dense_out");
+        DeviceGuard dg(device);
+        auto h = std::make_unique<mi_encoder>();
+        h->cfg = c;
+        h->device = device;
+        h->q_cols = c.n_heads * c.head_dim;
+        h->qk_cols = (c.n_heads + c.n_kv_heads) * c.head_dim;
+        h->v_cols = c.n_kv_heads * c.head_dim;
+        const size_t H = c.hidden, I = c.intermediate;
+        h->embed.reserve((size_t)c.vocab_size * H * 2);
+        h->norm_w.reserve(H * 4);
+        if (c.dense_out) {
+            h->dense_w.reserve((size_t)c.dense_out * H * 2);
+            h->dense_b.reserve((size_t)c.dense_out * 4);
+            MI_HIP(hipMemset(h->dense_b.p, 0, (size_t)c.dense_out * 4));
+        }
+        h->layers.resize(c.n_layers);
+        for (auto &w : h->layers) {
+            w.wqkv.reserve((size_t)(h->qk_cols + h->v_cols) * H * 2);
+            w.bqkv.reserve((size_t)(h->qk_cols + h->v_cols) * 4);
+            w.wo.reserve(H * (size_t)h->q_cols * 2);
+            w.wgu.reserve(2 * I * H * 2);
+            w.wd.reserve(H * I * 2);
+            w.ln1.reserve(H * 4);
+            w.ln2.reserve(H * 4);
+        }
+        // rotary tables in float64 -> f32, exactly like the oracle
+        const int half = c.head_dim / 2;
+        std::vector<float> cs((size_t)c.max_seq_len * half), sn((size_t)c.max_seq_len * half);
+        for (int p = 0; p < c.max_seq_len; ++p)
+            for (int i = 0; i < half; ++i) {
+                const double inv = 1.0 / std::pow((double)c.rope_theta, (double)(2 * i) / (double)c.head_dim);
+                const double ang = (double)p * inv;
+                cs[(size_t)p * half + i] = (float)std::cos(ang);
+                sn[(size_t)p * half + i] = (float)std::sin(ang);
+            }
+        MI_HIP(hipMemcpy(h->rope_cos.reserve(cs.size() * 4), cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+        MI_HIP(hipMemcpy(h->rope_sin.reserve(sn.size() * 4), sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+        register_params(h.get());
+        *out = h.release();
+    });
+}
+
+int mi_encoder_destroy(mi_encoder *h) {
+    return guard([&] {
+        if (!h) return;
+        DeviceGuard dg(h->device);
+        delete h;
+    });
+}
+
+int mi_encoder_load_tensor(mi_encoder *h, const char *name_c, const void *data, int dtype, const int64_t *shape,
+                           int ndim) {
+    return guard([&] {
+        MI_REQUIRE(h && name_c && data && shape, "null argument");
+        MI_REQUIRE(dtype >= 0 && dtype <= 2, "bad dtype");
+        std::string name(name_c);
+        if (name.rfind("model.", 0) == 0) name = name.substr(6);
+        auto it = h->loaded.find(name);
+        MI_REQUIRE(it != h->loaded.end(), "unknown parameter name: " + name);
+        DeviceGuard dg(h->device);
+        const mi_encoder_cfg &c = h->cfg;
+        const int64_t H = c.hidden, I = c.intermediate, hd = c.head_dim;
+        const int64_t BIG = (int64_t)1 << 40;
+        auto expect = [&](int64_t r, int64_t cc) {
+            const bool ok = (ndim == 2 && shape[0] == r && shape[1] == cc) || (ndim == 1 && cc == 1 && shape[0] == r);
+            MI_REQUIRE(ok, "shape mismatch for " + name);
+        };
+        if (name == "embed_tokens.weight") {
+            expect(c.vocab_size, H);
+            import_tensor(h, data, dtype, c.vocab_size, H, BIG, 0, 0, h->embed.get<bf16_t>(), nullptr);
+        } else if (name == "norm.weight") {
+            expect(H, 1);
+            import_tensor(h, data, dtype, H, 1, BIG, 0, 0, nullptr, h->norm_w.get<float>());
+        } else if (name == "dense.weight") {
+            expect(c.dense_out, H);
+            import_tensor(h, data, dtype, c.dense_out, H, BIG, 0, 0, h->dense_w.get<bf16_t>(), nullptr);
+        } else if (name == "dense.bias") {
+            expect(c.dense_out, 1);
+            import_tensor(h, data, dtype, c.dense_out, 1, BIG, 0, 0, nullptr, h->dense_b.get<float>());
+        } else {
+            MI_REQUIRE(name.rfind("layers.", 0) == 0, "unknown parameter name: " + name);
+            const size_t dot = name.find('.', 7);
+            const int l = std::stoi(name.substr(7, dot - 7));
+            MI_REQUIRE(l >= 0 && l < c.n_layers, "layer index out of range");
+            const std::string sub = name.substr(dot + 1);
+            LayerW &w = h->layers[l];
+            const int64_t qc = c.n_heads * hd, kc = c.n_kv_heads * hd;
+            if (sub == "input_layernorm.weight") { expect(H, 1); import_tensor(h, data, dtype, H, 1, BIG, 0, 0, nullptr, w.ln1.get<float>()); }
+            else if (sub == "post_attention_layernorm.weight") { expect(H, 1); import_tensor(h, data, dtype, H, 1, BIG, 0, 0, nullptr, w.ln2.get<float>()); }
+            else if (sub == "self_attn.q_proj.weight") { expect(qc, H); import_tensor(h, data, dtype, qc, H, BIG, 0, 0, w.wqkv.get<bf16_t>(), nullptr); }
+            else if (sub == "self_attn.k_proj.weight") { expect(kc, H); import_tensor(h, data, dtype, kc, H, BIG, 0, qc, w.wqkv.get<bf16_t>(), nullptr); }
+            else if (sub == "self_attn.v_proj.weight") { expect(kc, H); import_tensor(h, data, dtype, kc, H, BIG, 0, qc + kc, w.wqkv.get<bf16_t>(), nullptr); }
+            else if (sub == "self_attn.q_proj.bias") { expect(qc, 1); import_tensor(h, data, dtype, qc, 1, BIG, 0, 0, nullptr, w.bqkv.get<float>()); }
+            else if (sub == "self_attn.k_proj.bias") { expect(kc, 1); import_tensor(h, data, dtype, kc, 1, BIG, 0, qc, nullptr, w.bqkv.get<float>()); }
+            else if (sub == "self_attn.v_proj.bias") { expect(kc, 1); import_tensor(h, data, dtype, kc, 1, BIG, 0, qc + kc, nullptr, w.bqkv.get<float>()); }
+            else if (sub == "self_attn.o_proj.weight") { expect(H, qc); import_tensor(h, data, dtype, H, qc, BIG, 0, 0, w.wo.get<bf16_t>(), nullptr); }
+            // gate / up rows interleaved in blocks of 16 so that one MFMA wave tile
+            // holds gate_j and up_j of the same j (SwiGLU fused in the GEMM epilogue)
+            else if (sub == "mlp.gate_proj.weight") { expect(I, H); import_tensor(h, data, dtype, I, H, 16, 32, 0, w.wgu.get<bf16_t>(), nullptr); }
+            else if (sub == "mlp.up_proj.weight") { expect(I, H); import_tensor(h, data, dtype, I, H, 16, 32, 16, w.wgu.get<bf16_t>(), nullptr); }
+            else if (sub == "mlp.down_proj.weight") { expect(H, I); import_tensor(h, data, dtype, H, I, BIG, 0, 0, w.wd.get<bf16_t>(), nullptr); }
+            else throw Error("unknown parameter name: " + name);
+        }
+        it->second = true;
+    });
+}
+
+int mi_encoder_missing(mi_encoder *h, int *count) {
+    return guard([&] {
+        MI_REQUIRE(h && count, "null argument");
+        int n = 0;
+        for (auto &kv : h->loaded) n += kv.second ? 0 : 1;
+        *count = n;
+    });
+}
+
+int mi_encoder_out_dim(mi_encoder *h, int *out) {
+    return guard([&] {
+        MI_REQUIRE(h && out, "null argument");
+        *out = h->cfg.dense_out ? h->cfg.dense_out : h->cfg.hidden;
+    });
+}
+
+int mi_encoder_encode(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu, int normalize, float *out,
+                      void *stream) {
+    return guard([&] {
+        MI_REQUIRE(h && ids && cu && out, "null argument");
+        DeviceGuard dg(h->device);
+        hipStream_t st = as_stream(stream);
+        Batch b = prepare_batch(h, nseq, ids, cu, st);
+        run_stack(h, b, st);
+        const mi_encoder_cfg &c = h->cfg;
+        const int od = c.dense_out ? c.dense_out : c.hidden;
+        const bool od_dev = is_device_ptr(out);
+        float *o = od_dev ? out : h->ws_out.as<float>((size_t)nseq * od);
+        PoolArgs p{};
+        p.x = h->ws_x.get<float>(); p.norm_w = h->norm_w.get<float>();
+        p.dense_w = c.dense_out ? h->dense_w.get<bf16_t>() : nullptr;
+        p.dense_b = c.dense_out ? h->dense_b.get<float>() : nullptr;
+        p.seq_start = b.seq_start; p.seq_len = b.seq_len; p.out = o; p.H = c.hidden; p.out_dim = od;
+        p.Lmax = b.Lmax; p.normalize = normalize; p.eps = c.rms_eps;
+        const size_t smem = ((size_t)b.Lmax + c.hidden + od + 8) * 4;
+        hipLaunchKernelGGL(pool_kernel, dim3(nseq), dim3(256), smem, st, p);
+        MI_HIP(hipGetLastError());
+        if (!od_dev) {
+            MI_HIP(hipMemcpyAsync(out, o, (size_t)nseq * od * 4, hipMemcpyDeviceToHost, st));
+            MI_HIP(hipStreamSynchronize(st));
+        }
+    });
+}
+
+int mi_encoder_hidden(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu, float *out, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(h && ids && cu && out, "null argument");
+        DeviceGuard dg(h->device);
+        hipStream_t st = as_stream(stream);
+        Batch b = prepare_batch(h, nseq, ids, cu, st);
+        run_stack(h, b, st);
+        const int H = h->cfg.hidden;
+        const bool od_dev = is_device_ptr(out);
+        float *o = od_dev ? out : h->ws_out.as<float>((size_t)b.T_real * H);
+        hipLaunchKernelGGL(final_norm_kernel, dim3((b.T_real + 3) / 4), dim3(256), 0, st, h->ws_x.get<float>(),
+                           h->norm_w.get<float>(), H, b.T_real, b.tok_map, h->cfg.rms_eps, o);
+        MI_HIP(hipGetLastError());
+        if (!od_dev) {
+            MI_HIP(hipMemcpyAsync(out, o, (size_t)b.T_real * H * 4, hipMemcpyDeviceToHost, st));
+            MI_HIP(hipStreamSynchronize(st));
+        }
+    });
+}
+
+int mi_encoder_profile_enable(mi_encoder *h, int on) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        h->prof = on != 0;
+    });
+}
+
+int mi_encoder_profile_read(mi_encoder *h, double *gemm_ms, double *gemm_flops) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        DeviceGuard dg(h->device);
+        double tot = 0.0;
+        for (auto &e : h->evs) {
+            MI_HIP(hipEventSynchronize(e.second));
+            float ms = 0.f;
+            MI_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+            tot += ms;
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        h->evs.clear();
+        if (gemm_ms) *gemm_ms = tot;
+        if (gemm_flops) *gemm_flops = h->prof_flops;
+        h->prof_flops = 0.0;
+    });
+}
+
+int mi_enc_gemm_bf16(int device, int M, int N, int K, const void *A, const void *W, void *C, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(A && W && C, "null argument");
+        MI_REQUIRE(is_device_ptr(A) && is_device_ptr(W) && is_device_ptr(C), "mi_enc_gemm_bf16: device pointers only");
+        DeviceGuard dg(device);
+        GemmArgs g{};
+        g.A = static_cast<const bf16_t *>(A); g.lda = K; g.W = static_cast<const bf16_t *>(W); g.ldw = K;
+        g.M = M; g.N = N; g.K = K; g.C = static_cast<bf16_t *>(C); g.ldc = N;
+        launch_gemm(EPI_STORE, g, as_stream(stream));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,546 @@
+// encoder_kernels.h -- gfx950 (CDNA4, wave64) kernels of the encode hot path:
+// the Qwen2-style decoder stack of stella_en_1.5B_v5, mean pooling, Dense and
+// L2 normalisation (reference call sites: Makefile:65 `sidecar-search build`,
+// README.md:28 query-time app; arithmetic restated in oracle/encoder_oracle.py).
+//
+//   embed_kernel        token ids -> f32 residual stream
+//   rmsnorm_kernel      f32 residual -> bf16 GEMM operand (f32 statistics)
+//   gemm_bf16_nt_kernel C = A . W^T on v_mfma_f32_16x16x32_bf16, 128x128x64
+//                       tiles staged by LDS-DMA (global_load_lds_dwordx4) into
+//                       XOR-swizzled LDS, f32 accumulation, fused epilogues:
+//                       QKV (+bias, V written transposed), residual add into the
+//                       f32 stream, SwiGLU (gate/up interleaved weight rows)
+//   rope_kernel         rotary embedding on Q and K (host-built f32 tables)
+//   attn_kernel         varlen flash attention (bidirectional or causal, GQA),
+//                       QK^T and PV on MFMA, online softmax in registers
+//   pool_kernel         final RMSNorm + mean pooling + Dense + L2 normalise
+//
+// Tokens are packed; every sequence starts at a multiple of 8 tokens so that
+// rows of the transposed V buffer are 16-byte aligned, and T_pad is a multiple
+// of 128 (GEMM tile).  Padding tokens compute garbage that is never read by a
+// real token: attention masks keys >= the sequence length, pooling walks only
+// the real tokens.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mienc {
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return *reinterpret_cast<bf16x8 *>(&v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ---------------------------------------------------------------------
+// x[t][:] = embed[ids[t]][:]   (bf16 table -> f32 residual stream)
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    embed_kernel(const int32_t *__restrict__ ids, const bf16_t *__restrict__ table, int H, int T,
+                 float *__restrict__ x) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;
+    const bf16_t *src = table + (size_t)ids[t] * H;
+    float *dst = x + (size_t)t * H;
+    for (int c = lane * 8; c < H; c += 512) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + c);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        float4 a, b;
+        a.x = __uint_as_float(w[0] << 16); a.y = __uint_as_float(w[0] & 0xffff0000u);
+        a.z = __uint_as_float(w[1] << 16); a.w = __uint_as_float(w[1] & 0xffff0000u);
+        b.x = __uint_as_float(w[2] << 16); b.y = __uint_as_float(w[2] & 0xffff0000u);
+        b.z = __uint_as_float(w[3] << 16); b.w = __uint_as_float(w[3] & 0xffff0000u);
+        *reinterpret_cast<float4 *>(dst + c) = a;
+        *reinterpret_cast<float4 *>(dst + c + 4) = b;
+    }
+}
+
+// ---------------------------------------------------------------------
+// y[t][:] = bf16( x[t][:] * rsqrt(mean(x^2) + eps) * w[:] ), one wave per token
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    rmsnorm_kernel(const float *__restrict__ x, const float *__restrict__ w, int H, int T, float eps,
+                   bf16_t *__restrict__ y) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;
+    const float *src = x + (size_t)t * H;
+    float ss = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + c);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    const float inv = rsqrtf(ss / (float)H + eps);
+    bf16_t *dst = y + (size_t)t * H;
+    for (int c = lane * 4; c < H; c += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + c);
+        const float4 g = *reinterpret_cast<const float4 *>(w + c);
+        uint2 o;
+        o.x = pack2(v.x * inv * g.x, v.y * inv * g.y);
+        o.y = pack2(v.z * inv * g.z, v.w * inv * g.w);
+        *reinterpret_cast<uint2 *>(dst + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------------
+// bf16 GEMM, C[M][N] = A[M][K] . W[N][K]^T, f32 accumulation.
+// 128x128 workgroup tile, 4 waves (2x2) of 64x64, K step 64, double-buffered
+// LDS filled by LDS-DMA; LDS rows are 128 B with the 16-byte slot index XORed
+// with (row & 7) (applied on the global source address, the DMA itself is
+// lane-linear), which makes the ds_read_b128 fragment reads conflict-free.
+// Requires K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned bases.
+// ---------------------------------------------------------------------
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3 };
+
+struct GemmArgs {
+    const bf16_t *A;   // [M][lda]
+    const bf16_t *W;   // [N][ldw]
+    int lda, ldw, M, N, K;
+    const float *bias; // [N] or null
+    bf16_t *C;         // STORE / SWIGLU / QKV(q,k part): bf16 [M][ldc]
+    float *X;          // RESID: f32 residual stream [M][ldc], updated in place
+    bf16_t *Vt;        // QKV: V^T bf16 [N - qk_cols][ldvt]
+    int ldc, ldvt, qk_cols;
+    int tiles_m, tiles_n;
+};
+
+template <int EPI>
+__global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
+    constexpr int BM = 128, BN = 128, BK = 64;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];  // 64 KiB
+    bf16_t *As = smem;                    // [2][BM][BK]
+    bf16_t *Bs = smem + 2 * BM * BK;      // [2][BN][BK]
+
+    // XCD-aware order: the 8 XCDs each take a contiguous eighth of the tiles;
+    // within an XCD consecutive blocks walk the N tiles of one M row block
+    // (A rows stay in that XCD's L2).
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int per = (ntiles + 7) / 8;
+    const int t = (bid & 7) * per + (bid >> 3);
+    if (t >= ntiles || (bid >> 3) >= per) return;
+    const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w & 1, wn = w >> 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    // staging: per operand a wave issues 4 DMA instructions of 8 rows x 128 B
+    const int srow = lane >> 3;                       // row inside the 8-row piece
+    const int scol = ((lane & 7) ^ srow) * 8;         // swizzled source column (elements)
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r0 = (w * 4 + i) * 8;
+            const int ra = min(m0 + r0 + srow, g.M - 1);
+            const int rb = min(n0 + r0 + srow, g.N - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(g.A + (size_t)ra * g.lda + k0 + scol),
+                (__attribute__((address_space(3))) void *)(As + buf * BM * BK + r0 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(g.W + (size_t)rb * g.ldw + k0 + scol),
+                (__attribute__((address_space(3))) void *)(Bs + buf * BN * BK + r0 * BK), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+        const bf16_t *ab = As + (kt & 1) * BM * BK + (wm * 64 + li) * BK;
+        const bf16_t *bb = Bs + (kt & 1) * BN * BK + (wn * 64 + li) * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int slot = ((kk * 4 + lg) ^ (li & 7)) * 8;  // row & 7 == li & 7 (tile rows are multiples of 16)
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = as_bf16x8(*reinterpret_cast<const uint4 *>(ab + i * 16 * BK + slot));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = as_bf16x8(*reinterpret_cast<const uint4 *>(bb + j * 16 * BK + slot));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds rows lg*4 + r, column li of every 16x16 tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row0 = m0 + wm * 64 + i * 16 + lg * 4;
+        if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const int ocol = (n0 + wn * 64) / 2 + (j / 2) * 16 + li;
+                if (n0 + wn * 64 + j * 16 + li < g.N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float gt = acc[i][j][r], up = acc[i][j + 1][r];
+                        const float h = gt / (1.0f + __expf(-gt)) * up;
+                        if (row0 + r < g.M) g.C[(size_t)(row0 + r) * g.ldc + ocol] = f2bf(h);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wn * 64 + j * 16 + li;
+                if (col >= g.N) continue;
+                const float bv = g.bias ? g.bias[col] : 0.f;
+                if constexpr (EPI == EPI_QKV) {
+                    if (col >= g.qk_cols) {  // V: 4 consecutive tokens of one channel -> one 8-byte store
+                        if (row0 < g.M) {
+                            uint2 o;
+                            o.x = pack2(acc[i][j][0] + bv, acc[i][j][1] + bv);
+                            o.y = pack2(acc[i][j][2] + bv, acc[i][j][3] + bv);
+                            *reinterpret_cast<uint2 *>(g.Vt + (size_t)(col - g.qk_cols) * g.ldvt + row0) = o;
+                        }
+                        continue;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + r;
+                    if (row >= g.M) continue;
+                    if constexpr (EPI == EPI_RESID) {
+                        float *px = g.X + (size_t)row * g.ldc + col;
+                        *px = *px + acc[i][j][r] + bv;
+                    } else {
+                        g.C[(size_t)row * g.ldc + col] = f2bf(acc[i][j][r] + bv);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------
+// Rotary embedding in place on the q/k part of the QKV output:
+// X[t][h*hd + i], X[t][h*hd + i + hd/2]  (HF rotate_half pairing),
+// cos/sin f32 tables [max_seq][hd/2]; thread = (token, head, 8 pairs).
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    rope_kernel(bf16_t *__restrict__ X, int ldx, int nheads_qk, int hd, const int32_t *__restrict__ pos,
+                const float *__restrict__ cos_t, const float *__restrict__ sin_t, int T) {
+    const int per_tok = nheads_qk * (hd / 16);
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= (int64_t)T * per_tok) return;
+    const int t = (int)(gi / per_tok), rem = (int)(gi - (int64_t)t * per_tok);
+    const int h = rem / (hd / 16), i0 = (rem - h * (hd / 16)) * 8;
+    bf16_t *p1 = X + (size_t)t * ldx + h * hd + i0;
+    bf16_t *p2 = p1 + hd / 2;
+    const float *c = cos_t + (size_t)pos[t] * (hd / 2) + i0;
+    const float *s = sin_t + (size_t)pos[t] * (hd / 2) + i0;
+    const uint4 v1 = *reinterpret_cast<const uint4 *>(p1), v2 = *reinterpret_cast<const uint4 *>(p2);
+    const unsigned a[4] = {v1.x, v1.y, v1.z, v1.w}, b[4] = {v2.x, v2.y, v2.z, v2.w};
+    unsigned o1[4], o2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x1l = __uint_as_float(a[j] << 16), x1h = __uint_as_float(a[j] & 0xffff0000u);
+        const float x2l = __uint_as_float(b[j] << 16), x2h = __uint_as_float(b[j] & 0xffff0000u);
+        const float cl = c[2 * j], ch = c[2 * j + 1], sl = s[2 * j], sh = s[2 * j + 1];
+        o1[j] = pack2(x1l * cl - x2l * sl, x1h * ch - x2h * sh);
+        o2[j] = pack2(x2l * cl + x1l * sl, x2h * ch + x1h * sh);
+    }
+    *reinterpret_cast<uint4 *>(p1) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+    *reinterpret_cast<uint4 *>(p2) = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+}
+
+// ---------------------------------------------------------------------
+// Varlen attention.  grid = (work items, n_heads); a work item is a 64-row
+// query block of one sequence; 4 waves x 16 query rows.  Per 64-key chunk:
+// K rows and V^T rows are staged in XOR-swizzled LDS, S = Q K^T (16 MFMA per
+// wave), online softmax in registers (row statistics reduced over the 16 lanes
+// of a DPP row), P goes through a per-wave LDS tile to become the A operand,
+// O += P V (16 MFMA per wave).
+// ---------------------------------------------------------------------
+struct AttnArgs {
+    const bf16_t *QK;   // [T_pad][ldqk]: q heads then k heads (RoPE applied)
+    const bf16_t *Vt;   // [n_kv*hd][ldvt]
+    bf16_t *O;          // [T_pad][n_heads*hd]
+    const int32_t *work_seq, *work_q0;   // [nwork]
+    const int32_t *seq_start, *seq_len;  // [nseq] (padded-packed token offsets)
+    int ldqk, ldvt, n_heads, n_kv, causal;
+    float scale;
+};
+
+template <int HD>
+__global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
+    constexpr int KC = 64;          // keys per chunk
+    constexpr int NKK = HD / 32;    // MFMA k-steps over the head dimension
+    constexpr int NDT = HD / 16;    // 16-wide output tiles over the head dimension
+    constexpr int KSLOTS = HD / 8;  // 16-byte slots per K row
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KC * HD];      // [key][HD], slot ^= key&7
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[HD * KC];      // [d][key],  slot ^= d&7
+    __shared__ __attribute__((aligned(16))) bf16_t Ps[4 * 16 * KC];  // per wave [16][64], slot ^= row&7
+
+    const int item = blockIdx.x, h = blockIdx.y;
+    const int seq = a.work_seq[item], q0 = a.work_q0[item];
+    const int s0 = a.seq_start[seq], L = a.seq_len[seq];
+    const int kvh = h / (a.n_heads / a.n_kv);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+
+    // Q fragments of this wave's 16 rows (A operand: row li, 8 dims at 32*kk + 8*lg)
+    bf16x8 qf[NKK];
+    {
+        const int qrow = min(q0 + w * 16 + li, L - 1);
+        const bf16_t *qp = a.QK + (size_t)(s0 + qrow) * a.ldqk + h * HD + lg * 8;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) qf[kk] = as_bf16x8(*reinterpret_cast<const uint4 *>(qp + kk * 32));
+    }
+    f32x4 o[NDT];
+#pragma unroll
+    for (int n = 0; n < NDT; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrow[4], lrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        mrow[r] = -__builtin_huge_valf();
+        lrow[r] = 0.f;
+    }
+    const int kend = a.causal ? min(L, q0 + 64) : L;
+    bf16_t *pw = Ps + w * 16 * KC;
+
+    for (int kc = 0; kc < kend; kc += KC) {
+        __syncthreads();  // previous chunk's tiles are no longer read
+        // stage K: 64 keys x HD (KSLOTS 16-byte slots per row)
+        for (int idx = tid; idx < KC * KSLOTS; idx += 256) {
+            const int key = idx / KSLOTS, sl = idx - key * KSLOTS;
+            const int krow = min(kc + key, L - 1);
+            const uint4 v = *reinterpret_cast<const uint4 *>(
+                a.QK + (size_t)(s0 + krow) * a.ldqk + (a.n_heads + kvh) * HD + sl * 8);
+            *reinterpret_cast<uint4 *>(Ks + key * HD + ((sl ^ (key & 7)) * 8)) = v;
+        }
+        // stage V^T: HD rows x 64 keys (8 slots per row)
+        for (int idx = tid; idx < HD * 8; idx += 256) {
+            const int d = idx >> 3, sl = idx & 7;
+            const uint4 v = *reinterpret_cast<const uint4 *>(
+                a.Vt + (size_t)(kvh * HD + d) * a.ldvt + s0 + kc + sl * 8);
+            *reinterpret_cast<uint4 *>(Vs + d * KC + ((sl ^ (d & 7)) * 8)) = v;
+        }
+        __syncthreads();
+
+        // S = Q K^T for 4 tiles of 16 keys
+        f32x4 s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16_t *kb = Ks + (j * 16 + li) * HD;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const bf16x8 kf = as_bf16x8(*reinterpret_cast<const uint4 *>(kb + (((kk * 4 + lg) ^ (li & 7)) * 8)));
+                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], kf, s[j], 0, 0, 0);
+            }
+        }
+        // scale, mask, online softmax (lane holds rows lg*4+r, key column j*16+li)
+        float pmax[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pmax[r] = -__builtin_huge_valf();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kidx = kc + j * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qidx = q0 + w * 16 + lg * 4 + r;
+                float v = s[j][r] * a.scale;
+                if (kidx >= L || (a.causal && kidx > qidx)) v = -__builtin_huge_valf();
+                s[j][r] = v;
+                pmax[r] = fmaxf(pmax[r], v);
+            }
+        }
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = pmax[r];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 16));
+            const float mnew = fmaxf(mrow[r], m);
+            alpha[r] = (mrow[r] == -__builtin_huge_valf()) ? 0.f : __expf(mrow[r] - mnew);
+            mrow[r] = mnew;
+        }
+        float psum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = (mrow[r] == -__builtin_huge_valf()) ? 0.f : __expf(s[j][r] - mrow[r]);
+                psum[r] += p;
+                // P tile for the PV A operand: element (row, key) at row*64 + ((key/8)^(row&7))*8 + key%8
+                const int row = lg * 4 + r, key = j * 16 + li;
+                pw[row * KC + (((key >> 3) ^ (row & 7)) << 3) + (key & 7)] = f2bf(p);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = psum[r];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off, 16);
+            lrow[r] = lrow[r] * alpha[r] + t;
+        }
+#pragma unroll
+        for (int n = 0; n < NDT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[n][r] *= alpha[r];
+        // O += P V  (A: P[row li][keys 32*kk2 + 8*lg ..], B: V^T[d = 16n+li][same keys])
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) {
+            const bf16x8 pf = as_bf16x8(*reinterpret_cast<const uint4 *>(pw + li * KC + (((kk2 * 4 + lg) ^ (li & 7)) * 8)));
+#pragma unroll
+            for (int n = 0; n < NDT; ++n) {
+                const bf16x8 vf = as_bf16x8(*reinterpret_cast<const uint4 *>(
+                    Vs + (n * 16 + li) * KC + (((kk2 * 4 + lg) ^ (li & 7)) * 8)));
+                o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[n], 0, 0, 0);
+            }
+        }
+    }
+    // normalise and write rows < L
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qidx = q0 + w * 16 + lg * 4 + r;
+        if (qidx >= L) continue;
+        const float inv = lrow[r] > 0.f ? 1.0f / lrow[r] : 0.f;
+        bf16_t *op = a.O + (size_t)(s0 + qidx) * (a.n_heads * HD) + h * HD + li;
+#pragma unroll
+        for (int n = 0; n < NDT; ++n) op[n * 16] = f2bf(o[n][r] * inv);
+    }
+}
+
+// ---------------------------------------------------------------------
+// Final RMSNorm of every real token -> f32 [T_real][H] (parity hook).
+// tok_map[t_real] = padded-packed row.
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    final_norm_kernel(const float *__restrict__ x, const float *__restrict__ w, int H, int Treal,
+                      const int32_t *__restrict__ tok_map, float eps, float *__restrict__ out) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= Treal) return;
+    const float *src = x + (size_t)tok_map[t] * H;
+    float ss = 0.f;
+    for (int c = lane; c < H; c += 64) ss += src[c] * src[c];
+    ss = wave_sum(ss);
+    const float inv = rsqrtf(ss / (float)H + eps);
+    for (int c = lane; c < H; c += 64) out[(size_t)t * H + c] = src[c] * inv * w[c];
+}
+
+// ---------------------------------------------------------------------
+// Per sequence: final RMSNorm, mean over the tokens, Dense (+bias), optional
+// L2 normalisation.  One 256-thread workgroup per sequence.
+// dynamic LDS: inv[Lmax] | pooled[H] | outv[out_dim] | red[8]
+// ---------------------------------------------------------------------
+struct PoolArgs {
+    const float *x;          // [T_pad][H] residual stream
+    const float *norm_w;     // [H]
+    const bf16_t *dense_w;   // [out_dim][H] or null (no Dense: out = pooled)
+    const float *dense_b;    // [out_dim] or null
+    const int32_t *seq_start, *seq_len;
+    float *out;              // [nseq][out_dim]
+    int H, out_dim, Lmax, normalize;
+    float eps;
+};
+
+__global__ void __launch_bounds__(256) pool_kernel(PoolArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *inv = reinterpret_cast<float *>(smem_raw);
+    float *pooled = inv + a.Lmax;
+    float *outv = pooled + a.H;
+    float *red = outv + a.out_dim;
+    const int seq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s0 = a.seq_start[seq], L = a.seq_len[seq];
+    const int H = a.H;
+    for (int t = w; t < L; t += 4) {
+        const float *src = a.x + (size_t)(s0 + t) * H;
+        float ss = 0.f;
+        for (int c = lane * 4; c < H; c += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + c);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) inv[t] = rsqrtf(ss / (float)H + a.eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < H; c += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < L; ++t) acc += a.x[(size_t)(s0 + t) * H + c] * inv[t];
+        pooled[c] = acc * a.norm_w[c] / (float)L;
+    }
+    __syncthreads();
+    if (a.dense_w) {
+        for (int j = w; j < a.out_dim; j += 4) {
+            const bf16_t *wr = a.dense_w + (size_t)j * H;
+            float acc = 0.f;
+            for (int c = lane * 8; c < H; c += 512) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(wr + c);
+                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc += pooled[c + 2 * q] * __uint_as_float(u[q] << 16);
+                    acc += pooled[c + 2 * q + 1] * __uint_as_float(u[q] & 0xffff0000u);
+                }
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) outv[j] = acc + (a.dense_b ? a.dense_b[j] : 0.f);
+        }
+    } else {
+        for (int c = tid; c < a.out_dim; c += 256) outv[c] = pooled[c];
+    }
+    __syncthreads();
+    float scale = 1.f;
+    if (a.normalize) {
+        float ss = 0.f;
+        for (int c = tid; c < a.out_dim; c += 256) ss += outv[c] * outv[c];
+        ss = wave_sum(ss);
+        if (lane == 0) red[w] = ss;
+        __syncthreads();
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        scale = 1.0f / fmaxf(sqrtf(tot), 1e-12f);  // torch.nn.functional.normalize eps
+    }
+    for (int c = tid; c < a.out_dim; c += 256) a.out[(size_t)seq * a.out_dim + c] = outv[c] * scale;
+}
+
+// ---------------------------------------------------------------------
+// weight import: dst_bf16[map(r)][c] = convert(src[r][c]),
+// map(r) = (r / blk) * stride + off + r % blk
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    import_rows_kernel(const void *__restrict__ src, int dtype, int64_t rows, int64_t cols, int64_t blk,
+                       int64_t stride, int64_t off, bf16_t *__restrict__ dst, float *__restrict__ dst_f32) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols, c = i - r * cols;
+    float v;
+    if (dtype == 0) v = static_cast<const float *>(src)[i];
+    else if (dtype == 1) v = bf2f(static_cast<const bf16_t *>(src)[i]);
+    else v = __half2float(static_cast<const __half *>(src)[i]);
+    const int64_t dr = (r / blk) * stride + off + r % blk;
+    if (dst) dst[dr * cols + c] = f2bf(v);
+    else dst_f32[dr * cols + c] = v;
+}
+
+}  // namespace mienc

@@ -1,0 +1,306 @@
+"""sentence-transformers-shaped Python mirror of the MI355X encoder.
+
+Drop-in for the `SentenceTransformer` surface the reference reaches through
+``sidecar-search build -b 32`` (reference Makefile:65; README.md:60:
+``SIDECARSEARCH_MODEL``, ``SIDECARSEARCH_TRUST_REMOTE_CODE``) and its query-time
+``app.py`` (reference README.md:28: ``MODEL_NAME``, ``PROMPT_NAME=s2p_query``,
+``TRUST_REMOTE_CODE``): the constructor, ``encode``, ``tokenize``,
+``get_sentence_embedding_dimension``, ``max_seq_length``, ``prompts``.
+
+The numeric path (embedding gather, 28 decoder layers, pooling, Dense,
+normalisation) runs in HIP kernels behind ``include/mi_encoder.h``; this file
+tokenises on the host (the ``tokenizers`` library, as sentence-transformers
+does), sorts by length, packs batches without padding tokens and moves
+pointers.  There is no CPU fallback.
+
+A model directory in the usual sentence-transformers layout is read directly:
+``config.json``, ``*.safetensors`` (HF Qwen2 names), ``tokenizer.json``,
+``modules.json`` + ``<n>_Dense*/`` (``config.json``, ``model.safetensors``),
+``config_sentence_transformers.json`` (prompts), ``sentence_bert_config.json``
+(max_seq_length).  Without a checkpoint (this build environment has none), pass
+``config=`` and ``weights=`` (name -> tensor) explicitly.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+from . import _native
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [("vocab_size", c_int32), ("hidden", c_int32), ("n_layers", c_int32), ("n_heads", c_int32),
+                ("n_kv_heads", c_int32), ("head_dim", c_int32), ("intermediate", c_int32),
+                ("rms_eps", c_float), ("rope_theta", c_float), ("causal", c_int32), ("dense_out", c_int32),
+                ("dense_bias", c_int32), ("max_seq_len", c_int32)]
+
+
+class _Lib:
+    _lib = None
+
+    @classmethod
+    def get(cls):
+        if cls._lib is None:
+            lib = _native.load("encoder")
+            lib.mi_enc_last_error.restype = c_char_p
+            v = c_void_p
+            sigs = {
+                "mi_encoder_create": [POINTER(_Cfg), c_int, POINTER(v)],
+                "mi_encoder_destroy": [v],
+                "mi_encoder_load_tensor": [v, c_char_p, v, c_int, POINTER(c_int64), c_int],
+                "mi_encoder_missing": [v, POINTER(c_int)],
+                "mi_encoder_out_dim": [v, POINTER(c_int)],
+                "mi_encoder_encode": [v, c_int, v, v, c_int, v, v],
+                "mi_encoder_hidden": [v, c_int, v, v, v, v],
+                "mi_encoder_profile_enable": [v, c_int],
+                "mi_encoder_profile_read": [v, POINTER(c_double), POINTER(c_double)],
+                "mi_enc_gemm_bf16": [c_int, c_int, c_int, c_int, v, v, v, v],
+            }
+            for name, args in sigs.items():
+                fn = getattr(lib, name)
+                fn.argtypes = args
+                fn.restype = c_int
+            cls._lib = lib
+        return cls._lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise RuntimeError("mi_encoder: " + _Lib.get().mi_enc_last_error().decode())
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}
+
+# stella_en_1.5B_v5 (SURVEY Appendix B.1 [PRIOR]; every value is overridable by config.json)
+STELLA_EN_1_5B_V5 = dict(vocab_size=151646, hidden=1536, n_layers=28, n_heads=12, n_kv_heads=2, head_dim=128,
+                         intermediate=8960, rms_eps=1e-6, rope_theta=1e6, causal=False, dense_out=1024,
+                         dense_bias=True, max_seq_len=512)
+
+
+def _cfg_from_hf(hf: dict) -> dict:
+    hidden = int(hf["hidden_size"])
+    nh = int(hf["num_attention_heads"])
+    return dict(vocab_size=int(hf["vocab_size"]), hidden=hidden, n_layers=int(hf["num_hidden_layers"]),
+                n_heads=nh, n_kv_heads=int(hf.get("num_key_value_heads", nh)),
+                head_dim=int(hf.get("head_dim") or hidden // nh), intermediate=int(hf["intermediate_size"]),
+                rms_eps=float(hf.get("rms_norm_eps", 1e-6)), rope_theta=float(hf.get("rope_theta", 1e6)),
+                causal=bool(hf.get("is_causal", False)), dense_out=0, dense_bias=True,
+                max_seq_len=int(hf.get("max_position_embeddings", 512)))
+
+
+class SentenceTransformer:
+    """sentence_transformers.SentenceTransformer on one MI355X."""
+
+    def __init__(self, model_name_or_path: str | None = None, device=None, prompts: dict | None = None,
+                 default_prompt_name: str | None = None, trust_remote_code: bool = False,
+                 config: dict | None = None, weights: dict | None = None, tokenizer=None,
+                 max_seq_length: int | None = None, **_ignored):
+        self.trust_remote_code = trust_remote_code
+        self.prompts = dict(prompts or {})
+        self.default_prompt_name = default_prompt_name
+        self.tokenizer = tokenizer
+        self.add_eos = False
+        self._device_index = 0
+        if device is not None:
+            s = str(device)
+            self._device_index = int(s.split(":")[1]) if ":" in s else 0
+        cfg = dict(config) if config is not None else None
+        if model_name_or_path is not None and os.path.isdir(model_name_or_path):
+            cfg, weights = self._read_model_dir(model_name_or_path, cfg, weights)
+        elif model_name_or_path is not None and cfg is None:
+            raise FileNotFoundError(
+                f"{model_name_or_path!r} is not a local model directory (no network / hub access on this path); "
+                "pass a directory, or config= and weights=")
+        if cfg is None:
+            raise ValueError("SentenceTransformer: need a model directory or config=")
+        if hasattr(cfg, "to_dict"):
+            cfg = cfg.to_dict()
+        if max_seq_length is not None:
+            cfg["max_seq_len"] = int(max_seq_length)
+        self.config = cfg
+        c = _Cfg(**{k: (int(v) if isinstance(v, bool) else v) for k, v in cfg.items() if k in dict(_Cfg._fields_)})
+        self._h = c_void_p()
+        _check(_Lib.get().mi_encoder_create(ctypes.byref(c), self._device_index, ctypes.byref(self._h)))
+        if weights is not None:
+            self.load_weights(weights)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _Lib.get().mi_encoder_destroy(h)
+            except Exception:
+                pass
+
+    # -- loading -------------------------------------------------------
+    def _read_model_dir(self, path, cfg, weights):
+        from safetensors import safe_open
+        with open(os.path.join(path, "config.json")) as f:
+            hf = json.load(f)
+        cfg = cfg or _cfg_from_hf(hf)
+        weights = dict(weights or {})
+        files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+        for fn in files:
+            with safe_open(os.path.join(path, fn), framework="pt") as sf:
+                for k in sf.keys():
+                    weights[k[6:] if k.startswith("model.") else k] = sf.get_tensor(k)
+        mods = os.path.join(path, "modules.json")
+        if os.path.exists(mods):
+            for m in json.load(open(mods)):
+                if m.get("type", "").endswith("Dense"):
+                    dd = os.path.join(path, m["path"])
+                    dc = json.load(open(os.path.join(dd, "config.json")))
+                    cfg["dense_out"] = int(dc["out_features"])
+                    cfg["dense_bias"] = bool(dc.get("bias", True))
+                    with safe_open(os.path.join(dd, "model.safetensors"), framework="pt") as sf:
+                        weights["dense.weight"] = sf.get_tensor("linear.weight")
+                        if cfg["dense_bias"]:
+                            weights["dense.bias"] = sf.get_tensor("linear.bias")
+        st_cfg = os.path.join(path, "config_sentence_transformers.json")
+        if os.path.exists(st_cfg):
+            sc = json.load(open(st_cfg))
+            self.prompts = {**sc.get("prompts", {}), **self.prompts}
+            self.default_prompt_name = self.default_prompt_name or sc.get("default_prompt_name")
+        sb = os.path.join(path, "sentence_bert_config.json")
+        if os.path.exists(sb):
+            cfg["max_seq_len"] = int(json.load(open(sb)).get("max_seq_length", cfg["max_seq_len"]))
+        tk = os.path.join(path, "tokenizer.json")
+        if self.tokenizer is None and os.path.exists(tk):
+            from tokenizers import Tokenizer
+            self.tokenizer = Tokenizer.from_file(tk)
+        return cfg, weights
+
+    def load_weights(self, weights: dict):
+        """name -> torch tensor / numpy array (f32, bf16 or f16; host or CUDA)."""
+        import torch
+        lib = _Lib.get()
+        for name, t in weights.items():
+            if name.startswith("model."):
+                name = name[6:]
+            if name == "lm_head.weight" or "rotary_emb" in name:
+                continue
+            if not _is_torch(t):
+                t = torch.from_numpy(np.ascontiguousarray(t))
+            t = t.contiguous()
+            dt = str(t.dtype).replace("torch.", "")
+            if dt not in _DTYPES:
+                t, dt = t.float(), "float32"
+            shape = (c_int64 * t.dim())(*t.shape)
+            _check(lib.mi_encoder_load_tensor(self._h, name.encode(), c_void_p(t.data_ptr()), _DTYPES[dt],
+                                              shape, t.dim()))
+
+    # -- sentence-transformers surface ----------------------------------
+    @property
+    def max_seq_length(self) -> int:
+        return int(self.config["max_seq_len"])
+
+    def get_sentence_embedding_dimension(self) -> int:
+        n = c_int(0)
+        _check(_Lib.get().mi_encoder_out_dim(self._h, ctypes.byref(n)))
+        return n.value
+
+    def get_max_seq_length(self) -> int:
+        return self.max_seq_length
+
+    def tokenize(self, texts):
+        """list[str] -> list of token-id lists (truncated to max_seq_length)."""
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer: pass tokenizer= or a model directory with tokenizer.json")
+        enc = self.tokenizer.encode_batch(list(texts))
+        out = []
+        for e in enc:
+            ids = list(e.ids)[: self.max_seq_length]
+            out.append(ids if ids else [0])
+        return out
+
+    def encode(self, sentences, prompt_name: str | None = None, prompt: str | None = None,
+               batch_size: int = 32, show_progress_bar=None, output_value: str = "sentence_embedding",
+               precision: str = "float32", convert_to_numpy: bool = True, convert_to_tensor: bool = False,
+               device=None, normalize_embeddings: bool = False, **_ignored):
+        if output_value != "sentence_embedding" or precision != "float32":
+            raise NotImplementedError("only sentence embeddings in float32 are implemented")
+        single = isinstance(sentences, str)
+        if single:
+            sentences = [sentences]
+        if prompt is None:
+            name = prompt_name or self.default_prompt_name
+            if name is not None:
+                if name not in self.prompts:
+                    raise ValueError(f"Prompt name '{name}' not found in the configured prompts dictionary "
+                                     f"with keys {list(self.prompts)!r}.")
+                prompt = self.prompts[name]
+        if prompt:
+            sentences = [prompt + s for s in sentences]
+        toks = self.tokenize(sentences)
+        emb = self.encode_tokens(toks, batch_size=batch_size, normalize_embeddings=normalize_embeddings,
+                                 as_tensor=convert_to_tensor)
+        if single:
+            emb = emb[0]
+        return emb
+
+    def encode_tokens(self, token_lists, batch_size: int = 32, normalize_embeddings: bool = False,
+                      as_tensor: bool = False):
+        """list of token-id lists -> float32 [n, dim].  Like sentence-transformers,
+        inputs are sorted by length (longest first) before batching and the
+        result is put back in input order; a batch is packed, not padded."""
+        import torch
+        n = len(token_lists)
+        dim = self.get_sentence_embedding_dimension()
+        dev = torch.device("cuda", self._device_index)
+        out = torch.empty((n, dim), dtype=torch.float32, device=dev)
+        order = sorted(range(n), key=lambda i: -len(token_lists[i]))
+        stream = c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        lib = _Lib.get()
+        for b0 in range(0, n, batch_size):
+            sel = order[b0:b0 + batch_size]
+            lens = [len(token_lists[i]) for i in sel]
+            cu = np.zeros(len(sel) + 1, np.int32)
+            np.cumsum(lens, out=cu[1:])
+            ids = np.fromiter((t for i in sel for t in token_lists[i]), np.int32, count=int(cu[-1]))
+            part = torch.empty((len(sel), dim), dtype=torch.float32, device=dev)
+            _check(lib.mi_encoder_encode(self._h, len(sel), c_void_p(ids.ctypes.data), c_void_p(cu.ctypes.data),
+                                         int(normalize_embeddings), c_void_p(part.data_ptr()), stream))
+            out[torch.as_tensor(sel, device=dev)] = part
+        if as_tensor:
+            return out
+        return out.cpu().numpy()
+
+    # -- parity / measurement hooks ---------------------------------------
+    def last_hidden_state(self, token_lists):
+        """packed float32 [T, hidden] after the final norm (tests)."""
+        lens = [len(t) for t in token_lists]
+        cu = np.zeros(len(lens) + 1, np.int32)
+        np.cumsum(lens, out=cu[1:])
+        ids = np.fromiter((t for tl in token_lists for t in tl), np.int32, count=int(cu[-1]))
+        out = np.empty((int(cu[-1]), int(self.config["hidden"])), np.float32)
+        _check(_Lib.get().mi_encoder_hidden(self._h, len(lens), c_void_p(ids.ctypes.data), c_void_p(cu.ctypes.data),
+                                            c_void_p(out.ctypes.data), c_void_p(0)))
+        return out
+
+    def profile(self, on: bool = True):
+        _check(_Lib.get().mi_encoder_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms, fl = c_double(0), c_double(0)
+        _check(_Lib.get().mi_encoder_profile_read(self._h, ctypes.byref(ms), ctypes.byref(fl)))
+        return {"gemm_ms": ms.value, "gemm_flops": fl.value}
+
+
+def gemm_bf16(A, W):
+    """C = A @ W.T in bf16 with f32 accumulation on the MFMA kernel (tests)."""
+    import torch
+    M, K = A.shape
+    N = W.shape[0]
+    C = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    _check(_Lib.get().mi_enc_gemm_bf16(A.device.index or 0, M, N, K, c_void_p(A.data_ptr()),
+                                       c_void_p(W.data_ptr()), c_void_p(C.data_ptr()),
+                                       c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return C

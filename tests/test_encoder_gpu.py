@@ -1,0 +1,142 @@
+"""GPU parity tests of the encoder: HIP kernels (through the C ABI) vs plain
+PyTorch fp32 references of the same ops and vs the oracle / golden tensors.
+Tolerances: bf16 operands with f32 accumulation -> relative 1e-2 on GEMM
+outputs; embeddings within 1e-3 cosine (BASELINE.json north star)."""
+import os
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def st():
+    import abstracts_search_amd.sentence_transformers as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "encoder_tiny.npz"))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (1000, 520, 1536), (4096, 2048, 1536)])
+def test_gemm_bf16_vs_torch_fp32(st, M, N, K):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn((M, K), generator=g, device="cuda").bfloat16()
+    W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).bfloat16()
+    # asymmetric operands: a transposed or permuted fragment layout cannot pass
+    A[:, 0] += 3.0
+    W[0, :] += 0.5
+    C = st.gemm_bf16(A, W).float()
+    ref = A.float() @ W.float().T
+    err = (C - ref).abs().max().item()
+    assert err <= 1e-2 * ref.abs().max().item() + 1e-3, err
+
+
+def _split(ids, cu):
+    return [ids[cu[i]:cu[i + 1]].tolist() for i in range(len(cu) - 1)]
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_tiny_model_vs_golden(st, gold, causal):
+    from oracle import encoder_oracle as E
+    cfg = replace(E.TINY, causal=causal)
+    W = E.synth_weights(cfg, int(gold["seed"]))
+    model = st.SentenceTransformer(config=cfg.to_dict(), weights=W)
+    toks = _split(gold["ids"], gold["cu_seqlens"])
+    tag = "causal" if causal else "bidir"
+    hs = model.last_hidden_state(toks)
+    ref = gold[f"hidden_{tag}"]
+    assert hs.shape == ref.shape
+    cos = (hs * ref).sum(1) / (np.linalg.norm(hs, axis=1) * np.linalg.norm(ref, axis=1))
+    assert cos.min() > 1 - 1e-3, cos.min()
+    assert np.abs(hs - ref).max() < 0.08 * np.abs(ref).max()
+    e = model.encode_tokens(toks, batch_size=3, normalize_embeddings=True)   # several batches, re-ordered by length
+    cos = (e * gold[f"embed_{tag}"]).sum(1)
+    assert cos.min() > 1 - 1e-3, cos
+    assert np.allclose(np.linalg.norm(e, axis=1), 1.0, atol=1e-4)
+    raw = model.encode_tokens(toks, batch_size=32, normalize_embeddings=False)
+    ref_raw = gold[f"embed_raw_{tag}"]
+    assert np.abs(raw - ref_raw).max() < 0.03 * np.abs(ref_raw).max() + 1e-3
+
+
+def test_batching_invariance(st, gold):
+    """an embedding does not depend on which other sequences share its batch"""
+    from oracle import encoder_oracle as E
+    W = E.synth_weights(E.TINY, 7)
+    model = st.SentenceTransformer(config=E.TINY.to_dict(), weights=W)
+    toks = _split(gold["ids"], gold["cu_seqlens"])
+    a = model.encode_tokens(toks, batch_size=32, normalize_embeddings=True)
+    b = model.encode_tokens(toks, batch_size=1, normalize_embeddings=True)
+    assert np.abs(a - b).max() < 2e-3
+    c = model.encode_tokens(toks[::-1], batch_size=2, normalize_embeddings=True)[::-1]
+    assert np.abs(a - c).max() < 2e-3
+
+
+def test_errors(st):
+    from oracle import encoder_oracle as E
+    model = st.SentenceTransformer(config=E.TINY.to_dict())
+    with pytest.raises(RuntimeError, match="not loaded"):
+        model.encode_tokens([[1, 2, 3]])
+    model.load_weights(E.synth_weights(E.TINY, 7))
+    with pytest.raises(RuntimeError, match="longer than max_seq_len"):
+        model.encode_tokens([[1] * (E.TINY.max_seq_len + 1)])
+    with pytest.raises(RuntimeError, match="out of range"):
+        model.encode_tokens([[E.TINY.vocab_size]])
+    with pytest.raises(RuntimeError, match="no tokenizer"):
+        model.encode("hello")
+
+
+def test_model_directory_and_text_encode(st, tmp_path):
+    """the sentence-transformers directory layout + tokenizer + prompts path"""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from oracle import encoder_oracle as E
+    cfg = E.TINY
+    W = E.synth_weights(cfg, 11)
+    d = tmp_path / "model"
+    (d / "2_Dense_64").mkdir(parents=True)
+    json.dump(dict(hidden_size=cfg.hidden, num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads,
+                   head_dim=cfg.head_dim, num_hidden_layers=cfg.n_layers, intermediate_size=cfg.intermediate,
+                   vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+                   max_position_embeddings=cfg.max_seq_len, is_causal=False), open(d / "config.json", "w"))
+    save_file({("model." + k): v.bfloat16() for k, v in W.items() if not k.startswith("dense.")},
+              str(d / "model.safetensors"))
+    save_file({"linear.weight": W["dense.weight"], "linear.bias": W["dense.bias"]},
+              str(d / "2_Dense_64" / "model.safetensors"))
+    json.dump(dict(in_features=cfg.hidden, out_features=cfg.dense_out, bias=True), open(d / "2_Dense_64" / "config.json", "w"))
+    json.dump([dict(idx=0, name="0", path="", type="sentence_transformers.models.Transformer"),
+               dict(idx=1, name="1", path="1_Pooling", type="sentence_transformers.models.Pooling"),
+               dict(idx=2, name="2", path="2_Dense_64", type="sentence_transformers.models.Dense")],
+              open(d / "modules.json", "w"))
+    json.dump(dict(prompts={"s2p_query": "query: "}, default_prompt_name=None), open(d / "config_sentence_transformers.json", "w"))
+    json.dump(dict(max_seq_length=32), open(d / "sentence_bert_config.json", "w"))
+    vocab = {f"w{i}": i for i in range(cfg.vocab_size - 3)}
+    vocab.update({"query": cfg.vocab_size - 3, ":": cfg.vocab_size - 2, "[UNK]": cfg.vocab_size - 1})
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tk.save(str(d / "tokenizer.json"))
+
+    model = st.SentenceTransformer(str(d), trust_remote_code=True)
+    assert model.get_sentence_embedding_dimension() == cfg.dense_out and model.max_seq_length == 32
+    docs = ["w1 w2 w3 w4", "w9", "w5 w5 w7 unknownword w8 " * 20]
+    e = model.encode(docs, batch_size=2, normalize_embeddings=True)
+    assert e.shape == (3, cfg.dense_out) and e.dtype == np.float32
+    one = model.encode(docs[0], normalize_embeddings=True)
+    assert one.shape == (cfg.dense_out,) and np.abs(one - e[0]).max() < 2e-3
+    ids = [model.tokenize([s])[0] for s in docs]
+    assert len(ids[2]) == 32                                      # truncated to max_seq_length
+    cu = np.concatenate([[0], np.cumsum([len(i) for i in ids])])
+    ref = E.encode(replace(cfg, max_seq_len=32), W, np.concatenate(ids), cu, True).numpy()
+    assert ((e * ref).sum(1) > 1 - 1e-3).all()
+    qp = model.encode(docs[0], prompt_name="s2p_query", normalize_embeddings=True)
+    qm = model.encode("query: " + docs[0], normalize_embeddings=True)
+    assert np.abs(qp - qm).max() < 1e-6 and np.abs(qp - one).max() > 1e-3
+    with pytest.raises(ValueError, match="not found"):
+        model.encode(docs[0], prompt_name="nope")
