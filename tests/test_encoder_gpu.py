@@ -140,3 +140,50 @@ def test_model_directory_and_text_encode(st, tmp_path):
     assert np.abs(qp - qm).max() < 1e-6 and np.abs(qp - one).max() > 1e-3
     with pytest.raises(ValueError, match="not found"):
         model.encode(docs[0], prompt_name="nope")
+
+
+def _rand_weights_gpu(cfg, seed):
+    """random-init bf16 weights of a given architecture, generated on the GPU"""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+
+    def rnd(shape, scale):
+        return (torch.randn(shape, generator=g, device="cuda") * scale).bfloat16()
+
+    H, I = cfg["hidden"], cfg["intermediate"]
+    qc, kc = cfg["n_heads"] * cfg["head_dim"], cfg["n_kv_heads"] * cfg["head_dim"]
+    W = {"embed_tokens.weight": rnd((cfg["vocab_size"], H), 0.3), "norm.weight": 1 + rnd((H,), 0.1),
+         "dense.weight": rnd((cfg["dense_out"], H), H ** -0.5), "dense.bias": rnd((cfg["dense_out"],), 0.1)}
+    for l in range(cfg["n_layers"]):
+        p = f"layers.{l}."
+        W.update({p + "input_layernorm.weight": 1 + rnd((H,), 0.1), p + "post_attention_layernorm.weight": 1 + rnd((H,), 0.1),
+                  p + "self_attn.q_proj.weight": rnd((qc, H), H ** -0.5), p + "self_attn.q_proj.bias": rnd((qc,), 0.1),
+                  p + "self_attn.k_proj.weight": rnd((kc, H), H ** -0.5), p + "self_attn.k_proj.bias": rnd((kc,), 0.1),
+                  p + "self_attn.v_proj.weight": rnd((kc, H), H ** -0.5), p + "self_attn.v_proj.bias": rnd((kc,), 0.1),
+                  p + "self_attn.o_proj.weight": rnd((H, qc), qc ** -0.5), p + "mlp.gate_proj.weight": rnd((I, H), H ** -0.5),
+                  p + "mlp.up_proj.weight": rnd((I, H), H ** -0.5), p + "mlp.down_proj.weight": rnd((H, I), I ** -0.5)})
+    return W
+
+
+def test_stella_shape_full_depth_vs_oracle(st):
+    """BASELINE.json's encoder at its real shape (1536 hidden, 28 layers, 12/2
+    heads of 128, 8960 MLP, Dense 1024; vocabulary cut to 4096 rows to bound the
+    test's memory) with random-init weights: embeddings within 1e-3 cosine of the
+    fp32 CPU oracle, the north star's tolerance."""
+    import torch
+    from oracle import encoder_oracle as E
+    cfg = dict(st.STELLA_EN_1_5B_V5)
+    cfg["vocab_size"] = 4096
+    W = _rand_weights_gpu(cfg, 5)
+    model = st.SentenceTransformer(config=cfg, weights=W)
+    rng = np.random.default_rng(5)
+    lens = [3, 40, 130, 64, 17]
+    toks = [rng.integers(0, cfg["vocab_size"], L).tolist() for L in lens]
+    e = model.encode_tokens(toks, batch_size=8, normalize_embeddings=True)
+    ocfg = E.EncoderConfig(**cfg)
+    Wc = {k: v.float().cpu() for k, v in W.items()}
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    with torch.no_grad():
+        ref = E.encode(ocfg, Wc, np.concatenate(toks), cu, True).numpy()
+    cos = (e * ref).sum(1)
+    assert cos.min() > 1 - 1e-3, cos

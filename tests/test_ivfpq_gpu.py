@@ -299,3 +299,61 @@ def test_train_builds_a_usable_index(faiss):
     recall = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(I, If)])
     assert recall > 0.5, recall
     assert (D[:, :-1] >= D[:, 1:]).all()
+
+
+def test_cfg2_full_size_properties(faiss, oracle):
+    """BASELINE.json configs[1] at full size (1M x 1024, IVF4096,PQ64, batch 64):
+    size-independent properties + oracle parity on the full index."""
+    import torch
+    import abstracts_search_amd.synth as synth
+    n, d, nlist, M = 1_000_000, 1024, 4096, 64
+    x = synth.corpus_cuda(n, d)
+    idx = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT)
+    idx.cp.niter = 4
+    idx.train(x)
+    idx.add(x)
+    assert idx.ntotal == n
+    sizes = np.array([idx.list_size(l) for l in range(nlist)])
+    assert sizes.sum() == n                                   # every vector is in exactly one list
+    q = synth.queries_cuda(x, 64)
+    idx.nprobe = 16
+    D, I = idx.search(q, 10)
+    D2, I2 = idx.search(q, 10)
+    assert torch.equal(I, I2) and torch.equal(D, D2)           # idempotent / deterministic
+    Dn, In = D.cpu().numpy(), I.cpu().numpy()
+    assert (Dn[:, :-1] >= Dn[:, 1:]).all()                     # sorted best first
+    assert (In >= 0).all() and (In < n).all()
+    assert all(len(set(r.tolist())) == 10 for r in In)         # no duplicate ids
+    # the k=10 result is a prefix of the k=64 result and of the multi-pass k=100 result
+    D64, I64 = idx.search(q, 64)
+    D100, I100 = idx.search(q, 100)
+    assert torch.equal(I64[:, :10], I) and torch.equal(I100[:, :64], I64)
+    # a larger nprobe can only improve the k-th score
+    idx.nprobe = 64
+    Dw, _ = idx.search(q, 10)
+    assert (Dw[:, -1] >= D[:, -1]).all()
+    # permuting the queries permutes the rows
+    perm = torch.randperm(64, device="cuda")
+    idx.nprobe = 16
+    Dp, Ip = idx.search(q[perm].contiguous(), 10)
+    assert torch.equal(Ip, I[perm]) and torch.equal(Dp, D[perm])
+    # oracle parity on the full index (codes pulled back from the library)
+    cent, cb = idx.get_centroids(), idx.get_codebook()
+    off = np.zeros(nlist + 1, np.int64)
+    np.cumsum(sizes, out=off[1:])
+    codes = np.empty((n, M), np.uint8)
+    ids = np.empty(n, np.int64)
+    for l in range(nlist):
+        if sizes[l]:
+            codes[off[l]:off[l + 1]], ids[off[l]:off[l + 1]] = idx.get_list(l)
+    qh = q.cpu().numpy()
+    De, Ie = oracle.search(qh, cent, cb, off, codes, ids, 16, 10)
+    assert np.array_equal(In, Ie)
+    assert np.array_equal(bits(Dn), bits(De))
+    # and the stored codes are the oracle's encoding of the same rows (sample)
+    rows = np.arange(0, n, 9973)[:64]
+    ln, cs = oracle.encode(x[torch.as_tensor(rows, device="cuda")].cpu().numpy(), cent, cb)
+    pos = {int(i): p for p, i in enumerate(ids)}
+    for r, l, c in zip(rows, ln, cs):
+        p = pos[int(r)]
+        assert off[l] <= p < off[l + 1] and np.array_equal(codes[p], c)
