@@ -169,6 +169,25 @@ const void *to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t 
 // handles
 // ------------------------------------------------------------------
 
+// per-stream search workspaces (see mi_index::ws_sets)
+struct SearchWS {
+    DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters;
+    size_t counters_zeroed = 0;  // bytes of `counters` known to be zero
+    // most recent scan launch on this stream (mi_index_profile_scan replays it)
+    ScanArgs last_scan{};
+    bool have_last_scan = false;
+    int64_t last_nq = 0;
+    int last_nprobe = 0;
+    // optional side stream for the LUT kernel (MI_SIDE_STREAM=1; measured slower)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~SearchWS() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
+    }
+};
+
 struct mi_index {
     int d = 0, nlist = 0, M = 0, dsub = 0, metric = 0, by_residual = 1, device = 0;
     bool has_coarse = false, has_codebook = false;
@@ -181,28 +200,14 @@ struct mi_index {
     // device image (group-interleaved, see ivfpq_kernels.h)
     DevBuf d_codes, d_ids, d_goff, d_len;
     int64_t ngroups = 0;
-    // workspaces
-    DevBuf ws_q, ws_scores, ws_cidx, ws_cdis, ws_lut, ws_ps, ws_pid, ws_bs, ws_bid, ws_D, ws_I;
-    DevBuf ws_pgoff, ws_plen, ws_pprefix, ws_counters;
-    size_t counters_zeroed = 0;  // bytes of ws_counters known to be zero
-    DevBuf ws_x, ws_assign, ws_codes, ws_ids, ws_count;
-    // most recent scan launch (mi_index_profile_scan replays it)
-    ScanArgs last_scan{};
-    bool have_last_scan = false;
-    int64_t last_nq = 0;
-    int last_nprobe = 0;
-
-    // side stream: the LUT kernel is independent of coarse GEMM + select and
-    // runs beside them (fork/join with events; capturable in a hipGraph)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // search workspaces: one set per stream the index is searched on, so that
+    // batches issued on different streams overlap on the GPU (a serving loop
+    // round-robins 2-4 streams; each kernel of one batch leaves most CUs idle)
+    std::vector<std::pair<void *, std::unique_ptr<SearchWS>>> ws_sets;
+    // add()/encode() workspaces
+    DevBuf ws_scores, ws_x, ws_assign, ws_codes, ws_ids, ws_count;
 
     int nch() const { return (M + 15) / 16; }
-    ~mi_index() {
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side) (void)hipStreamDestroy(side);
-    }
 };
 
 struct mi_flat {
@@ -213,6 +218,14 @@ struct mi_flat {
 };
 
 namespace {
+
+SearchWS &ws_for(mi_index *h, void *stream) {
+    for (auto &kv : h->ws_sets)
+        if (kv.first == stream) return *kv.second;
+    MI_REQUIRE(h->ws_sets.size() < 16, "too many distinct streams on one index handle (max 16)");
+    h->ws_sets.emplace_back(stream, std::make_unique<SearchWS>());
+    return *h->ws_sets.back().second;
+}
 
 void require_trained(mi_index *h) {
     MI_REQUIRE(h->has_coarse && h->has_codebook, "index is not trained (set_coarse/set_codebook)");
@@ -496,22 +509,23 @@ int mi_index_get_list(mi_index *h, int list_no, uint8_t *codes, int64_t *ids) {
 int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_avg, int64_t *scan_bytes) {
     return guard([&] {
         MI_REQUIRE(h && reps >= 1, "bad argument");
-        MI_REQUIRE(h->have_last_scan, "mi_index_profile_scan: no search has run yet");
+        SearchWS &w = ws_for(h, stream);
+        MI_REQUIRE(w.have_last_scan, "mi_index_profile_scan: no search has run on this stream yet");
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);
         // algorithmic bytes of the launch: sum of the probed list lengths x (M + 8)
         unsigned long long *cnt = h->ws_count.as<unsigned long long>(1);
         MI_HIP(hipMemsetAsync(cnt, 0, 8, st));
-        const int64_t n = h->last_nq * h->last_nprobe;
+        const int64_t n = w.last_nq * w.last_nprobe;
         hipLaunchKernelGGL(count_codes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           h->ws_cidx.get<int32_t>(), n, h->d_len.get<int32_t>(), cnt);
+                           w.cidx.get<int32_t>(), n, h->d_len.get<int32_t>(), cnt);
         MI_HIP(hipGetLastError());
         hipEvent_t e0, e1;
         MI_HIP(hipEventCreate(&e0));
         MI_HIP(hipEventCreate(&e1));
-        launch_scan(h->M, h->last_scan, st);  // warm
+        launch_scan(h->M, w.last_scan, st);  // warm
         MI_HIP(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) launch_scan(h->M, h->last_scan, st);
+        for (int i = 0; i < reps; ++i) launch_scan(h->M, w.last_scan, st);
         MI_HIP(hipEventRecord(e1, st));
         MI_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -537,37 +551,37 @@ static int choose_nslice(const mi_index *h, int64_t nq, int nprobe) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(s, 32));
 }
 
-static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int nprobe, float *Ddev,
+static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev, int k, int nprobe, float *Ddev,
                          int64_t *Idev, hipStream_t st, int32_t *cI_out, float *cD_out,
                          float *lut_out, bool stop_after_lut) {
     const int M = h->M;
-    float *scores = h->ws_scores.as<float>((size_t)nq * h->nlist);
-    int32_t *cidx = h->ws_cidx.as<int32_t>((size_t)nq * nprobe);
-    float *cdis = h->ws_cdis.as<float>((size_t)nq * nprobe);
-    float *lut = h->ws_lut.as<float>((size_t)nq * M * 256);
+    float *scores = w.scores.as<float>((size_t)nq * h->nlist);
+    int32_t *cidx = w.cidx.as<int32_t>((size_t)nq * nprobe);
+    float *cdis = w.cdis.as<float>((size_t)nq * nprobe);
+    float *lut = w.lut.as<float>((size_t)nq * M * 256);
     const bool fork = std::getenv("MI_SIDE_STREAM") != nullptr;  // measured slower in eager mode: opt-in
     if (fork) {
-        if (!h->side) {
-            MI_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-            MI_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            MI_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        if (!w.side) {
+            MI_HIP(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
+            MI_HIP(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+            MI_HIP(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
         }
-        MI_HIP(hipEventRecord(h->ev_fork, st));
-        MI_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, h->side);
-        MI_HIP(hipEventRecord(h->ev_join, h->side));
+        MI_HIP(hipEventRecord(w.ev_fork, st));
+        MI_HIP(hipStreamWaitEvent(w.side, w.ev_fork, 0));
+        launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, w.side);
+        MI_HIP(hipEventRecord(w.ev_join, w.side));
     }
     launch_gemm(qdev, nq, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st);
     ProbeTables pt{};
     if (!stop_after_lut) {
         pt.list_goff = h->d_goff.get<int32_t>();
         pt.list_len = h->d_len.get<int32_t>();
-        pt.p_goff = h->ws_pgoff.as<int32_t>((size_t)nq * nprobe);
-        pt.p_len = h->ws_plen.as<int32_t>((size_t)nq * nprobe);
-        pt.p_prefix = h->ws_pprefix.as<int32_t>((size_t)nq * (nprobe + 1));
+        pt.p_goff = w.pgoff.as<int32_t>((size_t)nq * nprobe);
+        pt.p_len = w.plen.as<int32_t>((size_t)nq * nprobe);
+        pt.p_prefix = w.pprefix.as<int32_t>((size_t)nq * (nprobe + 1));
     }
     launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st, pt);
-    if (fork) MI_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    if (fork) MI_HIP(hipStreamWaitEvent(st, w.ev_join, 0));
     else launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
     if (cI_out) MI_HIP(hipMemcpyAsync(cI_out, cidx, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (cD_out) MI_HIP(hipMemcpyAsync(cD_out, cdis, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
@@ -576,13 +590,13 @@ static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int 
 
     const int nslice = choose_nslice(h, nq, nprobe);
     const int npass = (k + 63) / 64;
-    float *ps = h->ws_ps.as<float>((size_t)nq * nslice * 64);
-    int64_t *pid = h->ws_pid.as<int64_t>((size_t)nq * nslice * 64);
+    float *ps = w.ps.as<float>((size_t)nq * nslice * 64);
+    int64_t *pid = w.pid.as<int64_t>((size_t)nq * nslice * 64);
     float *bs = nullptr;
     int64_t *bid = nullptr;
     if (npass > 1) {
-        bs = h->ws_bs.as<float>((size_t)nq);
-        bid = h->ws_bid.as<int64_t>((size_t)nq);
+        bs = w.bs.as<float>((size_t)nq);
+        bid = w.bid.as<int64_t>((size_t)nq);
     }
     for (int pass = 0; pass < npass; ++pass) {
         const int kp = std::min(64, k - pass * 64);
@@ -603,20 +617,20 @@ static void search_chunk(mi_index *h, int64_t nq, const float *qdev, int k, int 
         a.next_bound_s = npass > 1 ? bs : nullptr; a.next_bound_id = npass > 1 ? bid : nullptr;
         if (fuse) {
             const size_t cb = (size_t)nq * sizeof(unsigned);
-            unsigned *cnt = h->ws_counters.as<unsigned>((size_t)nq);
-            if (h->counters_zeroed < h->ws_counters.cap) {  // fresh allocation: zero it once
-                MI_HIP(hipMemsetAsync(h->ws_counters.p, 0, h->ws_counters.cap, st));
-                h->counters_zeroed = h->ws_counters.cap;
+            unsigned *cnt = w.counters.as<unsigned>((size_t)nq);
+            if (w.counters_zeroed < w.counters.cap) {  // fresh allocation: zero it once
+                MI_HIP(hipMemsetAsync(w.counters.p, 0, w.counters.cap, st));
+                w.counters_zeroed = w.counters.cap;
             }
             (void)cb;
             a.counters = cnt;
         }
         launch_scan(M, a, st);
         if (pass == 0) {
-            h->last_scan = a;
-            h->have_last_scan = true;
-            h->last_nq = nq;
-            h->last_nprobe = nprobe;
+            w.last_scan = a;
+            w.have_last_scan = true;
+            w.last_nq = nq;
+            w.last_nprobe = nprobe;
         }
         if (!fuse)
             launch_merge(ps, pid, nslice, kp, (int64_t)nslice * kp, nq, kp, Ddev, Idev, k, pass * 64,
@@ -640,6 +654,7 @@ int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe, 
         if (nq == 0) return;
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);
+        SearchWS &w = ws_for(h, stream);
         nprobe = std::min(nprobe, h->nlist);
         sync_lists(h);
         const bool qd = is_device_ptr(q), Dd = is_device_ptr(D), Id = is_device_ptr(I);
@@ -647,10 +662,10 @@ int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe, 
         for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
             const int64_t m = std::min(chunk, nq - c0);
             const float *qs = q + (size_t)c0 * h->d;
-            if (!qd) qs = static_cast<const float *>(to_device(qs, (size_t)m * h->d * 4, h->ws_q, st));
-            float *Dc = Dd ? D + (size_t)c0 * k : h->ws_D.as<float>((size_t)m * k);
-            int64_t *Ic = Id ? I + (size_t)c0 * k : h->ws_I.as<int64_t>((size_t)m * k);
-            search_chunk(h, m, qs, k, nprobe, Dc, Ic, st, nullptr, nullptr, nullptr, false);
+            if (!qd) qs = static_cast<const float *>(to_device(qs, (size_t)m * h->d * 4, w.q, st));
+            float *Dc = Dd ? D + (size_t)c0 * k : w.D.as<float>((size_t)m * k);
+            int64_t *Ic = Id ? I + (size_t)c0 * k : w.I.as<int64_t>((size_t)m * k);
+            search_chunk(h, w, m, qs, k, nprobe, Dc, Ic, st, nullptr, nullptr, nullptr, false);
             if (!Dd) MI_HIP(hipMemcpyAsync(D + (size_t)c0 * k, Dc, (size_t)m * k * 4, hipMemcpyDeviceToHost, st));
             if (!Id) MI_HIP(hipMemcpyAsync(I + (size_t)c0 * k, Ic, (size_t)m * k * 8, hipMemcpyDeviceToHost, st));
             if (!qd || !Dd || !Id) MI_HIP(hipStreamSynchronize(st));
@@ -666,14 +681,15 @@ int mi_index_coarse_lut(mi_index *h, int64_t nq, const float *q, int nprobe, int
         require_trained(h);
         if (nq == 0) return;
         DeviceGuard dg(h->device);
+        SearchWS &w = ws_for(h, nullptr);
         nprobe = std::min(nprobe, h->nlist);
         const int64_t chunk = query_chunk_size(h);
         const bool qd = is_device_ptr(q);
         for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
             const int64_t m = std::min(chunk, nq - c0);
             const float *qs = q + (size_t)c0 * h->d;
-            if (!qd) qs = static_cast<const float *>(to_device(qs, (size_t)m * h->d * 4, h->ws_q, nullptr));
-            search_chunk(h, m, qs, 1, nprobe, nullptr, nullptr, nullptr,
+            if (!qd) qs = static_cast<const float *>(to_device(qs, (size_t)m * h->d * 4, w.q, nullptr));
+            search_chunk(h, w, m, qs, 1, nprobe, nullptr, nullptr, nullptr,
                          cI ? cI + (size_t)c0 * nprobe : nullptr, cD ? cD + (size_t)c0 * nprobe : nullptr,
                          lut ? lut + (size_t)c0 * h->M * 256 : nullptr, true);
             MI_HIP(hipStreamSynchronize(nullptr));

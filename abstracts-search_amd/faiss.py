@@ -372,12 +372,17 @@ class IndexIVFPQ:
         _check(_Lib.get().mi_index_search(self._h, nq, _ptr(x), k, nprobe, _ptr(D), _ptr(I), c_void_p(0)))
         return D, I
 
-    def search_into(self, x, k: int, D, I, nprobe: int | None = None):
+    def search_into(self, x, k: int, D, I, nprobe: int | None = None, stream: int | None = None):
         """search() into caller-owned CUDA tensors (no allocation; what a
-        captured / steady-state serving loop uses)."""
-        nprobe = int(self.nprobe if nprobe is None else nprobe)
-        _check(_Lib.get().mi_index_search(self._h, x.shape[0], _ptr(x), k, nprobe, _ptr(D), _ptr(I),
-                                          _current_stream()))
+        steady-state serving loop uses).  `stream`: raw hipStream_t (int), default
+        torch's current stream; the library keeps one workspace set per stream,
+        so batches issued on different streams overlap on the GPU."""
+        nprobe = self.nprobe if nprobe is None else nprobe
+        st = _current_stream() if stream is None else c_void_p(stream)
+        rc = _Lib.get().mi_index_search(self._h, x.shape[0], c_void_p(x.data_ptr()), k, nprobe,
+                                        c_void_p(D.data_ptr()), c_void_p(I.data_ptr()), st)
+        if rc:
+            _check(rc)
 
     def coarse_and_lut(self, x, nprobe: int | None = None, want_lut: bool = True):
         """Steps 1-2 of search for parity tests: (coarse_I, coarse_D, lut)."""
@@ -393,11 +398,12 @@ class IndexIVFPQ:
         return cI, cD, lut
 
     # -- scan-kernel timing (HIP events on the launch stream) ------------
-    def profile_scan(self, reps: int = 50):
-        """Replays the scan kernel of the last search `reps` times between two
-        HIP events on the current stream -> {"scan_ms_avg", "scan_bytes"}."""
+    def profile_scan(self, reps: int = 50, stream: int | None = None):
+        """Replays the scan kernel of the last search on `stream` `reps` times
+        between two HIP events on that stream -> {"scan_ms_avg", "scan_bytes"}."""
         ms, b = c_double(0), c_int64(0)
-        _check(_Lib.get().mi_index_profile_scan(self._h, int(reps), _current_stream(),
+        st = _current_stream() if stream is None else c_void_p(stream)
+        _check(_Lib.get().mi_index_profile_scan(self._h, int(reps), st,
                                                 ctypes.byref(ms), ctypes.byref(b)))
         return {"scan_ms_avg": ms.value, "scan_bytes": b.value}
 

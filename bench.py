@@ -48,8 +48,8 @@ def main():
     ap.add_argument("--train-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
-    ap.add_argument("--graph", type=int, default=0,
-                    help="replay the step from a captured hipGraph (measured slower than eager: off)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="HIP streams the steps are issued round-robin on (batches overlap on the GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -91,44 +91,32 @@ def main():
     qpool = synth.queries_cuda(x, NB * args.batch * world, seed=4321).view(NB, world, args.batch, d)
     my_q = [qpool[b, rank].contiguous() for b in range(NB)]
     nq_out = args.batch
-    D = torch.empty((nq_out, k), dtype=torch.float32, device=dev)
-    I = torch.empty((nq_out, k), dtype=torch.int64, device=dev)
+    # steps are independent query batches: they are issued round-robin on S
+    # streams (each with its own output buffers and library workspaces) so that
+    # consecutive batches overlap on the GPU, as a serving loop would run them
+    S = max(1, args.streams) if world == 1 else 1
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    Ds = [torch.empty((nq_out, k), dtype=torch.float32, device=dev) for _ in range(S)]
+    Is = [torch.empty((nq_out, k), dtype=torch.int64, device=dev) for _ in range(S)]
+    D, I = Ds[0], Is[0]
+    torch.cuda.synchronize()
+
+    sptr = [int(s_.cuda_stream) for s_ in streams]
 
     def step(b):
         if sharded is None:
-            index.search_into(my_q[b % NB], k, D, I)
+            j = b % S
+            index.search_into(my_q[b % NB], k, Ds[j], Is[j], None, sptr[j])
         else:
             sharded.search_into(my_q[b % NB], k, D, I)
 
-    # ---- optional hipGraph replay of the step (launch-bound inner loop)
-    graphs = None
-    for b in range(min(args.warmup, NB) or 1):
+    for b in range(max(args.warmup, 2 * S)):
         step(b)
     torch.cuda.synchronize()
-    if args.graph and sharded is None:
-        try:
-            graphs = []
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for b in range(NB):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=s, capture_error_mode="relaxed"):
-                        step(b)
-                    graphs.append(g)
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-        except Exception as e:  # capture is an optimisation, never a requirement
-            log(f"[rank {rank}] hipGraph capture unavailable ({type(e).__name__}: {e}); eager launches")
-            graphs = None
-            torch.cuda.synchronize()
 
     def run(nsteps, first=0):
         for i in range(nsteps):
-            if graphs is not None:
-                graphs[(first + i) % NB].replay()
-            else:
-                step(first + i)
+            step(first + i)
 
     def barrier():
         if world > 1:
@@ -151,9 +139,10 @@ def main():
     # ---- roofline of the dominant kernel (PQ-code scan): the library re-launches
     # the scan of the last step K times back to back between two HIP events
     # recorded on the launch stream (per-launch events cost more than the kernel)
-    step(args.warmup)
     torch.cuda.synchronize()
-    prof = index.profile_scan(args.steps)
+    index.search_into(my_q[0], k, Ds[0], Is[0], None, sptr[0])
+    prof = index.profile_scan(args.steps, sptr[0])
+    torch.cuda.synchronize()
     scan_ms = prof["scan_ms_avg"]
     scan_bytes = prof["scan_bytes"]
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
@@ -192,7 +181,7 @@ def main():
                        "corpus": args.corpus, "nlist": args.nlist, "M": 64, "nprobe": args.nprobe,
                        "k": k, "batch_per_rank": args.batch, "global_batch": args.batch * world,
                        "parallelism": "1 GPU" if world == 1 else f"vector-sharded x{world} + all-gather top-k",
-                       "launch": "hipGraph replay" if graphs is not None else "eager"},
+                       "launch": "eager (a hipGraph replay of the step measured slower)", "streams": S},
             "recall_at_10": None if recall is None else round(recall, 4),
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -22,8 +22,9 @@
  *     reference's normalised stella embeddings use); MI_METRIC_L2 is rejected.
  *   - nbits == 8 only (one byte per sub-quantiser, ksub = 256).
  *   - handles are opaque, freed only by *_destroy; one handle per device.
- *   - search is safe for concurrent readers on different streams only if each
- *     uses its own handle; add/train-type calls are exclusive.
+ *   - one host thread drives a handle.  mi_index_search() keeps one set of
+ *     workspaces per stream it is called with (up to 16), so batches issued on
+ *     different streams overlap on the GPU; add/train-type calls are exclusive.
  *   - result semantics (faiss): best first; unfilled slots I = -1,
  *     D = -FLT_MAX.  Exact score ties are ordered by ascending id.
  */
