@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -27,6 +28,25 @@ struct LayerW {
 void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
     MI_REQUIRE(g.K % 64 == 0, "encoder GEMM: K must be a multiple of 64");
     MI_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "encoder GEMM: leading dimensions must be multiples of 8");
+    MI_REQUIRE(g.N % 4 == 0 && g.ldc % 4 == 0, "encoder GEMM: N and ldc must be multiples of 4");
+    // big problems: 256x256 tiles, 8 waves, 4-stage LDS-DMA ring; small ones: 128x128
+    const bool big = g.M >= 512 && g.N >= 256 && g.K % 32 == 0 && !std::getenv("MI_GEMM128");
+    if (big) {
+        g.tiles_m = (g.M + 255) / 256;
+        g.tiles_n = (g.N + 255) / 256;
+        const int ntiles = g.tiles_m * g.tiles_n;
+        const int per = (ntiles + 7) / 8;
+        dim3 grid(8 * per), block(512);
+        switch (epi) {
+            case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_256_kernel<EPI_STORE>), grid, block, 0, st, g); break;
+            case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_256_kernel<EPI_RESID>), grid, block, 0, st, g); break;
+            case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_256_kernel<EPI_QKV>), grid, block, 0, st, g); break;
+            case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_256_kernel<EPI_SWIGLU>), grid, block, 0, st, g); break;
+            default: throw Error("bad epilogue");
+        }
+        MI_HIP(hipGetLastError());
+        return;
+    }
     g.tiles_m = (g.M + 127) / 128;
     g.tiles_n = (g.N + 127) / 128;
     const int ntiles = g.tiles_m * g.tiles_n;

@@ -107,6 +107,37 @@ __global__ void __launch_bounds__(256)
 // lane-linear), which makes the ds_read_b128 fragment reads conflict-free.
 // Requires K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned bases.
 // ---------------------------------------------------------------------
+// LDS-DMA of 16 bytes per lane: LDS address = wave-uniform base + lane*16.
+// Issued through inline asm on purpose: hipcc tracks the builtin form as an LDS
+// write and inserts `s_waitcnt vmcnt(0)` before the next ds_read of the same
+// array, which drains the whole prefetch ring every K step (measured: every
+// variant of the GEMM stuck at ~700 TFLOP/s).  With the DMA invisible to the
+// compiler the waits are ours: counted `s_waitcnt vmcnt(N)` + s_barrier.
+__device__ __forceinline__ void dma16(const void *gptr, void *lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n" ::"s"(m0v), "v"(gptr) : "memory");
+}
+
+// Tile order.  Block b runs on XCD b % 8 (each XCD has its own 4 MiB L2), so the
+// 8 XCDs each take a contiguous eighth of the tile sequence, and the sequence
+// itself is "grouped": GM consecutive M tiles are walked together along N, so
+// the ~32 tiles an XCD has in flight form a GM x 4 patch that shares GM A row
+// blocks and 4 W strips in L2 instead of streaming a different W strip per tile.
+__device__ __forceinline__ bool tile_coords(int tiles_m, int tiles_n, int &tm, int &tn) {
+    constexpr int GM = 8;
+    const int ntiles = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int per = (ntiles + 7) / 8;
+    const int t = (bid & 7) * per + (bid >> 3);
+    if (t >= ntiles || (bid >> 3) >= per) return false;
+    const int group = t / (GM * tiles_n), within = t - group * (GM * tiles_n);
+    const int gm = min(GM, tiles_m - group * GM);
+    tn = within / gm;
+    tm = group * GM + (within - tn * gm);
+    return true;
+}
+
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3 };
 
 struct GemmArgs {
@@ -121,6 +152,76 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
+// 4x4 transpose across the 4 lanes of a quad (DPP quad_perm, no LDS): before,
+// lane b of the quad holds C[4*lg + r][4a + b] in v[r]; after, it holds
+// C[4*lg + b][4a + c] in v[c] -- four consecutive columns of one row, so the
+// epilogue stores 8 or 16 bytes per lane instead of four scattered elements.
+__device__ __forceinline__ float dpp_quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+}
+__device__ __forceinline__ f32x4 quad_transpose(f32x4 v, int lane) {
+    const bool odd = lane & 1, hi = lane & 2;
+    float r0 = dpp_quad_xor1(odd ? v[0] : v[1]);
+    float r1 = dpp_quad_xor1(odd ? v[2] : v[3]);
+    if (odd) { v[0] = r0; v[2] = r1; } else { v[1] = r0; v[3] = r1; }
+    r0 = dpp_quad_xor2(hi ? v[0] : v[2]);
+    r1 = dpp_quad_xor2(hi ? v[1] : v[3]);
+    if (hi) { v[0] = r0; v[1] = r1; } else { v[2] = r0; v[3] = r1; }
+    return v;
+}
+
+// Epilogue of one 16x16 accumulator tile (two tiles for SwiGLU: gate and up).
+// trow = first row of the tile, tcol = first column (in C's column space).
+template <int EPI>
+__device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, f32x4 v2, int trow, int tcol, int lane) {
+    const int li = lane & 15, lg = lane >> 4;
+    if constexpr (EPI == EPI_QKV) {
+        if (tcol >= g.qk_cols) {  // V tile: 4 consecutive tokens of channel tcol+li -> one 8-byte store
+            const int col = tcol + li, row0 = trow + lg * 4;
+            if (col < g.N && row0 < g.M) {
+                const float bv = g.bias ? g.bias[col] : 0.f;
+                uint2 o;
+                o.x = pack2(v[0] + bv, v[1] + bv);
+                o.y = pack2(v[2] + bv, v[3] + bv);
+                *reinterpret_cast<uint2 *>(g.Vt + (size_t)(col - g.qk_cols) * g.ldvt + row0) = o;
+            }
+            return;
+        }
+    }
+    const int row = trow + lg * 4 + (li & 3), col0 = tcol + (li & ~3);
+    v = quad_transpose(v, lane);
+    if constexpr (EPI == EPI_SWIGLU) {
+        v2 = quad_transpose(v2, lane);
+        if (row < g.M && col0 < g.ldc) {
+            float h[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) h[c] = v[c] / (1.0f + __expf(-v[c])) * v2[c];
+            uint2 o;
+            o.x = pack2(h[0], h[1]);
+            o.y = pack2(h[2], h[3]);
+            *reinterpret_cast<uint2 *>(g.C + (size_t)row * g.ldc + col0) = o;
+        }
+    } else {
+        if (row >= g.M || col0 >= g.N) return;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias) b = *reinterpret_cast<const float4 *>(g.bias + col0);
+        if constexpr (EPI == EPI_RESID) {
+            float4 *px = reinterpret_cast<float4 *>(g.X + (size_t)row * g.ldc + col0);
+            float4 x = *px;
+            x.x += v[0] + b.x; x.y += v[1] + b.y; x.z += v[2] + b.z; x.w += v[3] + b.w;
+            *px = x;
+        } else {
+            uint2 o;
+            o.x = pack2(v[0] + b.x, v[1] + b.y);
+            o.y = pack2(v[2] + b.z, v[3] + b.w);
+            *reinterpret_cast<uint2 *>(g.C + (size_t)row * g.ldc + col0) = o;
+        }
+    }
+}
+
 template <int EPI>
 __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
     constexpr int BM = 128, BN = 128, BK = 64;
@@ -128,15 +229,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
     bf16_t *As = smem;                    // [2][BM][BK]
     bf16_t *Bs = smem + 2 * BM * BK;      // [2][BN][BK]
 
-    // XCD-aware order: the 8 XCDs each take a contiguous eighth of the tiles;
-    // within an XCD consecutive blocks walk the N tiles of one M row block
-    // (A rows stay in that XCD's L2).
-    const int ntiles = g.tiles_m * g.tiles_n;
-    const int bid = blockIdx.x;
-    const int per = (ntiles + 7) / 8;
-    const int t = (bid & 7) * per + (bid >> 3);
-    if (t >= ntiles || (bid >> 3) >= per) return;
-    const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+    int tm, tn;
+    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn)) return;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -153,12 +247,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
             const int r0 = (w * 4 + i) * 8;
             const int ra = min(m0 + r0 + srow, g.M - 1);
             const int rb = min(n0 + r0 + srow, g.N - 1);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(g.A + (size_t)ra * g.lda + k0 + scol),
-                (__attribute__((address_space(3))) void *)(As + buf * BM * BK + r0 * BK), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(g.W + (size_t)rb * g.ldw + k0 + scol),
-                (__attribute__((address_space(3))) void *)(Bs + buf * BN * BK + r0 * BK), 16, 0, 0);
+            dma16(g.A + (size_t)ra * g.lda + k0 + scol, As + buf * BM * BK + r0 * BK);
+            dma16(g.W + (size_t)rb * g.ldw + k0 + scol, Bs + buf * BN * BK + r0 * BK);
         }
     };
 
@@ -170,6 +260,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
 
     const int nk = g.K / BK;
     stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
@@ -189,55 +280,122 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA (issued above) has landed
         __syncthreads();
     }
 
-    // epilogue: lane holds rows lg*4 + r, column li of every 16x16 tile
+    // epilogue: 16x16 tiles, quad-transposed so that a lane stores 4 consecutive columns
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row0 = m0 + wm * 64 + i * 16 + lg * 4;
+        const int trow = m0 + wm * 64 + i * 16;
         if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                const int ocol = (n0 + wn * 64) / 2 + (j / 2) * 16 + li;
-                if (n0 + wn * 64 + j * 16 + li < g.N) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float gt = acc[i][j][r], up = acc[i][j + 1][r];
-                        const float h = gt / (1.0f + __expf(-gt)) * up;
-                        if (row0 + r < g.M) g.C[(size_t)(row0 + r) * g.ldc + ocol] = f2bf(h);
-                    }
-                }
-            }
+            for (int j = 0; j < 4; j += 2)
+                store_tile<EPI>(g, acc[i][j], acc[i][j + 1], trow, (n0 + wn * 64) / 2 + (j / 2) * 16, lane);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = n0 + wn * 64 + j * 16 + li;
-                if (col >= g.N) continue;
-                const float bv = g.bias ? g.bias[col] : 0.f;
-                if constexpr (EPI == EPI_QKV) {
-                    if (col >= g.qk_cols) {  // V: 4 consecutive tokens of one channel -> one 8-byte store
-                        if (row0 < g.M) {
-                            uint2 o;
-                            o.x = pack2(acc[i][j][0] + bv, acc[i][j][1] + bv);
-                            o.y = pack2(acc[i][j][2] + bv, acc[i][j][3] + bv);
-                            *reinterpret_cast<uint2 *>(g.Vt + (size_t)(col - g.qk_cols) * g.ldvt + row0) = o;
-                        }
-                        continue;
-                    }
-                }
+            for (int j = 0; j < 4; ++j) store_tile<EPI>(g, acc[i][j], acc[i][j], trow, n0 + wn * 64 + j * 16, lane);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------
+// 256x256 variant for the large GEMMs: 8 waves (2 x 4) of 128x64, K step 32,
+// a 4-stage LDS ring (128 KiB) filled by LDS-DMA three tiles ahead.  Waits are
+// counted (`s_waitcnt vmcnt(8/4/0)`: only the tile needed next must have
+// landed) and the barrier is the raw s_barrier, so the DMA of later tiles
+// stays in flight across it instead of being drained every step.
+// LDS rows are 64 B; 16-byte slot index XORed with (-(row >> 2)) & 3.
+// Requires M % 256 == 0 (rows are clamped anyway), K % 32 == 0.
+// ---------------------------------------------------------------------
+template <int EPI>
+__global__ void __launch_bounds__(512) gemm_bf16_256_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 32, ST = 4;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[ST * (BM + BN) * BK];  // 128 KiB
+
+    int tm, tn;
+    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn)) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w & 1, wn = w >> 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    // DMA: one instruction moves 16 rows x 64 B; a wave issues 2 for A and 2 for B per stage
+    const int srow = lane >> 2;
+    const int scol = ((lane & 3) ^ ((0 - (lane >> 4)) & 3)) * 8;   // row>>2 & 3 == lane>>4 (pieces are 16 rows)
+    const bf16_t *srcA[2], *srcB[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = row0 + r;
-                    if (row >= g.M) continue;
-                    if constexpr (EPI == EPI_RESID) {
-                        float *px = g.X + (size_t)row * g.ldc + col;
-                        *px = *px + acc[i][j][r] + bv;
-                    } else {
-                        g.C[(size_t)row * g.ldc + col] = f2bf(acc[i][j][r] + bv);
-                    }
-                }
-            }
+    for (int i = 0; i < 2; ++i) {
+        const int r0 = (w * 2 + i) * 16;
+        srcA[i] = g.A + (size_t)min(m0 + r0 + srow, g.M - 1) * g.lda + scol;
+        srcB[i] = g.W + (size_t)min(n0 + r0 + srow, g.N - 1) * g.ldw + scol;
+    }
+    auto issue = [&](int stage, int k0) {
+        bf16_t *As = smem + stage * (BM + BN) * BK;
+        bf16_t *Bs = As + BM * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r0 = (w * 2 + i) * 16;
+            dma16(srcA[i] + k0, As + r0 * BK);
+            dma16(srcB[i] + k0, Bs + r0 * BK);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    issue(0, 0);
+    if (nk > 1) issue(1, BK);
+    if (nk > 2) issue(2, 2 * BK);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // f(q) = (-q) & 3 with q = (row >> 2) & 3 makes each hardware 16-lane group of a
+    // ds_read_b128 hit 16 distinct 16-byte slots (the groups mix lg values)
+    const int fslot = (lg ^ ((0 - (li >> 2)) & 3)) * 8;
+    for (int t = 0; t < nk; ++t) {
+        if (t + 3 < nk) issue((t + 3) & 3, (t + 3) * BK);
+        const bf16_t *As = smem + (t & 3) * (BM + BN) * BK;
+        const bf16_t *ab = As + (wm * 128 + li) * BK + fslot;
+        const bf16_t *bb = As + BM * BK + (wn * 64 + li) * BK + fslot;
+        bf16x8 a[8], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = as_bf16x8(*reinterpret_cast<const uint4 *>(bb + j * 16 * BK));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = as_bf16x8(*reinterpret_cast<const uint4 *>(ab + i * 16 * BK));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        // tile t+1 must have landed (own DMA pieces), later tiles may stay in flight
+        if (t + 1 < nk) {
+            const int rem = min(nk - 2 - t, 2);  // tiles beyond t+1 already issued
+            if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int trow = m0 + wm * 128 + i * 16;
+        if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2)
+                store_tile<EPI>(g, acc[i][j], acc[i][j + 1], trow, (n0 + wn * 64) / 2 + (j / 2) * 16, lane);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) store_tile<EPI>(g, acc[i][j], acc[i][j], trow, n0 + wn * 64 + j * 16, lane);
         }
     }
 }
