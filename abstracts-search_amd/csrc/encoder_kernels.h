@@ -350,6 +350,36 @@ __global__ void __launch_bounds__(512) gemm_bf16_256_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.K / BK;
+    // Software pipeline: while the MFMAs of tile t run out of one register set,
+    // the fragments of tile t+1 are read from LDS into the other set and the DMA
+    // of tiles t+2, t+3 is in flight (ring of 4 stages, prefetch distance 3).
+    const int fslot = (lg ^ ((0 - (li >> 2)) & 3)) * 8;  // f(q) = (-q)&3: conflict-free b128 groups
+    const int a_off = (wm * 128 + li) * BK + fslot, b_off = BM * BK + (wn * 64 + li) * BK + fslot;
+    bf16x8 a0[8], b0[4], a1[8], b1[4];
+    auto read_frags = [&](int tile, bf16x8(&a)[8], bf16x8(&b)[4]) {
+        const bf16_t *base = smem + (tile & 3) * (BM + BN) * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = as_bf16x8(*reinterpret_cast<const uint4 *>(base + b_off + j * 16 * BK));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = as_bf16x8(*reinterpret_cast<const uint4 *>(base + a_off + i * 16 * BK));
+    };
+    auto mma = [&](const bf16x8(&a)[8], const bf16x8(&b)[4]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    // tile `next` must have landed in every wave's view before it is read:
+    // own DMA pieces by counted vmcnt (tile next+1 may stay in flight), the other
+    // waves' pieces by the barrier; lgkmcnt(0) first so that no ds_read of the
+    // stage about to be overwritten is still pending when the DMA is issued.
+    auto arrive = [&](int next) {
+        if (next + 1 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
     issue(0, 0);
     if (nk > 1) issue(1, BK);
     if (nk > 2) issue(2, 2 * BK);
@@ -357,33 +387,22 @@ __global__ void __launch_bounds__(512) gemm_bf16_256_kernel(GemmArgs g) {
     else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-
-    // f(q) = (-q) & 3 with q = (row >> 2) & 3 makes each hardware 16-lane group of a
-    // ds_read_b128 hit 16 distinct 16-byte slots (the groups mix lg values)
-    const int fslot = (lg ^ ((0 - (li >> 2)) & 3)) * 8;
-    for (int t = 0; t < nk; ++t) {
-        if (t + 3 < nk) issue((t + 3) & 3, (t + 3) * BK);
-        const bf16_t *As = smem + (t & 3) * (BM + BN) * BK;
-        const bf16_t *ab = As + (wm * 128 + li) * BK + fslot;
-        const bf16_t *bb = As + BM * BK + (wn * 64 + li) * BK + fslot;
-        bf16x8 a[8], b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = as_bf16x8(*reinterpret_cast<const uint4 *>(bb + j * 16 * BK));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = as_bf16x8(*reinterpret_cast<const uint4 *>(ab + i * 16 * BK));
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        // tile t+1 must have landed (own DMA pieces), later tiles may stay in flight
+    read_frags(0, a0, b0);
+    for (int t = 0; t < nk; t += 2) {
         if (t + 1 < nk) {
-            const int rem = min(nk - 2 - t, 2);  // tiles beyond t+1 already issued
-            if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            arrive(t + 1);
+            read_frags(t + 1, a1, b1);
         }
-        __builtin_amdgcn_s_barrier();
+        if (t + 3 < nk) issue((t + 3) & 3, (t + 3) * BK);
+        mma(a0, b0);
+        if (t + 1 < nk) {
+            if (t + 2 < nk) {
+                arrive(t + 2);
+                read_frags(t + 2, a0, b0);
+            }
+            if (t + 4 < nk) issue((t + 4) & 3, (t + 4) * BK);
+            mma(a1, b1);
+        }
     }
 
 #pragma unroll
