@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--train-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--workload", choices=["search", "encode"], default="search",
+                    help="search = cfg2 (the headline line); encode = cfg3 (stella_en_1.5B_v5 bf16 batch encode)")
+    ap.add_argument("--encode-batch", type=int, default=128, help="abstracts per encode step")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the steps are issued round-robin on (batches overlap on the GPU)")
     args = ap.parse_args()
@@ -63,8 +66,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_SHARDED"):
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload == "encode":
+        return encode_workload(args, np, torch, dist, world, rank, local_rank, dev)
 
     import abstracts_search_amd.faiss as faiss
     import abstracts_search_amd.synth as synth
@@ -77,14 +85,28 @@ def main():
     x = synth.corpus_cuda(args.corpus, d, device=local_rank)
     index = faiss.IndexIVFPQ(d, args.nlist, M, 8, faiss.METRIC_INNER_PRODUCT, device=local_rank)
     index.cp.niter = args.train_iters
-    index.train(x)                       # identical on every rank (same data, same seeds)
-    if world > 1:
+    force_sharded = bool(os.environ.get("BENCH_FORCE_SHARDED"))   # exercise the N>1 plumbing on one GPU
+    if world > 1 or force_sharded:
+        # rank 0 trains; centroids and codebook are broadcast so that every shard
+        # quantises with bit-identical tables (k-means uses atomic scatter-adds)
+        cent = torch.empty((args.nlist, d), dtype=torch.float32, device=dev)
+        cb = torch.empty((M, 256, d // M), dtype=torch.float32, device=dev)
+        if rank == 0:
+            index.train(x)
+            cent.copy_(torch.from_numpy(index.get_centroids()))
+            cb.copy_(torch.from_numpy(index.get_codebook()))
+        if dist.is_initialized():
+            dist.broadcast(cent, 0)
+            dist.broadcast(cb, 0)
+        index.set_centroids(cent)
+        index.set_codebook(cb)
         ids = torch.arange(rank, args.corpus, world, device=dev)
         index.add_with_ids(x[rank::world].contiguous(), ids)
     else:
+        index.train(x)
         index.add(x)
     index.nprobe = args.nprobe
-    sharded = ShardedIndex(index) if world > 1 else None
+    sharded = ShardedIndex(index) if (world > 1 or force_sharded) else None
     log(f"[rank {rank}] setup {time.time() - t0:.1f}s ntotal={index.ntotal}")
 
     NB = 16                               # pool of distinct query batches
@@ -94,7 +116,7 @@ def main():
     # steps are independent query batches: they are issued round-robin on S
     # streams (each with its own output buffers and library workspaces) so that
     # consecutive batches overlap on the GPU, as a serving loop would run them
-    S = max(1, args.streams) if world == 1 else 1
+    S = max(1, args.streams) if (world == 1 and not force_sharded) else 1
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
     Ds = [torch.empty((nq_out, k), dtype=torch.float32, device=dev) for _ in range(S)]
     Is = [torch.empty((nq_out, k), dtype=torch.int64, device=dev) for _ in range(S)]
@@ -155,7 +177,7 @@ def main():
     if rank == 0:
         # ---- recall@10 against exact search (untimed)
         recall = None
-        if not args.no_recall and world == 1:
+        if not args.no_recall and world == 1 and sharded is None:
             flat = faiss.IndexFlatIP(d, device=local_rank)
             flat.add(x)
             hits = tot = 0
@@ -186,9 +208,120 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def encode_workload(args, np, torch, dist, world, rank, local_rank, dev):
+    """cfg3: stella_en_1.5B_v5 architecture (random-init bf16 weights -- no
+    checkpoint is reachable from the build/bench boxes), synthetic abstracts with
+    clipped log-normal token counts (median 220, max 512).  A step encodes one
+    batch of `--encode-batch` abstracts: embedding gather, 28 decoder layers,
+    mean pooling, Dense 1536->1024, L2 normalise; token ids start on the host
+    (as they do after tokenisation), embeddings stay in HBM.  N > 1: replicas,
+    every rank encodes its own batches (no collective on this path)."""
+    import abstracts_search_amd.sentence_transformers as st
+    cfg = dict(st.STELLA_EN_1_5B_V5)
+    model = st.SentenceTransformer(config=cfg, device=f"cuda:{local_rank}")
+    g = torch.Generator(device=dev).manual_seed(7)
+
+    def rnd(shape, scale):
+        return (torch.randn(shape, generator=g, device=dev) * scale).bfloat16()
+
+    H, I = cfg["hidden"], cfg["intermediate"]
+    qc, kc = cfg["n_heads"] * cfg["head_dim"], cfg["n_kv_heads"] * cfg["head_dim"]
+    model.load_weights({"embed_tokens.weight": rnd((cfg["vocab_size"], H), 0.3), "norm.weight": torch.ones(H, device=dev),
+                        "dense.weight": rnd((cfg["dense_out"], H), H ** -0.5), "dense.bias": torch.zeros(cfg["dense_out"], device=dev)})
+    for l in range(cfg["n_layers"]):
+        p = f"layers.{l}."
+        model.load_weights({
+            p + "input_layernorm.weight": torch.ones(H, device=dev), p + "post_attention_layernorm.weight": torch.ones(H, device=dev),
+            p + "self_attn.q_proj.weight": rnd((qc, H), H ** -0.5), p + "self_attn.q_proj.bias": rnd((qc,), 0.1),
+            p + "self_attn.k_proj.weight": rnd((kc, H), H ** -0.5), p + "self_attn.k_proj.bias": rnd((kc,), 0.1),
+            p + "self_attn.v_proj.weight": rnd((kc, H), H ** -0.5), p + "self_attn.v_proj.bias": rnd((kc,), 0.1),
+            p + "self_attn.o_proj.weight": rnd((H, qc), qc ** -0.5), p + "mlp.gate_proj.weight": rnd((I, H), H ** -0.5),
+            p + "mlp.up_proj.weight": rnd((I, H), H ** -0.5), p + "mlp.down_proj.weight": rnd((H, I), I ** -0.5)})
+    bs = args.encode_batch
+    rng = np.random.default_rng(7 + rank)
+    NBATCH = 8
+    batches = []
+    for _ in range(NBATCH):
+        lens = np.clip(np.exp(rng.normal(np.log(220), 0.45, bs)), 8, 512).astype(int)
+        batches.append([rng.integers(0, cfg["vocab_size"], L).tolist() for L in lens])
+    ntok = [sum(len(t) for t in b) for b in batches]
+
+    def step(i):
+        return model.encode_tokens(batches[i % NBATCH], batch_size=bs, normalize_embeddings=True, as_tensor=True)
+
+    for i in range(max(args.warmup, 1)):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    toks = sum(ntok[(args.warmup + i) % NBATCH] for i in range(args.steps))
+    # roofline of the dominant kernel (bf16 MFMA GEMMs): HIP events around the GEMM launches
+    model.profile(True)
+    step(0)
+    torch.cuda.synchronize()
+    pr = model.profile_read()
+    model.profile(False)
+    tf = pr["gemm_flops"] / (pr["gemm_ms"] * 1e-3) / 1e12
+    roofline = {"kernel": "gemm_bf16_256_kernel (QKV / O / gate-up+SwiGLU / down, 112 launches per step)",
+                "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": round(tf / 2500.0, 4), "traffic": None,
+                "flops_per_step": pr["gemm_flops"], "gemm_ms_per_step": round(pr["gemm_ms"], 3)}
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = encode_cpu_baseline(model, cfg, batches, torch, np)
+        print(json.dumps({
+            "metric": "abstracts/sec, stella_en_1.5B_v5 bf16 batch encode (synthetic abstracts, median 220 tokens)",
+            "value": round(args.steps * bs * world / dt, 1), "unit": "abstracts/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (random-init weights of the real architecture, synthetic token ids)",
+            "config": {"workload": "cfg3: stella_en_1.5B_v5 bf16 batch encode", "batch": bs,
+                       "tokens_per_sec": round(toks * world / dt, 0), "parallelism": "replicas" if world > 1 else "1 GPU"},
+            "roofline": roofline, "cpu_baseline": cpu}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def encode_cpu_baseline(model, cfg, batches, torch, np):
+    """oracle port (torch fp32 on the host cores) on a bounded sample: the same
+    architecture cut to 2 layers and a 4096-row vocabulary (a 1.5 B-parameter fp32
+    copy is 6 GB and tens of seconds per batch), scaled by 28/2 layers."""
+    from oracle import encoder_oracle as E
+    small = dict(cfg)
+    small["n_layers"], small["vocab_size"] = 2, 4096
+    W = E.synth_weights(E.EncoderConfig(**small), 3)
+    toks = [[t % 4096 for t in s] for s in batches[0][:16]]
+    cu = np.concatenate([[0], np.cumsum([len(t) for t in toks])])
+    ids = np.concatenate(toks)
+    with torch.no_grad():
+        E.encode(E.EncoderConfig(**small), W, ids, cu, True)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            E.encode(E.EncoderConfig(**small), W, ids, cu, True)
+        dt = (time.perf_counter() - t0) / reps
+    full = dt * cfg["n_layers"] / 2
+    return {"value": round(len(toks) / full, 2), "unit": "abstracts/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"16 abstracts through 2 of 28 layers (oracle/encoder_oracle.py, torch fp32), "
+                                      f"{dt:.2f}s per pass, scaled x14 to full depth"}
 
 
 def cpu_baseline(index, my_q, args, np):
