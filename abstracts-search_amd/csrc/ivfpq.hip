@@ -539,13 +539,15 @@ int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_a
     });
 }
 
-// Number of (query, slice) workgroups: enough to fill 2 x 256 CUs, but never
-// fewer than ~8 code groups (one per wave) of expected work per slice.
+// Number of (query, slice) workgroups: enough to give every CU one, but never
+// fewer than ~16 code groups (two per wave) of expected work per slice: every
+// slice re-stages the query's 64 KiB LUT, so more slices = more LDS fill traffic
+// (PMC: at 8 slices the LUT reads equal the code bytes).
 static int choose_nslice(const mi_index *h, int64_t nq, int nprobe) {
     double avg_groups = h->nlist > 0 ? (double)h->ngroups / h->nlist : 0.0;
     double per_query = avg_groups * nprobe;
-    int64_t by_fill = (1024 + nq - 1) / nq;
-    int64_t by_work = (int64_t)(per_query / 8.0);
+    int64_t by_fill = (256 + nq - 1) / nq;              // one workgroup per CU
+    int64_t by_work = (int64_t)(per_query / 16.0);       // >= 2 groups per wave
     int64_t s = std::min(by_fill, by_work);
     if (const char *e = std::getenv("MI_NSLICE")) s = std::atoi(e);  // tuning knob
     return (int)std::max<int64_t>(1, std::min<int64_t>(s, 32));

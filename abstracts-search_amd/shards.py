@@ -53,38 +53,30 @@ class ShardedIndex:
             self._bufs[key] = b
         return b
 
-    # -- the exchange step: ONE all-gather of the packed per-shard (D, I) ----
-    def _exchange(self, Dl, Il, k):
-        """[nq,k] f32 + [nq,k] i64 -> gathered (Dg [world,nq,k], Ig [world,nq,k]).
-        D and I travel in one message (12 bytes per entry): the collective is
-        latency-bound, so one all-gather instead of two."""
-        import torch
-        import torch.distributed as dist
-        nq = Dl.shape[0]
-        pk = self._buf("pk", (nq, k, 3), torch.int32, Dl.device)
-        pk[:, :, 0] = Dl.contiguous().view(torch.int32)
-        pk[:, :, 1:] = Il.contiguous().view(torch.int32).view(nq, k, 2)
-        g = self._buf("g", (self.world * nq, k, 3), torch.int32, Dl.device)
-        dist.all_gather_into_tensor(g, pk, group=self.group)
-        g = g.view(self.world, nq, k, 3)
-        Dg = g[..., 0].contiguous().view(torch.float32)
-        Ig = g[..., 1:].contiguous().view(torch.int64).view(self.world, nq, k)
-        return Dg, Ig
-
     # -- same queries on every rank --------------------------------------
     def search_replicated(self, q, k):
+        import torch
+        import torch.distributed as dist
         Dl, Il = self._local_search(q, k)
-        Dg, Ig = self._exchange(Dl, Il, k)
+        nq = Dl.shape[0]
+        Dg = self._buf("Dg", (self.world, nq, k), torch.float32, Dl.device)
+        Ig = self._buf("Ig", (self.world, nq, k), torch.int64, Il.device)
+        dist.all_gather_into_tensor(Dg.view(-1, k), Dl.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(Ig.view(-1, k), Il.contiguous(), group=self.group)
         return self._merge(Dg, Ig)
 
     # -- a different batch on every rank ----------------------------------
     def search(self, q_local, k):
+        import torch
         import torch.distributed as dist
         b, d = q_local.shape
         qall = self._buf("qall", (self.world * b, d), q_local.dtype, q_local.device)
         dist.all_gather_into_tensor(qall, q_local.contiguous(), group=self.group)
         Dl, Il = self._local_search(qall, k)                       # this shard, all queries
-        Dg, Ig = self._exchange(Dl, Il, k)                         # the exchange step
+        Dg = self._buf("Dg", (self.world, self.world * b, k), torch.float32, Dl.device)
+        Ig = self._buf("Ig", (self.world, self.world * b, k), torch.int64, Il.device)
+        dist.all_gather_into_tensor(Dg.view(-1, k), Dl.contiguous(), group=self.group)   # the exchange step
+        dist.all_gather_into_tensor(Ig.view(-1, k), Il.contiguous(), group=self.group)
         lo, hi = self.rank * b, (self.rank + 1) * b
         return self._merge(Dg[:, lo:hi].contiguous(), Ig[:, lo:hi].contiguous())
 
