@@ -24,14 +24,14 @@ hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 // kernel launch helpers
 // ------------------------------------------------------------------
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int PF>
 void launch_gemm_cfg(const float *A, int na, const float *B, int nb, int d, float *S, int64_t ldS,
                      hipStream_t st) {
     constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
     int tiles_m = (na + BM - 1) / BM, tiles_n = (nb + BN - 1) / BN;
     int64_t grid = (int64_t)8 * tiles_m * ((tiles_n + 7) / 8);
     MI_REQUIRE(grid < (int64_t)1 << 31, "ip_gemm: grid too large");
-    hipLaunchKernelGGL((ip_gemm_kernel<WM, WN, WAVES_M, WAVES_N, BK>), dim3((unsigned)grid),
+    hipLaunchKernelGGL((ip_gemm_kernel<WM, WN, WAVES_M, WAVES_N, BK, PF>), dim3((unsigned)grid),
                        dim3(WAVES_M * WAVES_N * 64), 0, st, A, na, B, nb, d, S, ldS, tiles_m,
                        tiles_n);
     MI_HIP(hipGetLastError());
@@ -45,10 +45,10 @@ void launch_gemm(const float *A, int64_t na, const float *B, int64_t nb, int d, 
     MI_REQUIRE(d % 4 == 0, "d must be a multiple of 4");
     MI_REQUIRE(na > 0 && nb > 0, "empty gemm");
     MI_REQUIRE(na < ((int64_t)1 << 31) && nb < ((int64_t)1 << 31), "gemm dims exceed int32");
-    if (na <= 16) launch_gemm_cfg<1, 1, 1, 4, 128>(A, (int)na, B, (int)nb, d, S, ldS, st);
-    else if (na <= 128) launch_gemm_cfg<1, 1, 4, 1, 128>(A, (int)na, B, (int)nb, d, S, ldS, st);
-    else if (na <= 512) launch_gemm_cfg<2, 2, 2, 2, 32>(A, (int)na, B, (int)nb, d, S, ldS, st);
-    else launch_gemm_cfg<4, 4, 2, 2, 32>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    if (na <= 16) launch_gemm_cfg<1, 1, 1, 4, 64, 4>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    else if (na <= 128) launch_gemm_cfg<1, 1, 4, 1, 64, 4>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    else if (na <= 512) launch_gemm_cfg<2, 2, 2, 2, 32, 2>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    else launch_gemm_cfg<4, 4, 2, 2, 32, 1>(A, (int)na, B, (int)nb, d, S, ldS, st);
 }
 
 void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int32_t *oi32,

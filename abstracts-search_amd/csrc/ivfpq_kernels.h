@@ -66,7 +66,7 @@ __device__ __forceinline__ float o2f(unsigned o) {
 
 // ---------------------------------------------------------------------
 // S[na][nb] = A[na][d] . B[nb][d]^T, exact f32.
-// Workgroup tile BM x BN, K chunk BK (32 or 128), double-buffered through LDS in k-major
+// Workgroup tile BM x BN, K chunk BK, double-buffered through LDS in k-major
 // order so that lane (i = lane&15, g = lane>>4) reads A[k0+g][i]: the MFMA
 // then consumes k in ascending order and every output is an ascending-k fmaf
 // chain from +0.  LDS row stride == 16 (mod 32) keeps the four k-rows of one
@@ -74,7 +74,7 @@ __device__ __forceinline__ float o2f(unsigned o) {
 // Grid: 8 * tiles_m * ceil(tiles_n/8); block b runs on XCD b%8, and all
 // blocks of one XCD walk the M tiles of the same B strip (L2 reuse of B).
 // ---------------------------------------------------------------------
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int PF>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
     ip_gemm_kernel(const float *__restrict__ A, int na, const float *__restrict__ B, int nb,
                    int d, float *__restrict__ S, int64_t ldS, int tiles_m, int tiles_n) {
@@ -102,14 +102,17 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
     const int wmi = w % WAVES_M, wni = w / WAVES_M;
     const int li = lane & 15, lg = lane >> 4;
 
-    float4 ra[CA], rb[CB];
+    // PF register sets: the global loads of K chunk t+PF are issued while chunk t
+    // is multiplied, so PF chunks of memory latency are covered (small batches
+    // run one wave per SIMD: nothing else hides it).
+    float4 ra[PF][CA], rb[PF][CB];
     f32x4 acc[WM][WN];
 #pragma unroll
     for (int x = 0; x < WM; ++x)
 #pragma unroll
         for (int y = 0; y < WN; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto gload = [&](int k0) {
+    auto gload = [&](int k0, float4(&pa)[CA], float4(&pb)[CB]) {
 #pragma unroll
         for (int u = 0; u < CA; ++u) {
             int idx = tid + u * NT;
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
                 int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
                 int k = k0 + ((idx >> 4) & (KQ - 1)) * 4;
                 int gr = min(m0 + row, na - 1);
-                ra[u] = (k < d) ? *reinterpret_cast<const float4 *>(A + (size_t)gr * d + k)
+                pa[u] = (k < d) ? *reinterpret_cast<const float4 *>(A + (size_t)gr * d + k)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -128,22 +131,22 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
                 int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
                 int k = k0 + ((idx >> 4) & (KQ - 1)) * 4;
                 int gr = min(n0 + row, nb - 1);
-                rb[u] = (k < d) ? *reinterpret_cast<const float4 *>(B + (size_t)gr * d + k)
+                pb[u] = (k < d) ? *reinterpret_cast<const float4 *>(B + (size_t)gr * d + k)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const float4(&pa)[CA], const float4(&pb)[CB]) {
 #pragma unroll
         for (int u = 0; u < CA; ++u) {
             int idx = tid + u * NT;
             if ((BM * KQ) % NT == 0 || idx < BM * KQ) {
                 int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
                 float *p = As + buf * BK * SA + (((idx >> 4) & (KQ - 1)) * 4) * SA + row;
-                p[0] = ra[u].x;
-                p[SA] = ra[u].y;
-                p[2 * SA] = ra[u].z;
-                p[3 * SA] = ra[u].w;
+                p[0] = pa[u].x;
+                p[SA] = pa[u].y;
+                p[2 * SA] = pa[u].z;
+                p[3 * SA] = pa[u].w;
             }
         }
 #pragma unroll
@@ -152,22 +155,16 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
             if ((BN * KQ) % NT == 0 || idx < BN * KQ) {
                 int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
                 float *p = Bs + buf * BK * SB + (((idx >> 4) & (KQ - 1)) * 4) * SB + row;
-                p[0] = rb[u].x;
-                p[SB] = rb[u].y;
-                p[2 * SB] = rb[u].z;
-                p[3 * SB] = rb[u].w;
+                p[0] = pb[u].x;
+                p[SB] = pb[u].y;
+                p[2 * SB] = pb[u].z;
+                p[3 * SB] = pb[u].w;
             }
         }
     };
-
-    const int nk = (d + BK - 1) / BK;
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) gload((t + 1) * BK);
-        const float *ab = As + (t & 1) * BK * SA + lg * SA + wmi * WM * 16 + li;
-        const float *bb = Bs + (t & 1) * BK * SB + lg * SB + wni * WN * 16 + li;
+    auto compute = [&](int buf) {
+        const float *ab = As + buf * BK * SA + lg * SA + wmi * WM * 16 + li;
+        const float *bb = Bs + buf * BK * SB + lg * SB + wni * WN * 16 + li;
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             float a[WM], b[WN];
@@ -181,8 +178,25 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
                 for (int y = 0; y < WN; ++y)
                     acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[y], acc[x][y], 0, 0, 0);
         }
-        if (t + 1 < nk) sstore((t + 1) & 1);
-        __syncthreads();
+    };
+
+    const int nk = (d + BK - 1) / BK;
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (s < nk) gload(s * BK, ra[s], rb[s]);
+    sstore(0, ra[0], rb[0]);
+    __syncthreads();
+    for (int t0 = 0; t0 < nk; t0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = t0 + u;
+            if (t < nk) {
+                if (t + PF < nk) gload((t + PF) * BK, ra[u], rb[u]);   // set u was stored to LDS last step
+                compute(t & 1);
+                if (t + 1 < nk) sstore((t + 1) & 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+                __syncthreads();
+            }
+        }
     }
     // D layout of 16x16x4: lane holds rows (lane>>4)*4 + r, column lane&15
 #pragma unroll
