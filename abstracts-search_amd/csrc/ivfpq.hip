@@ -26,14 +26,14 @@ hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int PF>
 void launch_gemm_cfg(const float *A, int na, const float *B, int nb, int d, float *S, int64_t ldS,
-                     hipStream_t st) {
+                     hipStream_t st, const LutArgs &la) {
     constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
     int tiles_m = (na + BM - 1) / BM, tiles_n = (nb + BN - 1) / BN;
     int64_t grid = (int64_t)8 * tiles_m * ((tiles_n + 7) / 8);
-    MI_REQUIRE(grid < (int64_t)1 << 31, "ip_gemm: grid too large");
-    hipLaunchKernelGGL((ip_gemm_kernel<WM, WN, WAVES_M, WAVES_N, BK, PF>), dim3((unsigned)grid),
-                       dim3(WAVES_M * WAVES_N * 64), 0, st, A, na, B, nb, d, S, ldS, tiles_m,
-                       tiles_n);
+    MI_REQUIRE(grid + la.nblocks < (int64_t)1 << 31, "ip_gemm: grid too large");
+    static_assert(WAVES_M * WAVES_N * 64 == 256, "appended LUT workgroups need 256 threads");
+    hipLaunchKernelGGL((ip_gemm_kernel<WM, WN, WAVES_M, WAVES_N, BK, PF>), dim3((unsigned)(grid + la.nblocks)),
+                       dim3(256), 0, st, A, na, B, nb, d, S, ldS, tiles_m, tiles_n, (int)grid, la);
     MI_HIP(hipGetLastError());
 }
 
@@ -41,14 +41,14 @@ void launch_gemm_cfg(const float *A, int na, const float *B, int nb, int d, floa
 // query batches get many small tiles (one 16x16 MFMA tile per wave, so that a
 // 64 x 4096 problem still fills all 1024 SIMDs), big batches get 128x128.
 void launch_gemm(const float *A, int64_t na, const float *B, int64_t nb, int d, float *S,
-                 int64_t ldS, hipStream_t st) {
+                 int64_t ldS, hipStream_t st, const LutArgs &la = LutArgs{}) {
     MI_REQUIRE(d % 4 == 0, "d must be a multiple of 4");
     MI_REQUIRE(na > 0 && nb > 0, "empty gemm");
     MI_REQUIRE(na < ((int64_t)1 << 31) && nb < ((int64_t)1 << 31), "gemm dims exceed int32");
-    if (na <= 16) launch_gemm_cfg<1, 1, 1, 4, 64, 4>(A, (int)na, B, (int)nb, d, S, ldS, st);
-    else if (na <= 128) launch_gemm_cfg<1, 1, 4, 1, 64, 4>(A, (int)na, B, (int)nb, d, S, ldS, st);
-    else if (na <= 512) launch_gemm_cfg<2, 2, 2, 2, 32, 2>(A, (int)na, B, (int)nb, d, S, ldS, st);
-    else launch_gemm_cfg<4, 4, 2, 2, 32, 1>(A, (int)na, B, (int)nb, d, S, ldS, st);
+    if (na <= 16) launch_gemm_cfg<1, 1, 1, 4, 64, 4>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
+    else if (na <= 128) launch_gemm_cfg<1, 1, 4, 1, 64, 4>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
+    else if (na <= 512) launch_gemm_cfg<2, 2, 2, 2, 32, 2>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
+    else launch_gemm_cfg<4, 4, 2, 2, 32, 1>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
 }
 
 void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int32_t *oi32,
@@ -59,14 +59,20 @@ void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int3
     MI_HIP(hipGetLastError());
 }
 
+LutArgs make_lut_args(const float *q, int nq, int d, int M, const float *cb, float *lut) {
+    LutArgs a{};
+    a.q = q; a.codebook = cb; a.lut = lut; a.nq = nq; a.d = d; a.M = M; a.dsub = d / M; a.qtile = 8;
+    a.nblocks = M * ((nq + a.qtile - 1) / a.qtile);
+    return a;
+}
+
 void launch_lut(const float *q, int nq, int d, int M, const float *cb, float *lut, hipStream_t st) {
-    const int dsub = d / M;
-    const int qtile = 8;
-    dim3 grid(M, (nq + qtile - 1) / qtile), block(256);
-    switch (dsub) {
-#define MI_LUT_CASE(DS)                                                                      \
-    case DS:                                                                                 \
-        hipLaunchKernelGGL((lut_kernel<DS>), grid, block, 0, st, q, nq, d, M, cb, lut, qtile); \
+    const LutArgs a = make_lut_args(q, nq, d, M, cb, lut);
+    dim3 grid(a.nblocks), block(256);
+    switch (a.dsub) {
+#define MI_LUT_CASE(DS)                                                      \
+    case DS:                                                                 \
+        hipLaunchKernelGGL((lut_kernel<DS>), grid, block, 0, st, a);         \
         break;
         MI_LUT_CASE(1)
         MI_LUT_CASE(2)
@@ -573,7 +579,9 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, w.side);
         MI_HIP(hipEventRecord(w.ev_join, w.side));
     }
-    launch_gemm(qdev, nq, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st);
+    const bool lut_in_gemm = !fork && (h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && !std::getenv("MI_NO_LUT_FUSION");
+    launch_gemm(qdev, nq, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st,
+                lut_in_gemm ? make_lut_args(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut) : LutArgs{});
     ProbeTables pt{};
     if (!stop_after_lut) {
         pt.list_goff = h->d_goff.get<int32_t>();
@@ -584,7 +592,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     }
     launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st, pt);
     if (fork) MI_HIP(hipStreamWaitEvent(st, w.ev_join, 0));
-    else launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
+    else if (!lut_in_gemm) launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
     if (cI_out) MI_HIP(hipMemcpyAsync(cI_out, cidx, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (cD_out) MI_HIP(hipMemcpyAsync(cD_out, cdis, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (lut_out) MI_HIP(hipMemcpyAsync(lut_out, lut, (size_t)nq * M * 256 * 4, hipMemcpyDeviceToHost, st));

@@ -74,10 +74,51 @@ __device__ __forceinline__ float o2f(unsigned o) {
 // Grid: 8 * tiles_m * ceil(tiles_n/8); block b runs on XCD b%8, and all
 // blocks of one XCD walk the M tiles of the same B strip (L2 reuse of B).
 // ---------------------------------------------------------------------
+// ---------------------------------------------------------------------
+// LUT[q][m][j] = <q_m, codebook[m][j]>  (ascending-t fmaf chain from +0).
+// Work unit = (sub-quantiser m, tile of `qtile` queries); 256 threads: thread j
+// keeps codeword j of sub-quantiser m in registers and walks the queries.
+// Runs either as its own kernel or as extra workgroups appended to the coarse
+// GEMM launch (the GEMM of a small batch is latency-bound with one wave per
+// SIMD; the LUT workgroups fill the idle issue slots and a launch is saved).
+// ---------------------------------------------------------------------
+struct LutArgs {
+    const float *q;         // [nq][d]
+    const float *codebook;  // [M][256][dsub]
+    float *lut;             // [nq][M][256]; null = no LUT work
+    int nq, d, M, dsub, qtile, nblocks;
+};
+
+template <int DSUB>
+__device__ __forceinline__ void lut_block(const LutArgs &a, int blk) {
+    const int m = blk % a.M, j = threadIdx.x;
+    const int q0 = (blk / a.M) * a.qtile;
+    const int q1 = min(a.nq, q0 + a.qtile);
+    float cb[DSUB];
+    const float *cp = a.codebook + ((size_t)m * 256 + j) * DSUB;
+#pragma unroll
+    for (int t = 0; t < DSUB; ++t) cb[t] = cp[t];
+    for (int qi = q0; qi < q1; ++qi) {
+        const float *qs = a.q + (size_t)qi * a.d + m * DSUB;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < DSUB; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
+        a.lut[((size_t)qi * a.M + m) * 256 + j] = acc;
+    }
+}
+
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int PF>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
     ip_gemm_kernel(const float *__restrict__ A, int na, const float *__restrict__ B, int nb,
-                   int d, float *__restrict__ S, int64_t ldS, int tiles_m, int tiles_n) {
+                   int d, float *__restrict__ S, int64_t ldS, int tiles_m, int tiles_n, int gemm_blocks,
+                   LutArgs la) {
+    if ((int)blockIdx.x >= gemm_blocks) {  // appended LUT workgroups (dsub <= 16 only)
+        const int blk = blockIdx.x - gemm_blocks;
+        if (la.dsub == 16) lut_block<16>(la, blk);
+        else if (la.dsub == 8) lut_block<8>(la, blk);
+        else if (la.dsub == 4) lut_block<4>(la, blk);
+        return;
+    }
     constexpr int BM = 16 * WM * WAVES_M;
     constexpr int BN = 16 * WN * WAVES_N;
     constexpr int KQ = BK / 4;  // float4 per tile row
@@ -487,29 +528,9 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// ---------------------------------------------------------------------
-// LUT[q][m][j] = <q_m, codebook[m][j]>  (ascending-t fmaf chain from +0).
-// grid (M, ceil(nq/qtile)), 256 threads: thread j holds codeword j of
-// sub-quantiser m in registers and walks `qtile` queries.
-// ---------------------------------------------------------------------
 template <int DSUB>
-__global__ void __launch_bounds__(256)
-    lut_kernel(const float *__restrict__ q, int nq, int d, int M, const float *__restrict__ codebook,
-               float *__restrict__ lut, int qtile) {
-    const int m = blockIdx.x, j = threadIdx.x;
-    const int q0 = blockIdx.y * qtile;
-    const int q1 = min(nq, q0 + qtile);
-    float cb[DSUB];
-    const float *cp = codebook + ((size_t)m * 256 + j) * DSUB;
-#pragma unroll
-    for (int t = 0; t < DSUB; ++t) cb[t] = cp[t];
-    for (int qi = q0; qi < q1; ++qi) {
-        const float *qs = q + (size_t)qi * d + m * DSUB;
-        float acc = 0.f;
-#pragma unroll
-        for (int t = 0; t < DSUB; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
-        lut[((size_t)qi * M + m) * 256 + j] = acc;
-    }
+__global__ void __launch_bounds__(256) lut_kernel(LutArgs a) {
+    lut_block<DSUB>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------
