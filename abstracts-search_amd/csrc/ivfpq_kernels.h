@@ -598,14 +598,18 @@ __host__ __device__ inline size_t scan_smem_bytes(int M, int nprobe) {
     return scan_lut_bytes(M) + (size_t)SCAN_NW * SCAN_WBUF * 12 + (size_t)scan_tab_stride(nprobe) * 4 * 4 + 16;
 }
 
-// k-th largest of up to 128 order-preserving keys held two per lane (0 = empty)
+// (a lower bound of) the k-th largest of up to 128 order-preserving keys held
+// two per lane (0 = empty); exactly k keys are >= the result unless keys tie
 __device__ __forceinline__ unsigned wave_kth_largest(unsigned ka, unsigned kb, int k) {
+    // Early exit: as soon as exactly k keys are >= t, t itself separates the top k
+    // (a lower bound of the k-th key with the remaining low bits zero) -- on
+    // typical scores this takes ~10 of the 32 steps.
     unsigned prefix = 0;
-#pragma unroll 4
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned t = prefix | (1u << bit);
         const int c = __popcll(__ballot(ka >= t)) + __popcll(__ballot(kb >= t));
         if (c >= k) prefix = t;
+        if (c == k) break;
     }
     return prefix;
 }

@@ -27,9 +27,8 @@ def run(env):
     gbs = p["scan_bytes"] / (p["scan_ms_avg"] * 1e-3) / 1e9
     print(f"{env!s:45s} scan {p['scan_ms_avg']*1e3:8.1f} us  {gbs:8.1f} GB/s   step {dt*1e6:8.1f} us", flush=True)
 
-for ns in (2, 4, 6, 8, 12):
+for ns in (2, 4, 8):
     run({"MI_NSLICE": ns})
+for dbg in (1, 2, 3, 8, 9, 11):
+    run({"MI_NSLICE": 4, "MI_SCAN_DEBUG": dbg})
 run({"MI_NSLICE": 4, "MI_NO_FUSED_MERGE": 1})
-run({"MI_NSLICE": 4, "MI_NO_SIDE_STREAM": 1})
-run({"MI_NSLICE": 8, "MI_NO_FUSED_MERGE": 1, "MI_NO_SIDE_STREAM": 1})
-run({})
