@@ -52,10 +52,10 @@ void launch_gemm(const float *A, int64_t na, const float *B, int64_t nb, int d, 
 }
 
 void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int32_t *oi32,
-                   int64_t *oi64, float *os, hipStream_t st, ProbeTables pt = ProbeTables{}) {
+                   int64_t *oi64, float *os, hipStream_t st, ProbeTables pt = ProbeTables{}, int idx_off = 0) {
     MI_REQUIRE(K >= 1, "select: K < 1");
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(256), 0, st, S, ldS, n, K, oi32,
-                       oi64, os, pt);
+                       oi64, os, pt, idx_off);
     MI_HIP(hipGetLastError());
 }
 
@@ -561,12 +561,29 @@ static int choose_nslice(const mi_index *h, int64_t nq, int nprobe) {
 
 static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev, int k, int nprobe, float *Ddev,
                          int64_t *Idev, hipStream_t st, int32_t *cI_out, float *cD_out,
-                         float *lut_out, bool stop_after_lut) {
+                         float *lut_out, bool stop_after_lut, const int32_t *pre_I = nullptr,
+                         const float *pre_D = nullptr) {
     const int M = h->M;
-    float *scores = w.scores.as<float>((size_t)nq * h->nlist);
     int32_t *cidx = w.cidx.as<int32_t>((size_t)nq * nprobe);
     float *cdis = w.cdis.as<float>((size_t)nq * nprobe);
     float *lut = w.lut.as<float>((size_t)nq * M * 256);
+    ProbeTables pt{};
+    if (!stop_after_lut) {
+        pt.list_goff = h->d_goff.get<int32_t>();
+        pt.list_len = h->d_len.get<int32_t>();
+        pt.p_goff = w.pgoff.as<int32_t>((size_t)nq * nprobe);
+        pt.p_len = w.plen.as<int32_t>((size_t)nq * nprobe);
+        pt.p_prefix = w.pprefix.as<int32_t>((size_t)nq * (nprobe + 1));
+    }
+    if (pre_I) {
+        // search_preassigned: coarse result given (device pointers); tables + LUT only
+        MI_HIP(hipMemcpyAsync(cidx, pre_I, (size_t)nq * nprobe * 4, hipMemcpyDeviceToDevice, st));
+        MI_HIP(hipMemcpyAsync(cdis, pre_D, (size_t)nq * nprobe * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(probe_tables_kernel, dim3((unsigned)nq), dim3(256), 0, st, pt, nprobe, cidx);
+        MI_HIP(hipGetLastError());
+        launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
+    } else {
+    float *scores = w.scores.as<float>((size_t)nq * h->nlist);
     const bool fork = std::getenv("MI_SIDE_STREAM") != nullptr;  // measured slower in eager mode: opt-in
     if (fork) {
         if (!w.side) {
@@ -582,17 +599,10 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     const bool lut_in_gemm = !fork && (h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && !std::getenv("MI_NO_LUT_FUSION");
     launch_gemm(qdev, nq, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st,
                 lut_in_gemm ? make_lut_args(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut) : LutArgs{});
-    ProbeTables pt{};
-    if (!stop_after_lut) {
-        pt.list_goff = h->d_goff.get<int32_t>();
-        pt.list_len = h->d_len.get<int32_t>();
-        pt.p_goff = w.pgoff.as<int32_t>((size_t)nq * nprobe);
-        pt.p_len = w.plen.as<int32_t>((size_t)nq * nprobe);
-        pt.p_prefix = w.pprefix.as<int32_t>((size_t)nq * (nprobe + 1));
-    }
     launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st, pt);
     if (fork) MI_HIP(hipStreamWaitEvent(st, w.ev_join, 0));
     else if (!lut_in_gemm) launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
+    }
     if (cI_out) MI_HIP(hipMemcpyAsync(cI_out, cidx, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (cD_out) MI_HIP(hipMemcpyAsync(cD_out, cdis, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (lut_out) MI_HIP(hipMemcpyAsync(lut_out, lut, (size_t)nq * M * 256 * 4, hipMemcpyDeviceToHost, st));
@@ -703,6 +713,59 @@ int mi_index_coarse_lut(mi_index *h, int64_t nq, const float *q, int nprobe, int
                          cI ? cI + (size_t)c0 * nprobe : nullptr, cD ? cD + (size_t)c0 * nprobe : nullptr,
                          lut ? lut + (size_t)c0 * h->M * 256 : nullptr, true);
             MI_HIP(hipStreamSynchronize(nullptr));
+        }
+    });
+}
+
+int mi_index_coarse_slice(mi_index *h, int64_t nq, const float *q, int nprobe, int list_lo, int list_hi,
+                          int32_t *coarse_I, float *coarse_D, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(h && q && coarse_I && coarse_D, "null argument");
+        MI_REQUIRE(0 <= list_lo && list_lo < list_hi && list_hi <= h->nlist, "bad centroid slice");
+        MI_REQUIRE(nprobe >= 1, "nprobe must be >= 1");
+        MI_REQUIRE(h->has_coarse, "no coarse centroids set");
+        MI_REQUIRE(is_device_ptr(q) && is_device_ptr(coarse_I) && is_device_ptr(coarse_D),
+                   "mi_index_coarse_slice: device pointers only");
+        if (nq == 0) return;
+        DeviceGuard dg(h->device);
+        hipStream_t st = as_stream(stream);
+        SearchWS &w = ws_for(h, stream);
+        const int n = list_hi - list_lo;
+        const int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(4096, ((int64_t)1 << 28) / n));
+        for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
+            const int64_t m = std::min(chunk, nq - c0);
+            float *scores = w.scores.as<float>((size_t)m * n);
+            launch_gemm(q + (size_t)c0 * h->d, m, h->centroids.get<float>() + (size_t)list_lo * h->d, n, h->d,
+                        scores, n, st);
+            // K = nprobe even if the slice is smaller: the tail is -1 / -FLT_MAX padded
+            launch_select(scores, n, m, n, nprobe, coarse_I + (size_t)c0 * nprobe, nullptr,
+                          coarse_D + (size_t)c0 * nprobe, st, ProbeTables{}, list_lo);
+        }
+    });
+}
+
+int mi_index_search_preassigned(mi_index *h, int64_t nq, const float *q, int k, int nprobe,
+                                const int32_t *coarse_I, const float *coarse_D, float *D, int64_t *I,
+                                void *stream) {
+    return guard([&] {
+        MI_REQUIRE(h && (nq == 0 || (q && D && I && coarse_I && coarse_D)), "null argument");
+        MI_REQUIRE(k >= 1 && k <= 1024, "k must be in [1, 1024]");
+        MI_REQUIRE(nprobe >= 1, "nprobe must be >= 1");
+        require_trained(h);
+        if (nq == 0) return;
+        MI_REQUIRE(is_device_ptr(q) && is_device_ptr(D) && is_device_ptr(I) && is_device_ptr(coarse_I) &&
+                       is_device_ptr(coarse_D),
+                   "mi_index_search_preassigned: device pointers only");
+        DeviceGuard dg(h->device);
+        hipStream_t st = as_stream(stream);
+        SearchWS &w = ws_for(h, stream);
+        sync_lists(h);
+        const int64_t chunk = query_chunk_size(h);
+        for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
+            const int64_t m = std::min(chunk, nq - c0);
+            search_chunk(h, w, m, q + (size_t)c0 * h->d, k, nprobe, D + (size_t)c0 * k, I + (size_t)c0 * k, st,
+                         nullptr, nullptr, nullptr, false, coarse_I + (size_t)c0 * nprobe,
+                         coarse_D + (size_t)c0 * nprobe);
         }
     });
 }

@@ -289,11 +289,61 @@ struct ProbeTables {
     int32_t *p_prefix;         // [rows][K+1] out
 };
 
+// Per-row probe tables for the scan kernel from the selected list numbers
+// idx[row][0..K): first group and length of every probed list, exclusive prefix
+// of their group counts.  Whole 256-thread workgroup; idx was written by this
+// workgroup (or by an earlier kernel).
+__device__ __forceinline__ void emit_probe_tables(const ProbeTables &pt, int64_t row, int K,
+                                                  const int32_t *__restrict__ idx, int *wtot) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (K + 255) / 256;
+    const int b = tid * per;
+    int sum = 0;
+    for (int i = 0; i < per; ++i)
+        if (b + i < K) {
+            int l = idx[(size_t)row * K + b + i];
+            if (l >= 0) sum += pt.list_goff[l + 1] - pt.list_goff[l];
+        }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int ww = 0; ww < w; ++ww) run += wtot[ww];
+    for (int i = 0; i < per; ++i)
+        if (b + i < K) {
+            int l = idx[(size_t)row * K + b + i];
+            int g0 = 0, ng = 0, len = 0;
+            if (l >= 0) {
+                g0 = pt.list_goff[l];
+                ng = pt.list_goff[l + 1] - g0;
+                len = pt.list_len[l];
+            }
+            pt.p_goff[(size_t)row * K + b + i] = g0;
+            pt.p_len[(size_t)row * K + b + i] = len;
+            pt.p_prefix[(size_t)row * (K + 1) + b + i] = run;
+            run += ng;
+            if (b + i == K - 1) pt.p_prefix[(size_t)row * (K + 1) + K] = run;
+        }
+}
+
+// search_preassigned: the coarse result comes from outside (e.g. merged from
+// centroid slices computed on several GPUs); only the probe tables are needed.
+__global__ void __launch_bounds__(256)
+    probe_tables_kernel(ProbeTables pt, int K, const int32_t *__restrict__ idx) {
+    __shared__ int wtot[4];
+    emit_probe_tables(pt, blockIdx.x, K, idx, wtot);
+}
+
 constexpr int SEL_CAP = 1024;  // survivor slots of the fast path
 
 __global__ void __launch_bounds__(256)
     select_kernel(const float *__restrict__ S, int64_t ldS, int n, int K, int32_t *__restrict__ out_i32,
-                  int64_t *__restrict__ out_i64, float *__restrict__ out_s, ProbeTables pt) {
+                  int64_t *__restrict__ out_i64, float *__restrict__ out_s, ProbeTables pt, int idx_off) {
     __shared__ float c_s[SEL_CAP];   // survivors (fast path) / wave lists (fallback: first 256)
     __shared__ int c_i[SEL_CAP];
     __shared__ int c_rank[SEL_CAP];
@@ -418,8 +468,8 @@ __global__ void __launch_bounds__(256)
                 const int oi = o_i[tid];
                 const float os = o_s[tid];
                 const size_t o = (size_t)row * K + tid;
-                if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi;
-                if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi;
+                if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi + idx_off;
+                if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi + idx_off;
                 if (out_s) out_s[o] = oi == INT_MAX ? -FLT_MAX : os;
             }
             __syncthreads();
@@ -481,8 +531,8 @@ __global__ void __launch_bounds__(256)
                 int oi = o_i[tid];
                 float os = o_s[tid];
                 size_t o = (size_t)row * K + p0 + tid;
-                if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi;
-                if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi;
+                if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi + idx_off;
+                if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi + idx_off;
                 if (out_s) out_s[o] = oi == INT_MAX ? -FLT_MAX : os;
             }
             has_bound = true;
@@ -491,41 +541,7 @@ __global__ void __launch_bounds__(256)
             __syncthreads();
         }
     }
-    if (pt.list_goff) {  // probe tables (out_i32 is non-null on this path; written by this block)
-        const int per = (K + 255) / 256;
-        const int b = tid * per;
-        int sum = 0;
-        for (int i = 0; i < per; ++i)
-            if (b + i < K) {
-                int l = out_i32[(size_t)row * K + b + i];
-                if (l >= 0) sum += pt.list_goff[l + 1] - pt.list_goff[l];
-            }
-        int incl = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) wtot[w] = incl;
-        __syncthreads();
-        int run = incl - sum;
-        for (int ww = 0; ww < w; ++ww) run += wtot[ww];
-        for (int i = 0; i < per; ++i)
-            if (b + i < K) {
-                int l = out_i32[(size_t)row * K + b + i];
-                int g0 = 0, ng = 0, len = 0;
-                if (l >= 0) {
-                    g0 = pt.list_goff[l];
-                    ng = pt.list_goff[l + 1] - g0;
-                    len = pt.list_len[l];
-                }
-                pt.p_goff[(size_t)row * K + b + i] = g0;
-                pt.p_len[(size_t)row * K + b + i] = len;
-                pt.p_prefix[(size_t)row * (K + 1) + b + i] = run;
-                run += ng;
-                if (b + i == K - 1) pt.p_prefix[(size_t)row * (K + 1) + K] = run;
-            }
-    }
+    if (pt.list_goff) emit_probe_tables(pt, row, K, out_i32, wtot);
 }
 
 template <int DSUB>

@@ -61,6 +61,8 @@ class _Lib:
                 "mi_index_search": [v, c_int64, v, c_int, c_int, v, v, v],
                 "mi_index_coarse_lut": [v, c_int64, v, c_int, v, v, v],
                 "mi_index_profile_scan": [v, c_int, v, POINTER(c_double), POINTER(c_int64)],
+                "mi_index_coarse_slice": [v, c_int64, v, c_int, c_int, c_int, v, v, v],
+                "mi_index_search_preassigned": [v, c_int64, v, c_int, c_int, v, v, v, v, v],
                 "mi_merge_topk": [c_int, c_int, c_int64, c_int, v, v, v, v, v],
                 "mi_flat_create": [c_int, c_int, POINTER(v)],
                 "mi_flat_destroy": [v],
@@ -383,6 +385,33 @@ class IndexIVFPQ:
                                         c_void_p(D.data_ptr()), c_void_p(I.data_ptr()), st)
         if rc:
             _check(rc)
+
+    def coarse_slice(self, x, nprobe: int, list_lo: int, list_hi: int):
+        """quantizer.search restricted to centroids [list_lo, list_hi) with global
+        list numbers -> (coarse_I int32, coarse_D f32) CUDA tensors [nq, nprobe]."""
+        import torch
+        x = _as_f32(x, self.d)
+        nq = x.shape[0]
+        cI = torch.empty((nq, nprobe), dtype=torch.int32, device=x.device)
+        cD = torch.empty((nq, nprobe), dtype=torch.float32, device=x.device)
+        _check(_Lib.get().mi_index_coarse_slice(self._h, nq, _ptr(x), int(nprobe), int(list_lo), int(list_hi),
+                                                _ptr(cI), _ptr(cD), _current_stream()))
+        return cI, cD
+
+    def search_preassigned(self, x, k: int, coarse_I, coarse_D):
+        """faiss IndexIVF.search_preassigned (CUDA tensors): search with a given
+        coarse assignment [nq, nprobe] (int32 list numbers, -1 = none)."""
+        import torch
+        x = _as_f32(x, self.d)
+        nq = x.shape[0]
+        coarse_I = coarse_I.to(torch.int32).contiguous()
+        coarse_D = coarse_D.to(torch.float32).contiguous()
+        assert coarse_I.shape == coarse_D.shape and coarse_I.shape[0] == nq
+        D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+        _check(_Lib.get().mi_index_search_preassigned(self._h, nq, _ptr(x), k, coarse_I.shape[1], _ptr(coarse_I),
+                                                      _ptr(coarse_D), _ptr(D), _ptr(I), _current_stream()))
+        return D, I
 
     def coarse_and_lut(self, x, nprobe: int | None = None, want_lut: bool = True):
         """Steps 1-2 of search for parity tests: (coarse_I, coarse_D, lut)."""

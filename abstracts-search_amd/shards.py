@@ -25,7 +25,8 @@ from __future__ import annotations
 
 
 class ShardedIndex:
-    def __init__(self, index, group=None, local_search=None, merge=None):
+    def __init__(self, index, group=None, local_search=None, merge=None, shard_coarse=False,
+                 local_coarse=None, local_search_pre=None, nlist=None, nprobe=None):
         import torch.distributed as dist
         assert dist.is_initialized(), "ShardedIndex needs an initialised process group"
         self.index = index
@@ -35,6 +36,15 @@ class ShardedIndex:
         self._local_search = local_search or self._hip_search
         self._merge = merge or self._hip_merge
         self._bufs = {}
+        # shard_coarse: the coarse GEMM (2*d*nlist FLOP per query, replicated on
+        # every rank otherwise -- at IVF65536 more work than scanning a shard) is
+        # split by centroid range; the per-rank top-nprobe lists are all-gathered
+        # and merged (same total order => the same probe list as the full search)
+        self.shard_coarse = shard_coarse
+        self._local_coarse = local_coarse or (lambda q, nprobe, lo, hi: self.index.coarse_slice(q, nprobe, lo, hi))
+        self._local_search_pre = local_search_pre or (lambda q, k, cI, cD: self.index.search_preassigned(q, k, cI, cD))
+        self._nlist = nlist if nlist is not None else getattr(index, "nlist", None)
+        self._nprobe = nprobe
 
     # -- default (HIP) implementations ---------------------------------
     def _hip_search(self, q, k):
@@ -57,7 +67,7 @@ class ShardedIndex:
     def search_replicated(self, q, k):
         import torch
         import torch.distributed as dist
-        Dl, Il = self._local_search(q, k)
+        Dl, Il = self._search_sharded_coarse(q, k) if self.shard_coarse else self._local_search(q, k)
         nq = Dl.shape[0]
         Dg = self._buf("Dg", (self.world, nq, k), torch.float32, Dl.device)
         Ig = self._buf("Ig", (self.world, nq, k), torch.int64, Il.device)
@@ -72,13 +82,35 @@ class ShardedIndex:
         b, d = q_local.shape
         qall = self._buf("qall", (self.world * b, d), q_local.dtype, q_local.device)
         dist.all_gather_into_tensor(qall, q_local.contiguous(), group=self.group)
-        Dl, Il = self._local_search(qall, k)                       # this shard, all queries
+        if self.shard_coarse:
+            Dl, Il = self._search_sharded_coarse(qall, k)
+        else:
+            Dl, Il = self._local_search(qall, k)                   # this shard, all queries
         Dg = self._buf("Dg", (self.world, self.world * b, k), torch.float32, Dl.device)
         Ig = self._buf("Ig", (self.world, self.world * b, k), torch.int64, Il.device)
         dist.all_gather_into_tensor(Dg.view(-1, k), Dl.contiguous(), group=self.group)   # the exchange step
         dist.all_gather_into_tensor(Ig.view(-1, k), Il.contiguous(), group=self.group)
         lo, hi = self.rank * b, (self.rank + 1) * b
         return self._merge(Dg[:, lo:hi].contiguous(), Ig[:, lo:hi].contiguous())
+
+    def _search_sharded_coarse(self, qall, k):
+        import torch
+        import torch.distributed as dist
+        nprobe = min(int(self._nprobe if self._nprobe is not None else self.index.nprobe), self._nlist)
+        per = (self._nlist + self.world - 1) // self.world
+        lo, hi = min(self.rank * per, self._nlist), min((self.rank + 1) * per, self._nlist)
+        nq = qall.shape[0]
+        if hi > lo:
+            cI, cD = self._local_coarse(qall, nprobe, lo, hi)
+        else:
+            cI = torch.full((nq, nprobe), -1, dtype=torch.int32, device=qall.device)
+            cD = torch.full((nq, nprobe), -torch.finfo(torch.float32).max, device=qall.device)
+        Ig = self._buf("cIg", (self.world, nq, nprobe), torch.int64, qall.device)
+        Dg = self._buf("cDg", (self.world, nq, nprobe), torch.float32, qall.device)
+        dist.all_gather_into_tensor(Ig.view(-1, nprobe), cI.to(torch.int64).contiguous(), group=self.group)
+        dist.all_gather_into_tensor(Dg.view(-1, nprobe), cD.contiguous(), group=self.group)
+        mD, mI = self._merge(Dg, Ig)                                # global top-nprobe lists
+        return self._local_search_pre(qall, k, mI.to(torch.int32), mD)
 
     def search_into(self, q_local, k, D, I):
         Dm, Im = self.search(q_local, k)

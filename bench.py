@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--workload", choices=["search", "encode"], default="search",
                     help="search = cfg2 (the headline line); encode = cfg3 (stella_en_1.5B_v5 bf16 batch encode)")
     ap.add_argument("--encode-batch", type=int, default=128, help="abstracts per encode step")
+    ap.add_argument("--shard-coarse", type=int, default=0,
+                    help="N>1: also split the coarse quantiser across ranks (pays off at IVF65536, not at cfg2)")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the steps are issued round-robin on (batches overlap on the GPU)")
     args = ap.parse_args()
@@ -106,7 +108,7 @@ def main():
         index.train(x)
         index.add(x)
     index.nprobe = args.nprobe
-    sharded = ShardedIndex(index) if (world > 1 or force_sharded) else None
+    sharded = ShardedIndex(index, shard_coarse=bool(args.shard_coarse)) if (world > 1 or force_sharded) else None
     log(f"[rank {rank}] setup {time.time() - t0:.1f}s ntotal={index.ntotal}")
 
     NB = 16                               # pool of distinct query batches

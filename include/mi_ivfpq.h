@@ -97,6 +97,23 @@ int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe,
 int mi_index_coarse_lut(mi_index *h, int64_t nq, const float *q, int nprobe,
                         int32_t *coarse_I_host, float *coarse_D_host, float *lut_host);
 
+/* Coarse quantisation over a slice [list_lo, list_hi) of the centroids
+ * (IndexFlatIP.search on a sub-range; list numbers are global): used to split
+ * the coarse GEMM across the GPUs of a node -- at IVF65536 it costs more than
+ * the scan of a shard.  coarse_I int32 / coarse_D float32 [nq][nprobe], padded
+ * with -1 / -FLT_MAX when the slice holds fewer than nprobe lists.  Device
+ * pointers only; enqueues on `stream`. */
+int mi_index_coarse_slice(mi_index *h, int64_t nq, const float *q, int nprobe, int list_lo,
+                          int list_hi, int32_t *coarse_I, float *coarse_D, void *stream);
+
+/* IndexIVF.search_preassigned: search with a given coarse assignment
+ * (coarse_I int32 [nq][nprobe], -1 = no list; coarse_D float32 [nq][nprobe] =
+ * <q, centroid>), e.g. the merged result of mi_index_coarse_slice() calls.
+ * Device pointers only; enqueues on `stream`. */
+int mi_index_search_preassigned(mi_index *h, int64_t nq, const float *q, int k, int nprobe,
+                                const int32_t *coarse_I, const float *coarse_D, float *D,
+                                int64_t *I, void *stream);
+
 /* Timing of the dominant kernel for the roofline: re-launches the PQ-code scan
  * kernel of the most recent mi_index_search() call (same arguments, idempotent)
  * `reps` times back to back on `stream`, bracketed by two HIP events recorded on

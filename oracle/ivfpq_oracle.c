@@ -270,6 +270,42 @@ ORACLE_API void oracle_search(int64_t nq, int d, const float *q, int nlist,
     }
 }
 
+/* IndexIVF.search_preassigned: steps 2-4 with a given coarse assignment
+ * (coarse_I [nq][nprobe], -1 = none; coarse_D = <q, centroid>). */
+ORACLE_API void oracle_search_preassigned(int64_t nq, int d, const float *q, int M, int ksub,
+                                          const float *codebook, int by_residual,
+                                          const int64_t *list_off, const uint8_t *codes,
+                                          const int64_t *ids, int nprobe, const int32_t *coarse_I,
+                                          const float *coarse_D, int k, float *D, int64_t *I) {
+#pragma omp parallel
+    {
+        float *lut = (float *)malloc(sizeof(float) * (size_t)M * ksub);
+        cand_t *L = (cand_t *)malloc(sizeof(cand_t) * (size_t)k);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t qi = 0; qi < nq; ++qi) {
+            oracle_lut(d, M, ksub, q + qi * d, codebook, lut);
+            int n = 0;
+            for (int p = 0; p < nprobe; ++p) {
+                int64_t l = coarse_I[qi * nprobe + p];
+                if (l < 0) continue;
+                float dis0 = by_residual ? coarse_D[qi * nprobe + p] : 0.0f;
+                for (int64_t e = list_off[l]; e < list_off[l + 1]; ++e) {
+                    const uint8_t *c = codes + e * M;
+                    float acc = 0.0f;
+                    for (int m = 0; m < M; ++m) acc += lut[m * ksub + c[m]];
+                    topk_push(L, &n, k, dis0 + acc, ids[e]);
+                }
+            }
+            for (int j = 0; j < k; ++j) {
+                D[qi * k + j] = j < n ? L[j].s : -FLT_MAX;
+                I[qi * k + j] = j < n ? L[j].id : -1;
+            }
+        }
+        free(lut);
+        free(L);
+    }
+}
+
 /* Merge `nparts` per-shard top-k lists ([part][q][k], best first, -1 padded)
  * into one, under the same total order.  This is the exchange step's
  * arithmetic (faiss: IndexShards / merge_knn_results). */

@@ -128,6 +128,27 @@ def search(q, centroids, codebook, list_off, codes, ids, nprobe, k, by_residual=
     return D, I
 
 
+def search_preassigned(q, codebook, list_off, codes, ids, coarse_I, coarse_D, k, by_residual=True):
+    """IndexIVF.search_preassigned restatement -> (D, I)."""
+    q, codebook = _f32(q), _f32(codebook)
+    nq, d = q.shape
+    M, ksub, _ = codebook.shape
+    coarse_I = np.ascontiguousarray(coarse_I, np.int32)
+    coarse_D = _f32(coarse_D)
+    nprobe = coarse_I.shape[1]
+    list_off = np.ascontiguousarray(list_off, np.int64)
+    codes = np.ascontiguousarray(codes, np.uint8)
+    ids = np.ascontiguousarray(ids, np.int64)
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    lib().oracle_search_preassigned(ctypes.c_int64(nq), ctypes.c_int(d), _p(q, ctypes.c_float), ctypes.c_int(M),
+                                    ctypes.c_int(ksub), _p(codebook, ctypes.c_float), ctypes.c_int(int(by_residual)),
+                                    _p(list_off, ctypes.c_int64), _p(codes, ctypes.c_uint8), _p(ids, ctypes.c_int64),
+                                    ctypes.c_int(nprobe), _p(coarse_I, ctypes.c_int32), _p(coarse_D, ctypes.c_float),
+                                    ctypes.c_int(k), _p(D, ctypes.c_float), _p(I, ctypes.c_int64))
+    return D, I
+
+
 def merge(D_parts, I_parts):
     """k-way merge of per-shard results [nparts,nq,k] -> (D[nq,k], I[nq,k])."""
     D_parts = _f32(D_parts)

@@ -266,6 +266,41 @@ def test_merge_topk_and_shard_invariance(faiss, oracle):
         assert np.array_equal(Im2, Im)
 
 
+def test_coarse_slices_and_search_preassigned(faiss, oracle):
+    """the coarse quantiser split by centroid range (what each GPU of a node
+    computes) + merge + search_preassigned reproduces the full search bit for bit"""
+    import torch
+    cent, cb, x, q = random_problem(12, 128, 16, 40, 9000, 37)
+    idx = make_index(faiss, cent, cb)
+    idx.add(x)
+    nprobe, k = 7, 10
+    idx.nprobe = nprobe
+    D, I = idx.search(q, k)
+    qd = torch.from_numpy(q).cuda()
+    for nparts in (1, 3, 8):
+        per = (40 + nparts - 1) // nparts
+        cIs, cDs = [], []
+        for r in range(nparts):
+            lo, hi = min(r * per, 40), min((r + 1) * per, 40)
+            if hi <= lo:
+                continue
+            cI, cD = idx.coarse_slice(qd, nprobe, lo, hi)
+            cIs.append(cI.to(torch.int64)), cDs.append(cD)
+        mD, mI = faiss.merge_topk(torch.stack(cDs), torch.stack(cIs))
+        cIe, cDe, _ = idx.coarse_and_lut(q, nprobe, want_lut=False)
+        assert np.array_equal(mI.cpu().numpy(), cIe) and np.array_equal(bits(mD.cpu().numpy()), bits(cDe))
+        Dp, Ip = idx.search_preassigned(qd, k, mI.to(torch.int32), mD)
+        assert np.array_equal(Ip.cpu().numpy(), I) and np.array_equal(bits(Dp.cpu().numpy()), bits(D))
+    # oracle's search_preassigned agrees too (incl. -1 entries in the assignment)
+    ln, codes = oracle.encode(x, cent, cb)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(len(x)), 40)
+    cI2 = cIe.copy()
+    cI2[:, -2:] = -1
+    De, Ie = oracle.search_preassigned(q, cb, off, lc, li, cI2, cDe, k)
+    Dp, Ip = idx.search_preassigned(qd, k, torch.from_numpy(cI2).cuda(), torch.from_numpy(cDe).cuda())
+    assert np.array_equal(Ip.cpu().numpy(), Ie) and np.array_equal(bits(Dp.cpu().numpy()), bits(De))
+
+
 def test_write_read_roundtrip(faiss, tmp_path):
     cent, cb, x, q = random_problem(10, 64, 8, 16, 2000, 20)
     idx = make_index(faiss, cent, cb)

@@ -54,10 +54,20 @@ def _worker(rank, world, port, mode, ret):
         D, I = O.merge(Dp.numpy(), Ip.numpy())
         return torch.from_numpy(D), torch.from_numpy(I)
 
-    sh = ShardedIndex(index=None, local_search=local_search, merge=merge)
+    def local_coarse(q, npb, lo, hi):
+        D, I = O.flat_ip(q.numpy(), cent[lo:hi], npb)
+        I = np.where(I >= 0, I + lo, -1)
+        return torch.from_numpy(I.astype(np.int32)), torch.from_numpy(D)
+
+    def local_search_pre(q, kk, cI, cD):
+        D, I = O.search_preassigned(q.numpy(), cb, off, lc, li, cI.numpy(), cD.numpy(), kk)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    sh = ShardedIndex(index=None, local_search=local_search, merge=merge, shard_coarse=mode.endswith("+coarse"),
+                      local_coarse=local_coarse, local_search_pre=local_search_pre, nlist=nlist, nprobe=nprobe)
     rng = np.random.default_rng(100)
     qall = (x[rng.integers(0, n, world * b)] + 0.01 * rng.standard_normal((world * b, x.shape[1]))).astype(np.float32)
-    if mode == "own":
+    if mode.startswith("own"):
         D, I = sh.search(torch.from_numpy(qall[rank * b:(rank + 1) * b]), k)
         qs = qall[rank * b:(rank + 1) * b]
     else:
@@ -73,7 +83,8 @@ def _worker(rank, world, port, mode, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "own"), (2, "replicated"), (3, "own")])
+@pytest.mark.parametrize("world,mode", [(2, "own"), (2, "replicated"), (3, "own"), (2, "own+coarse"),
+                                        (3, "replicated+coarse")])
 def test_sharded_equals_unsharded(world, mode):
     from oracle import ivfpq_oracle as O
     O.build()
