@@ -392,3 +392,38 @@ def test_cfg2_full_size_properties(faiss, oracle):
     for r, l, c in zip(rows, ln, cs):
         p = pos[int(r)]
         assert off[l] <= p < off[l + 1] and np.array_equal(codes[p], c)
+
+
+def test_fuzz_against_oracle(faiss, oracle):
+    """seeded fuzz over shapes / parameters / degenerate inputs: HIP == oracle, bit for bit"""
+    rng = np.random.default_rng(2026)
+    for trial in range(40):
+        M = int(rng.choice([4, 8, 16]))
+        d = M * int(rng.choice([4, 8, 16]))
+        nlist = int(rng.integers(1, 40))
+        n = int(rng.choice([0, 1, 7, 63, 64, 65, 500, 3000]))
+        nq = int(rng.integers(1, 40))
+        k = int(rng.choice([1, 2, 10, 33, 64, 65, 100]))
+        nprobe = int(rng.integers(1, nlist + 3))
+        by_residual = bool(rng.integers(0, 2))
+        cent = rng.standard_normal((nlist, d)).astype(np.float32)
+        cb = (0.3 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+        x = (cent[rng.integers(0, nlist, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+        if n >= 64 and trial % 3 == 0:
+            x[n // 2:] = x[: n - n // 2]                    # many exact duplicates -> ties
+        if trial % 5 == 0:
+            x = np.round(x, 1)                              # coarse values -> score ties across lists
+            cent = np.round(cent, 1)
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+        ids = rng.permutation(n).astype(np.int64) * 3 + 1
+        idx = make_index(faiss, cent, cb, by_residual)
+        if n:
+            idx.add_with_ids(x, ids)
+        idx.nprobe = nprobe
+        D, I = idx.search(q, k)
+        ln, codes = oracle.encode(x, cent, cb, by_residual) if n else (np.zeros(0, np.int32), np.zeros((0, M), np.uint8))
+        off, lc, li = oracle.build_lists(ln, codes, ids, nlist)
+        De, Ie = oracle.search(q, cent, cb, off, lc, li, nprobe, k, by_residual)
+        ctx = dict(trial=trial, d=d, M=M, nlist=nlist, n=n, nq=nq, k=k, nprobe=nprobe, res=by_residual)
+        assert np.array_equal(I, Ie), ctx
+        assert np.array_equal(bits(D), bits(De)), ctx
