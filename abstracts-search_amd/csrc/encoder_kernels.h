@@ -359,9 +359,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_256_kernel(GemmArgs g) {
     auto read_frags = [&](int tile, bf16x8(&a)[8], bf16x8(&b)[4]) {
         const bf16_t *base = smem + (tile & 3) * (BM + BN) * BK;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = as_bf16x8(*reinterpret_cast<const uint4 *>(base + b_off + j * 16 * BK));
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(base + b_off + j * 16 * BK);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = as_bf16x8(*reinterpret_cast<const uint4 *>(base + a_off + i * 16 * BK));
+        for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(base + a_off + i * 16 * BK);
     };
     auto mma = [&](const bf16x8(&a)[8], const bf16x8(&b)[4]) {
 #pragma unroll
@@ -380,6 +380,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_256_kernel(GemmArgs g) {
         __builtin_amdgcn_s_barrier();
     };
 
+    // ring of 4 stages, DMA issued 3 tiles ahead (4 ahead measured 8 % slower)
     issue(0, 0);
     if (nk > 1) issue(1, BK);
     if (nk > 2) issue(2, 2 * BK);
@@ -388,7 +389,22 @@ __global__ void __launch_bounds__(512) gemm_bf16_256_kernel(GemmArgs g) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_frags(0, a0, b0);
-    for (int t = 0; t < nk; t += 2) {
+    // steady state, branch-free (so that hipcc counts the 12 prefetch reads as
+    // allowed-outstanding in front of the MFMAs instead of waiting lgkmcnt(0))
+    int t = 0;
+    for (; t + 4 < nk; t += 2) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(t + 1, a1, b1);
+        issue((t + 3) & 3, (t + 3) * BK);
+        mma(a0, b0);
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(t + 2, a0, b0);
+        issue((t + 4) & 3, (t + 4) * BK);
+        mma(a1, b1);
+    }
+    for (; t < nk; t += 2) {  // tail (at most 4 tiles): same schedule with guards
         if (t + 1 < nk) {
             arrive(t + 1);
             read_frags(t + 1, a1, b1);
