@@ -490,17 +490,40 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
     constexpr int KC = 64;          // keys per chunk
     constexpr int NKK = HD / 32;    // MFMA k-steps over the head dimension
     constexpr int NDT = HD / 16;    // 16-wide output tiles over the head dimension
-    constexpr int KSLOTS = HD / 8;  // 16-byte slots per K row
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[KC * HD];      // [key][HD], slot ^= key&7
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[HD * KC];      // [d][key],  slot ^= d&7
-    __shared__ __attribute__((aligned(16))) bf16_t Ps[4 * 16 * KC];  // per wave [16][64], slot ^= row&7
+    constexpr int KSL = HD / 8;     // 16-byte slots per K row
+    constexpr int KRPP = 64 / KSL;  // K rows per 1-KiB DMA piece
+    constexpr int STG = 2 * KC * HD;  // elements per stage: K tile + V^T tile
+    // one LDS array: [2 stages][K: key x HD, slot ^= key&7 | V^T: d x 64 keys, slot ^= d&7]
+    // followed by the per-wave P tiles [4][16][64] (slot ^= row&7)
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STG + 4 * 16 * KC];
 
     const int item = blockIdx.x, h = blockIdx.y;
     const int seq = a.work_seq[item], q0 = a.work_q0[item];
     const int s0 = a.seq_start[seq], L = a.seq_len[seq];
     const int kvh = h / (a.n_heads / a.n_kv);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
+
+    // K and V^T chunks arrive by LDS-DMA (1 KiB per wave instruction), double
+    // buffered: chunk c+1 is in flight while chunk c is multiplied
+    auto issue = [&](int stage, int kc) {
+        bf16_t *Ks = smem + stage * STG, *Vs = Ks + KC * HD;
+#pragma unroll
+        for (int i = 0; i < HD / 32; ++i) {   // HD/8 K pieces over 4 waves
+            const int p = w * (HD / 32) + i;
+            const int key = p * KRPP + lane / KSL, sl = lane % KSL;
+            const int krow = min(kc + key, L - 1);
+            dma16(a.QK + (size_t)(s0 + krow) * a.ldqk + (a.n_heads + kvh) * HD + ((sl ^ (key & 7)) * 8),
+                  Ks + p * 512);
+        }
+#pragma unroll
+        for (int i = 0; i < HD / 32; ++i) {   // HD/8 V^T pieces of 8 rows x 128 B
+            const int p = w * (HD / 32) + i;
+            const int d = p * 8 + (lane >> 3), sl = lane & 7;
+            dma16(a.Vt + (size_t)(kvh * HD + d) * a.ldvt + s0 + kc + ((sl ^ (d & 7)) * 8), Vs + p * 512);
+        }
+    };
 
     // Q fragments of this wave's 16 rows (A operand: row li, 8 dims at 32*kk + 8*lg)
     bf16x8 qf[NKK];
@@ -508,7 +531,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         const int qrow = min(q0 + w * 16 + li, L - 1);
         const bf16_t *qp = a.QK + (size_t)(s0 + qrow) * a.ldqk + h * HD + lg * 8;
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) qf[kk] = as_bf16x8(*reinterpret_cast<const uint4 *>(qp + kk * 32));
+        for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8 *>(qp + kk * 32);
     }
     f32x4 o[NDT];
 #pragma unroll
@@ -520,26 +543,14 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         lrow[r] = 0.f;
     }
     const int kend = a.causal ? min(L, q0 + 64) : L;
-    bf16_t *pw = Ps + w * 16 * KC;
+    bf16_t *pw = smem + 2 * STG + w * 16 * KC;
 
-    for (int kc = 0; kc < kend; kc += KC) {
-        __syncthreads();  // previous chunk's tiles are no longer read
-        // stage K: 64 keys x HD (KSLOTS 16-byte slots per row)
-        for (int idx = tid; idx < KC * KSLOTS; idx += 256) {
-            const int key = idx / KSLOTS, sl = idx - key * KSLOTS;
-            const int krow = min(kc + key, L - 1);
-            const uint4 v = *reinterpret_cast<const uint4 *>(
-                a.QK + (size_t)(s0 + krow) * a.ldqk + (a.n_heads + kvh) * HD + sl * 8);
-            *reinterpret_cast<uint4 *>(Ks + key * HD + ((sl ^ (key & 7)) * 8)) = v;
-        }
-        // stage V^T: HD rows x 64 keys (8 slots per row)
-        for (int idx = tid; idx < HD * 8; idx += 256) {
-            const int d = idx >> 3, sl = idx & 7;
-            const uint4 v = *reinterpret_cast<const uint4 *>(
-                a.Vt + (size_t)(kvh * HD + d) * a.ldvt + s0 + kc + sl * 8);
-            *reinterpret_cast<uint4 *>(Vs + d * KC + ((sl ^ (d & 7)) * 8)) = v;
-        }
-        __syncthreads();
+    issue(0, 0);
+    for (int kc = 0, c = 0; kc < kend; kc += KC, ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own DMA pieces of chunk c
+        __syncthreads();                                   // everyone's pieces; chunk c-1 fully consumed
+        if (kc + KC < kend) issue((c + 1) & 1, kc + KC);
+        const bf16_t *Ks = smem + (c & 1) * STG, *Vs = Ks + KC * HD;
 
         // S = Q K^T for 4 tiles of 16 keys
         f32x4 s[4];
@@ -549,7 +560,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
             const bf16_t *kb = Ks + (j * 16 + li) * HD;
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
-                const bf16x8 kf = as_bf16x8(*reinterpret_cast<const uint4 *>(kb + (((kk * 4 + lg) ^ (li & 7)) * 8)));
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kb + (((kk * 4 + lg) ^ (li & 7)) * 8));
                 s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], kf, s[j], 0, 0, 0);
             }
         }
@@ -581,15 +592,23 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         }
         float psum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = (mrow[r] == -__builtin_huge_valf()) ? 0.f : __expf(s[j][r] - mrow[r]);
                 psum[r] += p;
-                // P tile for the PV A operand: element (row, key) at row*64 + ((key/8)^(row&7))*8 + key%8
-                const int row = lg * 4 + r, key = j * 16 + li;
-                pw[row * KC + (((key >> 3) ^ (row & 7)) << 3) + (key & 7)] = f2bf(p);
+                s[j][r] = p;
             }
+            // P tile for the PV A operand: transposed across lane quads so that a lane
+            // writes 4 consecutive keys of one row (one 8-byte store instead of four
+            // 2-byte ones); element (row, key) at row*64 + ((key/8)^(row&7))*8 + key%8
+            const f32x4 pt = quad_transpose(s[j], lane);
+            const int row = lg * 4 + (li & 3), key = j * 16 + (li & ~3);
+            uint2 pk;
+            pk.x = pack2(pt[0], pt[1]);
+            pk.y = pack2(pt[2], pt[3]);
+            *reinterpret_cast<uint2 *>(pw + row * KC + (((key >> 3) ^ (row & 7)) << 3) + (key & 7)) = pk;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float t = psum[r];
@@ -604,24 +623,29 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         // O += P V  (A: P[row li][keys 32*kk2 + 8*lg ..], B: V^T[d = 16n+li][same keys])
 #pragma unroll
         for (int kk2 = 0; kk2 < 2; ++kk2) {
-            const bf16x8 pf = as_bf16x8(*reinterpret_cast<const uint4 *>(pw + li * KC + (((kk2 * 4 + lg) ^ (li & 7)) * 8)));
+            const bf16x8 pf = *reinterpret_cast<const bf16x8 *>(pw + li * KC + (((kk2 * 4 + lg) ^ (li & 7)) * 8));
 #pragma unroll
             for (int n = 0; n < NDT; ++n) {
-                const bf16x8 vf = as_bf16x8(*reinterpret_cast<const uint4 *>(
-                    Vs + (n * 16 + li) * KC + (((kk2 * 4 + lg) ^ (li & 7)) * 8)));
+                const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(
+                    Vs + (n * 16 + li) * KC + (((kk2 * 4 + lg) ^ (li & 7)) * 8));
                 o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[n], 0, 0, 0);
             }
         }
     }
-    // normalise and write rows < L
+    // normalise and write rows < L: quad-transposed, 4 consecutive dims per lane
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qidx = q0 + w * 16 + lg * 4 + r;
-        if (qidx >= L) continue;
-        const float inv = lrow[r] > 0.f ? 1.0f / lrow[r] : 0.f;
-        bf16_t *op = a.O + (size_t)(s0 + qidx) * (a.n_heads * HD) + h * HD + li;
+    for (int n = 0; n < NDT; ++n) {
+        f32x4 v = o[n];
 #pragma unroll
-        for (int n = 0; n < NDT; ++n) op[n * 16] = f2bf(o[n][r] * inv);
+        for (int r = 0; r < 4; ++r) v[r] *= (lrow[r] > 0.f ? 1.0f / lrow[r] : 0.f);
+        v = quad_transpose(v, lane);
+        const int qidx = q0 + w * 16 + lg * 4 + (li & 3);
+        if (qidx < L) {
+            uint2 pk;
+            pk.x = pack2(v[0], v[1]);
+            pk.y = pack2(v[2], v[3]);
+            *reinterpret_cast<uint2 *>(a.O + (size_t)(s0 + qidx) * (a.n_heads * HD) + h * HD + n * 16 + (li & ~3)) = pk;
+        }
     }
 }
 
