@@ -170,8 +170,21 @@ def main():
     scan_ms = prof["scan_ms_avg"]
     scan_bytes = prof["scan_bytes"]
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    # HBM traffic per launch: PMC counters cannot be collected from inside the timed
+    # process; the value comes from the committed separate --pmc passes of this same
+    # command (profiles/r01_cfg2_scan_pmc.json) and is reported only for that config
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_cfg2_scan_pmc.json")))
+        if (args.corpus, args.nlist, args.batch, args.nprobe, k, world) == (1_000_000, 4096, 64, 16, 10, 1) \
+                and not os.environ.get("MI_NSLICE"):
+            traffic = int(pmc["corrected_bytes_per_launch"])
+    except Exception:
+        traffic = None
     roofline = {"kernel": "scan_kernel<64>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, gfx950 x2 read correction "
+                                  "(profiles/r01_cfg2_scan_pmc.json)" if traffic else None,
                 "bytes_per_launch": int(scan_bytes), "avg_launch_ms": round(scan_ms, 5),
                 "launches": args.steps}
 
