@@ -25,26 +25,55 @@ struct LayerW {
     DevBuf wqkv, bqkv, wo, wgu, wd, ln1, ln2;
 };
 
+template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
+void launch_ring(int epi, GemmArgs g, hipStream_t st) {
+    constexpr int BM = 16 * WMT * WAVES_M, BN = 16 * WNT * WAVES_N;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int per = (ntiles + 7) / 8;
+    if (epi != EPI_RESID || g.bias) g.ksplit = 1;
+    g.ksplit = std::max(1, g.ksplit);
+    dim3 grid(8 * per * g.ksplit), block(64 * WAVES_M * WAVES_N);
+    switch (epi) {
+        case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_STORE, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_RESID, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_QKV, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_SWIGLU, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
+        default: throw Error("bad epilogue");
+    }
+    MI_HIP(hipGetLastError());
+}
+
 void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
     MI_REQUIRE(g.K % 64 == 0, "encoder GEMM: K must be a multiple of 64");
     MI_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "encoder GEMM: leading dimensions must be multiples of 8");
     MI_REQUIRE(g.N % 4 == 0 && g.ldc % 4 == 0, "encoder GEMM: N and ldc must be multiples of 4");
-    // big problems: 256x256 tiles, 8 waves, 4-stage LDS-DMA ring; small ones: 128x128
-    const bool big = g.M >= 512 && g.N >= 256 && g.K % 32 == 0 && !std::getenv("MI_GEMM128");
-    if (big) {
-        g.tiles_m = (g.M + 255) / 256;
-        g.tiles_n = (g.N + 255) / 256;
-        const int ntiles = g.tiles_m * g.tiles_n;
-        const int per = (ntiles + 7) / 8;
-        dim3 grid(8 * per), block(512);
-        switch (epi) {
-            case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_256_kernel<EPI_STORE>), grid, block, 0, st, g); break;
-            case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_256_kernel<EPI_RESID>), grid, block, 0, st, g); break;
-            case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_256_kernel<EPI_QKV>), grid, block, 0, st, g); break;
-            case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_256_kernel<EPI_SWIGLU>), grid, block, 0, st, g); break;
-            default: throw Error("bad epilogue");
+    const char *force = std::getenv("MI_GEMM_TILE");  // tuning knob: big | mid | small | tiny | 128 (legacy kernel)
+    const bool legacy = force && std::string(force) == "128";
+    if (!legacy) {
+        // tile by how many workgroups the problem yields (256 CUs to fill):
+        //   big   256x256 (8 waves)  needs >= ~100 tiles to pay off
+        //   mid   128x128 (4 waves)
+        //   small 128x32  (2 waves, 7 K tiles in flight): skinny / few-row GEMMs
+        //   tiny  32x64 + split-K on the residual GEMMs: a handful of tokens (one query)
+        const long tiles_big = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+        const long tiles_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+        std::string cfg = force ? std::string(force) : "";
+        if (cfg.empty()) cfg = g.M <= 64 ? "tiny" : tiles_big >= 100 ? "big" : tiles_mid >= 150 ? "mid" : "small";
+        g.ksplit = 1;
+        if (cfg == "big") {
+            launch_ring<8, 4, 2, 4, 4>(epi, g, st);
+        } else if (cfg == "mid") {
+            launch_ring<4, 4, 2, 2, 4>(epi, g, st);
+        } else if (cfg == "small") {
+            launch_ring<4, 2, 2, 1, 8>(epi, g, st);
+        } else {
+            const int tiles = ((g.M + 31) / 32) * ((g.N + 63) / 64);
+            const int nk = g.K / 32;
+            g.ksplit = std::max(1, std::min({8, nk / 8, 256 / std::max(1, tiles)}));
+            launch_ring<2, 2, 1, 2, 8>(epi, g, st);
         }
-        MI_HIP(hipGetLastError());
         return;
     }
     g.tiles_m = (g.M + 127) / 128;
@@ -131,7 +160,7 @@ struct Batch {
 };
 
 // Build the padded-packed layout (every sequence starts at a multiple of 8
-// tokens, T_pad a multiple of 128) and upload ids / positions / work lists.
+// tokens, T_pad a multiple of 32) and upload ids / positions / work lists.
 Batch prepare_batch(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu, hipStream_t st) {
     MI_REQUIRE(nseq > 0, "encode: nseq must be positive");
     std::vector<int32_t> cu_h((size_t)nseq + 1);
@@ -160,7 +189,7 @@ Batch prepare_batch(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *
         }
         cur += (L + 7) & ~7;
     }
-    b.T_pad = (cur + 127) & ~127;
+    b.T_pad = (cur + 31) & ~31;   // GEMM rows are clamped / guarded, no tile multiple needed
     b.nwork = (int)wseq.size();
     std::vector<int32_t> ids_pad((size_t)b.T_pad, 0), pos((size_t)b.T_pad, 0);
     for (int i = 0; i < nseq; ++i)

@@ -5,9 +5,10 @@
 //
 //   embed_kernel        token ids -> f32 residual stream
 //   rmsnorm_kernel      f32 residual -> bf16 GEMM operand (f32 statistics)
-//   gemm_bf16_nt_kernel C = A . W^T on v_mfma_f32_16x16x32_bf16, 128x128x64
-//                       tiles staged by LDS-DMA (global_load_lds_dwordx4) into
-//                       XOR-swizzled LDS, f32 accumulation, fused epilogues:
+//   gemm_bf16_ring_kernel C = A . W^T on v_mfma_f32_16x16x32_bf16, 256x256 (or
+//                       128x32) tiles staged by LDS-DMA (global_load_lds_dwordx4)
+//                       through a multi-stage XOR-swizzled LDS ring, f32
+//                       accumulation, fused epilogues:
 //                       QKV (+bias, V written transposed), residual add into the
 //                       f32 stream, SwiGLU (gate/up interleaved weight rows)
 //   rope_kernel         rotary embedding on Q and K (host-built f32 tables)
@@ -124,10 +125,10 @@ __device__ __forceinline__ void dma16(const void *gptr, void *lds_wave_base) {
 // itself is "grouped": GM consecutive M tiles are walked together along N, so
 // the ~32 tiles an XCD has in flight form a GM x 4 patch that shares GM A row
 // blocks and 4 W strips in L2 instead of streaming a different W strip per tile.
-__device__ __forceinline__ bool tile_coords(int tiles_m, int tiles_n, int &tm, int &tn) {
+__device__ __forceinline__ bool tile_coords(int tiles_m, int tiles_n, int &tm, int &tn, int vb = -1) {
     constexpr int GM = 8;
     const int ntiles = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
+    const int bid = vb < 0 ? (int)blockIdx.x : vb;
     const int per = (ntiles + 7) / 8;
     const int t = (bid & 7) * per + (bid >> 3);
     if (t >= ntiles || (bid >> 3) >= per) return false;
@@ -150,6 +151,7 @@ struct GemmArgs {
     bf16_t *Vt;        // QKV: V^T bf16 [N - qk_cols][ldvt]
     int ldc, ldvt, qk_cols;
     int tiles_m, tiles_n;
+    int ksplit;        // > 1 (EPI_RESID only): K range split over workgroups, f32 atomic adds into X
 };
 
 // 4x4 transpose across the 4 lanes of a quad (DPP quad_perm, no LDS): before,
@@ -209,10 +211,18 @@ __device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, f32x4 v2,
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g.bias) b = *reinterpret_cast<const float4 *>(g.bias + col0);
         if constexpr (EPI == EPI_RESID) {
-            float4 *px = reinterpret_cast<float4 *>(g.X + (size_t)row * g.ldc + col0);
-            float4 x = *px;
-            x.x += v[0] + b.x; x.y += v[1] + b.y; x.z += v[2] + b.z; x.w += v[3] + b.w;
-            *px = x;
+            if (g.ksplit > 1) {  // several workgroups add their K slice into the same element
+                float *px = g.X + (size_t)row * g.ldc + col0;
+                unsafeAtomicAdd(px + 0, v[0] + b.x);
+                unsafeAtomicAdd(px + 1, v[1] + b.y);
+                unsafeAtomicAdd(px + 2, v[2] + b.z);
+                unsafeAtomicAdd(px + 3, v[3] + b.w);
+            } else {
+                float4 *px = reinterpret_cast<float4 *>(g.X + (size_t)row * g.ldc + col0);
+                float4 x = *px;
+                x.x += v[0] + b.x; x.y += v[1] + b.y; x.z += v[2] + b.z; x.w += v[3] + b.w;
+                *px = x;
+            }
         } else {
             uint2 o;
             o.x = pack2(v[0] + b.x, v[1] + b.y);
@@ -300,137 +310,176 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------
-// 256x256 variant for the large GEMMs: 8 waves (2 x 4) of 128x64, K step 32,
-// a 4-stage LDS ring (128 KiB) filled by LDS-DMA three tiles ahead.  Waits are
-// counted (`s_waitcnt vmcnt(8/4/0)`: only the tile needed next must have
-// landed) and the barrier is the raw s_barrier, so the DMA of later tiles
-// stays in flight across it instead of being drained every step.
-// LDS rows are 64 B; 16-byte slot index XORed with (-(row >> 2)) & 3.
-// Requires M % 256 == 0 (rows are clamped anyway), K % 32 == 0.
+// Ring-pipelined GEMM (the one the encoder runs).  Workgroup tile
+// BM x BN = (16*WMT*WAVES_M) x (16*WNT*WAVES_N), K step 32, an ST-stage LDS ring
+// filled by LDS-DMA ST-1 tiles ahead; fragments of tile t+1 are read into a
+// second register set while tile t is multiplied.  Waits are counted
+// (`s_waitcnt vmcnt(N)`: only the tile needed next must have landed) and the
+// barrier is the raw s_barrier, so the DMA of later tiles stays in flight across
+// it.  LDS rows are 64 B; 16-byte slot index XORed with (-(row >> 2)) & 3.
+//   <EPI, 8, 4, 2, 4, 4>  256x256, 8 waves, 128 KiB ring: large token counts
+//   <EPI, 4, 2, 2, 1, 8>  128x32,  2 waves,  80 KiB ring, 7 tiles in flight:
+//                         small batches (a single query is weight-streaming
+//                         bound: many narrow workgroups, deep prefetch)
+// Requires K % 32 == 0; rows are clamped, stores guarded.
 // ---------------------------------------------------------------------
-template <int EPI>
-__global__ void __launch_bounds__(512) gemm_bf16_256_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, BK = 32, ST = 4;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[ST * (BM + BN) * BK];  // 128 KiB
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `tiles` tiles (PPW DMA instructions each) are still in flight
+template <int PPW, int MAXT>
+__device__ __forceinline__ void wait_tiles(int tiles, bool lgkm) {
+    static_assert(MAXT * PPW <= 63, "vmcnt immediate is 6 bits");
+#define MIENC_CASE(T)                                       \
+    if constexpr (T <= MAXT)                                \
+        if (tiles == T) {                                   \
+            if (lgkm) wait_vm_lgkm0<T * PPW>();             \
+            else wait_vm<T * PPW>();                        \
+            return;                                         \
+        }
+    MIENC_CASE(0) MIENC_CASE(1) MIENC_CASE(2) MIENC_CASE(3) MIENC_CASE(4) MIENC_CASE(5) MIENC_CASE(6)
+#undef MIENC_CASE
+    if (lgkm) wait_vm_lgkm0<0>();
+    else wait_vm<0>();
+}
 
+template <int EPI, int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
+__global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(GemmArgs g) {
+    constexpr int BM = 16 * WMT * WAVES_M, BN = 16 * WNT * WAVES_N, BK = 32;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int PA = BM / 16, PB = BN / 16;       // 1-KiB DMA pieces (16 rows x 64 B) per stage
+    static_assert((PA + PB) % NW == 0, "DMA pieces must divide evenly over the waves");
+    constexpr int PPW = (PA + PB) / NW;             // pieces per wave per stage
+    constexpr int D = ST - 1;                       // prefetch distance in tiles
+    static_assert((ST & (ST - 1)) == 0 && ST >= 4, "ring size must be a power of two >= 4");
+    static_assert(EPI != EPI_SWIGLU || WNT % 2 == 0, "SwiGLU pairs gate/up tiles inside a wave");
+    __shared__ __attribute__((aligned(16))) bf16_t smem[ST * (BM + BN) * BK];
+
+    // split-K (small batches, residual GEMMs): workgroup = (tile, K slice)
+    const int ksplit = (EPI == EPI_RESID && g.ksplit > 1) ? g.ksplit : 1;
+    const int ks = (int)blockIdx.x % ksplit;
     int tm, tn;
-    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn)) return;
+    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn, ksplit > 1 ? (int)blockIdx.x / ksplit : -1)) return;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w & 1, wn = w >> 1;
+    const int wm = w % WAVES_M, wn = w / WAVES_M;
     const int li = lane & 15, lg = lane >> 4;
 
-    // DMA: one instruction moves 16 rows x 64 B; a wave issues 2 for A and 2 for B per stage
+    // DMA sources of this wave's pieces (A pieces first, then B pieces)
     const int srow = lane >> 2;
     const int scol = ((lane & 3) ^ ((0 - (lane >> 4)) & 3)) * 8;   // row>>2 & 3 == lane>>4 (pieces are 16 rows)
-    const bf16_t *srcA[2], *srcB[2];
+    const bf16_t *src[PPW];
+    int dst[PPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r0 = (w * 2 + i) * 16;
-        srcA[i] = g.A + (size_t)min(m0 + r0 + srow, g.M - 1) * g.lda + scol;
-        srcB[i] = g.W + (size_t)min(n0 + r0 + srow, g.N - 1) * g.ldw + scol;
-    }
-    auto issue = [&](int stage, int k0) {
-        bf16_t *As = smem + stage * (BM + BN) * BK;
-        bf16_t *Bs = As + BM * BK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r0 = (w * 2 + i) * 16;
-            dma16(srcA[i] + k0, As + r0 * BK);
-            dma16(srcB[i] + k0, Bs + r0 * BK);
+    for (int i = 0; i < PPW; ++i) {
+        const int q = w * PPW + i;
+        if (q < PA) {
+            src[i] = g.A + (size_t)min(m0 + q * 16 + srow, g.M - 1) * g.lda + scol;
+            dst[i] = q * 16 * BK;
+        } else {
+            src[i] = g.W + (size_t)min(n0 + (q - PA) * 16 + srow, g.N - 1) * g.ldw + scol;
+            dst[i] = BM * BK + (q - PA) * 16 * BK;
         }
+    }
+    const int nk_all = g.K / BK;
+    const int kt0 = (nk_all * ks) / ksplit;              // first K tile of this slice
+    const int nk = (nk_all * (ks + 1)) / ksplit - kt0;   // tiles in this slice
+    auto issue = [&](int tile) {
+        bf16_t *base = smem + (tile & (ST - 1)) * (BM + BN) * BK;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt0 + tile) * BK, base + dst[i]);
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[WMT][WNT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < WMT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K / BK;
-    // Software pipeline: while the MFMAs of tile t run out of one register set,
-    // the fragments of tile t+1 are read from LDS into the other set and the DMA
-    // of tiles t+2, t+3 is in flight (ring of 4 stages, prefetch distance 3).
-    const int fslot = (lg ^ ((0 - (li >> 2)) & 3)) * 8;  // f(q) = (-q)&3: conflict-free b128 groups
-    const int a_off = (wm * 128 + li) * BK + fslot, b_off = BM * BK + (wn * 64 + li) * BK + fslot;
-    bf16x8 a0[8], b0[4], a1[8], b1[4];
-    auto read_frags = [&](int tile, bf16x8(&a)[8], bf16x8(&b)[4]) {
-        const bf16_t *base = smem + (tile & 3) * (BM + BN) * BK;
+    // f(q) = (-q) & 3 with q = (row >> 2) & 3 makes each hardware 16-lane group of a
+    // ds_read_b128 hit 16 distinct 16-byte slots (the groups mix lg values)
+    const int fslot = (lg ^ ((0 - (li >> 2)) & 3)) * 8;
+    const int a_off = (wm * WMT * 16 + li) * BK + fslot, b_off = BM * BK + (wn * WNT * 16 + li) * BK + fslot;
+    bf16x8 a0[WMT], b0[WNT], a1[WMT], b1[WNT];
+    auto read_frags = [&](int tile, bf16x8(&a)[WMT], bf16x8(&b)[WNT]) {
+        const bf16_t *base = smem + (tile & (ST - 1)) * (BM + BN) * BK;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(base + b_off + j * 16 * BK);
+        for (int j = 0; j < WNT; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(base + b_off + j * 16 * BK);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(base + a_off + i * 16 * BK);
+        for (int i = 0; i < WMT; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(base + a_off + i * 16 * BK);
     };
-    auto mma = [&](const bf16x8(&a)[8], const bf16x8(&b)[4]) {
+    auto mma = [&](const bf16x8(&a)[WMT], const bf16x8(&b)[WNT]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < WMT; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < WNT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     };
-    // tile `next` must have landed in every wave's view before it is read:
-    // own DMA pieces by counted vmcnt (tile next+1 may stay in flight), the other
-    // waves' pieces by the barrier; lgkmcnt(0) first so that no ds_read of the
-    // stage about to be overwritten is still pending when the DMA is issued.
+    // tile `next` must have landed in every wave's view before it is read: own DMA
+    // pieces by counted vmcnt (up to D-2 later tiles stay in flight), the other
+    // waves' pieces by the barrier; lgkmcnt(0) first so that no ds_read of the stage
+    // about to be refilled is still pending when its DMA is issued.
     auto arrive = [&](int next) {
-        if (next + 1 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        wait_tiles<PPW, D - 2>(min(D - 2, nk - 1 - next), true);
         __builtin_amdgcn_s_barrier();
     };
 
-    // ring of 4 stages, DMA issued 3 tiles ahead (4 ahead measured 8 % slower)
-    issue(0, 0);
-    if (nk > 1) issue(1, BK);
-    if (nk > 2) issue(2, 2 * BK);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s_ = 0; s_ < D; ++s_)
+        if (s_ < nk) issue(s_);
+    wait_tiles<PPW, D - 1>(min(D - 1, nk - 1), false);
     __builtin_amdgcn_s_barrier();
     read_frags(0, a0, b0);
-    // steady state, branch-free (so that hipcc counts the 12 prefetch reads as
+    // steady state, branch-free (so that hipcc counts the prefetch reads as
     // allowed-outstanding in front of the MFMAs instead of waiting lgkmcnt(0))
     int t = 0;
-    for (; t + 4 < nk; t += 2) {
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    for (; t + D + 1 < nk; t += 2) {
+        wait_vm_lgkm0<(D - 2) * PPW>();
         __builtin_amdgcn_s_barrier();
         read_frags(t + 1, a1, b1);
-        issue((t + 3) & 3, (t + 3) * BK);
+        issue(t + D);
         mma(a0, b0);
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        wait_vm_lgkm0<(D - 2) * PPW>();
         __builtin_amdgcn_s_barrier();
         read_frags(t + 2, a0, b0);
-        issue((t + 4) & 3, (t + 4) * BK);
+        issue(t + D + 1);
         mma(a1, b1);
     }
-    for (; t < nk; t += 2) {  // tail (at most 4 tiles): same schedule with guards
+    for (; t < nk; t += 2) {  // tail: same schedule with guards
         if (t + 1 < nk) {
             arrive(t + 1);
             read_frags(t + 1, a1, b1);
         }
-        if (t + 3 < nk) issue((t + 3) & 3, (t + 3) * BK);
+        if (t + D < nk) issue(t + D);
         mma(a0, b0);
         if (t + 1 < nk) {
             if (t + 2 < nk) {
                 arrive(t + 2);
                 read_frags(t + 2, a0, b0);
             }
-            if (t + 4 < nk) issue((t + 4) & 3, (t + 4) * BK);
+            if (t + D + 1 < nk) issue(t + D + 1);
             mma(a1, b1);
         }
     }
 
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int trow = m0 + wm * 128 + i * 16;
+    for (int i = 0; i < WMT; ++i) {
+        const int trow = m0 + (wm * WMT + i) * 16;
         if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
-            for (int j = 0; j < 4; j += 2)
-                store_tile<EPI>(g, acc[i][j], acc[i][j + 1], trow, (n0 + wn * 64) / 2 + (j / 2) * 16, lane);
+            for (int j = 0; j < WNT; j += 2)
+                store_tile<EPI>(g, acc[i][j], acc[i][j + 1], trow, (n0 + wn * WNT * 16) / 2 + (j / 2) * 16, lane);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) store_tile<EPI>(g, acc[i][j], acc[i][j], trow, n0 + wn * 64 + j * 16, lane);
+            for (int j = 0; j < WNT; ++j)
+                store_tile<EPI>(g, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
         }
     }
 }
