@@ -8,12 +8,18 @@ quantise + LUT + PQ-code scan + top-k), queries and outputs resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the corpus
-is sharded by vector across the ranks (rank r holds rows i = r mod N); every
-rank brings its own 64-query batch; an all-gather shares the queries, every
-rank scans its shard for all 64*N queries, an all-gather of the per-shard
-top-k (the path's one exchange step) is merged on every rank.  Per-rank scan
-work is constant in N ("weak"); value = all queries of all ranks / time.
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL).  Query
+batches are independent units, and the whole cfg2 index is 72 MB (the 207 M
+index of cfg4 is 15 GB) against 288 GB of HBM per GPU, so the default
+`--multi-gpu-mode replicas` shards the *queries*: every rank holds the index and
+searches its own 64-query batches, no collective on the data path, per-rank work
+constant in N ("weak"); value = all queries of all ranks / max-over-ranks time.
+`--multi-gpu-mode shards` runs the north star's vector-sharded variant instead
+(rank r holds rows i = r mod N; all-gather of the ranks' query batches, every
+rank scans its shard for all 64*N queries, all-gather of the per-shard top-k --
+the path's one exchange step -- and a k-way merge); it is what a 207 M index
+uses to cut single-batch latency, and it is latency-bound by its collectives at
+cfg2 sizes.
 
 One JSON line on stdout (rank 0).  Extra objects: "roofline" (PQ-scan kernel,
 HIP events on the launch stream) and "cpu_baseline" (oracle port on the host
@@ -51,6 +57,8 @@ def main():
     ap.add_argument("--workload", choices=["search", "encode"], default="search",
                     help="search = cfg2 (the headline line); encode = cfg3 (stella_en_1.5B_v5 bf16 batch encode)")
     ap.add_argument("--encode-batch", type=int, default=128, help="abstracts per encode step")
+    ap.add_argument("--multi-gpu-mode", choices=["replicas", "shards"], default="replicas",
+                    help="N>1: replicas = query-parallel, no collective (default); shards = vector-sharded index + all-gather")
     ap.add_argument("--shard-coarse", type=int, default=0,
                     help="N>1: also split the coarse quantiser across ranks (pays off at IVF65536, not at cfg2)")
     ap.add_argument("--streams", type=int, default=4,
@@ -88,8 +96,9 @@ def main():
     index = faiss.IndexIVFPQ(d, args.nlist, M, 8, faiss.METRIC_INNER_PRODUCT, device=local_rank)
     index.cp.niter = args.train_iters
     force_sharded = bool(os.environ.get("BENCH_FORCE_SHARDED"))   # exercise the N>1 plumbing on one GPU
+    use_shards = (world > 1 and args.multi_gpu_mode == "shards") or force_sharded
     if world > 1 or force_sharded:
-        # rank 0 trains; centroids and codebook are broadcast so that every shard
+        # rank 0 trains; centroids and codebook are broadcast so that every rank
         # quantises with bit-identical tables (k-means uses atomic scatter-adds)
         cent = torch.empty((args.nlist, d), dtype=torch.float32, device=dev)
         cb = torch.empty((M, 256, d // M), dtype=torch.float32, device=dev)
@@ -102,23 +111,26 @@ def main():
             dist.broadcast(cb, 0)
         index.set_centroids(cent)
         index.set_codebook(cb)
-        ids = torch.arange(rank, args.corpus, world, device=dev)
-        index.add_with_ids(x[rank::world].contiguous(), ids)
+        if use_shards:
+            ids = torch.arange(rank, args.corpus, world, device=dev)
+            index.add_with_ids(x[rank::world].contiguous(), ids)
+        else:
+            index.add(x)                     # replica: the whole corpus on every rank
     else:
         index.train(x)
         index.add(x)
     index.nprobe = args.nprobe
-    sharded = ShardedIndex(index, shard_coarse=bool(args.shard_coarse)) if (world > 1 or force_sharded) else None
+    sharded = ShardedIndex(index, shard_coarse=bool(args.shard_coarse)) if use_shards else None
     log(f"[rank {rank}] setup {time.time() - t0:.1f}s ntotal={index.ntotal}")
 
-    NB = 16                               # pool of distinct query batches
+    NB = 16                               # pool of distinct query batches (different per rank)
     qpool = synth.queries_cuda(x, NB * args.batch * world, seed=4321).view(NB, world, args.batch, d)
     my_q = [qpool[b, rank].contiguous() for b in range(NB)]
     nq_out = args.batch
     # steps are independent query batches: they are issued round-robin on S
     # streams (each with its own output buffers and library workspaces) so that
     # consecutive batches overlap on the GPU, as a serving loop would run them
-    S = max(1, args.streams) if (world == 1 and not force_sharded) else 1
+    S = max(1, args.streams) if not use_shards else 1
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
     Ds = [torch.empty((nq_out, k), dtype=torch.float32, device=dev) for _ in range(S)]
     Is = [torch.empty((nq_out, k), dtype=torch.int64, device=dev) for _ in range(S)]
@@ -217,7 +229,8 @@ def main():
             "config": {"workload": "cfg2: 1Mx1024 clustered synthetic corpus, IVF4096,PQ64, batch-64 queries",
                        "corpus": args.corpus, "nlist": args.nlist, "M": 64, "nprobe": args.nprobe,
                        "k": k, "batch_per_rank": args.batch, "global_batch": args.batch * world,
-                       "parallelism": "1 GPU" if world == 1 else f"vector-sharded x{world} + all-gather top-k",
+                       "parallelism": "1 GPU" if world == 1 else (f"vector-sharded x{world} + all-gather top-k" if use_shards
+                                                                  else f"query-parallel replicas x{world} (no collective)"),
                        "launch": "eager (a hipGraph replay of the step measured slower)", "streams": S},
             "recall_at_10": None if recall is None else round(recall, 4),
             "roofline": roofline, "cpu_baseline": cpu,
