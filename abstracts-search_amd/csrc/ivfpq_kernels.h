@@ -290,18 +290,17 @@ struct ProbeTables {
 };
 
 // Per-row probe tables for the scan kernel from the selected list numbers
-// idx[row][0..K): first group and length of every probed list, exclusive prefix
-// of their group counts.  Whole 256-thread workgroup; idx was written by this
-// workgroup (or by an earlier kernel).
+// idx_row[0..K) (global or LDS): first group and length of every probed list,
+// exclusive prefix of their group counts.  Whole 256-thread workgroup.
 __device__ __forceinline__ void emit_probe_tables(const ProbeTables &pt, int64_t row, int K,
-                                                  const int32_t *__restrict__ idx, int *wtot) {
+                                                  const int32_t *idx_row, int *wtot) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int per = (K + 255) / 256;
     const int b = tid * per;
     int sum = 0;
     for (int i = 0; i < per; ++i)
         if (b + i < K) {
-            int l = idx[(size_t)row * K + b + i];
+            int l = idx_row[b + i];
             if (l >= 0) sum += pt.list_goff[l + 1] - pt.list_goff[l];
         }
     int incl = sum;
@@ -316,7 +315,7 @@ __device__ __forceinline__ void emit_probe_tables(const ProbeTables &pt, int64_t
     for (int ww = 0; ww < w; ++ww) run += wtot[ww];
     for (int i = 0; i < per; ++i)
         if (b + i < K) {
-            int l = idx[(size_t)row * K + b + i];
+            int l = idx_row[b + i];
             int g0 = 0, ng = 0, len = 0;
             if (l >= 0) {
                 g0 = pt.list_goff[l];
@@ -336,7 +335,7 @@ __device__ __forceinline__ void emit_probe_tables(const ProbeTables &pt, int64_t
 __global__ void __launch_bounds__(256)
     probe_tables_kernel(ProbeTables pt, int K, const int32_t *__restrict__ idx) {
     __shared__ int wtot[4];
-    emit_probe_tables(pt, blockIdx.x, K, idx, wtot);
+    emit_probe_tables(pt, blockIdx.x, K, idx + (size_t)blockIdx.x * K, wtot);
 }
 
 constexpr int SEL_CAP = 1024;  // survivor slots of the fast path
@@ -361,7 +360,7 @@ __global__ void __launch_bounds__(256)
     // ---- fast path (K <= 256): the K-th largest of the 256 per-thread maxima
     // is a lower bound of the K-th largest element, so everything below it is
     // dropped with one compare; the few survivors are ranked by counting.
-    bool done = false;
+    bool done = false, tables_done = false;
     if (K <= 256) {
         // thread t owns 4 interleaved groups: elements c with c%256 == t, (c/256)%4 == g.
         // K <= 64 uses the 256 per-thread maxima, larger K the 1024 group maxima
@@ -386,12 +385,12 @@ __global__ void __launch_bounds__(256)
             gkey[tid] = max(max(gm[0], gm[1]), max(gm[2], gm[3]));
             __syncthreads();
             const unsigned k0 = gkey[lane], k1 = gkey[lane + 64], k2 = gkey[lane + 128], k3 = gkey[lane + 192];
-#pragma unroll 4
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned t = T0 | (1u << bit);
                 const int c = __popcll(__ballot(k0 >= t)) + __popcll(__ballot(k1 >= t)) +
                               __popcll(__ballot(k2 >= t)) + __popcll(__ballot(k3 >= t));
                 if (c >= K) T0 = t;
+                if (c == K) break;  // t already separates exactly K group maxima
             }
         } else {
 #pragma unroll
@@ -400,13 +399,13 @@ __global__ void __launch_bounds__(256)
             unsigned kk[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) kk[i] = gkey4[i * 64 + lane];
-#pragma unroll 2
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned t = T0 | (1u << bit);
                 int c = 0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) c += __popcll(__ballot(kk[i] >= t));
                 if (c >= K) T0 = t;
+                if (c == K) break;
             }
         }
         // survivors: key >= T0 (NaN has key 0 and never survives)
@@ -468,11 +467,17 @@ __global__ void __launch_bounds__(256)
                 const int oi = o_i[tid];
                 const float os = o_s[tid];
                 const size_t o = (size_t)row * K + tid;
-                if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi + idx_off;
-                if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi + idx_off;
+                const int sel = oi == INT_MAX ? -1 : oi + idx_off;
+                if (out_i32) out_i32[o] = sel;
+                if (out_i64) out_i64[o] = (int64_t)sel;
                 if (out_s) out_s[o] = oi == INT_MAX ? -FLT_MAX : os;
+                c_rank[tid] = sel;   // the selection stays in LDS for the probe tables
             }
             __syncthreads();
+            if (pt.list_goff) {
+                emit_probe_tables(pt, row, K, c_rank, wtot);
+                tables_done = true;
+            }
             done = true;
         }
     }
@@ -541,7 +546,7 @@ __global__ void __launch_bounds__(256)
             __syncthreads();
         }
     }
-    if (pt.list_goff) emit_probe_tables(pt, row, K, out_i32, wtot);
+    if (pt.list_goff && !tables_done) emit_probe_tables(pt, row, K, out_i32 + (size_t)row * K, wtot);
 }
 
 template <int DSUB>
