@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         }
         const float s = c_dis0 + acc;
 
-        const float wthr = o2f(*reinterpret_cast<volatile unsigned *>(wg_thr));
+        const float wthr = o2f(__hip_atomic_load(wg_thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         const float thr_eff = fmaxf(thr, wthr);
         bool pf = (lane < c_nvalid) && (s >= thr_eff);
         if (has_bound) pf = pf && (s < bs || (s == bs && c_id > bid));
@@ -863,28 +863,34 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         }
     }
     __syncthreads();
+    // The slice's partial list is published WRITE-THROUGH (relaxed agent-scope
+    // atomic stores lower to `global_store ... sc1`), so the fused final merge
+    // needs no release / acquire fence: the last arriver reads the lists back with
+    // sc1 loads that bypass its L1 (guide section 6 G16, "R1" form; correct for any
+    // placement of the slices on CUs / XCDs).
     if (tid < k) {
         const size_t o = ((size_t)q * a.nslice + slice) * k + tid;
-        a.part_s[o] = o_s[tid];
-        a.part_id[o] = o_id[tid];
+        if (a.counters) {
+            __hip_atomic_store(reinterpret_cast<unsigned *>(a.part_s) + o, __float_as_uint(o_s[tid]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.part_id) + o,
+                               (unsigned long long)o_id[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            a.part_s[o] = o_s[tid];
+            a.part_id[o] = o_id[tid];
+        }
     }
     if (!a.counters) return;
 
-    // ---- fused final merge: publish this slice's partial list (agent-scope
-    // release), take a ticket; the last arriver acquires and merges.  Correct
-    // for any placement of the slices on CUs / XCDs (guide section 6, G16).
+    // ---- fused final merge: every storing wave drains its stores, one lane takes
+    // a ticket; the last arriver merges the query's partial lists.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned ticket =
             __hip_atomic_fetch_add(a.counters + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = ticket == (unsigned)(a.nslice - 1);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(a.counters + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (last) __hip_atomic_store(a.counters + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *c_total = last;
     }
     __syncthreads();
@@ -897,8 +903,10 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
     float *f_s = reinterpret_cast<float *>(f_id + 64);            // [64]
     for (int e = tid; e < n; e += 512) {
         const size_t o = (size_t)q * n + e;
-        e_id[e] = a.part_id[o];
-        e_s[e] = a.part_s[o];
+        e_id[e] = (int64_t)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.part_id) + o,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        e_s[e] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(a.part_s) + o,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         e_rank[e] = 0;
     }
     if (tid < 64) {
