@@ -45,6 +45,23 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
     MI_HIP(hipGetLastError());
 }
 
+template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
+void launch_ring32(int epi, GemmArgs g, hipStream_t st) {
+    constexpr int BM = 32 * WMT * WAVES_M, BN = 32 * WNT * WAVES_N;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    g.ksplit = 1;
+    const int per = (g.tiles_m * g.tiles_n + 7) / 8;
+    dim3 grid(8 * per), block(64 * WAVES_M * WAVES_N);
+    switch (epi) {
+        case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_ring32_kernel<EPI_STORE, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_ring32_kernel<EPI_RESID, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_ring32_kernel<EPI_QKV, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
+        default: throw Error("32x32 GEMM: epilogue not implemented");
+    }
+    MI_HIP(hipGetLastError());
+}
+
 void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
     MI_REQUIRE(g.K % 64 == 0, "encoder GEMM: K must be a multiple of 64");
     MI_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "encoder GEMM: leading dimensions must be multiples of 8");
@@ -62,7 +79,9 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         std::string cfg = force ? std::string(force) : "";
         if (cfg.empty()) cfg = g.M <= 64 ? "tiny" : tiles_big >= 100 ? "big" : tiles_mid >= 150 ? "mid" : "small";
         g.ksplit = 1;
-        if (cfg == "big") {
+        if (cfg == "big32" && epi != EPI_SWIGLU) {
+            launch_ring32<4, 2, 2, 4, 4>(epi, g, st);   // 256x256 on the 32x32x16 MFMA shape (experimental)
+        } else if (cfg == "big" || cfg == "big32") {
             launch_ring<8, 4, 2, 4, 4>(epi, g, st);
         } else if (cfg == "mid") {
             launch_ring<4, 4, 2, 2, 4>(epi, g, st);

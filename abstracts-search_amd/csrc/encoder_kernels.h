@@ -175,14 +175,13 @@ __device__ __forceinline__ f32x4 quad_transpose(f32x4 v, int lane) {
     return v;
 }
 
-// Epilogue of one 16x16 accumulator tile (two tiles for SwiGLU: gate and up).
-// trow = first row of the tile, tcol = first column (in C's column space).
+// Epilogue of 4 consecutive rows x 1 column held by a lane (the lanes of a quad
+// hold 4 consecutive columns of the same rows); two values for SwiGLU (gate, up).
+// row0 = first of the lane's 4 rows, col = the lane's column in C's column space.
 template <int EPI>
-__device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, f32x4 v2, int trow, int tcol, int lane) {
-    const int li = lane & 15, lg = lane >> 4;
+__device__ __forceinline__ void store_rows4(const GemmArgs &g, f32x4 v, f32x4 v2, int row0, int col, int lane) {
     if constexpr (EPI == EPI_QKV) {
-        if (tcol >= g.qk_cols) {  // V tile: 4 consecutive tokens of channel tcol+li -> one 8-byte store
-            const int col = tcol + li, row0 = trow + lg * 4;
+        if (col >= g.qk_cols) {  // V: 4 consecutive tokens of one channel -> one 8-byte store (V^T layout)
             if (col < g.N && row0 < g.M) {
                 const float bv = g.bias ? g.bias[col] : 0.f;
                 uint2 o;
@@ -193,7 +192,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, f32x4 v2,
             return;
         }
     }
-    const int row = trow + lg * 4 + (li & 3), col0 = tcol + (li & ~3);
+    const int row = row0 + (lane & 3), col0 = col & ~3;
     v = quad_transpose(v, lane);
     if constexpr (EPI == EPI_SWIGLU) {
         v2 = quad_transpose(v2, lane);
@@ -230,6 +229,13 @@ __device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, f32x4 v2,
             *reinterpret_cast<uint2 *>(g.C + (size_t)row * g.ldc + col0) = o;
         }
     }
+}
+
+// 16x16 accumulator tile: lane holds rows (lane>>4)*4 + r of column lane&15.
+// trow / tcol = first row / column of the tile (tcol in C's column space).
+template <int EPI>
+__device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, f32x4 v2, int trow, int tcol, int lane) {
+    store_rows4<EPI>(g, v, v2, trow + (lane >> 4) * 4, tcol + (lane & 15), lane);
 }
 
 template <int EPI>
@@ -482,6 +488,141 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
                 store_tile<EPI>(g, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
         }
     }
+}
+
+// ---------------------------------------------------------------------
+// Same ring pipeline on v_mfma_f32_32x32x16_bf16 (half the MFMA issue slots per
+// FLOP; microbenchmark ceiling 2.38 vs 2.08 PFLOP/s for the 16x16 shape).
+// Fragment maps: A lane l -> row l&31, k = 8*(l>>5)..+7 (+16 per k-step);
+// C lane l -> col l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16).
+// Experimental: EPI_STORE / EPI_RESID / EPI_QKV only (MI_GEMM_TILE=big32).
+// ---------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int EPI, int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
+__global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring32_kernel(GemmArgs g) {
+    constexpr int BM = 32 * WMT * WAVES_M, BN = 32 * WNT * WAVES_N, BK = 32;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int PA = BM / 16, PB = BN / 16;
+    static_assert((PA + PB) % NW == 0, "DMA pieces must divide evenly over the waves");
+    constexpr int PPW = (PA + PB) / NW;
+    constexpr int D = ST - 1;
+    static_assert(EPI != EPI_SWIGLU, "SwiGLU epilogue not implemented for the 32x32 shape");
+    __shared__ __attribute__((aligned(16))) bf16_t smem[ST * (BM + BN) * BK];
+
+    int tm, tn;
+    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn)) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w % WAVES_M, wn = w / WAVES_M;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int srow = lane >> 2;
+    const int scol = ((lane & 3) ^ ((0 - (lane >> 4)) & 3)) * 8;
+    const bf16_t *src[PPW];
+    int dst[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = w * PPW + i;
+        if (q < PA) {
+            src[i] = g.A + (size_t)min(m0 + q * 16 + srow, g.M - 1) * g.lda + scol;
+            dst[i] = q * 16 * BK;
+        } else {
+            src[i] = g.W + (size_t)min(n0 + (q - PA) * 16 + srow, g.N - 1) * g.ldw + scol;
+            dst[i] = BM * BK + (q - PA) * 16 * BK;
+        }
+    }
+    auto issue = [&](int tile) {
+        bf16_t *base = smem + (tile & (ST - 1)) * (BM + BN) * BK;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma16(src[i] + tile * BK, base + dst[i]);
+    };
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = g.K / BK;
+    // row = 32*tile + l31 -> (row >> 2) & 3 == (l31 >> 2) & 3; k slot = 2*kk + lh
+    const int fsw = (0 - (l31 >> 2)) & 3;
+    const int a_off = (wm * WMT * 32 + l31) * BK, b_off = BM * BK + (wn * WNT * 32 + l31) * BK;
+    bf16x8 a0[WMT][2], b0[WNT][2], a1[WMT][2], b1[WNT][2];
+    auto read_frags = [&](int tile, bf16x8(&a)[WMT][2], bf16x8(&b)[WNT][2]) {
+        const bf16_t *base = smem + (tile & (ST - 1)) * (BM + BN) * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int slot = ((2 * kk + lh) ^ fsw) * 8;
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) b[j][kk] = *reinterpret_cast<const bf16x8 *>(base + b_off + j * 32 * BK + slot);
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) a[i][kk] = *reinterpret_cast<const bf16x8 *>(base + a_off + i * 32 * BK + slot);
+        }
+    };
+    auto mma = [&](const bf16x8(&a)[WMT][2], const bf16x8(&b)[WNT][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                for (int j = 0; j < WNT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+    };
+    auto arrive = [&](int next) {
+        wait_tiles<PPW, D - 2>(min(D - 2, nk - 1 - next), true);
+        __builtin_amdgcn_s_barrier();
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < D; ++s_)
+        if (s_ < nk) issue(s_);
+    wait_tiles<PPW, D - 1>(min(D - 1, nk - 1), false);
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, a0, b0);
+    int t = 0;
+    for (; t + D + 1 < nk; t += 2) {
+        wait_vm_lgkm0<(D - 2) * PPW>();
+        __builtin_amdgcn_s_barrier();
+        read_frags(t + 1, a1, b1);
+        issue(t + D);
+        mma(a0, b0);
+        wait_vm_lgkm0<(D - 2) * PPW>();
+        __builtin_amdgcn_s_barrier();
+        read_frags(t + 2, a0, b0);
+        issue(t + D + 1);
+        mma(a1, b1);
+    }
+    for (; t < nk; t += 2) {
+        if (t + 1 < nk) {
+            arrive(t + 1);
+            read_frags(t + 1, a1, b1);
+        }
+        if (t + D < nk) issue(t + D);
+        mma(a0, b0);
+        if (t + 1 < nk) {
+            if (t + 2 < nk) {
+                arrive(t + 2);
+                read_frags(t + 2, a0, b0);
+            }
+            if (t + D + 1 < nk) issue(t + D + 1);
+            mma(a1, b1);
+        }
+    }
+    // epilogue: each group of 4 accumulator registers is 4 consecutive rows of one column
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
+                const int row0 = m0 + (wm * WMT + i) * 32 + 8 * g4 + 4 * lh;
+                const int col = n0 + (wn * WNT + j) * 32 + l31;
+                store_rows4<EPI>(g, v, v, row0, col, lane);
+            }
 }
 
 // ---------------------------------------------------------------------

@@ -187,3 +187,20 @@ def test_stella_shape_full_depth_vs_oracle(st):
         ref = E.encode(ocfg, Wc, np.concatenate(toks), cu, True).numpy()
     cos = (e * ref).sum(1)
     assert cos.min() > 1 - 1e-3, cos
+
+
+@pytest.mark.parametrize("tile", ["big", "big32", "mid", "small", "tiny", "128"])
+def test_gemm_tile_configs_vs_torch(st, tile, monkeypatch):
+    """every GEMM tile configuration (forced through MI_GEMM_TILE) against torch fp32"""
+    import torch
+    monkeypatch.setenv("MI_GEMM_TILE", tile)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for M, N, K in ((1024, 512, 1536), (40, 1536, 256), (777, 260, 128)):
+        A = torch.randn((M, K), generator=g, device="cuda").bfloat16()
+        W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).bfloat16()
+        A[:, 0] += 3.0
+        W[0, :] += 0.5
+        C = st.gemm_bf16(A, W).float()
+        ref = A.float() @ W.float().T
+        err = (C - ref).abs().max().item()
+        assert err <= 1e-2 * ref.abs().max().item() + 1e-3, (tile, M, N, K, err)
