@@ -46,7 +46,7 @@ void launch_gemm(const float *A, int64_t na, const float *B, int64_t nb, int d, 
     MI_REQUIRE(na > 0 && nb > 0, "empty gemm");
     MI_REQUIRE(na < ((int64_t)1 << 31) && nb < ((int64_t)1 << 31), "gemm dims exceed int32");
     if (na <= 16) launch_gemm_cfg<1, 1, 1, 4, 64, 4>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
-    else if (na <= 128) launch_gemm_cfg<1, 1, 4, 1, 64, 4>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
+    else if (na <= 128) launch_gemm_cfg<1, 1, 2, 2, 64, 4>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
     else if (na <= 512) launch_gemm_cfg<2, 2, 2, 2, 32, 2>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
     else launch_gemm_cfg<4, 4, 2, 2, 32, 1>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
 }

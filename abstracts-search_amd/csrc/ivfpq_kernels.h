@@ -66,11 +66,12 @@ __device__ __forceinline__ float o2f(unsigned o) {
 
 // ---------------------------------------------------------------------
 // S[na][nb] = A[na][d] . B[nb][d]^T, exact f32.
-// Workgroup tile BM x BN, K chunk BK, double-buffered through LDS in k-major
-// order so that lane (i = lane&15, g = lane>>4) reads A[k0+g][i]: the MFMA
-// then consumes k in ascending order and every output is an ascending-k fmaf
-// chain from +0.  LDS row stride == 16 (mod 32) keeps the four k-rows of one
-// operand fetch on disjoint banks.
+// Workgroup tile BM x BN, K chunk BK, double-buffered through LDS (row-major,
+// padded).  Lane (i = lane&15, g = lane>>4) feeds A[i][k0+g] to the MFMA, which
+// then consumes k in ascending order: every output is an ascending-k fmaf
+// chain from +0.  Small batches are bound by what one CU can pull out of L2
+// (~35 GB/s/CU measured), hence the 32x32 tile for 16 < na <= 128: the fewest
+// bytes per CU that still gives every CU a tile.
 // Grid: 8 * tiles_m * ceil(tiles_n/8); block b runs on XCD b%8, and all
 // blocks of one XCD walk the M tiles of the same B strip (L2 reuse of B).
 // ---------------------------------------------------------------------
@@ -91,7 +92,12 @@ struct LutArgs {
 
 template <int DSUB>
 __device__ __forceinline__ void lut_block(const LutArgs &a, int blk) {
-    const int m = blk % a.M, j = threadIdx.x;
+    // 256 codewords per (m, query tile): one 256-thread workgroup, or four
+    // 64-thread ones when appended to the wave-per-tile GEMM launch
+    const int parts = 256 / (int)blockDim.x;
+    const int j = (blk % parts) * (int)blockDim.x + threadIdx.x;
+    blk /= parts;
+    const int m = blk % a.M;
     const int q0 = (blk / a.M) * a.qtile;
     const int q1 = min(a.nq, q0 + a.qtile);
     float cb[DSUB];
@@ -123,13 +129,18 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
     constexpr int BN = 16 * WN * WAVES_N;
     constexpr int KQ = BK / 4;  // float4 per tile row
     constexpr int NT = WAVES_M * WAVES_N * 64;
-    constexpr int SA = (BM % 32 == 16) ? BM : BM + 16;
-    constexpr int SB = (BN % 32 == 16) ? BN : BN + 16;
+    // LDS tiles are row-major [rows][ST], ST = BK + 4 floats (ST/4 odd).  The staging
+    // store is one ds_write_b128 per loaded float4 (consecutive lanes = consecutive k-quads
+    // of one row: whole 128 B lines on the global side, consecutive banks on the LDS side),
+    // the operand read is a ds_read_b32 with immediate
+    // offsets (16 rows x 4 consecutive k -> banks 4*(odd*row) + lg: all 64).
+    constexpr int ST = BK + 4;
+    static_assert((ST / 4) % 2 == 1, "row stride must be an odd number of float4");
     constexpr int CA = (BM * KQ + NT - 1) / NT;
     constexpr int CB = (BN * KQ + NT - 1) / NT;
-    __shared__ float smem[2 * BK * (SA + SB)];
-    float *As = smem;                 // [2][BK][SA]
-    float *Bs = smem + 2 * BK * SA;   // [2][BK][SB]
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * ST];
+    float *As = smem;                 // [2][BM][ST]
+    float *Bs = smem + 2 * BM * ST;   // [2][BN][ST]
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, jb = bid >> 3;
@@ -153,28 +164,30 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
 #pragma unroll
         for (int y = 0; y < WN; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto gload = [&](int k0, float4(&pa)[CA], float4(&pb)[CB]) {
+    // `full` (a literal at every call site) marks a K chunk that lies inside d: its
+    // loads carry no guard at all.  A guarded load is an exec-masked branch, after which
+    // hipcc falls back to s_waitcnt vmcnt(0) and the PF-deep prefetch is gone (rows are
+    // clamped, never guarded; a thread without a tile row re-reads a clamped row).
+    auto gload = [&](int k0, float4(&pa)[CA], float4(&pb)[CB], bool full) {
 #pragma unroll
         for (int u = 0; u < CA; ++u) {
             int idx = tid + u * NT;
-            if ((BM * KQ) % NT == 0 || idx < BM * KQ) {
-                int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
-                int k = k0 + ((idx >> 4) & (KQ - 1)) * 4;
-                int gr = min(m0 + row, na - 1);
-                pa[u] = (k < d) ? *reinterpret_cast<const float4 *>(A + (size_t)gr * d + k)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            int row = idx / KQ;
+            int k = k0 + (idx % KQ) * 4;
+            int gr = min(m0 + row, na - 1);
+            if (full) pa[u] = *reinterpret_cast<const float4 *>(A + (size_t)gr * d + k);
+            else pa[u] = (k < d) ? *reinterpret_cast<const float4 *>(A + (size_t)gr * d + k)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
             int idx = tid + u * NT;
-            if ((BN * KQ) % NT == 0 || idx < BN * KQ) {
-                int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
-                int k = k0 + ((idx >> 4) & (KQ - 1)) * 4;
-                int gr = min(n0 + row, nb - 1);
-                pb[u] = (k < d) ? *reinterpret_cast<const float4 *>(B + (size_t)gr * d + k)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            int row = idx / KQ;
+            int k = k0 + (idx % KQ) * 4;
+            int gr = min(n0 + row, nb - 1);
+            if (full) pb[u] = *reinterpret_cast<const float4 *>(B + (size_t)gr * d + k);
+            else pb[u] = (k < d) ? *reinterpret_cast<const float4 *>(B + (size_t)gr * d + k)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto sstore = [&](int buf, const float4(&pa)[CA], const float4(&pb)[CB]) {
@@ -182,37 +195,31 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
         for (int u = 0; u < CA; ++u) {
             int idx = tid + u * NT;
             if ((BM * KQ) % NT == 0 || idx < BM * KQ) {
-                int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
-                float *p = As + buf * BK * SA + (((idx >> 4) & (KQ - 1)) * 4) * SA + row;
-                p[0] = pa[u].x;
-                p[SA] = pa[u].y;
-                p[2 * SA] = pa[u].z;
-                p[3 * SA] = pa[u].w;
+                int row = idx / KQ;
+                int kq = idx % KQ;
+                *reinterpret_cast<float4 *>(As + (buf * BM + row) * ST + kq * 4) = pa[u];
             }
         }
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
             int idx = tid + u * NT;
             if ((BN * KQ) % NT == 0 || idx < BN * KQ) {
-                int row = ((idx / (16 * KQ)) << 4) | (idx & 15);
-                float *p = Bs + buf * BK * SB + (((idx >> 4) & (KQ - 1)) * 4) * SB + row;
-                p[0] = pb[u].x;
-                p[SB] = pb[u].y;
-                p[2 * SB] = pb[u].z;
-                p[3 * SB] = pb[u].w;
+                int row = idx / KQ;
+                int kq = idx % KQ;
+                *reinterpret_cast<float4 *>(Bs + (buf * BN + row) * ST + kq * 4) = pb[u];
             }
         }
     };
     auto compute = [&](int buf) {
-        const float *ab = As + buf * BK * SA + lg * SA + wmi * WM * 16 + li;
-        const float *bb = Bs + buf * BK * SB + lg * SB + wni * WN * 16 + li;
+        const float *ab = As + (buf * BM + wmi * WM * 16 + li) * ST + lg;
+        const float *bb = Bs + (buf * BN + wni * WN * 16 + li) * ST + lg;
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             float a[WM], b[WN];
 #pragma unroll
-            for (int x = 0; x < WM; ++x) a[x] = ab[kk * 4 * SA + x * 16];
+            for (int x = 0; x < WM; ++x) a[x] = ab[x * 16 * ST + kk * 4];
 #pragma unroll
-            for (int y = 0; y < WN; ++y) b[y] = bb[kk * 4 * SB + y * 16];
+            for (int y = 0; y < WN; ++y) b[y] = bb[y * 16 * ST + kk * 4];
 #pragma unroll
             for (int x = 0; x < WM; ++x)
 #pragma unroll
@@ -221,21 +228,40 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
         }
     };
 
+    // LDS hand-off between the waves of the workgroup: own LDS writes retired, then the
+    // barrier.  (__syncthreads() would also drain vmcnt, i.e. the prefetched chunks.)
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     const int nk = (d + BK - 1) / BK;
+    if (PF * BK <= d) {
 #pragma unroll
-    for (int s = 0; s < PF; ++s)
-        if (s < nk) gload(s * BK, ra[s], rb[s]);
+        for (int s = 0; s < PF; ++s) gload(s * BK, ra[s], rb[s], true);
+    } else {
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+            if (s < nk) gload(s * BK, ra[s], rb[s], false);
+    }
     sstore(0, ra[0], rb[0]);
-    __syncthreads();
-    for (int t0 = 0; t0 < nk; t0 += PF) {
+    lds_barrier();
+    int t0 = 0;
+    for (; (t0 + 2 * PF) * BK <= d; t0 += PF) {   // steady state: branch-free, waits stay counted
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = t0 + u;
+            gload((t + PF) * BK, ra[u], rb[u], true);   // set u was stored to LDS last step
+            compute(t & 1);
+            sstore((t + 1) & 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+            lds_barrier();
+        }
+    }
+    for (; t0 < nk; t0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int t = t0 + u;
             if (t < nk) {
-                if (t + PF < nk) gload((t + PF) * BK, ra[u], rb[u]);   // set u was stored to LDS last step
+                if (t + PF < nk) gload((t + PF) * BK, ra[u], rb[u], false);
                 compute(t & 1);
                 if (t + 1 < nk) sstore((t + 1) & 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
-                __syncthreads();
+                lds_barrier();
             }
         }
     }
@@ -365,17 +391,25 @@ __global__ void __launch_bounds__(256)
         // thread t owns 4 interleaved groups: elements c with c%256 == t, (c/256)%4 == g.
         // K <= 64 uses the 256 per-thread maxima, larger K the 1024 group maxima
         // (the bound is only tight when there are several times more groups than K).
-        unsigned gm[4] = {0u, 0u, 0u, 0u};
-        for (int c0 = tid; c0 < n; c0 += 1024) {
+        // The row is walked in tiles of 256 x VPT with VPT unconditional (clamped) loads
+        // per thread in flight at once; a row of one tile (n <= 4096: every coarse
+        // quantiser up to IVF4096) stays in registers for the survivor pass.
+        constexpr int VPT = 16, TILE = 256 * VPT;
+        const bool one_tile = n <= TILE;
+        unsigned key[VPT];
+        auto load_tile = [&](int base) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = c0 + g * 256;
-                if (c < n) {
-                    const float v = r[c];
-                    const unsigned key = (v == v) ? f2o(v) : 0u;
-                    gm[g] = max(gm[g], key);
-                }
+            for (int j = 0; j < VPT; ++j) {
+                const int c = base + j * 256 + tid;
+                const float v = r[min(c, n - 1)];
+                key[j] = (c < n && v == v) ? f2o(v) : 0u;
             }
+        };
+        unsigned gm[4] = {0u, 0u, 0u, 0u};
+        for (int base = 0; base < n; base += TILE) {
+            load_tile(base);
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) gm[j & 3] = max(gm[j & 3], key[j]);
         }
         o_s[tid] = MI_NEG_INF;
         o_i[tid] = INT_MAX;
@@ -408,24 +442,31 @@ __global__ void __launch_bounds__(256)
                 if (c == K) break;
             }
         }
-        // survivors: key >= T0 (NaN has key 0 and never survives)
-        for (int base = 0; base < n; base += 256) {
-            const int c = base + tid;
-            float v = 0.f;
-            unsigned key = 0;
-            if (c < n) {
-                v = r[c];
-                key = (v == v) ? f2o(v) : 0u;
+        // survivors: key >= T0 (NaN has key 0 and never survives); one LDS atomic per
+        // wave and tile reserves the slots of all VPT ballots
+        for (int base = 0; base < n; base += TILE) {
+            if (!one_tile) load_tile(base);
+            unsigned long long m[VPT];
+            int tot = 0;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                m[j] = __ballot(key[j] != 0u && key[j] >= T0);
+                tot += __popcll(m[j]);
             }
-            const bool pf = key != 0u && key >= T0;
-            const unsigned long long mask = __ballot(pf);
-            if (mask) {
+            if (tot) {
                 int o = 0;
-                if (lane == 0) o = atomicAdd(&c_cnt, __popcll(mask));
-                o = uniform_i(o) + lane_prefix_count(mask);
-                if (pf && o < SEL_CAP) {
-                    c_s[o] = v;
-                    c_i[o] = c;
+                if (lane == 0) o = atomicAdd(&c_cnt, tot);
+                o = uniform_i(o);
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    if (m[j]) {
+                        const int pos = o + lane_prefix_count(m[j]);
+                        if (((m[j] >> lane) & 1ull) && pos < SEL_CAP) {
+                            c_s[pos] = o2f(key[j]);
+                            c_i[pos] = base + j * 256 + tid;
+                        }
+                        o += __popcll(m[j]);
+                    }
                 }
             }
         }
