@@ -61,7 +61,7 @@ def main():
                     help="N>1: replicas = query-parallel, no collective (default); shards = vector-sharded index + all-gather")
     ap.add_argument("--shard-coarse", type=int, default=0,
                     help="N>1: also split the coarse quantiser across ranks (pays off at IVF65536, not at cfg2)")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps are issued round-robin on (batches overlap on the GPU)")
     args = ap.parse_args()
 
@@ -163,6 +163,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     run(args.steps, args.warmup)
+    t_issue = time.perf_counter() - t1     # host time to issue the steps (diagnostic only)
     barrier()
     dt = time.perf_counter() - t1
     if world > 1:
@@ -231,7 +232,8 @@ def main():
                        "k": k, "batch_per_rank": args.batch, "global_batch": args.batch * world,
                        "parallelism": "1 GPU" if world == 1 else (f"vector-sharded x{world} + all-gather top-k" if use_shards
                                                                   else f"query-parallel replicas x{world} (no collective)"),
-                       "launch": "eager (a hipGraph replay of the step measured slower)", "streams": S},
+                       "launch": "eager (a hipGraph replay of the step measured slower)", "streams": S,
+                       "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 5)},
             "recall_at_10": None if recall is None else round(recall, 4),
             "roofline": roofline, "cpu_baseline": cpu,
         }
