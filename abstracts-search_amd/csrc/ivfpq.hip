@@ -5,6 +5,7 @@
 #include "../../include/mi_ivfpq.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -120,7 +121,7 @@ void launch_scan_m(const ScanArgs &a, size_t smem, hipStream_t st) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((scan_kernel<M>), dim3((unsigned)((int64_t)a.nq * a.nslice)), dim3(512), smem,
+    hipLaunchKernelGGL((scan_kernel<M>), dim3(scan_grid(a.nq, a.nslice)), dim3(512), smem,
                        st, a);
     MI_HIP(hipGetLastError());
 }
@@ -538,6 +539,34 @@ int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_a
         MI_HIP(hipEventElapsedTime(&ms, e0, e1));
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
+        if (std::getenv("MI_SCAN_TS")) {
+            // one more replay with in-kernel s_memtime stamps: mean/max time of each phase
+            // boundary relative to the earliest workgroup start, printed to stderr
+            const size_t nb = scan_grid(w.last_scan.nq, w.last_scan.nslice);
+            DevBuf tsb;
+            unsigned long long *dts = tsb.as<unsigned long long>(nb * SCAN_TS);
+            MI_HIP(hipMemsetAsync(dts, 0, nb * SCAN_TS * 8, st));
+            ScanArgs sa = w.last_scan;
+            sa.ts = dts;
+            launch_scan(h->M, sa, st);
+            std::vector<unsigned long long> hts(nb * SCAN_TS);
+            MI_HIP(hipStreamSynchronize(st));
+            MI_HIP(hipMemcpy(hts.data(), dts, nb * SCAN_TS * 8, hipMemcpyDeviceToHost));
+            // every XCD has its own counter: only differences inside one workgroup mean anything
+            std::fprintf(stderr, "[scan stamps] %zu workgroups, s_memtime ticks since the workgroup's own start\n", nb);
+            for (int i = 1; i < SCAN_TS; ++i) {
+                double sum = 0, mx = 0, mn = 1e30;
+                size_t cntb = 0;
+                for (size_t b = 0; b < nb; ++b) {
+                    const unsigned long long v = hts[b * SCAN_TS + i], v0 = hts[b * SCAN_TS];
+                    if (!v || !v0) continue;
+                    const double dv = (double)(v - v0);
+                    sum += dv; mx = std::max(mx, dv); mn = std::min(mn, dv);
+                    ++cntb;
+                }
+                if (cntb) std::fprintf(stderr, "  stamp %2d: n=%5zu  min %8.0f  mean %8.0f  max %8.0f\n", i, cntb, mn, sum / cntb, mx);
+            }
+        }
         unsigned long long c = 0;
         MI_HIP(hipMemcpy(&c, cnt, 8, hipMemcpyDeviceToHost));
         if (scan_ms_avg) *scan_ms_avg = (double)ms / reps;
@@ -628,6 +657,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         a.bound_s = pass ? bs : nullptr; a.bound_id = pass ? bid : nullptr;
         a.nq = (int)nq; a.nprobe = nprobe; a.nslice = nslice; a.k = kp; a.by_residual = h->by_residual;
         a.debug = 0;
+        a.ts = nullptr;
         if (const char *e = std::getenv("MI_SCAN_DEBUG")) a.debug = std::atoi(e);
         // the last slice of each query merges the partial lists in-kernel when
         // they fit in the LUT's LDS region; otherwise a separate merge kernel

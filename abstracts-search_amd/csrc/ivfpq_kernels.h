@@ -37,6 +37,25 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 __device__ __forceinline__ unsigned readlane_u(unsigned v, int l) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, l);
 }
+// LDS-DMA issued from inline asm: lane i's 16 (4) bytes at gptr land at
+// lds_wave_base + 16 i (4 i).  hipcc treats the builtin form as an LDS write and puts
+// s_waitcnt vmcnt(0) in front of every later LDS read; with the asm form the waits
+// are ours (counted s_waitcnt vmcnt(N): loads and DMAs retire in issue order).
+__device__ __forceinline__ void dma16_lds(const void *gptr, void *lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n" ::"s"(m0v), "v"(gptr) : "memory");
+}
+__device__ __forceinline__ void dma4_lds(const void *gptr, void *lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n" ::"s"(m0v), "v"(gptr) : "memory");
+}
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int l) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v & 0xffffffffu), l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), l);
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float uniform_f(float v) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
@@ -630,6 +649,7 @@ struct ScanArgs {
     const int64_t *bound_id;   //      (bound_s, bound_id) are eligible
     int nq, nprobe, nslice, k, by_residual;
     int debug;  // ablation switches for tools/scan_ablate.py (0 in production)
+    unsigned long long *ts;    // null, or [workgroups][SCAN_TS] s_memtime stamps (MI_SCAN_TS=1 profile replay)
     // fused final merge (the last slice of a query to finish merges all of the
     // query's partial lists; counters must be zero on entry and are left zero)
     unsigned *counters;        // [nq] or null = separate merge kernel
@@ -647,13 +667,18 @@ __host__ __device__ inline size_t scan_fused_merge_bytes(int nslice, int k) {
 }
 
 constexpr int SCAN_NW = 8;        // waves per workgroup
+constexpr int SCAN_TS = 16;       // phase stamps per workgroup (profiling replay only)
 constexpr int SCAN_WBUF = 128;    // candidate slots per wave
 
-// LDS carve: [ LUT M KiB (>= 10 KiB, reused by the final merge) | wave buffers
+// LDS carve: [ LUT M KiB (>= 16 KiB, reused by the selection tail) | wave buffers
 //              8 x 128 x (8+4) B | prefix | p_goff | p_len | p_dis | misc 16 B ]
 __host__ __device__ inline size_t scan_lut_bytes(int M) {
     size_t b = (size_t)M * 1024;
-    return b < 10240 ? 10240 : b;
+    return b < 16384 ? 16384 : b;
+}
+// grid of the scan launch: the slices of a query share an XCD (see the kernel)
+__host__ __device__ inline unsigned scan_grid(int nq, int nslice) {
+    return 8u * (unsigned)((nq + 7) / 8) * (unsigned)nslice;
 }
 __host__ __device__ inline int scan_tab_stride(int nprobe) { return (nprobe + 1 + 3) & ~3; }
 __host__ __device__ inline size_t scan_smem_bytes(int M, int nprobe) {
@@ -674,6 +699,52 @@ __device__ __forceinline__ unsigned wave_kth_largest(unsigned ka, unsigned kb, i
         if (c == k) break;
     }
     return prefix;
+}
+
+// the same over N keys per lane; 0 when fewer than k keys are set
+template <int N>
+__device__ __forceinline__ unsigned wave_kth_largest_n(const unsigned (&key)[N], int k) {
+    int nz = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) nz += __popcll(__ballot(key[i] != 0u));
+    if (nz < k) return 0u;
+    unsigned prefix = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned t = prefix | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) c += __popcll(__ballot(key[i] >= t));
+        if (c >= k) prefix = t;
+        if (c == k) break;
+    }
+    return prefix;
+}
+
+// Rank (number of better entries) of this lane's entry among the wave's first n
+// lanes under (score desc, id asc, slot asc); empty entries carry key 0 and count
+// for nobody.  The common case is one readlane and one compare/add per step on the
+// order-preserving score keys; the full predicate only runs when two scores tie.
+__device__ __forceinline__ int wave_rank(unsigned key, int64_t id, int n, int lane) {
+    int gt = 0;
+#pragma unroll 8
+    for (int j = 0; j < n; ++j) gt += readlane_u(key, j) > key;
+    // Distinct keys give the set entries the ranks 0 .. nset-1 exactly once; a tie
+    // lowers somebody's rank, so the rank sum tells whether any two scores tie.
+    const bool set = key != 0u;
+    const int nset = __popcll(__ballot(set));
+    int sum = set ? gt : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (uniform_i(sum) != nset * (nset - 1) / 2) {
+        int r = 0;
+        for (int j = 0; j < n; ++j) {
+            const unsigned jk = readlane_u(key, j);
+            const int64_t jid = readlane_i64(id, j);
+            r += (jk > key) || (jk == key && (jid < id || (jid == id && j < lane)));
+        }
+        return r;
+    }
+    return gt;
 }
 
 // Reduce a wave's candidate buffer (cnt <= 128 entries) to its exact top-k
@@ -733,35 +804,81 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = uniform_i(tid >> 6);
-    const int q = blockIdx.x / a.nslice, slice = blockIdx.x % a.nslice;
+    // Workgroup b runs on XCD b % 8: the nslice slices of one query are placed on ONE
+    // XCD (grid = 8 x ceil(nq/8) x nslice), so the query's LUT is fetched from HBM
+    // once and re-staged from that XCD's L2 by the other slices.
+    const int q = ((int)(blockIdx.x >> 3) / a.nslice) * 8 + (int)(blockIdx.x & 7);
+    const int slice = (int)(blockIdx.x >> 3) % a.nslice;
+    if (q >= a.nq) return;
     const int nprobe = a.nprobe, k = a.k;
+    auto stamp = [&](int i) {   // wave 0 only; no-op unless a profiling replay asked for stamps
+        if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * SCAN_TS + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     int64_t *buf_id = reinterpret_cast<int64_t *>(wb) + w * SCAN_WBUF;                          // [8][128]
     float *buf_s = reinterpret_cast<float *>(wb + (size_t)SCAN_NW * SCAN_WBUF * 8) + w * SCAN_WBUF;  // [8][128]
 
+    // ---- probe tables.  nprobe <= 64: every wave keeps its own copy in registers
+    // (lane p = probe p), so locating a group is one ballot + readlanes and the first
+    // code groups are requested while the LUT is still in flight.  The copy travels
+    // by LDS-DMA into the wave's (still unused) candidate buffer, issued BEFORE the LUT
+    // rows: a counted wait then covers the tables but not the LUT.
+    // Larger nprobe: tables staged in LDS by the whole workgroup.
+    const bool reg_tab = nprobe <= 64;
+    constexpr int LUT_ROWS = (M + SCAN_NW - 1) / SCAN_NW;   // LUT rows staged per wave
+    if (reg_tab) {
+        const int pl = min(lane, nprobe - 1);
+        const size_t o = (size_t)q * nprobe + pl;
+        unsigned char *wt = reinterpret_cast<unsigned char *>(buf_id);
+        dma4_lds(a.p_prefix + (size_t)q * (nprobe + 1) + pl, wt);
+        dma4_lds(a.p_goff + o, wt + 256);
+        dma4_lds(a.p_len + o, wt + 512);
+        dma4_lds(a.by_residual ? a.coarse_dis + o : reinterpret_cast<const float *>(a.p_len + o), wt + 768);
+        dma4_lds(a.p_prefix + (size_t)q * (nprobe + 1) + pl + 1, buf_s);
+    }
     // ---- stage the query's LUT: row m (1 KiB) by one global_load_lds_dwordx4
     // per wave (LDS-DMA: wave-uniform LDS base + lane*16, no VGPR round trip)
     if (!(a.debug & 8)) {
         const float *lg = a.lut + (size_t)q * M * 256 + lane * 4;
-        for (int m = w; m < M; m += SCAN_NW)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(lg + m * 256),
-                (__attribute__((address_space(3))) void *)(lut_s + m * 256), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < LUT_ROWS; ++i) {
+            const int m = w + i * SCAN_NW;
+            if (M % SCAN_NW == 0 || m < M) dma16_lds(lg + m * 256, lut_s + m * 256);
+        }
     }
-    for (int p = tid; p < nprobe; p += 512) {
-        const size_t o = (size_t)q * nprobe + p;
-        prefix[p] = a.p_prefix[(size_t)q * (nprobe + 1) + p];
-        p_goff[p] = a.p_goff[o];
-        p_len[p] = a.p_len[o];
-        p_dis[p] = a.by_residual ? a.coarse_dis[o] : 0.0f;
+    int r_pre0 = 0, r_pre1 = INT_MAX, r_goff = 0, r_len = 0;
+    float r_dis = 0.f;
+    if (reg_tab) {
+        // tables landed once at most the (later issued) LUT rows are outstanding
+        if (a.debug & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(M / SCAN_NW) : "memory");
+        const int *wt = reinterpret_cast<const int *>(buf_id);
+        r_pre0 = wt[lane];
+        r_goff = wt[64 + lane];
+        r_len = wt[128 + lane];
+        if (a.by_residual) r_dis = __int_as_float(wt[192 + lane]);
+        r_pre1 = reinterpret_cast<const int *>(buf_s)[lane];
+    }
+    if (!reg_tab) {
+        for (int p = tid; p < nprobe; p += 512) {
+            const size_t o = (size_t)q * nprobe + p;
+            prefix[p] = a.p_prefix[(size_t)q * (nprobe + 1) + p];
+            p_goff[p] = a.p_goff[o];
+            p_len[p] = a.p_len[o];
+            p_dis[p] = a.by_residual ? a.coarse_dis[o] : 0.0f;
+        }
+        if (tid == 0) prefix[nprobe] = a.p_prefix[(size_t)q * (nprobe + 1) + nprobe];
     }
     if (tid == 0) {
-        prefix[nprobe] = a.p_prefix[(size_t)q * (nprobe + 1) + nprobe];
         *wg_thr = f2o(MI_NEG_INF);
         *c_total = 0;
     }
-    __syncthreads();  // LUT (DMA drained by the barrier's vmcnt(0)) and tables visible
+    if (!reg_tab) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // LDS tables visible (also drains the LUT DMA)
+    }
 
-    const int G = prefix[nprobe];
+    const int G = reg_tab ? __builtin_amdgcn_readlane(r_pre1, nprobe - 1) : prefix[nprobe];
     const int beg = (int)(((int64_t)G * slice) / a.nslice);
     const int end = (int)(((int64_t)G * (slice + 1)) / a.nslice);
 
@@ -779,7 +896,7 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
     // work items = 64-code groups [beg, end), dealt round-robin to the waves
     int t = beg + w;
     int p = 0;
-    if (t < end) {  // smallest p with prefix[p+1] > t
+    if (!reg_tab && t < end) {  // smallest p with prefix[p+1] > t
         int lo = 0, hi = nprobe - 1;
         while (lo < hi) {
             int mid = (lo + hi) >> 1;
@@ -788,36 +905,44 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         }
         p = lo;
     }
-    uint4 cur[NCH];
-    int64_t c_id = 0;
-    int c_nvalid = 0;
-    float c_dis0 = 0.f;
-    auto locate_and_load = [&](int tt, uint4(&buf)[NCH], int64_t &id, int &nvalid, float &dis0) {
-        while (uniform_i(prefix[p + 1]) <= tt) ++p;
-        const int gi = tt - uniform_i(prefix[p]);
-        const int gg = uniform_i(p_goff[p]) + gi;
-        nvalid = min(64, uniform_i(p_len[p]) - gi * 64);
-        dis0 = uniform_f(p_dis[p]);
+    struct Group {
+        uint4 c[NCH];
+        int64_t id;
+        int nvalid;
+        float dis0;
+    };
+    auto locate_and_load = [&](int tt, Group &g) {
+        int gi, gg;
+        if (reg_tab) {
+            // probes whose group range ends at or before tt: prefix is non-decreasing
+            const int pp = __popcll(__ballot(lane < nprobe && r_pre1 <= tt));
+            gi = tt - __builtin_amdgcn_readlane(r_pre0, pp);
+            gg = __builtin_amdgcn_readlane(r_goff, pp) + gi;
+            g.nvalid = min(64, __builtin_amdgcn_readlane(r_len, pp) - gi * 64);
+            g.dis0 = readlane_f(r_dis, pp);
+        } else {
+            while (uniform_i(prefix[p + 1]) <= tt) ++p;
+            gi = tt - uniform_i(prefix[p]);
+            gg = uniform_i(p_goff[p]) + gi;
+            g.nvalid = min(64, uniform_i(p_len[p]) - gi * 64);
+            g.dis0 = uniform_f(p_dis[p]);
+        }
         const uint4 *gp = reinterpret_cast<const uint4 *>(a.codes + (size_t)gg * (NCH * 1024)) + lane;
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) buf[ch] = gp[ch * 64];
-        id = a.ids[(size_t)gg * 64 + lane];
+        for (int ch = 0; ch < NCH; ++ch) g.c[ch] = gp[ch * 64];
+        g.id = a.ids[(size_t)gg * 64 + lane];
     };
-    if (t < end) locate_and_load(t, cur, c_id, c_nvalid, c_dis0);
-
-    while (t < end) {
-        const int tn = t + SCAN_NW;
-        uint4 nxt[NCH];
-        int64_t n_id = 0;
-        int n_nvalid = 0;
-        float n_dis0 = 0.f;
-        if (tn < end) locate_and_load(tn, nxt, n_id, n_nvalid, n_dis0);
-
+    // Two groups per wave are requested before the LUT barrier (most of a cfg2-sized
+    // slice is then in flight while the LUT is staged) and the loop keeps two in flight,
+    // rotating three register sets by name (a copy would wait for the newest load).
+    // A fourth set measured slower: 162 VGPRs, one workgroup per CU instead of two.
+    int n_proc = 0;
+    auto process = [&](const Group &g, bool more) {
         // M table look-ups, m ascending, f32 adds in that order (= the oracle)
         float acc = 0.f;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            const unsigned wd[4] = {cur[ch].x, cur[ch].y, cur[ch].z, cur[ch].w};
+            const unsigned wd[4] = {g.c[ch].x, g.c[ch].y, g.c[ch].z, g.c[ch].w};
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int m = ch * 16 + j;
@@ -827,104 +952,230 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
                 }
             }
         }
-        const float s = c_dis0 + acc;
+        const float s = g.dis0 + acc;
+        if (n_proc == 0) stamp(13);
 
         const float wthr = o2f(__hip_atomic_load(wg_thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         const float thr_eff = fmaxf(thr, wthr);
-        bool pf = (lane < c_nvalid) && (s >= thr_eff);
-        if (has_bound) pf = pf && (s < bs || (s == bs && c_id > bid));
+        bool pf = (lane < g.nvalid) && (s >= thr_eff);
+        if (has_bound) pf = pf && (s < bs || (s == bs && g.id > bid));
         unsigned long long mask = __ballot(pf);
         if (a.debug & 1) mask = 0;
         if (mask) {
             if (pf) {
                 const int o = cnt + lane_prefix_count(mask);
                 buf_s[o] = s;
-                buf_id[o] = c_id;
+                buf_id[o] = g.id;
             }
             cnt += __popcll(mask);
-            if (cnt > 64) {
+            // room for the next group (and a tighter threshold for everybody) -- unless this
+            // was the wave's last group: the selection tail takes up to 128 entries as they are
+            if (cnt > 64 && more) {
                 wave_compress(buf_s, buf_id, lane, k, cnt, thr);
                 if (thr > wthr && lane == 0) atomicMax(wg_thr, f2o(thr));
             }
         }
-
-        t = tn;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) cur[ch] = nxt[ch];
-        c_id = n_id;
-        c_nvalid = n_nvalid;
-        c_dis0 = n_dis0;
+        if (n_proc == 0) stamp(3);
+        ++n_proc;
+    };
+    Group g0{}, g1{};
+    if (t < end) locate_and_load(t, g0);
+    if (t + SCAN_NW < end) locate_and_load(t + SCAN_NW, g1);
+    stamp(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own LUT rows (DMA) and the first code groups
+    __syncthreads();  // every wave's LUT rows are in LDS
+    stamp(2);
+    while (t < end) {
+        process(g0, t + SCAN_NW < end);
+        if (t + 2 * SCAN_NW < end) locate_and_load(t + 2 * SCAN_NW, g0);
+        t += SCAN_NW;
+        if (t >= end) break;
+        process(g1, t + SCAN_NW < end);
+        if (t + 2 * SCAN_NW < end) locate_and_load(t + 2 * SCAN_NW, g1);
+        t += SCAN_NW;
     }
-    if (cnt > k) wave_compress(buf_s, buf_id, lane, k, cnt, thr);
 
-    // ---- gather the waves' survivors (<= 8k) and rank them by counting
+    stamp(4);
+    const bool va = lane < cnt, vb = lane + 64 < cnt;
+    const float sa = va ? buf_s[lane] : 0.f, sb = vb ? buf_s[lane + 64] : 0.f;
+    const int64_t ia = va ? buf_id[lane] : 0, ib = vb ? buf_id[lane + 64] : 0;
+    const unsigned ka = va ? f2o(sa) : 0u, kb = vb ? f2o(sb) : 0u;
+    unsigned *tmax = reinterpret_cast<unsigned *>(wb + (size_t)SCAN_NW * SCAN_WBUF * 8);  // over buf_s
+    tmax[w * SCAN_WBUF + lane] = max(ka, kb);
     __syncthreads();  // every wave is done with the LUT: its LDS is reused below
-    int64_t *g_id = reinterpret_cast<int64_t *>(lut_s);          // [512]
-    float *g_s = lut_s + 1024;                                   // [512]
-    int *g_rank = reinterpret_cast<int *>(lut_s) + 1536;         // [512]
-    int64_t *o_id = reinterpret_cast<int64_t *>(lut_s + 2048);   // [64]
-    float *o_s = lut_s + 2048 + 128;                             // [64]
-    int woff = 0;
-    if (lane == 0 && cnt > 0) woff = atomicAdd(c_total, cnt);
-    woff = uniform_i(woff);
-    if (lane < cnt) {
-        g_s[woff + lane] = buf_s[lane];
-        g_id[woff + lane] = buf_id[lane];
+    stamp(5);
+    // Any k distinct candidates bound the k-th largest from below, so for small k the
+    // 512 thread maxima are first folded to 64 (k <= 16) or 128 (k <= 32) column maxima:
+    // the descent then costs one or two ballots per step instead of eight.
+    unsigned T0 = 0;
+    {
+        unsigned kk[SCAN_NW];
+#pragma unroll
+        for (int ww = 0; ww < SCAN_NW; ++ww) kk[ww] = tmax[ww * SCAN_WBUF + lane];
+        if (k <= 16) {
+            const unsigned f[1] = {max(max(max(kk[0], kk[1]), max(kk[2], kk[3])),
+                                   max(max(kk[4], kk[5]), max(kk[6], kk[7])))};
+            T0 = wave_kth_largest_n<1>(f, k);
+        } else if (k <= 32) {
+            const unsigned f[2] = {max(max(kk[0], kk[1]), max(kk[2], kk[3])),
+                                   max(max(kk[4], kk[5]), max(kk[6], kk[7]))};
+            T0 = wave_kth_largest_n<2>(f, k);
+        } else {
+            T0 = wave_kth_largest_n<SCAN_NW>(kk, k);
+        }
     }
-    g_rank[tid] = 0;
-    if (tid < 64) {
-        o_s[tid] = MI_NEG_INF;
-        o_id[tid] = EMPTY_ID;
-    }
-    __syncthreads();
-    const int C = *c_total;  // <= 8 * 64
-    if (C > 0 && !(a.debug & 2)) {
-        const int P = max(1, 512 / C);          // thread groups sharing the j range
-        const int part = tid / C, e = tid - part * C;
-        if (part < P) {
-            const float es = g_s[e];
-            const int64_t eid = g_id[e];
-            const int j0 = (C * part) / P, j1 = (C * (part + 1)) / P;
-            int r = 0;
-#pragma unroll 4
-            for (int j = j0; j < j1; ++j) {
-                const float js = g_s[j];
-                const int64_t jid = g_id[j];
-                r += (js > es) || (js == es && (jid < eid || (jid == eid && j < e)));
+    int64_t *g_id = reinterpret_cast<int64_t *>(lut_s);          // [1024]
+    float *g_s = lut_s + 2048;                                   // [1024]
+    int *g_rank = reinterpret_cast<int *>(lut_s) + 3072;         // [1024]
+    int64_t *o_id = reinterpret_cast<int64_t *>(wb);             // [64]  (over buf_id, dead by now)
+    float *o_s = reinterpret_cast<float *>(wb + 512);            // [64]
+    {
+        const bool pa = ka != 0u && ka >= T0, pb = kb != 0u && kb >= T0;
+        const unsigned long long ma = __ballot(pa), mb = __ballot(pb);
+        const int na = __popcll(ma), tot = na + __popcll(mb);
+        if (tot) {
+            int o = 0;
+            if (lane == 0) o = atomicAdd(c_total, tot);
+            o = uniform_i(o);
+            if (pa) {
+                const int x = o + lane_prefix_count(ma);
+                g_s[x] = sa;
+                g_id[x] = ia;
             }
-            if (r) atomicAdd(&g_rank[e], r);
+            if (pb) {
+                const int x = o + na + lane_prefix_count(mb);
+                g_s[x] = sb;
+                g_id[x] = ib;
+            }
         }
     }
+    stamp(6);
     __syncthreads();
-    if (tid < C) {
-        const int r = g_rank[tid];
-        if (r < k) {
-            o_s[r] = g_s[tid];
-            o_id[r] = g_id[tid];
-        }
-    }
-    __syncthreads();
+    stamp(7);
+    const int C = uniform_i(*c_total);  // <= 1024
+    const size_t part_o = ((size_t)q * a.nslice + slice) * k;
     // The slice's partial list is published WRITE-THROUGH (relaxed agent-scope
     // atomic stores lower to `global_store ... sc1`), so the fused final merge
     // needs no release / acquire fence: the last arriver reads the lists back with
     // sc1 loads that bypass its L1 (guide section 6 G16, "R1" form; correct for any
     // placement of the slices on CUs / XCDs).
-    if (tid < k) {
-        const size_t o = ((size_t)q * a.nslice + slice) * k + tid;
+    auto publish = [&](int pos, float ps, int64_t pid) {
         if (a.counters) {
-            __hip_atomic_store(reinterpret_cast<unsigned *>(a.part_s) + o, __float_as_uint(o_s[tid]),
+            __hip_atomic_store(reinterpret_cast<unsigned *>(a.part_s) + part_o + pos, __float_as_uint(ps),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.part_id) + o,
-                               (unsigned long long)o_id[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.part_id) + part_o + pos,
+                               (unsigned long long)pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            a.part_s[o] = o_s[tid];
-            a.part_id[o] = o_id[tid];
+            a.part_s[part_o + pos] = ps;
+            a.part_id[part_o + pos] = pid;
         }
+    };
+    const bool small_rank = C <= 64;
+    if (small_rank) {
+        if (w == 0) {
+            const bool v = lane < C;
+            const float es = v ? g_s[lane] : 0.f;
+            const int64_t eid = v ? g_id[lane] : 0;
+            const int r = (a.debug & 2) ? 0 : wave_rank(v ? f2o(es) : 0u, eid, C, lane);
+            if (v) {
+                if (r < k) publish(r, es, eid);
+            } else if (lane < k) {
+                publish(lane, MI_NEG_INF, EMPTY_ID);   // positions C .. k-1
+            }
+        }
+    } else {
+        for (int e = tid; e < C; e += 512) g_rank[e] = 0;
+        if (tid < 64) {
+            o_s[tid] = MI_NEG_INF;
+            o_id[tid] = EMPTY_ID;
+        }
+        __syncthreads();
+        if (!(a.debug & 2)) {
+            const int P = C < 512 ? max(1, 512 / C) : 1;   // thread groups sharing the j range
+            for (int e0 = 0; e0 < C; e0 += 512) {
+                const int part = C < 512 ? tid / C : 0;
+                const int e = C < 512 ? tid - part * C : e0 + tid;
+                if (part < P && e < C) {
+                    const float es = g_s[e];
+                    const int64_t eid = g_id[e];
+                    const int j0 = (C * part) / P, j1 = (C * (part + 1)) / P;
+                    int r = 0;
+#pragma unroll 4
+                    for (int j = j0; j < j1; ++j) {
+                        const float js = g_s[j];
+                        const int64_t jid = g_id[j];
+                        r += (js > es) || (js == es && (jid < eid || (jid == eid && j < e)));
+                    }
+                    if (r) atomicAdd(&g_rank[e], r);
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < C; e += 512) {
+            const int r = g_rank[e];
+            if (r < k) {
+                o_s[r] = g_s[e];
+                o_id[r] = g_id[e];
+            }
+        }
+        __syncthreads();
+        if (tid < k) publish(tid, o_s[tid], o_id[tid]);
     }
+    stamp(8);
     if (!a.counters) return;
 
-    // ---- fused final merge: every storing wave drains its stores, one lane takes
-    // a ticket; the last arriver merges the query's partial lists.
+    // ---- fused final merge.  Small case (this slice ranked by wave 0 and the
+    // query's nslice*k partial entries fit one wave): wave 0 alone drains its
+    // stores, takes the ticket and, as the last arriver, merges in registers.
+    if (small_rank && a.nslice * k <= 64) {
+        if (w != 0) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(9);
+        unsigned ticket = 0;
+        if (lane == 0)
+            ticket = __hip_atomic_fetch_add(a.counters + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = (unsigned)uniform_i((int)ticket);
+        stamp(10);
+        if (ticket != (unsigned)(a.nslice - 1)) return;
+        if (lane == 0) __hip_atomic_store(a.counters + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int n = a.nslice * k;
+        int64_t eid = EMPTY_ID;
+        float es = 0.f;
+        if (lane < n) {
+            const size_t o = (size_t)q * n + lane;
+            eid = (int64_t)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.part_id) + o,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            es = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(a.part_s) + o,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        const bool v = eid != EMPTY_ID;
+        const int nvalid = __popcll(__ballot(v));
+        stamp(11);
+        const int r = wave_rank(v ? f2o(es) : 0u, eid, n, lane);
+        float *Dq = a.D + (size_t)q * a.ldo + a.out_off;
+        int64_t *Iq = a.I + (size_t)q * a.ldo + a.out_off;
+        if (v && r < k) {
+            Dq[r] = es;
+            Iq[r] = eid;
+            if (a.next_bound_s && r == k - 1) {
+                a.next_bound_s[q] = es;
+                a.next_bound_id[q] = eid;
+            }
+        }
+        if (lane < k && lane >= nvalid) {
+            Dq[lane] = -FLT_MAX;
+            Iq[lane] = -1;
+        }
+        if (a.next_bound_s && nvalid < k && lane == 0) {
+            a.next_bound_s[q] = MI_NEG_INF;
+            a.next_bound_id[q] = EMPTY_ID;
+        }
+        stamp(12);
+        return;
+    }
+
+    // General case: every storing wave drains its stores, one lane takes a ticket;
+    // the last arriver merges the query's partial lists with the whole workgroup.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
