@@ -554,7 +554,17 @@ int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_a
             MI_HIP(hipMemcpy(hts.data(), dts, nb * SCAN_TS * 8, hipMemcpyDeviceToHost));
             // every XCD has its own counter: only differences inside one workgroup mean anything
             std::fprintf(stderr, "[scan stamps] %zu workgroups, s_memtime ticks since the workgroup's own start\n", nb);
+            {   // slot 14 = survivors of the block threshold + 1
+                double sum = 0; unsigned long long mx = 0; size_t big = 0;
+                for (size_t b = 0; b < nb; ++b) {
+                    const unsigned long long c = hts[b * SCAN_TS + 14];
+                    if (!c) continue;
+                    sum += (double)(c - 1); mx = std::max(mx, c - 1); big += (c - 1) > 64;
+                }
+                std::fprintf(stderr, "  survivors per workgroup: mean %.1f max %llu, %zu workgroups above 64\n", sum / nb, mx, big);
+            }
             for (int i = 1; i < SCAN_TS; ++i) {
+                if (i == 14) continue;
                 double sum = 0, mx = 0, mn = 1e30;
                 size_t cntb = 0;
                 for (size_t b = 0; b < nb; ++b) {

@@ -667,7 +667,7 @@ __host__ __device__ inline size_t scan_fused_merge_bytes(int nslice, int k) {
 }
 
 constexpr int SCAN_NW = 8;        // waves per workgroup
-constexpr int SCAN_TS = 16;       // phase stamps per workgroup (profiling replay only)
+constexpr int SCAN_TS = 24;       // phase stamps per workgroup (profiling replay only)
 constexpr int SCAN_WBUF = 128;    // candidate slots per wave
 
 // LDS carve: [ LUT M KiB (>= 16 KiB, reused by the selection tail) | wave buffers
@@ -685,23 +685,11 @@ __host__ __device__ inline size_t scan_smem_bytes(int M, int nprobe) {
     return scan_lut_bytes(M) + (size_t)SCAN_NW * SCAN_WBUF * 12 + (size_t)scan_tab_stride(nprobe) * 4 * 4 + 16;
 }
 
-// (a lower bound of) the k-th largest of up to 128 order-preserving keys held
-// two per lane (0 = empty); exactly k keys are >= the result unless keys tie
-__device__ __forceinline__ unsigned wave_kth_largest(unsigned ka, unsigned kb, int k) {
-    // Early exit: as soon as exactly k keys are >= t, t itself separates the top k
-    // (a lower bound of the k-th key with the remaining low bits zero) -- on
-    // typical scores this takes ~10 of the 32 steps.
-    unsigned prefix = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const unsigned t = prefix | (1u << bit);
-        const int c = __popcll(__ballot(ka >= t)) + __popcll(__ballot(kb >= t));
-        if (c >= k) prefix = t;
-        if (c == k) break;
-    }
-    return prefix;
-}
-
-// the same over N keys per lane; 0 when fewer than k keys are set
+// (A lower bound of) the k-th largest of the wave's order-preserving keys, N per lane
+// (0 = empty): exactly k keys are >= the result unless keys tie; 0 when fewer than k
+// keys are set.  Bitwise descent with early exit -- as soon as exactly k keys are >= t,
+// t itself separates the top k (typical scores: about a third of the 32 steps).
+// (Two bits per step with three thresholds counted side by side measured slower.)
 template <int N>
 __device__ __forceinline__ unsigned wave_kth_largest_n(const unsigned (&key)[N], int k) {
     int nz = 0;
@@ -719,23 +707,26 @@ __device__ __forceinline__ unsigned wave_kth_largest_n(const unsigned (&key)[N],
     }
     return prefix;
 }
+__device__ __forceinline__ unsigned wave_kth_largest(unsigned ka, unsigned kb, int k) {
+    const unsigned kk[2] = {ka, kb};
+    return wave_kth_largest_n<2>(kk, k);
+}
 
 // Rank (number of better entries) of this lane's entry among the wave's first n
-// lanes under (score desc, id asc, slot asc); empty entries carry key 0 and count
-// for nobody.  The common case is one readlane and one compare/add per step on the
-// order-preserving score keys; the full predicate only runs when two scores tie.
-__device__ __forceinline__ int wave_rank(unsigned key, int64_t id, int n, int lane) {
-    int gt = 0;
-#pragma unroll 8
-    for (int j = 0; j < n; ++j) gt += readlane_u(key, j) > key;
-    // Distinct keys give the set entries the ranks 0 .. nset-1 exactly once; a tie
-    // lowers somebody's rank, so the rank sum tells whether any two scores tie.
-    const bool set = key != 0u;
-    const int nset = __popcll(__ballot(set));
-    int sum = set ? gt : 0;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
-    if (uniform_i(sum) != nset * (nset - 1) / 2) {
+// (<= 64) lanes under (score desc, id asc, slot asc); empty entries and lanes >= n carry
+// key 0 and count for nobody.  The keys go through a 64-word wave-private LDS scratch
+// and every lane reads them all back four at a time (same address in all lanes: a
+// broadcast, pipelined reads) -- a readlane loop costs a VALU -> SGPR -> VALU round
+// trip (~50 cycles) per entry.  The full predicate only runs when two scores tie.
+__device__ __forceinline__ int wave_rank(unsigned key, int64_t id, int n, int lane, unsigned *scratch) {
+    scratch[lane] = key;
+    int gt = 0, ge = 0;
+    for (int j0 = 0; j0 < n; j0 += 4) {   // whole blocks of 4: j0 + 3 <= 63
+        const uint4 kq = *reinterpret_cast<const uint4 *>(scratch + j0);
+        gt += (kq.x > key) + (kq.y > key) + (kq.z > key) + (kq.w > key);
+        ge += (kq.x >= key) + (kq.y >= key) + (kq.z >= key) + (kq.w >= key);
+    }
+    if (__ballot(key != 0u && ge - gt > 1)) {   // some score is held by two entries
         int r = 0;
         for (int j = 0; j < n; ++j) {
             const unsigned jk = readlane_u(key, j);
@@ -954,6 +945,8 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         }
         const float s = g.dis0 + acc;
         if (n_proc == 0) stamp(13);
+        if (n_proc == 1) stamp(17);
+        if (n_proc == 2) stamp(18);
 
         const float wthr = o2f(__hip_atomic_load(wg_thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         const float thr_eff = fmaxf(thr, wthr);
@@ -976,6 +969,8 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
             }
         }
         if (n_proc == 0) stamp(3);
+        if (n_proc == 1) stamp(16);
+        if (n_proc == 2) stamp(19);
         ++n_proc;
     };
     Group g0{}, g1{};
@@ -1011,7 +1006,8 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
     {
         unsigned kk[SCAN_NW];
 #pragma unroll
-        for (int ww = 0; ww < SCAN_NW; ++ww) kk[ww] = tmax[ww * SCAN_WBUF + lane];
+        for (int ww = 0; ww < SCAN_NW; ++ww)   // rotated: a compressed wave keeps its k entries in lanes 0..k-1
+            kk[ww] = tmax[ww * SCAN_WBUF + ((lane - ww * (64 / SCAN_NW)) & 63)];
         if (k <= 16) {
             const unsigned f[1] = {max(max(max(kk[0], kk[1]), max(kk[2], kk[3])),
                                    max(max(kk[4], kk[5]), max(kk[6], kk[7])))};
@@ -1053,6 +1049,7 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
     __syncthreads();
     stamp(7);
     const int C = uniform_i(*c_total);  // <= 1024
+    if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * SCAN_TS + 14] = (unsigned long long)C + 1;
     const size_t part_o = ((size_t)q * a.nslice + slice) * k;
     // The slice's partial list is published WRITE-THROUGH (relaxed agent-scope
     // atomic stores lower to `global_store ... sc1`), so the fused final merge
@@ -1076,7 +1073,7 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
             const bool v = lane < C;
             const float es = v ? g_s[lane] : 0.f;
             const int64_t eid = v ? g_id[lane] : 0;
-            const int r = (a.debug & 2) ? 0 : wave_rank(v ? f2o(es) : 0u, eid, C, lane);
+            const int r = (a.debug & 2) ? 0 : wave_rank(v ? f2o(es) : 0u, eid, C, lane, reinterpret_cast<unsigned *>(g_rank));
             if (v) {
                 if (r < k) publish(r, es, eid);
             } else if (lane < k) {
@@ -1151,7 +1148,8 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         const bool v = eid != EMPTY_ID;
         const int nvalid = __popcll(__ballot(v));
         stamp(11);
-        const int r = wave_rank(v ? f2o(es) : 0u, eid, n, lane);
+        const int r = wave_rank(v ? f2o(es) : 0u, eid, n, lane, reinterpret_cast<unsigned *>(g_rank));
+        stamp(15);
         float *Dq = a.D + (size_t)q * a.ldo + a.out_off;
         int64_t *Iq = a.I + (size_t)q * a.ldo + a.out_off;
         if (v && r < k) {
