@@ -113,17 +113,24 @@ void launch_pq_encode(const float *x, int64_t n, int d, int M, const float *cb, 
     MI_HIP(hipGetLastError());
 }
 
-template <int M>
-void launch_scan_m(const ScanArgs &a, size_t smem, hipStream_t st) {
+template <int M, int NW>
+void launch_scan_mw(const ScanArgs &a, hipStream_t st) {
+    const size_t smem = scan_smem_bytes(M, a.nprobe, NW);
+    MI_REQUIRE(smem <= 160 * 1024, "nprobe too large for the LDS probe tables");
     static bool attr_set = false;
     if (!attr_set) {
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<M>),
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<M, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((scan_kernel<M>), dim3(scan_grid(a.nq, a.nslice)), dim3(512), smem,
+    hipLaunchKernelGGL((scan_kernel<M, NW>), dim3(scan_grid(a.nq, a.nslice)), dim3(NW * 64), smem,
                        st, a);
     MI_HIP(hipGetLastError());
+}
+template <int M>
+void launch_scan_m(const ScanArgs &a, hipStream_t st) {
+    if (a.nw == 16) launch_scan_mw<M, 16>(a, st);
+    else launch_scan_mw<M, 8>(a, st);
 }
 
 bool scan_supports_M(int M) {
@@ -134,17 +141,15 @@ bool scan_supports_M(int M) {
 }
 
 void launch_scan(int M, const ScanArgs &a, hipStream_t st) {
-    size_t smem = scan_smem_bytes(M, a.nprobe);
-    MI_REQUIRE(smem <= 160 * 1024, "nprobe too large for the LDS probe tables");
     switch (M) {
-        case 4: launch_scan_m<4>(a, smem, st); break;
-        case 8: launch_scan_m<8>(a, smem, st); break;
-        case 16: launch_scan_m<16>(a, smem, st); break;
-        case 32: launch_scan_m<32>(a, smem, st); break;
-        case 48: launch_scan_m<48>(a, smem, st); break;
-        case 64: launch_scan_m<64>(a, smem, st); break;
-        case 96: launch_scan_m<96>(a, smem, st); break;
-        case 128: launch_scan_m<128>(a, smem, st); break;
+        case 4: launch_scan_m<4>(a, st); break;
+        case 8: launch_scan_m<8>(a, st); break;
+        case 16: launch_scan_m<16>(a, st); break;
+        case 32: launch_scan_m<32>(a, st); break;
+        case 48: launch_scan_m<48>(a, st); break;
+        case 64: launch_scan_m<64>(a, st); break;
+        case 96: launch_scan_m<96>(a, st); break;
+        case 128: launch_scan_m<128>(a, st); break;
         default: throw Error("unsupported M (PQ sub-quantisers: 4,8,16,32,48,64,96,128)");
     }
 }
@@ -657,6 +662,12 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         bs = w.bs.as<float>((size_t)nq);
         bid = w.bid.as<int64_t>((size_t)nq);
     }
+    // Waves per scan workgroup.  16 (one round less for the first wave of a cfg2-sized
+    // slice) measured the same kernel time -- the slice is bound by the CU's LDS gather
+    // rate, not by the number of rounds -- and costs the second co-resident workgroup
+    // (3 streams: 2.7M vs 3.2M QPS), so 8 it is; MI_SCAN_NW=16 keeps the experiment.
+    int scan_nw = 8;
+    if (const char *e = std::getenv("MI_SCAN_NW")) scan_nw = std::atoi(e) == 16 ? 16 : 8;
     for (int pass = 0; pass < npass; ++pass) {
         const int kp = std::min(64, k - pass * 64);
         ScanArgs a;
@@ -666,12 +677,13 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         a.part_s = ps; a.part_id = pid;
         a.bound_s = pass ? bs : nullptr; a.bound_id = pass ? bid : nullptr;
         a.nq = (int)nq; a.nprobe = nprobe; a.nslice = nslice; a.k = kp; a.by_residual = h->by_residual;
+        a.nw = scan_nw;
         a.debug = 0;
         a.ts = nullptr;
         if (const char *e = std::getenv("MI_SCAN_DEBUG")) a.debug = std::atoi(e);
         // the last slice of each query merges the partial lists in-kernel when
         // they fit in the LUT's LDS region; otherwise a separate merge kernel
-        const bool fuse = scan_fused_merge_bytes(nslice, kp) <= scan_lut_bytes(M) &&
+        const bool fuse = scan_fused_merge_bytes(nslice, kp) <= scan_lut_bytes(M, scan_nw) &&
                           !std::getenv("MI_NO_FUSED_MERGE");
         a.counters = nullptr; a.D = Ddev; a.I = Idev; a.ldo = k; a.out_off = pass * 64;
         a.next_bound_s = npass > 1 ? bs : nullptr; a.next_bound_id = npass > 1 ? bid : nullptr;

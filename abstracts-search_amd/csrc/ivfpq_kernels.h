@@ -648,6 +648,7 @@ struct ScanArgs {
     const float *bound_s;      // [nq] or null: only entries strictly after
     const int64_t *bound_id;   //      (bound_s, bound_id) are eligible
     int nq, nprobe, nslice, k, by_residual;
+    int nw;     // waves per workgroup of this launch (8 or 16): host-side dispatch only
     int debug;  // ablation switches for tools/scan_ablate.py (0 in production)
     unsigned long long *ts;    // null, or [workgroups][SCAN_TS] s_memtime stamps (MI_SCAN_TS=1 profile replay)
     // fused final merge (the last slice of a query to finish merges all of the
@@ -666,23 +667,23 @@ __host__ __device__ inline size_t scan_fused_merge_bytes(int nslice, int k) {
     return (size_t)nslice * k * 16 + 1024;
 }
 
-constexpr int SCAN_NW = 8;        // waves per workgroup
+// waves per workgroup: template parameter NW of the kernel (8, or 16 for short slices)
 constexpr int SCAN_TS = 24;       // phase stamps per workgroup (profiling replay only)
 constexpr int SCAN_WBUF = 128;    // candidate slots per wave
 
-// LDS carve: [ LUT M KiB (>= 16 KiB, reused by the selection tail) | wave buffers
+// LDS carve: [ LUT M KiB (>= 2 KiB per wave, reused by the selection tail) | wave buffers
 //              8 x 128 x (8+4) B | prefix | p_goff | p_len | p_dis | misc 16 B ]
-__host__ __device__ inline size_t scan_lut_bytes(int M) {
-    size_t b = (size_t)M * 1024;
-    return b < 16384 ? 16384 : b;
+__host__ __device__ inline size_t scan_lut_bytes(int M, int nw) {
+    size_t b = (size_t)M * 1024, floor_b = (size_t)nw * 2048;   // selection tail: 2 x 64 nw entries x 16 B
+    return b < floor_b ? floor_b : b;
 }
 // grid of the scan launch: the slices of a query share an XCD (see the kernel)
 __host__ __device__ inline unsigned scan_grid(int nq, int nslice) {
     return 8u * (unsigned)((nq + 7) / 8) * (unsigned)nslice;
 }
 __host__ __device__ inline int scan_tab_stride(int nprobe) { return (nprobe + 1 + 3) & ~3; }
-__host__ __device__ inline size_t scan_smem_bytes(int M, int nprobe) {
-    return scan_lut_bytes(M) + (size_t)SCAN_NW * SCAN_WBUF * 12 + (size_t)scan_tab_stride(nprobe) * 4 * 4 + 16;
+__host__ __device__ inline size_t scan_smem_bytes(int M, int nprobe, int nw) {
+    return scan_lut_bytes(M, nw) + (size_t)nw * SCAN_WBUF * 12 + (size_t)scan_tab_stride(nprobe) * 4 * 4 + 16;
 }
 
 // (A lower bound of) the k-th largest of the wave's order-preserving keys, N per lane
@@ -779,12 +780,13 @@ __device__ __forceinline__ void wave_compress(float *buf_s, int64_t *buf_id, int
     thr = (cnt >= k && T != 0u) ? o2f(T) : MI_NEG_INF;
 }
 
-template <int M>
-__global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
+template <int M, int NW>
+__global__ void __launch_bounds__(NW * 64) scan_kernel(ScanArgs a) {
     constexpr int NCH = (M + 15) / 16;
+    constexpr int SCAN_NW = NW, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *lut_s = reinterpret_cast<float *>(smem);
-    unsigned char *wb = smem + scan_lut_bytes(M);
+    unsigned char *wb = smem + scan_lut_bytes(M, NW);
     const int TS = scan_tab_stride(a.nprobe);
     int *prefix = reinterpret_cast<int *>(wb + (size_t)SCAN_NW * SCAN_WBUF * 12);
     int *p_goff = prefix + TS;
@@ -851,7 +853,7 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         r_pre1 = reinterpret_cast<const int *>(buf_s)[lane];
     }
     if (!reg_tab) {
-        for (int p = tid; p < nprobe; p += 512) {
+        for (int p = tid; p < nprobe; p += NT) {
             const size_t o = (size_t)q * nprobe + p;
             prefix[p] = a.p_prefix[(size_t)q * (nprobe + 1) + p];
             p_goff[p] = a.p_goff[o];
@@ -1009,20 +1011,23 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         for (int ww = 0; ww < SCAN_NW; ++ww)   // rotated: a compressed wave keeps its k entries in lanes 0..k-1
             kk[ww] = tmax[ww * SCAN_WBUF + ((lane - ww * (64 / SCAN_NW)) & 63)];
         if (k <= 16) {
-            const unsigned f[1] = {max(max(max(kk[0], kk[1]), max(kk[2], kk[3])),
-                                   max(max(kk[4], kk[5]), max(kk[6], kk[7])))};
+            unsigned f[1] = {0u};
+#pragma unroll
+            for (int ww = 0; ww < SCAN_NW; ++ww) f[0] = max(f[0], kk[ww]);
             T0 = wave_kth_largest_n<1>(f, k);
         } else if (k <= 32) {
-            const unsigned f[2] = {max(max(kk[0], kk[1]), max(kk[2], kk[3])),
-                                   max(max(kk[4], kk[5]), max(kk[6], kk[7]))};
+            unsigned f[2] = {0u, 0u};
+#pragma unroll
+            for (int ww = 0; ww < SCAN_NW; ++ww) f[ww & 1] = max(f[ww & 1], kk[ww]);
             T0 = wave_kth_largest_n<2>(f, k);
         } else {
             T0 = wave_kth_largest_n<SCAN_NW>(kk, k);
         }
     }
-    int64_t *g_id = reinterpret_cast<int64_t *>(lut_s);          // [1024]
-    float *g_s = lut_s + 2048;                                   // [1024]
-    int *g_rank = reinterpret_cast<int *>(lut_s) + 3072;         // [1024]
+    constexpr int CAP = 2 * NT;                                  // two candidates per thread at most
+    int64_t *g_id = reinterpret_cast<int64_t *>(lut_s);          // [CAP]
+    float *g_s = lut_s + 2 * CAP;                                // [CAP]
+    int *g_rank = reinterpret_cast<int *>(lut_s) + 3 * CAP;      // [CAP]
     int64_t *o_id = reinterpret_cast<int64_t *>(wb);             // [64]  (over buf_id, dead by now)
     float *o_s = reinterpret_cast<float *>(wb + 512);            // [64]
     {
@@ -1081,17 +1086,17 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
             }
         }
     } else {
-        for (int e = tid; e < C; e += 512) g_rank[e] = 0;
+        for (int e = tid; e < C; e += NT) g_rank[e] = 0;
         if (tid < 64) {
             o_s[tid] = MI_NEG_INF;
             o_id[tid] = EMPTY_ID;
         }
         __syncthreads();
         if (!(a.debug & 2)) {
-            const int P = C < 512 ? max(1, 512 / C) : 1;   // thread groups sharing the j range
-            for (int e0 = 0; e0 < C; e0 += 512) {
-                const int part = C < 512 ? tid / C : 0;
-                const int e = C < 512 ? tid - part * C : e0 + tid;
+            const int P = C < NT ? max(1, NT / C) : 1;   // thread groups sharing the j range
+            for (int e0 = 0; e0 < C; e0 += NT) {
+                const int part = C < NT ? tid / C : 0;
+                const int e = C < NT ? tid - part * C : e0 + tid;
                 if (part < P && e < C) {
                     const float es = g_s[e];
                     const int64_t eid = g_id[e];
@@ -1108,7 +1113,7 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
             }
         }
         __syncthreads();
-        for (int e = tid; e < C; e += 512) {
+        for (int e = tid; e < C; e += NT) {
             const int r = g_rank[e];
             if (r < k) {
                 o_s[r] = g_s[e];
@@ -1191,7 +1196,7 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
     int *e_rank = reinterpret_cast<int *>(e_s + n);               // [n]
     int64_t *f_id = reinterpret_cast<int64_t *>(smem + (size_t)n * 16);  // [64]
     float *f_s = reinterpret_cast<float *>(f_id + 64);            // [64]
-    for (int e = tid; e < n; e += 512) {
+    for (int e = tid; e < n; e += NT) {
         const size_t o = (size_t)q * n + e;
         e_id[e] = (int64_t)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.part_id) + o,
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1205,10 +1210,10 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
     }
     __syncthreads();
     {
-        const int P = n < 512 ? max(1, 512 / n) : 1;
-        for (int e0 = 0; e0 < n; e0 += 512) {
-            const int part = n < 512 ? tid / n : 0;
-            const int e = n < 512 ? tid - part * n : e0 + tid;
+        const int P = n < NT ? max(1, NT / n) : 1;
+        for (int e0 = 0; e0 < n; e0 += NT) {
+            const int part = n < NT ? tid / n : 0;
+            const int e = n < NT ? tid - part * n : e0 + tid;
             if (part < P && e < n) {
                 const int64_t eid = e_id[e];
                 if (eid != EMPTY_ID) {
@@ -1227,7 +1232,7 @@ __global__ void __launch_bounds__(512) scan_kernel(ScanArgs a) {
         }
     }
     __syncthreads();
-    for (int e = tid; e < n; e += 512) {
+    for (int e = tid; e < n; e += NT) {
         const int r = e_rank[e];
         if (e_id[e] != EMPTY_ID && r < k) {
             f_s[r] = e_s[e];
