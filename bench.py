@@ -194,7 +194,7 @@ def main():
             traffic = int(pmc["corrected_bytes_per_launch"])
     except Exception:
         traffic = None
-    roofline = {"kernel": "scan_kernel<64>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
+    roofline = {"kernel": "scan_kernel<64,8>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, gfx950 x2 read correction "
                                   "(profiles/r01_cfg2_scan_pmc.json)" if traffic else None,
