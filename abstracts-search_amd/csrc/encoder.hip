@@ -34,7 +34,26 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
     const int per = (ntiles + 7) / 8;
     if (epi != EPI_RESID || g.bias) g.ksplit = 1;
     g.ksplit = std::max(1, g.ksplit);
-    dim3 grid(8 * per * g.ksplit), block(64 * WAVES_M * WAVES_N);
+    unsigned nblocks = 8u * per * g.ksplit;
+    g.tail_first = 0;
+    g.tail_split = 1;
+    if (epi == EPI_RESID && !g.bias && g.ksplit == 1 && BM * BN >= 256 * 256 && !std::getenv("MI_NO_TAIL_SPLIT")) {
+        // wave quantisation: 780 tiles on 256 CUs are 3 full rounds + 12 tiles that would
+        // hold the kernel for a 4th tile time; split those along K (f32 atomics into the
+        // residual stream, as the small-batch split-K path does)
+        const int ncu = 256, nb = 8 * per;
+        const int main_b = nb / ncu * ncu, rem = nb - main_b;
+        const int nk = g.K / 32;
+        if (main_b > 0 && rem > 0 && rem <= ncu * 5 / 8) {
+            const int sp = std::min({ncu / rem, nk / 8, 16});
+            if (sp >= 2) {
+                g.tail_first = main_b;
+                g.tail_split = sp;
+                nblocks = (unsigned)(main_b + rem * sp);
+            }
+        }
+    }
+    dim3 grid(nblocks), block(64 * WAVES_M * WAVES_N);
     switch (epi) {
         case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_STORE, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
         case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_RESID, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;

@@ -152,6 +152,10 @@ struct GemmArgs {
     int ldc, ldvt, qk_cols;
     int tiles_m, tiles_n;
     int ksplit;        // > 1 (EPI_RESID only): K range split over workgroups, f32 atomic adds into X
+    // EPI_RESID, big tiles: the last, partly filled round of workgroups (blockIdx >=
+    // tail_first) is split tail_split ways along K so that it occupies the whole chip
+    // for 1/tail_split of a tile time instead of a few CUs for a full one
+    int tail_first, tail_split;
 };
 
 // 4x4 transpose across the 4 lanes of a quad (DPP quad_perm, no LDS): before,
@@ -367,10 +371,21 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
     __shared__ __attribute__((aligned(16))) bf16_t smem[ST * (BM + BN) * BK];
 
     // split-K (small batches, residual GEMMs): workgroup = (tile, K slice)
-    const int ksplit = (EPI == EPI_RESID && g.ksplit > 1) ? g.ksplit : 1;
-    const int ks = (int)blockIdx.x % ksplit;
+    int ksplit = 1, ks = 0, vb = -1;
+    if constexpr (EPI == EPI_RESID) {
+        if (g.ksplit > 1) {
+            ksplit = g.ksplit;
+            ks = (int)blockIdx.x % ksplit;
+            vb = (int)blockIdx.x / ksplit;
+        } else if (g.tail_split > 1 && (int)blockIdx.x >= g.tail_first) {
+            const int j = (int)blockIdx.x - g.tail_first;
+            ksplit = g.tail_split;
+            ks = j % ksplit;
+            vb = g.tail_first + j / ksplit;
+        }
+    }
     int tm, tn;
-    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn, ksplit > 1 ? (int)blockIdx.x / ksplit : -1)) return;
+    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn, vb)) return;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -475,17 +490,19 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
         }
     }
 
+    GemmArgs ge = g;
+    ge.ksplit = ksplit;   // this workgroup's share: > 1 = atomic adds
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         const int trow = m0 + (wm * WMT + i) * 16;
         if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
             for (int j = 0; j < WNT; j += 2)
-                store_tile<EPI>(g, acc[i][j], acc[i][j + 1], trow, (n0 + wn * WNT * 16) / 2 + (j / 2) * 16, lane);
+                store_tile<EPI>(ge, acc[i][j], acc[i][j + 1], trow, (n0 + wn * WNT * 16) / 2 + (j / 2) * 16, lane);
         } else {
 #pragma unroll
             for (int j = 0; j < WNT; ++j)
-                store_tile<EPI>(g, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
+                store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
         }
     }
 }
