@@ -23,7 +23,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 
 import numpy as np
 
-from . import _native
+from . import _native, faiss_io
 
 METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
@@ -508,13 +508,7 @@ class ParameterSpace:
 _MAGIC = "mi355x-ivfpq-v1"
 
 
-def write_index(index, fname: str) -> None:
-    """Own container (numpy .npz): parameters, centroids, codebook, and the
-    inverted lists as (list_no, codes, ids).  The faiss on-disk format
-    (index.faiss + ondisk.ivfdata, reference Makefile:11) is a SURVEY 8(f)
-    "next" row."""
-    if isinstance(index, IndexFlatIP):
-        raise NotImplementedError("write_index: IndexFlatIP is not serialised")
+def _lists_of(index):
     sizes = np.array([index.list_size(l) for l in range(index.nlist)], np.int64)
     codes = np.empty((int(sizes.sum()), index.pq.M), np.uint8)
     ids = np.empty(int(sizes.sum()), np.int64)
@@ -525,17 +519,50 @@ def write_index(index, fname: str) -> None:
             codes[o:o + sizes[l]] = c
             ids[o:o + sizes[l]] = i
             o += sizes[l]
+    return sizes, codes, ids
+
+
+def write_index(index, fname: str, ondisk_data: str | None = None) -> None:
+    """``faiss.write_index``.  Writes faiss's binary format (``IwPQ`` with an
+    ``IndexFlat`` quantiser; lists in the file, or in ``ondisk_data`` as
+    ``OnDiskInvertedLists`` -- the reference's ``index.faiss`` +
+    ``ondisk.ivfdata`` pair, Makefile:11-12) -- see faiss_io.py for the layout
+    and its validation status.  A name ending in ``.npz`` selects the package's
+    own numpy container instead."""
+    if isinstance(index, IndexFlatIP):
+        raise NotImplementedError("write_index: IndexFlatIP is not serialised")
+    sizes, codes, ids = _lists_of(index)
     trained = index.is_trained
+    cent = index.get_centroids() if trained else np.zeros((0,), np.float32)
+    cb = index.get_codebook() if trained else np.zeros((0,), np.float32)
+    if not str(fname).endswith(".npz"):
+        faiss_io.dump(fname, d=index.d, nlist=index.nlist, M=index.pq.M, nbits=index.pq.nbits,
+                      metric=index.metric_type, by_residual=index.by_residual, nprobe=index.nprobe,
+                      is_trained=trained, centroids=cent, codebook=cb, sizes=sizes, codes=codes, ids=ids,
+                      ondisk_data=ondisk_data)
+        return
     with open(fname, "wb") as f:
         np.savez(f, magic=np.array(_MAGIC),
                  params=np.array([index.d, index.nlist, index.pq.M, index.pq.nbits, index.metric_type,
                                   int(index.by_residual), index.nprobe, int(trained)], np.int64),
-                 centroids=index.get_centroids() if trained else np.zeros((0,), np.float32),
-                 codebook=index.get_codebook() if trained else np.zeros((0,), np.float32),
-                 sizes=sizes, codes=codes, ids=ids)
+                 centroids=cent, codebook=cb, sizes=sizes, codes=codes, ids=ids)
 
 
 def read_index(fname: str, device: int = 0):
+    """``faiss.read_index``: a faiss ``IwPQ`` file (in-file or on-disk lists) or
+    the package's own ``.npz`` container, told apart by their first bytes."""
+    with open(fname, "rb") as f:
+        head = f.read(4)
+    if head != b"PK\x03\x04":
+        z = faiss_io.parse(fname)
+        index = IndexIVFPQ(z["d"], z["nlist"], z["M"], z["nbits"], z["metric"], z["by_residual"], device)
+        index.nprobe = max(1, int(z["nprobe"]))
+        if z["is_trained"]:
+            index.set_centroids(z["centroids"])
+            index.set_codebook(z["codebook"])
+        if z["ntotal"]:
+            index.add_codes(np.repeat(np.arange(z["nlist"], dtype=np.int32), z["sizes"]), z["codes"], z["ids"])
+        return index
     z = np.load(fname, allow_pickle=False)
     if str(z["magic"]) != _MAGIC:
         raise ValueError(f"{fname}: not a {_MAGIC} file")

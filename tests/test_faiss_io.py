@@ -1,0 +1,138 @@
+"""faiss binary index format, host-side parsing only: no GPU.
+
+faiss is not importable here, so the byte layout is pinned to a hand-assembled
+file that follows faiss's documented serialisation field by field
+(faiss/impl/index_write.cpp: write_index_header, write_ivf_header,
+write_ProductQuantizer, write_InvertedLists; invlists/OnDiskInvertedLists.cpp),
+plus write -> read round trips of the package's own writer.
+"""
+import importlib
+import struct
+
+import numpy as np
+import pytest
+
+fio = importlib.import_module("abstracts_search_amd.faiss_io")
+
+
+def tiny(seed=0, d=8, nlist=4, M=2, sizes=(3, 0, 2, 1)):
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((nlist, d)).astype(np.float32)
+    cb = rng.standard_normal((M, 256, d // M)).astype(np.float32)
+    sizes = np.array(sizes, np.int64)
+    n = int(sizes.sum())
+    codes = rng.integers(0, 256, (n, M)).astype(np.uint8)
+    ids = rng.integers(0, 1 << 40, n).astype(np.int64)
+    return dict(d=d, nlist=nlist, M=M, nbits=8, metric=fio.METRIC_INNER_PRODUCT, by_residual=True, nprobe=3,
+                is_trained=True, centroids=cent, codebook=cb, sizes=sizes, codes=codes, ids=ids)
+
+
+def header(d, ntotal, trained, metric):
+    return struct.pack("<iqqqBi", d, ntotal, 1 << 20, 1 << 20, int(trained), metric)
+
+
+def hand_assembled(t, lists="full"):
+    """The file faiss's write_index would produce for `t`, field by field."""
+    b = b"IwPQ" + header(t["d"], int(t["sizes"].sum()), True, 0)
+    b += struct.pack("<QQ", t["nlist"], t["nprobe"])
+    b += b"IxFI" + header(t["d"], t["nlist"], True, 0)
+    b += struct.pack("<Q", t["centroids"].size) + t["centroids"].tobytes()
+    b += struct.pack("<b", 0) + struct.pack("<Q", 0)                      # direct map: NoMap, empty array
+    b += struct.pack("<BQ", 1, t["M"])                                    # by_residual, code_size
+    b += struct.pack("<QQQ", t["d"], t["M"], 8)
+    b += struct.pack("<Q", t["codebook"].size) + t["codebook"].tobytes()
+    b += b"ilar" + struct.pack("<QQ", t["nlist"], t["M"])
+    if lists == "full":
+        b += b"full" + struct.pack("<Q", t["nlist"]) + t["sizes"].astype("<u8").tobytes()
+    else:
+        nz = np.flatnonzero(t["sizes"])
+        b += b"sprs" + struct.pack("<Q", 2 * nz.size)
+        for l in nz:
+            b += struct.pack("<QQ", l, t["sizes"][l])
+    o = 0
+    for l in range(t["nlist"]):
+        k = int(t["sizes"][l])
+        b += t["codes"][o:o + k].tobytes() + t["ids"][o:o + k].tobytes()
+        o += k
+    return b
+
+
+def same(z, t):
+    for key in ("d", "nlist", "M", "nbits", "metric", "by_residual", "nprobe", "is_trained"):
+        assert z[key] == t[key], key
+    assert np.array_equal(z["centroids"], t["centroids"]) and np.array_equal(z["codebook"], t["codebook"])
+    assert np.array_equal(z["sizes"], t["sizes"])
+    assert np.array_equal(z["codes"], t["codes"]) and np.array_equal(z["ids"], t["ids"])
+
+
+@pytest.mark.parametrize("lists", ["full", "sprs"])
+def test_reader_follows_the_documented_layout(tmp_path, lists):
+    t = tiny()
+    f = tmp_path / "index.faiss"
+    f.write_bytes(hand_assembled(t, lists))
+    same(fio.parse(str(f)), t)
+
+
+def test_writer_emits_the_documented_layout(tmp_path):
+    t = tiny()                                  # 3 of 4 lists non-empty -> "full"
+    f = tmp_path / "index.faiss"
+    fio.dump(str(f), **t)
+    assert f.read_bytes() == hand_assembled(t, "full")
+    t = tiny(sizes=(5, 0, 0, 0))                # 1 of 4 -> "sprs"
+    fio.dump(str(f), **t)
+    assert f.read_bytes() == hand_assembled(t, "sprs")
+
+
+def test_ondisk_lists_roundtrip(tmp_path):
+    t = tiny(seed=3, nlist=6, sizes=(4, 0, 1, 7, 0, 2))
+    f, data = tmp_path / "index.faiss", tmp_path / "ondisk.ivfdata"
+    fio.dump(str(f), ondisk_data=str(data), **t)
+    assert data.stat().st_size == int(t["sizes"].sum()) * (t["M"] + 8)
+    raw = f.read_bytes()
+    assert b"ilod" in raw and b"ondisk.ivfdata" in raw
+    same(fio.parse(str(f)), t)
+    # capacity > size and a non-zero first offset, as a grown on-disk list file has them
+    recs, pos = [], 16
+    blob = bytearray(b"\xee" * 16)
+    o = 0
+    for l in range(t["nlist"]):
+        k = int(t["sizes"][l]); cap = k + 3
+        recs += [k, cap, pos]
+        blob += t["codes"][o:o + k].tobytes() + b"\x00" * (3 * t["M"])
+        blob += t["ids"][o:o + k].tobytes() + b"\x00" * 24
+        pos += cap * (t["M"] + 8); o += k
+    data.write_bytes(bytes(blob))
+    head = raw[:raw.index(b"ilod")]
+    tail = b"ilod" + struct.pack("<QQ", t["nlist"], t["M"]) + struct.pack("<Q", t["nlist"])
+    tail += struct.pack(f"<{len(recs)}Q", *recs) + struct.pack("<Q", 0)
+    name = b"/some/other/box/ondisk.ivfdata"       # stale absolute path: the sibling file is used
+    tail += struct.pack("<Q", len(name)) + name + struct.pack("<Q", pos)
+    f.write_bytes(head + tail)
+    same(fio.parse(str(f)), t)
+
+
+def test_untrained_and_empty(tmp_path):
+    t = tiny(sizes=(0, 0, 0, 0))
+    f = tmp_path / "e.faiss"
+    fio.dump(str(f), **t)
+    z = fio.parse(str(f))
+    assert z["ntotal"] == 0 and z["codes"].shape == (0, t["M"])
+
+
+def test_rejects_what_it_does_not_understand(tmp_path):
+    t = tiny()
+    good = hand_assembled(t)
+    f = tmp_path / "bad.faiss"
+    f.write_bytes(b"IxFI" + good[4:])
+    with pytest.raises(fio.FaissFormatError, match="not an IndexIVFPQ"):
+        fio.parse(str(f))
+    f.write_bytes(good[:100])
+    with pytest.raises(fio.FaissFormatError, match="truncated"):
+        fio.parse(str(f))
+    f.write_bytes(good.replace(b"ilar", b"ilzz"))
+    with pytest.raises(fio.FaissFormatError, match="not supported"):
+        fio.parse(str(f))
+    bad_total = b"IwPQ" + header(t["d"], 99, True, 0) + good[4 + len(header(0, 0, True, 0)):]
+    f.write_bytes(bad_total)
+    with pytest.raises(fio.FaissFormatError, match="header says 99"):
+        fio.parse(str(f))

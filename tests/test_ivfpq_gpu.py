@@ -301,14 +301,15 @@ def test_coarse_slices_and_search_preassigned(faiss, oracle):
     assert np.array_equal(Ip.cpu().numpy(), Ie) and np.array_equal(bits(Dp.cpu().numpy()), bits(De))
 
 
-def test_write_read_roundtrip(faiss, tmp_path):
+@pytest.mark.parametrize("kind", ["faiss", "faiss-ondisk", "npz"])
+def test_write_read_roundtrip(faiss, tmp_path, kind):
     cent, cb, x, q = random_problem(10, 64, 8, 16, 2000, 20)
     idx = make_index(faiss, cent, cb)
     idx.add_with_ids(x, np.arange(2000, dtype=np.int64) + 77)
     idx.nprobe = 4
     D, I = idx.search(q, 10)
-    f = str(tmp_path / "index.mi")
-    faiss.write_index(idx, f)
+    f = str(tmp_path / ("index.npz" if kind == "npz" else "index.faiss"))
+    faiss.write_index(idx, f, ondisk_data=str(tmp_path / "ondisk.ivfdata") if kind == "faiss-ondisk" else None)
     idx2 = faiss.read_index(f)
     assert idx2.ntotal == 2000 and idx2.nprobe == 4 and idx2.is_trained
     D2, I2 = idx2.search(q, 10)
