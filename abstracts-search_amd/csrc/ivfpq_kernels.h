@@ -259,28 +259,104 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
         for (int s = 0; s < PF; ++s)
             if (s < nk) gload(s * BK, ra[s], rb[s], false);
     }
-    sstore(0, ra[0], rb[0]);
-    lds_barrier();
-    int t0 = 0;
-    for (; (t0 + 2 * PF) * BK <= d; t0 += PF) {   // steady state: branch-free, waits stay counted
+    // One 16x16 tile per wave (small batches): every output is ONE dependent MFMA chain
+    // (40 cycles per link, 16 links per K chunk) and a wave has nothing else to run, so
+    // the whole chunk hand-off has to hide inside the chain.  Step t therefore starts
+    // with the barrier -- every LDS operation it waits for was issued a full step ago --
+    // then reads the operands of chunk t+1 (stored during step t-1) into the second
+    // register set, stores chunk t+2 into the buffer chunk t was read from, requests
+    // chunk t+PF, and only then issues chunk t's 16 MFMAs from registers: nothing inside
+    // or behind the chain waits for LDS or for the other waves.
+    constexpr bool PIPE = (WM * WN == 1) && (PF % 2 == 0) && PF >= 4;
+    if constexpr (PIPE) {
+        constexpr int NKK = BK / 4;
+        float opa[2][NKK], opb[2][NKK];
+        auto read_ops = [&](int buf, float(&pa)[NKK], float(&pb)[NKK]) {
+            const float *ab = As + (buf * BM + wmi * 16 + li) * ST + lg;
+            const float *bb = Bs + (buf * BN + wni * 16 + li) * ST + lg;
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int t = t0 + u;
-            gload((t + PF) * BK, ra[u], rb[u], true);   // set u was stored to LDS last step
-            compute(t & 1);
-            sstore((t + 1) & 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
-            lds_barrier();
-        }
-    }
-    for (; t0 < nk; t0 += PF) {
+            for (int kk = 0; kk < NKK; ++kk) {
+                pa[kk] = ab[kk * 4];
+                pb[kk] = bb[kk * 4];
+            }
+        };
+        auto mma_chunk = [&](const float(&pa)[NKK], const float(&pb)[NKK]) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int t = t0 + u;
-            if (t < nk) {
-                if (t + PF < nk) gload((t + PF) * BK, ra[u], rb[u], false);
-                compute(t & 1);
-                if (t + 1 < nk) sstore((t + 1) & 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+            for (int kk = 0; kk < NKK; ++kk)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk], pb[kk], acc[0][0], 0, 0, 0);
+        };
+        sstore(0, ra[0], rb[0]);
+        lds_barrier();
+        read_ops(0, opa[0], opb[0]);
+        if (1 < nk) sstore(1, ra[1], rb[1]);
+        int t0 = 0;
+        for (; (t0 + 2 * PF) * BK <= d; t0 += PF) {   // steady state: branch-free, waits stay counted
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 + u;   // t0 is a multiple of PF (even): buffer / register-set parities are static
                 lds_barrier();
+                read_ops((u + 1) & 1, opa[(u + 1) & 1], opb[(u + 1) & 1]);          // chunk t+1
+                sstore(u & 1, ra[(u + 2) % PF], rb[(u + 2) % PF]);                    // chunk t+2
+                gload((t + PF) * BK, ra[u], rb[u], true);                             // chunk t+PF
+                mma_chunk(opa[u & 1], opb[u & 1]);
+                // issue order inside the step: the chain first, everything else in the 40-cycle
+                // gaps between its links (an MFMA behind 20 fresh LDS operations would otherwise
+                // wait for lgkmcnt(0): the counter only encodes up to 15)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                }
+            }
+        }
+        for (; t0 < nk; t0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 + u;
+                if (t < nk) {
+                    lds_barrier();
+                    if (t + 1 < nk) read_ops((u + 1) & 1, opa[(u + 1) & 1], opb[(u + 1) & 1]);
+                    if (t + 2 < nk) sstore(u & 1, ra[(u + 2) % PF], rb[(u + 2) % PF]);
+                    if (t + PF < nk) gload((t + PF) * BK, ra[u], rb[u], false);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_chunk(opa[u & 1], opb[u & 1]);
+                }
+            }
+        }
+    } else {
+        sstore(0, ra[0], rb[0]);
+        lds_barrier();
+        int t0 = 0;
+        for (; (t0 + 2 * PF) * BK <= d; t0 += PF) {   // steady state: branch-free, waits stay counted
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 + u;
+                gload((t + PF) * BK, ra[u], rb[u], true);   // set u was stored to LDS last step
+                compute(t & 1);
+                sstore((t + 1) & 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+                lds_barrier();
+            }
+        }
+        for (; t0 < nk; t0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 + u;
+                if (t < nk) {
+                    if (t + PF < nk) gload((t + PF) * BK, ra[u], rb[u], false);
+                    compute(t & 1);
+                    if (t + 1 < nk) sstore((t + 1) & 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+                    lds_barrier();
+                }
             }
         }
     }
