@@ -88,9 +88,10 @@ __device__ __forceinline__ float o2f(unsigned o) {
 // Workgroup tile BM x BN, K chunk BK, double-buffered through LDS (row-major,
 // padded).  Lane (i = lane&15, g = lane>>4) feeds A[i][k0+g] to the MFMA, which
 // then consumes k in ascending order: every output is an ascending-k fmaf
-// chain from +0.  Small batches are bound by what one CU can pull out of L2
-// (~35 GB/s/CU measured), hence the 32x32 tile for 16 < na <= 128: the fewest
-// bytes per CU that still gives every CU a tile.
+// chain from +0.  Small batches (one 16x16 tile per SIMD) are bound by that chain:
+// d/4 dependent MFMAs at 40 cycles each, which the evaluation order forbids splitting;
+// the 32x32 workgroup tile for 16 < na <= 128 gives every CU a tile with the fewest
+// bytes to fetch, and the K loop is organised around never stalling the chain (below).
 // Grid: 8 * tiles_m * ceil(tiles_n/8); block b runs on XCD b%8, and all
 // blocks of one XCD walk the M tiles of the same B strip (L2 reuse of B).
 // ---------------------------------------------------------------------
