@@ -858,7 +858,7 @@ __device__ __forceinline__ void wave_compress(float *buf_s, int64_t *buf_id, int
 }
 
 template <int M, int NW>
-__global__ void __launch_bounds__(NW * 64) scan_kernel(ScanArgs a) {
+__global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 waves per SIMD = two 512-thread workgroups per CU
     constexpr int NCH = (M + 15) / 16;
     constexpr int SCAN_NW = NW, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -947,6 +947,17 @@ __global__ void __launch_bounds__(NW * 64) scan_kernel(ScanArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // LDS tables visible (also drains the LUT DMA)
     }
+    // 64 < nprobe <= 256: the group -> probe search still runs on registers (lane p keeps
+    // prefix[p+1], [p+65], [p+129], [p+193]: four ballots), only the four table values of
+    // the located probe come from LDS, as independent reads.  The sequential walk with one
+    // dependent LDS round trip per step is left for nprobe > 256.
+    const bool wide_tab = !reg_tab && nprobe <= 256;
+    int w_pre1[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+    if (wide_tab) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < nprobe) w_pre1[i] = prefix[lane + 64 * i + 1];
+    }
 
     const int G = reg_tab ? __builtin_amdgcn_readlane(r_pre1, nprobe - 1) : prefix[nprobe];
     const int beg = (int)(((int64_t)G * slice) / a.nslice);
@@ -966,7 +977,7 @@ __global__ void __launch_bounds__(NW * 64) scan_kernel(ScanArgs a) {
     // work items = 64-code groups [beg, end), dealt round-robin to the waves
     int t = beg + w;
     int p = 0;
-    if (!reg_tab && t < end) {  // smallest p with prefix[p+1] > t
+    if (!reg_tab && !wide_tab && t < end) {  // smallest p with prefix[p+1] > t
         int lo = 0, hi = nprobe - 1;
         while (lo < hi) {
             int mid = (lo + hi) >> 1;
@@ -990,6 +1001,16 @@ __global__ void __launch_bounds__(NW * 64) scan_kernel(ScanArgs a) {
             gg = __builtin_amdgcn_readlane(r_goff, pp) + gi;
             g.nvalid = min(64, __builtin_amdgcn_readlane(r_len, pp) - gi * 64);
             g.dis0 = readlane_f(r_dis, pp);
+        } else if (wide_tab) {
+            int pp = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pp += __popcll(__ballot(w_pre1[i] <= tt));
+            const int v0 = prefix[pp], v1 = p_goff[pp], v2 = p_len[pp];
+            const float v3 = p_dis[pp];
+            gi = tt - uniform_i(v0);
+            gg = uniform_i(v1) + gi;
+            g.nvalid = min(64, uniform_i(v2) - gi * 64);
+            g.dis0 = uniform_f(v3);
         } else {
             while (uniform_i(prefix[p + 1]) <= tt) ++p;
             gi = tt - uniform_i(prefix[p]);
