@@ -49,7 +49,7 @@ void launch_gemm(const float *A, int64_t na, const float *B, int64_t nb, int d, 
     if (na <= 16) launch_gemm_cfg<1, 1, 1, 4, 64, 4>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
     else if (na <= 128) launch_gemm_cfg<1, 1, 2, 2, 64, 4>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
     else if (na <= 512) launch_gemm_cfg<2, 2, 2, 2, 32, 2>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
-    else launch_gemm_cfg<4, 4, 2, 2, 32, 1>(A, (int)na, B, (int)nb, d, S, ldS, st, la);
+    else launch_gemm_cfg<4, 4, 2, 2, 16, 2>(A, (int)na, B, (int)nb, d, S, ldS, st, la);   // 134 TF at 1024x65536x1024 (BK 32 / PF 1: 123)
 }
 
 void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int32_t *oi32,
