@@ -105,6 +105,28 @@ def test_search_matches_oracle(faiss, oracle, d, M, nlist, n, nq, by_residual):
         assert np.array_equal(bits(D), bits(De))
 
 
+@pytest.mark.parametrize("env", [{}, {"MI_SCAN_NW": "16"}, {"MI_NO_FUSED_MERGE": "1"}, {"MI_NSLICE": "1"},
+                                 {"MI_NSLICE": "7"}])
+def test_probe_table_paths_and_launch_variants(faiss, oracle, monkeypatch, env):
+    """The scan kernel locates code groups three ways -- nprobe <= 64 (tables in
+    registers), <= 256 (register prefix search over LDS tables), > 256 (LDS walk) --
+    and has launch variants behind tuning knobs; all must give the oracle's bits."""
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    d, M, nlist, n, nq = 64, 8, 600, 24000, 37
+    cent, cb, x, q = random_problem(99, d, M, nlist, n, nq)
+    idx = make_index(faiss, cent, cb)
+    idx.add(x)
+    ln, codes = oracle.encode(x, cent, cb, True)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(n), nlist)
+    for nprobe, k in ((64, 10), (65, 10), (200, 33), (256, 10), (257, 10), (600, 100)):
+        idx.nprobe = nprobe
+        D, I = idx.search(q, k)
+        De, Ie = oracle.search(q, cent, cb, off, lc, li, nprobe, k, True)
+        assert np.array_equal(I, Ie), (env, nprobe, k, np.argwhere(I != Ie)[:5])
+        assert np.array_equal(bits(D), bits(De)), (env, nprobe, k)
+
+
 def test_lut_matches_oracle(faiss, oracle):
     cent, cb, x, q = random_problem(3, 1024, 64, 8, 64, 9)
     idx = make_index(faiss, cent, cb)
