@@ -443,6 +443,21 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
             for (int j = 0; j < WNT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     };
+    // Issue order of a steady-state step (MI_GEMM_SCHED builds only, experiment): the MFMAs
+    // first, the fragment reads of the next tile spread between them -- both waves of a SIMD
+    // leave the barrier together, and a block of 12 ds_read_b128 in front of the MFMAs
+    // would leave the matrix pipe idle while both issue it.
+    auto interleave = [&] {
+#ifdef MI_GEMM_SCHED
+        constexpr int NR = WMT + WNT, NM = WMT * WNT, PER = NM / NR;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * NR, 0);
+#endif
+    };
     // tile `next` must have landed in every wave's view before it is read: own DMA
     // pieces by counted vmcnt (up to D-2 later tiles stay in flight), the other
     // waves' pieces by the barrier; lgkmcnt(0) first so that no ds_read of the stage
@@ -467,11 +482,13 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
         read_frags(t + 1, a1, b1);
         issue(t + D);
         mma(a0, b0);
+        interleave();
         wait_vm_lgkm0<(D - 2) * PPW>();
         __builtin_amdgcn_s_barrier();
         read_frags(t + 2, a0, b0);
         issue(t + D + 1);
         mma(a1, b1);
+        interleave();
     }
     for (; t < nk; t += 2) {  // tail: same schedule with guards
         if (t + 1 < nk) {
