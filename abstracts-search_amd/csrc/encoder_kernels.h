@@ -756,6 +756,12 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         const bf16_t *qp = a.QK + (size_t)(s0 + qrow) * a.ldqk + h * HD + lg * 8;
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8 *>(qp + kk * 32);
+        // Pin the wait for these loads HERE.  Left to the compiler it sits in front of the
+        // first MFMA inside the loop as `s_waitcnt vmcnt(3..0)` -- counted without the LDS-DMA
+        // pieces (issued from asm, invisible to it), so every iteration it would drain the
+        // chunk that was just requested and the double buffering would be gone.
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]));
     }
     f32x4 o[NDT];
 #pragma unroll
