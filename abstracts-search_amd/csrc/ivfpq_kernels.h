@@ -694,23 +694,30 @@ __global__ void __launch_bounds__(256) lut_kernel(LutArgs a) {
 // ---------------------------------------------------------------------
 // PQ-code scan + per-slice top-k.
 //
-// One 512-thread workgroup per (query, slice).  The slice's work items are
-// the 64-code groups of the query's probed lists (concatenated, dealt
-// round-robin to the 8 waves); lane j of a wave owns code j of the group:
-// NCH coalesced 16-byte loads (+ one 8-byte id load), then M look-ups
-// LUT[m][code[m]] from LDS added in ascending m (the oracle's order).
+// One 512-thread workgroup per (query, slice); workgroup b runs on XCD b % 8 and the
+// slices of one query are 8 workgroups apart (one XCD: the query's LUT is fetched
+// from HBM once).  The slice's work items are the 64-code groups of the query's
+// probed lists (concatenated, dealt round-robin to the 8 waves); lane j of a wave
+// owns code j of the group: NCH coalesced 16-byte loads (+ one 8-byte id load), then
+// M look-ups LUT[m][code[m]] from LDS added in ascending m (the oracle's order).
+//
+// Prologue: per-wave probe tables by LDS-DMA (nprobe <= 64: kept in registers), LUT
+// rows by LDS-DMA behind them, the first two code groups of every wave requested
+// before the one barrier that covers LUT and codes.
 //
 // Selection is threshold-filtered and latency-free on the common path:
 //   - a score below the running threshold is dropped by one compare + ballot;
 //   - survivors are appended to a 128-entry per-wave LDS buffer;
-//   - when the buffer passes 64 entries it is compressed to the wave's exact
-//     top-k by a 32-step bitwise descent on order-preserving keys (ballot +
-//     popcount only: no shuffles, no serial insertion), which also tightens
-//     the threshold; the threshold is shared across the workgroup's waves
-//     through one LDS word (atomicMax);
+//   - when the buffer passes 64 entries and the wave has another group coming, it
+//     is compressed to the wave's exact top-k by a bitwise descent on
+//     order-preserving keys (ballot + popcount only: no shuffles, no serial
+//     insertion), which also tightens the threshold; the threshold is shared across
+//     the workgroup's waves through one LDS word (atomicMax);
 //   - exact score ties at the cut are resolved by ascending id.
-// At the end the waves' survivors (<= 8k) are ranked by parallel counting
-// and written as the slice's sorted partial top-k.
+// Tail: two candidates per lane in registers -> block-wide lower bound of the k-th
+// best from the folded per-thread maxima -> ~k survivors -> ranked by one wave and
+// published write-through; the last slice of the query to take its ticket merges
+// the nslice partial lists (one wave, registers) and writes D / I.
 // ---------------------------------------------------------------------
 struct ScanArgs {
     const float *lut;          // [nq][M*256]
