@@ -514,13 +514,27 @@ __global__ void __launch_bounds__(256)
         if (K <= 64) {
             gkey[tid] = max(max(gm[0], gm[1]), max(gm[2], gm[3]));
             __syncthreads();
-            const unsigned k0 = gkey[lane], k1 = gkey[lane + 64], k2 = gkey[lane + 128], k3 = gkey[lane + 192];
-            for (int bit = 31; bit >= 0; --bit) {
-                const unsigned t = T0 | (1u << bit);
-                const int c = __popcll(__ballot(k0 >= t)) + __popcll(__ballot(k1 >= t)) +
-                              __popcll(__ballot(k2 >= t)) + __popcll(__ballot(k3 >= t));
-                if (c >= K) T0 = t;
-                if (c == K) break;  // t already separates exactly K group maxima
+            // (rotated per wave, so that a fold below decorrelates the waves' columns)
+            const unsigned k0 = gkey[lane], k1 = gkey[64 + ((lane + 16) & 63)], k2 = gkey[128 + ((lane + 32) & 63)],
+                           k3 = gkey[192 + ((lane + 48) & 63)];
+            if (K <= 16) {
+                // any K distinct elements bound the K-th largest from below: the 64 column
+                // maxima do, at one ballot per descent step instead of four
+                const unsigned f = max(max(k0, k1), max(k2, k3));
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned t = T0 | (1u << bit);
+                    const int c = __popcll(__ballot(f >= t));
+                    if (c >= K) T0 = t;
+                    if (c == K) break;
+                }
+            } else {
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned t = T0 | (1u << bit);
+                    const int c = __popcll(__ballot(k0 >= t)) + __popcll(__ballot(k1 >= t)) +
+                                  __popcll(__ballot(k2 >= t)) + __popcll(__ballot(k3 >= t));
+                    if (c >= K) T0 = t;
+                    if (c == K) break;  // t already separates exactly K group maxima
+                }
             }
         } else {
 #pragma unroll
