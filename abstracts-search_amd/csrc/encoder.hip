@@ -64,6 +64,27 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
     MI_HIP(hipGetLastError());
 }
 
+// narrow tiles (WNT = 1): no SwiGLU instantiation (it pairs two N tiles inside a wave)
+template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
+void launch_ring_narrow(int epi, GemmArgs g, hipStream_t st) {
+    constexpr int BM = 16 * WMT * WAVES_M, BN = 16 * WNT * WAVES_N;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const int per = (g.tiles_m * g.tiles_n + 7) / 8;
+    if (epi != EPI_RESID || g.bias) g.ksplit = 1;
+    g.ksplit = std::max(1, g.ksplit);
+    g.tail_first = 0;
+    g.tail_split = 1;
+    dim3 grid(8 * per * g.ksplit), block(64 * WAVES_M * WAVES_N);
+    switch (epi) {
+        case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_STORE, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_RESID, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_QKV, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
+        default: throw Error("narrow GEMM tiles: epilogue not implemented");
+    }
+    MI_HIP(hipGetLastError());
+}
+
 template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
 void launch_ring32(int epi, GemmArgs g, hipStream_t st) {
     constexpr int BM = 32 * WMT * WAVES_M, BN = 32 * WNT * WAVES_N;
@@ -109,8 +130,19 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         } else {
             const int tiles = ((g.M + 31) / 32) * ((g.N + 63) / 64);
             const int nk = g.K / 32;
-            g.ksplit = std::max(1, std::min({8, nk / 8, 256 / std::max(1, tiles)}));
-            launch_ring<2, 2, 1, 2, 8>(epi, g, st);
+            if (epi != EPI_RESID && epi != EPI_SWIGLU && tiles < 128 && cfg != "tiny64") {
+                // no split-K for a bf16 output: a 32x64 tiling of the QKV projection of one query
+                // is 32 workgroups on 256 CUs -- 32x16 tiles, one wave each, give 128
+                launch_ring_narrow<2, 1, 1, 1, 8>(epi, g, st);
+            } else if (epi == EPI_SWIGLU) {
+                // gate/up of one query streams 55 MB of weights: 32x32 one-wave tiles (560
+                // workgroups, two per CU, twice the tiles in flight) measured 18.8 vs 22.4 us
+                g.ksplit = 1;
+                launch_ring<2, 2, 1, 1, 8>(epi, g, st);
+            } else {
+                g.ksplit = std::max(1, std::min({8, nk / 8, 256 / std::max(1, tiles)}));
+                launch_ring<2, 2, 1, 2, 8>(epi, g, st);
+            }
         }
         return;
     }
@@ -501,8 +533,14 @@ int mi_encoder_encode(mi_encoder *h, int nseq, const int32_t *ids, const int32_t
         p.seq_start = b.seq_start; p.seq_len = b.seq_len; p.out = o; p.H = c.hidden; p.out_dim = od;
         p.Lmax = b.Lmax; p.normalize = normalize; p.eps = c.rms_eps;
         const size_t smem = ((size_t)b.Lmax + c.hidden + od + 8) * 4;
-        hipLaunchKernelGGL(pool_kernel, dim3(nseq), dim3(256), smem, st, p);
+        // few sequences: split the Dense rows of each over several workgroups (256 CUs to fill)
+        p.parts = c.dense_out ? std::max(1, std::min(od / 64, 256 / std::max(1, nseq))) : 1;
+        hipLaunchKernelGGL(pool_kernel, dim3(nseq, p.parts), dim3(256), smem, st, p);
         MI_HIP(hipGetLastError());
+        if (p.parts > 1 && normalize) {
+            hipLaunchKernelGGL(l2norm_rows_kernel, dim3(nseq), dim3(256), 0, st, o, od);
+            MI_HIP(hipGetLastError());
+        }
         if (!od_dev) {
             MI_HIP(hipMemcpyAsync(out, o, (size_t)nseq * od * 4, hipMemcpyDeviceToHost, st));
             MI_HIP(hipStreamSynchronize(st));

@@ -910,6 +910,9 @@ struct PoolArgs {
     float *out;              // [nseq][out_dim]
     int H, out_dim, Lmax, normalize;
     float eps;
+    int parts;               // gridDim.y: the Dense rows are split over `parts` workgroups per sequence
+                             // (few sequences: one workgroup streaming the whole Dense matrix is
+                             // latency-bound, 536 us for a single query); > 1 => l2norm_rows_kernel follows
 };
 
 __global__ void __launch_bounds__(256) pool_kernel(PoolArgs a) {
@@ -938,28 +941,41 @@ __global__ void __launch_bounds__(256) pool_kernel(PoolArgs a) {
         pooled[c] = acc * a.norm_w[c] / (float)L;
     }
     __syncthreads();
+    const int parts = max(1, a.parts), part = blockIdx.y;
+    const int per = (a.out_dim + parts - 1) / parts;
+    const int j0 = part * per, j1 = min(a.out_dim, j0 + per);
     if (a.dense_w) {
-        for (int j = w; j < a.out_dim; j += 4) {
-            const bf16_t *wr = a.dense_w + (size_t)j * H;
-            float acc = 0.f;
+        // four Dense rows per wave step: four independent weight streams in flight
+        for (int j = j0 + w * 4; j < j1; j += 16) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
             for (int c = lane * 8; c < H; c += 512) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(wr + c);
-                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+                float pv[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc += pooled[c + 2 * q] * __uint_as_float(u[q] << 16);
-                    acc += pooled[c + 2 * q + 1] * __uint_as_float(u[q] & 0xffff0000u);
+                for (int q = 0; q < 8; ++q) pv[q] = pooled[c + q];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jr = min(j + r, j1 - 1);
+                    const uint4 v = *reinterpret_cast<const uint4 *>(a.dense_w + (size_t)jr * H + c);
+                    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[r] += pv[2 * q] * __uint_as_float(u[q] << 16);
+                        acc[r] += pv[2 * q + 1] * __uint_as_float(u[q] & 0xffff0000u);
+                    }
                 }
             }
-            acc = wave_sum(acc);
-            if (lane == 0) outv[j] = acc + (a.dense_b ? a.dense_b[j] : 0.f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = wave_sum(acc[r]);
+                if (lane == 0 && j + r < j1) outv[j + r] = t + (a.dense_b ? a.dense_b[j + r] : 0.f);
+            }
         }
     } else {
-        for (int c = tid; c < a.out_dim; c += 256) outv[c] = pooled[c];
+        for (int c = j0 + tid; c < j1; c += 256) outv[c] = pooled[c];
     }
     __syncthreads();
     float scale = 1.f;
-    if (a.normalize) {
+    if (a.normalize && parts == 1) {
         float ss = 0.f;
         for (int c = tid; c < a.out_dim; c += 256) ss += outv[c] * outv[c];
         ss = wave_sum(ss);
@@ -968,7 +984,21 @@ __global__ void __launch_bounds__(256) pool_kernel(PoolArgs a) {
         const float tot = red[0] + red[1] + red[2] + red[3];
         scale = 1.0f / fmaxf(sqrtf(tot), 1e-12f);  // torch.nn.functional.normalize eps
     }
-    for (int c = tid; c < a.out_dim; c += 256) a.out[(size_t)seq * a.out_dim + c] = outv[c] * scale;
+    for (int c = j0 + tid; c < j1; c += 256) a.out[(size_t)seq * a.out_dim + c] = outv[c] * scale;
+}
+
+// L2 normalisation of the rows of out[nseq][n] (second step of a split pool_kernel)
+__global__ void __launch_bounds__(256) l2norm_rows_kernel(float *__restrict__ out, int n) {
+    __shared__ float red[4];
+    float *row = out + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float ss = 0.f;
+    for (int c = tid; c < n; c += 256) ss += row[c] * row[c];
+    ss = wave_sum(ss);
+    if (lane == 0) red[w] = ss;
+    __syncthreads();
+    const float scale = 1.0f / fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+    for (int c = tid; c < n; c += 256) row[c] *= scale;
 }
 
 // ---------------------------------------------------------------------
