@@ -1,5 +1,5 @@
 """Batch-1 query encode (stella shape, random-init) repeated: per-kernel profile target.
-usage: python tools/encode_b1.py [ntokens] [reps]   (run under tools/prof_cmd.sh on the GPU box)"""
+usage: python tools/encode_b1.py [ntokens] [reps] [nseq]   (run under tools/prof_cmd.sh on the GPU box)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,6 +7,7 @@ import abstracts_search_amd.sentence_transformers as st
 
 ntok = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+nseq = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 cfg = dict(st.STELLA_EN_1_5B_V5)
 model = st.SentenceTransformer(config=cfg)
 g = torch.Generator(device="cuda").manual_seed(7)
@@ -23,12 +24,12 @@ for l in range(cfg["n_layers"]):
         p + "self_attn.o_proj.weight": rnd((H, qc), qc ** -0.5), p + "mlp.gate_proj.weight": rnd((I, H), H ** -0.5),
         p + "mlp.up_proj.weight": rnd((I, H), H ** -0.5), p + "mlp.down_proj.weight": rnd((H, I), I ** -0.5)})
 rng = np.random.default_rng(1)
-toks = [rng.integers(0, cfg["vocab_size"], ntok).tolist()]
+toks = [rng.integers(0, cfg["vocab_size"], ntok).tolist() for _ in range(nseq)]
 for _ in range(5):
-    model.encode_tokens(toks, batch_size=1, normalize_embeddings=True, as_tensor=True)
+    model.encode_tokens(toks, batch_size=nseq, normalize_embeddings=True, as_tensor=True)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):
-    model.encode_tokens(toks, batch_size=1, normalize_embeddings=True, as_tensor=True)
+    model.encode_tokens(toks, batch_size=nseq, normalize_embeddings=True, as_tensor=True)
 torch.cuda.synchronize()
-print(f"batch 1, {ntok} tokens: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per encode")
+print(f"batch {nseq}, {ntok} tokens each: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per encode")
