@@ -82,6 +82,35 @@ __global__ void __launch_bounds__(256)
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= T) return;
     const float *src = x + (size_t)t * H;
+    bf16_t *dst = y + (size_t)t * H;
+    constexpr int MAXC = 8;   // rows up to 2048 floats stay in registers: one pass over x, every
+                              // load of the row (and of the gains) in flight at once
+    if (H <= 256 * MAXC) {
+        float4 v[MAXC], g[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = min(lane * 4 + 256 * i, H - 4);   // clamped: unconditional loads
+            v[i] = *reinterpret_cast<const float4 *>(src + c);
+            g[i] = *reinterpret_cast<const float4 *>(w + c);
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+            if (lane * 4 + 256 * i < H) ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        ss = wave_sum(ss);
+        const float inv = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < H) {
+                uint2 o;
+                o.x = pack2(v[i].x * inv * g[i].x, v[i].y * inv * g[i].y);
+                o.y = pack2(v[i].z * inv * g[i].z, v[i].w * inv * g[i].w);
+                *reinterpret_cast<uint2 *>(dst + c) = o;
+            }
+        }
+        return;
+    }
     float ss = 0.f;
     for (int c = lane * 4; c < H; c += 256) {
         const float4 v = *reinterpret_cast<const float4 *>(src + c);
@@ -89,7 +118,6 @@ __global__ void __launch_bounds__(256)
     }
     ss = wave_sum(ss);
     const float inv = rsqrtf(ss / (float)H + eps);
-    bf16_t *dst = y + (size_t)t * H;
     for (int c = lane * 4; c < H; c += 256) {
         const float4 v = *reinterpret_cast<const float4 *>(src + c);
         const float4 g = *reinterpret_cast<const float4 *>(w + c);
