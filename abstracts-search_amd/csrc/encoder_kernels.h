@@ -196,6 +196,27 @@ __device__ __forceinline__ float dpp_quad_xor1(float v) {
 __device__ __forceinline__ float dpp_quad_xor2(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
 }
+// All-reduce over the 16 lanes of a DPP row in four VALU steps (no LDS crossbar):
+// quad butterflies, then row_half_mirror (lane i <- 7 - i within each 8: the other quad's
+// result) and row_mirror (lane i <- 15 - i: the other half's result).
+__device__ __forceinline__ float dpp_row_half_mirror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_row_mirror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_quad_xor1(v));
+    v = fmaxf(v, dpp_quad_xor2(v));
+    v = fmaxf(v, dpp_row_half_mirror(v));
+    return fmaxf(v, dpp_row_mirror(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_quad_xor1(v);
+    v += dpp_quad_xor2(v);
+    v += dpp_row_half_mirror(v);
+    return v + dpp_row_mirror(v);
+}
 __device__ __forceinline__ f32x4 quad_transpose(f32x4 v, int lane) {
     const bool odd = lane & 1, hi = lane & 2;
     float r0 = dpp_quad_xor1(odd ? v[0] : v[1]);
@@ -801,6 +822,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         lrow[r] = 0.f;
     }
     const int kend = a.causal ? min(L, q0 + 64) : L;
+    const float scale2 = a.scale * 1.4426950408889634f;
     bf16_t *pw = smem + 2 * STG + w * 16 * KC;
 
     issue(0, 0);
@@ -832,7 +854,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qidx = q0 + w * 16 + lg * 4 + r;
-                float v = s[j][r] * a.scale;
+                float v = s[j][r] * scale2;   // scores in log2 units: exp2 is the native v_exp_f32
                 if (kidx >= L || (a.causal && kidx > qidx)) v = -__builtin_huge_valf();
                 s[j][r] = v;
                 pmax[r] = fmaxf(pmax[r], v);
@@ -841,11 +863,9 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         float alpha[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float m = pmax[r];
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 16));
+            const float m = row16_max(pmax[r]);
             const float mnew = fmaxf(mrow[r], m);
-            alpha[r] = (mrow[r] == -__builtin_huge_valf()) ? 0.f : __expf(mrow[r] - mnew);
+            alpha[r] = (mrow[r] == -__builtin_huge_valf()) ? 0.f : __builtin_amdgcn_exp2f(mrow[r] - mnew);
             mrow[r] = mnew;
         }
         float psum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -853,7 +873,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = (mrow[r] == -__builtin_huge_valf()) ? 0.f : __expf(s[j][r] - mrow[r]);
+                const float p = (mrow[r] == -__builtin_huge_valf()) ? 0.f : __builtin_amdgcn_exp2f(s[j][r] - mrow[r]);
                 psum[r] += p;
                 s[j][r] = p;
             }
@@ -869,10 +889,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float t = psum[r];
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off, 16);
-            lrow[r] = lrow[r] * alpha[r] + t;
+            lrow[r] = lrow[r] * alpha[r] + row16_sum(psum[r]);
         }
 #pragma unroll
         for (int n = 0; n < NDT; ++n)
