@@ -34,7 +34,21 @@ void launch_gemm_cfg(const float *A, int na, const float *B, int nb, int d, floa
     MI_REQUIRE(grid + la.nblocks < (int64_t)1 << 31, "ip_gemm: grid too large");
     static_assert(WAVES_M * WAVES_N * 64 == 256, "appended LUT workgroups need 256 threads");
     hipLaunchKernelGGL((ip_gemm_kernel<WM, WN, WAVES_M, WAVES_N, BK, PF>), dim3((unsigned)(grid + la.nblocks)),
-                       dim3(256), 0, st, A, na, B, nb, d, S, ldS, tiles_m, tiles_n, (int)grid, la);
+                       dim3(256), 0, st, A, na, B, nb, d, S, ldS, tiles_m, tiles_n, (int)grid, la, GatherArgs{nullptr, 0});
+    MI_HIP(hipGetLastError());
+}
+
+// S[q][c] = <A[q], B[idx[q][c]]> for c < kc: one 16x64 tile row per query (gather mode)
+void launch_gemm_gather(const float *A, int nq, const float *B, int64_t nb, int d, const int64_t *idx, int kc,
+                        float *S, int64_t ldS, hipStream_t st) {
+    MI_REQUIRE(d % 4 == 0 && nq > 0 && kc > 0 && nb > 0, "bad gather gemm arguments");
+    constexpr int BN = 64;
+    const int tiles_m = nq, tiles_n = (kc + BN - 1) / BN;
+    const int64_t grid = (int64_t)8 * tiles_m * ((tiles_n + 7) / 8);
+    MI_REQUIRE(grid < (int64_t)1 << 31, "ip_gemm: grid too large");
+    hipLaunchKernelGGL((ip_gemm_kernel<1, 1, 1, 4, 64, 4>), dim3((unsigned)grid), dim3(256), 0, st, A, nq, B,
+                       (int)std::min<int64_t>(nb, INT32_MAX), d, S, ldS, tiles_m, tiles_n, (int)grid, LutArgs{},
+                       GatherArgs{idx, kc});
     MI_HIP(hipGetLastError());
 }
 
@@ -226,7 +240,10 @@ struct mi_flat {
     int d = 0, device = 0;
     int64_t ntotal = 0;
     DevBuf base;
-    DevBuf ws_q, ws_scores, ws_D, ws_I;
+    DevBuf ws_q, ws_scores, ws_D, ws_I, ws_cand;
+    // score workspaces of mi_flat_rerank, one per stream it is called on (batches on
+    // different streams overlap)
+    std::vector<std::pair<void *, std::unique_ptr<DevBuf>>> ws_rerank;
 };
 
 namespace {
@@ -892,6 +909,52 @@ int mi_flat_add(mi_flat *h, int64_t n, const float *x) {
         }
         MI_HIP(hipMemcpy(static_cast<char *>(h->base.p) + old_bytes, x, add_bytes, hipMemcpyDefault));
         h->ntotal += n;
+    });
+}
+
+int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t *cand_I, int k, float *D,
+                   int64_t *I, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(h && (nq == 0 || (q && cand_I && D && I)), "null argument");
+        MI_REQUIRE(k >= 1 && k <= 1024 && kc >= k && kc % k == 0, "kc must be a positive multiple of k (k <= 1024)");
+        MI_REQUIRE(h->ntotal > 0, "rerank: the refine index is empty");
+        MI_REQUIRE(nq < ((int64_t)1 << 24), "rerank: too many queries in one call");
+        if (nq == 0) return;
+        DeviceGuard dg(h->device);
+        hipStream_t st = as_stream(stream);
+        const bool dev = is_device_ptr(q);
+        MI_REQUIRE(is_device_ptr(cand_I) == dev && is_device_ptr(D) == dev && is_device_ptr(I) == dev,
+                   "rerank: q, cand_I, D and I must be all host or all device pointers");
+        const float *qs = q;
+        const int64_t *ci = cand_I;
+        if (!dev) {
+            // ids are validated on the host copy; device callers are trusted (ids come from
+            // the base index over the same vectors)
+            for (int64_t i = 0; i < nq * kc; ++i)
+                MI_REQUIRE(cand_I[i] < h->ntotal, "rerank: candidate id out of range");
+            qs = static_cast<const float *>(to_device(q, (size_t)nq * h->d * 4, h->ws_q, st));
+            ci = static_cast<const int64_t *>(to_device(cand_I, (size_t)nq * kc * 8, h->ws_cand, st));
+        }
+        DevBuf *wsb = nullptr;
+        for (auto &kv : h->ws_rerank)
+            if (kv.first == stream) wsb = kv.second.get();
+        if (!wsb) {
+            MI_REQUIRE(h->ws_rerank.size() < 16, "too many distinct streams on one flat index handle (max 16)");
+            h->ws_rerank.emplace_back(stream, std::make_unique<DevBuf>());
+            wsb = h->ws_rerank.back().second.get();
+        }
+        float *scores = wsb->as<float>((size_t)nq * kc);
+        float *Dc = dev ? D : h->ws_D.as<float>((size_t)nq * k);
+        int64_t *Ic = dev ? I : h->ws_I.as<int64_t>((size_t)nq * k);
+        launch_gemm_gather(qs, (int)nq, h->base.get<float>(), h->ntotal, h->d, ci, kc, scores, kc, st);
+        // the candidate list as kc/k "parts" of k entries: the k-way merge ranks them under
+        // (score desc, id asc) and skips the negative ids
+        launch_merge(scores, ci, kc / k, k, kc, nq, k, Dc, Ic, k, 0, nullptr, nullptr, st);
+        if (!dev) {
+            MI_HIP(hipMemcpyAsync(D, Dc, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+            MI_HIP(hipMemcpyAsync(I, Ic, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+            MI_HIP(hipStreamSynchronize(st));
+        }
     });
 }
 

@@ -133,11 +133,19 @@ __device__ __forceinline__ void lut_block(const LutArgs &a, int blk) {
     }
 }
 
+// Gather mode (re-ranking): M tile tm is ONE query (row tm of A) and its B rows are the
+// rows idx[tm][0..kc) of B (negative = empty slot: any row, the caller ignores the score);
+// S[tm][c] = <A[tm], B[idx[tm][c]]> with exactly the arithmetic of the plain mode.
+struct GatherArgs {
+    const int64_t *idx;   // [tiles_m][kc] or null = plain GEMM
+    int kc;
+};
+
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int PF>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
     ip_gemm_kernel(const float *__restrict__ A, int na, const float *__restrict__ B, int nb,
                    int d, float *__restrict__ S, int64_t ldS, int tiles_m, int tiles_n, int gemm_blocks,
-                   LutArgs la) {
+                   LutArgs la, GatherArgs ga) {
     if ((int)blockIdx.x >= gemm_blocks) {  // appended LUT workgroups (dsub <= 16 only)
         const int blk = blockIdx.x - gemm_blocks;
         if (la.dsub == 16) lut_block<16>(la, blk);
@@ -184,29 +192,38 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
 #pragma unroll
         for (int y = 0; y < WN; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // row pointers of this thread's staging loads (rows are clamped, never guarded; a thread
+    // without a tile row re-reads a clamped row)
+    const float *pa_row[CA], *pb_row[CB];
+#pragma unroll
+    for (int u = 0; u < CA; ++u) {
+        const int idx = tid + u * NT;
+        const int gr = ga.idx ? tm : min(m0 + idx / KQ, na - 1);
+        pa_row[u] = A + (size_t)gr * d + (idx % KQ) * 4;
+    }
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+        const int idx = tid + u * NT;
+        int64_t gr = min(n0 + idx / KQ, nb - 1);
+        if (ga.idx) gr = max(ga.idx[(size_t)tm * ga.kc + min(n0 + idx / KQ, ga.kc - 1)], (int64_t)0);
+        pb_row[u] = B + (size_t)gr * d + (idx % KQ) * 4;
+    }
     // `full` (a literal at every call site) marks a K chunk that lies inside d: its
     // loads carry no guard at all.  A guarded load is an exec-masked branch, after which
-    // hipcc falls back to s_waitcnt vmcnt(0) and the PF-deep prefetch is gone (rows are
-    // clamped, never guarded; a thread without a tile row re-reads a clamped row).
+    // hipcc falls back to s_waitcnt vmcnt(0) and the PF-deep prefetch is gone.
     auto gload = [&](int k0, float4(&pa)[CA], float4(&pb)[CB], bool full) {
 #pragma unroll
         for (int u = 0; u < CA; ++u) {
-            int idx = tid + u * NT;
-            int row = idx / KQ;
-            int k = k0 + (idx % KQ) * 4;
-            int gr = min(m0 + row, na - 1);
-            if (full) pa[u] = *reinterpret_cast<const float4 *>(A + (size_t)gr * d + k);
-            else pa[u] = (k < d) ? *reinterpret_cast<const float4 *>(A + (size_t)gr * d + k)
+            const int k = k0 + ((tid + u * NT) % KQ) * 4;
+            if (full) pa[u] = *reinterpret_cast<const float4 *>(pa_row[u] + k0);
+            else pa[u] = (k < d) ? *reinterpret_cast<const float4 *>(pa_row[u] + k0)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
-            int idx = tid + u * NT;
-            int row = idx / KQ;
-            int k = k0 + (idx % KQ) * 4;
-            int gr = min(n0 + row, nb - 1);
-            if (full) pb[u] = *reinterpret_cast<const float4 *>(B + (size_t)gr * d + k);
-            else pb[u] = (k < d) ? *reinterpret_cast<const float4 *>(B + (size_t)gr * d + k)
+            const int k = k0 + ((tid + u * NT) % KQ) * 4;
+            if (full) pb[u] = *reinterpret_cast<const float4 *>(pb_row[u] + k0);
+            else pb[u] = (k < d) ? *reinterpret_cast<const float4 *>(pb_row[u] + k0)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -369,8 +386,13 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
             int col = n0 + (wni * WN + y) * 16 + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int row = m0 + (wmi * WM + x) * 16 + lg * 4 + r;
-                if (row < na && col < nb) S[(size_t)row * ldS + col] = acc[x][y][r];
+                const int trow = (wmi * WM + x) * 16 + lg * 4 + r;   // row inside the tile
+                if (ga.idx) {
+                    if (trow == 0 && col < ga.kc) S[(size_t)tm * ldS + col] = acc[x][y][r];
+                } else {
+                    const int row = m0 + trow;
+                    if (row < na && col < nb) S[(size_t)row * ldS + col] = acc[x][y][r];
+                }
             }
         }
 }

@@ -138,6 +138,15 @@ int mi_flat_ntotal(mi_flat *h, int64_t *out);
 int mi_flat_reset(mi_flat *h);
 int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int64_t *I,
                    void *stream);
+/* Re-ranking step of faiss's IndexRefineFlat::search (the refine index is an IndexFlat;
+ * reference call site: the same `index tune` / query-time search, Makefile:32, README.md:28,
+ * when the factory string carries ",RFlat").  cand_I int64 [nq][kc] are candidate ids from a
+ * base index (positions in this flat index; negative = empty slot), kc a multiple of k.
+ * Exact inner products of every query with its candidates -- the same arithmetic as
+ * mi_flat_search -- then the k best under (score desc, id asc); unfilled: -1 / -FLT_MAX.
+ * q, cand_I, D, I: all host or all device pointers. */
+int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t *cand_I, int k,
+                   float *D, int64_t *I, void *stream);
 
 /* ---- building blocks used by train() in the Python mirror ---------- */
 

@@ -168,6 +168,33 @@ ORACLE_API void oracle_flat_ip(int64_t nq, int d, const float *q, int64_t nb,
     }
 }
 
+/* IndexRefineFlat::search, re-ranking step (faiss: the base index returns
+ * k * k_factor labels, the refine index -- an IndexFlat over the same vectors in
+ * add() order -- recomputes their exact distances, the k best are kept).  cand_I
+ * [nq][kc], negative = empty slot.  Same dot product and the same total order
+ * (score desc, id asc) as everywhere else in this file. */
+ORACLE_API void oracle_rerank(int64_t nq, int d, const float *q, const float *base, int kc,
+                              const int64_t *cand_I, int k, float *D, int64_t *I) {
+#pragma omp parallel
+    {
+        cand_t *L = (cand_t *)malloc(sizeof(cand_t) * (size_t)k);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t qi = 0; qi < nq; ++qi) {
+            int n = 0;
+            for (int c = 0; c < kc; ++c) {
+                const int64_t id = cand_I[qi * kc + c];
+                if (id < 0) continue;
+                topk_push(L, &n, k, dot_chain(q + qi * d, base + id * (int64_t)d, d), id);
+            }
+            for (int j = 0; j < k; ++j) {
+                D[qi * k + j] = j < n ? L[j].s : -FLT_MAX;
+                I[qi * k + j] = j < n ? L[j].id : -1;
+            }
+        }
+        free(L);
+    }
+}
+
 /* ADC look-up table for one query: lut[m*ksub + j] = <q_m, codebook[m][j]> */
 ORACLE_API void oracle_lut(int d, int M, int ksub, const float *q,
                            const float *codebook, float *lut) {

@@ -149,6 +149,21 @@ def search_preassigned(q, codebook, list_off, codes, ids, coarse_I, coarse_D, k,
     return D, I
 
 
+def rerank(q, base, cand_I, k):
+    """IndexRefineFlat re-ranking restatement: exact scores of the candidate ids
+    (negative = empty), k best under (score desc, id asc) -> (D[nq,k], I[nq,k])."""
+    q, base = _f32(q), _f32(base)
+    cand_I = np.ascontiguousarray(cand_I, np.int64)
+    nq, d = q.shape
+    kc = cand_I.shape[1]
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    lib().oracle_rerank(ctypes.c_int64(nq), ctypes.c_int(d), _p(q, ctypes.c_float), _p(base, ctypes.c_float),
+                        ctypes.c_int(kc), _p(cand_I, ctypes.c_int64), ctypes.c_int(k),
+                        _p(D, ctypes.c_float), _p(I, ctypes.c_int64))
+    return D, I
+
+
 def merge(D_parts, I_parts):
     """k-way merge of per-shard results [nparts,nq,k] -> (D[nq,k], I[nq,k])."""
     D_parts = _f32(D_parts)

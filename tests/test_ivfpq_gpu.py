@@ -127,6 +127,55 @@ def test_probe_table_paths_and_launch_variants(faiss, oracle, monkeypatch, env):
         assert np.array_equal(bits(D), bits(De)), (env, nprobe, k)
 
 
+def test_refine_flat_matches_oracle(faiss, oracle):
+    """IndexRefineFlat: base IVF-PQ candidates (k * k_factor) re-ranked with exact inner
+    products.  The re-ranking scores are bit-identical to IndexFlatIP.search's for the same
+    ids (same kernel), the result equals the oracle's re-ranking of the oracle's candidates,
+    and on clustered data recall against the exact search goes up."""
+    d, M, nlist, n, nq, k = 128, 16, 64, 20000, 50, 10
+    cent, cb, x, q = random_problem(5, d, M, nlist, n, nq)
+    base = make_index(faiss, cent, cb)
+    idx = faiss.IndexRefineFlat(base)
+    idx.add(x)
+    assert idx.ntotal == n and idx.refine_index.ntotal == n
+    idx.nprobe = 8
+    ln, codes = oracle.encode(x, cent, cb, True)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(n), nlist)
+    Dx, Ix = oracle.flat_ip(q, x, k)
+    recalls = []
+    for kf in (1, 4, 10):
+        idx.k_factor = kf
+        D, I = idx.search(q, k)
+        _, cand = oracle.search(q, cent, cb, off, lc, li, 8, k * kf, True)
+        De, Ie = oracle.rerank(q, x, cand, k)
+        assert np.array_equal(I, Ie), (kf, np.argwhere(I != Ie)[:5])
+        assert np.array_equal(bits(D), bits(De)), kf
+        recalls.append(np.mean([len(set(I[i]) & set(Ix[i])) / k for i in range(nq)]))
+    assert recalls[2] >= recalls[0] and recalls[2] > 0.5, recalls
+    # scores of the kept ids are the flat index's scores, bit for bit
+    flat = faiss.IndexFlatIP(d)
+    flat.add(x)
+    Df, If = flat.search(q, 200)
+    for i in range(nq):
+        pos = {int(v): j for j, v in enumerate(If[i])}
+        for j in range(k):
+            if int(I[i, j]) in pos:
+                assert bits(D[i, j:j + 1])[0] == bits(Df[i, pos[int(I[i, j])]:pos[int(I[i, j])] + 1])[0]
+    # empty slots (a base index that cannot fill k * k_factor) and the torch path
+    import torch
+    idx.nprobe = 1
+    idx.k_factor = 50
+    D, I = idx.search(q[:5], k)
+    _, cand = oracle.search(q[:5], cent, cb, off, lc, li, 1, k * 50, True)
+    assert (cand < 0).any()
+    De, Ie = oracle.rerank(q[:5], x, cand, k)
+    assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De))
+    Dt, It = idx.search(torch.from_numpy(q[:5]).cuda(), k)
+    assert np.array_equal(It.cpu().numpy(), Ie) and np.array_equal(bits(Dt.cpu().numpy()), bits(De))
+    f = faiss.index_factory(d, "IVF64,PQ16,RFlat", faiss.METRIC_INNER_PRODUCT)
+    assert isinstance(f, faiss.IndexRefineFlat) and f.base_index.nlist == 64
+
+
 def test_lut_matches_oracle(faiss, oracle):
     cent, cb, x, q = random_problem(3, 1024, 64, 8, 64, 9)
     idx = make_index(faiss, cent, cb)

@@ -113,3 +113,29 @@ def test_merge_equals_global_topk(nparts, nq, k, seed):
     perm = rng.permutation(nparts)
     Dm2, Im2 = O.merge(D[perm], I[perm])
     assert np.array_equal(Im, Im2) and np.array_equal(Dm, Dm2)
+
+
+def test_rerank_restatement():
+    """oracle.rerank: exact scores of candidate ids, k best under (score desc, id asc);
+    with the true top-k among unique candidates it reproduces flat_ip, empty slots are
+    skipped, short candidate lists pad with -1 / -FLT_MAX."""
+    from oracle import ivfpq_oracle as o
+    rng = np.random.default_rng(0)
+    base = rng.standard_normal((500, 32)).astype(np.float32)
+    q = rng.standard_normal((7, 32)).astype(np.float32)
+    Df, If = o.flat_ip(q, base, 10)
+    cand = np.empty((7, 40), np.int64)
+    for i in range(7):
+        rest = np.setdiff1d(np.arange(500), If[i])
+        cand[i] = rng.permutation(np.concatenate([If[i], rng.permutation(rest)[:30]]))
+    D, I = o.rerank(q, base, cand, 10)
+    assert np.array_equal(I, If) and np.array_equal(D.view(np.uint32), Df.view(np.uint32))
+    cand[:, 10:] = -1
+    D, I = o.rerank(q, base, cand, 20)
+    assert (I[:, 10:] == -1).all() and (D[:, 10:] == -np.finfo(np.float32).max).all()
+    for i in range(7):
+        assert set(I[i, :10]) == set(cand[i, :10]) and (np.diff(D[i, :10]) <= 0).all()
+    # ties: equal vectors rank by ascending id
+    base2 = np.repeat(base[:1], 6, 0)
+    D, I = o.rerank(q[:1], base2, np.array([[5, 2, 4, 0, -1, 3]], np.int64), 3)
+    assert I.tolist() == [[0, 2, 3]]
