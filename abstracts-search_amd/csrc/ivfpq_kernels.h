@@ -1143,7 +1143,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
     __syncthreads();  // every wave is done with the LUT: its LDS is reused below
     stamp(5);
     // Any k distinct candidates bound the k-th largest from below, so for small k the
-    // 512 thread maxima are first folded to 64 (k <= 16) or 128 (k <= 32) column maxima:
+    // 512 thread maxima are first folded to 64 (k <= 16) or 128 (k <= 64) column maxima:
     // the descent then costs one or two ballots per step instead of eight.
     unsigned T0 = 0;
     {
@@ -1156,7 +1156,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
 #pragma unroll
             for (int ww = 0; ww < SCAN_NW; ++ww) f[0] = max(f[0], kk[ww]);
             T0 = wave_kth_largest_n<1>(f, k);
-        } else if (k <= 32) {
+        } else if (k <= 64) {
             unsigned f[2] = {0u, 0u};
 #pragma unroll
             for (int ww = 0; ww < SCAN_NW; ++ww) f[ww & 1] = max(f[ww & 1], kk[ww]);
