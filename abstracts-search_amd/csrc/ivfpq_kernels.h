@@ -794,7 +794,7 @@ constexpr int SCAN_WBUF = 128;    // candidate slots per wave
 // LDS carve: [ LUT M KiB (>= 2 KiB per wave, reused by the selection tail) | wave buffers
 //              8 x 128 x (8+4) B | prefix | p_goff | p_len | p_dis | misc 16 B ]
 __host__ __device__ inline size_t scan_lut_bytes(int M, int nw) {
-    size_t b = (size_t)M * 1024, floor_b = (size_t)nw * 2048;   // selection tail: 2 x 64 nw entries x 16 B
+    size_t b = (size_t)M * 1024, floor_b = (size_t)nw * 3072;   // selection tail: 3 x 64 nw entries x 16 B
     return b < floor_b ? floor_b : b;
 }
 // grid of the scan launch: the slices of a query share an XCD (see the kernel)
@@ -1071,6 +1071,9 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
     // rotating three register sets by name (a copy would wait for the newest load).
     // A fourth set measured slower: 162 VGPRs, one workgroup per CU instead of two.
     int n_proc = 0;
+    bool last_ok = false;
+    float last_s = 0.f;
+    int64_t last_id = 0;
     auto process = [&](const Group &g, bool more) {
         // M table look-ups, m ascending, f32 adds in that order (= the oracle)
         float acc = 0.f;
@@ -1095,20 +1098,27 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         const float thr_eff = fmaxf(thr, wthr);
         bool pf = (lane < g.nvalid) && (s >= thr_eff);
         if (has_bound) pf = pf && (s < bs || (s == bs && g.id > bid));
-        unsigned long long mask = __ballot(pf);
-        if (a.debug & 1) mask = 0;
-        if (mask) {
-            if (pf) {
-                const int o = cnt + lane_prefix_count(mask);
-                buf_s[o] = s;
-                buf_id[o] = g.id;
-            }
-            cnt += __popcll(mask);
-            // room for the next group (and a tighter threshold for everybody) -- unless this
-            // was the wave's last group: the selection tail takes up to 128 entries as they are
-            if (cnt > 64 && more) {
-                wave_compress(buf_s, buf_id, lane, k, cnt, thr);
-                if (thr > wthr && lane == 0) atomicMax(wg_thr, f2o(thr));
+        if (a.debug & 1) pf = false;
+        if (!more) {
+            // the wave's last group never goes through the LDS buffer: its candidates stay in
+            // registers as the third entry per lane of the selection tail (a slice of up to
+            // three groups per wave -- the bench configuration -- never compresses)
+            last_ok = pf;
+            last_s = s;
+            last_id = g.id;
+        } else {
+            const unsigned long long mask = __ballot(pf);
+            if (mask) {
+                if (cnt > 64) {  // make room: reduce the buffer to the wave's top k, tighten the threshold
+                    wave_compress(buf_s, buf_id, lane, k, cnt, thr);
+                    if (thr > wthr && lane == 0) atomicMax(wg_thr, f2o(thr));
+                }
+                if (pf) {
+                    const int o = cnt + lane_prefix_count(mask);
+                    buf_s[o] = s;
+                    buf_id[o] = g.id;
+                }
+                cnt += __popcll(mask);
             }
         }
         if (n_proc == 0) stamp(3);
@@ -1138,8 +1148,9 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
     const float sa = va ? buf_s[lane] : 0.f, sb = vb ? buf_s[lane + 64] : 0.f;
     const int64_t ia = va ? buf_id[lane] : 0, ib = vb ? buf_id[lane + 64] : 0;
     const unsigned ka = va ? f2o(sa) : 0u, kb = vb ? f2o(sb) : 0u;
+    const unsigned kc3 = last_ok ? f2o(last_s) : 0u;   // the last group, straight from registers
     unsigned *tmax = reinterpret_cast<unsigned *>(wb + (size_t)SCAN_NW * SCAN_WBUF * 8);  // over buf_s
-    tmax[w * SCAN_WBUF + lane] = max(ka, kb);
+    tmax[w * SCAN_WBUF + lane] = max(max(ka, kb), kc3);
     __syncthreads();  // every wave is done with the LUT: its LDS is reused below
     stamp(5);
     // Any k distinct candidates bound the k-th largest from below, so for small k the
@@ -1165,16 +1176,16 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
             T0 = wave_kth_largest_n<SCAN_NW>(kk, k);
         }
     }
-    constexpr int CAP = 2 * NT;                                  // two candidates per thread at most
+    constexpr int CAP = 3 * NT;                                  // three candidates per thread at most
     int64_t *g_id = reinterpret_cast<int64_t *>(lut_s);          // [CAP]
     float *g_s = lut_s + 2 * CAP;                                // [CAP]
     int *g_rank = reinterpret_cast<int *>(lut_s) + 3 * CAP;      // [CAP]
     int64_t *o_id = reinterpret_cast<int64_t *>(wb);             // [64]  (over buf_id, dead by now)
     float *o_s = reinterpret_cast<float *>(wb + 512);            // [64]
     {
-        const bool pa = ka != 0u && ka >= T0, pb = kb != 0u && kb >= T0;
-        const unsigned long long ma = __ballot(pa), mb = __ballot(pb);
-        const int na = __popcll(ma), tot = na + __popcll(mb);
+        const bool pa = ka != 0u && ka >= T0, pb = kb != 0u && kb >= T0, pc = kc3 != 0u && kc3 >= T0;
+        const unsigned long long ma = __ballot(pa), mb = __ballot(pb), mc = __ballot(pc);
+        const int na = __popcll(ma), nb2 = __popcll(mb), tot = na + nb2 + __popcll(mc);
         if (tot) {
             int o = 0;
             if (lane == 0) o = atomicAdd(c_total, tot);
@@ -1189,12 +1200,17 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
                 g_s[x] = sb;
                 g_id[x] = ib;
             }
+            if (pc) {
+                const int x = o + na + nb2 + lane_prefix_count(mc);
+                g_s[x] = last_s;
+                g_id[x] = last_id;
+            }
         }
     }
     stamp(6);
     __syncthreads();
     stamp(7);
-    const int C = uniform_i(*c_total);  // <= 1024
+    const int C = uniform_i(*c_total);  // <= CAP
     if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * SCAN_TS + 14] = (unsigned long long)C + 1;
     const size_t part_o = ((size_t)q * a.nslice + slice) * k;
     // The slice's partial list is published WRITE-THROUGH (relaxed agent-scope
