@@ -199,6 +199,25 @@ def test_gemm_tile_configs_bit_exact(faiss, oracle):
         assert np.array_equal(bits(D), bits(De)), nq
 
 
+def test_gemm_awkward_shapes_bit_exact(faiss, oracle):
+    """The f32 score GEMM over awkward shapes -- every tile configuration (1..600 query
+    rows), partial and single K chunks (d = 4 .. 260, 1024), ragged and tiny bases --
+    against the oracle's flat search, bit for bit."""
+    rng = np.random.default_rng(3)
+    for d in (4, 8, 36, 60, 64, 68, 100, 128, 132, 192, 260, 1024):
+        for nb in (1, 15, 64, 777):
+            base = rng.standard_normal((nb, d)).astype(np.float32)
+            ix = faiss.IndexFlatIP(d)
+            ix.add(base)
+            for na in (1, 5, 16, 17, 64, 100, 128, 129, 300, 600):
+                q = rng.standard_normal((na, d)).astype(np.float32)
+                k = min(7, nb)
+                D, I = ix.search(q, k)
+                De, Ie = oracle.flat_ip(q, base, k)
+                assert np.array_equal(I, Ie), (d, nb, na)
+                assert np.array_equal(bits(D), bits(De)), (d, nb, na)
+
+
 def test_large_k_multipass(faiss, oracle):
     cent, cb, x, q = random_problem(21, 64, 8, 8, 4000, 12)
     idx = make_index(faiss, cent, cb)
