@@ -205,7 +205,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
     for (int u = 0; u < CB; ++u) {
         const int idx = tid + u * NT;
         int64_t gr = min(n0 + idx / KQ, nb - 1);
-        if (ga.idx) gr = max(ga.idx[(size_t)tm * ga.kc + min(n0 + idx / KQ, ga.kc - 1)], (int64_t)0);
+        if (ga.idx)   // clamped both ways: an id that is not a position in B must not fault
+            gr = max(min(ga.idx[(size_t)tm * ga.kc + min(n0 + idx / KQ, ga.kc - 1)], (int64_t)nb - 1), (int64_t)0);
         pb_row[u] = B + (size_t)gr * d + (idx % KQ) * 4;
     }
     // `full` (a literal at every call site) marks a K chunk that lies inside d: its
