@@ -126,7 +126,16 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         } else if (cfg == "mid") {
             launch_ring<4, 4, 2, 2, 4>(epi, g, st);
         } else if (cfg == "small") {
-            launch_ring<4, 2, 2, 1, 8>(epi, g, st);
+            if (epi == EPI_RESID && !g.bias && g.K >= 4096 && !force) {
+                // a few hundred tokens through the down projection (K = 8960): 128x32 tiles are one
+                // long DMA-issue-bound K loop per workgroup (82 us at 512 tokens); 128x128 tiles
+                // with K split three ways (f32 atomics) measured best (batch-16 encode 5.07 -> 4.80 ms;
+                // 2 ways 5.11, 4 ways 4.84, 6 ways 5.38)
+                g.ksplit = 3;
+                launch_ring<4, 4, 2, 2, 4>(epi, g, st);
+            } else {
+                launch_ring<4, 2, 2, 1, 8>(epi, g, st);
+            }
         } else {
             const int tiles = ((g.M + 31) / 32) * ((g.N + 63) / 64);
             const int nk = g.K / 32;
