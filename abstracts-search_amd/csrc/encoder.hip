@@ -23,6 +23,7 @@ hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 struct LayerW {
     DevBuf wqkv, bqkv, wo, wgu, wd, ln1, ln2;
+    DevBuf wqkv_t, wo_t, wgu_t, wd_t;   // fragment-major copies for the few-token GEMM path (built lazily)
 };
 
 template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
@@ -119,6 +120,7 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         std::string cfg = force ? std::string(force) : "";
         if (cfg.empty()) cfg = g.M <= 64 ? "tiny" : tiles_big >= 100 ? "big" : tiles_mid >= 150 ? "mid" : "small";
         g.ksplit = 1;
+        if (cfg != "tiny" || std::getenv("MI_NO_TILED_W")) g.Wt = nullptr;   // only the few-token path streams fragment-major weights
         if (cfg == "big32" && epi != EPI_SWIGLU) {
             launch_ring32<4, 2, 2, 4, 4>(epi, g, st);   // 256x256 on the 32x32x16 MFMA shape (experimental)
         } else if (cfg == "big" || cfg == "big32") {
@@ -155,6 +157,7 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         }
         return;
     }
+    g.Wt = nullptr;
     g.tiles_m = (g.M + 127) / 128;
     g.tiles_n = (g.N + 127) / 128;
     const int ntiles = g.tiles_m * g.tiles_n;
@@ -182,6 +185,7 @@ struct mi_encoder {
     // workspaces
     DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_ids, ws_pos, ws_meta, ws_out, ws_stage;
     size_t vt_zeroed = 0;
+    bool tiled_ok = false;   // fragment-major weight copies are current
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
@@ -335,6 +339,26 @@ void run_stack(mi_encoder *h, const Batch &b, hipStream_t st) {
     bf16_t *att = h->ws_att.as<bf16_t>((size_t)T * h->q_cols);
     bf16_t *hb = h->ws_h.as<bf16_t>((size_t)T * I);
 
+    // few tokens (a query, or a handful): the GEMMs stream the weights once and are bound by how
+    // they read them -- use the fragment-major copies (a second copy of the layer weights, built
+    // on first use: 16-row x 64-byte fragments of a row-major matrix are 16 DRAM pages per wave-load)
+    const bool few = T <= 64 && H % 32 == 0 && I % 32 == 0 && h->q_cols % 32 == 0 &&
+                     (h->qk_cols + h->v_cols) % 16 == 0 && (2 * I) % 16 == 0 && H % 16 == 0;
+    if (few && !h->tiled_ok) {
+        auto tile = [&](const DevBuf &src, int N, int K, DevBuf &dstb) {
+            bf16_t *d = dstb.as<bf16_t>((size_t)N * K);
+            hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)((N / 16) * (K / 32))), dim3(64), 0, st,
+                               src.get<bf16_t>(), N, K, K, d);
+            MI_HIP(hipGetLastError());
+        };
+        for (auto &w : h->layers) {
+            tile(w.wqkv, h->qk_cols + h->v_cols, H, w.wqkv_t);
+            tile(w.wo, H, h->q_cols, w.wo_t);
+            tile(w.wgu, 2 * I, H, w.wgu_t);
+            tile(w.wd, H, I, w.wd_t);
+        }
+        h->tiled_ok = true;
+    }
     hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, st, h->ws_ids.get<int32_t>(),
                        h->embed.get<bf16_t>(), H, T, x);
     MI_HIP(hipGetLastError());
@@ -345,6 +369,7 @@ void run_stack(mi_encoder *h, const Batch &b, hipStream_t st) {
         GemmArgs g{};
         g.A = xn; g.lda = H; g.W = w.wqkv.get<bf16_t>(); g.ldw = H; g.M = T; g.N = h->qk_cols + h->v_cols; g.K = H;
         g.bias = w.bqkv.get<float>(); g.C = qk; g.ldc = h->qk_cols; g.Vt = vt; g.ldvt = ldvt; g.qk_cols = h->qk_cols;
+        if (few) g.Wt = w.wqkv_t.get<bf16_t>();
         timed_gemm(h, EPI_QKV, g, st);
         {
             const int nh_qk = c.n_heads + c.n_kv_heads;
@@ -364,14 +389,17 @@ void run_stack(mi_encoder *h, const Batch &b, hipStream_t st) {
         GemmArgs o{};
         o.A = att; o.lda = h->q_cols; o.W = w.wo.get<bf16_t>(); o.ldw = h->q_cols; o.M = T; o.N = H; o.K = h->q_cols;
         o.X = x; o.ldc = H;
+        if (few) o.Wt = w.wo_t.get<bf16_t>();
         timed_gemm(h, EPI_RESID, o, st);
         hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln2.get<float>(), H, T,
                            c.rms_eps, xn);
         GemmArgs u{};
         u.A = xn; u.lda = H; u.W = w.wgu.get<bf16_t>(); u.ldw = H; u.M = T; u.N = 2 * I; u.K = H; u.C = hb; u.ldc = I;
+        if (few) u.Wt = w.wgu_t.get<bf16_t>();
         timed_gemm(h, EPI_SWIGLU, u, st);
         GemmArgs d{};
         d.A = hb; d.lda = I; d.W = w.wd.get<bf16_t>(); d.ldw = I; d.M = T; d.N = H; d.K = I; d.X = x; d.ldc = H;
+        if (few) d.Wt = w.wd_t.get<bf16_t>();
         timed_gemm(h, EPI_RESID, d, st);
     }
 }
@@ -455,6 +483,7 @@ int mi_encoder_load_tensor(mi_encoder *h, const char *name_c, const void *data, 
     return guard([&] {
         MI_REQUIRE(h && name_c && data && shape, "null argument");
         MI_REQUIRE(dtype >= 0 && dtype <= 2, "bad dtype");
+        h->tiled_ok = false;   // any new weight invalidates the fragment-major copies
         std::string name(name_c);
         if (name.rfind("model.", 0) == 0) name = name.substr(6);
         auto it = h->loaded.find(name);

@@ -172,6 +172,9 @@ enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3 };
 struct GemmArgs {
     const bf16_t *A;   // [M][lda]
     const bf16_t *W;   // [N][ldw]
+    const bf16_t *Wt;  // fragment-major copy of W (tile_weights_kernel) or null: piece (16-row block nb,
+                       // K step ks) is the 1 KiB at ((nb * K/32) + ks) * 512 elements, already in the
+                       // lane order the LDS-DMA wants -- a 16-row block's K run is one contiguous stream
     int lda, ldw, M, N, K;
     const float *bias; // [N] or null
     bf16_t *C;         // STORE / SWIGLU / QKV(q,k part): bf16 [M][ldc]
@@ -185,6 +188,18 @@ struct GemmArgs {
     // for 1/tail_split of a tile time instead of a few CUs for a full one
     int tail_first, tail_split;
 };
+
+// W [N][ldw] (N % 16 == 0, K % 32 == 0) -> fragment-major Wt: one 64-thread workgroup per
+// (16-row block, K step); lane i carries what the ring kernel's DMA lane i would fetch:
+// row 16 nb + (i >> 2), 16-byte slot (i & 3) ^ ((-(i >> 4)) & 3) of the 64-byte K step.
+__global__ void __launch_bounds__(64) tile_weights_kernel(const bf16_t *__restrict__ W, int N, int K, int ldw,
+                                                          bf16_t *__restrict__ Wt) {
+    const int nk = K / 32, piece = blockIdx.x, nb = piece / nk, ks = piece - nb * nk, i = threadIdx.x;
+    const int row = nb * 16 + (i >> 2), slot = (i & 3) ^ ((0 - (i >> 4)) & 3);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < N) v = *reinterpret_cast<const uint4 *>(W + (size_t)row * ldw + ks * 32 + slot * 8);
+    *reinterpret_cast<uint4 *>(Wt + (size_t)piece * 512 + i * 8) = v;
+}
 
 // 4x4 transpose across the 4 lanes of a quad (DPP quad_perm, no LDS): before,
 // lane b of the quad holds C[4*lg + r][4a + b] in v[r]; after, it holds
@@ -446,16 +461,23 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
     const int srow = lane >> 2;
     const int scol = ((lane & 3) ^ ((0 - (lane >> 4)) & 3)) * 8;   // row>>2 & 3 == lane>>4 (pieces are 16 rows)
     const bf16_t *src[PPW];
-    int dst[PPW];
+    int dst[PPW], kstride[PPW];   // elements a piece's source advances per K step
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int q = w * PPW + i;
         if (q < PA) {
             src[i] = g.A + (size_t)min(m0 + q * 16 + srow, g.M - 1) * g.lda + scol;
             dst[i] = q * 16 * BK;
+            kstride[i] = BK;
+        } else if (g.Wt) {   // fragment-major weights: the piece is 1 KiB contiguous, pre-swizzled
+            const int nblk = min((n0 + (q - PA) * 16) / 16, g.N / 16 - 1);
+            src[i] = g.Wt + (size_t)nblk * (g.K / BK) * 512 + lane * 8;
+            dst[i] = BM * BK + (q - PA) * 16 * BK;
+            kstride[i] = 512;
         } else {
             src[i] = g.W + (size_t)min(n0 + (q - PA) * 16 + srow, g.N - 1) * g.ldw + scol;
             dst[i] = BM * BK + (q - PA) * 16 * BK;
+            kstride[i] = BK;
         }
     }
     const int nk_all = g.K / BK;
@@ -464,7 +486,7 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
     auto issue = [&](int tile) {
         bf16_t *base = smem + (tile & (ST - 1)) * (BM + BN) * BK;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt0 + tile) * BK, base + dst[i]);
+        for (int i = 0; i < PPW; ++i) dma16(src[i] + (size_t)(kt0 + tile) * kstride[i], base + dst[i]);
     };
 
     f32x4 acc[WMT][WNT];
