@@ -86,6 +86,41 @@ void launch_ring_narrow(int epi, GemmArgs g, hipStream_t st) {
     MI_HIP(hipGetLastError());
 }
 
+// skinny GEMM (M <= 32, fragment-major weights): W streamed global -> registers, A slice in LDS
+template <int EPI, int WN>
+void launch_skinny_e(GemmArgs g, int wpb, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_skinny_kernel<EPI, WN>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    // K slices: as few as the LDS-resident A slice allows, more (residual epilogue only) when
+    // the N dimension alone does not give every CU a wave
+    const int waves_n = (g.N + WN * 16 - 1) / (WN * 16);
+    int ksplit = (g.K + SKINNY_KS_MAX - 1) / SKINNY_KS_MAX;
+    if (EPI == EPI_RESID && !g.bias) ksplit = std::max(ksplit, std::min(8, 1024 / std::max(1, waves_n)));
+    int kslice = ((g.K / 32 + ksplit - 1) / ksplit) * 32;
+    ksplit = (g.K + kslice - 1) / kslice;
+    g.ksplit = ksplit;
+    const int mtiles = (g.M + 15) / 16;
+    const size_t smem = (size_t)mtiles * 16 * (kslice + 8) * sizeof(bf16_t);
+    const int nblocks_n = (waves_n + wpb - 1) / wpb;
+    hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, WN>), dim3((unsigned)(nblocks_n * ksplit)), dim3(64 * wpb), smem, st,
+                       g, kslice);
+    MI_HIP(hipGetLastError());
+}
+void launch_skinny(int epi, GemmArgs g, hipStream_t st) {
+    static const int wpb_env = std::getenv("MI_SKINNY_WPB") ? atoi(std::getenv("MI_SKINNY_WPB")) : 0;
+    switch (epi) {
+        case EPI_STORE: launch_skinny_e<EPI_STORE, 1>(g, wpb_env ? wpb_env : 2, st); break;
+        case EPI_RESID: launch_skinny_e<EPI_RESID, 1>(g, wpb_env ? wpb_env : 2, st); break;
+        case EPI_QKV: launch_skinny_e<EPI_QKV, 1>(g, wpb_env ? wpb_env : 2, st); break;
+        case EPI_SWIGLU: launch_skinny_e<EPI_SWIGLU, 2>(g, wpb_env ? wpb_env : 4, st); break;
+        default: throw Error("bad epilogue");
+    }
+}
+
 template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
 void launch_ring32(int epi, GemmArgs g, hipStream_t st) {
     constexpr int BM = 32 * WMT * WAVES_M, BN = 32 * WNT * WAVES_N;
@@ -121,7 +156,13 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         if (cfg.empty()) cfg = g.M <= 64 ? "tiny" : tiles_big >= 100 ? "big" : tiles_mid >= 150 ? "mid" : "small";
         g.ksplit = 1;
         if (cfg != "tiny" || std::getenv("MI_NO_TILED_W")) g.Wt = nullptr;   // only the few-token path streams fragment-major weights
-        if (cfg == "big32" && epi != EPI_SWIGLU) {
+        const bool skinny_ok = g.Wt && g.M <= 32 && g.N % 16 == 0 && (g.K <= SKINNY_KS_MAX || (epi == EPI_RESID && !g.bias));
+        // measured per launch for one query: gate/up 14.5 vs 17.3 us (ring tiles), but QKV 10.7 vs 8.1
+        // and the residual GEMMs 13.0 vs 10.2 -- so only the SwiGLU GEMM takes it (MI_SKINNY=all/none)
+        static const std::string skinny_env = std::getenv("MI_SKINNY") ? std::getenv("MI_SKINNY") : "";
+        if (skinny_ok && cfg == "tiny" && skinny_env != "none" && (epi == EPI_SWIGLU || skinny_env == "all")) {
+            launch_skinny(epi, g, st);
+        } else if (cfg == "big32" && epi != EPI_SWIGLU) {
             launch_ring32<4, 2, 2, 4, 4>(epi, g, st);   // 256x256 on the 32x32x16 MFMA shape (experimental)
         } else if (cfg == "big" || cfg == "big32") {
             launch_ring<8, 4, 2, 4, 4>(epi, g, st);

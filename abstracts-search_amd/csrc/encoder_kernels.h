@@ -596,6 +596,137 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
 }
 
 // ---------------------------------------------------------------------
+// Skinny GEMM for a handful of tokens (M <= 32: one query, or a few) over the
+// fragment-major weight copy.  The job is weight streaming: W never touches LDS --
+// each wave reads its B fragments (16 W rows x 32 k = one contiguous 1 KiB piece of
+// Wt, 16 bytes per lane) straight into registers, UNR K steps ahead, and multiplies
+// them with the A fragments of the (at most two) 16-token tiles, which sit in LDS for
+// the whole kernel (padded rows: conflict-free ds_read_b128, read one step ahead).
+// No barrier, no DMA and no LDS traffic for W inside the K loop.  A wave owns WN
+// 16-row blocks of W (WN = 2 for SwiGLU: one gate/up pair); a workgroup is 1-4
+// independent waves; K is split over workgroups in slices of at most SKINNY_KS_MAX
+// (the A slice must fit LDS), with f32 atomics for the residual epilogue (the only
+// one that may be split).
+// ---------------------------------------------------------------------
+constexpr int SKINNY_KS_MAX = 1536;
+template <int EPI, int WN>
+__global__ void __launch_bounds__(256) gemm_bf16_skinny_kernel(GemmArgs g, int kslice) {
+    constexpr int UNR = 8;   // W fragments in flight per owned row block
+    extern __shared__ __attribute__((aligned(16))) bf16_t a_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
+    const int ks = (int)blockIdx.x % ksplit, nb = (int)blockIdx.x / ksplit;
+    const int k_lo = ks * kslice, k_hi = min(g.K, k_lo + kslice), klen = k_hi - k_lo;
+    if (klen <= 0) return;
+    const int mtiles = (g.M + 15) / 16;                  // 1 or 2
+    const int stride = klen + 8;                         // elements: one 16-byte slot of padding per row
+
+    const int n0 = (nb * (int)(blockDim.x >> 6) + w) * WN * 16;   // first W row of this wave
+    // B fragment of (row block, K step): lane (n = li, k group lg) wants W[row li][8 lg ..]; in the
+    // piece that element group sits at DMA-lane position 4 li + (lg ^ ((-(li >> 2)) & 3))
+    const int jpos = li * 4 + (lg ^ ((0 - (li >> 2)) & 3));
+    const bf16_t *wpiece[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int nblk = min(n0 / 16 + j, g.N / 16 - 1);
+        wpiece[j] = g.Wt + ((size_t)nblk * (g.K / 32) + k_lo / 32) * 512 + jpos * 8;
+    }
+    const int nkk = klen / 32;
+    bf16x8 bq[UNR][WN];
+    auto wload = [&](int kk, bf16x8(&b)[WN]) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(wpiece[j] + (size_t)kk * 512);
+    };
+    // the first UNR weight fragments are requested before anything else: their latency
+    // overlaps the staging of A
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) wload(min(u, nkk - 1), bq[u]);
+
+    // A[0 .. 16 mtiles)[k_lo .. k_hi) -> LDS (rows clamped to M - 1; coalesced 16-byte pieces,
+    // eight loads per thread in flight; unconditional stores -- a clamped index rewrites the
+    // last piece with its own data: a guarded store is a branch, and behind a branch hipcc
+    // waits vmcnt(0) per load)
+    {
+        const int slots = klen / 8, total = mtiles * 16 * slots, nthr = (int)blockDim.x;
+        for (int base = tid; base < total; base += 8 * nthr) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(base + u * nthr, total - 1), r = i / slots, c = i - r * slots;
+                v[u] = *reinterpret_cast<const uint4 *>(g.A + (size_t)min(r, g.M - 1) * g.lda + k_lo + c * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(base + u * nthr, total - 1), r = i / slots, c = i - r * slots;
+                *reinterpret_cast<uint4 *>(a_lds + r * stride + c * 8) = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    if (n0 >= g.N) return;
+    const bf16_t *arow = a_lds + li * stride + lg * 8;
+
+    f32x4 acc[2][WN];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // A fragments one step ahead of their MFMAs
+    const int a1off = mtiles > 1 ? 16 * stride : 0;
+    bf16x8 an0 = *reinterpret_cast<const bf16x8 *>(arow);
+    bf16x8 an1 = *reinterpret_cast<const bf16x8 *>(arow + a1off);
+    auto step = [&](int kk, const bf16x8(&b)[WN]) {
+        const bf16x8 a0 = an0, a1 = an1;
+        const int kn = min(kk + 1, nkk - 1);
+        an0 = *reinterpret_cast<const bf16x8 *>(arow + kn * 32);
+        an1 = *reinterpret_cast<const bf16x8 *>(arow + a1off + kn * 32);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[j], acc[0][j], 0, 0, 0);
+        if (mtiles > 1) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[j], acc[1][j], 0, 0, 0);
+        }
+    };
+    // ring of UNR fragment sets: unconditional loads in the steady state, clamped K index in the tail
+    int kk0 = 0;
+    for (; kk0 + 2 * UNR <= nkk; kk0 += UNR) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            step(kk0 + u, bq[u]);
+            wload(kk0 + u + UNR, bq[u]);
+        }
+    }
+    for (; kk0 < nkk; kk0 += UNR) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (kk0 + u < nkk) {
+                step(kk0 + u, bq[u]);
+                wload(min(kk0 + u + UNR, nkk - 1), bq[u]);
+            }
+        }
+    }
+
+    GemmArgs ge = g;
+    ge.ksplit = ksplit;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (m < mtiles) {
+            if constexpr (EPI == EPI_SWIGLU) {
+                static_assert(EPI != EPI_SWIGLU || WN == 2, "SwiGLU: a wave owns one gate/up pair");
+                store_tile<EPI>(ge, acc[m][0], acc[m][WN - 1], m * 16, n0 / 2, lane);
+            } else {
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    if (n0 + j * 16 < g.N) store_tile<EPI>(ge, acc[m][j], acc[m][j], m * 16, n0 + j * 16, lane);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------
 // Same ring pipeline on v_mfma_f32_32x32x16_bf16 (half the MFMA issue slots per
 // FLOP; microbenchmark ceiling 2.38 vs 2.08 PFLOP/s for the 16x16 shape).
 // Fragment maps: A lane l -> row l&31, k = 8*(l>>5)..+7 (+16 per k-step);
