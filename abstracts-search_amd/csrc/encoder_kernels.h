@@ -1001,6 +1001,8 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         float pmax[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) pmax[r] = -__builtin_huge_valf();
+        // masking only where it can bite: the last (partial) chunk of the sequence, or causal
+        const bool need_mask = a.causal || kc + KC > L;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int kidx = kc + j * 16 + li;
@@ -1008,7 +1010,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int qidx = q0 + w * 16 + lg * 4 + r;
                 float v = s[j][r] * scale2;   // scores in log2 units: exp2 is the native v_exp_f32
-                if (kidx >= L || (a.causal && kidx > qidx)) v = -__builtin_huge_valf();
+                if (need_mask && (kidx >= L || (a.causal && kidx > qidx))) v = -__builtin_huge_valf();
                 s[j][r] = v;
                 pmax[r] = fmaxf(pmax[r], v);
             }
