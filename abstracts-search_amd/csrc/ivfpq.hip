@@ -69,6 +69,16 @@ void launch_gemm(const float *A, int64_t na, const float *B, int64_t nb, int d, 
 void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int32_t *oi32,
                    int64_t *oi64, float *os, hipStream_t st, ProbeTables pt = ProbeTables{}, int idx_off = 0) {
     MI_REQUIRE(K >= 1, "select: K < 1");
+    // 64 < K <= 4096: threshold + bitonic sort (K = 256 of 4096: 16 us; the rank-counting path of
+    // select_kernel 55 us, its insertion path 764 us at K = 1024).  MI_SELECT_BIG_FROM moves the border.
+    const char *e = std::getenv("MI_SELECT_BIG_FROM");
+    const int big_from = e ? std::atoi(e) : 65;
+    if (K >= big_from && K <= SELB_CAP) {
+        hipLaunchKernelGGL(select_big_kernel, dim3((unsigned)rows), dim3(256), 0, st, S, ldS, n, K, oi32,
+                           oi64, os, pt, idx_off);
+        MI_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(256), 0, st, S, ldS, n, K, oi32,
                        oi64, os, pt, idx_off);
     MI_HIP(hipGetLastError());
@@ -683,7 +693,14 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     // slice) measured the same kernel time -- the slice is bound by the CU's LDS gather
     // rate, not by the number of rounds -- and costs the second co-resident workgroup
     // (3 streams: 2.7M vs 3.2M QPS), so 8 it is; MI_SCAN_NW=16 keeps the experiment.
+    // Large nprobe at a small batch is the other regime: at most one workgroup per CU and
+    // >= 128 code groups per slice.  There 16 waves (4 per SIMD) hide the gather/load
+    // latency that a second co-resident workgroup would: 254 -> 232 us at 64 x nprobe 1024.
     int scan_nw = 8;
+    {
+        const double groups_per_slice = (h->nlist > 0 ? (double)h->ngroups / h->nlist : 0.0) * nprobe / nslice;
+        if (scan_grid((int)nq, nslice) <= 256 && groups_per_slice >= 128.0) scan_nw = 16;
+    }
     if (const char *e = std::getenv("MI_SCAN_NW")) scan_nw = std::atoi(e) == 16 ? 16 : 8;
     for (int pass = 0; pass < npass; ++pass) {
         const int kp = std::min(64, k - pass * 64);

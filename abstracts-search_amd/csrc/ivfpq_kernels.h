@@ -483,6 +483,79 @@ __global__ void __launch_bounds__(256)
     emit_probe_tables(pt, blockIdx.x, K, idx + (size_t)blockIdx.x * K, wtot);
 }
 
+// Last-resort selection for any K and n: per-wave sorted lists with serial insertion, 64
+// results per pass over the row (pass p keeps the best 64 among the entries strictly after
+// the last entry of pass p-1).  Whole 256-thread workgroup; c_s / c_i: 256 LDS slots,
+// o_s / o_i: 64.  Slow (one pass over the row per 64 results): only rows with more tied
+// scores than the threshold paths have survivor slots end up here.
+__device__ __noinline__ void select_by_insertion(const float *__restrict__ r, int n, int K, int64_t row,
+                                                 int32_t *__restrict__ out_i32, int64_t *__restrict__ out_i64,
+                                                 float *__restrict__ out_s, int idx_off, float *c_s, int *c_i,
+                                                 float *o_s, int *o_i) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = uniform_i(tid >> 6);
+    float *m_s = c_s;
+    int *m_i = c_i;
+    bool has_bound = false;
+    float bs = 0.f;
+    int bi = 0;
+    for (int p0 = 0; p0 < K; p0 += 64) {
+        const int kp = min(64, K - p0);
+        float ls = MI_NEG_INF, thr = MI_NEG_INF;
+        int li = INT_MAX;
+        for (int base = w * 64; base < n; base += 256) {
+            int c = base + lane;
+            bool valid = c < n;
+            float s = valid ? r[c] : 0.f;
+            bool pf = valid && (s >= thr);
+            if (has_bound) pf = pf && (s < bs || (s == bs && c > bi));
+            unsigned long long mask = __ballot(pf);
+            while (mask) {
+                int src = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                float cs = readlane_f(s, src);
+                if (!(cs >= thr)) continue;
+                wave_insert_i32(ls, li, lane, kp, cs, base + src);
+                thr = readlane_f(ls, kp - 1);
+            }
+        }
+        m_s[tid] = ls;
+        m_i[tid] = li;
+        if (tid < 64) {
+            o_s[tid] = MI_NEG_INF;
+            o_i[tid] = INT_MAX;
+        }
+        __syncthreads();
+        if (lane < kp && li != INT_MAX) {
+            int rank = 0;
+            for (int ww = 0; ww < 4; ++ww)
+#pragma unroll 8
+                for (int j = 0; j < kp; ++j) {
+                    float js = m_s[ww * 64 + j];
+                    int ji = m_i[ww * 64 + j];
+                    rank += (js > ls) || (js == ls && ji < li);
+                }
+            if (rank < kp) {
+                o_s[rank] = ls;
+                o_i[rank] = li;
+            }
+        }
+        __syncthreads();
+        if (tid < kp) {
+            int oi = o_i[tid];
+            float os = o_s[tid];
+            size_t o = (size_t)row * K + p0 + tid;
+            if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi + idx_off;
+            if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi + idx_off;
+            if (out_s) out_s[o] = oi == INT_MAX ? -FLT_MAX : os;
+        }
+        has_bound = true;
+        bs = o_s[kp - 1];
+        bi = o_i[kp - 1];
+        __syncthreads();
+    }
+}
+
 constexpr int SEL_CAP = 1024;  // survivor slots of the fast path
 
 __global__ void __launch_bounds__(256)
@@ -498,7 +571,6 @@ __global__ void __launch_bounds__(256)
     __shared__ int wtot[4];
     __shared__ int c_cnt;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = uniform_i(tid >> 6);
     const int64_t row = blockIdx.x;
     const float *r = S + row * ldS;
 
@@ -656,71 +728,154 @@ __global__ void __launch_bounds__(256)
         }
     }
 
-    // ---- general path (K > 256, or a pathological row with > SEL_CAP ties):
-    // per-wave sorted lists with serial insertion, 64 results per pass.
-    if (!done) {
-        float *m_s = c_s;
-        int *m_i = c_i;
-        bool has_bound = false;
-        float bs = 0.f;
-        int bi = 0;
-        for (int p0 = 0; p0 < K; p0 += 64) {
-            const int kp = min(64, K - p0);
-            float ls = MI_NEG_INF, thr = MI_NEG_INF;
-            int li = INT_MAX;
-            for (int base = w * 64; base < n; base += 256) {
-                int c = base + lane;
-                bool valid = c < n;
-                float s = valid ? r[c] : 0.f;
-                bool pf = valid && (s >= thr);
-                if (has_bound) pf = pf && (s < bs || (s == bs && c > bi));
-                unsigned long long mask = __ballot(pf);
-                while (mask) {
-                    int src = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    float cs = readlane_f(s, src);
-                    if (!(cs >= thr)) continue;
-                    wave_insert_i32(ls, li, lane, kp, cs, base + src);
-                    thr = readlane_f(ls, kp - 1);
+    // ---- K > 256 reaches this kernel only through select_big_kernel's overflow; a
+    // pathological row with > SEL_CAP tied survivors falls through to here as well.
+    if (!done) select_by_insertion(r, n, K, row, out_i32, out_i64, out_s, idx_off, c_s, c_i, o_s, o_i);
+    if (pt.list_goff && !tables_done) emit_probe_tables(pt, row, K, out_i32 + (size_t)row * K, wtot);
+}
+
+// ---------------------------------------------------------------------
+// Best K of each row for 256 < K <= SELB_CAP (large nprobe: the recall >= 0.95 operating
+// points probe a quarter of the lists; flat search with a large k).  Same contract as
+// select_kernel, one 256-thread workgroup per row, three steps:
+//   1. one pass over the row keeps 16 maxima per thread (thread t, slot j: the elements
+//      c = t + 256 (j + 16 i)): 4096 group maxima -- the elements themselves when
+//      n <= 4096, which then stay in registers;
+//   2. the K-th largest of the 4096 maxima by a bitwise descent on order-preserving keys
+//      (per step: 16 ballots per wave, one LDS word per wave, one barrier).  Any K distinct
+//      elements bound the K-th largest element from below, so everything under it is
+//      dropped by one compare (exact for n <= 4096; ~K(1 + 1/7) survivors at K = 1024 of
+//      65536);
+//   3. survivors become 64-bit keys (score key << 32 | ~column: descending order = score
+//      desc, column asc) and are sorted by a bitonic network in LDS; the first K leave.
+// More than SELB_CAP survivors (masses of tied scores): select_by_insertion.
+// ---------------------------------------------------------------------
+constexpr int SELB_CAP = 4096;
+
+__global__ void __launch_bounds__(256)
+    select_big_kernel(const float *__restrict__ S, int64_t ldS, int n, int K, int32_t *__restrict__ out_i32,
+                      int64_t *__restrict__ out_i64, float *__restrict__ out_s, ProbeTables pt, int idx_off) {
+    __shared__ unsigned long long skey[SELB_CAP];   // survivors; afterwards the selection (int32)
+    __shared__ int wcnt[2][4];
+    __shared__ int wtot[4];
+    __shared__ int c_cnt;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = uniform_i(tid >> 6);
+    const int64_t row = blockIdx.x;
+    const float *r = S + row * ldS;
+    constexpr int VPT = 16, TILE = 256 * VPT;
+    const bool one_tile = n <= TILE;
+    unsigned key[VPT];
+    auto load_tile = [&](int base) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int c = base + j * 256 + tid;
+            const float v = r[min(c, n - 1)];
+            key[j] = (c < n && v == v) ? f2o(v) : 0u;
+        }
+    };
+    unsigned gm[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) gm[j] = 0u;
+    for (int base = 0; base < n; base += TILE) {
+        load_tile(base);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) gm[j] = max(gm[j], key[j]);
+    }
+    if (tid == 0) c_cnt = 0;
+    // K-th largest group maximum (0 when fewer than K groups hold anything: keep all)
+    unsigned T0 = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned t = T0 | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) c += __popcll(__ballot(gm[j] >= t));
+        if (lane == 0) wcnt[bit & 1][w] = c;
+        __syncthreads();
+        c = wcnt[bit & 1][0] + wcnt[bit & 1][1] + wcnt[bit & 1][2] + wcnt[bit & 1][3];
+        if (c >= K) T0 = t;
+        if (c == K) break;
+    }
+    for (int base = 0; base < n; base += TILE) {
+        if (!one_tile) load_tile(base);
+        unsigned long long m[VPT];
+        int tot = 0;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            m[j] = __ballot(key[j] != 0u && key[j] >= T0);
+            tot += __popcll(m[j]);
+        }
+        if (tot) {
+            int o = 0;
+            if (lane == 0) o = atomicAdd(&c_cnt, tot);
+            o = uniform_i(o);
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                if (m[j]) {
+                    const int pos = o + lane_prefix_count(m[j]);
+                    if (((m[j] >> lane) & 1ull) && pos < SELB_CAP)
+                        skey[pos] = ((unsigned long long)key[j] << 32) | (unsigned)~(unsigned)(base + j * 256 + tid);
+                    o += __popcll(m[j]);
                 }
             }
-            m_s[tid] = ls;
-            m_i[tid] = li;
-            if (tid < 64) {
-                o_s[tid] = MI_NEG_INF;
-                o_i[tid] = INT_MAX;
-            }
-            __syncthreads();
-            if (lane < kp && li != INT_MAX) {
-                int rank = 0;
-                for (int ww = 0; ww < 4; ++ww)
-#pragma unroll 8
-                    for (int j = 0; j < kp; ++j) {
-                        float js = m_s[ww * 64 + j];
-                        int ji = m_i[ww * 64 + j];
-                        rank += (js > ls) || (js == ls && ji < li);
-                    }
-                if (rank < kp) {
-                    o_s[rank] = ls;
-                    o_i[rank] = li;
-                }
-            }
-            __syncthreads();
-            if (tid < kp) {
-                int oi = o_i[tid];
-                float os = o_s[tid];
-                size_t o = (size_t)row * K + p0 + tid;
-                if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi + idx_off;
-                if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi + idx_off;
-                if (out_s) out_s[o] = oi == INT_MAX ? -FLT_MAX : os;
-            }
-            has_bound = true;
-            bs = o_s[kp - 1];
-            bi = o_i[kp - 1];
-            __syncthreads();
         }
     }
-    if (pt.list_goff && !tables_done) emit_probe_tables(pt, row, K, out_i32 + (size_t)row * K, wtot);
+    __syncthreads();
+    const int Sn = c_cnt;
+    if (Sn > SELB_CAP) {   // wave-uniform, workgroup-uniform
+        __syncthreads();
+        float *f = reinterpret_cast<float *>(skey);
+        select_by_insertion(r, n, K, row, out_i32, out_i64, out_s, idx_off, f, reinterpret_cast<int *>(f + 256),
+                            f + 512, reinterpret_cast<int *>(f + 768));
+        if (pt.list_goff) emit_probe_tables(pt, row, K, out_i32 + (size_t)row * K, wtot);
+        return;
+    }
+    int P = 64;
+    while (P < Sn) P <<= 1;
+    for (int e = Sn + tid; e < P; e += 256) skey[e] = 0ull;   // below every survivor (their score key is never 0)
+    __syncthreads();
+    // bitonic network, descending
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < (P >> 1); i += 256) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int hi = lo | j;
+                const unsigned long long a = skey[lo], b = skey[hi];
+                const bool desc = (lo & k2) == 0;
+                if ((a < b) == desc) {
+                    skey[lo] = b;
+                    skey[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    // results (K <= 4096: at most 16 per thread, through registers so that the selection can
+    // take the place of the keys)
+    constexpr int RPT = SELB_CAP / 256;
+    unsigned long long res[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int e = tid + i * 256;
+        res[i] = (e < K && e < Sn) ? skey[e] : 0ull;
+    }
+    __syncthreads();
+    int32_t *sel = reinterpret_cast<int32_t *>(skey);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int e = tid + i * 256;
+        if (e < K) {
+            const bool filled = res[i] != 0ull;
+            const int col = (int)~(unsigned)res[i];
+            const int si = filled ? col + idx_off : -1;
+            const size_t o = (size_t)row * K + e;
+            if (out_i32) out_i32[o] = si;
+            if (out_i64) out_i64[o] = (int64_t)si;
+            if (out_s) out_s[o] = filled ? o2f((unsigned)(res[i] >> 32)) : -FLT_MAX;
+            sel[e] = si;
+        }
+    }
+    __syncthreads();
+    if (pt.list_goff) emit_probe_tables(pt, row, K, sel, wtot);
 }
 
 template <int DSUB>

@@ -5,7 +5,8 @@ through ``sidecar-search index train|fill|tune`` (reference Makefile:39,
 Makefile:25, Makefile:32) and its query-time ``app.py`` (reference
 README.md:28): ``index_factory``, ``IndexIVFPQ.{train,add,add_with_ids,search,
 reset}``, ``nprobe``, ``ntotal``, ``is_trained``, ``IndexFlatIP``,
-``write_index`` / ``read_index`` (own container format), ``ParameterSpace``.
+``write_index`` / ``read_index`` (faiss's file format), ``ParameterSpace`` /
+``OperatingPoints`` / ``IntersectionCriterion`` (autotune.py: the `tune` step).
 
 Everything numeric happens in HIP kernels behind the C ABI of
 ``include/mi_ivfpq.h``; this file only checks arguments, moves pointers and
@@ -24,6 +25,8 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 import numpy as np
 
 from . import _native, faiss_io
+from .autotune import (AutoTuneCriterion, IntersectionCriterion, OneRecallAtRCriterion,  # noqa: F401
+                       OperatingPoint, OperatingPoints, ParameterRange, ParameterSpace)
 
 METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
@@ -570,21 +573,6 @@ def extract_index_ivf(index):
 
 def downcast_index(index):
     return index
-
-
-class ParameterSpace:
-    """faiss.ParameterSpace subset (what an autotune sweep sets)."""
-
-    def set_index_parameter(self, index, name: str, value):
-        if name != "nprobe":
-            raise ValueError(f"unknown parameter {name!r}")
-        index.nprobe = int(value)
-
-    def set_index_parameters(self, index, description: str):
-        for tok in description.split(","):
-            if tok:
-                k, v = tok.split("=")
-                self.set_index_parameter(index, k, float(v))
 
 
 _MAGIC = "mi355x-ivfpq-v1"

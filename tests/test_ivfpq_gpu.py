@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path (through the C ABI) vs the oracle, bit-exact
 for codes / indices / f32 scores, on golden fixtures, seeded random indexes
 and edge cases."""
+import importlib
 import os
 
 import numpy as np
@@ -176,6 +177,53 @@ def test_refine_flat_matches_oracle(faiss, oracle):
     assert isinstance(f, faiss.IndexRefineFlat) and f.base_index.nlist == 64
 
 
+def test_autotune_on_the_hip_index(faiss, oracle, tmp_path):
+    """The `tune` step (reference Makefile:32) over the real index: every experiment is a
+    search on the HIP path; each reported recall equals the oracle's result scored the same
+    way, the front is a Pareto front, and the written params reproduce the chosen point."""
+    at = importlib.import_module("abstracts_search_amd.autotune")
+    d, M, nlist, n, nq, k = 64, 8, 32, 12000, 64, 10
+    cent, cb, x, q = random_problem(11, d, M, nlist, n, nq)
+    idx = faiss.IndexRefineFlat(make_index(faiss, cent, cb))
+    idx.add(x)
+    _, gt = oracle.flat_ip(q, x, k)
+    ln, codes = oracle.encode(x, cent, cb, True)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(n), nlist)
+    ps = faiss.ParameterSpace()
+    ps.initialize(idx)
+    assert [pr.name for pr in ps.parameter_ranges] == ["k_factor_rf", "nprobe"]
+    ps.parameter_ranges[0].values = [1.0, 4.0]
+    ps.parameter_ranges[1].values = [1.0, 4.0, 16.0]
+    ps.n_experiments = 0
+    ps.verbose = 0
+    crit = faiss.IntersectionCriterion(nq, k)
+    crit.set_groundtruth(None, gt)
+    ops = ps.explore(idx, q, crit)
+    assert len(ops.all_pts) == 6
+    for p in ops.all_pts:
+        kf, nprobe = (int(float(t.split("=")[1])) for t in p.key.split(","))
+        _, cand = oracle.search(q, cent, cb, off, lc, li, nprobe, k * kf, True)
+        _, Ie = oracle.rerank(q, x, cand, k)
+        assert p.perf == crit.evaluate(None, Ie), p
+    by_key = {p.key: p.perf for p in ops.all_pts}
+    assert by_key["k_factor_rf=4,nprobe=16"] >= by_key["k_factor_rf=1,nprobe=1"]
+    front = ops.optimal_pts
+    assert all(a.perf < b.perf and a.t < b.t for a, b in zip(front, front[1:]))
+    doc = at.write_params(str(tmp_path / "params.json"), ops, min_perf=front[-1].perf)
+    idx.nprobe, idx.k_factor = 1, 1.0
+    at.read_params(str(tmp_path / "params.json"), idx)
+    assert crit.evaluate(*idx.search(q, k)) == doc["perf"] == front[-1].perf
+    # torch queries take the device path; same recalls
+    import torch
+    ops_t = ps.explore(idx, torch.from_numpy(q).cuda(), crit)
+    assert [p.perf for p in ops_t.all_pts] == [p.perf for p in ops.all_pts]
+    # a plain IVF-PQ index only exposes nprobe
+    ps.initialize(idx.base_index)
+    assert [pr.name for pr in ps.parameter_ranges] == ["nprobe"] and ps.n_combinations() == 5
+    with pytest.raises(ValueError):
+        ps.set_index_parameter(idx.base_index, "k_factor_rf", 2)
+
+
 def test_lut_matches_oracle(faiss, oracle):
     cent, cb, x, q = random_problem(3, 1024, 64, 8, 64, 9)
     idx = make_index(faiss, cent, cb)
@@ -241,30 +289,45 @@ def test_large_k_multipass(faiss, oracle):
     assert cI.shape == (12, 8)
 
 
-def test_select_paths(faiss, oracle):
-    """flat search exercises select_kernel: threshold fast path (K <= 256), the
-    insertion path (K > 256) and the tie-overflow fallback (> 1024 equal scores)."""
+@pytest.mark.parametrize("big_from", [None, "257", "100000"])
+def test_select_paths(faiss, oracle, monkeypatch, big_from):
+    """flat search exercises the selection kernels: select_kernel's threshold paths
+    (K <= 64; K <= 256 with MI_SELECT_BIG_FROM=257), select_big_kernel (threshold + bitonic
+    sort, 64 < K <= 4096), the insertion path (K > 4096, or everything above 256 with
+    MI_SELECT_BIG_FROM=100000) and the tie-overflow fallbacks (more equal scores than
+    survivor slots)."""
+    if big_from:
+        monkeypatch.setenv("MI_SELECT_BIG_FROM", big_from)
     rng = np.random.default_rng(77)
     d = 32
     base = rng.standard_normal((5000, d)).astype(np.float32)
     q = rng.standard_normal((9, d)).astype(np.float32)
     flat = faiss.IndexFlatIP(d)
     flat.add(base)
-    for k in (1, 10, 64, 200, 256, 257, 300, 1000):
+    for k in (1, 10, 64, 65, 200, 256, 257, 300, 1000, 1024):
         D, I = flat.search(q, k)
         De, Ie = oracle.flat_ip(q, base, k)
         assert np.array_equal(I, Ie), k
         assert np.array_equal(bits(D), bits(De)), k
-    # 3000 identical vectors + a few distinct ones: every score ties
-    dup = np.repeat(base[:1], 3000, axis=0)
+    # 6000 identical vectors + a few distinct ones: every score ties
+    dup = np.repeat(base[:1], 6000, axis=0)
     dup = np.concatenate([dup, base[1:40]])
     flat2 = faiss.IndexFlatIP(d)
     flat2.add(dup)
-    for k in (5, 100, 300):
+    for k in (5, 100, 300, 1024):
         D, I = flat2.search(q, k)
         De, Ie = oracle.flat_ip(q, dup, k)
         assert np.array_equal(I, Ie), k
         assert np.array_equal(bits(D), bits(De)), k
+    # the coarse quantiser takes K = nprobe up to nlist: 5000 centroids (two row tiles)
+    cent = base
+    cb = rng.standard_normal((4, 256, d // 4)).astype(np.float32)
+    idx = make_index(faiss, cent, cb)
+    for nprobe in (65, 512, 2048, 4096, 4097, 5000):
+        cI, cD, _ = idx.coarse_and_lut(q, nprobe, want_lut=False)
+        De, Ie = oracle.flat_ip(q, cent, nprobe)
+        assert np.array_equal(cI, Ie), nprobe
+        assert np.array_equal(bits(cD), bits(De)), nprobe
     # fewer rows than k, NaN-free tiny inputs
     flat3 = faiss.IndexFlatIP(d)
     flat3.add(base[:7])
