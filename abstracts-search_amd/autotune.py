@@ -290,6 +290,9 @@ class ParameterSpace:
             import torch
             sync = torch.cuda.synchronize
             sync()
+        index.search(xq[:bs], crit.nnn)       # untimed: first-use allocations of this (k, nprobe)
+        if sync:
+            sync()
         nrun = 0
         t0 = time.perf_counter()
         while True:

@@ -929,6 +929,20 @@ int mi_flat_add(mi_flat *h, int64_t n, const float *x) {
     });
 }
 
+int mi_flat_reserve(mi_flat *h, int64_t n) {
+    return guard([&] {
+        MI_REQUIRE(h && n >= 0, "bad argument");
+        DeviceGuard dg(h->device);
+        const size_t want = (size_t)n * h->d * 4, old_bytes = (size_t)h->ntotal * h->d * 4;
+        if (want <= h->base.cap) return;
+        DevBuf nb;
+        nb.reserve(want);
+        if (old_bytes) MI_HIP(hipMemcpy(nb.p, h->base.p, old_bytes, hipMemcpyDeviceToDevice));
+        std::swap(nb.p, h->base.p);
+        std::swap(nb.cap, h->base.cap);
+    });
+}
+
 int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t *cand_I, int k, float *D,
                    int64_t *I, void *stream) {
     return guard([&] {

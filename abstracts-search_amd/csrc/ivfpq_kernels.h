@@ -1606,15 +1606,59 @@ __global__ void __launch_bounds__(256)
             o_id[j] = EMPTY_ID;
         }
     }
+    // Ranking by counting is O(n^2): with many candidates (re-ranking 64 x k exact scores,
+    // 32 slices x 64) first drop everything below the k-th largest score -- a bitwise
+    // descent on order-preserving keys, ballots only -- and compact the survivors (k plus
+    // ties) to the front, in place (an entry only ever moves down, and every lane has read
+    // its entry before any lane writes).  Re-ranking 640 candidates per query (cfg4 shard,
+    // k_factor 64): whole search 3.24 -> 2.95 ms per 1024 queries.
+    int S = n;
+    if (live && n > 64) {
+        auto keyof = [&](int e) -> unsigned { return (e < n && e_id[e] != EMPTY_ID) ? f2o(e_s[e]) : 0u; };
+        unsigned T = 0;
+        if (n <= 1024) {
+            unsigned kk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kk[i] = keyof(i * 64 + lane);
+            T = wave_kth_largest_n<16>(kk, k);
+        } else {
+            int nz = 0;
+            for (int e0 = 0; e0 < n; e0 += 64) nz += __popcll(__ballot(keyof(e0 + lane) != 0u));
+            if (nz >= k)
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned t = T | (1u << bit);
+                    int c = 0;
+                    for (int e0 = 0; e0 < n; e0 += 64) c += __popcll(__ballot(keyof(e0 + lane) >= t));
+                    if (c >= k) T = t;
+                    if (c == k) break;
+                }
+        }
+        int cnt = 0;
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            const int e = e0 + lane;
+            const bool in = e < n;
+            const float es = in ? e_s[e] : 0.f;
+            const int64_t ei = in ? e_id[e] : EMPTY_ID;
+            const bool keep = ei != EMPTY_ID && f2o(es) >= T;
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int pos = cnt + lane_prefix_count(m);
+                e_s[pos] = es;
+                e_id[pos] = ei;
+            }
+            cnt += __popcll(m);
+        }
+        S = cnt;
+    }
     __syncthreads();
     if (live) {
-        for (int e = lane; e < n; e += 64) {
+        for (int e = lane; e < S; e += 64) {
             const int64_t mi_ = e_id[e];
             if (mi_ == EMPTY_ID) continue;
             const float ms = e_s[e];
             int rank = 0;
 #pragma unroll 8
-            for (int j = 0; j < n; ++j) {
+            for (int j = 0; j < S; ++j) {
                 float js = e_s[j];
                 int64_t ji = e_id[j];
                 rank += (js > ms) || (js == ms && (ji < mi_ || (ji == mi_ && j < e)));

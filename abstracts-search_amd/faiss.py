@@ -70,6 +70,7 @@ class _Lib:
                 "mi_flat_create": [c_int, c_int, POINTER(v)],
                 "mi_flat_destroy": [v],
                 "mi_flat_add": [v, c_int64, v],
+                "mi_flat_reserve": [v, c_int64],
                 "mi_flat_ntotal": [v, POINTER(c_int64)],
                 "mi_flat_reset": [v],
                 "mi_flat_search": [v, c_int64, v, c_int, v, v, v],
@@ -169,6 +170,11 @@ class IndexFlatIP:
     def add(self, x):
         x = _as_f32(x, self.d)
         _check(_Lib.get().mi_flat_add(self._h, x.shape[0], _ptr(x)))
+
+    def reserve(self, n: int):
+        """Room for n vectors in total (not in faiss's Python API; its C++ callers reserve the
+        codes vector): a store filled in chunks then never holds two copies while growing."""
+        _check(_Lib.get().mi_flat_reserve(self._h, int(n)))
 
     def reset(self):
         _check(_Lib.get().mi_flat_reset(self._h))

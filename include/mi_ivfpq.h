@@ -134,6 +134,9 @@ int mi_merge_topk(int device, int nparts, int64_t nq, int k, const float *D_part
 int mi_flat_create(int d, int device, mi_flat **out);
 int mi_flat_destroy(mi_flat *h);
 int mi_flat_add(mi_flat *h, int64_t n, const float *x);
+/* Capacity hint (std::vector::reserve on faiss's IndexFlat::codes): room for n vectors in
+ * total, so that a 100 GB store filled in chunks never holds two copies while growing. */
+int mi_flat_reserve(mi_flat *h, int64_t n);
 int mi_flat_ntotal(mi_flat *h, int64_t *out);
 int mi_flat_reset(mi_flat *h);
 int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int64_t *I,

@@ -172,7 +172,7 @@ def test_explore_exhaustive_and_pruned():
     ps.batchsize = 16
     ops = ps.explore(ivf, q, crit)
     assert [p.cno for p in ops.all_pts] == list(range(5))
-    assert ivf.calls[:2] == [(1, 16), (1, 14)]                         # batched, every query once
+    assert ivf.calls[:3] == [(1, 16), (1, 16), (1, 14)]                # a warm-up batch, then every query once
     perf = [p.perf for p in ops.all_pts]
     assert perf == sorted(perf) and perf[-1] > perf[0]                  # more probes never hurt here
     # every reported perf is reproducible by setting the key

@@ -24,7 +24,7 @@ q = synth.queries_cuda(x, nq, seed=4321)
 gt = torch.cat([idx.refine_index.search(q[i:i + 256], k)[1] for i in range(0, nq, 256)])
 ps = faiss.ParameterSpace()
 ps.initialize(idx)
-ps.parameter_ranges[0].values = [1.0, 2.0, 4.0, 8.0, 16.0]            # k_factor_rf
+ps.parameter_ranges[0].values = [1.0, 2.0, 4.0, 6.0, 8.0, 16.0]       # k_factor_rf (k_base > 64: two scan passes)
 ps.parameter_ranges[1].values = [float(1 << i) for i in range(3, 11)]  # nprobe 8 .. 1024
 ps.batchsize = batch
 ps.min_test_duration = 0.05
