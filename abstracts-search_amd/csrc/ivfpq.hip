@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <utility>
 #include <vector>
@@ -137,24 +138,27 @@ void launch_pq_encode(const float *x, int64_t n, int d, int M, const float *cb, 
     MI_HIP(hipGetLastError());
 }
 
-template <int M, int NW>
+template <int M, int NW, bool ALL>
 void launch_scan_mw(const ScanArgs &a, hipStream_t st) {
     const size_t smem = scan_smem_bytes(M, a.nprobe, NW);
     MI_REQUIRE(smem <= 160 * 1024, "nprobe too large for the LDS probe tables");
     static bool attr_set = false;
     if (!attr_set) {
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<M, NW>),
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<M, NW, ALL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((scan_kernel<M, NW>), dim3(scan_grid(a.nq, a.nslice)), dim3(NW * 64), smem,
+    hipLaunchKernelGGL((scan_kernel<M, NW, ALL>), dim3(scan_grid(a.nq, a.nslice)), dim3(NW * 64), smem,
                        st, a);
     MI_HIP(hipGetLastError());
 }
 template <int M>
 void launch_scan_m(const ScanArgs &a, hipStream_t st) {
-    if (a.nw == 16) launch_scan_mw<M, 16>(a, st);
-    else launch_scan_mw<M, 8>(a, st);
+    if (a.all_s) {
+        if (a.nw == 16) launch_scan_mw<M, 16, true>(a, st);
+        else launch_scan_mw<M, 8, true>(a, st);
+    } else if (a.nw == 16) launch_scan_mw<M, 16, false>(a, st);
+    else launch_scan_mw<M, 8, false>(a, st);
 }
 
 bool scan_supports_M(int M) {
@@ -207,7 +211,7 @@ const void *to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t 
 
 // per-stream search workspaces (see mi_index::ws_sets)
 struct SearchWS {
-    DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters;
+    DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters, all_s, all_id;
     size_t counters_zeroed = 0;  // bytes of `counters` known to be zero
     // most recent scan launch on this stream (mi_index_profile_scan replays it)
     ScanArgs last_scan{};
@@ -236,6 +240,9 @@ struct mi_index {
     // device image (group-interleaved, see ivfpq_kernels.h)
     DevBuf d_codes, d_ids, d_goff, d_len;
     int64_t ngroups = 0;
+    // code groups of the cap_nprobe longest lists (row capacity of the all-scores path)
+    int cap_nprobe = -1;
+    int64_t cap_groups = 0;
     // search workspaces: one set per stream the index is searched on, so that
     // batches issued on different streams overlap on the GPU (a serving loop
     // round-robins 2-4 streams; each kernel of one batch leaves most CUs idle)
@@ -286,6 +293,7 @@ void sync_lists(mi_index *h) {
     }
     goff[nlist] = (int32_t)g;
     h->ngroups = g;
+    h->cap_nprobe = -1;
     const size_t gbytes = (size_t)NCH * 1024;
     std::vector<uint8_t> codes((size_t)std::max<int64_t>(g, 1) * gbytes, 0);
     std::vector<int64_t> ids((size_t)std::max<int64_t>(g, 1) * 64, -1);
@@ -702,9 +710,50 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         if (scan_grid((int)nq, nslice) <= 256 && groups_per_slice >= 128.0) scan_nw = 16;
     }
     if (const char *e = std::getenv("MI_SCAN_NW")) scan_nw = std::atoi(e) == 16 ? 16 : 8;
+    if (npass > 1 && !std::getenv("MI_NO_ALLSCORES")) {
+        // k > 64: one pass over the codes that stores every (score, id) of the probed lists,
+        // then the k best of each row (select_pairs_kernel) -- instead of one scan per 64
+        // results.  Row capacity = the groups of the nprobe longest lists; queries go in
+        // sub-batches so that the rows stay under 2 GiB.
+        if (h->cap_nprobe != nprobe) {
+            std::vector<int64_t> g((size_t)h->nlist);
+            for (int l = 0; l < h->nlist; ++l) g[(size_t)l] = ((int64_t)h->h_ids[(size_t)l].size() + 63) / 64;
+            std::nth_element(g.begin(), g.begin() + (nprobe - 1), g.end(), std::greater<int64_t>());
+            int64_t tot = 0;
+            for (int i = 0; i < nprobe; ++i) tot += g[(size_t)i];
+            h->cap_groups = std::max<int64_t>(tot, 1);
+            h->cap_nprobe = nprobe;
+        }
+        const int64_t R = h->cap_groups * 64;
+        const int64_t qc = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (R * 12)));
+        float *all_s = w.all_s.as<float>((size_t)(qc * R));
+        int64_t *all_id = w.all_id.as<int64_t>((size_t)(qc * R));
+        for (int64_t c0 = 0; c0 < nq; c0 += qc) {
+            const int64_t m = std::min(qc, nq - c0);
+            ScanArgs a{};
+            a.lut = lut + (size_t)c0 * M * 256; a.coarse_dis = cdis + (size_t)c0 * nprobe;
+            a.p_goff = pt.p_goff + (size_t)c0 * nprobe; a.p_len = pt.p_len + (size_t)c0 * nprobe;
+            a.p_prefix = pt.p_prefix + (size_t)c0 * (nprobe + 1);
+            a.codes = h->d_codes.get<uint8_t>(); a.ids = h->d_ids.get<int64_t>();
+            a.nq = (int)m; a.nprobe = nprobe; a.nslice = choose_nslice(h, m, nprobe); a.k = 64;
+            a.by_residual = h->by_residual;
+            a.nw = 8;
+            {
+                const double groups_per_slice = (h->nlist > 0 ? (double)h->ngroups / h->nlist : 0.0) * nprobe / a.nslice;
+                if (scan_grid((int)m, a.nslice) <= 256 && groups_per_slice >= 128.0) a.nw = 16;
+            }
+            if (const char *e = std::getenv("MI_SCAN_NW")) a.nw = std::atoi(e) == 16 ? 16 : 8;
+            a.all_s = all_s; a.all_id = all_id; a.all_ld = R;
+            launch_scan(M, a, st);
+            hipLaunchKernelGGL(select_pairs_kernel, dim3((unsigned)m), dim3(256), 0, st, all_s, all_id, R,
+                               a.p_prefix, nprobe, k, Ddev + (size_t)c0 * k, Idev + (size_t)c0 * k, (int64_t)k);
+            MI_HIP(hipGetLastError());
+        }
+        return;
+    }
     for (int pass = 0; pass < npass; ++pass) {
         const int kp = std::min(64, k - pass * 64);
-        ScanArgs a;
+        ScanArgs a{};
         a.lut = lut; a.coarse_dis = cdis;
         a.p_goff = pt.p_goff; a.p_len = pt.p_len; a.p_prefix = pt.p_prefix;
         a.codes = h->d_codes.get<uint8_t>(); a.ids = h->d_ids.get<int64_t>();

@@ -419,8 +419,8 @@ __device__ __forceinline__ void wave_insert_i32(float &ls, int &li, int lane, in
 
 // ---------------------------------------------------------------------
 // Best K entries of each row of S under (score desc, column asc); one
-// 256-thread workgroup per row.  K > 64 is extracted 64 at a time: pass p
-// keeps the best 64 among entries strictly after the last entry of pass p-1.
+// 256-thread workgroup per row.  Threshold paths for K <= 64 and K <= 256 (the host
+// sends 64 < K <= 4096 to select_big_kernel); anything else: select_by_insertion.
 // Unfilled: index -1, score -FLT_MAX.  out_i32 / out_i64 / out_s may be null.
 // With list tables (coarse quantiser of a search): also emits, per row, the
 // probe tables the scan kernel walks -- first group and length of every
@@ -878,6 +878,188 @@ __global__ void __launch_bounds__(256)
     if (pt.list_goff) emit_probe_tables(pt, row, K, sel, wtot);
 }
 
+// ---------------------------------------------------------------------
+// Best K (score desc, id asc) of each row of (score, id) pairs -- the rows
+// scan_kernel<.., ALL> stores when k > 64: row q holds p_prefix[q][nprobe] * 64 pairs,
+// NaN scores are padding.  One pass over the codes instead of one per 64 results.
+// select_big_kernel's scheme (4096 group maxima -> K-th largest by block-wide descent ->
+// survivors -> bitonic sort) on (score key, id) keys; the ids of the survivors only are
+// fetched.  More survivors than slots (masses of tied scores) take the exact route: the
+// K-th largest score key T by a descent over the whole row, then -- if the entries
+// tied at T still do not fit -- the id of the last tied entry to keep by a descent over
+// the id bits; exactly K entries survive.
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    select_pairs_kernel(const float *__restrict__ S, const int64_t *__restrict__ IDS, int64_t ld,
+                        const int32_t *__restrict__ p_prefix, int nprobe, int K, float *__restrict__ D,
+                        int64_t *__restrict__ I, int64_t ldo) {
+    __shared__ unsigned sk[SELB_CAP];
+    __shared__ int64_t sid[SELB_CAP];
+    __shared__ int wcnt[2][4];
+    __shared__ int c_cnt, c_eq;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = uniform_i(tid >> 6);
+    const int64_t row = blockIdx.x;
+    const int n = p_prefix[row * (nprobe + 1) + nprobe] * 64;
+    const float *r = S + row * ld;
+    const int64_t *ids = IDS + row * ld;
+    constexpr int VPT = 16, TILE = 256 * VPT;
+    const bool one_tile = n <= TILE;
+    unsigned key[VPT];
+    auto load_tile = [&](int base) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int c = base + j * 256 + tid;
+            const float v = r[min(c, max(n - 1, 0))];
+            key[j] = (c < n && v == v) ? f2o(v) : 0u;
+        }
+    };
+    unsigned gm[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) gm[j] = 0u;
+    for (int base = 0; base < n; base += TILE) {
+        load_tile(base);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) gm[j] = max(gm[j], key[j]);
+    }
+    if (tid == 0) {
+        c_cnt = 0;
+        c_eq = 0;
+    }
+    int ph = 0;
+    auto block_sum = [&](int wave_total) -> int {   // one barrier; alternating slots
+        if (lane == 0) wcnt[ph][w] = wave_total;
+        __syncthreads();
+        const int c = wcnt[ph][0] + wcnt[ph][1] + wcnt[ph][2] + wcnt[ph][3];
+        ph ^= 1;
+        return c;
+    };
+    unsigned T0 = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned t = T0 | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) c += __popcll(__ballot(gm[j] >= t));
+        c = block_sum(c);
+        if (c >= K) T0 = t;
+        if (c == K) break;
+    }
+    // survivors of `keep(key, column)` into sk / sid
+    auto compact = [&](auto keep) {
+        for (int base = 0; base < n; base += TILE) {
+            if (!one_tile) load_tile(base);
+            unsigned long long m[VPT];
+            int tot = 0;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                m[j] = __ballot(key[j] != 0u && keep(key[j], base + j * 256 + tid));
+                tot += __popcll(m[j]);
+            }
+            if (tot) {
+                int o = 0;
+                if (lane == 0) o = atomicAdd(&c_cnt, tot);
+                o = uniform_i(o);
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    if (m[j]) {
+                        const int pos = o + lane_prefix_count(m[j]);
+                        if (((m[j] >> lane) & 1ull) && pos < SELB_CAP) {
+                            sk[pos] = key[j];
+                            sid[pos] = ids[base + j * 256 + tid];
+                        }
+                        o += __popcll(m[j]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+    compact([&](unsigned kx, int) { return kx >= T0; });
+    int Sn = c_cnt;
+    if (Sn > SELB_CAP) {   // workgroup-uniform
+        // exact route: counts over the whole row, streamed (rare: masses of tied scores)
+        auto count_row = [&](auto pred) -> int {
+            int c = 0;
+            for (int base = 0; base < n; base += 256) {
+                const int col = base + tid;
+                bool p = false;
+                if (col < n) {
+                    const float v = r[col];
+                    const unsigned kx = v == v ? f2o(v) : 0u;
+                    p = kx != 0u && pred(kx, col);
+                }
+                c += __popcll(__ballot(p));
+            }
+            return block_sum(c);
+        };
+        unsigned T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned t = T | (1u << bit);
+            const int c = count_row([&](unsigned kx, int) { return kx >= t; });
+            if (c >= K) T = t;
+            if (c == K) break;
+        }
+        const int cgt = count_row([&](unsigned kx, int) { return kx > T; });
+        const int ceq = count_row([&](unsigned kx, int) { return kx == T; });
+        if (tid == 0) c_cnt = 0;
+        __syncthreads();
+        if (cgt + ceq <= SELB_CAP) {
+            compact([&](unsigned kx, int) { return kx >= T; });
+        } else {
+            // the (K - cgt)-th smallest id among the entries tied at T: the largest U with
+            // fewer than that many tied ids below it
+            const int need = K - cgt;
+            int64_t U = 0;
+            for (int bit = 62; bit >= 0; --bit) {
+                const int64_t t = U | ((int64_t)1 << bit);
+                const int c = count_row([&](unsigned kx, int col) { return kx == T && ids[col] < t; });
+                if (c < need) U = t;
+            }
+            const int below = count_row([&](unsigned kx, int col) { return kx == T && ids[col] < U; });
+            const int take_eq = need - below;   // entries with id == U to keep (duplicated ids)
+            compact([&](unsigned kx, int col) {
+                if (kx > T) return true;
+                if (kx != T) return false;
+                const int64_t id = ids[col];
+                if (id < U) return true;
+                if (id > U) return false;
+                return atomicAdd(&c_eq, 1) < take_eq;
+            });
+        }
+        Sn = c_cnt;   // <= SELB_CAP now
+    }
+    int P = 64;
+    while (P < Sn) P <<= 1;
+    for (int e = Sn + tid; e < P; e += 256) {
+        sk[e] = 0u;   // after every survivor
+        sid[e] = INT64_MAX;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < (P >> 1); i += 256) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int hi = lo | j;
+                const unsigned ka = sk[lo], kb = sk[hi];
+                const int64_t ia = sid[lo], ib = sid[hi];
+                const bool b_first = kb > ka || (kb == ka && ib < ia);   // entry hi ranks before entry lo
+                const bool desc = (lo & k2) == 0;
+                if (b_first == desc && !(ka == kb && ia == ib)) {
+                    sk[lo] = kb;
+                    sid[lo] = ib;
+                    sk[hi] = ka;
+                    sid[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    for (int e = tid; e < K; e += 256) {
+        const bool filled = e < Sn && sk[e] != 0u;
+        D[row * ldo + e] = filled ? o2f(sk[e]) : -FLT_MAX;
+        I[row * ldo + e] = filled ? sid[e] : (int64_t)-1;
+    }
+}
+
 template <int DSUB>
 __global__ void __launch_bounds__(256) lut_kernel(LutArgs a) {
     lut_block<DSUB>(a, blockIdx.x);
@@ -936,6 +1118,12 @@ struct ScanArgs {
     int64_t *next_bound_id;
     int64_t ldo;
     int out_off;
+    // all-scores mode (scan_kernel<M, NW, true>; k > 64): no selection, every (score, id) of
+    // the probed lists is stored at [q][group_in_query * 64 + lane] (score NaN in the padding
+    // lanes of a list's last group) for select_pairs_kernel
+    float *all_s;              // [nq][all_ld]
+    int64_t *all_id;           // [nq][all_ld]
+    int64_t all_ld;
 };
 
 // LDS bytes the fused final merge needs inside the LUT region
@@ -1056,7 +1244,7 @@ __device__ __forceinline__ void wave_compress(float *buf_s, int64_t *buf_id, int
     thr = (cnt >= k && T != 0u) ? o2f(T) : MI_NEG_INF;
 }
 
-template <int M, int NW>
+template <int M, int NW, bool ALL = false>
 __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 waves per SIMD = two 512-thread workgroups per CU
     constexpr int NCH = (M + 15) / 16;
     constexpr int SCAN_NW = NW, NT = NW * 64;
@@ -1246,6 +1434,12 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
             }
         }
         const float s = g.dis0 + acc;
+        if constexpr (ALL) {
+            const size_t o = (size_t)q * a.all_ld + (size_t)t * 64 + lane;   // t: this group's index in the query
+            a.all_s[o] = lane < g.nvalid ? s : __builtin_nanf("");
+            a.all_id[o] = g.id;
+            return;
+        }
         if (n_proc == 0) stamp(13);
         if (n_proc == 1) stamp(17);
         if (n_proc == 2) stamp(18);
@@ -1299,6 +1493,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         t += SCAN_NW;
     }
 
+    if constexpr (ALL) return;
     stamp(4);
     const bool va = lane < cnt, vb = lane + 64 < cnt;
     const float sa = va ? buf_s[lane] : 0.f, sb = vb ? buf_s[lane + 64] : 0.f;

@@ -266,25 +266,65 @@ def test_gemm_awkward_shapes_bit_exact(faiss, oracle):
                 assert np.array_equal(bits(D), bits(De)), (d, nb, na)
 
 
-def test_large_k_multipass(faiss, oracle):
+@pytest.mark.parametrize("multipass", [False, True])
+def test_large_k(faiss, oracle, monkeypatch, multipass):
+    """k > 64: one scan that stores every (score, id) + select_pairs_kernel (default), or one
+    extraction pass per 64 results (MI_NO_ALLSCORES=1); both equal the oracle bit for bit."""
+    if multipass:
+        monkeypatch.setenv("MI_NO_ALLSCORES", "1")
     cent, cb, x, q = random_problem(21, 64, 8, 8, 4000, 12)
     idx = make_index(faiss, cent, cb)
     idx.add(x)
     ln, codes = oracle.encode(x, cent, cb)
     off, lc, li = oracle.build_lists(ln, codes, np.arange(len(x)), 8)
-    for k, nprobe in ((65, 8), (200, 3), (1000, 8)):
+    for k, nprobe in ((65, 8), (200, 3), (1000, 8), (1024, 1)):
         idx.nprobe = nprobe
         D, I = idx.search(q, k)
         De, Ie = oracle.search(q, cent, cb, off, lc, li, nprobe, k)
         assert np.array_equal(I, Ie), k
         assert np.array_equal(bits(D), bits(De)), k
+    # rows longer than one tile (> 4096 pairs per query), ragged lists, more lists than probes
+    cent, cb, x, q = random_problem(22, 32, 4, 40, 30000, 9)
+    idx = make_index(faiss, cent, cb)
+    ids = np.random.default_rng(5).permutation(1 << 20)[:len(x)].astype(np.int64)
+    idx.add_with_ids(x, ids)
+    ln, codes = oracle.encode(x, cent, cb)
+    off, lc, li = oracle.build_lists(ln, codes, ids, 40)
+    for k, nprobe in ((100, 17), (640, 40), (70, 1)):
+        idx.nprobe = nprobe
+        D, I = idx.search(q, k)
+        De, Ie = oracle.search(q, cent, cb, off, lc, li, nprobe, k)
+        assert np.array_equal(I, Ie), (k, nprobe)
+        assert np.array_equal(bits(D), bits(De)), (k, nprobe)
+    # masses of tied scores: 7000 copies of one vector (one list, identical codes) next to
+    # 500 others, first with distinct ids (the cut falls inside the tie: lowest ids win),
+    # then with every id used twice
+    rng = np.random.default_rng(6)
+    cent, cb, x, q = random_problem(23, 32, 4, 4, 500, 6)
+    x = np.concatenate([np.repeat(x[:1], 7000, axis=0), x])
+    q[0] = x[0]
+    id_sets = [rng.permutation(1 << 16)[:len(x)].astype(np.int64)]
+    if not multipass:   # extraction passes continue "strictly after (score, id)": identical pairs would be skipped
+        id_sets.append((np.arange(len(x)) // 2).astype(np.int64))
+    for ids in id_sets:
+        idx = make_index(faiss, cent, cb)
+        idx.add_with_ids(x, ids)
+        ln, codes = oracle.encode(x, cent, cb)
+        off, lc, li = oracle.build_lists(ln, codes, ids, 4)
+        for k in (65, 300, 1024):
+            idx.nprobe = 4
+            D, I = idx.search(q, k)
+            De, Ie = oracle.search(q, cent, cb, off, lc, li, 4, k)
+            assert np.array_equal(I, Ie), k
+            assert np.array_equal(bits(D), bits(De)), k
     # flat index / coarse quantiser with K > 64
+    cent, cb, x, q = random_problem(21, 64, 8, 8, 4000, 12)
     flat = faiss.IndexFlatIP(64)
     flat.add(x)
     D, I = flat.search(q, 130)
     De, Ie = oracle.flat_ip(q, x, 130)
     assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De))
-    idx.nprobe = 8
+    idx = make_index(faiss, cent, cb)
     cI, cD, _ = idx.coarse_and_lut(q, 8, want_lut=False)
     assert cI.shape == (12, 8)
 
