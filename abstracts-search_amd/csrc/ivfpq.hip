@@ -724,7 +724,12 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
             h->cap_groups = std::max<int64_t>(tot, 1);
             h->cap_nprobe = nprobe;
         }
-        const int64_t R = h->cap_groups * 64;
+        int64_t R = h->cap_groups * 64;
+        if (pre_I) {   // caller-assigned lists may repeat: nprobe times the longest list
+            int64_t gmax = 1;
+            for (int l = 0; l < h->nlist; ++l) gmax = std::max(gmax, ((int64_t)h->h_ids[(size_t)l].size() + 63) / 64);
+            R = gmax * nprobe * 64;
+        }
         const int64_t qc = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (R * 12)));
         float *all_s = w.all_s.as<float>((size_t)(qc * R));
         int64_t *all_id = w.all_id.as<int64_t>((size_t)(qc * R));

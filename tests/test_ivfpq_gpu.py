@@ -492,6 +492,14 @@ def test_coarse_slices_and_search_preassigned(faiss, oracle):
     De, Ie = oracle.search_preassigned(q, cb, off, lc, li, cI2, cDe, k)
     Dp, Ip = idx.search_preassigned(qd, k, torch.from_numpy(cI2).cuda(), torch.from_numpy(cDe).cuda())
     assert np.array_equal(Ip.cpu().numpy(), Ie) and np.array_equal(bits(Dp.cpu().numpy()), bits(De))
+    # k > 64 with a caller's assignment that names the longest list in every probe slot
+    # (rows longer than the nprobe longest distinct lists: the all-pairs buffers must hold them)
+    longest = int(np.argmax(np.diff(off)))
+    cI3 = np.full_like(cIe, longest)
+    cI3[:, 0] = cIe[:, 0]
+    De, Ie = oracle.search_preassigned(q, cb, off, lc, li, cI3, cDe, 200)
+    Dp, Ip = idx.search_preassigned(qd, 200, torch.from_numpy(cI3).cuda(), torch.from_numpy(cDe).cuda())
+    assert np.array_equal(Ip.cpu().numpy(), Ie) and np.array_equal(bits(Dp.cpu().numpy()), bits(De))
 
 
 @pytest.mark.parametrize("kind", ["faiss", "faiss-ondisk", "npz"])
