@@ -808,7 +808,7 @@ int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe, 
                     void *stream) {
     return guard([&] {
         MI_REQUIRE(h && (nq == 0 || (q && D && I)), "null argument");
-        MI_REQUIRE(k >= 1 && k <= 1024, "k must be in [1, 1024]");
+        MI_REQUIRE(k >= 1 && k <= 4096, "k must be in [1, 4096]");
         MI_REQUIRE(nprobe >= 1, "nprobe must be >= 1");
         require_trained(h);
         if (nq == 0) return;
@@ -889,7 +889,7 @@ int mi_index_search_preassigned(mi_index *h, int64_t nq, const float *q, int k, 
                                 void *stream) {
     return guard([&] {
         MI_REQUIRE(h && (nq == 0 || (q && D && I && coarse_I && coarse_D)), "null argument");
-        MI_REQUIRE(k >= 1 && k <= 1024, "k must be in [1, 1024]");
+        MI_REQUIRE(k >= 1 && k <= 4096, "k must be in [1, 4096]");
         MI_REQUIRE(nprobe >= 1, "nprobe must be >= 1");
         require_trained(h);
         if (nq == 0) return;
@@ -1060,7 +1060,7 @@ int mi_flat_reset(mi_flat *h) {
 int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int64_t *I, void *stream) {
     return guard([&] {
         MI_REQUIRE(h && (nq == 0 || (q && D && I)), "null argument");
-        MI_REQUIRE(k >= 1 && k <= 1024, "k must be in [1, 1024]");
+        MI_REQUIRE(k >= 1 && k <= 4096, "k must be in [1, 4096]");
         if (nq == 0) return;
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);

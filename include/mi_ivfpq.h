@@ -86,7 +86,7 @@ int mi_index_list_size(mi_index *h, int list_no, int64_t *out);
 int mi_index_get_list(mi_index *h, int list_no, uint8_t *codes_host, int64_t *ids_host);
 
 /* IndexIVFPQ.search with index.nprobe = nprobe.
- * q float32 [nq][d]; D float32 [nq][k]; I int64 [nq][k].  1 <= k <= 1024. */
+ * q float32 [nq][d]; D float32 [nq][k]; I int64 [nq][k].  1 <= k <= 4096. */
 int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe,
                     float *D, int64_t *I, void *stream);
 

@@ -277,7 +277,7 @@ def test_large_k(faiss, oracle, monkeypatch, multipass):
     idx.add(x)
     ln, codes = oracle.encode(x, cent, cb)
     off, lc, li = oracle.build_lists(ln, codes, np.arange(len(x)), 8)
-    for k, nprobe in ((65, 8), (200, 3), (1000, 8), (1024, 1)):
+    for k, nprobe in ((65, 8), (200, 3), (1000, 8), (1024, 1), (2000, 8), (4096, 8)):
         idx.nprobe = nprobe
         D, I = idx.search(q, k)
         De, Ie = oracle.search(q, cent, cb, off, lc, li, nprobe, k)
@@ -344,7 +344,7 @@ def test_select_paths(faiss, oracle, monkeypatch, big_from):
     q = rng.standard_normal((9, d)).astype(np.float32)
     flat = faiss.IndexFlatIP(d)
     flat.add(base)
-    for k in (1, 10, 64, 65, 200, 256, 257, 300, 1000, 1024):
+    for k in (1, 10, 64, 65, 200, 256, 257, 300, 1000, 1024, 2500, 4096):
         D, I = flat.search(q, k)
         De, Ie = oracle.flat_ip(q, base, k)
         assert np.array_equal(I, Ie), k
