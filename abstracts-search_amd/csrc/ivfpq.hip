@@ -5,6 +5,7 @@
 #include "../../include/mi_ivfpq.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -82,6 +83,23 @@ void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int3
     }
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(256), 0, st, S, ldS, n, K, oi32,
                        oi64, os, pt, idx_off);
+    MI_HIP(hipGetLastError());
+}
+
+void launch_to_f16(const float *x, int64_t n, f16_t *y, hipStream_t st) {
+    MI_REQUIRE(n % 4 == 0, "to_f16: length must be a multiple of 4");
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(to_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, n4, y);
+    MI_HIP(hipGetLastError());
+}
+
+void launch_gemm_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int K, float *S, int64_t ldS,
+                     hipStream_t st) {
+    MI_REQUIRE(K % 64 == 0 && ldS % 4 == 0, "f16 gemm: K % 64 and ldS % 4");
+    const int tiles_m = (int)((na + 127) / 128), tiles_n = (int)((nb + 127) / 128);
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL(ip_gemm_f16_kernel, dim3((unsigned)(per * 8)), dim3(256), 0, st, A, (int)na, B, (int)nb, K, S,
+                       ldS, tiles_m, tiles_n);
     MI_HIP(hipGetLastError());
 }
 
@@ -211,7 +229,7 @@ const void *to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t 
 
 // per-stream search workspaces (see mi_index::ws_sets)
 struct SearchWS {
-    DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters, all_s, all_id;
+    DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters, all_s, all_id, q16, rstats;
     size_t counters_zeroed = 0;  // bytes of `counters` known to be zero
     // most recent scan launch on this stream (mi_index_profile_scan replays it)
     ScanArgs last_scan{};
@@ -232,6 +250,10 @@ struct mi_index {
     int d = 0, nlist = 0, M = 0, dsub = 0, metric = 0, by_residual = 1, device = 0;
     bool has_coarse = false, has_codebook = false;
     DevBuf centroids, codebook;
+    // two-stage coarse quantiser: f16 copy of the centroids, their largest norm
+    DevBuf cent16, cmax_dev;
+    float cmax = 0.f;
+    bool cent16_ok = false;
     // master copy of the inverted lists (insertion order, row-major codes)
     std::vector<std::vector<uint8_t>> h_codes;
     std::vector<std::vector<int64_t>> h_ids;
@@ -402,6 +424,7 @@ int mi_index_set_coarse(mi_index *h, const float *centroids) {
         size_t bytes = (size_t)h->nlist * h->d * sizeof(float);
         MI_HIP(hipMemcpy(h->centroids.reserve(bytes), centroids, bytes, hipMemcpyDefault));
         h->has_coarse = true;
+        h->cent16_ok = false;
     });
 }
 
@@ -675,12 +698,62 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, w.side);
         MI_HIP(hipEventRecord(w.ev_join, w.side));
     }
+    // Large batches: f16 MFMA scores + exact re-scoring of the few centroids within a proven
+    // error margin of the cut (bit-identical result, see select_refine_kernel) instead of the
+    // exact f32 GEMM over all of them.  MI_TWO_STAGE=0 / 1 forces it off / on.
+    bool two_stage = nq >= 256 && h->nlist >= 8192 && (int64_t)nq * h->nlist >= ((int64_t)1 << 24) && nprobe <= 128;
+    if (const char *e = std::getenv("MI_TWO_STAGE")) two_stage = std::atoi(e) != 0;
+    two_stage = two_stage && h->d % 128 == 0 && h->d <= 4096 && h->nlist % 4 == 0 && nprobe <= 1024;
+    if (two_stage) {
+        if (!h->cent16_ok) {
+            const int64_t ne = (int64_t)h->nlist * h->d;
+            launch_to_f16(h->centroids.get<float>(), ne, static_cast<f16_t *>(h->cent16.reserve((size_t)ne * 2)), st);
+            unsigned *cm = static_cast<unsigned *>(h->cmax_dev.reserve(4));
+            MI_HIP(hipMemsetAsync(cm, 0, 4, st));
+            hipLaunchKernelGGL(max_row_norm_kernel, dim3((unsigned)((h->nlist + 3) / 4)), dim3(256), 0, st,
+                               h->centroids.get<float>(), h->nlist, h->d, cm);
+            MI_HIP(hipGetLastError());
+            unsigned bits = 0;
+            MI_HIP(hipMemcpyAsync(&bits, cm, 4, hipMemcpyDeviceToHost, st));
+            MI_HIP(hipStreamSynchronize(st));
+            std::memcpy(&h->cmax, &bits, 4);
+            h->cent16_ok = true;
+        }
+        f16_t *q16 = static_cast<f16_t *>(w.q16.reserve((size_t)nq * h->d * 2));
+        launch_to_f16(qdev, (int64_t)nq * h->d, q16, st);
+        launch_gemm_f16(q16, nq, static_cast<const f16_t *>(h->cent16.p), h->nlist, h->d, scores, h->nlist, st);
+        RefineArgs ra{};
+        ra.q = qdev; ra.cent = h->centroids.get<float>(); ra.Sa = scores; ra.ldS = h->nlist;
+        ra.n = h->nlist; ra.d = h->d; ra.K = nprobe;
+        ra.eps_rel = 0x1p-10f * 1.001f + (float)h->d * (0x1p-22f + 0x1p-24f);
+        ra.eps_abs = 0x1p-25f * std::sqrt((float)h->d) * 1.01f;
+        ra.cmax = h->cmax;
+        ra.out_i32 = cidx; ra.out_s = cdis; ra.pt = pt;
+        if (const char *e = std::getenv("MI_REFINE_DEBUG")) ra.debug = std::atoi(e);
+        const bool want_stats = std::getenv("MI_REFINE_STATS") != nullptr;
+        if (want_stats) {
+            ra.stats = static_cast<unsigned *>(w.rstats.reserve(8));
+            MI_HIP(hipMemsetAsync(ra.stats, 0, 8, st));
+        }
+        hipLaunchKernelGGL(select_refine_kernel, dim3((unsigned)nq), dim3(256), 0, st, ra);
+        MI_HIP(hipGetLastError());
+        if (want_stats) {
+            unsigned hs[2] = {0, 0};
+            MI_HIP(hipMemcpyAsync(hs, ra.stats, 8, hipMemcpyDeviceToHost, st));
+            MI_HIP(hipStreamSynchronize(st));
+            std::fprintf(stderr, "two-stage coarse: %lld rows, nprobe %d: %.2f candidates per row, %u exact-fallback rows\n",
+                         (long long)nq, nprobe, (double)hs[0] / (double)nq, hs[1]);
+        }
+        if (fork) MI_HIP(hipStreamWaitEvent(st, w.ev_join, 0));
+        else launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
+    } else {
     const bool lut_in_gemm = !fork && (h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && !std::getenv("MI_NO_LUT_FUSION");
     launch_gemm(qdev, nq, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st,
                 lut_in_gemm ? make_lut_args(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut) : LutArgs{});
     launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st, pt);
     if (fork) MI_HIP(hipStreamWaitEvent(st, w.ev_join, 0));
     else if (!lut_in_gemm) launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
+    }
     }
     if (cI_out) MI_HIP(hipMemcpyAsync(cI_out, cidx, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (cD_out) MI_HIP(hipMemcpyAsync(cD_out, cdis, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));

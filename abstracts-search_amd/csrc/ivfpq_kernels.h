@@ -347,8 +347,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
                     if (t + 1 < nk) read_ops((u + 1) & 1, opa[(u + 1) & 1], opb[(u + 1) & 1]);
                     if (t + 2 < nk) sstore(u & 1, ra[(u + 2) % PF], rb[(u + 2) % PF]);
                     if (t + PF < nk) gload((t + PF) * BK, ra[u], rb[u], false);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma_chunk(opa[u & 1], opb[u & 1]);
+                            mma_chunk(opa[u & 1], opb[u & 1]);
                 }
             }
         }
@@ -1058,6 +1057,422 @@ __global__ void __launch_bounds__(256)
         D[row * ldo + e] = filled ? o2f(sk[e]) : -FLT_MAX;
         I[row * ldo + e] = filled ? sid[e] : (int64_t)-1;
     }
+}
+
+// =====================================================================
+// Two-stage coarse quantiser for large batches (1024 queries x 65536 centroids: the exact
+// f32 GEMM is 1.03 ms of a 1.43 ms search step).  Stage 1: f16 MFMA GEMM, approximate
+// scores.  Stage 2 (select_refine_kernel): every centroid whose approximate score is
+// within 2 eps of the K-th best approximate score, eps a proven bound on |approx - exact|,
+// gets its exact score (the f32 fmaf chain, k ascending -- what the f32 MFMA GEMM and the
+// oracle compute) and the K best of those under (exact score desc, index asc) are the
+// result: bit-identical to the one-stage path, because the exact top K all lie inside the
+// candidate set:  exact_c >= exact_(K) >= approx_(K) - eps  =>  approx_c >= approx_(K) - 2 eps.
+// eps = eps_rel * |q| * max|c| + eps_abs * (|q| + max|c|)  (Cauchy-Schwarz on sum |q_i c_i|):
+//   f16 rounding of both operands 2 * 2^-11 (+ 2^-22), subnormal spacing 2^-25 per element,
+//   f32 accumulation of d exact f16 x f16 products d * 2^-22 (generous for any summation
+//   order), the exact chain's own rounding d * 2^-24.
+// =====================================================================
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ void __launch_bounds__(256) to_f16_kernel(const float *__restrict__ x, int64_t n4, f16_t *__restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4 *>(x)[i];
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 o = {(f16_t)v.x, (f16_t)v.y, (f16_t)v.z, (f16_t)v.w};
+    reinterpret_cast<h4 *>(y)[i] = o;
+}
+
+// largest row norm of x [n][d] -> *out (float bits; non-negative floats order like ints)
+__global__ void __launch_bounds__(256) max_row_norm_kernel(const float *__restrict__ x, int n, int d, unsigned *__restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float acc = 0.f;
+    for (int k = lane; k < d; k += 64) {
+        const float v = x[(size_t)row * d + k];
+        acc = __builtin_fmaf(v, v, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    // round up generously: the bound only has to be an upper bound
+    if (lane == 0) atomicMax(out, __float_as_uint(sqrtf(acc) * 1.0001f));
+}
+
+__device__ __forceinline__ float ivf_dpp_quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float ivf_dpp_quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+}
+// 4x4 transpose across a lane quad: before, lane b of the quad holds C[4 lg + r][4a + b] in
+// v[r]; after, C[4 lg + b][4a + c] in v[c] (four consecutive columns: one 16-byte store)
+__device__ __forceinline__ f32x4 ivf_quad_transpose(f32x4 v, int lane) {
+    const bool odd = lane & 1, hi = lane & 2;
+    float r0 = ivf_dpp_quad_xor1(odd ? v[0] : v[1]);
+    float r1 = ivf_dpp_quad_xor1(odd ? v[2] : v[3]);
+    if (odd) { v[0] = r0; v[2] = r1; } else { v[1] = r0; v[3] = r1; }
+    r0 = ivf_dpp_quad_xor2(hi ? v[0] : v[2]);
+    r1 = ivf_dpp_quad_xor2(hi ? v[1] : v[3]);
+    if (hi) { v[0] = r0; v[1] = r1; } else { v[2] = r0; v[3] = r1; }
+    return v;
+}
+
+// S[na][nb] ~= A[na][K] . B[nb][K]^T, f16 operands, f32 accumulate (v_mfma_f32_16x16x32_f16).
+// 128 x 128 x 64 tiles, 4 waves of 64 x 64, two LDS stages filled by LDS-DMA (128-byte rows,
+// 16-byte slots XOR-swizzled by row & 7).  Tile order: every XCD walks a contiguous eighth
+// of a sequence in which 8 M tiles share one B strip (its L2 holds the strip and all of A).
+// K % 64 == 0, ldS % 4 == 0; rows are clamped, stores guarded.
+__global__ void __launch_bounds__(256)
+    ip_gemm_f16_kernel(const f16_t *__restrict__ A, int na, const f16_t *__restrict__ B, int nb, int K,
+                       float *__restrict__ S, int64_t ldS, int tiles_m, int tiles_n) {
+    constexpr int BM = 128, BN = 128, BK = 64, GM = 8;
+    __shared__ __attribute__((aligned(16))) f16_t smem[2 * (BM + BN) * BK];   // 64 KiB
+    f16_t *As = smem, *Bs = smem + 2 * BM * BK;
+    int tm, tn;
+    {
+        const int ntiles = tiles_m * tiles_n, bid = (int)blockIdx.x, per = (ntiles + 7) / 8;
+        const int t = (bid & 7) * per + (bid >> 3);
+        if (t >= ntiles || (bid >> 3) >= per) return;
+        const int group = t / (GM * tiles_n), within = t - group * (GM * tiles_n);
+        const int gm = min(GM, tiles_m - group * GM);
+        tn = within / gm;
+        tm = group * GM + (within - tn * gm);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = uniform_i(tid >> 6);
+    const int wm = w & 1, wn = w >> 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int srow = lane >> 3, scol = ((lane & 7) ^ srow) * 8;
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r0 = (w * 4 + i) * 8;
+            const int ra = min(m0 + r0 + srow, na - 1), rb = min(n0 + r0 + srow, nb - 1);
+            dma16_lds(A + (size_t)ra * K + k0 + scol, As + buf * BM * BK + r0 * BK);
+            dma16_lds(B + (size_t)rb * K + k0 + scol, Bs + buf * BN * BK + r0 * BK);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+        const f16_t *ab = As + (kt & 1) * BM * BK + (wm * 64 + li) * BK;
+        const f16_t *bb = Bs + (kt & 1) * BN * BK + (wn * 64 + li) * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int slot = ((kk * 4 + lg) ^ (li & 7)) * 8;
+            f16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f16x8 *>(ab + i * 16 * BK + slot);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f16x8 *>(bb + j * 16 * BK + slot);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // lane: rows (lane >> 4) * 4 + r of column lane & 15 -> after the quad transpose,
+            // row (lane >> 4) * 4 + (lane & 3), columns (lane & 12) .. + 3
+            const f32x4 v = ivf_quad_transpose(acc[i][j], lane);
+            const int row = m0 + wm * 64 + i * 16 + lg * 4 + (lane & 3);
+            const int col = n0 + wn * 64 + j * 16 + (li & ~3);
+            if (row < na) {
+                float *o = S + (size_t)row * ldS + col;
+                if (col + 3 < nb) *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int c = 0; c < 4; ++c)
+                        if (col + c < nb) o[c] = v[c];
+            }
+        }
+}
+
+// Stage 2: one 256-thread workgroup per query row of approximate scores Sa [rows][ldS].
+//   cut = (K-th largest of 4096 group maxima of the approximate row) - 2 eps;
+//   candidates = columns with approximate score >= cut;
+//   exact score of each candidate: fmaf chain over d, k ascending (one lane per candidate,
+//     the query row in LDS), = the f32 MFMA GEMM's value for that pair;
+//   bitonic sort on (exact score key << 32 | ~column), first K out + the probe tables.
+// A row with more than SELB_CAP candidates (or non-finite approximate scores: f16 overflow)
+// is recomputed exactly in full -- slow, but only degenerate data gets there -- and selected
+// with a zero margin.  Same outputs as select_kernel / select_big_kernel.
+struct RefineArgs {
+    const float *q;       // [rows][d]  f32 queries
+    const float *cent;    // [n][d]     f32 centroids
+    float *Sa;            // [rows][ldS] approximate scores (overwritten by exact ones on the fallback)
+    int64_t ldS;
+    int n, d, K;
+    float eps_rel, eps_abs, cmax;
+    int32_t *out_i32;     // [rows][K]
+    float *out_s;         // [rows][K]
+    ProbeTables pt;
+    unsigned *stats;      // null, or [2]: total candidates, rows that fell back
+    int debug;            // timing experiments: 1 = no exact chain
+};
+
+__global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
+    __shared__ unsigned long long skey[SELB_CAP];
+    __shared__ float qs[4096];          // the query row (d <= 4096)
+    __shared__ int wcnt[2][4];
+    __shared__ float wred[4];
+    __shared__ int wtot[4];
+    __shared__ int c_cnt;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = uniform_i(tid >> 6);
+    const int64_t row = blockIdx.x;
+    const int n = a.n, d = a.d, K = a.K;
+    float *r = a.Sa + row * a.ldS;
+    const float *qg = a.q + row * d;
+    // query row -> LDS, its norm
+    float nrm = 0.f;
+    for (int k = tid; k < d; k += 256) {
+        const float v = qg[k];
+        qs[k] = v;
+        nrm = __builtin_fmaf(v, v, nrm);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor(nrm, off);
+    if (lane == 0) wred[w] = nrm;
+    if (tid == 0) c_cnt = 0;
+    __syncthreads();
+    const float qn = sqrtf(wred[0] + wred[1] + wred[2] + wred[3]) * 1.0001f;
+    float margin = 2.f * (a.eps_rel * qn * a.cmax + a.eps_abs * (qn + a.cmax));
+    bool bad = !(margin < 3.0e38f);   // NaN / inf query
+    auto exact = [&](int col) -> float {
+        // d % 128 == 0 (host).  The centroid row is streamed through two register sets of
+        // 16 x 16 B, named (not copied: a copy would make hipcc wait for the newest loads), so
+        // the loads of one set are in flight while the chain -- d dependent fmafs -- runs on
+        // the other.
+        const float4 *cp = reinterpret_cast<const float4 *>(a.cent + (size_t)col * d);
+        const int n4 = d >> 2;
+        float4 A[16], B[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) A[i] = cp[i];
+        float acc = 0.f;
+        for (int k4 = 0; k4 < n4; k4 += 32) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) B[i] = cp[k4 + 16 + i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float4 qv = *reinterpret_cast<const float4 *>(qs + 4 * (k4 + i));
+                acc = __builtin_fmaf(qv.x, A[i].x, acc);
+                acc = __builtin_fmaf(qv.y, A[i].y, acc);
+                acc = __builtin_fmaf(qv.z, A[i].z, acc);
+                acc = __builtin_fmaf(qv.w, A[i].w, acc);
+            }
+            const int nx = min(k4 + 32, n4 - 16);   // last round: a harmless re-read
+#pragma unroll
+            for (int i = 0; i < 16; ++i) A[i] = cp[nx + i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float4 qv = *reinterpret_cast<const float4 *>(qs + 4 * (k4 + 16 + i));
+                acc = __builtin_fmaf(qv.x, B[i].x, acc);
+                acc = __builtin_fmaf(qv.y, B[i].y, acc);
+                acc = __builtin_fmaf(qv.z, B[i].z, acc);
+                acc = __builtin_fmaf(qv.w, B[i].w, acc);
+            }
+        }
+        return acc;
+    };
+    constexpr int VPT = 16, TILE = 256 * VPT;
+    int ph = 0;
+    auto block_sum = [&](int wave_total) -> int {
+        if (lane == 0) wcnt[ph][w] = wave_total;
+        __syncthreads();
+        const int c = wcnt[ph][0] + wcnt[ph][1] + wcnt[ph][2] + wcnt[ph][3];
+        ph ^= 1;
+        return c;
+    };
+    bool exact_row = false;
+    int Sn = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        unsigned key[VPT];
+        unsigned gm[VPT];
+        int nonfinite = 0;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) gm[j] = 0u;
+        for (int base = 0; base < n; base += TILE) {
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                const int c = base + j * 256 + tid;
+                const float v = r[min(c, n - 1)];
+                // approximate rows must be finite (else: exact fallback); exact rows follow
+                // select_kernel: NaN never survives, +-inf are ordinary scores
+                const bool fin = exact_row ? (v == v) : (fabsf(v) <= 3.0e38f);
+                nonfinite |= (c < n && !fin);
+                key[j] = (c < n && fin) ? f2o(v) : 0u;
+                gm[j] = max(gm[j], key[j]);
+            }
+        }
+        if (!exact_row && block_sum(__popcll(__ballot(nonfinite != 0))) > 0) bad = true;
+        unsigned T0 = 0;
+        if (K <= 256) {
+            // barrier-free, as in select_kernel: 1024 maxima (4 per thread) in LDS, every wave
+            // descends over all of them (K <= 16: over their 64 column maxima -- any K
+            // distinct entries bound the K-th largest from below)
+            unsigned *gk = reinterpret_cast<unsigned *>(skey);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                gk[g * 256 + tid] = max(max(gm[g], gm[g + 4]), max(gm[g + 8], gm[g + 12]));
+            __syncthreads();
+            unsigned kk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kk[i] = gk[i * 64 + ((lane + 4 * i) & 63)];
+            if (K <= 16) {
+                unsigned f = 0u;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) f = max(f, kk[i]);
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned t = T0 | (1u << bit);
+                    const int c = __popcll(__ballot(f >= t));
+                    if (c >= K) T0 = t;
+                    if (c == K) break;
+                }
+            } else {
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned t = T0 | (1u << bit);
+                    int c = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) c += __popcll(__ballot(kk[i] >= t));
+                    if (c >= K) T0 = t;
+                    if (c == K) break;
+                }
+            }
+            __syncthreads();   // skey is reused for the candidates
+        } else {
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned t = T0 | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) c += __popcll(__ballot(gm[j] >= t));
+                c = block_sum(c);
+                if (c >= K) T0 = t;
+                if (c == K) break;
+            }
+        }
+        // cut in the score domain; T0 == 0: fewer than K finite entries, keep all
+        const float cut = T0 ? o2f(T0) - (exact_row ? 0.f : margin) : -__builtin_inff();
+        if (!bad || exact_row) {
+            for (int base = 0; base < n; base += TILE) {
+                unsigned long long m[VPT];
+                float sv[VPT];
+                int tot = 0;
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    const int c = base + j * 256 + tid;
+                    sv[j] = r[min(c, n - 1)];
+                    m[j] = __ballot(c < n && sv[j] >= cut);   // false for NaN
+                    tot += __popcll(m[j]);
+                }
+                if (tot) {
+                    int o = 0;
+                    if (lane == 0) o = atomicAdd(&c_cnt, tot);
+                    o = uniform_i(o);
+#pragma unroll
+                    for (int j = 0; j < VPT; ++j) {
+                        if (m[j]) {
+                            const int pos = o + lane_prefix_count(m[j]);
+                            if (((m[j] >> lane) & 1ull) && pos < SELB_CAP)
+                                skey[pos] = ((unsigned long long)__float_as_uint(sv[j]) << 32) |
+                                            (unsigned)(base + j * 256 + tid);   // (score bits, column) for now
+                            o += __popcll(m[j]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        Sn = c_cnt;
+        if ((bad && !exact_row) || Sn > SELB_CAP) {
+            if (exact_row) break;   // still too many after the exact pass: masses of exact ties
+            // exact scores for the whole row, in place
+            for (int c = tid; c < n; c += 256) r[c] = exact(c);
+            __threadfence_block();
+            if (tid == 0) c_cnt = 0;
+            if (a.stats && tid == 0) atomicAdd(a.stats + 1, 1u);
+            __syncthreads();
+            exact_row = true;
+            continue;
+        }
+        break;
+    }
+    if (Sn > SELB_CAP) {
+        __syncthreads();
+        float *f = reinterpret_cast<float *>(skey);
+        select_by_insertion(r, n, K, row, a.out_i32, nullptr, a.out_s, 0, f, reinterpret_cast<int *>(f + 256),
+                            f + 512, reinterpret_cast<int *>(f + 768));
+        if (a.pt.list_goff) emit_probe_tables(a.pt, row, K, a.out_i32 + (size_t)row * K, wtot);
+        return;
+    }
+    if (a.stats && tid == 0) atomicAdd(a.stats, (unsigned)Sn);
+    // exact score of every candidate, then the sort key
+    __syncthreads();
+    // candidate e goes to thread (e % 4) * 64 + e / 4: the chains spread over the four SIMDs
+    for (int e0 = 0; e0 < Sn; e0 += 256) {
+        const int e = e0 + (tid >> 6) + 4 * (tid & 63);
+        if (e >= Sn) continue;
+        const unsigned col = (unsigned)skey[e];
+        const float s = (exact_row || (a.debug & 1)) ? __uint_as_float((unsigned)(skey[e] >> 32)) : exact((int)col);
+        skey[e] = s == s ? ((unsigned long long)f2o(s) << 32) | (unsigned)~col : 0ull;   // NaN never survives
+    }
+    int P = 64;
+    while (P < Sn) P <<= 1;
+    for (int e = Sn + tid; e < P; e += 256) skey[e] = 0ull;
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < (P >> 1); i += 256) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int hi = lo | j;
+                const unsigned long long x = skey[lo], y = skey[hi];
+                const bool desc = (lo & k2) == 0;
+                if ((x < y) == desc) {
+                    skey[lo] = y;
+                    skey[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    constexpr int RPT = SELB_CAP / 256;
+    unsigned long long res[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int e = tid + i * 256;
+        res[i] = (e < K && e < Sn) ? skey[e] : 0ull;
+    }
+    __syncthreads();
+    int32_t *sel = reinterpret_cast<int32_t *>(skey);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int e = tid + i * 256;
+        if (e < K) {
+            const bool filled = res[i] != 0ull;
+            const int si = filled ? (int)~(unsigned)res[i] : -1;
+            const size_t o = (size_t)row * K + e;
+            if (a.out_i32) a.out_i32[o] = si;
+            if (a.out_s) a.out_s[o] = filled ? o2f((unsigned)(res[i] >> 32)) : -FLT_MAX;
+            sel[e] = si;
+        }
+    }
+    __syncthreads();
+    if (a.pt.list_goff) emit_probe_tables(a.pt, row, K, sel, wtot);
 }
 
 template <int DSUB>

@@ -224,6 +224,76 @@ def test_autotune_on_the_hip_index(faiss, oracle, tmp_path):
         ps.set_index_parameter(idx.base_index, "k_factor_rf", 2)
 
 
+def test_two_stage_coarse_is_bit_identical(faiss, oracle, monkeypatch):
+    """Large batches take the two-stage coarse quantiser (f16 MFMA scores, then the exact f32
+    chain for every centroid within the proven error margin of the cut).  Its result must be
+    the one-stage result bit for bit -- list numbers, scores, and therefore the search --
+    also on adversarial inputs: large and tiny norms, duplicated centroids (exact ties broken
+    by index), rows whose f16 image overflows, a NaN query."""
+    rng = np.random.default_rng(314)
+    d, M, nlist, nq = 128, 16, 1024, 300
+    cb = (0.3 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+
+    def run(cent, q, nprobes, x=None):
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("MI_TWO_STAGE", mode)
+            idx = make_index(faiss, cent, cb)
+            if x is not None:
+                idx.add(x)
+            res = []
+            for nprobe in nprobes:
+                cI, cD, _ = idx.coarse_and_lut(q, nprobe, want_lut=False)
+                res.append((cI, bits(cD)))
+                if x is not None:
+                    idx.nprobe = nprobe
+                    D, I = idx.search(q, 10)
+                    res.append((I, bits(D)))
+            out[mode] = res
+        for a, b in zip(out["0"], out["1"]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        return out["1"]
+
+    # clustered centroids (many near-equal scores around the cut), unit-ish norms
+    base = rng.standard_normal((64, d)).astype(np.float32)
+    cent = (base[rng.integers(0, 64, nlist)] + 0.02 * rng.standard_normal((nlist, d))).astype(np.float32)
+    q = (cent[rng.integers(0, nlist, nq)] + 0.1 * rng.standard_normal((nq, d))).astype(np.float32)
+    x = (cent[rng.integers(0, nlist, 20000)] + 0.1 * rng.standard_normal((20000, d))).astype(np.float32)
+    got = run(cent, q, (1, 16, 64, 300, 1024), x)
+    De, Ie = oracle.flat_ip(q, cent, 16)
+    assert np.array_equal(got[2][0], Ie) and np.array_equal(got[2][1], bits(De))
+    # duplicated centroids: exact ties, the lower index wins
+    cent2 = cent.copy()
+    cent2[1::2] = cent2[0::2]
+    run(cent2, q, (1, 7, 64))
+    # large and tiny norms (the margin scales with |q| max|c|), mixed in one batch
+    scale = np.where(np.arange(nq) % 3 == 0, 100.0, np.where(np.arange(nq) % 3 == 1, 1e-3, 1.0)).astype(np.float32)
+    run((cent * 30).astype(np.float32), (q * scale[:, None]).astype(np.float32), (5, 64))
+    run((cent * 1e-3).astype(np.float32), q, (5, 64))
+    # f16 overflow in some centroids / one query, and a NaN query: exact fallback rows
+    cent3 = cent.copy()
+    cent3[10] *= 1e5
+    cent3[500, 3] = 7e4
+    q3 = q.copy()
+    q3[5] *= 1e6
+    run(cent3, q3, (3, 32))
+    q4 = q.copy()
+    q4[7, 0] = np.nan
+    res = run(cent, q4, (3,))
+    assert (res[0][0][7] == -1).all()
+    # the default dispatch (no forcing): 2048 queries x 8192 centroids takes the two-stage path
+    cent8 = rng.standard_normal((8192, d)).astype(np.float32)
+    q8 = (cent8[rng.integers(0, 8192, 2048)] + 0.5 * rng.standard_normal((2048, d))).astype(np.float32)
+    idx = make_index(faiss, cent8, cb)
+    monkeypatch.delenv("MI_TWO_STAGE")
+    cI1, cD1, _ = idx.coarse_and_lut(q8, 16, want_lut=False)
+    monkeypatch.setenv("MI_TWO_STAGE", "0")
+    cI0, cD0, _ = idx.coarse_and_lut(q8, 16, want_lut=False)
+    assert np.array_equal(cI0, cI1) and np.array_equal(bits(cD0), bits(cD1))
+    De, Ie = oracle.flat_ip(q8[:64], cent8, 16)
+    assert np.array_equal(cI1[:64], Ie) and np.array_equal(bits(cD1[:64]), bits(De))
+
+
 def test_lut_matches_oracle(faiss, oracle):
     cent, cb, x, q = random_problem(3, 1024, 64, 8, 64, 9)
     idx = make_index(faiss, cent, cb)
