@@ -86,10 +86,10 @@ void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int3
     MI_HIP(hipGetLastError());
 }
 
-void launch_to_f16(const float *x, int64_t n, f16_t *y, hipStream_t st) {
-    MI_REQUIRE(n % 4 == 0, "to_f16: length must be a multiple of 4");
-    const int64_t n4 = n / 4;
-    hipLaunchKernelGGL(to_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, n4, y);
+void launch_to_f16_rows(const float *x, int64_t rows, int d, f16_t *y, float *scale_out, float scale_all,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(to_f16_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, (int)rows, d, y,
+                       scale_out, scale_all);
     MI_HIP(hipGetLastError());
 }
 
@@ -101,6 +101,71 @@ void launch_gemm_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int
     hipLaunchKernelGGL(ip_gemm_f16_kernel, dim3((unsigned)(per * 8)), dim3(256), 0, st, A, (int)na, B, (int)nb, K, S,
                        ldS, tiles_m, tiles_n);
     MI_HIP(hipGetLastError());
+}
+
+// ---- two-stage coarse quantiser (select_refine_kernel): shared by search, add and k-means ----
+// f16 image of a centroid matrix + the two numbers the error bound needs
+void prepare_cent16(const float *c, int64_t nc, int d, DevBuf &c16, DevBuf &stat, float &cmax, float &cscale,
+                    hipStream_t st) {
+    unsigned *cm = static_cast<unsigned *>(stat.reserve(8));
+    MI_HIP(hipMemsetAsync(cm, 0, 8, st));
+    hipLaunchKernelGGL(max_row_norm_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, st, c, (int)nc, d, cm);
+    MI_HIP(hipGetLastError());
+    unsigned bits[2] = {0, 0};
+    MI_HIP(hipMemcpyAsync(bits, cm, 8, hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
+    float maxabs = 0.f;
+    std::memcpy(&cmax, &bits[0], 4);
+    std::memcpy(&maxabs, &bits[1], 4);
+    cscale = 1.f;
+    if (maxabs > 0.f && maxabs <= 3.0e38f) {
+        int e = 0;
+        (void)std::frexp(maxabs, &e);
+        cscale = std::ldexp(1.f, std::min(std::max(14 - e, -100), 100));
+    }
+    launch_to_f16_rows(c, nc, d, static_cast<f16_t *>(c16.reserve((size_t)nc * d * 2)), nullptr, cscale, st);
+}
+
+// Large batches only: below, the exact GEMM is latency-bound and the second stage costs more
+// than it saves.  MI_TWO_STAGE=0 / 1 forces it off / on (tests).
+bool two_stage_wanted(int64_t nq, int64_t nc, int d, int K) {
+    bool on = nq >= 256 && nc >= 8192 && nq * nc >= ((int64_t)1 << 24) && K <= 128;
+    if (const char *e = std::getenv("MI_TWO_STAGE")) on = std::atoi(e) != 0;
+    return on && d % 128 == 0 && d <= 4096 && nc % 4 == 0 && K <= 1024 && nc < ((int64_t)1 << 31);
+}
+
+// best K of q [nq][d] against c32 [nc][d]: approximate scores into `scores` [nq][nc], then the
+// exact second stage; outputs as launch_select's
+void launch_two_stage(const float *q, int64_t nq, const float *c32, const f16_t *c16, int64_t nc, int d, int K,
+                      float cmax, float cscale, float *scores, DevBuf &q16buf, DevBuf &qscalebuf, DevBuf &statbuf,
+                      int32_t *out_i32, float *out_s, ProbeTables pt, hipStream_t st) {
+    f16_t *q16 = static_cast<f16_t *>(q16buf.reserve((size_t)nq * d * 2));
+    float *qscale = static_cast<float *>(qscalebuf.reserve((size_t)nq * 4));
+    launch_to_f16_rows(q, nq, d, q16, qscale, 0.f, st);
+    launch_gemm_f16(q16, nq, c16, nc, d, scores, nc, st);
+    RefineArgs ra{};
+    ra.q = q; ra.cent = c32; ra.Sa = scores; ra.ldS = nc;
+    ra.n = (int)nc; ra.d = d; ra.K = K;
+    // |approx - exact| <= eps_rel |q| |c|  (derivation: ivfpq_kernels.h); the 1 % covers every
+    // second-order term (products of the relative errors, d u / (1 - d u))
+    ra.eps_rel = (0x1p-10f + (float)d * (0x1p-22f + 0x1p-24f) + 0x1p-26f * std::sqrt((float)d)) * 1.01f;
+    ra.qscale = qscale; ra.cscale = cscale; ra.cmax = cmax;
+    ra.out_i32 = out_i32; ra.out_s = out_s; ra.pt = pt;
+    if (const char *e = std::getenv("MI_REFINE_DEBUG")) ra.debug = std::atoi(e);
+    const bool want_stats = std::getenv("MI_REFINE_STATS") != nullptr;
+    if (want_stats) {
+        ra.stats = static_cast<unsigned *>(statbuf.reserve(8));
+        MI_HIP(hipMemsetAsync(ra.stats, 0, 8, st));
+    }
+    hipLaunchKernelGGL(select_refine_kernel, dim3((unsigned)nq), dim3(256), 0, st, ra);
+    MI_HIP(hipGetLastError());
+    if (want_stats) {
+        unsigned hs[2] = {0, 0};
+        MI_HIP(hipMemcpyAsync(hs, ra.stats, 8, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
+        std::fprintf(stderr, "two-stage coarse: %lld rows, K %d: %.2f candidates per row, %u exact-fallback rows\n",
+                     (long long)nq, K, (double)hs[0] / (double)nq, hs[1]);
+    }
 }
 
 LutArgs make_lut_args(const float *q, int nq, int d, int M, const float *cb, float *lut) {
@@ -229,7 +294,7 @@ const void *to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t 
 
 // per-stream search workspaces (see mi_index::ws_sets)
 struct SearchWS {
-    DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters, all_s, all_id, q16, rstats;
+    DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters, all_s, all_id, q16, qscale, rstats;
     size_t counters_zeroed = 0;  // bytes of `counters` known to be zero
     // most recent scan launch on this stream (mi_index_profile_scan replays it)
     ScanArgs last_scan{};
@@ -252,7 +317,7 @@ struct mi_index {
     DevBuf centroids, codebook;
     // two-stage coarse quantiser: f16 copy of the centroids, their largest norm
     DevBuf cent16, cmax_dev;
-    float cmax = 0.f;
+    float cmax = 0.f, cscale = 1.f;
     bool cent16_ok = false;
     // master copy of the inverted lists (insertion order, row-major codes)
     std::vector<std::vector<uint8_t>> h_codes;
@@ -270,7 +335,7 @@ struct mi_index {
     // round-robins 2-4 streams; each kernel of one batch leaves most CUs idle)
     std::vector<std::pair<void *, std::unique_ptr<SearchWS>>> ws_sets;
     // add()/encode() workspaces
-    DevBuf ws_scores, ws_x, ws_assign, ws_codes, ws_ids, ws_count;
+    DevBuf ws_scores, ws_x, ws_assign, ws_codes, ws_ids, ws_count, ws_x16, ws_xscale, ws_rstats;
 
     int nch() const { return (M + 15) / 16; }
 };
@@ -345,8 +410,18 @@ void encode_chunk(mi_index *h, const float *xdev, int64_t n, hipStream_t st) {
     float *scores = h->ws_scores.as<float>((size_t)n * h->nlist);
     int32_t *assign = h->ws_assign.as<int32_t>((size_t)n);
     uint8_t *codes = h->ws_codes.as<uint8_t>((size_t)n * h->M);
-    launch_gemm(xdev, n, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st);
-    launch_select(scores, h->nlist, n, h->nlist, 1, assign, nullptr, nullptr, st);
+    if (two_stage_wanted(n, h->nlist, h->d, 1)) {
+        if (!h->cent16_ok) {
+            prepare_cent16(h->centroids.get<float>(), h->nlist, h->d, h->cent16, h->cmax_dev, h->cmax, h->cscale, st);
+            h->cent16_ok = true;
+        }
+        launch_two_stage(xdev, n, h->centroids.get<float>(), static_cast<const f16_t *>(h->cent16.p), h->nlist, h->d, 1,
+                         h->cmax, h->cscale, scores, h->ws_x16, h->ws_xscale, h->ws_rstats, assign, nullptr,
+                         ProbeTables{}, st);
+    } else {
+        launch_gemm(xdev, n, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st);
+        launch_select(scores, h->nlist, n, h->nlist, 1, assign, nullptr, nullptr, st);
+    }
     launch_pq_encode(xdev, n, h->d, h->M, h->codebook.get<float>(),
                      h->by_residual ? h->centroids.get<float>() : nullptr, assign, codes, st);
 }
@@ -425,6 +500,12 @@ int mi_index_set_coarse(mi_index *h, const float *centroids) {
         MI_HIP(hipMemcpy(h->centroids.reserve(bytes), centroids, bytes, hipMemcpyDefault));
         h->has_coarse = true;
         h->cent16_ok = false;
+        // the f16 image the two-stage coarse quantiser uses is built here, not lazily inside a
+        // search (concurrent searches on several streams only read the index)
+        if (h->nlist >= 8192 && h->d % 128 == 0 && h->d <= 4096 && h->nlist % 4 == 0) {
+            prepare_cent16(h->centroids.get<float>(), h->nlist, h->d, h->cent16, h->cmax_dev, h->cmax, h->cscale, nullptr);
+            h->cent16_ok = true;
+        }
     });
 }
 
@@ -700,50 +781,14 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     }
     // Large batches: f16 MFMA scores + exact re-scoring of the few centroids within a proven
     // error margin of the cut (bit-identical result, see select_refine_kernel) instead of the
-    // exact f32 GEMM over all of them.  MI_TWO_STAGE=0 / 1 forces it off / on.
-    bool two_stage = nq >= 256 && h->nlist >= 8192 && (int64_t)nq * h->nlist >= ((int64_t)1 << 24) && nprobe <= 128;
-    if (const char *e = std::getenv("MI_TWO_STAGE")) two_stage = std::atoi(e) != 0;
-    two_stage = two_stage && h->d % 128 == 0 && h->d <= 4096 && h->nlist % 4 == 0 && nprobe <= 1024;
-    if (two_stage) {
+    // exact f32 GEMM over all of them.
+    if (two_stage_wanted(nq, h->nlist, h->d, nprobe)) {
         if (!h->cent16_ok) {
-            const int64_t ne = (int64_t)h->nlist * h->d;
-            launch_to_f16(h->centroids.get<float>(), ne, static_cast<f16_t *>(h->cent16.reserve((size_t)ne * 2)), st);
-            unsigned *cm = static_cast<unsigned *>(h->cmax_dev.reserve(4));
-            MI_HIP(hipMemsetAsync(cm, 0, 4, st));
-            hipLaunchKernelGGL(max_row_norm_kernel, dim3((unsigned)((h->nlist + 3) / 4)), dim3(256), 0, st,
-                               h->centroids.get<float>(), h->nlist, h->d, cm);
-            MI_HIP(hipGetLastError());
-            unsigned bits = 0;
-            MI_HIP(hipMemcpyAsync(&bits, cm, 4, hipMemcpyDeviceToHost, st));
-            MI_HIP(hipStreamSynchronize(st));
-            std::memcpy(&h->cmax, &bits, 4);
+            prepare_cent16(h->centroids.get<float>(), h->nlist, h->d, h->cent16, h->cmax_dev, h->cmax, h->cscale, st);
             h->cent16_ok = true;
         }
-        f16_t *q16 = static_cast<f16_t *>(w.q16.reserve((size_t)nq * h->d * 2));
-        launch_to_f16(qdev, (int64_t)nq * h->d, q16, st);
-        launch_gemm_f16(q16, nq, static_cast<const f16_t *>(h->cent16.p), h->nlist, h->d, scores, h->nlist, st);
-        RefineArgs ra{};
-        ra.q = qdev; ra.cent = h->centroids.get<float>(); ra.Sa = scores; ra.ldS = h->nlist;
-        ra.n = h->nlist; ra.d = h->d; ra.K = nprobe;
-        ra.eps_rel = 0x1p-10f * 1.001f + (float)h->d * (0x1p-22f + 0x1p-24f);
-        ra.eps_abs = 0x1p-25f * std::sqrt((float)h->d) * 1.01f;
-        ra.cmax = h->cmax;
-        ra.out_i32 = cidx; ra.out_s = cdis; ra.pt = pt;
-        if (const char *e = std::getenv("MI_REFINE_DEBUG")) ra.debug = std::atoi(e);
-        const bool want_stats = std::getenv("MI_REFINE_STATS") != nullptr;
-        if (want_stats) {
-            ra.stats = static_cast<unsigned *>(w.rstats.reserve(8));
-            MI_HIP(hipMemsetAsync(ra.stats, 0, 8, st));
-        }
-        hipLaunchKernelGGL(select_refine_kernel, dim3((unsigned)nq), dim3(256), 0, st, ra);
-        MI_HIP(hipGetLastError());
-        if (want_stats) {
-            unsigned hs[2] = {0, 0};
-            MI_HIP(hipMemcpyAsync(hs, ra.stats, 8, hipMemcpyDeviceToHost, st));
-            MI_HIP(hipStreamSynchronize(st));
-            std::fprintf(stderr, "two-stage coarse: %lld rows, nprobe %d: %.2f candidates per row, %u exact-fallback rows\n",
-                         (long long)nq, nprobe, (double)hs[0] / (double)nq, hs[1]);
-        }
+        launch_two_stage(qdev, nq, h->centroids.get<float>(), static_cast<const f16_t *>(h->cent16.p), h->nlist, h->d,
+                         nprobe, h->cmax, h->cscale, scores, w.q16, w.qscale, w.rstats, cidx, cdis, pt, st);
         if (fork) MI_HIP(hipStreamWaitEvent(st, w.ev_join, 0));
         else launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
     } else {
@@ -1174,8 +1219,11 @@ int mi_ip_assign(int device, int64_t n, const float *x, int64_t nc, const float 
         hipStream_t st = as_stream(stream);
         MI_REQUIRE(is_device_ptr(x) && is_device_ptr(c), "mi_ip_assign: x and c must be device pointers");
         const bool ad = is_device_ptr(assign), sd = score ? is_device_ptr(score) : true;
-        DevBuf scores, da, ds;
+        DevBuf scores, da, ds, c16, cstat, x16, xscale, rstat;
         int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(65536, ((int64_t)1 << 28) / nc));
+        const bool two = two_stage_wanted(std::min(chunk, n), nc, d, 1);
+        float cmax = 0.f, cscale = 1.f;
+        if (two) prepare_cent16(c, nc, d, c16, cstat, cmax, cscale, st);
         scores.reserve((size_t)std::min(chunk, n) * nc * 4);
         if (!ad) da.reserve((size_t)n * 4);
         if (score && !sd) ds.reserve((size_t)n * 4);
@@ -1183,6 +1231,11 @@ int mi_ip_assign(int device, int64_t n, const float *x, int64_t nc, const float 
         float *sp = score ? (sd ? score : ds.get<float>()) : nullptr;
         for (int64_t c0 = 0; c0 < n; c0 += chunk) {
             int64_t m = std::min(chunk, n - c0);
+            if (two) {
+                launch_two_stage(x + (size_t)c0 * d, m, c, static_cast<const f16_t *>(c16.p), nc, d, 1, cmax, cscale,
+                                 scores.get<float>(), x16, xscale, rstat, ap + c0, sp ? sp + c0 : nullptr, ProbeTables{}, st);
+                continue;
+            }
             launch_gemm(x + (size_t)c0 * d, m, c, nc, d, scores.get<float>(), nc, st);
             launch_select(scores.get<float>(), nc, m, (int)nc, 1, ap + c0, nullptr, sp ? sp + c0 : nullptr, st);
         }

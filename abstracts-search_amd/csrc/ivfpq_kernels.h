@@ -1068,36 +1068,79 @@ __global__ void __launch_bounds__(256)
 // oracle compute) and the K best of those under (exact score desc, index asc) are the
 // result: bit-identical to the one-stage path, because the exact top K all lie inside the
 // candidate set:  exact_c >= exact_(K) >= approx_(K) - eps  =>  approx_c >= approx_(K) - 2 eps.
-// eps = eps_rel * |q| * max|c| + eps_abs * (|q| + max|c|)  (Cauchy-Schwarz on sum |q_i c_i|):
-//   f16 rounding of both operands 2 * 2^-11 (+ 2^-22), subnormal spacing 2^-25 per element,
-//   f32 accumulation of d exact f16 x f16 products d * 2^-22 (generous for any summation
-//   order), the exact chain's own rounding d * 2^-24.
+// eps = eps_rel |q| max|c|, from  approx - exact = (approx - sum q~c~) + (sum q~c~ - sum qc)
+// + (sum qc - exact)  and Cauchy-Schwarz, sum |q_i c_i| <= |q| |c|:
+//   f16 rounding of both operands: relative 2 * 2^-11 + 2^-22 per product.  Every query row
+//     and the centroid matrix are multiplied by a power of two first that puts their largest
+//     magnitude in [2^13, 2^14) (no overflow; undone exactly on the scores), so an element
+//     only leaves f16's normal range when it is below 2^-27 of that magnitude -- even if the
+//     MFMA flushed such inputs to zero the loss is <= 2^-27 sqrt(d) |q| |c| per operand;
+//   f32 accumulation of the d exact f16 x f16 products inside the MFMA: d 2^-22 relative to
+//     sum |q~c~| -- two units in the last place per addition, whatever the summation order
+//     or rounding mode of the unit;
+//   the exact chain's own rounding: d 2^-24.
+// The host adds 1 % for the second-order terms; |q| and max|c| are rounded up by 0.1 %.
 // =====================================================================
 typedef _Float16 f16_t;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-__global__ void __launch_bounds__(256) to_f16_kernel(const float *__restrict__ x, int64_t n4, f16_t *__restrict__ y) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const float4 v = reinterpret_cast<const float4 *>(x)[i];
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    h4 o = {(f16_t)v.x, (f16_t)v.y, (f16_t)v.z, (f16_t)v.w};
-    reinterpret_cast<h4 *>(y)[i] = o;
+// Power of two that brings a largest magnitude m into [2^13, 2^14): far from f16's overflow
+// (65504), and an element then only leaves f16's normal range if it is below 2^-27 m.
+__device__ __forceinline__ float f16_pow2_scale(float m) {
+    if (!(m > 0.f) || !(m <= 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.f, min(max(14 - e, -100), 100));
 }
 
-// largest row norm of x [n][d] -> *out (float bits; non-negative floats order like ints)
+// rows of x [rows][d] -> f16, each row times its own power-of-two scale (stored); one wave per row.
+// scale_all != 0: one given scale for every row (the centroids: no per-column unscale later).
+__global__ void __launch_bounds__(256) to_f16_rows_kernel(const float *__restrict__ x, int rows, int d, f16_t *__restrict__ y,
+                                                          float *__restrict__ scale_out, float scale_all) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * d);
+    float sc = scale_all;
+    if (sc == 0.f) {
+        float m = 0.f;
+        for (int k = lane; k < (d >> 2); k += 64) {
+            const float4 v = xr[k];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        sc = f16_pow2_scale(m);
+        if (lane == 0) scale_out[row] = sc;
+    }
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 *yr = reinterpret_cast<h4 *>(y + (size_t)row * d);
+    for (int k = lane; k < (d >> 2); k += 64) {
+        const float4 v = xr[k];
+        h4 o = {(f16_t)(v.x * sc), (f16_t)(v.y * sc), (f16_t)(v.z * sc), (f16_t)(v.w * sc)};
+        yr[k] = o;
+    }
+}
+
+// out[0] = largest row norm of x [n][d] (rounded up), out[1] = largest |element|
+// (float bits; non-negative floats order like ints)
 __global__ void __launch_bounds__(256) max_row_norm_kernel(const float *__restrict__ x, int n, int d, unsigned *__restrict__ out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= n) return;
-    float acc = 0.f;
+    float acc = 0.f, m = 0.f;
     for (int k = lane; k < d; k += 64) {
         const float v = x[(size_t)row * d + k];
         acc = __builtin_fmaf(v, v, acc);
+        m = fmaxf(m, fabsf(v));
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    // round up generously: the bound only has to be an upper bound
-    if (lane == 0) atomicMax(out, __float_as_uint(sqrtf(acc) * 1.0001f));
+    for (int off = 32; off > 0; off >>= 1) {
+        acc += __shfl_xor(acc, off);
+        m = fmaxf(m, __shfl_xor(m, off));
+    }
+    if (lane == 0) {
+        atomicMax(out, __float_as_uint(sqrtf(acc) * 1.001f));
+        atomicMax(out + 1, __float_as_uint(m));
+    }
 }
 
 __device__ __forceinline__ float ivf_dpp_quad_xor1(float v) {
@@ -1219,7 +1262,9 @@ struct RefineArgs {
     float *Sa;            // [rows][ldS] approximate scores (overwritten by exact ones on the fallback)
     int64_t ldS;
     int n, d, K;
-    float eps_rel, eps_abs, cmax;
+    float eps_rel, cmax;
+    const float *qscale;  // [rows] power-of-two scale of each f16 query row
+    float cscale;         // power-of-two scale of the f16 centroids
     int32_t *out_i32;     // [rows][K]
     float *out_s;         // [rows][K]
     ProbeTables pt;
@@ -1252,8 +1297,9 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
     if (lane == 0) wred[w] = nrm;
     if (tid == 0) c_cnt = 0;
     __syncthreads();
-    const float qn = sqrtf(wred[0] + wred[1] + wred[2] + wred[3]) * 1.0001f;
-    float margin = 2.f * (a.eps_rel * qn * a.cmax + a.eps_abs * (qn + a.cmax));
+    const float qn = sqrtf(wred[0] + wred[1] + wred[2] + wred[3]) * 1.001f;   // an upper bound of |q| (f32 sum: d 2^-25 relative)
+    float margin = 2.f * a.eps_rel * qn * a.cmax;
+    const float inv = 1.f / (a.qscale[row] * a.cscale);   // exact: powers of two
     bool bad = !(margin < 3.0e38f);   // NaN / inf query
     auto exact = [&](int col) -> float {
         // d % 128 == 0 (host).  The centroid row is streamed through two register sets of
@@ -1312,7 +1358,7 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
 #pragma unroll
             for (int j = 0; j < VPT; ++j) {
                 const int c = base + j * 256 + tid;
-                const float v = r[min(c, n - 1)];
+                const float v = r[min(c, n - 1)] * (exact_row ? 1.f : inv);
                 // approximate rows must be finite (else: exact fallback); exact rows follow
                 // select_kernel: NaN never survives, +-inf are ordinary scores
                 const bool fin = exact_row ? (v == v) : (fabsf(v) <= 3.0e38f);
@@ -1377,7 +1423,7 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
 #pragma unroll
                 for (int j = 0; j < VPT; ++j) {
                     const int c = base + j * 256 + tid;
-                    sv[j] = r[min(c, n - 1)];
+                    sv[j] = r[min(c, n - 1)] * (exact_row ? 1.f : inv);
                     m[j] = __ballot(c < n && sv[j] >= cut);   // false for NaN
                     tot += __popcll(m[j]);
                 }

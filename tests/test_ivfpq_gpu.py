@@ -270,6 +270,11 @@ def test_two_stage_coarse_is_bit_identical(faiss, oracle, monkeypatch):
     scale = np.where(np.arange(nq) % 3 == 0, 100.0, np.where(np.arange(nq) % 3 == 1, 1e-3, 1.0)).astype(np.float32)
     run((cent * 30).astype(np.float32), (q * scale[:, None]).astype(np.float32), (5, 64))
     run((cent * 1e-3).astype(np.float32), q, (5, 64))
+    # far below f16's range, and rows whose components span 12 orders of magnitude
+    run((cent * 1e-9).astype(np.float32), (q * 1e-12).astype(np.float32), (5, 64))
+    wide = np.exp(rng.uniform(-14, 14, (1, d))).astype(np.float32)
+    run((cent * wide).astype(np.float32), (q / wide).astype(np.float32), (5, 64))
+    run((cent * wide).astype(np.float32), q, (5, 64))
     # f16 overflow in some centroids / one query, and a NaN query: exact fallback rows
     cent3 = cent.copy()
     cent3[10] *= 1e5
