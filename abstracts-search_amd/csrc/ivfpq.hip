@@ -129,7 +129,7 @@ void prepare_cent16(const float *c, int64_t nc, int d, DevBuf &c16, DevBuf &stat
 // Large batches only: below, the exact GEMM is latency-bound and the second stage costs more
 // than it saves.  MI_TWO_STAGE=0 / 1 forces it off / on (tests).
 bool two_stage_wanted(int64_t nq, int64_t nc, int d, int K) {
-    bool on = nq >= 256 && nc >= 8192 && nq * nc >= ((int64_t)1 << 24) && K <= 128;
+    bool on = nq >= 256 && nc >= 8192 && nq * nc >= ((int64_t)1 << 24) && (K <= 128 || nq * nc >= ((int64_t)1 << 26));   // (1024 x 65536, K 256: 2.68 -> 2.16 ms)
     if (const char *e = std::getenv("MI_TWO_STAGE")) on = std::atoi(e) != 0;
     return on && d % 128 == 0 && d <= 4096 && nc % 4 == 0 && K <= 1024 && nc < ((int64_t)1 << 31);
 }
