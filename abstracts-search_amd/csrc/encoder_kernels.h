@@ -167,7 +167,8 @@ __device__ __forceinline__ bool tile_coords(int tiles_m, int tiles_n, int &tm, i
     return true;
 }
 
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3,
+       EPI_F32H = 4 };   // f16 (not bf16) operands, plain f32 store to X: the index library's approximate score GEMM
 
 struct GemmArgs {
     const bf16_t *A;   // [M][lda]
@@ -275,6 +276,10 @@ __device__ __forceinline__ void store_rows4(const GemmArgs &g, f32x4 v, f32x4 v2
         }
     } else {
         if (row >= g.M || col0 >= g.N) return;
+        if constexpr (EPI == EPI_F32H) {
+            *reinterpret_cast<float4 *>(g.X + (size_t)row * g.ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
+            return;
+        }
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g.bias) b = *reinterpret_cast<const float4 *>(g.bias + col0);
         if constexpr (EPI == EPI_RESID) {
@@ -511,8 +516,15 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
 #pragma unroll
         for (int i = 0; i < WMT; ++i)
 #pragma unroll
-            for (int j = 0; j < WNT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < WNT; ++j) {
+                if constexpr (EPI == EPI_F32H) {
+                    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[i]), __builtin_bit_cast(h8, b[j]),
+                                                                       acc[i][j], 0, 0, 0);
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
     };
     // Issue order of a steady-state step (MI_GEMM_SCHED builds only, experiment): the MFMAs
     // first, the fragment reads of the next tile spread between them -- both waves of a SIMD

@@ -11,11 +11,20 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <string>
 #include <utility>
 #include <vector>
 
 #include "common.h"
 #include "ivfpq_kernels.h"
+// The ring-pipelined 16-bit MFMA GEMM of the encoder library, f16 instantiation (approximate
+// coarse scores).  Wrapped in a namespace of its own: both shared libraries live in one
+// process, and identically named kernels / host stubs in two of them preempt each other.
+#include <hip/hip_fp16.h>
+namespace mi_ring {
+#include "encoder_kernels.h"
+}
+namespace mienc = mi_ring::mienc;
 
 using namespace mi;
 
@@ -93,9 +102,35 @@ void launch_to_f16_rows(const float *x, int64_t rows, int d, f16_t *y, float *sc
     MI_HIP(hipGetLastError());
 }
 
+template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
+void launch_ring_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int K, float *S, int64_t ldS, hipStream_t st) {
+    constexpr int BM = 16 * WMT * WAVES_M, BN = 16 * WNT * WAVES_N;
+    mienc::GemmArgs g{};
+    g.A = reinterpret_cast<const mienc::bf16_t *>(A);
+    g.W = reinterpret_cast<const mienc::bf16_t *>(B);
+    g.lda = K; g.ldw = K; g.M = (int)na; g.N = (int)nb; g.K = K;
+    g.X = S; g.ldc = (int)ldS;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    g.ksplit = 1; g.tail_first = 0; g.tail_split = 1;
+    const int per = (g.tiles_m * g.tiles_n + 7) / 8;
+    hipLaunchKernelGGL((mienc::gemm_bf16_ring_kernel<mienc::EPI_F32H, WMT, WNT, WAVES_M, WAVES_N, ST>), dim3(8u * per),
+                       dim3(64 * WAVES_M * WAVES_N), 0, st, g);
+    MI_HIP(hipGetLastError());
+}
+
 void launch_gemm_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int K, float *S, int64_t ldS,
                      hipStream_t st) {
     MI_REQUIRE(K % 64 == 0 && ldS % 4 == 0, "f16 gemm: K % 64 and ldS % 4");
+    // the encoder's ring-pipelined kernel, f16 instantiation (MI_F16_GEMM=simple: the two-stage
+    // 128 x 128 kernel of ivfpq_kernels.h, for A/B runs)
+    const char *e = std::getenv("MI_F16_GEMM");
+    if (!(e && std::string(e) == "simple") && ldS < ((int64_t)1 << 31)) {
+        const int64_t tiles_big = ((na + 255) / 256) * ((nb + 255) / 256);
+        if (tiles_big >= 512) launch_ring_f16<8, 4, 2, 4, 4>(A, na, B, nb, K, S, ldS, st);   // 256 x 256, 8 waves
+        else launch_ring_f16<4, 4, 2, 2, 4>(A, na, B, nb, K, S, ldS, st);                    // 128 x 128, 4 waves
+        return;
+    }
     const int tiles_m = (int)((na + 127) / 128), tiles_n = (int)((nb + 127) / 128);
     const int per = (tiles_m * tiles_n + 7) / 8;
     hipLaunchKernelGGL(ip_gemm_f16_kernel, dim3((unsigned)(per * 8)), dim3(256), 0, st, A, (int)na, B, (int)nb, K, S,
