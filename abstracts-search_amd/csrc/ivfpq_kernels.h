@@ -1415,7 +1415,31 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
         }
         // cut in the score domain; T0 == 0: fewer than K finite entries, keep all
         const float cut = T0 ? o2f(T0) - (exact_row ? 0.f : margin) : -__builtin_inff();
-        if (!bad || exact_row) {
+        if ((!bad || exact_row) && n > TILE) {
+            // long rows: only the thread groups whose maximum reaches the cut hold candidates
+            // (a few dozen of the 4096), so the second pass touches a few cache lines instead
+            // of re-reading the row
+            const float sc = exact_row ? 1.f : inv;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                if (gm[j] != 0u && o2f(gm[j]) >= cut) {
+                    for (int c0 = j * 256 + tid; c0 < n; c0 += 16 * TILE) {   // 16 loads in flight
+                        float vv[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) vv[i] = r[min(c0 + i * TILE, n - 1)];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int c = c0 + i * TILE;
+                            const float v = vv[i] * sc;
+                            if (c < n && v >= cut) {
+                                const int pos = atomicAdd(&c_cnt, 1);
+                                if (pos < SELB_CAP) skey[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)c;
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (!bad || exact_row) {
             for (int base = 0; base < n; base += TILE) {
                 unsigned long long m[VPT];
                 float sv[VPT];
