@@ -297,6 +297,20 @@ def test_two_stage_coarse_is_bit_identical(faiss, oracle, monkeypatch):
     assert np.array_equal(cI0, cI1) and np.array_equal(bits(cD0), bits(cD1))
     De, Ie = oracle.flat_ip(q8[:64], cent8, 16)
     assert np.array_equal(cI1[:64], Ie) and np.array_equal(bits(cD1[:64]), bits(De))
+    # 1024 x 32768: the 256 x 256 tiles of the approximate GEMM, rows of eight tiles in the
+    # second stage; nprobe 200 takes the block-wide descent
+    cent32 = rng.standard_normal((32768, d)).astype(np.float32)
+    q32 = (cent32[rng.integers(0, 32768, 1024)] + 0.5 * rng.standard_normal((1024, d))).astype(np.float32)
+    idx = make_index(faiss, cent32, cb)
+    for nprobe in (8, 200, 300):
+        if nprobe <= 128:
+            monkeypatch.delenv("MI_TWO_STAGE")             # default dispatch
+        else:
+            monkeypatch.setenv("MI_TWO_STAGE", "1")        # (the default wants 2^26 scores for nprobe > 128)
+        cI1, cD1, _ = idx.coarse_and_lut(q32, nprobe, want_lut=False)
+        monkeypatch.setenv("MI_TWO_STAGE", "0")
+        cI0, cD0, _ = idx.coarse_and_lut(q32, nprobe, want_lut=False)
+        assert np.array_equal(cI0, cI1) and np.array_equal(bits(cD0), bits(cD1)), nprobe
 
 
 def test_lut_matches_oracle(faiss, oracle):
