@@ -5,11 +5,18 @@
 //
 //   ip_gemm_kernel   S = Q . C^T, exact f32 on v_mfma_f32_16x16x4_f32
 //                    (bitwise an ascending-k fmaf chain = the oracle's dot)
-//   select_kernel    best-K of each row of S under (score desc, index asc)
+//   select_kernel    best-K of each row of S under (score desc, index asc), K <= 64
+//   select_big_kernel  the same for 64 < K <= 4096 (threshold + bitonic sort)
+//   to_f16_rows_kernel / [ring GEMM, f16] / select_refine_kernel
+//                    large batches: the same coarse result from f16 MFMA scores +
+//                    exact re-scoring of the centroids within a proven error margin
 //   lut_kernel       LUT[q][m][j] = <q_m, codebook[m][j]>
 //   scan_kernel      stream PQ codes of the probed lists, 64 LDS table
-//                    look-ups per code, per-wave register top-k       (HBM/LDS bound)
-//   merge_kernel     k-way merge of per-slice / per-shard partial top-k
+//                    look-ups per code, per-wave register top-k       (HBM/LDS bound);
+//                    k > 64: ALL mode stores every (score, id), select_pairs_kernel
+//                    keeps the k best
+//   merge_kernel     k-way merge of per-slice / per-shard partial top-k and of the
+//                    re-ranked candidates of IndexRefineFlat
 //   pq_encode_kernel Index.add: residual + nearest codeword per sub-vector
 //
 // Inverted-list layout in HBM ("group-interleaved"): a list is padded to
