@@ -718,3 +718,47 @@ def test_fuzz_against_oracle(faiss, oracle):
         ctx = dict(trial=trial, d=d, M=M, nlist=nlist, n=n, nq=nq, k=k, nprobe=nprobe, res=by_residual)
         assert np.array_equal(I, Ie), ctx
         assert np.array_equal(bits(D), bits(De)), ctx
+
+
+def test_fuzz_large_paths(faiss, oracle, monkeypatch):
+    """seeded fuzz over the large-parameter paths: nprobe in the hundreds (select_big_kernel /
+    the block-wide descent), k > 64 (all-pairs pass + select_pairs_kernel), the two-stage
+    coarse quantiser forced on half of the trials (search and add), duplicated / rounded
+    data for ties: HIP == oracle, bit for bit"""
+    rng = np.random.default_rng(777)
+    for trial in range(24):
+        d = int(rng.choice([128, 256]))
+        M = int(rng.choice([d // 16, d // 8, d // 4]))
+        nlist = int(rng.choice([100, 257, 640, 1500]))
+        n = int(rng.choice([300, 5000, 20000]))
+        nq = int(rng.integers(1, 24))
+        k = int(rng.choice([10, 64, 65, 130, 700, 2000]))
+        nprobe = int(rng.choice([1, 17, 64, 65, 200, 257, 600, nlist]))
+        nprobe = min(nprobe, nlist)
+        by_residual = bool(rng.integers(0, 2))
+        two = trial % 2 == 1 and nlist % 4 == 0
+        monkeypatch.setenv("MI_TWO_STAGE", "1" if two else "0")
+        cent = rng.standard_normal((nlist, d)).astype(np.float32)
+        if trial % 4 == 2:
+            cent[nlist // 2:] = cent[: nlist - nlist // 2]      # duplicated centroids: coarse ties
+        cb = (0.3 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+        x = (cent[rng.integers(0, nlist, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+        if trial % 3 == 0:
+            x[n // 2:] = x[: n - n // 2]
+        if trial % 5 == 0:
+            x = np.round(x, 1)
+        q = (x[rng.integers(0, n, nq)] + 0.2 * rng.standard_normal((nq, d))).astype(np.float32)
+        ids = rng.permutation(n).astype(np.int64) * 5 + 2
+        idx = make_index(faiss, cent, cb, by_residual)
+        idx.add_with_ids(x, ids)
+        idx.nprobe = nprobe
+        D, I = idx.search(q, k)
+        ln, codes = oracle.encode(x, cent, cb, by_residual)
+        off, lc, li = oracle.build_lists(ln, codes, ids, nlist)
+        for l in (0, nlist - 1):                                  # add(): the oracle's lists
+            c, i = idx.get_list(l)
+            assert np.array_equal(c, lc[off[l]:off[l + 1]]) and np.array_equal(i, li[off[l]:off[l + 1]])
+        De, Ie = oracle.search(q, cent, cb, off, lc, li, nprobe, k, by_residual)
+        ctx = dict(trial=trial, d=d, M=M, nlist=nlist, n=n, nq=nq, k=k, nprobe=nprobe, res=by_residual, two=two)
+        assert np.array_equal(I, Ie), ctx
+        assert np.array_equal(bits(D), bits(De)), ctx
