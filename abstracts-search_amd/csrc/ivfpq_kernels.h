@@ -458,11 +458,27 @@ __device__ __forceinline__ void emit_probe_tables(const ProbeTables &pt, int64_t
     const int per = (K + 255) / 256;
     const int b = tid * per;
     int sum = 0;
-    for (int i = 0; i < per; ++i)
-        if (b + i < K) {
-            int l = idx_row[b + i];
-            if (l >= 0) sum += pt.list_goff[l + 1] - pt.list_goff[l];
+    // K <= 256 (one entry per thread): the list's first group, group count and length are
+    // fetched once, together, and kept -- the second loop below would pay another dependent
+    // memory round trip for the same three words
+    int g0_1 = 0, ng_1 = 0, len_1 = 0;
+    if (per == 1) {
+        if (tid < K) {
+            const int l = idx_row[tid];
+            if (l >= 0) {
+                g0_1 = pt.list_goff[l];
+                ng_1 = pt.list_goff[l + 1] - g0_1;
+                len_1 = pt.list_len[l];
+            }
         }
+        sum = ng_1;
+    } else {
+        for (int i = 0; i < per; ++i)
+            if (b + i < K) {
+                int l = idx_row[b + i];
+                if (l >= 0) sum += pt.list_goff[l + 1] - pt.list_goff[l];
+            }
+    }
     int incl = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -473,6 +489,15 @@ __device__ __forceinline__ void emit_probe_tables(const ProbeTables &pt, int64_t
     __syncthreads();
     int run = incl - sum;
     for (int ww = 0; ww < w; ++ww) run += wtot[ww];
+    if (per == 1) {
+        if (tid < K) {
+            pt.p_goff[(size_t)row * K + tid] = g0_1;
+            pt.p_len[(size_t)row * K + tid] = len_1;
+            pt.p_prefix[(size_t)row * (K + 1) + tid] = run;
+            if (tid == K - 1) pt.p_prefix[(size_t)row * (K + 1) + K] = run + ng_1;
+        }
+        return;
+    }
     for (int i = 0; i < per; ++i)
         if (b + i < K) {
             int l = idx_row[b + i];
