@@ -457,6 +457,16 @@ def test_select_paths(faiss, oracle, monkeypatch, big_from):
         De, Ie = oracle.flat_ip(q, cent, nprobe)
         assert np.array_equal(cI, Ie), nprobe
         assert np.array_equal(bits(cD), bits(De)), nprobe
+    # reserve(): capacity hint only -- chunked adds after it give the same store
+    flat4 = faiss.IndexFlatIP(d)
+    flat4.reserve(len(base))
+    for c0 in range(0, len(base), 1300):
+        flat4.add(base[c0:c0 + 1300])
+    flat4.reserve(10)                      # smaller than what is there: a no-op
+    assert flat4.ntotal == len(base)
+    D4, I4 = flat4.search(q, 10)
+    D0, I0 = flat.search(q, 10)
+    assert np.array_equal(I4, I0) and np.array_equal(bits(D4), bits(D0))
     # fewer rows than k, NaN-free tiny inputs
     flat3 = faiss.IndexFlatIP(d)
     flat3.add(base[:7])
