@@ -1,6 +1,6 @@
 """BASELINE.json configs[4] on one GPU: end-to-end encode + search for mixed query
 batches 1 / 16 / 256 (latency and throughput), stella-shape random-init encoder,
-cfg2 index.  Queries are short (prompt + question, 16-48 tokens).  GPU box."""
+cfg2 index (or, E2E_N / E2E_NLIST, one shard of the 207 M index).  Queries are short (prompt + question, 16-48 tokens).  GPU box."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -24,9 +24,21 @@ for l in range(cfg["n_layers"]):
         p + "self_attn.v_proj.weight": rnd((kc, H), H ** -0.5), p + "self_attn.v_proj.bias": rnd((kc,), 0.1),
         p + "self_attn.o_proj.weight": rnd((H, qc), qc ** -0.5), p + "mlp.gate_proj.weight": rnd((I, H), H ** -0.5),
         p + "mlp.up_proj.weight": rnd((I, H), H ** -0.5), p + "mlp.down_proj.weight": rnd((H, I), I ** -0.5)})
-x = synth.corpus_cuda(1_000_000, 1024)
-idx = faiss.IndexIVFPQ(1024, 4096, 64, 8, faiss.METRIC_INNER_PRODUCT)
-idx.cp.niter = 6; idx.train(x); idx.add(x); idx.nprobe = 16
+# index: cfg2 by default; E2E_N=25875000 E2E_NLIST=65536 is one shard of the 207 M configuration
+N, NLIST = int(os.environ.get("E2E_N", 1_000_000)), int(os.environ.get("E2E_NLIST", 4096))
+idx = faiss.IndexIVFPQ(1024, NLIST, 64, 8, faiss.METRIC_INNER_PRODUCT)
+idx.cp.niter = 6 if NLIST <= 4096 else 4
+x = synth.corpus_cuda(min(N, max(1_000_000, 64 * NLIST)), 1024)
+idx.train(x)
+if N <= x.shape[0]:
+    idx.add(x)
+else:
+    del x
+    CH = 65536 * 16
+    for c0 in range(0, N, CH):
+        idx.add(synth.corpus_cuda(min(CH, N - c0), 1024, row0=c0))
+idx.nprobe = int(os.environ.get("E2E_NPROBE", 16))
+print(f"index: {N} x 1024, IVF{NLIST},PQ64, nprobe {idx.nprobe}", flush=True)
 rng = np.random.default_rng(1)
 for batch in (1, 16, 256):
     toks = [rng.integers(0, cfg["vocab_size"], int(rng.integers(16, 49))).tolist() for _ in range(batch)]
