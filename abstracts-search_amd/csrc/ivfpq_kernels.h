@@ -1315,7 +1315,7 @@ struct RefineArgs {
 
 __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
     __shared__ unsigned long long skey[SELB_CAP];
-    __shared__ float qs[4096];          // the query row (d <= 4096)
+    __shared__ __attribute__((aligned(16))) float qs[4096];   // the query row (d <= 4096), read as float4
     __shared__ int wcnt[2][4];
     __shared__ float wred[4];
     __shared__ int wtot[4];
