@@ -7,7 +7,9 @@ has exactly one exchange step: an all-gather of the per-shard top-k
 (k * 12 bytes per query per rank -- latency-bound, not bandwidth-bound),
 followed by a k-way merge under the same (score desc, id asc) order the
 single-GPU search uses, so the sharded result is bit-identical to the
-unsharded one.
+unsharded one.  With a re-ranking shard index (IndexRefineFlat over the shard's raw
+vectors, `id_map` = the shard's global row numbers) the result is the merge of the
+shards' exact re-ranked lists: every shard re-ranks its own k * k_factor candidates.
 
 Two entry points:
   search_replicated(q, k)  every rank passes the SAME queries (a front end
@@ -26,7 +28,7 @@ from __future__ import annotations
 
 class ShardedIndex:
     def __init__(self, index, group=None, local_search=None, merge=None, shard_coarse=False,
-                 local_coarse=None, local_search_pre=None, nlist=None, nprobe=None):
+                 local_coarse=None, local_search_pre=None, nlist=None, nprobe=None, id_map=None):
         import torch.distributed as dist
         assert dist.is_initialized(), "ShardedIndex needs an initialised process group"
         self.index = index
@@ -45,6 +47,11 @@ class ShardedIndex:
         self._local_search_pre = local_search_pre or (lambda q, k, cI, cD: self.index.search_preassigned(q, k, cI, cD))
         self._nlist = nlist if nlist is not None else getattr(index, "nlist", None)
         self._nprobe = nprobe
+        # id_map: local result ids -> global ids, applied before the exchange step.  For a
+        # shard index that numbers its vectors by position -- an IndexRefineFlat over the
+        # shard's raw vectors must -- pass the int64 tensor of the shard's global row numbers
+        # (round-robin sharding: torch.arange(rank, n, world)) or a callable on id tensors.
+        self._id_map = id_map
 
     # -- default (HIP) implementations ---------------------------------
     def _hip_search(self, q, k):
@@ -53,6 +60,15 @@ class ShardedIndex:
     def _hip_merge(self, Dp, Ip):
         from . import faiss
         return faiss.merge_topk(Dp, Ip)
+
+    def _global_ids(self, I):
+        if self._id_map is None:
+            return I
+        if callable(self._id_map):
+            return self._id_map(I)
+        import torch
+        out = self._id_map.to(I.device)[I.clamp_min(0)]
+        return torch.where(I < 0, torch.full_like(out, -1), out)
 
     def _buf(self, name, shape, dtype, device):
         import torch
@@ -68,6 +84,7 @@ class ShardedIndex:
         import torch
         import torch.distributed as dist
         Dl, Il = self._search_sharded_coarse(q, k) if self.shard_coarse else self._local_search(q, k)
+        Il = self._global_ids(Il)
         nq = Dl.shape[0]
         Dg = self._buf("Dg", (self.world, nq, k), torch.float32, Dl.device)
         Ig = self._buf("Ig", (self.world, nq, k), torch.int64, Il.device)
@@ -86,6 +103,7 @@ class ShardedIndex:
             Dl, Il = self._search_sharded_coarse(qall, k)
         else:
             Dl, Il = self._local_search(qall, k)                   # this shard, all queries
+        Il = self._global_ids(Il)
         Dg = self._buf("Dg", (self.world, self.world * b, k), torch.float32, Dl.device)
         Ig = self._buf("Ig", (self.world, self.world * b, k), torch.int64, Il.device)
         dist.all_gather_into_tensor(Dg.view(-1, k), Dl.contiguous(), group=self.group)   # the exchange step

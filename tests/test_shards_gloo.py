@@ -63,6 +63,40 @@ def _worker(rank, world, port, mode, ret):
         D, I = O.search_preassigned(q.numpy(), cb, off, lc, li, cI.numpy(), cD.numpy(), kk)
         return torch.from_numpy(D), torch.from_numpy(I)
 
+    if mode == "refine":
+        # every shard: IVF-PQ over its rows numbered by position, exact re-ranking of k * 4
+        # candidates against its raw vectors, positions -> global row numbers through id_map
+        def shard_refine(r, q, kk):
+            rr = np.fromiter(shard_rows(n, r, world), np.int64)
+            ln_, codes_ = O.encode(x[rr], cent, cb)
+            off_, lc_, li_ = O.build_lists(ln_, codes_, np.arange(len(rr)), nlist)   # local ids
+            _, cand = O.search(q, cent, cb, off_, lc_, li_, nprobe, kk * 4)
+            return O.rerank(q, x[rr], cand, kk)
+
+        def local_refine(q, kk):
+            D, I = shard_refine(rank, q.numpy(), kk)
+            return torch.from_numpy(D), torch.from_numpy(I)
+
+        sh = ShardedIndex(index=None, local_search=local_refine, merge=merge, id_map=torch.from_numpy(rows))
+        rng = np.random.default_rng(100)
+        qall = (x[rng.integers(0, n, world * b)] + 0.01 * rng.standard_normal((world * b, x.shape[1]))).astype(np.float32)
+        D, I = sh.search(torch.from_numpy(qall[rank * b:(rank + 1) * b]), k)
+        qs = qall[rank * b:(rank + 1) * b]
+        parts = []
+        for r in range(world):
+            Dr, Ir = shard_refine(r, qs, k)
+            rr = np.fromiter(shard_rows(n, r, world), np.int64)
+            parts.append((Dr, np.where(Ir >= 0, rr[np.maximum(Ir, 0)], -1)))
+        De, Ie = O.merge(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
+        # scores are exact inner products of the global rows the ids name
+        exact = np.array([[np.float32(0) if i < 0 else O.flat_ip(qs[j:j + 1], x[i:i + 1], 1)[0][0, 0] for i in row]
+                          for j, row in enumerate(I.numpy())], np.float32)
+        ok = (np.array_equal(I.numpy(), Ie) and np.array_equal(D.numpy().view(np.uint32), De.view(np.uint32))
+              and np.array_equal(exact.view(np.uint32)[I.numpy() >= 0], D.numpy().view(np.uint32)[I.numpy() >= 0]))
+        ret[rank] = bool(ok)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     sh = ShardedIndex(index=None, local_search=local_search, merge=merge, shard_coarse=mode.endswith("+coarse"),
                       local_coarse=local_coarse, local_search_pre=local_search_pre, nlist=nlist, nprobe=nprobe)
     rng = np.random.default_rng(100)
@@ -84,7 +118,7 @@ def _worker(rank, world, port, mode, ret):
 
 
 @pytest.mark.parametrize("world,mode", [(2, "own"), (2, "replicated"), (3, "own"), (2, "own+coarse"),
-                                        (3, "replicated+coarse")])
+                                        (3, "replicated+coarse"), (2, "refine"), (3, "refine")])
 def test_sharded_equals_unsharded(world, mode):
     from oracle import ivfpq_oracle as O
     O.build()
