@@ -18,5 +18,4 @@ for _ in range(3): flat.rerank(q, cand, 10, D, I)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): flat.rerank(q, cand, 10, D, I)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-pf = os.environ.get("MI_GATHER_PF", "4")
-print(f"PF {pf}: rerank 1024 x 640 of {n} rows: {dt * 1e3:.3f} ms  ({1024 * 640 * 4096 / dt / 1e12:.2f} TB/s)")
+print(f"rerank 1024 x 640 of {n} rows: {dt * 1e3:.3f} ms  ({1024 * 640 * 4096 / dt / 1e12:.2f} TB/s)")
