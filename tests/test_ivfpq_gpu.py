@@ -772,3 +772,38 @@ def test_fuzz_large_paths(faiss, oracle, monkeypatch):
         ctx = dict(trial=trial, d=d, M=M, nlist=nlist, n=n, nq=nq, k=k, nprobe=nprobe, res=by_residual, two=two)
         assert np.array_equal(I, Ie), ctx
         assert np.array_equal(bits(D), bits(De)), ctx
+
+
+def test_sharded_index_with_refine_and_id_map_rccl_world1(faiss, oracle):
+    """ShardedIndex over an IndexRefineFlat shard on the real RCCL path (world size 1: the
+    collectives and the HIP merge run, the shard is the whole index): local result ids are
+    positions; id_map turns them into the caller's global numbering before the exchange."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from abstracts_search_amd.shards import ShardedIndex
+    d, M, nlist, n, nq, k = 64, 8, 32, 6000, 24, 10
+    cent, cb, x, q = random_problem(41, d, M, nlist, n, nq)
+    idx = faiss.IndexRefineFlat(make_index(faiss, cent, cb))
+    idx.add(x)
+    faiss.ParameterSpace().set_index_parameters(idx, "nprobe=6,k_factor_rf=4")
+    rows = torch.arange(n, dtype=torch.int64) * 3 + 1            # the "global" numbering of this shard
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sh = ShardedIndex(idx, id_map=rows.cuda())
+        qd = torch.from_numpy(q).cuda()
+        D, I = sh.search(qd, k)
+        Dr, Ir = sh.search_replicated(qd, k)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    ln, codes = oracle.encode(x, cent, cb, True)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(n), nlist)
+    _, cand = oracle.search(q, cent, cb, off, lc, li, 6, k * 4, True)
+    De, Ie = oracle.rerank(q, x, cand, k)
+    Ie = np.where(Ie >= 0, Ie * 3 + 1, -1)
+    for Dg, Ig in ((D, I), (Dr, Ir)):
+        assert np.array_equal(Ig.cpu().numpy(), Ie)
+        assert np.array_equal(bits(Dg.cpu().numpy()), bits(De))
