@@ -6,7 +6,9 @@ Makefile:25, Makefile:32) and its query-time ``app.py`` (reference
 README.md:28): ``index_factory``, ``IndexIVFPQ.{train,add,add_with_ids,search,
 reset}``, ``nprobe``, ``ntotal``, ``is_trained``, ``IndexFlatIP``,
 ``write_index`` / ``read_index`` (faiss's file format), ``ParameterSpace`` /
-``OperatingPoints`` / ``IntersectionCriterion`` (autotune.py: the `tune` step).
+``OperatingPoints`` / ``IntersectionCriterion`` (autotune.py: the `tune` step),
+``IndexRefineFlat``, ``SearchParametersIVF`` / ``IndexRefineSearchParameters``
+(``search(x, k, params=...)``).
 
 Everything numeric happens in HIP kernels behind the C ABI of
 ``include/mi_ivfpq.h``; this file only checks arguments, moves pointers and
@@ -388,9 +390,15 @@ class IndexIVFPQ:
         return codes, ids
 
     # -- search ------------------------------------------------------------
-    def search(self, x, k: int, nprobe: int | None = None):
+    def search(self, x, k: int, nprobe: int | None = None, params=None):
+        """faiss's search(x, k, params=SearchParametersIVF(nprobe=...)): per-call parameters
+        override the index attribute (`nprobe=` is this mirror's shorthand for the same)."""
         x = _as_f32(x, self.d)
         assert k > 0
+        if params is not None:
+            if getattr(params, "sel", None) is not None or getattr(params, "max_codes", 0):
+                raise NotImplementedError("SearchParametersIVF: only nprobe is implemented on the MI355X path")
+            nprobe = getattr(params, "nprobe", nprobe)
         nprobe = int(self.nprobe if nprobe is None else nprobe)
         nq = x.shape[0]
         if _is_torch(x) and x.is_cuda:
@@ -540,16 +548,37 @@ class IndexRefineFlat:
         self.base_index.reset()
         self.refine_index.reset()
 
-    def search(self, x, k: int):
-        k_base = int(k * self.k_factor)
+    def search(self, x, k: int, params=None):
+        """params: faiss.IndexRefineSearchParameters(k_factor=..., base_index_params=...)."""
+        k_factor = self.k_factor if params is None else getattr(params, "k_factor", self.k_factor)
+        k_base = int(k * k_factor)
         k_base = max(k, k_base - k_base % k)      # the re-ranking step takes whole multiples of k
-        _, cand = self.base_index.search(x, k_base)
+        _, cand = self.base_index.search(x, k_base, params=getattr(params, "base_index_params", None))
         return self.refine_index.rerank(x, cand, k)
 
     def search_into(self, x, k: int, D, I, cand_D, cand_I, stream: int | None = None):
         """search() into caller-owned CUDA tensors (cand_D / cand_I: [nq, k_base] scratch)."""
         self.base_index.search_into(x, int(cand_I.shape[1]), cand_D, cand_I, None, stream)
         self.refine_index.rerank(x, cand_I, k, D, I, stream)
+
+
+class SearchParameters:
+    """faiss.SearchParameters (base class; `sel` = IDSelector is not implemented here)."""
+
+    def __init__(self, sel=None):
+        self.sel = sel
+
+
+class SearchParametersIVF(SearchParameters):
+    def __init__(self, sel=None, nprobe: int = 1, max_codes: int = 0, quantizer_params=None):
+        super().__init__(sel)
+        self.nprobe, self.max_codes, self.quantizer_params = int(nprobe), int(max_codes), quantizer_params
+
+
+class IndexRefineSearchParameters(SearchParameters):
+    def __init__(self, sel=None, k_factor: float = 1.0, base_index_params=None):
+        super().__init__(sel)
+        self.k_factor, self.base_index_params = float(k_factor), base_index_params
 
 
 _FACTORY_RE = re.compile(r"^IVF(\d+)(?:_HNSW\d+)?,PQ(\d+)(?:x(\d+))?(,RFlat)?$")

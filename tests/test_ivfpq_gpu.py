@@ -173,6 +173,19 @@ def test_refine_flat_matches_oracle(faiss, oracle):
     assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De))
     Dt, It = idx.search(torch.from_numpy(q[:5]).cuda(), k)
     assert np.array_equal(It.cpu().numpy(), Ie) and np.array_equal(bits(Dt.cpu().numpy()), bits(De))
+    # per-call parameters (faiss.SearchParametersIVF / IndexRefineSearchParameters)
+    idx.nprobe, idx.k_factor = 1, 1.0
+    p = faiss.IndexRefineSearchParameters(k_factor=4, base_index_params=faiss.SearchParametersIVF(nprobe=8))
+    D, I = idx.search(q, k, params=p)
+    _, cand = oracle.search(q, cent, cb, off, lc, li, 8, k * 4, True)
+    De, Ie = oracle.rerank(q, x, cand, k)
+    assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De))
+    assert idx.nprobe == 1 and idx.k_factor == 1.0            # the index attributes are untouched
+    Db, Ib = idx.base_index.search(q, k, params=faiss.SearchParametersIVF(nprobe=8))
+    Dbe, Ibe = oracle.search(q, cent, cb, off, lc, li, 8, k, True)
+    assert np.array_equal(Ib, Ibe) and np.array_equal(bits(Db), bits(Dbe))
+    with pytest.raises(NotImplementedError):
+        idx.base_index.search(q, k, params=faiss.SearchParametersIVF(nprobe=8, max_codes=100))
     f = faiss.index_factory(d, "IVF64,PQ16,RFlat", faiss.METRIC_INNER_PRODUCT)
     assert isinstance(f, faiss.IndexRefineFlat) and f.base_index.nlist == 64
 
