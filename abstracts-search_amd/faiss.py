@@ -602,6 +602,61 @@ def index_factory(d: int, description: str, metric: int = METRIC_L2, device: int
     return IndexRefineFlat(index) if m.group(4) else index
 
 
+def normalize_L2(x) -> None:
+    """faiss.normalize_L2: rows of a float32 matrix scaled to unit length, in place (what a
+    cosine-similarity pipeline does before an inner-product index; zero rows stay zero)."""
+    if _is_torch(x):
+        n = x.norm(dim=1, keepdim=True)
+        x.div_(n.masked_fill_(n == 0, 1.0))
+        return
+    if not (isinstance(x, np.ndarray) and x.dtype == np.float32 and x.ndim == 2 and x.flags.c_contiguous):
+        raise TypeError("normalize_L2 needs a C-contiguous float32 matrix")
+    n = np.sqrt(np.einsum("ij,ij->i", x, x, dtype=np.float32))
+    n[n == 0] = 1.0
+    x /= n[:, None]
+
+
+# ---- faiss-gpu's cloning entry points: the index already lives on the GPU, so they are
+# identities (kept so that code written for faiss-cpu + faiss-gpu runs unchanged) ----
+class StandardGpuResources:
+    def noTempMemory(self): pass
+    def setTempMemory(self, nbytes): pass
+    def setDefaultNullStreamAllDevices(self): pass
+
+
+class GpuClonerOptions:
+    def __init__(self):
+        self.useFloat16 = False
+        self.useFloat16CoarseQuantizer = False
+        self.usePrecomputed = False
+        self.indicesOptions = 0
+        self.reserveVecs = 0
+        self.storeTransposed = False
+        self.verbose = False
+
+
+class GpuMultipleClonerOptions(GpuClonerOptions):
+    def __init__(self):
+        super().__init__()
+        self.shard = False
+
+
+def index_cpu_to_gpu(res, device: int, index, options=None):
+    if getattr(index, "device", device) != device:
+        raise NotImplementedError("the index lives on the device it was created on (device=%d)" % index.device)
+    return index
+
+
+def index_cpu_to_all_gpus(index, co=None, ngpu: int = -1):
+    """One process drives one GPU here; multi-GPU search is `shards.ShardedIndex` (one
+    process per GPU over RCCL), not an in-process replica set."""
+    return index
+
+
+def index_gpu_to_cpu(index):
+    return index
+
+
 def extract_index_ivf(index):
     return index
 
