@@ -820,3 +820,32 @@ def test_sharded_index_with_refine_and_id_map_rccl_world1(faiss, oracle):
     for Dg, Ig in ((D, I), (Dr, Ir)):
         assert np.array_equal(Ig.cpu().numpy(), Ie)
         assert np.array_equal(bits(Dg.cpu().numpy()), bits(De))
+
+
+def test_two_stage_coarse_full_cfg4_size(faiss, monkeypatch):
+    """BASELINE configs[3]'s coarse quantiser at full size -- 1024 queries x 65536 centroids x
+    1024 dimensions, unit-norm clustered data -- through the default (two-stage) dispatch and
+    through the exact f32 GEMM: the same lists and the same scores, bit for bit."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(5)
+    d, nlist, nq = 1024, 65536, 1024
+    base = torch.randn((4096, d), generator=g, device="cuda")
+    cent = base[torch.randint(0, 4096, (nlist,), generator=g, device="cuda")] + 0.6 * torch.randn((nlist, d), generator=g, device="cuda")
+    cent = (cent / cent.norm(dim=1, keepdim=True)).contiguous()
+    q = cent[torch.randint(0, nlist, (nq,), generator=g, device="cuda")] + 0.3 / 32 * torch.randn((nq, d), generator=g, device="cuda")
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    cb = torch.randn((64, 256, 16), generator=g, device="cuda") * 0.05
+    idx = faiss.IndexIVFPQ(d, nlist, 64, 8, faiss.METRIC_INNER_PRODUCT)
+    idx.set_centroids(cent)
+    idx.set_codebook(cb)
+    qh = q.cpu().numpy()
+    out = {}
+    for mode in (None, "0"):
+        if mode is None:
+            monkeypatch.delenv("MI_TWO_STAGE", raising=False)
+        else:
+            monkeypatch.setenv("MI_TWO_STAGE", mode)
+        out[mode] = [idx.coarse_and_lut(qh, nprobe, want_lut=False)[:2] for nprobe in (1, 16, 64)]
+    for (cI1, cD1), (cI0, cD0) in zip(out[None], out["0"]):
+        assert np.array_equal(cI1, cI0) and np.array_equal(bits(cD1), bits(cD0))
+        assert (cI1 >= 0).all() and (np.diff(cD1, axis=1) <= 0).all()
