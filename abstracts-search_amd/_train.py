@@ -63,9 +63,13 @@ def kmeans_l2(x, k: int, niter: int, seed: int, device: int, verbose: bool = Fal
     c = x[perm].clone()
     if n <= k:  # degenerate: fewer points than centroids
         c = torch.cat([c, c[torch.randint(0, max(n, 1), (k - c.shape[0],), generator=g).to(x.device)]])
-    xa = torch.cat([x, torch.ones(n, 1, device=x.device), torch.zeros(n, 3, device=x.device)], 1).contiguous()
+    # zero columns after the augmenting one add exact zeros to the end of every fmaf chain (the
+    # scores do not change); padding to a multiple of 128 columns lets big problems take the
+    # two-stage assignment (f16 MFMA scores + exact re-scoring, bit-identical arg max)
+    pad = 127 if d % 128 == 0 and k >= 8192 else 3
+    xa = torch.cat([x, torch.ones(n, 1, device=x.device), torch.zeros(n, pad, device=x.device)], 1).contiguous()
     for it in range(niter):
-        ca = torch.cat([c, -0.5 * (c * c).sum(1, keepdim=True), torch.zeros(k, 3, device=x.device)], 1).contiguous()
+        ca = torch.cat([c, -0.5 * (c * c).sum(1, keepdim=True), torch.zeros(k, pad, device=x.device)], 1).contiguous()
         a = _assign_ip(xa, ca, device)
         sums = torch.zeros(k, d, device=x.device).index_add_(0, a, x)
         cnt = torch.bincount(a, minlength=k).to(torch.float32)
