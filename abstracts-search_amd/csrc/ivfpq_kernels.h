@@ -1344,32 +1344,32 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
     bool bad = !(margin < 3.0e38f);   // NaN / inf query
     auto exact = [&](int col) -> float {
         // d % 128 == 0 (host).  The centroid row is streamed through two register sets of
-        // 16 x 16 B, named (not copied: a copy would make hipcc wait for the newest loads), so
+        // 8 x 16 B, named (not copied: a copy would make hipcc wait for the newest loads), so
         // the loads of one set are in flight while the chain -- d dependent fmafs -- runs on
         // the other.
         const float4 *cp = reinterpret_cast<const float4 *>(a.cent + (size_t)col * d);
         const int n4 = d >> 2;
-        float4 A[16], B[16];
+        float4 A[8], B[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) A[i] = cp[i];
+        for (int i = 0; i < 8; ++i) A[i] = cp[i];
         float acc = 0.f;
-        for (int k4 = 0; k4 < n4; k4 += 32) {
+        for (int k4 = 0; k4 < n4; k4 += 16) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) B[i] = cp[k4 + 16 + i];
+            for (int i = 0; i < 8; ++i) B[i] = cp[k4 + 8 + i];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 const float4 qv = *reinterpret_cast<const float4 *>(qs + 4 * (k4 + i));
                 acc = __builtin_fmaf(qv.x, A[i].x, acc);
                 acc = __builtin_fmaf(qv.y, A[i].y, acc);
                 acc = __builtin_fmaf(qv.z, A[i].z, acc);
                 acc = __builtin_fmaf(qv.w, A[i].w, acc);
             }
-            const int nx = min(k4 + 32, n4 - 16);   // last round: a harmless re-read
+            const int nx = min(k4 + 16, n4 - 8);   // last round: a harmless re-read
 #pragma unroll
-            for (int i = 0; i < 16; ++i) A[i] = cp[nx + i];
+            for (int i = 0; i < 8; ++i) A[i] = cp[nx + i];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float4 qv = *reinterpret_cast<const float4 *>(qs + 4 * (k4 + 16 + i));
+            for (int i = 0; i < 8; ++i) {
+                const float4 qv = *reinterpret_cast<const float4 *>(qs + 4 * (k4 + 8 + i));
                 acc = __builtin_fmaf(qv.x, B[i].x, acc);
                 acc = __builtin_fmaf(qv.y, B[i].y, acc);
                 acc = __builtin_fmaf(qv.z, B[i].z, acc);
