@@ -225,7 +225,7 @@ struct mi_encoder {
     std::map<std::string, bool> loaded;
     // workspaces
     DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_ids, ws_pos, ws_meta, ws_out, ws_stage;
-    size_t vt_zeroed = 0;
+    size_t vt_zeroed = 0, att_zeroed = 0;
     bool tiled_ok = false;   // fragment-major weight copies are current
     // profiling
     bool prof = false;
@@ -378,6 +378,16 @@ void run_stack(mi_encoder *h, const Batch &b, hipStream_t st) {
         h->vt_zeroed = h->ws_vt.cap;
     }
     bf16_t *att = h->ws_att.as<bf16_t>((size_t)T * h->q_cols);
+    if (h->att_zeroed != h->ws_att.cap) {
+        // The attention kernel writes the rows of real tokens only; the rows of padding tokens
+        // (between packed sequences, up to T_pad) feed the output projection and from there the
+        // padding rows of the residual stream, K and V^T -- which neighbouring real tokens do
+        // multiply by their masked (exactly zero) probabilities: 0 x NaN = NaN.  Recycled device
+        // memory is not zero, so a fresh buffer is cleared once; afterwards it only ever holds
+        // finite values.
+        MI_HIP(hipMemsetAsync(h->ws_att.p, 0, h->ws_att.cap, st));
+        h->att_zeroed = h->ws_att.cap;
+    }
     bf16_t *hb = h->ws_h.as<bf16_t>((size_t)T * I);
 
     // few tokens (a query, or a handful): the GEMMs stream the weights once and are bound by how
