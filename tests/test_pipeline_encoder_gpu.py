@@ -1,7 +1,13 @@
 """GPU parity tests of the encoder: HIP kernels (through the C ABI) vs plain
 PyTorch fp32 references of the same ops and vs the oracle / golden tensors.
 Tolerances: bf16 operands with f32 accumulation -> relative 1e-2 on GEMM
-outputs; embeddings within 1e-3 cosine (BASELINE.json north star)."""
+outputs; embeddings within 1e-3 cosine (BASELINE.json north star).
+
+The file name sorts AFTER test_ivfpq_gpu.py on purpose: the encoder must give the same
+embeddings in a process that has searched an index first (a serving process does both).  Its
+workspaces then come out of recycled device memory; an attention-output buffer whose padding
+rows were never written turned embeddings into NaN in exactly that order (0 x NaN in the
+masked part of P.V) while the suite ran the encoder tests first and stayed green."""
 import os
 from dataclasses import replace
 
@@ -39,6 +45,44 @@ def test_gemm_bf16_vs_torch_fp32(st, M, N, K):
 
 def _split(ids, cu):
     return [ids[cu[i]:cu[i + 1]].tolist() for i in range(len(cu) - 1)]
+
+
+def test_recycled_device_memory_does_not_poison_padding_rows(st, gold):
+    """Workspaces come from recycled device memory, not from zeroed pages: device buffers full
+    of NaN are released by an index of the same process, then a new encoder allocates.  Padding
+    rows (between packed sequences) must still hold finite values everywhere a real token's
+    masked attention weights -- exact zeros -- multiply them."""
+    import gc
+    import abstracts_search_amd.faiss as faiss
+    from oracle import encoder_oracle as E
+    import torch
+    # what an index that lived in the same process leaves behind: ids of -1, scores of -FLT_MAX
+    # (as bf16 pairs: NaN and -inf patterns) in buffers that go back to the allocator
+    rng = np.random.default_rng(0)
+    d, nlist, n = 64, 32, 12000
+    cent = rng.standard_normal((nlist, d)).astype(np.float32)
+    cb = (0.3 * rng.standard_normal((8, 256, 8))).astype(np.float32)
+    x = (cent[rng.integers(0, nlist, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+    base = faiss.IndexIVFPQ(d, nlist, 8, 8, faiss.METRIC_INNER_PRODUCT)
+    base.set_centroids(cent)
+    base.set_codebook(cb)
+    idx = faiss.IndexRefineFlat(base)
+    idx.add(x)
+    for nprobe, kf in ((1, 1), (4, 4), (16, 4)):
+        idx.nprobe, idx.k_factor = nprobe, kf
+        idx.search(x[:64], 10)
+        idx.search(torch.from_numpy(x[:64]).cuda(), 10)
+    torch.cuda.synchronize()
+    del idx, base
+    gc.collect()
+    W = E.synth_weights(E.TINY, int(gold["seed"]))
+    model = st.SentenceTransformer(config=E.TINY.to_dict(), weights=W)
+    toks = _split(gold["ids"], gold["cu_seqlens"])
+    hs = model.last_hidden_state(toks)
+    ref = gold["hidden_bidir"]
+    assert np.isfinite(hs).all()
+    cos = (hs * ref).sum(1) / (np.linalg.norm(hs, axis=1) * np.linalg.norm(ref, axis=1))
+    assert cos.min() > 1 - 1e-3, cos.min()
 
 
 @pytest.mark.parametrize("causal", [False, True])
