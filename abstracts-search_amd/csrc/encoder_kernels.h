@@ -18,9 +18,12 @@
 //
 // Tokens are packed; every sequence starts at a multiple of 8 tokens so that
 // rows of the transposed V buffer are 16-byte aligned, and T_pad is a multiple
-// of 128 (GEMM tile).  Padding tokens compute garbage that is never read by a
-// real token: attention masks keys >= the sequence length, pooling walks only
-// the real tokens.
+// of 128 (GEMM tile).  Padding tokens compute values no real token uses --
+// attention masks keys >= the sequence length, pooling walks only the real
+// tokens -- but those values must stay FINITE: a masked key's probability is an
+// exact zero that still multiplies its V row in the P.V MFMA (0 x NaN = NaN).
+// Hence padding ids embed token 0, the V^T slack and the attention-output
+// buffer (whose padding rows no kernel writes) are cleared when allocated.
 #pragma once
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
