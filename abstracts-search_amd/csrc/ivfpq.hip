@@ -348,15 +348,21 @@ struct SearchWS {
 
 struct mi_index {
     int d = 0, nlist = 0, M = 0, dsub = 0, metric = 0, by_residual = 1, device = 0;
+    int nprobe_attr = 1;   // faiss's index.nprobe as stored in / restored from index files (search takes nprobe per call)
     bool has_coarse = false, has_codebook = false;
     DevBuf centroids, codebook;
     // two-stage coarse quantiser: f16 copy of the centroids, their largest norm
     DevBuf cent16, cmax_dev;
     float cmax = 0.f, cscale = 1.f;
     bool cent16_ok = false;
-    // master copy of the inverted lists (insertion order, row-major codes)
-    std::vector<std::vector<uint8_t>> h_codes;
-    std::vector<std::vector<int64_t>> h_ids;
+    // master copy of the inverted lists: an append log in HBM, insertion order (codes row-major
+    // [n][M], list number, slot inside the list, id) -- see "Inverted-list maintenance" in
+    // ivfpq_kernels.h.  d_cnt[l] = current length of list l; h_len mirrors it on the host when
+    // len_ok.  Nothing proportional to ntotal lives on the host.
+    DevBuf log_codes, log_list, log_pos, log_ids, d_cnt;
+    int64_t log_cap = 0;
+    std::vector<int32_t> h_len;
+    bool len_ok = true;
     int64_t ntotal = 0;
     bool dirty = true;
     // device image (group-interleaved, see ivfpq_kernels.h)
@@ -399,52 +405,88 @@ void require_trained(mi_index *h) {
     MI_REQUIRE(h->has_coarse && h->has_codebook, "index is not trained (set_coarse/set_codebook)");
 }
 
-// rebuild the device image of the inverted lists from the host master copy
+// host mirror of the list lengths
+void refresh_len(mi_index *h) {
+    if (h->len_ok) return;
+    h->h_len.resize((size_t)h->nlist);
+    MI_HIP(hipMemcpy(h->h_len.data(), h->d_cnt.p, (size_t)h->nlist * 4, hipMemcpyDeviceToHost));
+    h->len_ok = true;
+}
+
+// room for `need` entries in the append log (grows by half, contents preserved)
+void ensure_log_cap(mi_index *h, int64_t need) {
+    if (need <= h->log_cap) return;
+    const int64_t cap = std::max<int64_t>(need, std::max<int64_t>(h->log_cap + h->log_cap / 2, 4096));
+    auto grow = [&](DevBuf &b, size_t elem) {
+        DevBuf nb;
+        nb.reserve((size_t)cap * elem);
+        if (h->ntotal) MI_HIP(hipMemcpyAsync(nb.p, b.p, (size_t)h->ntotal * elem, hipMemcpyDeviceToDevice, nullptr));
+        MI_HIP(hipStreamSynchronize(nullptr));
+        std::swap(nb.p, b.p);
+        std::swap(nb.cap, b.cap);
+    };
+    grow(h->log_codes, (size_t)h->M);
+    grow(h->log_list, 4);
+    grow(h->log_pos, 4);
+    grow(h->log_ids, 8);
+    h->log_cap = cap;
+}
+
+// Entries [ntotal, ntotal + n) of the log have codes / list numbers / ids in place: give them
+// their slots (insertion order) and count them.  Stream-ordered chunks of <= 65536.
+void commit_log_entries(mi_index *h, int64_t n, hipStream_t st) {
+    int32_t *cnt = h->d_cnt.get<int32_t>();
+    for (int64_t c0 = 0; c0 < n; c0 += 65536) {
+        const int m = (int)std::min<int64_t>(65536, n - c0);
+        const int32_t *ln = h->log_list.get<int32_t>() + h->ntotal + c0;
+        hipLaunchKernelGGL(list_rank_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, ln, m, cnt,
+                           h->log_pos.get<int32_t>() + h->ntotal + c0);
+        hipLaunchKernelGGL(list_count_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, ln, m, cnt);
+        MI_HIP(hipGetLastError());
+    }
+    h->ntotal += n;
+    h->dirty = true;
+    h->len_ok = false;
+}
+
+// rebuild the group-interleaved device image of the inverted lists from the log
 void sync_lists(mi_index *h) {
     if (!h->dirty) return;
+    refresh_len(h);
     const int nlist = h->nlist, M = h->M, NCH = h->nch();
-    std::vector<int32_t> goff(nlist + 1, 0), len(nlist, 0);
+    std::vector<int32_t> goff(nlist + 1, 0);
     int64_t g = 0;
     for (int l = 0; l < nlist; ++l) {
         goff[l] = (int32_t)g;
-        int64_t n = (int64_t)h->h_ids[l].size();
-        MI_REQUIRE(n < ((int64_t)1 << 31), "list too long");
-        len[l] = (int32_t)n;
-        g += (n + 63) / 64;
+        g += ((int64_t)h->h_len[l] + 63) / 64;
         MI_REQUIRE(g * 64 < ((int64_t)1 << 32), "more than 2^32 padded codes on one device");
     }
     goff[nlist] = (int32_t)g;
     h->ngroups = g;
     h->cap_nprobe = -1;
     const size_t gbytes = (size_t)NCH * 1024;
-    std::vector<uint8_t> codes((size_t)std::max<int64_t>(g, 1) * gbytes, 0);
-    std::vector<int64_t> ids((size_t)std::max<int64_t>(g, 1) * 64, -1);
-    for (int l = 0; l < nlist; ++l) {
-        const uint8_t *src = h->h_codes[l].data();
-        const int64_t n = len[l];
-        for (int64_t e = 0; e < n; ++e) {
-            const size_t grp = (size_t)goff[l] + (size_t)(e >> 6);
-            const int lane = (int)(e & 63);
-            uint8_t *dst = codes.data() + grp * gbytes + (size_t)lane * 16;
-            const uint8_t *c = src + (size_t)e * M;
-            for (int ch = 0; ch < NCH; ++ch)
-                std::memcpy(dst + (size_t)ch * 1024, c + ch * 16, (size_t)std::min(16, M - ch * 16));
-            ids[grp * 64 + lane] = h->h_ids[l][e];
-        }
+    const size_t ng = (size_t)std::max<int64_t>(g, 1);
+    uint8_t *img = static_cast<uint8_t *>(h->d_codes.reserve(ng * gbytes));
+    int64_t *img_ids = static_cast<int64_t *>(h->d_ids.reserve(ng * 64 * 8));
+    MI_HIP(hipMemsetAsync(img, 0, ng * gbytes, nullptr));
+    MI_HIP(hipMemsetAsync(img_ids, 0xFF, ng * 64 * 8, nullptr));   // every id -1
+    MI_HIP(hipMemcpyAsync(h->d_goff.reserve(goff.size() * 4), goff.data(), goff.size() * 4, hipMemcpyHostToDevice, nullptr));
+    MI_HIP(hipMemcpyAsync(h->d_len.reserve((size_t)nlist * 4), h->d_cnt.p, (size_t)nlist * 4, hipMemcpyDeviceToDevice, nullptr));
+    if (h->ntotal) {
+        const int64_t threads = h->ntotal * NCH;
+        hipLaunchKernelGGL(build_image_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr,
+                           h->log_codes.get<uint8_t>(), h->log_list.get<int32_t>(), h->log_pos.get<int32_t>(),
+                           h->log_ids.get<int64_t>(), h->ntotal, h->d_goff.get<int32_t>(), M, NCH, img, img_ids);
+        MI_HIP(hipGetLastError());
     }
-    MI_HIP(hipMemcpy(h->d_codes.reserve(codes.size()), codes.data(), codes.size(), hipMemcpyHostToDevice));
-    MI_HIP(hipMemcpy(h->d_ids.reserve(ids.size() * 8), ids.data(), ids.size() * 8, hipMemcpyHostToDevice));
-    MI_HIP(hipMemcpy(h->d_goff.reserve(goff.size() * 4), goff.data(), goff.size() * 4, hipMemcpyHostToDevice));
-    MI_HIP(hipMemcpy(h->d_len.reserve(len.size() * 4), len.data(), len.size() * 4, hipMemcpyHostToDevice));
+    MI_HIP(hipStreamSynchronize(nullptr));   // searches run on other (non-blocking) streams
     h->dirty = false;
 }
 
-// coarse assign + PQ encode of n vectors (device pointer xdev); results stay in
-// ws_assign / ws_codes on the device.
-void encode_chunk(mi_index *h, const float *xdev, int64_t n, hipStream_t st) {
+// coarse assign + PQ encode of n vectors (device pointer xdev) into assign [n] / codes [n][M]
+// (device pointers: the add() path passes the tail of the append log).
+void encode_chunk(mi_index *h, const float *xdev, int64_t n, int32_t *assign, uint8_t *codes, hipStream_t st) {
     float *scores = h->ws_scores.as<float>((size_t)n * h->nlist);
-    int32_t *assign = h->ws_assign.as<int32_t>((size_t)n);
-    uint8_t *codes = h->ws_codes.as<uint8_t>((size_t)n * h->M);
     if (two_stage_wanted(n, h->nlist, h->d, 1)) {
         if (!h->cent16_ok) {
             prepare_cent16(h->centroids.get<float>(), h->nlist, h->d, h->cent16, h->cmax_dev, h->cmax, h->cscale, st);
@@ -513,8 +555,11 @@ int mi_index_create(int d, int nlist, int M, int nbits, int metric, int by_resid
         auto h = std::make_unique<mi_index>();
         h->d = d; h->nlist = nlist; h->M = M; h->dsub = dsub; h->metric = metric;
         h->by_residual = by_residual ? 1 : 0; h->device = device;
-        h->h_codes.resize(nlist);
-        h->h_ids.resize(nlist);
+        {
+            DeviceGuard dg(device);
+            MI_HIP(hipMemset(h->d_cnt.reserve((size_t)nlist * 4), 0, (size_t)nlist * 4));
+        }
+        h->h_len.assign((size_t)nlist, 0);
         *out = h.release();
     });
 }
@@ -589,8 +634,10 @@ int mi_index_ntotal(mi_index *h, int64_t *out) {
 int mi_index_reset(mi_index *h) {
     return guard([&] {
         MI_REQUIRE(h, "null argument");
-        for (auto &v : h->h_codes) std::vector<uint8_t>().swap(v);
-        for (auto &v : h->h_ids) std::vector<int64_t>().swap(v);
+        DeviceGuard dg(h->device);
+        MI_HIP(hipMemset(h->d_cnt.p, 0, (size_t)h->nlist * 4));
+        h->h_len.assign((size_t)h->nlist, 0);
+        h->len_ok = true;
         h->ntotal = 0;
         h->dirty = true;
     });
@@ -611,7 +658,7 @@ int mi_index_encode(mi_index *h, int64_t n, const float *x, int32_t *list_no, ui
                 MI_HIP(hipMemcpy(stage, xs, (size_t)m * h->d * 4, hipMemcpyHostToDevice));
                 xs = stage;
             }
-            encode_chunk(h, xs, m, nullptr);
+            encode_chunk(h, xs, m, h->ws_assign.as<int32_t>((size_t)m), h->ws_codes.as<uint8_t>((size_t)m * h->M), nullptr);
             if (list_no) MI_HIP(hipMemcpy(list_no + c0, h->ws_assign.p, (size_t)m * 4, hipMemcpyDeviceToHost));
             if (codes) MI_HIP(hipMemcpy(codes + (size_t)c0 * h->M, h->ws_codes.p, (size_t)m * h->M, hipMemcpyDeviceToHost));
         }
@@ -622,15 +669,34 @@ int mi_index_add_codes(mi_index *h, int64_t n, const int32_t *list_no, const uin
                        const int64_t *ids) {
     return guard([&] {
         MI_REQUIRE(h && (n == 0 || (list_no && codes)), "null argument");
-        for (int64_t i = 0; i < n; ++i)
-            MI_REQUIRE(list_no[i] >= 0 && list_no[i] < h->nlist, "list number out of range");
-        for (int64_t i = 0; i < n; ++i) {
-            int l = list_no[i];
-            h->h_codes[l].insert(h->h_codes[l].end(), codes + (size_t)i * h->M, codes + (size_t)(i + 1) * h->M);
-            h->h_ids[l].push_back(ids ? ids[i] : h->ntotal + i);
+        if (n == 0) return;
+        DeviceGuard dg(h->device);
+        const bool dev = is_device_ptr(list_no);
+        MI_REQUIRE(is_device_ptr(codes) == dev && (!ids || is_device_ptr(ids) == dev),
+                   "add_codes: list_no, codes and ids must be all host or all device pointers");
+        if (!dev)
+            for (int64_t i = 0; i < n; ++i)
+                MI_REQUIRE(list_no[i] >= 0 && list_no[i] < h->nlist, "list number out of range");
+        ensure_log_cap(h, h->ntotal + n);
+        const int64_t at = h->ntotal;
+        MI_HIP(hipMemcpyAsync(h->log_list.get<int32_t>() + at, list_no, (size_t)n * 4, hipMemcpyDefault, nullptr));
+        MI_HIP(hipMemcpyAsync(h->log_codes.get<uint8_t>() + (size_t)at * h->M, codes, (size_t)n * h->M, hipMemcpyDefault, nullptr));
+        if (ids) MI_HIP(hipMemcpyAsync(h->log_ids.get<int64_t>() + at, ids, (size_t)n * 8, hipMemcpyDefault, nullptr));
+        else {
+            hipLaunchKernelGGL(iota_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
+                               h->log_ids.get<int64_t>() + at, n, at);
+            MI_HIP(hipGetLastError());
         }
-        h->ntotal += n;
-        h->dirty = true;
+        commit_log_entries(h, n, nullptr);
+        if (!dev) MI_HIP(hipStreamSynchronize(nullptr));   // the caller may reuse its host buffers
+    });
+}
+
+int mi_index_reserve(mi_index *h, int64_t n) {
+    return guard([&] {
+        MI_REQUIRE(h && n >= 0, "bad argument");
+        DeviceGuard dg(h->device);
+        ensure_log_cap(h, n);
     });
 }
 
@@ -638,17 +704,18 @@ int mi_index_add(mi_index *h, int64_t n, const float *x, const int64_t *ids) {
     return guard([&] {
         MI_REQUIRE(h && (n == 0 || x), "null argument");
         require_trained(h);
+        if (n == 0) return;
         DeviceGuard dg(h->device);
-        std::vector<int64_t> ids_host;
-        if (ids && is_device_ptr(ids)) {
-            ids_host.resize((size_t)n);
-            MI_HIP(hipMemcpy(ids_host.data(), ids, (size_t)n * 8, hipMemcpyDeviceToHost));
-            ids = ids_host.data();
+        ensure_log_cap(h, h->ntotal + n);
+        const int64_t at = h->ntotal;
+        if (ids) MI_HIP(hipMemcpyAsync(h->log_ids.get<int64_t>() + at, ids, (size_t)n * 8, hipMemcpyDefault, nullptr));
+        else {
+            hipLaunchKernelGGL(iota_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
+                               h->log_ids.get<int64_t>() + at, n, at);
+            MI_HIP(hipGetLastError());
         }
         const int64_t chunk = add_chunk_size(h);
         const bool xdev = is_device_ptr(x);
-        std::vector<int32_t> a_host;
-        std::vector<uint8_t> c_host;
         for (int64_t c0 = 0; c0 < n; c0 += chunk) {
             int64_t m = std::min(chunk, n - c0);
             const float *xs = x + (size_t)c0 * h->d;
@@ -657,21 +724,12 @@ int mi_index_add(mi_index *h, int64_t n, const float *x, const int64_t *ids) {
                 MI_HIP(hipMemcpy(stage, xs, (size_t)m * h->d * 4, hipMemcpyHostToDevice));
                 xs = stage;
             }
-            encode_chunk(h, xs, m, nullptr);
-            a_host.resize((size_t)m);
-            c_host.resize((size_t)m * h->M);
-            MI_HIP(hipMemcpy(a_host.data(), h->ws_assign.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-            MI_HIP(hipMemcpy(c_host.data(), h->ws_codes.p, (size_t)m * h->M, hipMemcpyDeviceToHost));
-            for (int64_t i = 0; i < m; ++i) {
-                int l = a_host[i];
-                MI_REQUIRE(l >= 0 && l < h->nlist, "internal: bad list assignment");
-                h->h_codes[l].insert(h->h_codes[l].end(), c_host.begin() + (size_t)i * h->M,
-                                     c_host.begin() + (size_t)(i + 1) * h->M);
-                h->h_ids[l].push_back(ids ? ids[c0 + i] : h->ntotal + c0 + i);
-            }
+            // list numbers and codes are written straight into the tail of the log
+            encode_chunk(h, xs, m, h->log_list.get<int32_t>() + at + c0,
+                         h->log_codes.get<uint8_t>() + (size_t)(at + c0) * h->M, nullptr);
         }
-        h->ntotal += n;
-        h->dirty = true;
+        commit_log_entries(h, n, nullptr);
+        if (!xdev || (ids && !is_device_ptr(ids))) MI_HIP(hipStreamSynchronize(nullptr));
     });
 }
 
@@ -679,17 +737,54 @@ int mi_index_list_size(mi_index *h, int list_no, int64_t *out) {
     return guard([&] {
         MI_REQUIRE(h && out, "null argument");
         MI_REQUIRE(list_no >= 0 && list_no < h->nlist, "list number out of range");
-        *out = (int64_t)h->h_ids[list_no].size();
+        DeviceGuard dg(h->device);
+        refresh_len(h);
+        *out = (int64_t)h->h_len[(size_t)list_no];
+    });
+}
+
+int mi_index_list_sizes(mi_index *h, int64_t *sizes) {
+    return guard([&] {
+        MI_REQUIRE(h && sizes, "null argument");
+        DeviceGuard dg(h->device);
+        refresh_len(h);
+        for (int l = 0; l < h->nlist; ++l) sizes[l] = h->h_len[(size_t)l];
+    });
+}
+
+int mi_index_export_lists(mi_index *h, int list_lo, int list_hi, uint8_t *codes, int64_t *ids) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        MI_REQUIRE(0 <= list_lo && list_lo <= list_hi && list_hi <= h->nlist, "list range out of bounds");
+        DeviceGuard dg(h->device);
+        refresh_len(h);
+        std::vector<int64_t> start((size_t)(list_hi - list_lo) + 1, 0);
+        for (int l = list_lo; l < list_hi; ++l) start[(size_t)(l - list_lo) + 1] = start[(size_t)(l - list_lo)] + h->h_len[(size_t)l];
+        const int64_t rows = start.back();
+        if (rows == 0 || (!codes && !ids)) return;
+        DevBuf dstart, dc, di;
+        MI_HIP(hipMemcpyAsync(dstart.reserve(start.size() * 8), start.data(), start.size() * 8, hipMemcpyHostToDevice, nullptr));
+        const bool cdev = codes && is_device_ptr(codes), idev = ids && is_device_ptr(ids);
+        uint8_t *oc = cdev ? codes : dc.as<uint8_t>((size_t)rows * h->M);
+        int64_t *oi = idev ? ids : di.as<int64_t>((size_t)rows);
+        const int64_t threads = h->ntotal * h->nch();
+        hipLaunchKernelGGL(export_lists_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr,
+                           h->log_codes.get<uint8_t>(), h->log_list.get<int32_t>(), h->log_pos.get<int32_t>(),
+                           h->log_ids.get<int64_t>(), h->ntotal, list_lo, list_hi, dstart.get<int64_t>(), h->M, h->nch(),
+                           oc, oi);
+        MI_HIP(hipGetLastError());
+        if (codes && !cdev) MI_HIP(hipMemcpyAsync(codes, oc, (size_t)rows * h->M, hipMemcpyDeviceToHost, nullptr));
+        if (ids && !idev) MI_HIP(hipMemcpyAsync(ids, oi, (size_t)rows * 8, hipMemcpyDeviceToHost, nullptr));
+        MI_HIP(hipStreamSynchronize(nullptr));
     });
 }
 
 int mi_index_get_list(mi_index *h, int list_no, uint8_t *codes, int64_t *ids) {
-    return guard([&] {
-        MI_REQUIRE(h, "null argument");
-        MI_REQUIRE(list_no >= 0 && list_no < h->nlist, "list number out of range");
-        if (codes) std::memcpy(codes, h->h_codes[list_no].data(), h->h_codes[list_no].size());
-        if (ids) std::memcpy(ids, h->h_ids[list_no].data(), h->h_ids[list_no].size() * 8);
-    });
+    if (!h || list_no < 0 || list_no >= h->nlist) {
+        last_error() = !h ? "null argument" : "list number out of range";
+        return 1;
+    }
+    return mi_index_export_lists(h, list_no, list_no + 1, codes, ids);
 }
 
 int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_avg, int64_t *scan_bytes) {
@@ -870,7 +965,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         // sub-batches so that the rows stay under 2 GiB.
         if (h->cap_nprobe != nprobe) {
             std::vector<int64_t> g((size_t)h->nlist);
-            for (int l = 0; l < h->nlist; ++l) g[(size_t)l] = ((int64_t)h->h_ids[(size_t)l].size() + 63) / 64;
+            for (int l = 0; l < h->nlist; ++l) g[(size_t)l] = ((int64_t)h->h_len[(size_t)l] + 63) / 64;   // valid: sync_lists ran
             std::nth_element(g.begin(), g.begin() + (nprobe - 1), g.end(), std::greater<int64_t>());
             int64_t tot = 0;
             for (int i = 0; i < nprobe; ++i) tot += g[(size_t)i];
@@ -880,7 +975,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         int64_t R = h->cap_groups * 64;
         if (pre_I) {   // caller-assigned lists may repeat: nprobe times the longest list
             int64_t gmax = 1;
-            for (int l = 0; l < h->nlist; ++l) gmax = std::max(gmax, ((int64_t)h->h_ids[(size_t)l].size() + 63) / 64);
+            for (int l = 0; l < h->nlist; ++l) gmax = std::max(gmax, ((int64_t)h->h_len[(size_t)l] + 63) / 64);
             R = gmax * nprobe * 64;
         }
         const int64_t qc = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (R * 12)));
@@ -1087,6 +1182,323 @@ int mi_merge_topk(int device, int nparts, int64_t nq, int k, const float *D_part
         MI_HIP(hipMemcpyAsync(D, oD.p, n_out * 4, hipMemcpyDeviceToHost, st));
         MI_HIP(hipMemcpyAsync(I, oI.p, n_out * 8, hipMemcpyDeviceToHost, st));
         MI_HIP(hipStreamSynchronize(st));
+    });
+}
+
+// ---- write_index / read_index: faiss's binary IndexIVFPQ format ---------------------
+// (IwPQ + IndexFlat quantiser + ArrayInvertedLists `ilar` or OnDiskInvertedLists `ilod`: the
+// reference's index.faiss + ondisk.ivfdata pair, Makefile:11-12.)  Layout restated from
+// faiss's documented serialisation -- abstracts-search_amd/faiss_io.py holds the field-by-
+// field description and the same validation caveat.  Lists stream between the device log and
+// the file in bounded slabs: the host never holds more than one slab.
+
+}  // extern "C"
+
+namespace {
+
+struct FileW {
+    FILE *f = nullptr;
+    std::string name;
+    explicit FileW(const char *path) : f(std::fopen(path, "wb")), name(path) {
+        if (!f) throw Error("cannot open " + name + " for writing");
+    }
+    ~FileW() { if (f) std::fclose(f); }
+    void raw(const void *p, size_t n) {
+        if (n && std::fwrite(p, 1, n, f) != n) throw Error("short write to " + name);
+    }
+    template <class T> void one(T v) { raw(&v, sizeof(T)); }
+    void cc(const char *four) { raw(four, 4); }
+    void close() {
+        if (f && std::fclose(f) != 0) { f = nullptr; throw Error("error closing " + name); }
+        f = nullptr;
+    }
+};
+
+struct FileR {
+    FILE *f = nullptr;
+    std::string name;
+    explicit FileR(const char *path) : f(std::fopen(path, "rb")), name(path) {
+        if (!f) throw Error("cannot open " + name);
+    }
+    ~FileR() { if (f) std::fclose(f); }
+    void raw(void *p, size_t n) {
+        if (n && std::fread(p, 1, n, f) != n) throw Error(name + ": truncated file");
+    }
+    template <class T> T one() { T v; raw(&v, sizeof(T)); return v; }
+    std::string cc() { char c[4]; raw(c, 4); return std::string(c, 4); }
+    void seek(uint64_t off) {
+        if (fseeko(f, (off_t)off, SEEK_SET) != 0) throw Error(name + ": seek failed");
+    }
+};
+
+void write_index_header(FileW &w, int d, int64_t ntotal, bool trained, int metric) {
+    w.one<int32_t>(d); w.one<int64_t>(ntotal); w.one<int64_t>((int64_t)1 << 20); w.one<int64_t>((int64_t)1 << 20);
+    w.one<uint8_t>(trained ? 1 : 0); w.one<int32_t>(metric);
+}
+
+struct IndexHeader { int d; int64_t ntotal; bool trained; int metric; };
+IndexHeader read_index_header(FileR &r) {
+    IndexHeader h{};
+    h.d = r.one<int32_t>(); h.ntotal = r.one<int64_t>(); (void)r.one<int64_t>(); (void)r.one<int64_t>();
+    h.trained = r.one<uint8_t>() != 0; h.metric = r.one<int32_t>();
+    if (h.metric > 1) (void)r.one<float>();
+    return h;
+}
+
+// lists [lo, hi) such that a slab stays under ~256 MiB of codes
+int slab_end(const std::vector<int32_t> &len, int lo, int M) {
+    int64_t rows = 0;
+    int hi = lo;
+    while (hi < (int)len.size() && (hi == lo || (rows + len[(size_t)hi]) * (int64_t)(M + 8) <= ((int64_t)256 << 20))) rows += len[(size_t)hi++];
+    return hi;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_index_save(mi_index *h, const char *fname, const char *ondisk_data) {
+    return guard([&] {
+        MI_REQUIRE(h && fname, "null argument");
+        DeviceGuard dg(h->device);
+        refresh_len(h);
+        const int d = h->d, nlist = h->nlist, M = h->M;
+        const bool trained = h->has_coarse && h->has_codebook;
+        FileW w(fname);
+        w.cc("IwPQ");
+        write_index_header(w, d, h->ntotal, trained, h->metric);
+        w.one<uint64_t>((uint64_t)nlist); w.one<uint64_t>((uint64_t)std::max(1, h->nprobe_attr));
+        w.cc(h->metric == MI_METRIC_INNER_PRODUCT ? "IxFI" : "IxF2");
+        write_index_header(w, d, h->has_coarse ? nlist : 0, true, h->metric);
+        {
+            std::vector<float> c(h->has_coarse ? (size_t)nlist * d : 0);
+            if (h->has_coarse) MI_HIP(hipMemcpy(c.data(), h->centroids.p, c.size() * 4, hipMemcpyDeviceToHost));
+            w.one<uint64_t>(c.size()); w.raw(c.data(), c.size() * 4);
+        }
+        w.one<int8_t>(0); w.one<uint64_t>(0);                         // DirectMap::NoMap, empty array
+        w.one<uint8_t>(h->by_residual ? 1 : 0); w.one<uint64_t>((uint64_t)M);
+        w.one<uint64_t>((uint64_t)d); w.one<uint64_t>((uint64_t)M); w.one<uint64_t>(8);
+        {
+            std::vector<float> c(h->has_codebook ? (size_t)M * 256 * h->dsub : 0);
+            if (h->has_codebook) MI_HIP(hipMemcpy(c.data(), h->codebook.p, c.size() * 4, hipMemcpyDeviceToHost));
+            w.one<uint64_t>(c.size()); w.raw(c.data(), c.size() * 4);
+        }
+        std::vector<uint8_t> cbuf;
+        std::vector<int64_t> ibuf;
+        auto stream_lists = [&](FileW &out) {   // per list: codes then ids
+            for (int lo = 0; lo < nlist;) {
+                const int hi = slab_end(h->h_len, lo, M);
+                int64_t rows = 0;
+                for (int l = lo; l < hi; ++l) rows += h->h_len[(size_t)l];
+                if (rows) {
+                    cbuf.resize((size_t)rows * M); ibuf.resize((size_t)rows);
+                    if (mi_index_export_lists(h, lo, hi, cbuf.data(), ibuf.data())) throw Error(last_error());
+                    int64_t o = 0;
+                    for (int l = lo; l < hi; ++l) {
+                        const int64_t k = h->h_len[(size_t)l];
+                        out.raw(cbuf.data() + (size_t)o * M, (size_t)k * M);
+                        out.raw(ibuf.data() + o, (size_t)k * 8);
+                        o += k;
+                    }
+                }
+                lo = hi;
+            }
+        };
+        if (!ondisk_data) {
+            w.cc("ilar");
+            w.one<uint64_t>((uint64_t)nlist); w.one<uint64_t>((uint64_t)M);
+            int64_t nz = 0;
+            for (int l = 0; l < nlist; ++l) nz += h->h_len[(size_t)l] != 0;
+            if (nz > nlist / 2) {
+                w.cc("full"); w.one<uint64_t>((uint64_t)nlist);
+                for (int l = 0; l < nlist; ++l) w.one<uint64_t>((uint64_t)h->h_len[(size_t)l]);
+            } else {
+                w.cc("sprs"); w.one<uint64_t>((uint64_t)nz);
+                for (int l = 0; l < nlist; ++l)
+                    if (h->h_len[(size_t)l]) { w.one<uint64_t>((uint64_t)l); w.one<uint64_t>((uint64_t)h->h_len[(size_t)l]); }
+            }
+            stream_lists(w);
+        } else {
+            FileW dw(ondisk_data);
+            stream_lists(dw);
+            dw.close();
+            w.cc("ilod");
+            w.one<uint64_t>((uint64_t)nlist); w.one<uint64_t>((uint64_t)M);
+            w.one<uint64_t>((uint64_t)nlist);
+            uint64_t pos = 0;
+            for (int l = 0; l < nlist; ++l) {                         // {size, capacity, offset}
+                const uint64_t k = (uint64_t)h->h_len[(size_t)l];
+                w.one<uint64_t>(k); w.one<uint64_t>(k); w.one<uint64_t>(pos);
+                pos += k * (uint64_t)(M + 8);
+            }
+            w.one<uint64_t>(0);                                       // free slots
+            std::string base(ondisk_data);
+            const size_t sl = base.find_last_of('/');
+            if (sl != std::string::npos) base = base.substr(sl + 1);
+            w.one<uint64_t>(base.size()); w.raw(base.data(), base.size());
+            w.one<uint64_t>(pos);
+        }
+        w.close();
+    });
+}
+
+int mi_index_load(const char *fname, int device, mi_index **out) {
+    mi_index *h = nullptr;
+    int rc = guard([&] {
+        MI_REQUIRE(fname && out, "null argument");
+        FileR r(fname);
+        const std::string name(fname);
+        const std::string cc = r.cc();
+        if (cc == "IvPQ" || cc == "IvQR" || cc == "IwQR") throw Error(name + ": " + cc + " (legacy / refined IVFPQ) is not supported, only IwPQ");
+        if (cc != "IwPQ") throw Error(name + ": fourcc '" + cc + "' is not an IndexIVFPQ (IwPQ)");
+        const IndexHeader ih = read_index_header(r);
+        const uint64_t nlist = r.one<uint64_t>(), nprobe = r.one<uint64_t>();
+        MI_REQUIRE(nlist > 0 && nlist < ((uint64_t)1 << 31), "implausible nlist");
+        const std::string qcc = r.cc();
+        if (qcc != "IxFI" && qcc != "IxF2" && qcc != "IxFl") throw Error(name + ": coarse quantiser '" + qcc + "' is not an IndexFlat");
+        const IndexHeader qh = read_index_header(r);
+        const uint64_t ncf = r.one<uint64_t>();
+        if (qh.d != ih.d || ncf != (uint64_t)qh.ntotal * (uint64_t)ih.d) throw Error(name + ": quantiser shape mismatch");
+        if (ih.trained && (uint64_t)qh.ntotal != nlist) throw Error(name + ": quantiser holds " + std::to_string(qh.ntotal) + " centroids, nlist is " + std::to_string(nlist));
+        std::vector<float> cent((size_t)ncf);
+        r.raw(cent.data(), cent.size() * 4);
+        (void)r.one<int8_t>();
+        { const uint64_t n = r.one<uint64_t>(); std::vector<int64_t> dm((size_t)n); r.raw(dm.data(), dm.size() * 8); }
+        const bool by_res = r.one<uint8_t>() != 0;
+        const uint64_t code_size = r.one<uint64_t>();
+        const uint64_t pd = r.one<uint64_t>(), M = r.one<uint64_t>(), nbits = r.one<uint64_t>();
+        const uint64_t ncb = r.one<uint64_t>();
+        if (pd != (uint64_t)ih.d || M == 0 || ih.d % (int)M || nbits != 8 || code_size != M)
+            throw Error(name + ": unsupported PQ (d=" + std::to_string(pd) + ", M=" + std::to_string(M) + ", nbits=" + std::to_string(nbits) + ", code_size=" + std::to_string(code_size) + ")");
+        if (ncb != 0 && ncb != M * 256 * ((uint64_t)ih.d / M)) throw Error(name + ": PQ codebook has " + std::to_string(ncb) + " floats");
+        std::vector<float> cb((size_t)ncb);
+        r.raw(cb.data(), cb.size() * 4);
+        if (mi_index_create(ih.d, (int)nlist, (int)M, 8, ih.metric, by_res ? 1 : 0, device, &h)) throw Error(last_error());
+        h->nprobe_attr = (int)std::max<uint64_t>(1, std::min<uint64_t>(nprobe, nlist));
+        if (ih.trained && !cent.empty()) {
+            if (mi_index_set_coarse(h, cent.data())) throw Error(last_error());
+            if (!cb.empty() && mi_index_set_codebook(h, cb.data())) throw Error(last_error());
+        }
+        // inverted lists
+        const std::string lcc = r.cc();
+        std::vector<uint64_t> sizes((size_t)nlist, 0), caps, offs;
+        std::unique_ptr<FileR> data;
+        FileR *src = &r;
+        bool ondisk = false;
+        if (lcc == "il00") {
+            // none
+        } else if (lcc == "ilar" || lcc == "ilod") {
+            const uint64_t nl = r.one<uint64_t>(), cs = r.one<uint64_t>();
+            if (nl != nlist || cs != code_size) throw Error(name + ": inverted lists are " + std::to_string(nl) + " x " + std::to_string(cs) + " B");
+            if (lcc == "ilar") {
+                const std::string kind = r.cc();
+                const uint64_t n = r.one<uint64_t>();
+                if (kind == "full") {
+                    if (n != nlist) throw Error(name + ": " + std::to_string(n) + " list sizes for " + std::to_string(nlist) + " lists");
+                    r.raw(sizes.data(), (size_t)n * 8);
+                } else if (kind == "sprs") {
+                    for (uint64_t i = 0; i < n; ++i) {
+                        const uint64_t l = r.one<uint64_t>(), k = r.one<uint64_t>();
+                        if (l >= nlist) throw Error(name + ": sparse list number out of range");
+                        sizes[(size_t)l] = k;
+                    }
+                } else throw Error(name + ": list size encoding '" + kind + "'");
+            } else {
+                ondisk = true;
+                const uint64_t n = r.one<uint64_t>();
+                if (n != nlist) throw Error(name + ": " + std::to_string(n) + " on-disk list records for " + std::to_string(nlist) + " lists");
+                caps.resize((size_t)nlist); offs.resize((size_t)nlist);
+                for (uint64_t l = 0; l < nlist; ++l) { sizes[(size_t)l] = r.one<uint64_t>(); caps[(size_t)l] = r.one<uint64_t>(); offs[(size_t)l] = r.one<uint64_t>(); }
+                { const uint64_t nf = r.one<uint64_t>(); std::vector<uint64_t> fs((size_t)nf * 2); r.raw(fs.data(), fs.size() * 8); }
+                const uint64_t nn = r.one<uint64_t>();
+                std::string dname((size_t)nn, '\0');
+                r.raw(&dname[0], (size_t)nn);
+                (void)r.one<uint64_t>();
+                // faiss stores the path it was written with; the file travels next to the index
+                std::string dir = name;
+                const size_t sl = dir.find_last_of('/');
+                dir = sl == std::string::npos ? std::string(".") : dir.substr(0, sl);
+                std::string bn = dname;
+                const size_t s2 = bn.find_last_of('/');
+                if (s2 != std::string::npos) bn = bn.substr(s2 + 1);
+                FILE *t = std::fopen(dname.c_str(), "rb");
+                std::string path = dname;
+                if (!t) { path = dir + "/" + bn; t = std::fopen(path.c_str(), "rb"); }
+                if (!t) throw Error(name + ": on-disk list data '" + dname + "' not found (also tried " + path + ")");
+                std::fclose(t);
+                data = std::make_unique<FileR>(path.c_str());
+                src = data.get();
+            }
+        } else throw Error(name + ": inverted lists '" + lcc + "' are not supported (ilar, ilod, il00)");
+        uint64_t tot = 0;
+        for (uint64_t l = 0; l < nlist; ++l) {
+            if (sizes[(size_t)l] >= ((uint64_t)1 << 31)) throw Error(name + ": list too long");
+            tot += sizes[(size_t)l];
+        }
+        if (tot != (uint64_t)ih.ntotal) throw Error(name + ": lists hold " + std::to_string(tot) + " vectors, header says " + std::to_string(ih.ntotal));
+        if (tot) {
+            DeviceGuard dg(device);
+            ensure_log_cap(h, (int64_t)tot);
+            std::vector<int32_t> len32((size_t)nlist);
+            for (uint64_t l = 0; l < nlist; ++l) len32[(size_t)l] = (int32_t)sizes[(size_t)l];
+            std::vector<uint8_t> cbuf;
+            std::vector<int64_t> ibuf;
+            std::vector<int32_t> lbuf;
+            for (int lo = 0; lo < (int)nlist;) {
+                const int hi = slab_end(len32, lo, (int)M);
+                int64_t rows = 0;
+                for (int l = lo; l < hi; ++l) rows += len32[(size_t)l];
+                if (rows) {
+                    cbuf.resize((size_t)rows * M); ibuf.resize((size_t)rows); lbuf.resize((size_t)rows);
+                    int64_t o = 0;
+                    for (int l = lo; l < hi; ++l) {
+                        const int64_t k = len32[(size_t)l];
+                        if (!k) continue;
+                        if (ondisk) {
+                            if (sizes[(size_t)l] > caps[(size_t)l]) throw Error(name + ": list " + std::to_string(l) + " exceeds its capacity");
+                            src->seek(offs[(size_t)l]);
+                            src->raw(cbuf.data() + (size_t)o * M, (size_t)k * M);
+                            src->seek(offs[(size_t)l] + caps[(size_t)l] * M);
+                            src->raw(ibuf.data() + o, (size_t)k * 8);
+                        } else {
+                            src->raw(cbuf.data() + (size_t)o * M, (size_t)k * M);
+                            src->raw(ibuf.data() + o, (size_t)k * 8);
+                        }
+                        std::fill(lbuf.begin() + o, lbuf.begin() + o + k, (int32_t)l);
+                        o += k;
+                    }
+                    if (mi_index_add_codes(h, rows, lbuf.data(), cbuf.data(), ibuf.data())) throw Error(last_error());
+                }
+                lo = hi;
+            }
+        }
+        *out = h;
+    });
+    if (rc && h) {
+        const std::string keep = last_error();
+        (void)mi_index_destroy(h);
+        last_error() = keep;
+    }
+    return rc;
+}
+
+int mi_index_get_params(mi_index *h, int *d, int *nlist, int *M, int *nbits, int *metric, int *by_residual, int *nprobe) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        if (d) *d = h->d;
+        if (nlist) *nlist = h->nlist;
+        if (M) *M = h->M;
+        if (nbits) *nbits = 8;
+        if (metric) *metric = h->metric;
+        if (by_residual) *by_residual = h->by_residual;
+        if (nprobe) *nprobe = h->nprobe_attr;
+    });
+}
+
+int mi_index_set_nprobe(mi_index *h, int nprobe) {
+    return guard([&] {
+        MI_REQUIRE(h && nprobe >= 1, "bad argument");
+        h->nprobe_attr = nprobe;
     });
 }
 

@@ -2462,4 +2462,105 @@ __global__ void count_codes_kernel(const int32_t *__restrict__ coarse_idx, int64
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
 }
 
+
+// ---------------------------------------------------------------------
+// Inverted-list maintenance (Index.add's append; reference Makefile:25 `index fill`).
+// The master copy of the lists is an append log in HBM, insertion order:
+// codes u8 [n][M] row-major, list number i32 [n], id i64 [n], and the slot of the
+// entry inside its list, pos i32 [n] (= how many earlier entries went to the same
+// list: faiss's insertion order).  The group-interleaved image the scan streams is
+// derived from the log by one scatter pass; nothing of a 207 M-vector index ever
+// lives on the host.
+// ---------------------------------------------------------------------
+
+// pos[i] = cnt[list[i]] + #{ j < i in this chunk : list[j] == list[i] } -- deterministic
+// (no atomics decide an order).  Chunks are <= 65536 entries and stream-ordered; the
+// in-chunk rank is a brute-force count over LDS tiles read as broadcasts.
+__global__ void __launch_bounds__(256)
+    list_rank_kernel(const int32_t *__restrict__ list_no, int n, const int32_t *__restrict__ cnt,
+                     int32_t *__restrict__ pos) {
+    __shared__ __attribute__((aligned(16))) int32_t tile[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int i = b * 256 + tid;
+    const int mine = i < n ? list_no[i] : -1;
+    int r = 0;
+    for (int t = 0; t <= b; ++t) {
+        __syncthreads();
+        const int j = t * 256 + tid;
+        tile[tid] = j < n ? list_no[j] : -2;
+        __syncthreads();
+        const int4 *t4 = reinterpret_cast<const int4 *>(tile);
+        if (t < b) {
+#pragma unroll 8
+            for (int jj = 0; jj < 64; ++jj) {
+                const int4 v = t4[jj];
+                r += (v.x == mine) + (v.y == mine) + (v.z == mine) + (v.w == mine);
+            }
+        } else {  // own tile: earlier entries only
+            for (int jj = 0; jj < tid; ++jj) r += tile[jj] == mine;
+        }
+    }
+    if (i < n) pos[i] = cnt[mine] + r;
+}
+
+__global__ void __launch_bounds__(256)
+    list_count_kernel(const int32_t *__restrict__ list_no, int n, int32_t *__restrict__ cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[list_no[i]], 1);
+}
+
+__global__ void __launch_bounds__(256) iota_ids_kernel(int64_t *__restrict__ ids, int64_t n, int64_t start) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ids[i] = start + i;
+}
+
+// log -> group-interleaved image: one thread per (entry, 16-byte chunk).  The image is
+// pre-filled (codes 0, ids -1) so that the padding lanes of a list's last group are inert.
+__global__ void __launch_bounds__(256)
+    build_image_kernel(const uint8_t *__restrict__ log_codes, const int32_t *__restrict__ log_list,
+                       const int32_t *__restrict__ log_pos, const int64_t *__restrict__ log_ids, int64_t n,
+                       const int32_t *__restrict__ goff, int M, int NCH, uint8_t *__restrict__ img,
+                       int64_t *__restrict__ img_ids) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t e = t / NCH;
+    const int ch = (int)(t - e * NCH);
+    if (e >= n) return;
+    const int l = log_list[e], p = log_pos[e];
+    const size_t grp = (size_t)goff[l] + (size_t)(p >> 6);
+    const int lane = p & 63;
+    uint8_t *dst = img + (grp * NCH + ch) * 1024 + (size_t)lane * 16;
+    const uint8_t *src = log_codes + (size_t)e * M + ch * 16;
+    if ((M & 15) == 0) {
+        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+    } else {
+        const int nb = min(16, M - ch * 16);
+        for (int i = 0; i < nb; ++i) dst[i] = src[i];
+    }
+    if (ch == 0) img_ids[grp * 64 + lane] = log_ids[e];
+}
+
+// log -> the lists [list_lo, list_hi) concatenated, row-major codes, insertion order
+// (InvertedLists::get_codes / get_ids; write_index).  start[l - list_lo] = first output row
+// of list l.  One thread per (entry, 16-byte piece).
+__global__ void __launch_bounds__(256)
+    export_lists_kernel(const uint8_t *__restrict__ log_codes, const int32_t *__restrict__ log_list,
+                        const int32_t *__restrict__ log_pos, const int64_t *__restrict__ log_ids, int64_t n,
+                        int list_lo, int list_hi, const int64_t *__restrict__ start, int M, int NCH,
+                        uint8_t *__restrict__ out_codes, int64_t *__restrict__ out_ids) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t e = t / NCH;
+    const int ch = (int)(t - e * NCH);
+    if (e >= n) return;
+    const int l = log_list[e];
+    if (l < list_lo || l >= list_hi) return;
+    const int64_t row = start[l - list_lo] + log_pos[e];
+    const uint8_t *src = log_codes + (size_t)e * M + ch * 16;
+    uint8_t *dst = out_codes + (size_t)row * M + ch * 16;
+    const int nb = min(16, M - ch * 16);
+    if ((M & 15) == 0) *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+    else
+        for (int i = 0; i < nb; ++i) dst[i] = src[i];
+    if (ch == 0) out_ids[row] = log_ids[e];
+}
+
 }  // namespace mi

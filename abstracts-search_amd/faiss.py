@@ -63,6 +63,14 @@ class _Lib:
                 "mi_index_add_codes": [v, c_int64, v, v, v],
                 "mi_index_list_size": [v, c_int, POINTER(c_int64)],
                 "mi_index_get_list": [v, c_int, v, v],
+                "mi_index_list_sizes": [v, v],
+                "mi_index_export_lists": [v, c_int, c_int, v, v],
+                "mi_index_reserve": [v, c_int64],
+                "mi_index_save": [v, c_char_p, c_char_p],
+                "mi_index_load": [c_char_p, c_int, POINTER(v)],
+                "mi_index_get_params": [v, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                        POINTER(c_int), POINTER(c_int), POINTER(c_int)],
+                "mi_index_set_nprobe": [v, c_int],
                 "mi_index_search": [v, c_int64, v, c_int, c_int, v, v, v],
                 "mi_index_coarse_lut": [v, c_int64, v, c_int, v, v, v],
                 "mi_index_profile_scan": [v, c_int, v, POINTER(c_double), POINTER(c_int64)],
@@ -275,6 +283,21 @@ class IndexIVFPQ:
         _check(_Lib.get().mi_index_create(self.d, self.nlist, int(M), int(nbits), self.metric_type,
                                           int(self.by_residual), self.device, ctypes.byref(self._h)))
 
+    @classmethod
+    def _from_handle(cls, h, device: int = 0):
+        """Wrap a handle created by the library (mi_index_load)."""
+        vals = [c_int(0) for _ in range(7)]
+        _check(_Lib.get().mi_index_get_params(h, *[ctypes.byref(x) for x in vals]))
+        d, nlist, M, nbits, metric, by_res, nprobe = (x.value for x in vals)
+        self = cls.__new__(cls)
+        self.d, self.nlist, self.device = d, nlist, int(device)
+        self.metric_type, self.by_residual, self.nprobe = metric, bool(by_res), max(1, nprobe)
+        self.pq = _PQ(d, M, nbits)
+        self.cp = ClusteringParameters()
+        self.verbose = False
+        self._h = h
+        return self
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
@@ -388,6 +411,27 @@ class IndexIVFPQ:
         ids = np.empty(n, np.int64)
         _check(_Lib.get().mi_index_get_list(self._h, int(list_no), _ptr(codes), _ptr(ids)))
         return codes, ids
+
+    def list_sizes(self) -> np.ndarray:
+        """All list sizes (int64 [nlist]) in one call."""
+        out = np.empty(self.nlist, np.int64)
+        _check(_Lib.get().mi_index_list_sizes(self._h, _ptr(out)))
+        return out
+
+    def export_lists(self, list_lo: int = 0, list_hi: int | None = None):
+        """(codes [rows, M] uint8, ids [rows] int64) of the lists [list_lo, list_hi)
+        concatenated in list order, each list in insertion order (host arrays)."""
+        list_hi = self.nlist if list_hi is None else int(list_hi)
+        rows = int(self.list_sizes()[list_lo:list_hi].sum())
+        codes = np.empty((rows, self.pq.M), np.uint8)
+        ids = np.empty(rows, np.int64)
+        _check(_Lib.get().mi_index_export_lists(self._h, int(list_lo), list_hi, _ptr(codes), _ptr(ids)))
+        return codes, ids
+
+    def reserve(self, n: int):
+        """Room for n vectors in total (the lists live in HBM; a fill of known size then
+        never re-allocates while growing)."""
+        _check(_Lib.get().mi_index_reserve(self._h, int(n)))
 
     # -- search ------------------------------------------------------------
     def search(self, x, k: int, nprobe: int | None = None, params=None):
@@ -669,16 +713,8 @@ _MAGIC = "mi355x-ivfpq-v1"
 
 
 def _lists_of(index):
-    sizes = np.array([index.list_size(l) for l in range(index.nlist)], np.int64)
-    codes = np.empty((int(sizes.sum()), index.pq.M), np.uint8)
-    ids = np.empty(int(sizes.sum()), np.int64)
-    o = 0
-    for l in range(index.nlist):
-        if sizes[l]:
-            c, i = index.get_list(l)
-            codes[o:o + sizes[l]] = c
-            ids[o:o + sizes[l]] = i
-            o += sizes[l]
+    sizes = index.list_sizes()
+    codes, ids = index.export_lists()
     return sizes, codes, ids
 
 
@@ -691,16 +727,19 @@ def write_index(index, fname: str, ondisk_data: str | None = None) -> None:
     own numpy container instead."""
     if isinstance(index, IndexFlatIP):
         raise NotImplementedError("write_index: IndexFlatIP is not serialised")
+    if isinstance(index, IndexRefineFlat):
+        raise NotImplementedError("write_index: IndexRefineFlat (faiss's IxRF) is not serialised -- write "
+                                  "index.base_index; the refine stage re-reads the raw vectors at load time")
+    if not str(fname).endswith(".npz"):
+        # the C ABI streams the lists from HBM to the file slab by slab (mi_index_save)
+        _check(_Lib.get().mi_index_set_nprobe(index._h, max(1, int(index.nprobe))))
+        _check(_Lib.get().mi_index_save(index._h, str(fname).encode(),
+                                        None if ondisk_data is None else str(ondisk_data).encode()))
+        return
     sizes, codes, ids = _lists_of(index)
     trained = index.is_trained
     cent = index.get_centroids() if trained else np.zeros((0,), np.float32)
     cb = index.get_codebook() if trained else np.zeros((0,), np.float32)
-    if not str(fname).endswith(".npz"):
-        faiss_io.dump(fname, d=index.d, nlist=index.nlist, M=index.pq.M, nbits=index.pq.nbits,
-                      metric=index.metric_type, by_residual=index.by_residual, nprobe=index.nprobe,
-                      is_trained=trained, centroids=cent, codebook=cb, sizes=sizes, codes=codes, ids=ids,
-                      ondisk_data=ondisk_data)
-        return
     with open(fname, "wb") as f:
         np.savez(f, magic=np.array(_MAGIC),
                  params=np.array([index.d, index.nlist, index.pq.M, index.pq.nbits, index.metric_type,
@@ -714,15 +753,14 @@ def read_index(fname: str, device: int = 0):
     with open(fname, "rb") as f:
         head = f.read(4)
     if head != b"PK\x03\x04":
-        z = faiss_io.parse(fname)
-        index = IndexIVFPQ(z["d"], z["nlist"], z["M"], z["nbits"], z["metric"], z["by_residual"], device)
-        index.nprobe = max(1, int(z["nprobe"]))
-        if z["is_trained"]:
-            index.set_centroids(z["centroids"])
-            index.set_codebook(z["codebook"])
-        if z["ntotal"]:
-            index.add_codes(np.repeat(np.arange(z["nlist"], dtype=np.int32), z["sizes"]), z["codes"], z["ids"])
-        return index
+        h = c_void_p()
+        rc = _Lib.get().mi_index_load(str(fname).encode(), int(device), ctypes.byref(h))
+        if rc:
+            msg = _Lib.get().mi_last_error().decode()
+            if "no HIP device" in msg:
+                raise RuntimeError("mi_ivfpq: " + msg)
+            raise faiss_io.FaissFormatError(msg)
+        return IndexIVFPQ._from_handle(h, device)
     z = np.load(fname, allow_pickle=False)
     if str(z["magic"]) != _MAGIC:
         raise ValueError(f"{fname}: not a {_MAGIC} file")

@@ -78,12 +78,34 @@ int mi_index_encode(mi_index *h, int64_t n, const float *x, int32_t *list_no_hos
                     uint8_t *codes_host);
 
 /* Append pre-encoded entries (read_index path; InvertedLists.add_entries). */
-int mi_index_add_codes(mi_index *h, int64_t n, const int32_t *list_no_host,
-                       const uint8_t *codes_host, const int64_t *ids_host);
+int mi_index_add_codes(mi_index *h, int64_t n, const int32_t *list_no,
+                       const uint8_t *codes, const int64_t *ids); /* all host or all device pointers */
 
 /* InvertedLists.list_size / get_codes+get_ids (host outputs, insertion order). */
 int mi_index_list_size(mi_index *h, int list_no, int64_t *out);
 int mi_index_get_list(mi_index *h, int list_no, uint8_t *codes_host, int64_t *ids_host);
+/* All list sizes at once: sizes_host int64 [nlist]. */
+int mi_index_list_sizes(mi_index *h, int64_t *sizes_host);
+/* The lists [list_lo, list_hi) concatenated in list order, each in insertion order:
+ * codes uint8 [rows][M], ids int64 [rows] with rows = the sum of their sizes (host or
+ * device outputs; either may be NULL).  What write_index streams to disk slab by slab
+ * (the lists live in HBM; the host never holds the whole index). */
+int mi_index_export_lists(mi_index *h, int list_lo, int list_hi, uint8_t *codes, int64_t *ids);
+/* Capacity hint for add(): room for n vectors in total (std::vector::reserve). */
+int mi_index_reserve(mi_index *h, int64_t n);
+
+/* faiss.write_index / faiss.read_index for this index family, in faiss's binary format
+ * (IwPQ + IndexFlat quantiser + in-file `ilar` lists, or -- with ondisk_data != NULL -- the
+ * OnDiskInvertedLists pair: the reference's index.faiss + ondisk.ivfdata, Makefile:11-12).
+ * The lists stream between HBM and the file in bounded slabs. */
+int mi_index_save(mi_index *h, const char *fname, const char *ondisk_data);
+int mi_index_load(const char *fname, int device, mi_index **out);
+/* Parameters of a handle (e.g. one returned by mi_index_load); any output may be NULL.
+ * nprobe is faiss's index.nprobe attribute as stored in index files -- mi_index_search()
+ * takes nprobe per call. */
+int mi_index_get_params(mi_index *h, int *d, int *nlist, int *M, int *nbits, int *metric,
+                        int *by_residual, int *nprobe);
+int mi_index_set_nprobe(mi_index *h, int nprobe);
 
 /* IndexIVFPQ.search with index.nprobe = nprobe.
  * q float32 [nq][d]; D float32 [nq][k]; I int64 [nq][k].  1 <= k <= 4096. */
