@@ -19,7 +19,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-shared", "-Wall", "-Wextra", "-Wl,-rpath,/opt/rocm/lib"]
 
 LIBS = {
-    "ivfpq": ("libmi_ivfpq.so", ["ivfpq.hip"], ["ivfpq_kernels.h", "common.h"]),
+    "ivfpq": ("libmi_ivfpq.so", ["ivfpq.hip"], ["ivfpq_kernels.h", "encoder_kernels.h", "common.h"]),   # ivfpq.hip includes the ring GEMM
     "encoder": ("libmi_encoder.so", ["encoder.hip"], ["encoder_kernels.h", "common.h"]),
 }
 

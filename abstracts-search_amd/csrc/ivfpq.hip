@@ -300,17 +300,58 @@ void launch_scan(int M, const ScanArgs &a, hipStream_t st) {
     }
 }
 
+// k-way merge of nparts candidate lists per query.  Three tiers by the LDS one query needs
+// (12 B per candidate + 16 B per result): several queries per workgroup in the default 64 KiB;
+// one query per workgroup in up to 160 KiB (gfx950's LDS per CU); beyond that the candidates are
+// laid out as one row of pairs per query in `scratch` and reduced by select_pairs_kernel
+// (k <= 4096).  8 shards x k = 4096, or re-ranking k * k_factor = 50 000 candidates, all work.
 void launch_merge(const float *ps, const int64_t *pid, int nparts, int64_t stride_p,
                   int64_t stride_q, int64_t nq, int k, float *D, int64_t *I, int64_t ldo,
-                  int out_off, float *bs, int64_t *bid, hipStream_t st) {
+                  int out_off, float *bs, int64_t *bid, hipStream_t st, int64_t stride_p_id = -1,
+                  IdMap im = IdMap{}, DevBuf *scratch = nullptr) {
+    if (stride_p_id < 0) stride_p_id = stride_p;
     const size_t per_wave = merge_wave_bytes(nparts, k);
-    MI_REQUIRE(per_wave <= 64 * 1024, "merge: nparts*k too large");
-    int qpb = (int)std::min<size_t>(4, (64 * 1024) / per_wave);   // queries (waves) per workgroup
-    if (qpb == 3) qpb = 2;
-    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((nq + qpb - 1) / qpb)), dim3(64 * qpb),
-                       per_wave * qpb, st, ps, pid, nparts, stride_p, stride_q, nq, k, D, I, ldo,
-                       out_off, bs, bid);
-    MI_HIP(hipGetLastError());
+    if (per_wave <= 64 * 1024) {
+        int qpb = (int)std::min<size_t>(4, (64 * 1024) / per_wave);   // queries (waves) per workgroup
+        if (qpb == 3) qpb = 2;
+        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((nq + qpb - 1) / qpb)), dim3(64 * qpb),
+                           per_wave * qpb, st, ps, pid, nparts, stride_p, stride_p_id, stride_q, nq, k, D, I, ldo,
+                           out_off, bs, bid, im);
+        MI_HIP(hipGetLastError());
+        return;
+    }
+    if (per_wave <= 160 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(64), per_wave, st, ps, pid, nparts, stride_p,
+                           stride_p_id, stride_q, nq, k, D, I, ldo, out_off, bs, bid, im);
+        MI_HIP(hipGetLastError());
+        return;
+    }
+    MI_REQUIRE(k <= SELB_CAP, "merge: k too large (max 4096)");
+    MI_REQUIRE(!bs && !bid, "internal: bounded merge on the large path");
+    const int64_t ld = (((int64_t)nparts * k + 63) / 64) * 64;
+    DevBuf local;
+    DevBuf &sb = scratch ? *scratch : local;
+    // queries in sub-batches so that the rows stay under 1 GiB
+    const int64_t qc = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 30) / (ld * 12)));
+    char *base = static_cast<char *>(sb.reserve((size_t)qc * ld * 12 + (size_t)qc * 8 + 64));
+    int64_t *rid = reinterpret_cast<int64_t *>(base);
+    float *rs = reinterpret_cast<float *>(base + (size_t)qc * ld * 8);
+    int32_t *prefix = reinterpret_cast<int32_t *>(base + (size_t)qc * ld * 12);
+    for (int64_t c0 = 0; c0 < nq; c0 += qc) {
+        const int64_t m = std::min(qc, nq - c0);
+        hipLaunchKernelGGL(gather_parts_kernel, dim3((unsigned)m), dim3(256), 0, st, ps + (size_t)c0 * stride_q,
+                           pid + (size_t)c0 * stride_q, nparts, stride_p, stride_p_id, stride_q, k, ld, rs, rid, prefix, im);
+        hipLaunchKernelGGL(select_pairs_kernel, dim3((unsigned)m), dim3(256), 0, st, rs, rid, ld, prefix, 1, k,
+                           D + (size_t)c0 * ldo + out_off, I + (size_t)c0 * ldo + out_off, ldo);
+        MI_HIP(hipGetLastError());
+    }
+    if (!scratch) MI_HIP(hipStreamSynchronize(st));   // `local` dies with this scope
 }
 
 // copy `bytes` to the device if `src` is a host pointer; returns a device pointer.
@@ -385,7 +426,7 @@ struct mi_flat {
     int d = 0, device = 0;
     int64_t ntotal = 0;
     DevBuf base;
-    DevBuf ws_q, ws_scores, ws_D, ws_I, ws_cand;
+    DevBuf ws_q, ws_scores, ws_D, ws_I, ws_cand, ws_bigmerge;
     // score workspaces of mi_flat_rerank, one per stream it is called on (batches on
     // different streams overlap)
     std::vector<std::pair<void *, std::unique_ptr<DevBuf>>> ws_rerank;
@@ -1185,6 +1226,28 @@ int mi_merge_topk(int device, int nparts, int64_t nq, int k, const float *D_part
     });
 }
 
+int mi_merge_topk_gathered(int device, int nparts, int64_t nq, int k, const void *gathered, int64_t blk_bytes,
+                           int64_t id_mul, int64_t id_add, int64_t id_step, int64_t q_lo, int64_t nq_out, float *D,
+                           int64_t *I, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(nparts >= 1 && k >= 1 && nq >= 0, "bad sizes");
+        MI_REQUIRE(q_lo >= 0 && nq_out >= 0 && q_lo + nq_out <= nq, "merge: query slice out of range");
+        MI_REQUIRE(gathered && D && I, "null argument");
+        const int64_t d_bytes = ((nq * k * 4 + 7) / 8) * 8;
+        MI_REQUIRE(blk_bytes >= d_bytes + nq * k * 8 && blk_bytes % 8 == 0, "merge: block size does not hold nq*k (f32, i64) pairs");
+        MI_REQUIRE(is_device_ptr(gathered) && is_device_ptr(D) && is_device_ptr(I), "mi_merge_topk_gathered: device pointers only");
+        if (nq_out == 0) return;
+        DeviceGuard dg(device);
+        const char *base = static_cast<const char *>(gathered);
+        IdMap im;
+        im.mul = id_mul; im.add = id_add; im.step = id_step;
+        static thread_local DevBuf scratch;   // only the > 160 KiB tier uses it
+        launch_merge(reinterpret_cast<const float *>(base) + (size_t)q_lo * k,
+                     reinterpret_cast<const int64_t *>(base + d_bytes) + (size_t)q_lo * k, nparts, blk_bytes / 4, k, nq_out, k,
+                     D, I, k, 0, nullptr, nullptr, as_stream(stream), blk_bytes / 8, im, &scratch);
+    });
+}
+
 // ---- write_index / read_index: faiss's binary IndexIVFPQ format ---------------------
 // (IwPQ + IndexFlat quantiser + ArrayInvertedLists `ilar` or OnDiskInvertedLists `ilod`: the
 // reference's index.faiss + ondisk.ivfdata pair, Makefile:11-12.)  Layout restated from
@@ -1599,7 +1662,7 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
         launch_gemm_gather(qs, (int)nq, h->base.get<float>(), h->ntotal, h->d, ci, kc, scores, kc, st);
         // the candidate list as kc/k "parts" of k entries: the k-way merge ranks them under
         // (score desc, id asc) and skips the negative ids
-        launch_merge(scores, ci, kc / k, k, kc, nq, k, Dc, Ic, k, 0, nullptr, nullptr, st);
+        launch_merge(scores, ci, kc / k, k, kc, nq, k, Dc, Ic, k, 0, nullptr, nullptr, st, -1, IdMap{}, &h->ws_bigmerge);
         if (!dev) {
             MI_HIP(hipMemcpyAsync(D, Dc, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
             MI_HIP(hipMemcpyAsync(I, Ic, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));

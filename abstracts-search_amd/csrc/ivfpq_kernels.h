@@ -2294,6 +2294,42 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
 // One wave per query, QPB = blockDim/64 queries per workgroup; rank by
 // counting over the n = nparts*k candidates staged in LDS.
 // ---------------------------------------------------------------------
+// Part p's ids may be local to the part: global = id * id_mul + id_add + p * id_step (the
+// closed form of a round-robin or contiguous-range shard numbering; identity = {1, 0, 0}),
+// applied on load so that the exchange step needs no translation pass.
+struct IdMap {
+    int64_t mul = 1, add = 0, step = 0;
+};
+
+// Candidate lists too long for the LDS of merge_kernel: [nparts][nq][k] parts -> one row of
+// (score, id) pairs per query (empty slots: NaN score), which select_pairs_kernel reduces.
+// prefix[q] = {0, row length / 64}: the one-"probe" table select_pairs_kernel reads its n from.
+__global__ void __launch_bounds__(256)
+    gather_parts_kernel(const float *__restrict__ ps, const int64_t *__restrict__ pid, int nparts, int64_t stride_p,
+                        int64_t stride_p_id, int64_t stride_q, int k, int64_t ld, float *__restrict__ rs,
+                        int64_t *__restrict__ rid, int32_t *__restrict__ prefix, IdMap im) {
+    const int64_t q = blockIdx.x;
+    const int n = nparts * k;
+    for (int e = threadIdx.x; e < (int)ld; e += 256) {
+        float s = __builtin_nanf("");
+        int64_t id = -1;
+        if (e < n) {
+            const int p = e / k, j = e - p * k;
+            const int64_t v = pid[(size_t)p * stride_p_id + (size_t)q * stride_q + j];
+            if (v >= 0) {
+                id = v * im.mul + im.add + p * im.step;
+                s = ps[(size_t)p * stride_p + (size_t)q * stride_q + j];
+            }
+        }
+        rs[q * ld + e] = s;
+        rid[q * ld + e] = id;
+    }
+    if (threadIdx.x == 0) {
+        prefix[q * 2] = 0;
+        prefix[q * 2 + 1] = (int32_t)(ld / 64);
+    }
+}
+
 __host__ __device__ inline size_t merge_wave_bytes(int nparts, int k) {
     size_t n = (size_t)nparts * k;
     return ((n * 12 + 7) & ~(size_t)7) + (size_t)k * 16;   // e_id[n] e_s[n] | o_id[k] o_s[k](+pad)
@@ -2301,9 +2337,9 @@ __host__ __device__ inline size_t merge_wave_bytes(int nparts, int k) {
 
 __global__ void __launch_bounds__(256)
     merge_kernel(const float *__restrict__ ps, const int64_t *__restrict__ pid, int nparts,
-                 int64_t stride_p, int64_t stride_q, int64_t nq, int k, float *__restrict__ D,
+                 int64_t stride_p, int64_t stride_p_id, int64_t stride_q, int64_t nq, int k, float *__restrict__ D,
                  int64_t *__restrict__ I, int64_t ldo, int out_off, float *__restrict__ bound_s,
-                 int64_t *__restrict__ bound_id) {
+                 int64_t *__restrict__ bound_id, IdMap im) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = nparts * k;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, qpb = blockDim.x >> 6;
@@ -2317,9 +2353,9 @@ __global__ void __launch_bounds__(256)
     if (live) {
         for (int e = lane; e < n; e += 64) {
             int p = e / k, j = e - p * k;
-            size_t o = (size_t)p * stride_p + (size_t)q * stride_q + j;
-            int64_t id = pid[o];
-            e_id[e] = id < 0 ? EMPTY_ID : id;
+            const size_t o = (size_t)p * stride_p + (size_t)q * stride_q + j;
+            const int64_t id = pid[(size_t)p * stride_p_id + (size_t)q * stride_q + j];
+            e_id[e] = id < 0 ? EMPTY_ID : id * im.mul + im.add + p * im.step;
             e_s[e] = id < 0 ? MI_NEG_INF : ps[o];
         }
         for (int j = lane; j < k; j += 64) {

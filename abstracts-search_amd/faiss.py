@@ -77,6 +77,8 @@ class _Lib:
                 "mi_index_coarse_slice": [v, c_int64, v, c_int, c_int, c_int, v, v, v],
                 "mi_index_search_preassigned": [v, c_int64, v, c_int, c_int, v, v, v, v, v],
                 "mi_merge_topk": [c_int, c_int, c_int64, c_int, v, v, v, v, v],
+                "mi_merge_topk_gathered": [c_int, c_int, c_int64, c_int, v, c_int64, c_int64, c_int64, c_int64,
+                                           c_int64, c_int64, v, v, v],
                 "mi_flat_create": [c_int, c_int, POINTER(v)],
                 "mi_flat_destroy": [v],
                 "mi_flat_add": [v, c_int64, v],
@@ -540,6 +542,23 @@ def merge_topk(D_parts, I_parts, device: int = 0):
     I = np.empty((nq, k), np.int64)
     _check(_Lib.get().mi_merge_topk(device, nparts, nq, k, _ptr(D_parts), _ptr(I_parts), _ptr(D),
                                     _ptr(I), c_void_p(0)))
+    return D, I
+
+
+def merge_topk_gathered(gathered, nparts: int, nq: int, k: int, blk_bytes: int, id_affine=(1, 0, 0),
+                        q_lo: int = 0, nq_out: int | None = None, D=None, I=None):
+    """The exchange step's merge straight on the receive buffer of one all-gather
+    (uint8 CUDA tensor, `nparts` blocks of `blk_bytes` = [D f32 | pad 8 | I i64], see
+    mi_merge_topk_gathered); ids are translated local -> global by the affine map."""
+    import torch
+    nq_out = nq if nq_out is None else nq_out
+    if D is None:
+        D = torch.empty((nq_out, k), dtype=torch.float32, device=gathered.device)
+        I = torch.empty((nq_out, k), dtype=torch.int64, device=gathered.device)
+    mul, add, step = id_affine
+    _check(_Lib.get().mi_merge_topk_gathered(gathered.device.index or 0, int(nparts), int(nq), int(k), _ptr(gathered),
+                                             int(blk_bytes), int(mul), int(add), int(step), int(q_lo), int(nq_out),
+                                             _ptr(D), _ptr(I), _current_stream()))
     return D, I
 
 

@@ -1,23 +1,26 @@
 """Vector-sharded IVF-PQ search across the GPUs of one node.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
-Rank r holds a shard of every inverted list (e.g. rows i = r mod N) with
-*global* int64 ids; coarse centroids and PQ codebook are replicated.  The path
-has exactly one exchange step: an all-gather of the per-shard top-k
-(k * 12 bytes per query per rank -- latency-bound, not bandwidth-bound),
-followed by a k-way merge under the same (score desc, id asc) order the
-single-GPU search uses, so the sharded result is bit-identical to the
-unsharded one.  With a re-ranking shard index (IndexRefineFlat over the shard's raw
-vectors, `id_map` = the shard's global row numbers) the result is the merge of the
-shards' exact re-ranked lists: every shard re-ranks its own k * k_factor candidates.
+Rank r holds a shard of every inverted list (e.g. rows i = r mod N); coarse
+centroids and PQ codebook are replicated.  The path has exactly ONE exchange
+step: every rank's search writes its (D, I) into the two halves of one send
+buffer (``nq*k*12`` bytes: latency-bound, not bandwidth-bound), ONE
+``all_gather_into_tensor`` moves the buffers, and ``mi_merge_topk_gathered``
+merges straight out of the receive buffer under the same (score desc, id asc)
+order the single-GPU search uses -- so the sharded result is bit-identical to
+the unsharded one.  Shard-local ids are translated to global ids inside the
+merge (``id_affine``: global = local * mul + add + rank * step, the closed form
+of a round-robin or contiguous shard numbering); an arbitrary ``id_map`` table
+is applied locally before the exchange instead.  With a re-ranking shard index
+(IndexRefineFlat over the shard's raw vectors, which numbers its vectors by
+position) the result is the merge of the shards' exact re-ranked lists.
 
 Two entry points:
   search_replicated(q, k)  every rank passes the SAME queries (a front end
-                           broadcast them); one all-gather of (D, I).
+                           broadcast them): the one all-gather and nothing else.
   search(q_local, k)       every rank brings its OWN batch (data-parallel
-                           clients); the batches are all-gathered first, the
-                           per-shard top-k all-gathered after, and every rank
-                           merges the slice belonging to its own queries.
+                           clients): the batches are all-gathered first and
+                           every rank merges the slice of its own queries.
 
 `local_search` / `merge` are injectable so that the collective plumbing can be
 exercised on CPU with the gloo backend (tests/test_shards_gloo.py); the
@@ -26,40 +29,49 @@ defaults are the HIP paths and fail loudly without a GPU.
 from __future__ import annotations
 
 
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
 class ShardedIndex:
     def __init__(self, index, group=None, local_search=None, merge=None, shard_coarse=False,
-                 local_coarse=None, local_search_pre=None, nlist=None, nprobe=None, id_map=None):
+                 local_coarse=None, local_search_pre=None, nlist=None, nprobe=None, id_map=None,
+                 id_affine=None):
         import torch.distributed as dist
         assert dist.is_initialized(), "ShardedIndex needs an initialised process group"
         self.index = index
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self._local_search = local_search or self._hip_search
-        self._merge = merge or self._hip_merge
+        self._local_search = local_search          # None: the HIP index writes into the send buffer
+        self._merge = merge                        # None: mi_merge_topk_gathered on the receive buffer
         self._bufs = {}
         # shard_coarse: the coarse GEMM (2*d*nlist FLOP per query, replicated on
-        # every rank otherwise -- at IVF65536 more work than scanning a shard) is
-        # split by centroid range; the per-rank top-nprobe lists are all-gathered
-        # and merged (same total order => the same probe list as the full search)
+        # every rank otherwise -- at IVF65536 as much work as scanning a shard) is
+        # split by centroid range; the per-rank top-nprobe lists take the same
+        # exchange + merge (same total order => the same probe list as the full search)
         self.shard_coarse = shard_coarse
         self._local_coarse = local_coarse or (lambda q, nprobe, lo, hi: self.index.coarse_slice(q, nprobe, lo, hi))
         self._local_search_pre = local_search_pre or (lambda q, k, cI, cD: self.index.search_preassigned(q, k, cI, cD))
         self._nlist = nlist if nlist is not None else getattr(index, "nlist", None)
         self._nprobe = nprobe
-        # id_map: local result ids -> global ids, applied before the exchange step.  For a
-        # shard index that numbers its vectors by position -- an IndexRefineFlat over the
-        # shard's raw vectors must -- pass the int64 tensor of the shard's global row numbers
-        # (round-robin sharding: torch.arange(rank, n, world)) or a callable on id tensors.
+        # id_affine = (mul, add, step): global id = local * mul + add + rank * step, applied by the
+        # merge while it loads the gathered ids (round-robin shards numbered by position:
+        # (world, 0, 1)).  id_map: an int64 tensor (local id -> global id) or a callable on id
+        # tensors, for numberings without a closed form; applied before the exchange.
+        assert id_map is None or id_affine is None, "id_map and id_affine are alternatives"
         self._id_map = id_map
+        self._id_affine = tuple(int(v) for v in id_affine) if id_affine is not None else (1, 0, 0)
 
-    # -- default (HIP) implementations ---------------------------------
-    def _hip_search(self, q, k):
-        return self.index.search(q, k)
-
-    def _hip_merge(self, Dp, Ip):
-        from . import faiss
-        return faiss.merge_topk(Dp, Ip)
+    # -- helpers -----------------------------------------------------------
+    def _buf(self, name, nbytes, device):
+        import torch
+        key = (name, int(nbytes), str(device))
+        b = self._bufs.get(key)
+        if b is None:
+            b = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._bufs[key] = b
+        return b
 
     def _global_ids(self, I):
         if self._id_map is None:
@@ -70,50 +82,86 @@ class ShardedIndex:
         out = self._id_map.to(I.device)[I.clamp_min(0)]
         return torch.where(I < 0, torch.full_like(out, -1), out)
 
-    def _buf(self, name, shape, dtype, device):
+    def _hip_search_into(self, q, k, D, I):
+        idx = self.index
+        if hasattr(idx, "base_index"):                       # IndexRefineFlat: candidates in scratch
+            import torch
+            kb = int(k * idx.k_factor)
+            kb = max(k, kb - kb % k)
+            cD = self._buf("candD", q.shape[0] * kb * 4, q.device).view(torch.float32).view(q.shape[0], kb)
+            cI = self._buf("candI", q.shape[0] * kb * 8, q.device).view(torch.int64).view(q.shape[0], kb)
+            idx.search_into(q, k, D, I, cD, cI)
+        else:
+            idx.search_into(q, k, D, I)
+
+    # -- the exchange step ---------------------------------------------------
+    def _exchange_merge(self, nq, k, device, fill, q_lo=0, nq_out=None, affine=(1, 0, 0)):
+        """fill(Dview, Iview) writes this rank's [nq, k] lists into the send buffer; one
+        all-gather; merged (D, I) of the queries [q_lo, q_lo + nq_out)."""
         import torch
-        key = (name, tuple(shape), dtype, str(device))
-        b = self._bufs.get(key)
-        if b is None:
-            b = torch.empty(shape, dtype=dtype, device=device)
-            self._bufs[key] = b
-        return b
+        import torch.distributed as dist
+        nq_out = nq if nq_out is None else nq_out
+        dbytes = _pad8(nq * k * 4)
+        blk = dbytes + nq * k * 8
+        send = self._buf("send", blk, device)
+        recv = self._buf("recv", blk * self.world, device)
+        Dv = send[:nq * k * 4].view(torch.float32).view(nq, k)
+        Iv = send[dbytes:].view(torch.int64).view(nq, k)
+        fill(Dv, Iv)
+        dist.all_gather_into_tensor(recv, send, group=self.group)      # the path's one exchange step
+        if self._merge is None:
+            from . import faiss
+            return faiss.merge_topk_gathered(recv, self.world, nq, k, blk, affine, q_lo, nq_out)
+        # injected merge (CPU tests): the same views, ids translated with torch
+        parts = recv.view(self.world, blk)
+        Dg = torch.stack([parts[p, :nq * k * 4].view(torch.float32).view(nq, k) for p in range(self.world)])
+        Ig = torch.stack([parts[p, dbytes:].view(torch.int64).view(nq, k) for p in range(self.world)])
+        mul, add, step = affine
+        if (mul, add, step) != (1, 0, 0):
+            off = (add + step * torch.arange(self.world, dtype=torch.int64, device=Ig.device)).view(-1, 1, 1)
+            Ig = torch.where(Ig < 0, Ig, Ig * mul + off)
+        return self._merge(Dg[:, q_lo:q_lo + nq_out].contiguous(), Ig[:, q_lo:q_lo + nq_out].contiguous())
+
+    def _search_all(self, qall, k, q_lo, nq_out):
+        nq = qall.shape[0]
+        if self.shard_coarse:
+            Dl, Il = self._search_sharded_coarse(qall, k)
+
+            def fill(Dv, Iv):
+                Dv.copy_(Dl)
+                Iv.copy_(self._global_ids(Il))
+        elif self._local_search is None and self._id_map is None:
+            def fill(Dv, Iv):                                       # the search writes the send buffer
+                self._hip_search_into(qall, k, Dv, Iv)
+        else:
+            def fill(Dv, Iv):
+                if self._local_search is None:
+                    self._hip_search_into(qall, k, Dv, Iv)
+                    Iv.copy_(self._global_ids(Iv.clone()))
+                else:
+                    Dl, Il = self._local_search(qall, k)
+                    Dv.copy_(Dl)
+                    Iv.copy_(self._global_ids(Il))
+        return self._exchange_merge(nq, k, qall.device, fill, q_lo, nq_out, self._id_affine)
 
     # -- same queries on every rank --------------------------------------
     def search_replicated(self, q, k):
-        import torch
-        import torch.distributed as dist
-        Dl, Il = self._search_sharded_coarse(q, k) if self.shard_coarse else self._local_search(q, k)
-        Il = self._global_ids(Il)
-        nq = Dl.shape[0]
-        Dg = self._buf("Dg", (self.world, nq, k), torch.float32, Dl.device)
-        Ig = self._buf("Ig", (self.world, nq, k), torch.int64, Il.device)
-        dist.all_gather_into_tensor(Dg.view(-1, k), Dl.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(Ig.view(-1, k), Il.contiguous(), group=self.group)
-        return self._merge(Dg, Ig)
+        return self._search_all(q.contiguous(), k, 0, q.shape[0])
 
     # -- a different batch on every rank ----------------------------------
     def search(self, q_local, k):
         import torch
         import torch.distributed as dist
         b, d = q_local.shape
-        qall = self._buf("qall", (self.world * b, d), q_local.dtype, q_local.device)
+        if self.world == 1:
+            return self._search_all(q_local.contiguous(), k, 0, b)
+        qall = self._buf("qall", self.world * b * d * q_local.element_size(), q_local.device) \
+            .view(q_local.dtype).view(self.world * b, d)
         dist.all_gather_into_tensor(qall, q_local.contiguous(), group=self.group)
-        if self.shard_coarse:
-            Dl, Il = self._search_sharded_coarse(qall, k)
-        else:
-            Dl, Il = self._local_search(qall, k)                   # this shard, all queries
-        Il = self._global_ids(Il)
-        Dg = self._buf("Dg", (self.world, self.world * b, k), torch.float32, Dl.device)
-        Ig = self._buf("Ig", (self.world, self.world * b, k), torch.int64, Il.device)
-        dist.all_gather_into_tensor(Dg.view(-1, k), Dl.contiguous(), group=self.group)   # the exchange step
-        dist.all_gather_into_tensor(Ig.view(-1, k), Il.contiguous(), group=self.group)
-        lo, hi = self.rank * b, (self.rank + 1) * b
-        return self._merge(Dg[:, lo:hi].contiguous(), Ig[:, lo:hi].contiguous())
+        return self._search_all(qall, k, self.rank * b, b)       # this shard, all queries; own slice merged
 
     def _search_sharded_coarse(self, qall, k):
         import torch
-        import torch.distributed as dist
         nprobe = min(int(self._nprobe if self._nprobe is not None else self.index.nprobe), self._nlist)
         per = (self._nlist + self.world - 1) // self.world
         lo, hi = min(self.rank * per, self._nlist), min((self.rank + 1) * per, self._nlist)
@@ -123,11 +171,12 @@ class ShardedIndex:
         else:
             cI = torch.full((nq, nprobe), -1, dtype=torch.int32, device=qall.device)
             cD = torch.full((nq, nprobe), -torch.finfo(torch.float32).max, device=qall.device)
-        Ig = self._buf("cIg", (self.world, nq, nprobe), torch.int64, qall.device)
-        Dg = self._buf("cDg", (self.world, nq, nprobe), torch.float32, qall.device)
-        dist.all_gather_into_tensor(Ig.view(-1, nprobe), cI.to(torch.int64).contiguous(), group=self.group)
-        dist.all_gather_into_tensor(Dg.view(-1, nprobe), cD.contiguous(), group=self.group)
-        mD, mI = self._merge(Dg, Ig)                                # global top-nprobe lists
+
+        def fill(Dv, Iv):
+            Dv.copy_(cD)
+            Iv.copy_(cI)                                            # int32 -> int64
+
+        mD, mI = self._exchange_merge(nq, nprobe, qall.device, fill)   # global top-nprobe lists
         return self._local_search_pre(qall, k, mI.to(torch.int32), mD)
 
     def search_into(self, q_local, k, D, I):

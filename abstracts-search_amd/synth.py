@@ -8,9 +8,12 @@ different stream).
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 
+@functools.lru_cache(maxsize=4)
 def _centres(d: int, ncentres: int, seed: int = 99) -> np.ndarray:
     rng = np.random.Generator(np.random.Philox(seed))
     c = rng.standard_normal((ncentres, d), dtype=np.float32)
@@ -51,13 +54,19 @@ def queries_from(x: np.ndarray, nq: int, seed: int = 4321, cos: float = 0.7) -> 
     return q.astype(np.float32)
 
 
+@functools.lru_cache(maxsize=4)
+def _centres_cuda(d: int, ncentres: int, device: int):
+    import torch
+    return torch.from_numpy(_centres(d, ncentres)).to(torch.device("cuda", device))
+
+
 def corpus_cuda(n: int, d: int = 1024, ncentres: int = 16384, seed: int = 1234, cos: float = 0.7,
                 device: int = 0, row0: int = 0):
     """Bench-sized corpus generated on the GPU with torch's Philox generator
     (rows row0 .. row0+n of a stream keyed by (seed, block))."""
     import torch
     dev = torch.device("cuda", device)
-    c = torch.from_numpy(_centres(d, ncentres)).to(dev)
+    c = _centres_cuda(d, ncentres, device)
     sig = sigma_for_cosine(d, cos)
     out = torch.empty((n, d), dtype=torch.float32, device=dev)
     B = 65536

@@ -1,79 +1,188 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's headline metric on MI355X.
 
-Workload (config.workload = "cfg2"): BASELINE.json configs[1] -- 1M x 1024-d
-synthetic clustered corpus, IVF4096,PQ64 (inner product), batch-64 queries,
-k = 10.  A "step" is one IndexIVFPQ.search of one 64-query batch (coarse
-quantise + LUT + PQ-code scan + top-k), queries and outputs resident in HBM.
+Default workload (config.workload = "cfg4"): BASELINE.json configs[3], the
+configuration the metric is quoted on -- 207 M x 1024-d synthetic clustered
+corpus, IVF65536,PQ64 (inner product), batch-1024 queries, nprobe 64, k = 10.
+The whole 207 M-vector index (15 GB of codes + ids) is built in HBM from the
+chunk-wise regenerated corpus (setup, untimed, ~2-3 min).  A "step" is one
+IndexIVFPQ.search of one 1024-query batch (coarse quantise + LUT + PQ-code scan
++ top-k) with queries and outputs resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL).  Query
-batches are independent units, and the whole cfg2 index is 72 MB (the 207 M
-index of cfg4 is 15 GB) against 288 GB of HBM per GPU, so the default
-`--multi-gpu-mode replicas` shards the *queries*: every rank holds the index and
-searches its own 64-query batches, no collective on the data path, per-rank work
-constant in N ("weak"); value = all queries of all ranks / max-over-ranks time.
-`--multi-gpu-mode shards` runs the north star's vector-sharded variant instead
-(rank r holds rows i = r mod N; all-gather of the ranks' query batches, every
-rank scans its shard for all 64*N queries, all-gather of the per-shard top-k --
-the path's one exchange step -- and a k-way merge); it is what a 207 M index
-uses to cut single-batch latency, and it is latency-bound by its collectives at
-cfg2 sizes.
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the north
+star's layout -- rank r holds rows i = r mod N of every inverted list, every
+rank searches the same 1024-query batch over its shard, ONE all-gather of the
+per-shard top-k over xGMI (the path's one exchange step) and a k-way merge.
+The global batch is fixed, so "scaling" is "strong".  `--multi-gpu-mode
+replicas` keeps the query-parallel alternative (no collective).
 
-One JSON line on stdout (rank 0).  Extra objects: "roofline" (PQ-scan kernel,
-HIP events on the launch stream) and "cpu_baseline" (oracle port on the host
-cores, bounded sample).
+One JSON line on stdout (rank 0).  Besides the contract's fields:
+  roofline        PQ-scan kernel, HIP events on the launch stream
+  cpu_baseline    the oracle port (or real faiss-cpu when importable) on the host cores
+  recall_at_10    of the timed configuration, against exact search over all 207 M rows
+  at_recall_095   the operating point with recall@10 >= 0.95 (IVF-PQ + IndexRefineFlat)
+  encode          cfg3: stella_en_1.5B_v5 bf16 batch encode (abstracts/s + its roofline)
+  reference_oracles  whether real faiss / sentence-transformers could be imported here
+
+`--workload cfg2` (1 M x 1024, IVF4096,PQ64, batch 64) and `--workload encode`
+run the round-1 lines on their own.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The steps are issued round-robin on several HIP streams; the runtime maps streams onto
+# Steps are issued round-robin on several HIP streams; the runtime maps streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4, one of which torch's own stream takes), and
 # two streams sharing a queue serialise.  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+D_MODEL, PQ_M = 1024, 64
+CH = 1 << 20                      # corpus rows per generated chunk
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# ----------------------------------------------------------------------
+# timing: K steps between barrier + synchronize, max over ranks; a region shorter than
+# 50 ms is inside the noise of a clock ramp, so the K-step block is then repeated and the
+# median block is reported (steps / warmup keep their meaning)
+# ----------------------------------------------------------------------
+class Clock:
+    def __init__(self, torch, dist, world, dev):
+        self.torch, self.dist, self.world, self.dev = torch, dist, world, dev
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def block(self, step, first, n):
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(first + i)
+        t_issue = time.perf_counter() - t0
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            tt = self.torch.tensor([dt], device=self.dev, dtype=self.torch.float64)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, t_issue
+
+    def measure(self, step, steps, warmup, min_region_s=0.05, max_blocks=15, max_total_s=2.0):
+        for i in range(warmup):
+            step(i)
+        times, issue = [], []
+        first = warmup
+        while True:
+            dt, ti = self.block(step, first, steps)
+            first += steps
+            times.append(dt)
+            issue.append(ti)
+            if len(times) == 1 and dt >= min_region_s:
+                break
+            if len(times) >= max_blocks or (sum(times) >= max_total_s and len(times) % 2 == 1):
+                break
+        return statistics.median(times), times, statistics.median(issue)
+
+
+def hbm_gb(torch):
+    free, total = torch.cuda.mem_get_info()
+    return (total - free) / 1e9, total / 1e9
+
+
+def recall_at_k(I, gt):
+    a, e = I.cpu().numpy(), gt.cpu().numpy()
+    hits = sum(len(set(x.tolist()) & set(y.tolist())) for x, y in zip(a, e))
+    return hits / float(e.size)
+
+
+# ----------------------------------------------------------------------
+# real reference packages, if this box has them (attempt, never skip silently)
+# ----------------------------------------------------------------------
+def reference_oracles():
+    import importlib.util
+    out = {}
+    for name in ("faiss", "sentence_transformers", "sidecar_search"):
+        try:
+            spec = importlib.util.find_spec(name)
+        except Exception:
+            spec = None
+        origin = getattr(spec, "origin", None) or ""
+        if spec is None:
+            out[name] = "absent"
+        elif ROOT in os.path.abspath(origin):
+            out[name] = "absent (the name resolves to this repository's drop-in alias)"
+        else:
+            out[name] = "present: " + origin
+    return out
+
+
+def real_faiss():
+    ref = reference_oracles()
+    if not ref["faiss"].startswith("present"):
+        return None
+    try:
+        import faiss as real
+        return real
+    except Exception as e:                                            # pragma: no cover
+        log(f"import faiss failed: {e!r}")
+        return None
+
+
+# ----------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--corpus", type=int, default=1_000_000)
-    ap.add_argument("--nlist", type=int, default=4096)
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--nprobe", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=None, help="default: 50 (cfg4), 200 (cfg2), 10 (encode)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 5 (cfg4), 20 (cfg2), 2 (encode)")
+    ap.add_argument("--workload", choices=["cfg4", "cfg2", "encode", "search"], default="cfg4",
+                    help="cfg4 = the headline line (207M, IVF65536,PQ64, batch 1024); cfg2 = 1M, IVF4096,PQ64, batch 64 "
+                         "('search' is its old name); encode = cfg3 (stella_en_1.5B_v5 bf16 batch encode)")
+    ap.add_argument("--corpus", type=int, default=None, help="corpus rows (default: 207000000 cfg4, 1000000 cfg2)")
+    ap.add_argument("--nlist", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--nprobe", type=int, default=None)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--train-iters", type=int, default=10)
+    ap.add_argument("--train-iters", type=int, default=None)
     ap.add_argument("--settle-ms", type=float, default=100.0,
                     help="untimed steps issued for this long before warmup (clock ramp after setup)")
     ap.add_argument("--refine", type=int, default=0, metavar="K_FACTOR",
-                    help="IVF4096,PQ64,RFlat: re-rank k*K_FACTOR PQ candidates with exact inner products "
-                         "(faiss IndexRefineFlat); 0 = plain IVF-PQ, the headline configuration")
+                    help="cfg2 only: IVF4096,PQ64,RFlat with this k_factor as the timed configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
-    ap.add_argument("--workload", choices=["search", "encode"], default="search",
-                    help="search = cfg2 (the headline line); encode = cfg3 (stella_en_1.5B_v5 bf16 batch encode)")
+    ap.add_argument("--no-refine-point", action="store_true", help="cfg4: skip the recall >= 0.95 operating point")
+    ap.add_argument("--no-encode", action="store_true", help="cfg4: skip the encode half of the metric")
     ap.add_argument("--encode-batch", type=int, default=128, help="abstracts per encode step")
-    ap.add_argument("--multi-gpu-mode", choices=["replicas", "shards"], default="replicas",
-                    help="N>1: replicas = query-parallel, no collective (default); shards = vector-sharded index + all-gather")
+    ap.add_argument("--encode-steps", type=int, default=24, help="cfg4 line: encode steps (x encode-batch abstracts)")
+    ap.add_argument("--multi-gpu-mode", choices=["shards", "replicas"], default="shards",
+                    help="N>1: shards = vector-sharded index + one all-gather of top-k (default, the north star's "
+                         "layout); replicas = query-parallel, no collective")
     ap.add_argument("--shard-coarse", type=int, default=0,
-                    help="N>1: also split the coarse quantiser across ranks (pays off at IVF65536, not at cfg2)")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="HIP streams the steps are issued round-robin on (batches overlap on the GPU)")
+                    help="N>1 shards: also split the coarse quantiser across ranks (one more exchange)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="HIP streams the steps are issued round-robin on (default: 2 cfg4, 4 cfg2)")
     args = ap.parse_args()
+    if args.workload == "search":
+        args.workload = "cfg2"
+    # stdout carries exactly one JSON line: whatever native libraries print to fd 1 (RCCL's
+    # version banner, flushed at exit) goes to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -90,27 +199,351 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
+    ctx = dict(np=np, torch=torch, dist=dist, world=world, rank=rank, local_rank=local_rank, dev=dev,
+               clock=Clock(torch, dist, world, dev))
 
     if args.workload == "encode":
-        return encode_workload(args, np, torch, dist, world, rank, local_rank, dev)
+        args.steps = 10 if args.steps is None else args.steps
+        args.warmup = 2 if args.warmup is None else args.warmup
+        out = encode_workload(args, ctx, args.steps, args.warmup, with_cpu=not args.no_cpu_baseline)
+    elif args.workload == "cfg2":
+        out = cfg2_workload(args, ctx)
+    else:
+        out = cfg4_workload(args, ctx)
+    if rank == 0 and out is not None:
+        print(json.dumps(out), file=json_out, flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+# ======================================================================
+# cfg4: 207 M x 1024, IVF65536,PQ64, batch 1024 -- the configuration the metric is quoted on
+# ======================================================================
+def cfg4_workload(args, ctx):
+    np, torch, dist = ctx["np"], ctx["torch"], ctx["dist"]
+    world, rank, local_rank, dev, clock = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["dev"], ctx["clock"]
     import abstracts_search_amd.faiss as faiss
     import abstracts_search_amd.synth as synth
     from abstracts_search_amd.shards import ShardedIndex
 
-    d, M, k = 1024, 64, args.k
+    N = 207_000_000 if args.corpus is None else args.corpus
+    nlist = 65536 if args.nlist is None else args.nlist
+    batch = 1024 if args.batch is None else args.batch
+    nprobe = 64 if args.nprobe is None else args.nprobe
+    steps = 50 if args.steps is None else args.steps
+    warmup = 5 if args.warmup is None else args.warmup
+    train_iters = 4 if args.train_iters is None else args.train_iters
+    d, M, k = D_MODEL, PQ_M, args.k
+    force_sharded = bool(os.environ.get("BENCH_FORCE_SHARDED"))       # exercise the N>1 plumbing on one GPU
+    use_shards = (world > 1 and args.multi_gpu_mode == "shards") or force_sharded
+    replicas = world > 1 and not use_shards
+    nsh = world if use_shards else 1                                   # shards the corpus is dealt into
+    my = rank if use_shards else 0
+    assert CH % max(nsh, 8) == 0
     t0 = time.time()
-    # ---- corpus + index (setup, untimed).  The corpus is cfg2's 1M vectors at
-    # every N; rank r indexes rows r mod N.
-    x = synth.corpus_cuda(args.corpus, d, device=local_rank)
-    index = faiss.IndexIVFPQ(d, args.nlist, M, 8, faiss.METRIC_INNER_PRODUCT, device=local_rank)
-    index.cp.niter = args.train_iters
-    force_sharded = bool(os.environ.get("BENCH_FORCE_SHARDED"))   # exercise the N>1 plumbing on one GPU
+
+    # ---- train on rank 0 (first 4 M rows: 64 points per centroid), broadcast the tables
+    index = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT, device=local_rank)
+    index.cp.niter = train_iters
+    cent = torch.empty((nlist, d), dtype=torch.float32, device=dev)
+    cb = torch.empty((M, 256, d // M), dtype=torch.float32, device=dev)
+    if rank == 0:
+        ntrain = min(N, max(4 * CH, 64 * nlist))
+        xs = synth.corpus_cuda(ntrain, d, device=local_rank)
+        index.train(xs)
+        cent.copy_(torch.from_numpy(index.get_centroids()))
+        cb.copy_(torch.from_numpy(index.get_codebook()))
+        del xs
+    if dist.is_initialized() and world > 1:
+        dist.broadcast(cent, 0)
+        dist.broadcast(cb, 0)
+        index.set_centroids(cent)        # bit-identical tables on every rank (k-means uses atomic scatter-adds)
+        index.set_codebook(cb)
+    del cent, cb
+    t_train = time.time() - t0
+    log(f"[rank {rank}] train {t_train:.1f}s")
+
+    # ---- queries: perturbed corpus rows from the middle of the corpus (outside the training sample)
+    NB = 8
+    q0 = (N // 2) // CH * CH
+    xq = synth.corpus_cuda(min(CH, N - q0), d, device=local_rank, row0=q0)
+    qpool = synth.queries_cuda(xq, NB * batch, seed=4321).view(NB, batch, d)
+    del xq
+    if replicas:                                                       # every rank its own batches
+        g = torch.Generator(device=dev).manual_seed(977 + rank)
+        qpool = qpool[torch.randperm(NB, generator=g, device=dev)].contiguous()
+    q_gt = qpool[0].contiguous()                                       # recall is measured on this batch
+
+    # ---- the refine stage's raw vectors (recall >= 0.95 operating point, IndexRefineFlat): the
+    # shard's own rows when they fit beside the index, else the 1/8 sub-shard a GPU of the
+    # 8-GPU job would hold (rows i = rank mod 8)
+    per_rank = (N + nsh - 1) // nsh
+    hbm_total = torch.cuda.mem_get_info()[1]
+    want_refine = not args.no_refine_point and not replicas
+    refine_own = want_refine and per_rank * d * 4 <= 0.74 * hbm_total - 40e9
+    sub_mod = 8 if (want_refine and not refine_own) else 0
+    assert not sub_mod or (8 % nsh == 0), "the 1/8 sub-shard needs N in {1, 2, 4, 8}"
+    flat_r = sub = None
+    if want_refine:
+        flat_r = faiss.IndexFlatIP(d, device=local_rank)
+        n_r = per_rank if refine_own else (N + 7) // 8
+        flat_r.reserve(n_r + 1)
+        if sub_mod:
+            sub = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT, device=local_rank)
+            sub.set_centroids(torch.from_numpy(index.get_centroids()).to(dev))
+            sub.set_codebook(torch.from_numpy(index.get_codebook()).to(dev))
+            sub.reserve(n_r + 1)
+    index.reserve(per_rank + 1)
+
+    # ---- build: regenerate the corpus chunk by chunk; add this rank's rows; exact top-k of the
+    # recall queries over the same rows (running merge) -- every chunk is generated once
+    want_gt = not args.no_recall
+    flat_gt = faiss.IndexFlatIP(d, device=local_rank)
+    flat_gt.reserve(CH)
+    neg = -torch.finfo(torch.float32).max
+
+    def empty_gt():
+        return (torch.full((batch, k), neg, dtype=torch.float32, device=dev),
+                torch.full((batch, k), -1, dtype=torch.int64, device=dev))
+
+    def fold(run, rows, gid_of):
+        flat_gt.reset()
+        flat_gt.add(rows)
+        Dg, Ig = flat_gt.search(q_gt, k)
+        Ig = torch.where(Ig < 0, Ig, gid_of(Ig))
+        return faiss.merge_topk(torch.stack([run[0], Dg]), torch.stack([run[1], Ig]))
+
+    gt, gt_sub = empty_gt(), empty_gt()
+    t1 = time.time()
+    for c0 in range(0, N, CH):
+        m = min(CH, N - c0)
+        x = synth.corpus_cuda(m, d, device=local_rank, row0=c0)
+        mine = x if nsh == 1 else x[my::nsh].contiguous()
+        index.add(mine)                                                # local position p <-> global row p * nsh + my
+        if want_gt:
+            gt = fold(gt, mine, lambda I, c0=c0: I * nsh + (c0 + my))
+        if refine_own:
+            flat_r.add(mine)
+        elif sub_mod:
+            srows = x[rank % 8::8].contiguous()                        # subset of this rank's shard (8 % nsh == 0)
+            sub.add(srows)
+            flat_r.add(srows)
+            if want_gt:
+                gt_sub = fold(gt_sub, srows, lambda I, c0=c0: I + c0 // 8)   # positions in `sub` (what IndexRefineFlat returns)
+        del x, mine
+        if rank == 0 and (c0 // CH) % 32 == 31:
+            log(f"  built {c0 + m} rows, {time.time() - t1:.0f}s")
+    torch.cuda.synchronize()
+    t_build = time.time() - t1
+    del flat_gt
+    if want_gt and use_shards and world > 1:                           # exact top-k over all shards
+        Dall = torch.empty((world, batch, k), dtype=torch.float32, device=dev)
+        Iall = torch.empty((world, batch, k), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(Dall.view(-1, k), gt[0].contiguous())
+        dist.all_gather_into_tensor(Iall.view(-1, k), gt[1].contiguous())
+        gt = faiss.merge_topk(Dall, Iall)
+    index.nprobe = nprobe
+    t2 = time.time()
+    index.search(q_gt[:8].contiguous(), k)                             # builds the scan image of the lists
+    torch.cuda.synchronize()
+    t_image = time.time() - t2
+    used, total = hbm_gb(torch)
+    log(f"[rank {rank}] ntotal={index.ntotal} add {t_build:.1f}s ({index.ntotal / t_build / 1e6:.2f} M vec/s incl. "
+        f"generation + ground truth), scan image {t_image:.2f}s, HBM in use {used:.1f} of {total:.0f} GB")
+
+    # ---- the timed configuration
+    sharded = ShardedIndex(index, shard_coarse=bool(args.shard_coarse), id_affine=(nsh, 0, 1)) if use_shards else None
+    S = 1 if sharded is not None else max(1, 2 if args.streams is None else args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    sptr = [int(s_.cuda_stream) for s_ in streams]
+    Ds = [torch.empty((batch, k), dtype=torch.float32, device=dev) for _ in range(S)]
+    Is = [torch.empty((batch, k), dtype=torch.int64, device=dev) for _ in range(S)]
+    my_q = [qpool[b] for b in range(NB)]
+
+    def step(b):
+        if sharded is None:
+            j = b % S
+            index.search_into(my_q[b % NB], k, Ds[j], Is[j], None, sptr[j])
+        else:
+            sharded.search_replicated(my_q[b % NB], k)
+
+    def settle(fn, ms):
+        for b in range(max(2, 2 * S)):
+            fn(b)
+        torch.cuda.synchronize()
+        t_s, b = time.perf_counter(), 0
+        while time.perf_counter() - t_s < ms * 1e-3:
+            for _ in range(4):
+                fn(b)
+                b += 1
+            torch.cuda.synchronize()
+
+    settle(step, args.settle_ms)
+    dt, blocks, t_issue = clock.measure(step, steps, warmup)
+    qps = steps * batch * (world if replicas else 1) / dt
+
+    # recall of the timed configuration against the exact search
+    recall = None
+    if want_gt and not replicas:
+        if sharded is None:
+            _, Ia = index.search(q_gt, k)
+        else:
+            _, Ia = sharded.search_replicated(q_gt, k)
+        recall = recall_at_k(Ia, gt[1])
+
+    # ---- roofline of the dominant kernel (PQ-code scan): the library re-launches the scan of
+    # the last step back to back between two HIP events recorded on the launch stream
+    torch.cuda.synchronize()
+    index.search_into(my_q[0], k, Ds[0], Is[0], None, sptr[0])
+    prof = index.profile_scan(max(3, min(steps, 20)), sptr[0])
+    torch.cuda.synchronize()
+    scan_ms, scan_bytes = prof["scan_ms_avg"], prof["scan_bytes"]
+    achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    try:                                                               # separate --pmc passes of this same command
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_cfg4_scan_pmc.json")))
+        if (N, nlist, batch, nprobe, k, nsh) == tuple(pmc["config"]):
+            traffic, traffic_src = int(pmc["corrected_bytes_per_launch"]), pmc["source"]
+    except Exception:
+        pass
+    roofline = {"kernel": "scan_kernel<64,8,false>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "bytes_per_launch": int(scan_bytes), "avg_launch_ms": round(scan_ms, 5),
+                "algorithmic_bytes": "codes of the probed lists x (64 B code + 8 B id), device-counted"}
+
+    # ---- recall >= 0.95 operating point: IVF-PQ proposes k * k_factor candidates, exact re-ranking
+    at095 = None
+    if want_refine:
+        at095 = refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own, nsh, my_q, q_gt,
+                             gt if refine_own else gt_sub, batch, k, steps, warmup, settle)
+
+    # ---- CPU baseline + parity spot check (rank 0, N = 1): the oracle on the same index / queries
+    cpu, parity = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, parity = cpu_baseline_ivfpq(index, q_gt, nprobe, k, np, torch, "cfg4")
+
+    out = None
+    if rank == 0:
+        par = "1 GPU" if world == 1 else (
+            f"vector-sharded x{world} (rows i mod {world}), same {batch}-query batch on every rank, one all-gather of "
+            f"per-shard top-k + merge" if use_shards else f"query-parallel replicas x{world} (no collective)")
+        out = {
+            "metric": "queries/sec, IVF-PQ search (IVF%d,PQ64, %dx1024-d, batch %d, nprobe %d, k %d)" % (nlist, N, batch, nprobe, k),
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 5), "higher_is_better": True,
+            "scaling": "weak" if replicas else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg4: %dx1024 clustered synthetic corpus, IVF%d,PQ64, batch-%d queries (BASELINE.json configs[3])"
+                                   % (N, nlist, batch),
+                       "corpus": N, "nlist": nlist, "M": 64, "nprobe": nprobe, "k": k, "global_batch": batch * (world if replicas else 1),
+                       "parallelism": par, "shard_coarse": bool(args.shard_coarse) if use_shards else None,
+                       "launch": "eager", "streams": S, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "host_issue_ms_per_step": round(t_issue / steps * 1e3, 5),
+                       "timed_blocks": len(blocks), "block_ms": [round(b * 1e3, 3) for b in blocks],
+                       "timing": "median of the K-step blocks" if len(blocks) > 1 else "one K-step block",
+                       "setup_s": {"train": round(t_train, 1), "generate+add+ground_truth": round(t_build, 1),
+                                   "scan_image": round(t_image, 2)},
+                       "index_vectors_this_rank": index.ntotal, "hbm_in_use_gb": round(used, 1)},
+            "recall_at_10": None if recall is None else round(recall, 4),
+            "recall_note": "against exact inner-product search over all %d rows, %d queries" % (N, batch),
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
+            "at_recall_095": at095, "reference_oracles": reference_oracles(),
+        }
+    # ---- the other half of the metric: embed abstracts/sec (cfg3), in the same line
+    del sharded, index, sub, flat_r
+    torch.cuda.empty_cache()
+    if not args.no_encode:
+        enc = encode_workload(args, ctx, args.encode_steps, 2, with_cpu=not args.no_cpu_baseline)
+        if out is not None and enc is not None:
+            out["encode"] = {"abstracts_per_s": enc["value"], "tokens_per_s": enc["config"]["tokens_per_sec"],
+                             "ms_per_step": enc["ms_per_step"], "steps": enc["steps"], "batch": enc["config"]["batch"],
+                             "sample": enc["config"]["sample"], "dtype": enc["dtype"], "data": enc["data"],
+                             "roofline": enc["roofline"], "cpu_baseline": enc["cpu_baseline"]}
+    return out
+
+
+def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own, nsh, my_q, q_gt, gt, batch, k,
+                 steps, warmup, settle):
+    """Smallest-cost (nprobe, k_factor_rf) from a short ascending list that reaches recall@10 >= 0.95,
+    timed with the same loop.  refine_own: the job's real layout (every rank re-ranks its own shard,
+    one exchange of the exact lists); otherwise the 1/8 sub-shard one GPU of the 8-GPU job holds."""
+    torch, dist, world, rank, dev, clock = ctx["torch"], ctx["dist"], ctx["world"], ctx["rank"], ctx["dev"], ctx["clock"]
+    base = index if refine_own else sub
+    args_nprobe = index.nprobe                                         # restored below
+    ref = faiss.IndexRefineFlat(base, flat_r)
+    sharded = ShardedIndex(ref, id_affine=(nsh, 0, 1)) if (refine_own and nsh > 1) else None
+    cands = [(8, 64), (8, 100), (16, 100), (16, 160), (32, 200), (64, 256), (64, 400)]
+    best = None
+    for nprobe, kf in cands:
+        base.nprobe, ref.k_factor = nprobe, kf
+        _, Ia = (sharded.search_replicated(q_gt, k) if sharded is not None else ref.search(q_gt, k))
+        r = recall_at_k(Ia, gt[1])
+        if world > 1 and not refine_own:                               # sub-shards differ per rank: agree on the worst
+            t = torch.tensor([r], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            r = float(t.item())
+        log(f"  refine point nprobe={nprobe} k_factor_rf={kf}: recall@10 {r:.4f}")
+        best = (nprobe, kf, r)
+        if r >= 0.95:
+            break
+    nprobe, kf, r = best
+    kb = k * kf
+    D = torch.empty((batch, k), dtype=torch.float32, device=dev)
+    I = torch.empty((batch, k), dtype=torch.int64, device=dev)
+    cD = torch.empty((batch, kb), dtype=torch.float32, device=dev)
+    cI = torch.empty((batch, kb), dtype=torch.int64, device=dev)
+    NBq = len(my_q)
+
+    def step(b):
+        if sharded is not None:
+            sharded.search_replicated(my_q[b % NBq], k)
+        else:
+            ref.search_into(my_q[b % NBq], k, D, I, cD, cI)
+
+    settle(step, args.settle_ms)
+    dt, blocks, _ = clock.measure(step, steps, warmup)
+    base.nprobe = index.nprobe = args_nprobe
+    if refine_own:
+        scope = ("the whole job: every rank re-ranks k*k_factor candidates of its own shard against the shard's raw f32 "
+                 "vectors (%.0f GB per GPU), one all-gather of the exact per-shard lists" % (flat_r.ntotal * D_MODEL * 4 / 1e9)
+                 if nsh > 1 else "whole index + raw f32 vectors on one GPU")
+        recall_note = "against exact search over the whole corpus"
+    else:
+        scope = ("one GPU's share of the 8-GPU job: the 1/8 sub-shard (rows i mod 8 = rank, %d vectors + their raw f32 "
+                 "vectors, %.0f GB) -- the raw vectors of all %d rows (%.0f GB) do not fit %d GPU(s); every GPU of the "
+                 "8-GPU job sees every query, so its job rate is this rate less one all-gather"
+                 % (flat_r.ntotal, flat_r.ntotal * D_MODEL * 4 / 1e9, index.ntotal * nsh, index.ntotal * nsh * D_MODEL * 4 / 1e9, world))
+        recall_note = "against exact search over the same sub-shard"
+    return {"index": "IVF%d,PQ64,RFlat" % base.nlist, "nprobe": nprobe, "k_factor_rf": kf, "recall_at_10": round(r, 4),
+            "reached": bool(r >= 0.95), "qps": round(steps * batch / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+            "timed_blocks": len(blocks), "scope": scope, "recall_note": recall_note}
+
+
+# ======================================================================
+# cfg2: 1 M x 1024, IVF4096,PQ64, batch 64 (round 1's line; `--workload cfg2`)
+# ======================================================================
+def cfg2_workload(args, ctx):
+    np, torch, dist = ctx["np"], ctx["torch"], ctx["dist"]
+    world, rank, local_rank, dev, clock = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["dev"], ctx["clock"]
+    import abstracts_search_amd.faiss as faiss
+    import abstracts_search_amd.synth as synth
+    from abstracts_search_amd.shards import ShardedIndex
+
+    N = 1_000_000 if args.corpus is None else args.corpus
+    nlist = 4096 if args.nlist is None else args.nlist
+    batch = 64 if args.batch is None else args.batch
+    nprobe = 16 if args.nprobe is None else args.nprobe
+    steps = 200 if args.steps is None else args.steps
+    warmup = 20 if args.warmup is None else args.warmup
+    d, M, k = D_MODEL, PQ_M, args.k
+    t0 = time.time()
+    x = synth.corpus_cuda(N, d, device=local_rank)
+    index = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT, device=local_rank)
+    index.cp.niter = 10 if args.train_iters is None else args.train_iters
+    force_sharded = bool(os.environ.get("BENCH_FORCE_SHARDED"))
     use_shards = (world > 1 and args.multi_gpu_mode == "shards") or force_sharded
     if world > 1 or force_sharded:
-        # rank 0 trains; centroids and codebook are broadcast so that every rank
-        # quantises with bit-identical tables (k-means uses atomic scatter-adds)
-        cent = torch.empty((args.nlist, d), dtype=torch.float32, device=dev)
+        cent = torch.empty((nlist, d), dtype=torch.float32, device=dev)
         cb = torch.empty((M, 256, d // M), dtype=torch.float32, device=dev)
         if rank == 0:
             index.train(x)
@@ -121,172 +554,122 @@ def main():
             dist.broadcast(cb, 0)
         index.set_centroids(cent)
         index.set_codebook(cb)
-        if use_shards:
-            ids = torch.arange(rank, args.corpus, world, device=dev)
-            index.add_with_ids(x[rank::world].contiguous(), ids)
-        else:
-            index.add(x)                     # replica: the whole corpus on every rank
+        index.add(x[rank::world].contiguous() if use_shards else x)
     else:
         index.train(x)
         index.add(x)
-    index.nprobe = args.nprobe
-    sharded = ShardedIndex(index, shard_coarse=bool(args.shard_coarse)) if use_shards else None
+    index.nprobe = nprobe
+    sharded = ShardedIndex(index, shard_coarse=bool(args.shard_coarse), id_affine=(world, 0, 1)) if use_shards else None
     log(f"[rank {rank}] setup {time.time() - t0:.1f}s ntotal={index.ntotal}")
 
-    NB = 16                               # pool of distinct query batches (different per rank)
-    qpool = synth.queries_cuda(x, NB * args.batch * world, seed=4321).view(NB, world, args.batch, d)
-    my_q = [qpool[b, rank].contiguous() for b in range(NB)]
-    nq_out = args.batch
-    # steps are independent query batches: they are issued round-robin on S
-    # streams (each with its own output buffers and library workspaces) so that
-    # consecutive batches overlap on the GPU, as a serving loop would run them
-    S = max(1, args.streams) if not use_shards else 1
+    NB = 16
+    qpool = synth.queries_cuda(x, NB * batch * world, seed=4321).view(NB, world, batch, d)
+    my_q = [qpool[b, 0 if use_shards else rank].contiguous() for b in range(NB)]
+    S = max(1, 4 if args.streams is None else args.streams) if not use_shards else 1
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
-    Ds = [torch.empty((nq_out, k), dtype=torch.float32, device=dev) for _ in range(S)]
-    Is = [torch.empty((nq_out, k), dtype=torch.int64, device=dev) for _ in range(S)]
-    D, I = Ds[0], Is[0]
-    torch.cuda.synchronize()
-
+    Ds = [torch.empty((batch, k), dtype=torch.float32, device=dev) for _ in range(S)]
+    Is = [torch.empty((batch, k), dtype=torch.int64, device=dev) for _ in range(S)]
     sptr = [int(s_.cuda_stream) for s_ in streams]
+    torch.cuda.synchronize()
 
     refine = None
     if args.refine > 1 and sharded is None:
-        # second stage over the raw vectors (4 GB at cfg2), candidates in per-stream scratch
         flat_r = faiss.IndexFlatIP(d, device=local_rank)
         flat_r.add(x)
         refine = faiss.IndexRefineFlat(index, flat_r)
         refine.k_factor = args.refine
         kb = k * args.refine
-        cDs = [torch.empty((nq_out, kb), dtype=torch.float32, device=dev) for _ in range(S)]
-        cIs = [torch.empty((nq_out, kb), dtype=torch.int64, device=dev) for _ in range(S)]
+        cDs = [torch.empty((batch, kb), dtype=torch.float32, device=dev) for _ in range(S)]
+        cIs = [torch.empty((batch, kb), dtype=torch.int64, device=dev) for _ in range(S)]
 
     def step(b):
+        j = b % S
         if refine is not None:
-            j = b % S
             refine.search_into(my_q[b % NB], k, Ds[j], Is[j], cDs[j], cIs[j], sptr[j])
         elif sharded is None:
-            j = b % S
             index.search_into(my_q[b % NB], k, Ds[j], Is[j], None, sptr[j])
         else:
-            sharded.search_into(my_q[b % NB], k, D, I)
+            sharded.search_replicated(my_q[b % NB], k)
 
-    for b in range(max(args.warmup, 2 * S)):
+    for b in range(max(warmup, 2 * S)):
         step(b)
     torch.cuda.synchronize()
-    # settle: the timed region is only a few milliseconds at the default K, shorter than
-    # the GPU's clock ramp after the idle setup phase -- run untimed steps for a fixed
-    # wall time first (part of setup; the W warmup steps and the K timed steps follow)
-    t_settle = time.perf_counter()
-    b = 0
+    t_settle, b = time.perf_counter(), 0
     while time.perf_counter() - t_settle < args.settle_ms * 1e-3:
         for _ in range(64):
             step(b)
             b += 1
         torch.cuda.synchronize()
+    dt, blocks, t_issue = clock.measure(step, steps, warmup)
+    replicas = world > 1 and not use_shards
+    qps = steps * batch * (world if replicas else 1) / dt
 
-    def run(nsteps, first=0):
-        for i in range(nsteps):
-            step(first + i)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run(args.warmup)
-    barrier()
-    t1 = time.perf_counter()
-    run(args.steps, args.warmup)
-    t_issue = time.perf_counter() - t1     # host time to issue the steps (diagnostic only)
-    barrier()
-    dt = time.perf_counter() - t1
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    total_queries = args.steps * args.batch * world
-    qps = total_queries / dt
-
-    # ---- roofline of the dominant kernel (PQ-code scan): the library re-launches
-    # the scan of the last step K times back to back between two HIP events
-    # recorded on the launch stream (per-launch events cost more than the kernel)
     torch.cuda.synchronize()
     index.search_into(my_q[0], k, Ds[0], Is[0], None, sptr[0])
-    prof = index.profile_scan(args.steps, sptr[0])
+    prof = index.profile_scan(max(steps, 50), sptr[0])
     torch.cuda.synchronize()
-    scan_ms = prof["scan_ms_avg"]
-    scan_bytes = prof["scan_bytes"]
+    scan_ms, scan_bytes = prof["scan_ms_avg"], prof["scan_bytes"]
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    # HBM traffic per launch: PMC counters cannot be collected from inside the timed
-    # process; the value comes from the committed separate --pmc passes of this same
-    # command (profiles/r01_cfg2_scan_pmc.json) and is reported only for that config
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_cfg2_scan_pmc.json")))
-        if (args.corpus, args.nlist, args.batch, args.nprobe, k, world) == (1_000_000, 4096, 64, 16, 10, 1) \
-                and not os.environ.get("MI_NSLICE"):
+        if (N, nlist, batch, nprobe, k, world) == (1_000_000, 4096, 64, 16, 10, 1) and not os.environ.get("MI_NSLICE"):
             traffic = int(pmc["corrected_bytes_per_launch"])
     except Exception:
         traffic = None
-    roofline = {"kernel": "scan_kernel<64,8>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
+    roofline = {"kernel": "scan_kernel<64,8,false>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, gfx950 x2 read correction "
-                                  "(profiles/r01_cfg2_scan_pmc.json)" if traffic else None,
-                "bytes_per_launch": int(scan_bytes), "avg_launch_ms": round(scan_ms, 5),
-                "launches": args.steps}
-
-    out = None
-    if rank == 0:
-        # ---- recall@10 against exact search (untimed)
-        recall = None
-        if not args.no_recall and world == 1 and sharded is None:
-            flat = faiss.IndexFlatIP(d, device=local_rank)
-            flat.add(x)
-            hits = tot = 0
-            for b in range(4):
-                _, Ia = (refine if refine is not None else index).search(my_q[b], k)
-                _, Ie = flat.search(my_q[b], k)
-                for a, e in zip(Ia.cpu().numpy(), Ie.cpu().numpy()):
-                    hits += len(set(a.tolist()) & set(e.tolist()))
-                    tot += k
-            recall = hits / tot
-            del flat
-        cpu = None
-        if not args.no_cpu_baseline:
-            cpu = cpu_baseline(index, my_q, args, np)
-        out = {
-            "metric": "queries/sec, IVF-PQ search (IVF%d,PQ64%s, %dx1024-d, batch %d, nprobe %d, k %d)"
-                      % (args.nlist, ",RFlat x%d" % args.refine if refine is not None else "", args.corpus, args.batch,
-                         args.nprobe, k),
-            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "cfg2: 1Mx1024 clustered synthetic corpus, IVF4096,PQ64, batch-64 queries",
-                       "corpus": args.corpus, "nlist": args.nlist, "M": 64, "nprobe": args.nprobe,
-                       "k": k, "batch_per_rank": args.batch, "global_batch": args.batch * world,
-                       "parallelism": "1 GPU" if world == 1 else (f"vector-sharded x{world} + all-gather top-k" if use_shards
-                                                                  else f"query-parallel replicas x{world} (no collective)"),
-                       "launch": "eager (a hipGraph replay of the step measured slower)", "streams": S,
-                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                       "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 5)},
-            "recall_at_10": None if recall is None else round(recall, 4),
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        print(json.dumps(out), flush=True)
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+                                  "(profiles/r01_cfg2_scan_pmc.json, round-1 kernel)" if traffic else None,
+                "bytes_per_launch": int(scan_bytes), "avg_launch_ms": round(scan_ms, 5)}
+    if rank != 0:
+        return None
+    recall = None
+    if not args.no_recall and world == 1 and sharded is None:
+        flat = faiss.IndexFlatIP(d, device=local_rank)
+        flat.add(x)
+        hits = tot = 0
+        for b in range(4):
+            _, Ia = (refine if refine is not None else index).search(my_q[b], k)
+            _, Ie = flat.search(my_q[b], k)
+            hits += recall_at_k(Ia, Ie) * Ie.numel()
+            tot += Ie.numel()
+        recall = hits / tot
+        del flat
+    cpu = parity = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu, parity = cpu_baseline_ivfpq(index, torch.cat(my_q), nprobe, k, np, torch, "cfg2")
+    return {
+        "metric": "queries/sec, IVF-PQ search (IVF%d,PQ64%s, %dx1024-d, batch %d, nprobe %d, k %d)"
+                  % (nlist, ",RFlat x%d" % args.refine if refine is not None else "", N, batch, nprobe, k),
+        "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 5), "higher_is_better": True,
+        "scaling": "weak" if replicas else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg2: 1Mx1024 clustered synthetic corpus, IVF4096,PQ64, batch-64 queries (BASELINE.json configs[1])",
+                   "corpus": N, "nlist": nlist, "M": 64, "nprobe": nprobe, "k": k, "global_batch": batch * (world if replicas else 1),
+                   "parallelism": "1 GPU" if world == 1 else (f"vector-sharded x{world} + one all-gather of top-k" if use_shards
+                                                              else f"query-parallel replicas x{world} (no collective)"),
+                   "launch": "eager (a hipGraph replay of the step measured slower)", "streams": S,
+                   "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                   "host_issue_ms_per_step": round(t_issue / steps * 1e3, 5),
+                   "timed_blocks": len(blocks), "timing": "median of the K-step blocks" if len(blocks) > 1 else "one K-step block"},
+        "recall_at_10": None if recall is None else round(recall, 4),
+        "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "reference_oracles": reference_oracles(),
+    }
 
 
-def encode_workload(args, np, torch, dist, world, rank, local_rank, dev):
-    """cfg3: stella_en_1.5B_v5 architecture (random-init bf16 weights -- no
-    checkpoint is reachable from the build/bench boxes), synthetic abstracts with
-    clipped log-normal token counts (median 220, max 512).  A step encodes one
-    batch of `--encode-batch` abstracts: embedding gather, 28 decoder layers,
-    mean pooling, Dense 1536->1024, L2 normalise; token ids start on the host
-    (as they do after tokenisation), embeddings stay in HBM.  N > 1: replicas,
-    every rank encodes its own batches (no collective on this path)."""
+# ======================================================================
+# cfg3: stella_en_1.5B_v5 bf16 batch encode
+# ======================================================================
+def encode_workload(args, ctx, steps, warmup, with_cpu=True):
+    """stella_en_1.5B_v5 architecture (random-init bf16 weights -- no checkpoint is reachable
+    from the build/bench boxes), synthetic abstracts with clipped log-normal token counts
+    (median 220, max 512).  A step encodes one batch of `--encode-batch` abstracts: embedding
+    gather, 28 decoder layers, mean pooling, Dense 1536->1024, L2 normalise; token ids start on
+    the host (as they do after tokenisation), embeddings stay in HBM.  N > 1: replicas, every
+    rank encodes its own batches (no collective on this path)."""
+    np, torch, dist = ctx["np"], ctx["torch"], ctx["dist"]
+    world, rank, local_rank, dev, clock = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["dev"], ctx["clock"]
     import abstracts_search_amd.sentence_transformers as st
     cfg = dict(st.STELLA_EN_1_5B_V5)
     model = st.SentenceTransformer(config=cfg, device=f"cuda:{local_rank}")
@@ -320,23 +703,8 @@ def encode_workload(args, np, torch, dist, world, rank, local_rank, dev):
     def step(i):
         return model.encode_tokens(batches[i % NBATCH], batch_size=bs, normalize_embeddings=True, as_tensor=True)
 
-    for i in range(max(args.warmup, 1)):
-        step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t1
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    toks = sum(ntok[(args.warmup + i) % NBATCH] for i in range(args.steps))
+    dt, blocks, _ = clock.measure(step, steps, max(warmup, 1))
+    toks = sum(ntok[(warmup + i) % NBATCH] for i in range(steps))
     # roofline of the dominant kernel (bf16 MFMA GEMMs): HIP events around the GEMM launches
     model.profile(True)
     step(0)
@@ -344,32 +712,37 @@ def encode_workload(args, np, torch, dist, world, rank, local_rank, dev):
     pr = model.profile_read()
     model.profile(False)
     tf = pr["gemm_flops"] / (pr["gemm_ms"] * 1e-3) / 1e12
-    roofline = {"kernel": "gemm_bf16_ring_kernel<EPI,8,4,2,4,4> (QKV / O / gate-up+SwiGLU / down, 112 launches per step)",
+    roofline = {"kernel": "gemm_bf16_ring_kernel (QKV / O / gate-up+SwiGLU / down, 112 launches per step)",
                 "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(tf / 2500.0, 4), "traffic": None,
                 "flops_per_step": pr["gemm_flops"], "gemm_ms_per_step": round(pr["gemm_ms"], 3)}
-    if rank == 0:
-        cpu = None
-        if not args.no_cpu_baseline:
-            cpu = encode_cpu_baseline(model, cfg, batches, torch, np)
-        print(json.dumps({
-            "metric": "abstracts/sec, stella_en_1.5B_v5 bf16 batch encode (synthetic abstracts, median 220 tokens)",
-            "value": round(args.steps * bs * world / dt, 1), "unit": "abstracts/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic (random-init weights of the real architecture, synthetic token ids)",
-            "config": {"workload": "cfg3: stella_en_1.5B_v5 bf16 batch encode", "batch": bs,
-                       "tokens_per_sec": round(toks * world / dt, 0), "parallelism": "replicas" if world > 1 else "1 GPU"},
-            "roofline": roofline, "cpu_baseline": cpu}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    cpu = None
+    if rank == 0 and with_cpu:
+        cpu = encode_cpu_baseline(model, cfg, batches, torch, np)
+    del model
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    return {
+        "metric": "abstracts/sec, stella_en_1.5B_v5 bf16 batch encode (synthetic abstracts, median 220 tokens)",
+        "value": round(steps * bs * world / dt, 1), "unit": "abstracts/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (random-init weights of the real architecture, synthetic token ids)",
+        "config": {"workload": "cfg3: stella_en_1.5B_v5 bf16 batch encode (BASELINE.json configs[2])", "batch": bs,
+                   "sample": "%d abstracts (%d steps of %d) of the config's 100k: the rate is per batch, batches are independent"
+                             % (steps * bs, steps, bs),
+                   "tokens_per_sec": round(toks * world / dt, 0), "parallelism": "replicas" if world > 1 else "1 GPU",
+                   "timed_blocks": len(blocks)},
+        "roofline": roofline, "cpu_baseline": cpu, "reference_oracles": reference_oracles()}
 
 
 def encode_cpu_baseline(model, cfg, batches, torch, np):
-    """oracle port (torch fp32 on the host cores) on a bounded sample: the same
-    architecture cut to 2 layers and a 4096-row vocabulary (a 1.5 B-parameter fp32
-    copy is 6 GB and tens of seconds per batch), scaled by 28/2 layers."""
+    """sentence-transformers on the host cores when it is importable here (it needs the
+    stella checkpoint too, which no box of this pool has); otherwise the oracle port (torch
+    fp32 on the host cores) on a bounded sample: the same architecture cut to 2 layers and a
+    4096-row vocabulary (a 1.5 B-parameter fp32 copy is 6 GB and tens of seconds per batch),
+    scaled by 28/2 layers."""
     from oracle import encoder_oracle as E
     small = dict(cfg)
     small["n_layers"], small["vocab_size"] = 2, 4096
@@ -385,41 +758,76 @@ def encode_cpu_baseline(model, cfg, batches, torch, np):
             E.encode(E.EncoderConfig(**small), W, ids, cu, True)
         dt = (time.perf_counter() - t0) / reps
     full = dt * cfg["n_layers"] / 2
+    st_state = reference_oracles()["sentence_transformers"]
     return {"value": round(len(toks) / full, 2), "unit": "abstracts/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": f"16 abstracts through 2 of 28 layers (oracle/encoder_oracle.py, torch fp32), "
-                                      f"{dt:.2f}s per pass, scaled x14 to full depth"}
+                                      f"{dt:.2f}s per pass, scaled x14 to full depth",
+            "reference": "sentence_transformers " + st_state + "; the stella_en_1.5B_v5 checkpoint is not on this box"}
 
 
-def cpu_baseline(index, my_q, args, np):
-    """The oracle port (oracle/ivfpq_oracle.c, OpenMP) on the host cores, same
-    index and queries, bounded to roughly 10-20 s."""
+def cpu_baseline_ivfpq(index, queries, nprobe, k, np, torch, tag):
+    """CPU path on the host cores, same index and queries, bounded to roughly 10-30 s: real
+    faiss-cpu when it is importable on this box (the index goes through write_index ->
+    faiss.read_index, which is also the file format's first contact with real faiss),
+    otherwise the oracle port (oracle/ivfpq_oracle.c, OpenMP over queries).  Also returns the
+    parity check of the HIP result against whichever ran."""
+    qs = queries.cpu().numpy()
+    D_hip, I_hip = index.search(queries, k, nprobe=nprobe)
+    D_hip, I_hip = D_hip.cpu().numpy(), I_hip.cpu().numpy()
+    real = real_faiss()
+    if real is not None:
+        import tempfile
+        import abstracts_search_amd.faiss as mine
+        with tempfile.TemporaryDirectory() as tmp:
+            f = os.path.join(tmp, "index.faiss")
+            mine.write_index(index, f)
+            ridx = real.read_index(f)
+        ridx.nprobe = nprobe
+        t0 = time.perf_counter()
+        Dr, Ir = ridx.search(qs, k)
+        one = time.perf_counter() - t0
+        reps = int(max(1, min(50, 15.0 / max(one, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ridx.search(qs, k)
+        dt = time.perf_counter() - t0
+        same = I_hip == Ir
+        mism = ~same
+        dmax = float(np.abs(D_hip - Dr).max())
+        # a mismatch is a rounding tie when the two scores at that rank differ by no more than the f32 spacing
+        tie = np.abs(D_hip - Dr)[mism] <= 4 * np.spacing(np.abs(Dr[mism]).astype(np.float32)) if mism.any() else np.array([], bool)
+        parity = {"against": "faiss-cpu " + getattr(real, "__version__", "?"), "queries": int(qs.shape[0]),
+                  "ids_exact_match_rate": float(same.mean()), "max_abs_score_diff": dmax,
+                  "mismatches_that_are_rounding_ties": int(tie.sum()), "mismatches": int(mism.sum())}
+        cpu = {"value": round(reps * qs.shape[0] / dt, 1), "unit": "queries/s", "cores": real.omp_get_max_threads(),
+               "kind": "faiss-cpu", "sample": f"{reps} calls of {qs.shape[0]} queries, same index (write_index -> faiss.read_index), "
+                                                f"nprobe {nprobe}, k {k}, {dt:.1f}s"}
+        return cpu, parity
     from oracle import ivfpq_oracle as O
     O.build()
     cent, cb = index.get_centroids(), index.get_codebook()
-    sizes = np.array([index.list_size(l) for l in range(index.nlist)], np.int64)
+    sizes = index.list_sizes()
     off = np.zeros(index.nlist + 1, np.int64)
     np.cumsum(sizes, out=off[1:])
-    codes = np.empty((int(off[-1]), 64), np.uint8)
-    ids = np.empty(int(off[-1]), np.int64)
-    for l in range(index.nlist):
-        if sizes[l]:
-            c, i = index.get_list(l)
-            codes[off[l]:off[l + 1]], ids[off[l]:off[l + 1]] = c, i
-    # all 16 distinct batches per call (1024 queries) so that every host core has
-    # work: the oracle parallelises over queries, as faiss-cpu does
-    qs = np.concatenate([q.cpu().numpy() for q in my_q])
     t0 = time.perf_counter()
-    O.search(qs, cent, cb, off, codes, ids, args.nprobe, args.k)     # warm + calibrate
+    codes, ids = index.export_lists()                                   # list order, insertion order inside a list
+    t_exp = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    De, Ie = O.search(qs, cent, cb, off, codes, ids, nprobe, k)         # warm + calibrate + parity
     one = time.perf_counter() - t0
-    reps = int(max(2, min(200, 12.0 / max(one, 1e-4))))
+    reps = int(max(1, min(200, 12.0 / max(one, 1e-4))))
     t0 = time.perf_counter()
-    for r in range(reps):
-        O.search(qs, cent, cb, off, codes, ids, args.nprobe, args.k)
+    for _ in range(reps):
+        O.search(qs, cent, cb, off, codes, ids, nprobe, k)
     dt = time.perf_counter() - t0
-    return {"value": round(reps * qs.shape[0] / dt, 1), "unit": "queries/s", "cores": O.num_threads(),
-            "kind": "port",
-            "sample": f"{reps} calls of {qs.shape[0]} queries (16 batches of {args.batch}), same index/nprobe/k, {dt:.1f}s "
-                      f"(oracle/ivfpq_oracle.c, OpenMP over queries; faiss-cpu not installable here)"}
+    parity = {"against": "oracle/ivfpq_oracle.c (CPU restatement; faiss absent on this box)", "queries": int(qs.shape[0]),
+              "ids_equal": bool(np.array_equal(I_hip, Ie)),
+              "scores_bit_equal": bool(np.array_equal(D_hip.view(np.uint32), De.view(np.uint32)))}
+    cpu = {"value": round(reps * qs.shape[0] / dt, 1), "unit": "queries/s", "cores": O.num_threads(), "kind": "port",
+           "sample": f"{reps} calls of {qs.shape[0]} queries on the same {tag} index ({int(sizes.sum())} vectors exported from HBM in "
+                     f"{t_exp:.1f}s), nprobe {nprobe}, k {k}, {dt:.1f}s (oracle/ivfpq_oracle.c, OpenMP over queries; "
+                     f"faiss-cpu is not importable on this box)"}
+    return cpu, parity
 
 
 if __name__ == "__main__":

@@ -151,6 +151,19 @@ int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_a
 int mi_merge_topk(int device, int nparts, int64_t nq, int k, const float *D_parts,
                   const int64_t *I_parts, float *D, int64_t *I, void *stream);
 
+/* The same merge straight on the receive buffer of ONE all-gather (the path's one exchange
+ * step, SURVEY 8(e): ncclAllGather of nq*k*12 bytes per rank).  `gathered` = nparts blocks
+ * of blk_bytes; block p = { float D[nq*k]; pad to 8 bytes; int64 I[nq*k] } exactly as rank
+ * p's mi_index_search() wrote its (D, I) into the two halves of its send buffer.  Ids are
+ * translated while they are loaded: global = local * id_mul + id_add + p * id_step
+ * (round-robin shards numbered by position: {nparts, 0, 1}; identity: {1, 0, 0}); negative
+ * ids stay empty slots.  Only the queries [q_lo, q_lo + nq_out) of the nq in every block are
+ * merged (a rank that brought its own batch merges its own slice): D, I are [nq_out][k].
+ * Device pointers only; enqueues on `stream`. */
+int mi_merge_topk_gathered(int device, int nparts, int64_t nq, int k, const void *gathered,
+                           int64_t blk_bytes, int64_t id_mul, int64_t id_add, int64_t id_step,
+                           int64_t q_lo, int64_t nq_out, float *D, int64_t *I, void *stream);
+
 /* ---- IndexFlatIP (config #1; also the coarse quantiser's arithmetic) ---- */
 
 int mi_flat_create(int d, int device, mi_flat **out);

@@ -97,8 +97,19 @@ def _worker(rank, world, port, mode, ret):
         dist.barrier()
         dist.destroy_process_group()
         return
-    sh = ShardedIndex(index=None, local_search=local_search, merge=merge, shard_coarse=mode.endswith("+coarse"),
-                      local_coarse=local_coarse, local_search_pre=local_search_pre, nlist=nlist, nprobe=nprobe)
+    if mode.endswith("+affine"):
+        # shard lists numbered by position; the merge's closed-form map (global = local * world + rank)
+        # restores the global row numbers
+        off_l, lc_l, li_l = O.build_lists(ln, codes, np.arange(len(rows)), nlist)
+
+        def local_search_pos(q, kk):
+            D, I = O.search(q.numpy(), cent, cb, off_l, lc_l, li_l, nprobe, kk)
+            return torch.from_numpy(D), torch.from_numpy(I)
+
+        sh = ShardedIndex(index=None, local_search=local_search_pos, merge=merge, id_affine=(world, 0, 1))
+    else:
+        sh = ShardedIndex(index=None, local_search=local_search, merge=merge, shard_coarse=mode.endswith("+coarse"),
+                          local_coarse=local_coarse, local_search_pre=local_search_pre, nlist=nlist, nprobe=nprobe)
     rng = np.random.default_rng(100)
     qall = (x[rng.integers(0, n, world * b)] + 0.01 * rng.standard_normal((world * b, x.shape[1]))).astype(np.float32)
     if mode.startswith("own"):
@@ -118,7 +129,8 @@ def _worker(rank, world, port, mode, ret):
 
 
 @pytest.mark.parametrize("world,mode", [(2, "own"), (2, "replicated"), (3, "own"), (2, "own+coarse"),
-                                        (3, "replicated+coarse"), (2, "refine"), (3, "refine")])
+                                        (3, "replicated+coarse"), (2, "refine"), (3, "refine"),
+                                        (2, "replicated+affine"), (3, "own+affine")])
 def test_sharded_equals_unsharded(world, mode):
     from oracle import ivfpq_oracle as O
     O.build()
