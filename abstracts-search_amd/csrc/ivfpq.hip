@@ -903,12 +903,19 @@ int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_a
 // fewer than ~16 code groups (two per wave) of expected work per slice: every
 // slice re-stages the query's 64 KiB LUT, so more slices = more LDS fill traffic
 // (PMC: at 8 slices the LUT reads equal the code bytes).
-static int choose_nslice(const mi_index *h, int64_t nq, int nprobe) {
+static int choose_nslice(const mi_index *h, int64_t nq, int nprobe, int k = 10) {
     double avg_groups = h->nlist > 0 ? (double)h->ngroups / h->nlist : 0.0;
     double per_query = avg_groups * nprobe;
     int64_t by_fill = (256 + nq - 1) / nq;              // one workgroup per CU
     int64_t by_work = (int64_t)(per_query / 16.0);       // >= 2 groups per wave
     int64_t s = std::min(by_fill, by_work);
+    // Big scans (cfg4: 1024 queries x 3160 groups): one workgroup per query is two rounds of
+    // 512 co-resident workgroups whose lengths differ with the probed lists -- the last CUs idle
+    // while the longest finish.  Slices of >= 128 groups even that out (207 M index, 1024 x
+    // nprobe 64: scan 2.77 -> 2.49 ms, 5.27 -> 5.85 TB/s; profiles/r02_cfg4_scan_sweep.txt);
+    // at most 64 / k slices so that the cross-slice merge stays on its one-wave path.
+    const int64_t by_tail = std::min<int64_t>((int64_t)(per_query / 128.0), std::max(1, std::min(8, 64 / std::max(1, std::min(k, 64)))));
+    s = std::max(s, by_tail);
     if (const char *e = std::getenv("MI_NSLICE")) s = std::atoi(e);  // tuning knob
     return (int)std::max<int64_t>(1, std::min<int64_t>(s, 32));
 }
@@ -976,7 +983,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     if (lut_out) MI_HIP(hipMemcpyAsync(lut_out, lut, (size_t)nq * M * 256 * 4, hipMemcpyDeviceToHost, st));
     if (stop_after_lut) return;
 
-    const int nslice = choose_nslice(h, nq, nprobe);
+    const int nslice = choose_nslice(h, nq, nprobe, std::min(k, 64));
     const int npass = (k + 63) / 64;
     float *ps = w.ps.as<float>((size_t)nq * nslice * 64);
     int64_t *pid = w.pid.as<int64_t>((size_t)nq * nslice * 64);

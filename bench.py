@@ -472,7 +472,7 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     args_nprobe = index.nprobe                                         # restored below
     ref = faiss.IndexRefineFlat(base, flat_r)
     sharded = ShardedIndex(ref, id_affine=(nsh, 0, 1)) if (refine_own and nsh > 1) else None
-    cands = [(8, 64), (8, 100), (16, 100), (16, 160), (32, 200), (64, 256), (64, 400)]
+    cands = [(8, 64), (8, 80), (8, 100), (16, 100), (16, 160), (32, 200), (64, 256), (64, 400)]
     best = None
     for nprobe, kf in cands:
         base.nprobe, ref.k_factor = nprobe, kf
