@@ -96,6 +96,57 @@ def _cfg_from_hf(hf: dict) -> dict:
                 max_seq_len=int(hf.get("max_position_embeddings", 512)))
 
 
+class HostTokenizer:
+    """Host-side tokenisation with sentence-transformers / HF semantics (the
+    `tokenizers` library does the work, nothing is re-implemented): `truncation=True,
+    max_length=max_seq_length` keeps the special tokens the post-processor adds (the tail of
+    an over-long input is cut *before* post-processing, as HF fast tokenizers do), and a
+    tokenizer_config.json with `add_eos_token: true` whose tokenizer.json does not already
+    append the end-of-sequence token gets it appended after truncating to max_length - 1 --
+    what a trust_remote_code tokenizer class that appends EOS at run time does."""
+
+    def __init__(self, tokenizer, add_eos: bool = False, eos_token: str | None = None):
+        self.tk = tokenizer
+        self.eos_id = tokenizer.token_to_id(eos_token) if (add_eos and eos_token) else None
+        self.appends_eos = False
+        if self.eos_id is not None:
+            probe = tokenizer.encode("a").ids
+            self.appends_eos = bool(probe) and probe[-1] == self.eos_id
+        self._trunc = None
+        try:
+            tokenizer.no_padding()
+        except Exception:
+            pass
+
+    @classmethod
+    def from_dir(cls, path: str, tokenizer=None):
+        from tokenizers import Tokenizer
+        tk = tokenizer if tokenizer is not None else Tokenizer.from_file(os.path.join(path, "tokenizer.json"))
+        add_eos, eos = False, None
+        tc = os.path.join(path, "tokenizer_config.json")
+        if os.path.exists(tc):
+            c = json.load(open(tc))
+            add_eos = bool(c.get("add_eos_token", False))
+            eos = c.get("eos_token")
+            if isinstance(eos, dict):
+                eos = eos.get("content")
+        return cls(tk, add_eos, eos)
+
+    def __call__(self, texts, max_length: int):
+        manual_eos = self.eos_id is not None and not self.appends_eos
+        want = max(1, max_length - 1) if manual_eos else max_length
+        if self._trunc != want:
+            self.tk.enable_truncation(max_length=want)
+            self._trunc = want
+        out = []
+        for e in self.tk.encode_batch(list(texts)):
+            ids = list(e.ids)
+            if manual_eos:
+                ids.append(self.eos_id)
+            out.append(ids if ids else [0])
+        return out
+
+
 class SentenceTransformer:
     """sentence_transformers.SentenceTransformer on one MI355X."""
 
@@ -107,7 +158,7 @@ class SentenceTransformer:
         self.prompts = dict(prompts or {})
         self.default_prompt_name = default_prompt_name
         self.tokenizer = tokenizer
-        self.add_eos = False
+        self._host_tok = HostTokenizer(tokenizer) if tokenizer is not None else None
         self._device_index = 0
         if device is not None:
             s = str(device)
@@ -173,9 +224,9 @@ class SentenceTransformer:
         if os.path.exists(sb):
             cfg["max_seq_len"] = int(json.load(open(sb)).get("max_seq_length", cfg["max_seq_len"]))
         tk = os.path.join(path, "tokenizer.json")
-        if self.tokenizer is None and os.path.exists(tk):
-            from tokenizers import Tokenizer
-            self.tokenizer = Tokenizer.from_file(tk)
+        if self.tokenizer is not None or os.path.exists(tk):
+            self._host_tok = HostTokenizer.from_dir(path, self.tokenizer)   # + tokenizer_config.json (add_eos_token)
+            self.tokenizer = self._host_tok.tk
         return cfg, weights
 
     def load_weights(self, weights: dict):
@@ -211,15 +262,11 @@ class SentenceTransformer:
         return self.max_seq_length
 
     def tokenize(self, texts):
-        """list[str] -> list of token-id lists (truncated to max_seq_length)."""
-        if self.tokenizer is None:
+        """list[str] -> list of token-id lists, truncated to max_seq_length the way
+        sentence-transformers does (special tokens survive; see HostTokenizer)."""
+        if self._host_tok is None:
             raise RuntimeError("no tokenizer: pass tokenizer= or a model directory with tokenizer.json")
-        enc = self.tokenizer.encode_batch(list(texts))
-        out = []
-        for e in enc:
-            ids = list(e.ids)[: self.max_seq_length]
-            out.append(ids if ids else [0])
-        return out
+        return self._host_tok(texts, self.max_seq_length)
 
     def encode(self, sentences, prompt_name: str | None = None, prompt: str | None = None,
                batch_size: int = 32, show_progress_bar=None, output_value: str = "sentence_embedding",

@@ -137,35 +137,12 @@ def test_errors(st):
 
 def test_model_directory_and_text_encode(st, tmp_path):
     """the sentence-transformers directory layout + tokenizer + prompts path"""
-    import json
-    import torch
-    from safetensors.torch import save_file
-    from tokenizers import Tokenizer, models, pre_tokenizers
     from oracle import encoder_oracle as E
+    from helpers_modeldir import write_model_dir
     cfg = E.TINY
     W = E.synth_weights(cfg, 11)
     d = tmp_path / "model"
-    (d / "2_Dense_64").mkdir(parents=True)
-    json.dump(dict(hidden_size=cfg.hidden, num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads,
-                   head_dim=cfg.head_dim, num_hidden_layers=cfg.n_layers, intermediate_size=cfg.intermediate,
-                   vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
-                   max_position_embeddings=cfg.max_seq_len, is_causal=False), open(d / "config.json", "w"))
-    save_file({("model." + k): v.bfloat16() for k, v in W.items() if not k.startswith("dense.")},
-              str(d / "model.safetensors"))
-    save_file({"linear.weight": W["dense.weight"], "linear.bias": W["dense.bias"]},
-              str(d / "2_Dense_64" / "model.safetensors"))
-    json.dump(dict(in_features=cfg.hidden, out_features=cfg.dense_out, bias=True), open(d / "2_Dense_64" / "config.json", "w"))
-    json.dump([dict(idx=0, name="0", path="", type="sentence_transformers.models.Transformer"),
-               dict(idx=1, name="1", path="1_Pooling", type="sentence_transformers.models.Pooling"),
-               dict(idx=2, name="2", path="2_Dense_64", type="sentence_transformers.models.Dense")],
-              open(d / "modules.json", "w"))
-    json.dump(dict(prompts={"s2p_query": "query: "}, default_prompt_name=None), open(d / "config_sentence_transformers.json", "w"))
-    json.dump(dict(max_seq_length=32), open(d / "sentence_bert_config.json", "w"))
-    vocab = {f"w{i}": i for i in range(cfg.vocab_size - 3)}
-    vocab.update({"query": cfg.vocab_size - 3, ":": cfg.vocab_size - 2, "[UNK]": cfg.vocab_size - 1})
-    tk = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
-    tk.pre_tokenizer = pre_tokenizers.Whitespace()
-    tk.save(str(d / "tokenizer.json"))
+    write_model_dir(d, cfg, W, max_seq_length=32)
 
     model = st.SentenceTransformer(str(d), trust_remote_code=True)
     assert model.get_sentence_embedding_dimension() == cfg.dense_out and model.max_seq_length == 32
