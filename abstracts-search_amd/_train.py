@@ -84,15 +84,18 @@ def kmeans_l2(x, k: int, niter: int, seed: int, device: int, verbose: bool = Fal
     return c.contiguous()
 
 
-def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbose: bool = False):
+def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbose: bool = False, centroids=None):
     import torch
     d = x.shape[1]
     dsub = d // M
-    # coarse centroids
-    xs = _to_device_sample(x, cp.max_points_per_centroid * nlist, cp.seed, device)
-    if verbose:
-        print(f"train: coarse k-means on {xs.shape[0]} points, k={nlist}")
-    cent = kmeans_l2(xs, nlist, cp.niter, cp.seed, device, verbose)
+    # coarse centroids (given: the caller's quantizer was already trained)
+    if centroids is not None:
+        cent = centroids.contiguous()
+    else:
+        xs = _to_device_sample(x, cp.max_points_per_centroid * nlist, cp.seed, device)
+        if verbose:
+            print(f"train: coarse k-means on {xs.shape[0]} points, k={nlist}")
+        cent = kmeans_l2(xs, nlist, cp.niter, cp.seed, device, verbose)
     # PQ codebooks on (residual) sub-vectors
     xp = _to_device_sample(x, cp.max_points_per_centroid * 256, cp.seed + 1, device)
     if by_residual:

@@ -1678,6 +1678,16 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
     });
 }
 
+int mi_flat_reconstruct_n(mi_flat *h, int64_t i0, int64_t n, float *out) {
+    return guard([&] {
+        MI_REQUIRE(h && (n == 0 || out), "null argument");
+        MI_REQUIRE(i0 >= 0 && n >= 0 && i0 + n <= h->ntotal, "reconstruct_n: range out of bounds");
+        if (n == 0) return;
+        DeviceGuard dg(h->device);
+        MI_HIP(hipMemcpy(out, h->base.get<float>() + (size_t)i0 * h->d, (size_t)n * h->d * 4, hipMemcpyDefault));
+    });
+}
+
 int mi_flat_ntotal(mi_flat *h, int64_t *out) {
     return guard([&] {
         MI_REQUIRE(h && out, "null argument");

@@ -84,6 +84,7 @@ class _Lib:
                 "mi_flat_add": [v, c_int64, v],
                 "mi_flat_reserve": [v, c_int64],
                 "mi_flat_ntotal": [v, POINTER(c_int64)],
+                "mi_flat_reconstruct_n": [v, c_int64, c_int64, v],
                 "mi_flat_reset": [v],
                 "mi_flat_search": [v, c_int64, v, c_int, v, v, v],
                 "mi_flat_rerank": [v, c_int64, v, c_int, v, c_int, v, v, v],
@@ -191,7 +192,18 @@ class IndexFlatIP:
     def reset(self):
         _check(_Lib.get().mi_flat_reset(self._h))
 
+    def reconstruct_n(self, i0: int = 0, ni: int = -1) -> np.ndarray:
+        """faiss Index.reconstruct_n: the stored vectors [i0, i0 + ni) (all of them by default)."""
+        ni = self.ntotal - i0 if ni < 0 else ni
+        out = np.empty((ni, self.d), np.float32)
+        _check(_Lib.get().mi_flat_reconstruct_n(self._h, int(i0), int(ni), _ptr(out)))
+        return out
+
+    def reconstruct(self, i: int) -> np.ndarray:
+        return self.reconstruct_n(int(i), 1)[0]
+
     def search(self, x, k: int):
+        self._require_ip("search")
         x = _as_f32(x, self.d)
         assert k > 0
         nq = x.shape[0]
@@ -209,10 +221,17 @@ class IndexFlatIP:
         return D, I
 
 
+    def _require_ip(self, what: str):
+        if self.metric_type != METRIC_INNER_PRODUCT:
+            raise NotImplementedError(f"IndexFlatL2.{what}: only METRIC_INNER_PRODUCT is computed on the MI355X path "
+                                      "(an L2 IndexFlat is accepted as a container -- e.g. the quantizer object "
+                                      "handed to IndexIVFPQ -- but not searched)")
+
     def rerank(self, x, cand_I, k: int, D=None, I=None, stream: int | None = None):
         """Exact scores of the candidate ids cand_I [nq, kc] (kc a multiple of k,
         negative = empty) and the k best -- the second stage of IndexRefineFlat.
         numpy in -> numpy out; CUDA tensors in -> CUDA tensors (D / I may be given)."""
+        self._require_ip("rerank")
         x = _as_f32(x, self.d)
         nq, kc = x.shape[0], int(cand_I.shape[1])
         if _is_torch(x) and x.is_cuda:
@@ -233,10 +252,20 @@ class IndexFlatIP:
 
 
 class IndexFlat(IndexFlatIP):
+    """faiss.IndexFlat(d, metric).  METRIC_L2 (faiss's default) gives a storage-only index:
+    add / ntotal / reconstruct_n work -- enough for the `quantizer` argument of the real
+    IndexIVFPQ constructor -- and search raises NotImplementedError."""
+
     def __init__(self, d: int, metric: int = METRIC_L2, device: int = 0):
-        if metric != METRIC_INNER_PRODUCT:
-            raise NotImplementedError("only METRIC_INNER_PRODUCT is implemented on the MI355X path")
+        if metric not in (METRIC_INNER_PRODUCT, METRIC_L2):
+            raise NotImplementedError("metric must be METRIC_INNER_PRODUCT or METRIC_L2")
         super().__init__(d, device)
+        self.metric_type = int(metric)
+
+
+class IndexFlatL2(IndexFlat):
+    def __init__(self, d: int, device: int = 0):
+        super().__init__(d, METRIC_L2, device)
 
 
 # ----------------------------------------------------------------------
@@ -272,8 +301,29 @@ class IndexIVFPQ:
     nprobe nlist metric_type by_residual pq``.
     """
 
-    def __init__(self, d: int, nlist: int, M: int, nbits: int = 8,
-                 metric: int = METRIC_INNER_PRODUCT, by_residual: bool = True, device: int = 0):
+    def __init__(self, *args, **kw):
+        """Two signatures: faiss's own ``IndexIVFPQ(quantizer, d, nlist, M, nbits_per_idx[, metric])``
+        (first argument an IndexFlat; centroids it already holds are taken over, and faiss's default
+        metric there is METRIC_L2, which this path rejects -- pass METRIC_INNER_PRODUCT) and this
+        mirror's ``IndexIVFPQ(d, nlist, M, nbits=8, metric=METRIC_INNER_PRODUCT, by_residual=True, device=0)``."""
+        quantizer = None
+        if args and isinstance(args[0], IndexFlatIP):
+            quantizer, args = args[0], args[1:]
+            names = ("d", "nlist", "M", "nbits", "metric")
+            p = dict(nbits=8, metric=METRIC_L2, by_residual=True, device=quantizer.device)
+        else:
+            names = ("d", "nlist", "M", "nbits", "metric", "by_residual", "device")
+            p = dict(nbits=8, metric=METRIC_INNER_PRODUCT, by_residual=True, device=0)
+        if len(args) > len(names):
+            raise TypeError("IndexIVFPQ: too many positional arguments")
+        p.update(dict(zip(names, args)))
+        p.update(kw)
+        d, nlist, M, nbits, metric, by_residual, device = (p[k] for k in ("d", "nlist", "M", "nbits", "metric", "by_residual", "device"))
+        if quantizer is not None:
+            assert quantizer.d == int(d), f"quantizer.d ({quantizer.d}) != d ({d})"
+            if int(metric) != METRIC_INNER_PRODUCT:
+                raise NotImplementedError("IndexIVFPQ(quantizer, d, nlist, M, nbits): faiss's default metric is METRIC_L2; only "
+                                          "METRIC_INNER_PRODUCT is implemented on the MI355X path -- pass it as the sixth argument")
         self.d, self.nlist, self.device = int(d), int(nlist), int(device)
         self.metric_type = int(metric)
         self.by_residual = bool(by_residual)
@@ -284,6 +334,21 @@ class IndexIVFPQ:
         self._h = c_void_p()
         _check(_Lib.get().mi_index_create(self.d, self.nlist, int(M), int(nbits), self.metric_type,
                                           int(self.by_residual), self.device, ctypes.byref(self._h)))
+        self._coarse_set = False
+        if quantizer is not None and quantizer.ntotal:
+            # a quantizer that already holds centroids is a trained quantizer (faiss: quantizer.is_trained
+            # and quantizer.ntotal == nlist -> train() only trains the PQ)
+            assert quantizer.ntotal == self.nlist, f"quantizer holds {quantizer.ntotal} vectors, nlist is {self.nlist}"
+            self.set_centroids(quantizer.reconstruct_n(0, self.nlist))
+
+    @property
+    def quantizer(self):
+        """faiss's index.quantizer: an IndexFlat over the coarse centroids (a copy; empty
+        until the index is trained)."""
+        q = IndexFlat(self.d, self.metric_type, self.device)
+        if self._coarse_set:
+            q.add(self.get_centroids())
+        return q
 
     @classmethod
     def _from_handle(cls, h, device: int = 0):
@@ -298,6 +363,7 @@ class IndexIVFPQ:
         self.cp = ClusteringParameters()
         self.verbose = False
         self._h = h
+        self._coarse_set = self.is_trained
         return self
 
     def __del__(self):
@@ -330,6 +396,7 @@ class IndexIVFPQ:
         c = np.ascontiguousarray(centroids, np.float32) if not _is_torch(centroids) else centroids.contiguous()
         assert tuple(c.shape) == (self.nlist, self.d)
         _check(_Lib.get().mi_index_set_coarse(self._h, _ptr(c)))
+        self._coarse_set = True
 
     def set_codebook(self, codebook):
         """PQ codebook [M, 256, d/M] (faiss: index.pq.centroids)."""
@@ -355,8 +422,14 @@ class IndexIVFPQ:
         the centroid means are torch scatter-adds on the device."""
         from . import _train
         x = _as_f32(x, self.d)
+        # faiss: a quantizer that is already trained and holds nlist centroids keeps them
+        # (IndexIVFPQ(quantizer, ...) with a filled quantizer): only the PQ is trained then
+        given = None
+        if self._coarse_set and not self.is_trained:
+            import torch
+            given = torch.from_numpy(self.get_centroids()).to(torch.device("cuda", self.device))
         cent, cb = _train.train_ivfpq(x, self.nlist, self.pq.M, self.by_residual, self.cp,
-                                      self.device, self.verbose)
+                                      self.device, self.verbose, centroids=given)
         self.set_centroids(cent)
         self.set_codebook(cb)
 
@@ -721,6 +794,12 @@ def index_gpu_to_cpu(index):
 
 
 def extract_index_ivf(index):
+    """faiss.extract_index_ivf: the IndexIVF inside a wrapper (IndexRefineFlat -> its base index)."""
+    while not isinstance(index, IndexIVFPQ):
+        inner = getattr(index, "base_index", None) or getattr(index, "index", None)
+        if inner is None:
+            raise RuntimeError("extract_index_ivf: no IndexIVF inside this index")
+        index = inner
     return index
 
 

@@ -172,6 +172,9 @@ int mi_flat_add(mi_flat *h, int64_t n, const float *x);
 /* Capacity hint (std::vector::reserve on faiss's IndexFlat::codes): room for n vectors in
  * total, so that a 100 GB store filled in chunks never holds two copies while growing. */
 int mi_flat_reserve(mi_flat *h, int64_t n);
+/* IndexFlat.reconstruct_n: vectors [i0, i0 + n) as stored, float32 [n][d] (host or device
+ * output) -- e.g. the centroids of an IndexFlat handed to IndexIVFPQ as its quantizer. */
+int mi_flat_reconstruct_n(mi_flat *h, int64_t i0, int64_t n, float *out);
 int mi_flat_ntotal(mi_flat *h, int64_t *out);
 int mi_flat_reset(mi_flat *h);
 int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int64_t *I,
