@@ -58,6 +58,20 @@ def build(name: str, force: bool = False, verbose: bool = False) -> str:
     return so
 
 
+def oa_jsonl_path() -> str:
+    return os.path.join(_PKG, "oa_jsonl_mt")
+
+
+def build_oa_jsonl(force: bool = False) -> str:
+    """The host-side OpenAlex text filter (csrc/oa_jsonl_mt.c, plain C + pthreads)."""
+    src, exe = os.path.join(_CSRC, "oa_jsonl_mt.c"), oa_jsonl_path()
+    if force or not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        cc = shutil.which("gcc") or shutil.which("cc")
+        subprocess.check_call([cc, "-O2", "-Wall", "-Wextra", "-pthread", "-o", exe + ".tmp", src])
+        os.replace(exe + ".tmp", exe)
+    return exe
+
+
 def build_all(force: bool = False, verbose: bool = False) -> list[str]:
     out = []
     for name, (_, srcs, _) in LIBS.items():
