@@ -4,8 +4,9 @@ the nlist coarse centroids and for the M sub-quantiser codebooks.
 Not on the timed path.  The assignment steps -- the only
 heavy part -- run on the library's own kernels through the C ABI
 (``mi_ip_assign``: exact-f32 MFMA GEMM + arg max; ``mi_pq_encode``: nearest
-codeword per sub-vector).  The centroid means are torch scatter-adds on the
-device (plumbing).
+codeword per sub-vector).  The update step is the library's deterministic
+``mi_cluster_means`` (a cluster's members summed in ascending row order), so
+training is bit-reproducible and restated by oracle/train_oracle.py.
 """
 from __future__ import annotations
 
@@ -43,19 +44,41 @@ def _to_device_sample(x, nmax: int, seed: int, device: int):
 
 
 def _assign_ip(x, c, device):
+    """arg max_j <x_i, c_j> (ties: smallest j) -> int32 CUDA tensor."""
     import torch
     n = x.shape[0]
     a = torch.empty(n, dtype=torch.int32, device=x.device)
     stream = c_void_p(torch.cuda.current_stream().cuda_stream)
     _check(_lib().mi_ip_assign(device, n, c_void_p(x.data_ptr()), c.shape[0], c_void_p(c.data_ptr()),
                                x.shape[1], c_void_p(a.data_ptr()), c_void_p(0), stream))
-    return a.long()
+    return a
+
+
+def _cluster_means(x, assign, cent, device):
+    """In-place k-means update on the library's deterministic kernel (mi_cluster_means):
+    members summed in ascending row order; empty clusters keep their row.  Returns counts."""
+    import torch
+    k, d = cent.shape
+    cnt = torch.empty(k, dtype=torch.int32, device=x.device)
+    stream = c_void_p(torch.cuda.current_stream().cuda_stream)
+    _check(_lib().mi_cluster_means(device, x.shape[0], c_void_p(x.data_ptr()), d, c_void_p(assign.data_ptr()), k,
+                                   c_void_p(cent.data_ptr()), c_void_p(cnt.data_ptr()), stream))
+    return cnt
+
+
+def _neg_half_sqnorm(c, device):
+    import torch
+    out = torch.empty(c.shape[0], dtype=torch.float32, device=c.device)
+    _check(_lib().mi_neg_half_sqnorm(device, c.shape[0], c_void_p(c.data_ptr()), c.shape[1], c_void_p(out.data_ptr()),
+                                     c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
 
 
 def kmeans_l2(x, k: int, niter: int, seed: int, device: int, verbose: bool = False):
-    """Lloyd k-means, L2.  arg min ||x-c||^2 = arg max (<x,c> - ||c||^2/2), evaluated
-    by the inner-product kernel on vectors augmented with 4 columns
-    ([x, 1, 0, 0, 0] . [c, -||c||^2/2, 0, 0, 0])."""
+    """Lloyd k-means, L2, bit-reproducible (restated by oracle/train_oracle.py).
+    arg min ||x-c||^2 = arg max (<x,c> - ||c||^2/2), evaluated by the inner-product kernel on
+    vectors augmented with one column ([x, 1, 0...] . [c, -||c||^2/2, 0...]); the update step
+    sums a cluster's members in ascending row order (mi_cluster_means)."""
     import torch
     n, d = x.shape
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -63,18 +86,17 @@ def kmeans_l2(x, k: int, niter: int, seed: int, device: int, verbose: bool = Fal
     c = x[perm].clone()
     if n <= k:  # degenerate: fewer points than centroids
         c = torch.cat([c, c[torch.randint(0, max(n, 1), (k - c.shape[0],), generator=g).to(x.device)]])
+    c = c.contiguous()
     # zero columns after the augmenting one add exact zeros to the end of every fmaf chain (the
     # scores do not change); padding to a multiple of 128 columns lets big problems take the
     # two-stage assignment (f16 MFMA scores + exact re-scoring, bit-identical arg max)
     pad = 127 if d % 128 == 0 and k >= 8192 else 3
     xa = torch.cat([x, torch.ones(n, 1, device=x.device), torch.zeros(n, pad, device=x.device)], 1).contiguous()
     for it in range(niter):
-        ca = torch.cat([c, -0.5 * (c * c).sum(1, keepdim=True), torch.zeros(k, pad, device=x.device)], 1).contiguous()
+        ca = torch.cat([c, _neg_half_sqnorm(c, device).unsqueeze(1), torch.zeros(k, pad, device=x.device)], 1).contiguous()
         a = _assign_ip(xa, ca, device)
-        sums = torch.zeros(k, d, device=x.device).index_add_(0, a, x)
-        cnt = torch.bincount(a, minlength=k).to(torch.float32)
+        cnt = _cluster_means(x, a, c, device)
         empty = cnt == 0
-        c = sums / cnt.clamp(min=1).unsqueeze(1)
         ne = int(empty.sum())
         if ne:  # re-seed empty clusters from random points
             idx = torch.randint(0, n, (ne,), generator=g).to(x.device)
@@ -99,7 +121,7 @@ def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbo
     # PQ codebooks on (residual) sub-vectors
     xp = _to_device_sample(x, cp.max_points_per_centroid * 256, cp.seed + 1, device)
     if by_residual:
-        a = _assign_ip(xp, cent, device)
+        a = _assign_ip(xp, cent, device).long()
         xp = (xp - cent[a]).contiguous()
     n = xp.shape[0]
     g = torch.Generator(device="cpu").manual_seed(cp.seed + 2)
@@ -109,15 +131,12 @@ def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbo
     cb = xp[init.to(xp.device)].view(256, M, dsub).permute(1, 0, 2).contiguous()  # [M,256,dsub]
     codes = torch.empty(n, M, dtype=torch.uint8, device=xp.device)
     stream = lambda: c_void_p(torch.cuda.current_stream().cuda_stream)
-    offs = (torch.arange(M, device=xp.device) * 256).unsqueeze(0)
+    offs = (torch.arange(M, device=xp.device, dtype=torch.int32) * 256).unsqueeze(0)
+    rows = xp.view(n * M, dsub)                      # row i*M + m = sub-vector m of point i
     for it in range(cp.niter):
         _check(_lib().mi_pq_encode(device, n, c_void_p(xp.data_ptr()), d, M, c_void_p(cb.data_ptr()),
                                    c_void_p(codes.data_ptr()), stream()))
-        idx = (codes.long() + offs).reshape(-1)
-        sums = torch.zeros(M * 256, dsub, device=xp.device).index_add_(0, idx, xp.view(n * M, dsub))
-        cnt = torch.bincount(idx, minlength=M * 256).to(torch.float32)
-        new = sums / cnt.clamp(min=1).unsqueeze(1)
-        keep = (cnt == 0).unsqueeze(1)
-        cb = torch.where(keep, cb.view(M * 256, dsub), new).view(M, 256, dsub).contiguous()
+        a = (codes.to(torch.int32) + offs).reshape(-1).contiguous()          # cluster = m * 256 + code
+        _cluster_means(rows, a, cb.view(M * 256, dsub), device)              # in place; empty codewords keep their value
     torch.cuda.synchronize()
     return cent, cb

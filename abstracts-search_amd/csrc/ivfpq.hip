@@ -473,18 +473,21 @@ void ensure_log_cap(mi_index *h, int64_t need) {
     h->log_cap = cap;
 }
 
-// Entries [ntotal, ntotal + n) of the log have codes / list numbers / ids in place: give them
-// their slots (insertion order) and count them.  Stream-ordered chunks of <= 65536.
-void commit_log_entries(mi_index *h, int64_t n, hipStream_t st) {
-    int32_t *cnt = h->d_cnt.get<int32_t>();
+// pos[i] = slot of entry i inside its list (entries of one list in ascending i), cnt[l] += members;
+// stream-ordered chunks of <= 65536 (list_rank_kernel).
+void rank_and_count(const int32_t *list_no, int64_t n, int32_t *cnt, int32_t *pos, hipStream_t st) {
     for (int64_t c0 = 0; c0 < n; c0 += 65536) {
         const int m = (int)std::min<int64_t>(65536, n - c0);
-        const int32_t *ln = h->log_list.get<int32_t>() + h->ntotal + c0;
-        hipLaunchKernelGGL(list_rank_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, ln, m, cnt,
-                           h->log_pos.get<int32_t>() + h->ntotal + c0);
-        hipLaunchKernelGGL(list_count_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, ln, m, cnt);
+        hipLaunchKernelGGL(list_rank_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, list_no + c0, m, cnt, pos + c0);
+        hipLaunchKernelGGL(list_count_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, list_no + c0, m, cnt);
         MI_HIP(hipGetLastError());
     }
+}
+
+// Entries [ntotal, ntotal + n) of the log have codes / list numbers / ids in place: give them
+// their slots (insertion order) and count them.
+void commit_log_entries(mi_index *h, int64_t n, hipStream_t st) {
+    rank_and_count(h->log_list.get<int32_t>() + h->ntotal, n, h->d_cnt.get<int32_t>(), h->log_pos.get<int32_t>() + h->ntotal, st);
     h->ntotal += n;
     h->dirty = true;
     h->len_ok = false;
@@ -1769,6 +1772,47 @@ int mi_ip_assign(int device, int64_t n, const float *x, int64_t nc, const float 
         if (!ad) MI_HIP(hipMemcpyAsync(assign, ap, (size_t)n * 4, hipMemcpyDeviceToHost, st));
         if (score && !sd) MI_HIP(hipMemcpyAsync(score, sp, (size_t)n * 4, hipMemcpyDeviceToHost, st));
         MI_HIP(hipStreamSynchronize(st));  // scratch buffers die with this scope
+    });
+}
+
+int mi_cluster_means(int device, int64_t n, const float *x, int d, const int32_t *assign, int k, float *centroids,
+                     int32_t *counts, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(x && assign && centroids, "null argument");
+        MI_REQUIRE(n > 0 && n < ((int64_t)1 << 31) && d > 0 && k > 0, "bad sizes");
+        DeviceGuard dg(device);
+        hipStream_t st = as_stream(stream);
+        MI_REQUIRE(is_device_ptr(x) && is_device_ptr(assign) && is_device_ptr(centroids),
+                   "mi_cluster_means: x, assign and centroids must be device pointers");
+        DevBuf cnt, pos, perm, start;
+        int32_t *dc = cnt.as<int32_t>((size_t)k);
+        MI_HIP(hipMemsetAsync(dc, 0, (size_t)k * 4, st));
+        rank_and_count(assign, n, dc, pos.as<int32_t>((size_t)n), st);
+        std::vector<int32_t> hc((size_t)k);
+        MI_HIP(hipMemcpyAsync(hc.data(), dc, (size_t)k * 4, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
+        std::vector<int64_t> hs((size_t)k);
+        int64_t o = 0;
+        for (int c = 0; c < k; ++c) { hs[(size_t)c] = o; o += hc[(size_t)c]; }
+        MI_REQUIRE(o == n, "mi_cluster_means: an assignment is out of range");
+        MI_HIP(hipMemcpyAsync(start.as<int64_t>((size_t)k), hs.data(), (size_t)k * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(cluster_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, assign,
+                           pos.get<int32_t>(), start.get<int64_t>(), n, perm.as<int32_t>((size_t)n));
+        hipLaunchKernelGGL(cluster_mean_kernel, dim3((unsigned)k), dim3(256), 0, st, x, d, perm.get<int32_t>(),
+                           start.get<int64_t>(), dc, centroids);
+        MI_HIP(hipGetLastError());
+        if (counts) MI_HIP(hipMemcpyAsync(counts, dc, (size_t)k * 4, hipMemcpyDefault, st));
+        MI_HIP(hipStreamSynchronize(st));  // scratch buffers die with this scope
+    });
+}
+
+int mi_neg_half_sqnorm(int device, int64_t n, const float *x, int d, float *out, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(x && out && n > 0 && d > 0, "bad argument");
+        DeviceGuard dg(device);
+        MI_REQUIRE(is_device_ptr(x) && is_device_ptr(out), "mi_neg_half_sqnorm: device pointers only");
+        hipLaunchKernelGGL(neg_half_sqnorm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, n, d, out);
+        MI_HIP(hipGetLastError());
     });
 }
 

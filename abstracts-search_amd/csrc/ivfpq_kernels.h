@@ -2599,4 +2599,45 @@ __global__ void __launch_bounds__(256)
     if (ch == 0) out_ids[row] = log_ids[e];
 }
 
+
+// ---------------------------------------------------------------------
+// k-means update step (IndexIVFPQ.train; reference Makefile:39 `index train`), deterministic:
+// the members of a cluster are summed in ascending row order by sequential f32 adds -- an
+// order the oracle restates with a plain loop -- instead of atomic scatter-adds whose order
+// changes from run to run.  list_rank_kernel gives every row its slot inside its cluster.
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    cluster_scatter_kernel(const int32_t *__restrict__ assign, const int32_t *__restrict__ pos,
+                           const int64_t *__restrict__ start, int64_t n, int32_t *__restrict__ perm) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) perm[start[assign[i]] + pos[i]] = (int32_t)i;
+}
+
+// one workgroup per cluster, one thread per dimension (strided): reads are coalesced along d
+__global__ void __launch_bounds__(256)
+    cluster_mean_kernel(const float *__restrict__ x, int d, const int32_t *__restrict__ perm,
+                        const int64_t *__restrict__ start, const int32_t *__restrict__ cnt, float *__restrict__ cent) {
+    const int c = blockIdx.x;
+    const int m = cnt[c];
+    if (m == 0) return;                       // an empty cluster keeps its row (the caller re-seeds it)
+    const int32_t *mem = perm + start[c];
+    for (int t = threadIdx.x; t < d; t += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < m; ++j) acc = acc + x[(size_t)mem[j] * d + t];
+        cent[(size_t)c * d + t] = acc / (float)m;
+    }
+}
+
+// out[r] = -0.5 * <x_r, x_r>, the dot an ascending-k fmaf chain from +0 (the oracle's dot):
+// the augmenting column that turns arg max <x, c> into arg min |x - c|^2.  One thread per row.
+__global__ void __launch_bounds__(256)
+    neg_half_sqnorm_kernel(const float *__restrict__ x, int64_t n, int d, float *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const float *p = x + (size_t)r * d;
+    float acc = 0.f;
+    for (int k = 0; k < d; ++k) acc = __builtin_fmaf(p[k], p[k], acc);
+    out[r] = -0.5f * acc;
+}
+
 }  // namespace mi

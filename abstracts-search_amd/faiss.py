@@ -90,6 +90,8 @@ class _Lib:
                 "mi_flat_rerank": [v, c_int64, v, c_int, v, c_int, v, v, v],
                 "mi_ip_assign": [c_int, c_int64, v, c_int64, v, c_int, v, v, v],
                 "mi_pq_encode": [c_int, c_int64, v, c_int, c_int, v, v, v],
+                "mi_cluster_means": [c_int, c_int64, v, c_int, v, c_int, v, v, v],
+                "mi_neg_half_sqnorm": [c_int, c_int64, v, c_int, v, v],
             }
             for name, args in sigs.items():
                 fn = getattr(lib, name)

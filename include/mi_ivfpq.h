@@ -196,6 +196,18 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
 int mi_ip_assign(int device, int64_t n, const float *x, int64_t nc, const float *c, int d,
                  int32_t *assign, float *score, void *stream);
 
+/* The update step of Lloyd's k-means, deterministic: centroids[c] = mean of the rows x_i with
+ * assign[i] == c, the members summed in ascending i by sequential f32 adds, divided by their
+ * count (faiss Clustering's centroid update, with a fixed summation order so that training is
+ * bit-reproducible and restated by the oracle).  Clusters without members keep their row of
+ * `centroids`; counts int32 [k] (host or device, may be NULL).  x, assign, centroids: device. */
+int mi_cluster_means(int device, int64_t n, const float *x, int d, const int32_t *assign, int k,
+                     float *centroids, int32_t *counts, void *stream);
+
+/* out[r] = -0.5 * <x_r, x_r> (the dot an ascending-k fmaf chain from +0): the augmenting column
+ * that makes arg max of an inner product the arg min of the L2 distance in mi_ip_assign. */
+int mi_neg_half_sqnorm(int device, int64_t n, const float *x, int d, float *out, void *stream);
+
 /* ProductQuantizer.compute_codes: codes uint8 [n][M] (host or device output),
  * codebook float32 [M][256][d/M]. */
 int mi_pq_encode(int device, int64_t n, const float *x, int d, int M, const float *codebook,

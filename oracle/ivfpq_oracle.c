@@ -353,3 +353,34 @@ ORACLE_API void oracle_merge(int nparts, int64_t nq, int k, const float *Dp,
     }
     free(L);
 }
+
+/* ------------------------------------------------------------------
+ * k-means building blocks (IndexIVFPQ.train; reference Makefile:39 `index train`).
+ * The product's update step (mi_cluster_means) fixes the summation order -- members of a
+ * cluster in ascending row order, sequential f32 adds, one division by the count -- so
+ * that training is bit-reproducible; this is that order as a plain loop.
+ * ------------------------------------------------------------------ */
+ORACLE_API void oracle_cluster_means(int64_t n, int d, const float *x, const int32_t *assign, int k,
+                                     float *centroids, int32_t *counts) {
+    float *acc = (float *)calloc((size_t)k * d, sizeof(float));
+    int32_t *cnt = (int32_t *)calloc((size_t)k, sizeof(int32_t));
+    for (int64_t i = 0; i < n; ++i) {
+        const int c = assign[i];
+        float *a = acc + (size_t)c * d;
+        const float *xi = x + (size_t)i * d;
+        for (int t = 0; t < d; ++t) a[t] = a[t] + xi[t];
+        ++cnt[c];
+    }
+    for (int c = 0; c < k; ++c) {
+        if (counts) counts[c] = cnt[c];
+        if (!cnt[c]) continue;                      /* an empty cluster keeps its row */
+        for (int t = 0; t < d; ++t) centroids[(size_t)c * d + t] = acc[(size_t)c * d + t] / (float)cnt[c];
+    }
+    free(acc);
+    free(cnt);
+}
+
+/* out[r] = -0.5 * dot(x_r, x_r) */
+ORACLE_API void oracle_neg_half_sqnorm(int64_t n, int d, const float *x, float *out) {
+    for (int64_t r = 0; r < n; ++r) out[r] = -0.5f * dot_chain(x + (size_t)r * d, x + (size_t)r * d, d);
+}

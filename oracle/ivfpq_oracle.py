@@ -210,3 +210,24 @@ def brute_force_search(q, centroids, codebook, list_off, codes, ids, nprobe, k,
         D[qi, :len(o)] = sc[o]
         I[qi, :len(o)] = sid[o]
     return D, I
+
+
+def cluster_means(x, assign, centroids):
+    """In-place k-means update (mi_cluster_means): returns the member counts."""
+    x = _f32(x)
+    assign = np.ascontiguousarray(assign, np.int32)
+    assert centroids.dtype == np.float32 and centroids.flags.c_contiguous
+    k, d = centroids.shape
+    counts = np.empty(k, np.int32)
+    lib().oracle_cluster_means(ctypes.c_int64(x.shape[0]), ctypes.c_int(d), _p(x, ctypes.c_float),
+                               _p(assign, ctypes.c_int32), ctypes.c_int(k), _p(centroids, ctypes.c_float),
+                               _p(counts, ctypes.c_int32))
+    return counts
+
+
+def neg_half_sqnorm(x):
+    x = _f32(x)
+    out = np.empty(x.shape[0], np.float32)
+    lib().oracle_neg_half_sqnorm(ctypes.c_int64(x.shape[0]), ctypes.c_int(x.shape[1]), _p(x, ctypes.c_float),
+                                 _p(out, ctypes.c_float))
+    return out
