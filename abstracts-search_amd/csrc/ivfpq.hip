@@ -49,18 +49,43 @@ void launch_gemm_cfg(const float *A, int na, const float *B, int nb, int d, floa
     MI_HIP(hipGetLastError());
 }
 
-// S[q][c] = <A[q], B[idx[q][c]]> for c < kc: one 16x64 tile row per query (gather mode)
-void launch_gemm_gather(const float *A, int nq, const float *B, int64_t nb, int d, const int64_t *idx, int kc,
+// S[q][c] = <A[q], B[idx[q][c]]> for c < kc: one 16x64 tile row per query (gather mode);
+// B rows f32 or IEEE half (widened exactly, same f32 chain)
+template <typename TB>
+void launch_gemm_gather(const float *A, int nq, const TB *B, int64_t nb, int d, const int64_t *idx, int kc,
                         float *S, int64_t ldS, hipStream_t st) {
     MI_REQUIRE(d % 4 == 0 && nq > 0 && kc > 0 && nb > 0, "bad gather gemm arguments");
     constexpr int BN = 64;
     const int tiles_m = nq, tiles_n = (kc + BN - 1) / BN;
     const int64_t grid = (int64_t)8 * tiles_m * ((tiles_n + 7) / 8);
     MI_REQUIRE(grid < (int64_t)1 << 31, "ip_gemm: grid too large");
-    hipLaunchKernelGGL((ip_gemm_kernel<1, 1, 1, 4, 64, 4>), dim3((unsigned)grid), dim3(256), 0, st, A, nq, B,
+    hipLaunchKernelGGL((ip_gemm_kernel<1, 1, 1, 4, 64, 4, TB>), dim3((unsigned)grid), dim3(256), 0, st, A, nq, B,
                        (int)std::min<int64_t>(nb, INT32_MAX), d, S, ldS, tiles_m, tiles_n, (int)grid, LutArgs{},
                        GatherArgs{idx, kc});
     MI_HIP(hipGetLastError());
+}
+
+// exact scores of kc candidate rows per query: the streaming kernel when the rows are whole
+// 128-byte pieces, else the gather mode of the score GEMM (MI_RERANK=gemm forces the latter)
+template <typename TB>
+void launch_rerank_scores(const float *q, int nq, const TB *base, int64_t nb, int d, const int64_t *idx, int kc,
+                          float *S, int64_t ldS, hipStream_t st) {
+    const char *e = std::getenv("MI_RERANK");
+    const bool force_gemm = e && std::string(e) == "gemm";
+    const int tiles = (kc + 63) / 64;
+    if (!force_gemm && ((size_t)d * sizeof(TB)) % 128 == 0 && (int64_t)nq * tiles < ((int64_t)1 << 31)) {
+        int nst = 3;   // 24.5 KiB of LDS per wave: 6 waves per CU, 2 x 8 KiB each in flight (tools/gather_bench.py: 3 > 4 > 6 > 8 stages)
+        if (e && std::atoi(e) > 0) nst = std::atoi(e);
+        const unsigned grid = (unsigned)((int64_t)nq * tiles);
+        if (nst == 6) hipLaunchKernelGGL((rerank_rows_kernel<TB, 6>), dim3(grid), dim3(64), 0, st, q, base, nb, d, idx, kc, S, ldS, tiles);
+        else if (nst == 4) hipLaunchKernelGGL((rerank_rows_kernel<TB, 4>), dim3(grid), dim3(64), 0, st, q, base, nb, d, idx, kc, S, ldS, tiles);
+        else if (nst == 2) hipLaunchKernelGGL((rerank_rows_kernel<TB, 2>), dim3(grid), dim3(64), 0, st, q, base, nb, d, idx, kc, S, ldS, tiles);
+        else if (nst == 8) hipLaunchKernelGGL((rerank_rows_kernel<TB, 8>), dim3(grid), dim3(64), 0, st, q, base, nb, d, idx, kc, S, ldS, tiles);
+        else hipLaunchKernelGGL((rerank_rows_kernel<TB, 3>), dim3(grid), dim3(64), 0, st, q, base, nb, d, idx, kc, S, ldS, tiles);
+        MI_HIP(hipGetLastError());
+        return;
+    }
+    launch_gemm_gather<TB>(q, nq, base, nb, d, idx, kc, S, ldS, st);
 }
 
 // S[na][nb] = A . B^T (exact f32).  Tile shape by the number of A rows: small
@@ -424,6 +449,7 @@ struct mi_index {
 
 struct mi_flat {
     int d = 0, device = 0;
+    int elem = 4;          // bytes per stored component: 4 = f32 (IndexFlat), 2 = IEEE half (IndexScalarQuantizer QT_fp16)
     int64_t ntotal = 0;
     DevBuf base;
     DevBuf ws_q, ws_scores, ws_D, ws_I, ws_cand, ws_bigmerge;
@@ -1595,6 +1621,16 @@ int mi_flat_create(int d, int device, mi_flat **out) {
     });
 }
 
+int mi_flat_create_ex(int d, int device, int storage, mi_flat **out) {
+    if (storage != MI_STORE_F32 && storage != MI_STORE_F16) {
+        last_error() = "mi_flat_create_ex: storage must be MI_STORE_F32 or MI_STORE_F16";
+        return 1;
+    }
+    int rc = mi_flat_create(d, device, out);
+    if (rc == 0) (*out)->elem = storage == MI_STORE_F16 ? 2 : 4;
+    return rc;
+}
+
 int mi_flat_destroy(mi_flat *h) {
     return guard([&] {
         if (!h) return;
@@ -1608,7 +1644,8 @@ int mi_flat_add(mi_flat *h, int64_t n, const float *x) {
         MI_REQUIRE(h && (n == 0 || x), "null argument");
         if (n == 0) return;
         DeviceGuard dg(h->device);
-        size_t old_bytes = (size_t)h->ntotal * h->d * 4, add_bytes = (size_t)n * h->d * 4;
+        const size_t row = (size_t)h->d * h->elem;
+        size_t old_bytes = (size_t)h->ntotal * row, add_bytes = (size_t)n * row;
         if (old_bytes + add_bytes > h->base.cap) {
             DevBuf nb;
             nb.reserve((old_bytes + add_bytes) * 3 / 2);
@@ -1616,7 +1653,25 @@ int mi_flat_add(mi_flat *h, int64_t n, const float *x) {
             std::swap(nb.p, h->base.p);
             std::swap(nb.cap, h->base.cap);
         }
-        MI_HIP(hipMemcpy(static_cast<char *>(h->base.p) + old_bytes, x, add_bytes, hipMemcpyDefault));
+        char *dst = static_cast<char *>(h->base.p) + old_bytes;
+        if (h->elem == 4) {
+            MI_HIP(hipMemcpy(dst, x, add_bytes, hipMemcpyDefault));
+        } else {
+            // QT_fp16: every component rounded to nearest-even half, no scaling (faiss ScalarQuantizer)
+            const int64_t chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)h->d * 4));
+            const bool xdev = is_device_ptr(x);
+            for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+                const int64_t m = std::min(chunk, n - c0);
+                const float *xs = x + (size_t)c0 * h->d;
+                if (!xdev) {
+                    float *stage = h->ws_q.as<float>((size_t)m * h->d);
+                    MI_HIP(hipMemcpy(stage, xs, (size_t)m * h->d * 4, hipMemcpyHostToDevice));
+                    xs = stage;
+                }
+                launch_to_f16_rows(xs, m, h->d, reinterpret_cast<f16_t *>(dst + (size_t)c0 * row), nullptr, 1.f, nullptr);
+            }
+            MI_HIP(hipStreamSynchronize(nullptr));
+        }
         h->ntotal += n;
     });
 }
@@ -1625,7 +1680,7 @@ int mi_flat_reserve(mi_flat *h, int64_t n) {
     return guard([&] {
         MI_REQUIRE(h && n >= 0, "bad argument");
         DeviceGuard dg(h->device);
-        const size_t want = (size_t)n * h->d * 4, old_bytes = (size_t)h->ntotal * h->d * 4;
+        const size_t want = (size_t)n * h->d * h->elem, old_bytes = (size_t)h->ntotal * h->d * h->elem;
         if (want <= h->base.cap) return;
         DevBuf nb;
         nb.reserve(want);
@@ -1669,7 +1724,8 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
         float *scores = wsb->as<float>((size_t)nq * kc);
         float *Dc = dev ? D : h->ws_D.as<float>((size_t)nq * k);
         int64_t *Ic = dev ? I : h->ws_I.as<int64_t>((size_t)nq * k);
-        launch_gemm_gather(qs, (int)nq, h->base.get<float>(), h->ntotal, h->d, ci, kc, scores, kc, st);
+        if (h->elem == 4) launch_rerank_scores<float>(qs, (int)nq, h->base.get<float>(), h->ntotal, h->d, ci, kc, scores, kc, st);
+        else launch_rerank_scores<f16_t>(qs, (int)nq, h->base.get<f16_t>(), h->ntotal, h->d, ci, kc, scores, kc, st);
         // the candidate list as kc/k "parts" of k entries: the k-way merge ranks them under
         // (score desc, id asc) and skips the negative ids
         launch_merge(scores, ci, kc / k, k, kc, nq, k, Dc, Ic, k, 0, nullptr, nullptr, st, -1, IdMap{}, &h->ws_bigmerge);
@@ -1687,7 +1743,17 @@ int mi_flat_reconstruct_n(mi_flat *h, int64_t i0, int64_t n, float *out) {
         MI_REQUIRE(i0 >= 0 && n >= 0 && i0 + n <= h->ntotal, "reconstruct_n: range out of bounds");
         if (n == 0) return;
         DeviceGuard dg(h->device);
-        MI_HIP(hipMemcpy(out, h->base.get<float>() + (size_t)i0 * h->d, (size_t)n * h->d * 4, hipMemcpyDefault));
+        if (h->elem == 4) {
+            MI_HIP(hipMemcpy(out, h->base.get<float>() + (size_t)i0 * h->d, (size_t)n * h->d * 4, hipMemcpyDefault));
+            return;
+        }
+        const bool odev = is_device_ptr(out);
+        float *dst = odev ? out : h->ws_scores.as<float>((size_t)n * h->d);
+        hipLaunchKernelGGL(f16_to_f32_kernel, dim3((unsigned)(((size_t)n * h->d + 255) / 256)), dim3(256), 0, nullptr,
+                           h->base.get<f16_t>() + (size_t)i0 * h->d, (int64_t)n * h->d, dst);
+        MI_HIP(hipGetLastError());
+        if (!odev) MI_HIP(hipMemcpy(out, dst, (size_t)n * h->d * 4, hipMemcpyDeviceToHost));
+        else MI_HIP(hipStreamSynchronize(nullptr));
     });
 }
 
@@ -1709,6 +1775,7 @@ int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int6
     return guard([&] {
         MI_REQUIRE(h && (nq == 0 || (q && D && I)), "null argument");
         MI_REQUIRE(k >= 1 && k <= 4096, "k must be in [1, 4096]");
+        MI_REQUIRE(h->elem == 4, "mi_flat_search: the half-precision store serves re-ranking (mi_flat_rerank) only");
         if (nq == 0) return;
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);

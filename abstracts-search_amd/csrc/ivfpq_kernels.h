@@ -33,6 +33,8 @@
 namespace mi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr unsigned EMPTY_POS = 0xFFFFFFFFu;
 constexpr int64_t EMPTY_ID = INT64_MAX;
@@ -157,9 +159,12 @@ struct GatherArgs {
     int kc;
 };
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int PF>
+// TB = f16_t: B is stored as IEEE half (IndexScalarQuantizer QT_fp16, the refine store of
+// "Refine(SQfp16)"): the loads move half the bytes, every element is widened to f32 exactly
+// on its way into LDS and the arithmetic is the same f32 chain -- score = chain(q_k * (float)x16_k).
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int PF, typename TB = float>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
-    ip_gemm_kernel(const float *__restrict__ A, int na, const float *__restrict__ B, int nb,
+    ip_gemm_kernel(const float *__restrict__ A, int na, const TB *__restrict__ B, int nb,
                    int d, float *__restrict__ S, int64_t ldS, int tiles_m, int tiles_n, int gemm_blocks,
                    LutArgs la, GatherArgs ga) {
     if ((int)blockIdx.x >= gemm_blocks) {  // appended LUT workgroups (dsub <= 16 only)
@@ -210,7 +215,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
 
     // row pointers of this thread's staging loads (rows are clamped, never guarded; a thread
     // without a tile row re-reads a clamped row)
-    const float *pa_row[CA], *pb_row[CB];
+    const float *pa_row[CA];
+    const TB *pb_row[CB];
 #pragma unroll
     for (int u = 0; u < CA; ++u) {
         const int idx = tid + u * NT;
@@ -239,9 +245,16 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64)
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
             const int k = k0 + ((tid + u * NT) % KQ) * 4;
-            if (full) pb[u] = *reinterpret_cast<const float4 *>(pb_row[u] + k0);
-            else pb[u] = (k < d) ? *reinterpret_cast<const float4 *>(pb_row[u] + k0)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (sizeof(TB) == 4) {
+                if (full) pb[u] = *reinterpret_cast<const float4 *>(pb_row[u] + k0);
+                else pb[u] = (k < d) ? *reinterpret_cast<const float4 *>(pb_row[u] + k0)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 hv = {(f16_t)0.f, (f16_t)0.f, (f16_t)0.f, (f16_t)0.f};
+                if (full || k < d) hv = *reinterpret_cast<const h4 *>(pb_row[u] + k0);
+                pb[u] = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+            }
         }
     };
     auto sstore = [&](int buf, const float4(&pa)[CA], const float4(&pb)[CB]) {
@@ -1122,8 +1135,6 @@ __global__ void __launch_bounds__(256)
 //   the exact chain's own rounding: d 2^-24.
 // The host adds 1 % for the second-order terms; |q| and max|c| are rounded up by 0.1 %.
 // =====================================================================
-typedef _Float16 f16_t;
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // Power of two that brings a largest magnitude m into [2^13, 2^14): far from f16's overflow
 // (65504), and an element then only leaves f16's normal range if it is below 2^-27 m.
@@ -2638,6 +2649,94 @@ __global__ void __launch_bounds__(256)
     float acc = 0.f;
     for (int k = 0; k < d; ++k) acc = __builtin_fmaf(p[k], p[k], acc);
     out[r] = -0.5f * acc;
+}
+
+
+// half -> f32, exact (IndexScalarQuantizer.reconstruct_n of a QT_fp16 store)
+__global__ void __launch_bounds__(256) f16_to_f32_kernel(const f16_t *__restrict__ x, int64_t n, float *__restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = (float)x[i];
+}
+
+
+// ---------------------------------------------------------------------
+// Re-ranking (IndexRefine: exact scores of k * k_factor candidate rows per query; faiss
+// IndexRefineFlat::search / Refine(SQfp16)).  The gather mode of ip_gemm_kernel fetches each
+// 64-candidate tile through a two-chunk-deep register pipeline built for L2-resident centroids;
+// on rows scattered over a 50-100 GB store every chunk step waits out a DRAM latency (measured:
+// the same 0.62 ms for 640 or 800 candidates, f32 or half rows, a 1 GB or a 106 GB store --
+// tools/gather_bench.py).  This kernel is built around memory-level parallelism instead:
+//   * one wave per (query, 64 candidates); lane r owns candidate r and runs its score as ONE
+//     ascending-k fmaf chain on the VALU -- the oracle's dot, the same bits the f32 MFMA
+//     produces -- so 64 chains advance per instruction instead of 16 per 40-cycle MFMA;
+//   * the rows stream through an NST-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4:
+//     8 lanes fetch one row's 128-byte piece, 8 instructions = one 8 KiB stage), NST-1 stages
+//     requested ahead with counted s_waitcnt vmcnt -- no registers hold data in flight, no
+//     barrier (one wave), and 4-5 waves per CU keep ~100 KB of row pieces in flight per CU;
+//   * the 16-byte slots of a row piece are XOR-swizzled by (row >> 1) & 7 on the global side,
+//     so that lane r's ds_read_b128 of "its" slot is bank-conflict-free across 16 lanes;
+//   * the query row is wave-uniform: scalar loads, operands straight from SGPRs.
+// TB = float (IndexFlat) or f16_t (IndexScalarQuantizer QT_fp16: widened exactly, same chain).
+// Requires d * sizeof(TB) % 128 == 0.
+// ---------------------------------------------------------------------
+template <typename TB, int NST>
+__global__ void __launch_bounds__(64)
+    rerank_rows_kernel(const float *__restrict__ q, const TB *__restrict__ base, int64_t nb, int d,
+                       const int64_t *__restrict__ cand, int kc, float *__restrict__ S, int64_t ldS, int tiles) {
+    constexpr int EPC = 128 / (int)sizeof(TB);   // elements per 128-byte piece
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[NST][8192];
+    __shared__ const unsigned char *rowp[64];
+    const int lane = threadIdx.x;
+    const int qi = blockIdx.x / tiles, t = blockIdx.x - qi * tiles;
+    const int c = t * 64 + lane;
+    int64_t id = cand[(size_t)qi * kc + min(c, kc - 1)];
+    id = max(min(id, nb - 1), (int64_t)0);       // an empty slot (negative) or a stray id must not fault; the caller ignores its score
+    rowp[lane] = reinterpret_cast<const unsigned char *>(base + (size_t)id * d);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned char *src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 8 * i + (lane >> 3);
+        src[i] = rowp[row] + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    const int nch = d / EPC;
+    auto issue = [&](int ch) {
+        unsigned char *st = ring[ch % NST];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma16_lds(src[i] + (size_t)ch * 128, st + i * 1024);
+    };
+    for (int ch = 0; ch < NST - 1 && ch < nch; ++ch) issue(ch);
+    const float *qrow = q + (size_t)qi * d;
+    const int sw = (lane >> 1) & 7;
+    float acc = 0.f;
+    auto consume = [&](int ch) {
+        const unsigned char *mine = ring[ch % NST] + lane * 128;
+        const float *qk = qrow + ch * EPC;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const unsigned char *slot = mine + ((p ^ sw) << 4);
+            if constexpr (sizeof(TB) == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(slot);
+                acc = __builtin_fmaf(qk[p * 4 + 0], v.x, acc);
+                acc = __builtin_fmaf(qk[p * 4 + 1], v.y, acc);
+                acc = __builtin_fmaf(qk[p * 4 + 2], v.z, acc);
+                acc = __builtin_fmaf(qk[p * 4 + 3], v.w, acc);
+            } else {
+                const f16x8 v = *reinterpret_cast<const f16x8 *>(slot);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qk[p * 8 + e], (float)v[e], acc);
+            }
+        }
+    };
+    int ch = 0;
+    for (; ch + NST - 1 < nch; ++ch) {           // steady state: NST-1 stages stay in flight behind the one consumed
+        issue(ch + NST - 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NST - 1)) : "memory");
+        consume(ch);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (; ch < nch; ++ch) consume(ch);
+    if (c < kc) S[(size_t)qi * ldS + c] = acc;
 }
 
 }  // namespace mi

@@ -80,6 +80,7 @@ class _Lib:
                 "mi_merge_topk_gathered": [c_int, c_int, c_int64, c_int, v, c_int64, c_int64, c_int64, c_int64,
                                            c_int64, c_int64, v, v, v],
                 "mi_flat_create": [c_int, c_int, POINTER(v)],
+                "mi_flat_create_ex": [c_int, c_int, c_int, POINTER(v)],
                 "mi_flat_destroy": [v],
                 "mi_flat_add": [v, c_int64, v],
                 "mi_flat_reserve": [v, c_int64],
@@ -159,11 +160,11 @@ class IndexFlatIP:
     metric_type = METRIC_INNER_PRODUCT
     is_trained = True
 
-    def __init__(self, d: int, device: int = 0):
+    def __init__(self, d: int, device: int = 0, _storage: int = 0):
         self.d = int(d)
         self.device = int(device)
         self._h = c_void_p()
-        _check(_Lib.get().mi_flat_create(self.d, self.device, ctypes.byref(self._h)))
+        _check(_Lib.get().mi_flat_create_ex(self.d, self.device, int(_storage), ctypes.byref(self._h)))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -268,6 +269,30 @@ class IndexFlat(IndexFlatIP):
 class IndexFlatL2(IndexFlat):
     def __init__(self, d: int, device: int = 0):
         super().__init__(d, METRIC_L2, device)
+
+
+class ScalarQuantizer:
+    """faiss.ScalarQuantizer's quantiser-type constants (only QT_fp16 is implemented)."""
+    QT_8bit, QT_4bit, QT_8bit_uniform, QT_4bit_uniform, QT_fp16, QT_8bit_direct, QT_6bit = range(7)
+
+
+class IndexScalarQuantizer(IndexFlatIP):
+    """faiss.IndexScalarQuantizer(d, ScalarQuantizer.QT_fp16, METRIC_INNER_PRODUCT): the vectors
+    are kept as IEEE half (round to nearest even at add(), no scaling) and scored as
+    <q, (float)x16> in the same f32 chain as IndexFlatIP -- half the bytes per re-ranked
+    candidate.  On this path it is the refine index of "...,Refine(SQfp16)": rerank() and
+    reconstruct_n() work, a full search() is not implemented."""
+
+    def __init__(self, d: int, qtype: int = ScalarQuantizer.QT_fp16, metric: int = METRIC_INNER_PRODUCT, device: int = 0):
+        if qtype != ScalarQuantizer.QT_fp16:
+            raise NotImplementedError("IndexScalarQuantizer: only ScalarQuantizer.QT_fp16 is implemented on the MI355X path")
+        if metric != METRIC_INNER_PRODUCT:
+            raise NotImplementedError("only METRIC_INNER_PRODUCT is implemented on the MI355X path")
+        super().__init__(d, device, _storage=1)
+        self.qtype = qtype
+
+    def search(self, x, k: int):
+        raise NotImplementedError("IndexScalarQuantizer.search: the half-precision store serves re-ranking only")
 
 
 # ----------------------------------------------------------------------
@@ -641,8 +666,8 @@ def merge_topk_gathered(gathered, nparts: int, nq: int, k: int, blk_bytes: int, 
 # module-level faiss functions
 # ----------------------------------------------------------------------
 
-class IndexRefineFlat:
-    """faiss.IndexRefineFlat(base_index): the base index proposes
+class IndexRefine:
+    """faiss.IndexRefine(base_index, refine_index) / IndexRefineFlat(base_index): the base index proposes
     ``k * k_factor`` candidates, an IndexFlat over the same vectors (in add()
     order: the base index must number its vectors sequentially, as faiss
     requires) recomputes their exact scores and the k best are returned.
@@ -700,6 +725,10 @@ class IndexRefineFlat:
         self.refine_index.rerank(x, cand_I, k, D, I, stream)
 
 
+class IndexRefineFlat(IndexRefine):
+    """faiss.IndexRefineFlat: IndexRefine whose refine index is an IndexFlat (factory ",RFlat")."""
+
+
 class SearchParameters:
     """faiss.SearchParameters (base class; `sel` = IDSelector is not implemented here)."""
 
@@ -719,7 +748,7 @@ class IndexRefineSearchParameters(SearchParameters):
         self.k_factor, self.base_index_params = float(k_factor), base_index_params
 
 
-_FACTORY_RE = re.compile(r"^IVF(\d+)(?:_HNSW\d+)?,PQ(\d+)(?:x(\d+))?(,RFlat)?$")
+_FACTORY_RE = re.compile(r"^IVF(\d+)(?:_HNSW\d+)?,PQ(\d+)(?:x(\d+))?(,RFlat|,Refine\(SQfp16\)|,Refine\(Flat\))?$")
 
 
 def index_factory(d: int, description: str, metric: int = METRIC_L2, device: int = 0):
@@ -732,11 +761,13 @@ def index_factory(d: int, description: str, metric: int = METRIC_L2, device: int
     m = _FACTORY_RE.match(description)
     if not m:
         raise ValueError(f"index_factory: unsupported description {description!r} "
-                         "(supported: 'Flat', 'IVF<nlist>,PQ<M>[x8][,RFlat]')")
+                         "(supported: 'Flat', 'IVF<nlist>,PQ<M>[x8][,RFlat | ,Refine(SQfp16)]')")
     if metric != METRIC_INNER_PRODUCT:
         raise NotImplementedError("only METRIC_INNER_PRODUCT is implemented on the MI355X path")
     nlist, M, nbits = int(m.group(1)), int(m.group(2)), int(m.group(3) or 8)
     index = IndexIVFPQ(d, nlist, M, nbits, metric, device=device)
+    if m.group(4) == ",Refine(SQfp16)":          # half-precision refine store: half the HBM and half the bytes per candidate
+        return IndexRefine(index, IndexScalarQuantizer(d, ScalarQuantizer.QT_fp16, metric, device))
     return IndexRefineFlat(index) if m.group(4) else index
 
 
@@ -827,8 +858,8 @@ def write_index(index, fname: str, ondisk_data: str | None = None) -> None:
     own numpy container instead."""
     if isinstance(index, IndexFlatIP):
         raise NotImplementedError("write_index: IndexFlatIP is not serialised")
-    if isinstance(index, IndexRefineFlat):
-        raise NotImplementedError("write_index: IndexRefineFlat (faiss's IxRF) is not serialised -- write "
+    if isinstance(index, IndexRefine):
+        raise NotImplementedError("write_index: IndexRefine / IndexRefineFlat (faiss's IxRF) is not serialised -- write "
                                   "index.base_index; the refine stage re-reads the raw vectors at load time")
     if not str(fname).endswith(".npz"):
         # the C ABI streams the lists from HBM to the file slab by slab (mi_index_save)

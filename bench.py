@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-refine-point", action="store_true", help="cfg4: skip the recall >= 0.95 operating point")
     ap.add_argument("--no-encode", action="store_true", help="cfg4: skip the encode half of the metric")
+    ap.add_argument("--refine-store", choices=["f32", "f16"], default="f16",
+                    help="cfg4 refine stage: f32 = IndexRefineFlat over the raw vectors (faiss ',RFlat'); f16 = "
+                         "',Refine(SQfp16)': IEEE-half store, half the HBM and half the bytes per re-ranked candidate")
     ap.add_argument("--encode-batch", type=int, default=128, help="abstracts per encode step")
     ap.add_argument("--encode-steps", type=int, default=24, help="cfg4 line: encode steps (x encode-batch abstracts)")
     ap.add_argument("--multi-gpu-mode", choices=["shards", "replicas"], default="shards",
@@ -281,12 +284,14 @@ def cfg4_workload(args, ctx):
     per_rank = (N + nsh - 1) // nsh
     hbm_total = torch.cuda.mem_get_info()[1]
     want_refine = not args.no_refine_point and not replicas
-    refine_own = want_refine and per_rank * d * 4 <= 0.74 * hbm_total - 40e9
+    relem = 2 if args.refine_store == "f16" else 4
+    refine_own = want_refine and per_rank * d * relem <= 0.74 * hbm_total - 40e9
     sub_mod = 8 if (want_refine and not refine_own) else 0
     assert not sub_mod or (8 % nsh == 0), "the 1/8 sub-shard needs N in {1, 2, 4, 8}"
     flat_r = sub = None
     if want_refine:
-        flat_r = faiss.IndexFlatIP(d, device=local_rank)
+        flat_r = (faiss.IndexScalarQuantizer(d, faiss.ScalarQuantizer.QT_fp16, faiss.METRIC_INNER_PRODUCT, device=local_rank)
+                  if relem == 2 else faiss.IndexFlatIP(d, device=local_rank))
         n_r = per_rank if refine_own else (N + 7) // 8
         flat_r.reserve(n_r + 1)
         if sub_mod:
@@ -470,7 +475,9 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     torch, dist, world, rank, dev, clock = ctx["torch"], ctx["dist"], ctx["world"], ctx["rank"], ctx["dev"], ctx["clock"]
     base = index if refine_own else sub
     args_nprobe = index.nprobe                                         # restored below
-    ref = faiss.IndexRefineFlat(base, flat_r)
+    ref = faiss.IndexRefine(base, flat_r)
+    relem = 2 if isinstance(flat_r, faiss.IndexScalarQuantizer) else 4
+    store = "IEEE-half (SQfp16)" if relem == 2 else "raw f32"
     sharded = ShardedIndex(ref, id_affine=(nsh, 0, 1)) if (refine_own and nsh > 1) else None
     cands = [(8, 64), (8, 80), (8, 100), (16, 100), (16, 160), (32, 200), (64, 256), (64, 400)]
     best = None
@@ -503,18 +510,19 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     settle(step, args.settle_ms)
     dt, blocks, _ = clock.measure(step, steps, warmup)
     base.nprobe = index.nprobe = args_nprobe
+    gb = flat_r.ntotal * D_MODEL * relem / 1e9
     if refine_own:
-        scope = ("the whole job: every rank re-ranks k*k_factor candidates of its own shard against the shard's raw f32 "
-                 "vectors (%.0f GB per GPU), one all-gather of the exact per-shard lists" % (flat_r.ntotal * D_MODEL * 4 / 1e9)
-                 if nsh > 1 else "whole index + raw f32 vectors on one GPU")
+        scope = (f"the whole job: every rank re-ranks k*k_factor candidates of its own shard against the shard's {store} "
+                 f"vectors ({gb:.0f} GB per GPU), one all-gather of the exact per-shard lists"
+                 if nsh > 1 else f"whole index + {store} vectors on one GPU")
         recall_note = "against exact search over the whole corpus"
     else:
-        scope = ("one GPU's share of the 8-GPU job: the 1/8 sub-shard (rows i mod 8 = rank, %d vectors + their raw f32 "
-                 "vectors, %.0f GB) -- the raw vectors of all %d rows (%.0f GB) do not fit %d GPU(s); every GPU of the "
-                 "8-GPU job sees every query, so its job rate is this rate less one all-gather"
-                 % (flat_r.ntotal, flat_r.ntotal * D_MODEL * 4 / 1e9, index.ntotal * nsh, index.ntotal * nsh * D_MODEL * 4 / 1e9, world))
+        scope = (f"one GPU's share of the 8-GPU job: the 1/8 sub-shard (rows i mod 8 = rank, {flat_r.ntotal} vectors + their "
+                 f"{store} vectors, {gb:.0f} GB) -- the refine store of all {index.ntotal * nsh} rows "
+                 f"({index.ntotal * nsh * D_MODEL * relem / 1e9:.0f} GB) does not fit {world} GPU(s); every GPU of the 8-GPU job "
+                 f"sees every query, so its job rate is this rate less one all-gather")
         recall_note = "against exact search over the same sub-shard"
-    return {"index": "IVF%d,PQ64,RFlat" % base.nlist, "nprobe": nprobe, "k_factor_rf": kf, "recall_at_10": round(r, 4),
+    return {"index": "IVF%d,PQ64,%s" % (base.nlist, "Refine(SQfp16)" if relem == 2 else "RFlat"), "nprobe": nprobe, "k_factor_rf": kf, "recall_at_10": round(r, 4),
             "reached": bool(r >= 0.95), "qps": round(steps * batch / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
             "timed_blocks": len(blocks), "scope": scope, "recall_note": recall_note}
 

@@ -167,6 +167,13 @@ int mi_merge_topk_gathered(int device, int nparts, int64_t nq, int k, const void
 /* ---- IndexFlatIP (config #1; also the coarse quantiser's arithmetic) ---- */
 
 int mi_flat_create(int d, int device, mi_flat **out);
+/* storage = MI_STORE_F16: components kept as IEEE half, rounded to nearest-even at add() with no
+ * scaling -- faiss's IndexScalarQuantizer(d, QT_fp16), the refine index of the factory string
+ * "...,Refine(SQfp16)".  Scores are <q, (float)x16> in the same f32 chain as the f32 store: half
+ * the bytes per re-ranked candidate.  Such a store serves mi_flat_rerank / reconstruct_n only. */
+#define MI_STORE_F32 0
+#define MI_STORE_F16 1
+int mi_flat_create_ex(int d, int device, int storage, mi_flat **out);
 int mi_flat_destroy(mi_flat *h);
 int mi_flat_add(mi_flat *h, int64_t n, const float *x);
 /* Capacity hint (std::vector::reserve on faiss's IndexFlat::codes): room for n vectors in

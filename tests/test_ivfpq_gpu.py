@@ -849,3 +849,32 @@ def test_two_stage_coarse_full_cfg4_size(faiss, monkeypatch):
     for (cI1, cD1), (cI0, cD0) in zip(out[None], out["0"]):
         assert np.array_equal(cI1, cI0) and np.array_equal(bits(cD1), bits(cD0))
         assert (cI1 >= 0).all() and (np.diff(cD1, axis=1) <= 0).all()
+
+
+def test_refine_sqfp16_matches_oracle(faiss, oracle):
+    """factory "IVF..,PQ..,Refine(SQfp16)": the refine store holds IEEE halves (round to nearest
+    even, no scaling); re-ranked scores are <q, (float)x16> in the f32 chain -> bit-equal to the
+    oracle's rerank over the half-rounded vectors; half the bytes per candidate."""
+    d, M, nlist, n, nq, k = 128, 16, 32, 9000, 50, 10
+    cent, cb, x, q = random_problem(77, d, M, nlist, n, nq)
+    x16 = x.astype(np.float16).astype(np.float32)
+    idx = faiss.index_factory(d, f"IVF{nlist},PQ{M},Refine(SQfp16)", faiss.METRIC_INNER_PRODUCT)
+    assert isinstance(idx, faiss.IndexRefine) and isinstance(idx.refine_index, faiss.IndexScalarQuantizer)
+    idx.base_index.set_centroids(cent)
+    idx.base_index.set_codebook(cb)
+    idx.add(x[: n // 3])
+    idx.add(x[n // 3:])
+    assert np.array_equal(bits(idx.refine_index.reconstruct_n(0, n)), bits(x16))     # the stored halves, widened
+    ln, codes = oracle.encode(x, cent, cb, True)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(n), nlist)
+    for nprobe, kf in ((4, 4), (8, 16)):
+        faiss.ParameterSpace().set_index_parameters(idx, f"nprobe={nprobe},k_factor_rf={kf}")
+        D, I = idx.search(q, k)
+        _, cand = oracle.search(q, cent, cb, off, lc, li, nprobe, k * kf, True)
+        De, Ie = oracle.rerank(q, x16, cand, k)
+        assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De)), (nprobe, kf)
+    import torch
+    Dt, It = idx.search(torch.from_numpy(q).cuda(), k)                                # device path
+    assert np.array_equal(It.cpu().numpy(), Ie) and np.array_equal(bits(Dt.cpu().numpy()), bits(De))
+    with pytest.raises(NotImplementedError):
+        idx.refine_index.search(q, k)
