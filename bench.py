@@ -149,9 +149,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default: 50 (cfg4), 200 (cfg2), 10 (encode)")
     ap.add_argument("--warmup", type=int, default=None, help="default: 5 (cfg4), 20 (cfg2), 2 (encode)")
-    ap.add_argument("--workload", choices=["cfg4", "cfg2", "encode", "search"], default="cfg4",
+    ap.add_argument("--workload", choices=["cfg4", "cfg2", "encode", "search", "cfg5"], default="cfg4",
                     help="cfg4 = the headline line (207M, IVF65536,PQ64, batch 1024); cfg2 = 1M, IVF4096,PQ64, batch 64 "
-                         "('search' is its old name); encode = cfg3 (stella_en_1.5B_v5 bf16 batch encode)")
+                         "('search' is its old name); encode = cfg3 (stella_en_1.5B_v5 bf16 batch encode); cfg5 = end-to-end encode + search "
+                         "over the cfg4 index at query batches 1 / 16 / 256 (latency and throughput curve)")
     ap.add_argument("--corpus", type=int, default=None, help="corpus rows (default: 207000000 cfg4, 1000000 cfg2)")
     ap.add_argument("--nlist", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None)
@@ -211,6 +212,8 @@ def main():
         out = encode_workload(args, ctx, args.steps, args.warmup, with_cpu=not args.no_cpu_baseline)
     elif args.workload == "cfg2":
         out = cfg2_workload(args, ctx)
+    elif args.workload == "cfg5":
+        out = cfg5_workload(args, ctx)
     else:
         out = cfg4_workload(args, ctx)
     if rank == 0 and out is not None:
@@ -525,6 +528,122 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     return {"index": "IVF%d,PQ64,%s" % (base.nlist, "Refine(SQfp16)" if relem == 2 else "RFlat"), "nprobe": nprobe, "k_factor_rf": kf, "recall_at_10": round(r, 4),
             "reached": bool(r >= 0.95), "qps": round(steps * batch / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
             "timed_blocks": len(blocks), "scope": scope, "recall_note": recall_note}
+
+
+# ======================================================================
+# cfg5: end to end -- encode + search over the cfg4 index, query batches 1 / 16 / 256
+# ======================================================================
+def stella_random_model(args, ctx):
+    """stella_en_1.5B_v5 architecture with random-init bf16 weights (no checkpoint on these boxes)."""
+    torch, dev, local_rank = ctx["torch"], ctx["dev"], ctx["local_rank"]
+    import abstracts_search_amd.sentence_transformers as st
+    cfg = dict(st.STELLA_EN_1_5B_V5)
+    model = st.SentenceTransformer(config=cfg, device=f"cuda:{local_rank}")
+    g = torch.Generator(device=dev).manual_seed(7)
+
+    def rnd(shape, scale):
+        return (torch.randn(shape, generator=g, device=dev) * scale).bfloat16()
+
+    H, I = cfg["hidden"], cfg["intermediate"]
+    qc, kc = cfg["n_heads"] * cfg["head_dim"], cfg["n_kv_heads"] * cfg["head_dim"]
+    model.load_weights({"embed_tokens.weight": rnd((cfg["vocab_size"], H), 0.3), "norm.weight": torch.ones(H, device=dev),
+                        "dense.weight": rnd((cfg["dense_out"], H), H ** -0.5), "dense.bias": torch.zeros(cfg["dense_out"], device=dev)})
+    for l in range(cfg["n_layers"]):
+        p = f"layers.{l}."
+        model.load_weights({
+            p + "input_layernorm.weight": torch.ones(H, device=dev), p + "post_attention_layernorm.weight": torch.ones(H, device=dev),
+            p + "self_attn.q_proj.weight": rnd((qc, H), H ** -0.5), p + "self_attn.q_proj.bias": rnd((qc,), 0.1),
+            p + "self_attn.k_proj.weight": rnd((kc, H), H ** -0.5), p + "self_attn.k_proj.bias": rnd((kc,), 0.1),
+            p + "self_attn.v_proj.weight": rnd((kc, H), H ** -0.5), p + "self_attn.v_proj.bias": rnd((kc,), 0.1),
+            p + "self_attn.o_proj.weight": rnd((H, qc), qc ** -0.5), p + "mlp.gate_proj.weight": rnd((I, H), H ** -0.5),
+            p + "mlp.up_proj.weight": rnd((I, H), H ** -0.5), p + "mlp.down_proj.weight": rnd((H, I), I ** -0.5)})
+    return model, cfg
+
+
+def cfg5_workload(args, ctx):
+    """BASELINE.json configs[4]: a query batch arrives as token ids on the host (what the tokenizer
+    hands over), is encoded (prompted query, 16-48 tokens) and searched over the cfg4 index
+    (IVF65536,PQ64, nprobe 64, k 10); N > 1: the index is vector-sharded, every rank encodes the
+    same batch (replicated queries) and the per-shard top-k go through the one exchange step.
+    Reported per batch size: latency of one call (median / p95 over the timed calls) and the
+    throughput of back-to-back calls."""
+    np, torch, dist = ctx["np"], ctx["torch"], ctx["dist"]
+    world, rank, local_rank, dev, clock = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["dev"], ctx["clock"]
+    import abstracts_search_amd.faiss as faiss
+    import abstracts_search_amd.synth as synth
+    from abstracts_search_amd.shards import ShardedIndex
+    N = 207_000_000 if args.corpus is None else args.corpus
+    nlist = 65536 if args.nlist is None else args.nlist
+    nprobe = 64 if args.nprobe is None else args.nprobe
+    steps = 30 if args.steps is None else args.steps
+    warmup = 3 if args.warmup is None else args.warmup
+    d, M, k = D_MODEL, PQ_M, args.k
+    nsh = world
+    t0 = time.time()
+    index = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT, device=local_rank)
+    index.cp.niter = 4 if args.train_iters is None else args.train_iters
+    cent = torch.empty((nlist, d), dtype=torch.float32, device=dev)
+    cb = torch.empty((M, 256, d // M), dtype=torch.float32, device=dev)
+    if rank == 0:
+        index.train(synth.corpus_cuda(min(N, max(4 * CH, 64 * nlist)), d, device=local_rank))
+        cent.copy_(torch.from_numpy(index.get_centroids()))
+        cb.copy_(torch.from_numpy(index.get_codebook()))
+    if world > 1:
+        dist.broadcast(cent, 0)
+        dist.broadcast(cb, 0)
+        index.set_centroids(cent)
+        index.set_codebook(cb)
+    del cent, cb
+    index.reserve((N + nsh - 1) // nsh + 1)
+    for c0 in range(0, N, CH):
+        x = synth.corpus_cuda(min(CH, N - c0), d, device=local_rank, row0=c0)
+        index.add(x if nsh == 1 else x[rank::nsh].contiguous())
+        del x
+    index.nprobe = nprobe
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] index ntotal={index.ntotal} built in {time.time() - t0:.0f}s")
+    sharded = ShardedIndex(index, id_affine=(nsh, 0, 1)) if world > 1 else None
+    model, cfg = stella_random_model(args, ctx)
+    rng = np.random.default_rng(1)                                      # the same queries on every rank
+    curve = []
+    for batch in (1, 16, 256):
+        toks = [rng.integers(0, cfg["vocab_size"], int(rng.integers(16, 49))).tolist() for _ in range(batch)]
+
+        def once(_=0):
+            e = model.encode_tokens(toks, batch_size=batch, normalize_embeddings=True, as_tensor=True)
+            return index.search(e, k) if sharded is None else sharded.search_replicated(e, k)
+
+        for i in range(warmup):
+            once()
+        lat = []
+        for i in range(steps):                                          # latency: one call at a time
+            clock.barrier()
+            t1 = time.perf_counter()
+            once()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        dt, blocks, _ = clock.measure(once, steps, 1)                   # throughput: back to back
+        t1 = time.perf_counter()
+        for i in range(steps):
+            model.encode_tokens(toks, batch_size=batch, normalize_embeddings=True, as_tensor=True)
+        torch.cuda.synchronize()
+        enc = (time.perf_counter() - t1) / steps
+        lat.sort()
+        curve.append({"batch": batch, "latency_ms_p50": round(lat[len(lat) // 2] * 1e3, 3),
+                      "latency_ms_p95": round(lat[min(len(lat) - 1, int(0.95 * len(lat)))] * 1e3, 3),
+                      "queries_per_s": round(steps * batch / dt, 1), "encode_alone_ms": round(enc * 1e3, 3),
+                      "tokens": sum(len(t) for t in toks)})
+        log(f"  batch {batch}: {curve[-1]}")
+    if rank != 0:
+        return None
+    return {"metric": "queries/sec end to end (stella_en_1.5B_v5 encode + IVF%d,PQ64 search over %dx1024-d, batch 256)" % (nlist, N),
+            "value": curve[-1]["queries_per_s"], "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(256e3 / curve[-1]["queries_per_s"], 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16 encoder, f32 search", "data": "synthetic (random-init encoder weights, synthetic token ids and corpus)",
+            "config": {"workload": "cfg5: end-to-end encode + search, %dx1024 IVF%d,PQ64 index, query batches 1/16/256 (BASELINE.json configs[4])" % (N, nlist),
+                       "nprobe": nprobe, "k": k, "query_tokens": "16-48 per query (prompt + question)",
+                       "parallelism": "1 GPU" if world == 1 else f"index vector-sharded x{world}, queries replicated, one all-gather of top-k"},
+            "curve": curve, "reference_oracles": reference_oracles()}
 
 
 # ======================================================================
