@@ -1284,6 +1284,135 @@ int mi_merge_topk_gathered(int device, int nparts, int64_t nq, int k, const void
     });
 }
 
+// ---- vector-sharded search over RCCL (one process per GPU): the exchange step in the C ABI ----
+// RCCL is bound at run time (dlopen): a host that never shards does not need it, and a Python
+// host passes the path of the librccl torch already loaded so that one copy serves both.
+
+}  // extern "C"
+
+#include <dlfcn.h>
+
+namespace {
+
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, /* ncclUniqueId by value: 128 bytes */ struct Id128, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+struct Id128 { char b[128]; };
+
+RcclApi &rccl(const char *path) {
+    static RcclApi api;
+    if (api.lib) return api;
+    const char *cands[] = {path, std::getenv("MI_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *c : cands) {
+        if (!c || !*c) continue;
+        api.lib = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) throw Error(std::string("cannot load RCCL (librccl.so): ") + (dlerror() ? dlerror() : "not found"));
+    auto sym = [&](const char *n) {
+        void *p = dlsym(api.lib, n);
+        if (!p) throw Error(std::string("RCCL symbol missing: ") + n);
+        return p;
+    };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    return api;
+}
+
+void nccl_check(RcclApi &r, int rc, const char *what) {
+    if (rc != 0) throw Error(std::string(what) + " failed: " + (r.GetErrorString ? r.GetErrorString(rc) : "?"));
+}
+
+}  // namespace
+
+struct mi_shards {
+    mi_index *local = nullptr;
+    mi_flat *refine = nullptr;     // optional: the shard's raw vectors (IndexRefine over the local index)
+    int k_factor = 1;
+    int rank = 0, world = 1, device = 0;
+    IdMap im;
+    void *comm = nullptr;
+    DevBuf send, recv, cand_D, cand_I, big;
+};
+
+extern "C" {
+
+int mi_shards_unique_id(const char *rccl_lib, void *id128) {
+    return guard([&] {
+        MI_REQUIRE(id128, "null argument");
+        RcclApi &r = rccl(rccl_lib);
+        nccl_check(r, r.GetUniqueId(id128), "ncclGetUniqueId");
+    });
+}
+
+int mi_shards_create(mi_index *local, mi_flat *refine, int k_factor, int rank, int world, const void *id128,
+                     const char *rccl_lib, int64_t id_mul, int64_t id_add, int64_t id_step, mi_shards **out) {
+    return guard([&] {
+        MI_REQUIRE(local && id128 && out, "null argument");
+        MI_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank / world size");
+        MI_REQUIRE(!refine || k_factor >= 1, "k_factor must be >= 1");
+        RcclApi &r = rccl(rccl_lib);
+        DeviceGuard dg(local->device);
+        auto s = std::make_unique<mi_shards>();
+        s->local = local; s->refine = refine; s->k_factor = refine ? k_factor : 1;
+        s->rank = rank; s->world = world; s->device = local->device;
+        s->im.mul = id_mul; s->im.add = id_add; s->im.step = id_step;
+        Id128 id;
+        std::memcpy(id.b, id128, 128);
+        nccl_check(r, r.CommInitRank(&s->comm, world, id, rank), "ncclCommInitRank");
+        *out = s.release();
+    });
+}
+
+int mi_shards_destroy(mi_shards *s) {
+    return guard([&] {
+        if (!s) return;
+        DeviceGuard dg(s->device);
+        if (s->comm) (void)rccl(nullptr).CommDestroy(s->comm);
+        delete s;
+    });
+}
+
+int mi_shards_search(mi_shards *s, int64_t nq, const float *q, int k, int nprobe, float *D, int64_t *I, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(s && (nq == 0 || (q && D && I)), "null argument");
+        MI_REQUIRE(k >= 1 && k <= 4096, "k must be in [1, 4096]");
+        if (nq == 0) return;
+        MI_REQUIRE(is_device_ptr(q) && is_device_ptr(D) && is_device_ptr(I), "mi_shards_search: device pointers only");
+        DeviceGuard dg(s->device);
+        hipStream_t st = as_stream(stream);
+        const size_t d_bytes = (((size_t)nq * k * 4 + 7) / 8) * 8, blk = d_bytes + (size_t)nq * k * 8;
+        char *send = static_cast<char *>(s->send.reserve(blk));
+        char *recv = static_cast<char *>(s->recv.reserve(blk * s->world));
+        float *Dl = reinterpret_cast<float *>(send);
+        int64_t *Il = reinterpret_cast<int64_t *>(send + d_bytes);
+        // this shard, all queries: straight into the two halves of the send buffer
+        if (s->refine) {
+            const int kb = k * s->k_factor;
+            MI_REQUIRE(kb <= 4096, "k * k_factor must be <= 4096");
+            float *cD = s->cand_D.as<float>((size_t)nq * kb);
+            int64_t *cI = s->cand_I.as<int64_t>((size_t)nq * kb);
+            if (mi_index_search(s->local, nq, q, kb, nprobe, cD, cI, stream)) throw Error(last_error());
+            if (mi_flat_rerank(s->refine, nq, q, kb, cI, k, Dl, Il, stream)) throw Error(last_error());
+        } else {
+            if (mi_index_search(s->local, nq, q, k, nprobe, Dl, Il, stream)) throw Error(last_error());
+        }
+        // the path's one exchange step
+        RcclApi &r = rccl(nullptr);
+        nccl_check(r, r.AllGather(send, recv, blk, /* ncclInt8 */ 0, s->comm, st), "ncclAllGather");
+        launch_merge(reinterpret_cast<const float *>(recv), reinterpret_cast<const int64_t *>(recv + d_bytes), s->world,
+                     (int64_t)(blk / 4), k, nq, k, D, I, k, 0, nullptr, nullptr, st, (int64_t)(blk / 8), s->im, &s->big);
+    });
+}
+
 // ---- write_index / read_index: faiss's binary IndexIVFPQ format ---------------------
 // (IwPQ + IndexFlat quantiser + ArrayInvertedLists `ilar` or OnDiskInvertedLists `ilod`: the
 // reference's index.faiss + ondisk.ivfdata pair, Makefile:11-12.)  Layout restated from

@@ -79,6 +79,10 @@ class _Lib:
                 "mi_merge_topk": [c_int, c_int, c_int64, c_int, v, v, v, v, v],
                 "mi_merge_topk_gathered": [c_int, c_int, c_int64, c_int, v, c_int64, c_int64, c_int64, c_int64,
                                            c_int64, c_int64, v, v, v],
+                "mi_shards_unique_id": [c_char_p, v],
+                "mi_shards_create": [v, v, c_int, c_int, c_int, v, c_char_p, c_int64, c_int64, c_int64, POINTER(v)],
+                "mi_shards_search": [v, c_int64, v, c_int, c_int, v, v, v],
+                "mi_shards_destroy": [v],
                 "mi_flat_create": [c_int, c_int, POINTER(v)],
                 "mi_flat_create_ex": [c_int, c_int, c_int, POINTER(v)],
                 "mi_flat_destroy": [v],

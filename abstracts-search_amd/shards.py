@@ -185,6 +185,68 @@ class ShardedIndex:
         I.copy_(Im)
 
 
+class NativeShardedIndex:
+    """The same sharded search with the exchange step inside the C ABI (`mi_shards_search`:
+    local search -> one ncclAllGather -> merge, all enqueued on the caller's stream by one
+    call): what a host without torch.distributed binds, and the lowest-overhead path for a
+    Python host too.  The 128-byte RCCL id is created on rank 0 and broadcast through the
+    already initialised torch.distributed group (any backend); RCCL itself is the copy torch
+    loaded.  `index` is an IndexIVFPQ or an IndexRefine over one (numbered by position)."""
+
+    def __init__(self, index, group=None, id_affine=None, rank=None, world=None):
+        import ctypes
+        import os
+        import torch
+        from .faiss import _Lib, _check
+        self._lib, self._check = _Lib.get(), _check
+        if world is None:
+            import torch.distributed as dist
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world, self.rank, self.index = int(world), int(rank), index
+        base = getattr(index, "base_index", index)
+        refine = getattr(index, "refine_index", None)
+        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        rccl = rccl.encode() if os.path.exists(rccl) else None
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (ctypes.c_char * 128)()
+            _check(self._lib.mi_shards_unique_id(rccl, buf))
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if self.world > 1:
+            import torch.distributed as dist
+            dev = torch.device("cuda", base.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            t = uid.to(dev)
+            dist.broadcast(t, 0, group=group)
+            uid = t.cpu()
+        mul, add, step = (int(v) for v in (id_affine if id_affine is not None else (1, 0, 0)))
+        self._h = ctypes.c_void_p()
+        kf = int(getattr(index, "k_factor", 1)) if refine is not None else 1
+        _check(self._lib.mi_shards_create(base._h, refine._h if refine is not None else None, kf, self.rank, self.world,
+                                          bytes(uid.numpy().tobytes()), rccl, mul, add, step, ctypes.byref(self._h)))
+        self._base = base
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.mi_shards_destroy(h)
+            except Exception:
+                pass
+
+    def search_replicated(self, q, k, D=None, I=None):
+        import ctypes
+        import torch
+        nq = q.shape[0]
+        if D is None:
+            D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        self._check(self._lib.mi_shards_search(self._h, nq, ctypes.c_void_p(q.data_ptr()), int(k), int(self._base.nprobe),
+                                               ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return D, I
+
+
 def shard_rows(n: int, rank: int, world: int):
     """Row indices of shard `rank` (round-robin by vector)."""
     return range(rank, n, world)

@@ -175,6 +175,9 @@ def main():
     ap.add_argument("--multi-gpu-mode", choices=["shards", "replicas"], default="shards",
                     help="N>1: shards = vector-sharded index + one all-gather of top-k (default, the north star's "
                          "layout); replicas = query-parallel, no collective")
+    ap.add_argument("--exchange", choices=["torch", "native"], default="torch",
+                    help="N>1 shards: torch = one torch.distributed all_gather_into_tensor + mi_merge_topk_gathered (default); "
+                         "native = the whole step inside the C ABI (mi_shards_search: ncclAllGather bound by dlopen)")
     ap.add_argument("--shard-coarse", type=int, default=0,
                     help="N>1 shards: also split the coarse quantiser across ranks (one more exchange)")
     ap.add_argument("--streams", type=int, default=None,
@@ -361,7 +364,12 @@ def cfg4_workload(args, ctx):
         f"generation + ground truth), scan image {t_image:.2f}s, HBM in use {used:.1f} of {total:.0f} GB")
 
     # ---- the timed configuration
-    sharded = ShardedIndex(index, shard_coarse=bool(args.shard_coarse), id_affine=(nsh, 0, 1)) if use_shards else None
+    sharded = None
+    if use_shards and args.exchange == "native" and not args.shard_coarse:
+        from abstracts_search_amd.shards import NativeShardedIndex
+        sharded = NativeShardedIndex(index, id_affine=(nsh, 0, 1))
+    elif use_shards:
+        sharded = ShardedIndex(index, shard_coarse=bool(args.shard_coarse), id_affine=(nsh, 0, 1))
     S = 1 if sharded is not None else max(1, 2 if args.streams is None else args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
     sptr = [int(s_.cuda_stream) for s_ in streams]
@@ -445,6 +453,7 @@ def cfg4_workload(args, ctx):
                                    % (N, nlist, batch),
                        "corpus": N, "nlist": nlist, "M": 64, "nprobe": nprobe, "k": k, "global_batch": batch * (world if replicas else 1),
                        "parallelism": par, "shard_coarse": bool(args.shard_coarse) if use_shards else None,
+                       "exchange": (args.exchange if use_shards else None),
                        "launch": "eager", "streams": S, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "host_issue_ms_per_step": round(t_issue / steps * 1e3, 5),
                        "timed_blocks": len(blocks), "block_ms": [round(b * 1e3, 3) for b in blocks],

@@ -41,7 +41,7 @@ extern "C" {
 #define MI_METRIC_L2 1            /* faiss.METRIC_L2 (not implemented) */
 
 typedef struct mi_index mi_index; /* faiss.IndexIVFPQ */
-typedef struct mi_flat mi_flat;   /* faiss.IndexFlatIP */
+typedef struct mi_flat mi_flat;   /* faiss.IndexFlatIP / IndexScalarQuantizer(QT_fp16) */
 
 /* Last error message of the calling thread ("" if none). */
 const char *mi_last_error(void);
@@ -163,6 +163,28 @@ int mi_merge_topk(int device, int nparts, int64_t nq, int k, const float *D_part
 int mi_merge_topk_gathered(int device, int nparts, int64_t nq, int k, const void *gathered,
                            int64_t blk_bytes, int64_t id_mul, int64_t id_add, int64_t id_step,
                            int64_t q_lo, int64_t nq_out, float *D, int64_t *I, void *stream);
+
+/* ---- vector-sharded search, one process per GPU ----------
+ * The whole sharded search step behind one call, for a host without torch.distributed: the
+ * local shard is searched for all nq (replicated) queries straight into a send buffer, ONE
+ * ncclAllGather (RCCL over xGMI, nq*k*12 bytes per rank) moves the per-shard (D, I), and the
+ * k-way merge -- ids translated local -> global as global = local * id_mul + id_add +
+ * rank * id_step -- writes the result; everything is enqueued on `stream`.
+ * RCCL is bound at run time: rccl_lib = path of the librccl.so to use (NULL: $MI_RCCL_LIB,
+ * then the system's); a Python host passes the copy torch already loaded.
+ * mi_shards_unique_id: rank 0 creates the 128-byte id and ships it to the other ranks out of
+ * band (file, socket, MPI, torch.distributed...); every rank then calls mi_shards_create with
+ * the same id (ncclCommInitRank: a collective call).  refine != NULL makes every shard an
+ * IndexRefine: k * k_factor candidates from `local`, exact re-ranking against `refine`
+ * (numbered by position like `local`), the exact per-shard lists exchanged. */
+typedef struct mi_shards mi_shards;
+int mi_shards_unique_id(const char *rccl_lib, void *id128);
+int mi_shards_create(mi_index *local, mi_flat *refine, int k_factor, int rank, int world,
+                     const void *id128, const char *rccl_lib, int64_t id_mul, int64_t id_add,
+                     int64_t id_step, mi_shards **out);
+int mi_shards_search(mi_shards *s, int64_t nq, const float *q, int k, int nprobe, float *D,
+                     int64_t *I, void *stream);
+int mi_shards_destroy(mi_shards *s);
 
 /* ---- IndexFlatIP (config #1; also the coarse quantiser's arithmetic) ---- */
 

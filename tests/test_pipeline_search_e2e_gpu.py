@@ -223,3 +223,31 @@ def test_cfg5_encode_then_search_vs_oracle_chain(faiss, oracle, tmp_path):
     # random-init model's near-collinear embeddings clear it, every one that does must agree
     assert compared >= 100 and agreed == compared, (compared, agreed, total)
     assert overlap / total > 0.9
+
+
+def test_native_exchange_step_rccl_world1(faiss, cfg4):
+    """mi_shards_search (local search -> ncclAllGather -> merge inside the C ABI) on the real RCCL
+    at world size 1, plain and with a half-precision refine stage and an affine id map: equal to
+    the same search without the exchange."""
+    import torch
+    from abstracts_search_amd.shards import NativeShardedIndex
+    idx, q, x = cfg4["idx"], cfg4["q"], cfg4["x"]
+    idx.nprobe = 16
+    D0, I0 = idx.search(q, 10)
+    sh = NativeShardedIndex(idx, rank=0, world=1)
+    D1, I1 = sh.search_replicated(q, 10)
+    torch.cuda.synchronize()
+    assert torch.equal(I1, I0) and torch.equal(D1, D0)
+    # refine shard numbered by position, global id = 3 * local + 1
+    n = 200_000
+    base = faiss.IndexIVFPQ(cfg4["d"], cfg4["nlist"], cfg4["M"], 8, faiss.METRIC_INNER_PRODUCT)
+    base.set_centroids(torch.from_numpy(idx.get_centroids()).cuda())
+    base.set_codebook(torch.from_numpy(idx.get_codebook()).cuda())
+    ref = faiss.IndexRefine(base, faiss.IndexScalarQuantizer(cfg4["d"]))
+    ref.add(x[:n].contiguous())
+    base.nprobe, ref.k_factor = 8, 16
+    De, Ie = ref.search(q[:128].contiguous(), 10)
+    shr = NativeShardedIndex(ref, id_affine=(3, 1, 0), rank=0, world=1)
+    Dr, Ir = shr.search_replicated(q[:128].contiguous(), 10)
+    torch.cuda.synchronize()
+    assert torch.equal(Dr, De) and torch.equal(Ir, torch.where(Ie < 0, Ie, Ie * 3 + 1))
