@@ -106,7 +106,20 @@ def kmeans_l2(x, k: int, niter: int, seed: int, device: int, verbose: bool = Fal
     return c.contiguous()
 
 
-def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbose: bool = False, centroids=None):
+def _assign_list(x, c, device, metric):
+    """List of every row: arg max <x, c> (inner product) or arg min |x - c|^2 (L2: the
+    augmented inner product, as k-means assigns)."""
+    import torch
+    if metric == 0:
+        return _assign_ip(x, c, device)
+    n, k = x.shape[0], c.shape[0]
+    xa = torch.cat([x, torch.ones(n, 1, device=x.device), torch.zeros(n, 3, device=x.device)], 1).contiguous()
+    ca = torch.cat([c, _neg_half_sqnorm(c, device).unsqueeze(1), torch.zeros(k, 3, device=x.device)], 1).contiguous()
+    return _assign_ip(xa, ca, device)
+
+
+def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbose: bool = False, centroids=None,
+                metric: int = 0):
     import torch
     d = x.shape[1]
     dsub = d // M
@@ -121,7 +134,7 @@ def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbo
     # PQ codebooks on (residual) sub-vectors
     xp = _to_device_sample(x, cp.max_points_per_centroid * 256, cp.seed + 1, device)
     if by_residual:
-        a = _assign_ip(xp, cent, device).long()
+        a = _assign_list(xp, cent, device, metric).long()
         xp = (xp - cent[a]).contiguous()
     n = xp.shape[0]
     g = torch.Generator(device="cpu").manual_seed(cp.seed + 2)

@@ -295,8 +295,26 @@ void launch_scan_mw(const ScanArgs &a, hipStream_t st) {
                        st, a);
     MI_HIP(hipGetLastError());
 }
+template <int M, bool ALL>
+void launch_scan_l2(const ScanArgs &a, hipStream_t st) {
+    const size_t smem = scan_smem_bytes(M, a.nprobe, 8);
+    MI_REQUIRE(smem <= 160 * 1024, "nprobe too large for the LDS probe tables");
+    static bool attr_set = false;
+    if (!attr_set) {
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<M, 8, ALL, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((scan_kernel<M, 8, ALL, true>), dim3(scan_grid(a.nq, a.nslice)), dim3(8 * 64), smem, st, a);
+    MI_HIP(hipGetLastError());
+}
 template <int M>
 void launch_scan_m(const ScanArgs &a, hipStream_t st) {
+    if (a.tnorm) {   // METRIC_L2: 8 waves per workgroup only
+        if (a.all_s) launch_scan_l2<M, true>(a, st);
+        else launch_scan_l2<M, false>(a, st);
+        return;
+    }
     if (a.all_s) {
         if (a.nw == 16) launch_scan_mw<M, 16, true>(a, st);
         else launch_scan_mw<M, 8, true>(a, st);
@@ -395,7 +413,7 @@ const void *to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t 
 
 // per-stream search workspaces (see mi_index::ws_sets)
 struct SearchWS {
-    DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters, all_s, all_id, q16, qscale, rstats;
+    DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters, all_s, all_id, q16, qscale, rstats, qaug, qn, cscan;
     size_t counters_zeroed = 0;  // bytes of `counters` known to be zero
     // most recent scan launch on this stream (mi_index_profile_scan replays it)
     ScanArgs last_scan{};
@@ -426,6 +444,10 @@ struct mi_index {
     // ivfpq_kernels.h.  d_cnt[l] = current length of list l; h_len mirrors it on the host when
     // len_ok.  Nothing proportional to ntotal lives on the host.
     DevBuf log_codes, log_list, log_pos, log_ids, d_cnt;
+    // METRIC_L2 (oracle: "METRIC_L2" section): centroids augmented to `da` columns
+    // [c, -|c|^2/2, 0..] for the coarse quantiser; per-vector term t in the log and in the image
+    DevBuf cent_aug, log_t, d_tnorm, ws_xaug;
+    int da = 0;
     int64_t log_cap = 0;
     std::vector<int32_t> h_len;
     bool len_ok = true;
@@ -450,6 +472,9 @@ struct mi_index {
 struct mi_flat {
     int d = 0, device = 0;
     int elem = 4;          // bytes per stored component: 4 = f32 (IndexFlat), 2 = IEEE half (IndexScalarQuantizer QT_fp16)
+    int metric = MI_METRIC_INNER_PRODUCT;
+    int da = 0;            // stored row width: d, or d + 4 for METRIC_L2 ([x, -|x|^2/2, 0, 0, 0]: oracle flat_l2)
+    DevBuf ws_qaug, ws_qn;
     int64_t ntotal = 0;
     DevBuf base;
     DevBuf ws_q, ws_scores, ws_D, ws_I, ws_cand, ws_bigmerge;
@@ -496,6 +521,7 @@ void ensure_log_cap(mi_index *h, int64_t need) {
     grow(h->log_list, 4);
     grow(h->log_pos, 4);
     grow(h->log_ids, 8);
+    if (h->metric == MI_METRIC_L2) grow(h->log_t, 4);
     h->log_cap = cap;
 }
 
@@ -513,6 +539,14 @@ void rank_and_count(const int32_t *list_no, int64_t n, int32_t *cnt, int32_t *po
 // Entries [ntotal, ntotal + n) of the log have codes / list numbers / ids in place: give them
 // their slots (insertion order) and count them.
 void commit_log_entries(mi_index *h, int64_t n, hipStream_t st) {
+    if (h->metric == MI_METRIC_L2) {   // the per-vector term of the expansion, from the codes just written
+        MI_REQUIRE(h->has_coarse && h->has_codebook, "METRIC_L2: the index must be trained before entries are added");
+        hipLaunchKernelGGL(l2_term_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           h->log_codes.get<uint8_t>() + (size_t)h->ntotal * h->M, h->log_list.get<int32_t>() + h->ntotal, n,
+                           h->d, h->M, h->codebook.get<float>(), h->centroids.get<float>(), h->by_residual,
+                           h->log_t.get<float>() + h->ntotal);
+        MI_HIP(hipGetLastError());
+    }
     rank_and_count(h->log_list.get<int32_t>() + h->ntotal, n, h->d_cnt.get<int32_t>(), h->log_pos.get<int32_t>() + h->ntotal, st);
     h->ntotal += n;
     h->dirty = true;
@@ -540,13 +574,19 @@ void sync_lists(mi_index *h) {
     int64_t *img_ids = static_cast<int64_t *>(h->d_ids.reserve(ng * 64 * 8));
     MI_HIP(hipMemsetAsync(img, 0, ng * gbytes, nullptr));
     MI_HIP(hipMemsetAsync(img_ids, 0xFF, ng * 64 * 8, nullptr));   // every id -1
+    float *img_t = nullptr;
+    if (h->metric == MI_METRIC_L2) {
+        img_t = static_cast<float *>(h->d_tnorm.reserve(ng * 64 * 4));
+        MI_HIP(hipMemsetAsync(img_t, 0, ng * 64 * 4, nullptr));
+    }
     MI_HIP(hipMemcpyAsync(h->d_goff.reserve(goff.size() * 4), goff.data(), goff.size() * 4, hipMemcpyHostToDevice, nullptr));
     MI_HIP(hipMemcpyAsync(h->d_len.reserve((size_t)nlist * 4), h->d_cnt.p, (size_t)nlist * 4, hipMemcpyDeviceToDevice, nullptr));
     if (h->ntotal) {
         const int64_t threads = h->ntotal * NCH;
         hipLaunchKernelGGL(build_image_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr,
                            h->log_codes.get<uint8_t>(), h->log_list.get<int32_t>(), h->log_pos.get<int32_t>(),
-                           h->log_ids.get<int64_t>(), h->ntotal, h->d_goff.get<int32_t>(), M, NCH, img, img_ids);
+                           h->log_ids.get<int64_t>(), h->ntotal, h->d_goff.get<int32_t>(), M, NCH, img, img_ids,
+                           img_t ? h->log_t.get<float>() : nullptr, img_t);
         MI_HIP(hipGetLastError());
     }
     MI_HIP(hipStreamSynchronize(nullptr));   // searches run on other (non-blocking) streams
@@ -555,8 +595,29 @@ void sync_lists(mi_index *h) {
 
 // coarse assign + PQ encode of n vectors (device pointer xdev) into assign [n] / codes [n][M]
 // (device pointers: the add() path passes the tail of the append log).
+void launch_augment(const float *x, int64_t n, int d, int da, int mode, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(augment_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, x, n, d, da, mode, out);
+    MI_HIP(hipGetLastError());
+}
+
 void encode_chunk(mi_index *h, const float *xdev, int64_t n, int32_t *assign, uint8_t *codes, hipStream_t st) {
     float *scores = h->ws_scores.as<float>((size_t)n * h->nlist);
+    if (h->metric == MI_METRIC_L2) {
+        // arg min |x - c|^2 = arg max of the augmented inner product: the same kernels on `da` columns
+        float *xa = h->ws_xaug.as<float>((size_t)n * h->da);
+        launch_augment(xdev, n, h->d, h->da, 0, xa, st);
+        if (two_stage_wanted(n, h->nlist, h->da, 1)) {
+            launch_two_stage(xa, n, h->cent_aug.get<float>(), static_cast<const f16_t *>(h->cent16.p), h->nlist, h->da, 1,
+                             h->cmax, h->cscale, scores, h->ws_x16, h->ws_xscale, h->ws_rstats, assign, nullptr,
+                             ProbeTables{}, st);
+        } else {
+            launch_gemm(xa, n, h->cent_aug.get<float>(), h->nlist, h->da, scores, h->nlist, st);
+            launch_select(scores, h->nlist, n, h->nlist, 1, assign, nullptr, nullptr, st);
+        }
+        launch_pq_encode(xdev, n, h->d, h->M, h->codebook.get<float>(),
+                         h->by_residual ? h->centroids.get<float>() : nullptr, assign, codes, st);
+        return;
+    }
     if (two_stage_wanted(n, h->nlist, h->d, 1)) {
         if (!h->cent16_ok) {
             prepare_cent16(h->centroids.get<float>(), h->nlist, h->d, h->cent16, h->cmax_dev, h->cmax, h->cscale, st);
@@ -604,8 +665,7 @@ int mi_index_create(int d, int nlist, int M, int nbits, int metric, int by_resid
                     mi_index **out) {
     return guard([&] {
         MI_REQUIRE(out != nullptr, "out is null");
-        MI_REQUIRE(metric == MI_METRIC_INNER_PRODUCT,
-                   "only METRIC_INNER_PRODUCT is implemented on the MI355X path");
+        MI_REQUIRE(metric == MI_METRIC_INNER_PRODUCT || metric == MI_METRIC_L2, "metric must be MI_METRIC_INNER_PRODUCT or MI_METRIC_L2");
         MI_REQUIRE(nbits == 8, "only nbits == 8 is implemented");
         MI_REQUIRE(d > 0 && M > 0 && d % M == 0, "d must be a positive multiple of M");
         MI_REQUIRE(d % 4 == 0, "d must be a multiple of 4");
@@ -625,6 +685,9 @@ int mi_index_create(int d, int nlist, int M, int nbits, int metric, int by_resid
         auto h = std::make_unique<mi_index>();
         h->d = d; h->nlist = nlist; h->M = M; h->dsub = dsub; h->metric = metric;
         h->by_residual = by_residual ? 1 : 0; h->device = device;
+        // augmented width for METRIC_L2: one more column, padded so that the two-stage coarse
+        // quantiser (d % 128 == 0) still applies to big indexes
+        h->da = (d % 128 == 0 && nlist >= 8192) ? d + 128 : d + 4;
         {
             DeviceGuard dg(device);
             MI_HIP(hipMemset(h->d_cnt.reserve((size_t)nlist * 4), 0, (size_t)nlist * 4));
@@ -650,12 +713,20 @@ int mi_index_set_coarse(mi_index *h, const float *centroids) {
         MI_HIP(hipMemcpy(h->centroids.reserve(bytes), centroids, bytes, hipMemcpyDefault));
         h->has_coarse = true;
         h->cent16_ok = false;
+        const float *cq = h->centroids.get<float>();   // what the coarse quantiser multiplies
+        int dq = h->d;
+        if (h->metric == MI_METRIC_L2) {
+            launch_augment(cq, h->nlist, h->d, h->da, 1, h->cent_aug.as<float>((size_t)h->nlist * h->da), nullptr);
+            cq = h->cent_aug.get<float>();
+            dq = h->da;
+        }
         // the f16 image the two-stage coarse quantiser uses is built here, not lazily inside a
         // search (concurrent searches on several streams only read the index)
-        if (h->nlist >= 8192 && h->d % 128 == 0 && h->d <= 4096 && h->nlist % 4 == 0) {
-            prepare_cent16(h->centroids.get<float>(), h->nlist, h->d, h->cent16, h->cmax_dev, h->cmax, h->cscale, nullptr);
+        if (h->nlist >= 8192 && dq % 128 == 0 && dq <= 4096 && h->nlist % 4 == 0) {
+            prepare_cent16(cq, h->nlist, dq, h->cent16, h->cmax_dev, h->cmax, h->cscale, nullptr);
             h->cent16_ok = true;
         }
+        MI_HIP(hipStreamSynchronize(nullptr));
     });
 }
 
@@ -954,6 +1025,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
                          float *lut_out, bool stop_after_lut, const int32_t *pre_I = nullptr,
                          const float *pre_D = nullptr) {
     const int M = h->M;
+    const bool l2 = h->metric == MI_METRIC_L2;
     int32_t *cidx = w.cidx.as<int32_t>((size_t)nq * nprobe);
     float *cdis = w.cdis.as<float>((size_t)nq * nprobe);
     float *lut = w.lut.as<float>((size_t)nq * M * 256);
@@ -974,6 +1046,16 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
     } else {
     float *scores = w.scores.as<float>((size_t)nq * h->nlist);
+    // what the coarse quantiser multiplies: the vectors themselves, or (METRIC_L2) their augmented images
+    const float *qc = qdev, *cc = h->centroids.get<float>();
+    int dc = h->d;
+    if (l2) {
+        float *qa = w.qaug.as<float>((size_t)nq * h->da);
+        launch_augment(qdev, nq, h->d, h->da, 0, qa, st);
+        hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, qdev, nq, h->d, w.qn.as<float>((size_t)nq));
+        MI_HIP(hipGetLastError());
+        qc = qa; cc = h->cent_aug.get<float>(); dc = h->da;
+    }
     const bool fork = std::getenv("MI_SIDE_STREAM") != nullptr;  // measured slower in eager mode: opt-in
     if (fork) {
         if (!w.side) {
@@ -989,24 +1071,38 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     // Large batches: f16 MFMA scores + exact re-scoring of the few centroids within a proven
     // error margin of the cut (bit-identical result, see select_refine_kernel) instead of the
     // exact f32 GEMM over all of them.
-    if (two_stage_wanted(nq, h->nlist, h->d, nprobe)) {
+    if (two_stage_wanted(nq, h->nlist, dc, nprobe)) {
         if (!h->cent16_ok) {
-            prepare_cent16(h->centroids.get<float>(), h->nlist, h->d, h->cent16, h->cmax_dev, h->cmax, h->cscale, st);
+            prepare_cent16(cc, h->nlist, dc, h->cent16, h->cmax_dev, h->cmax, h->cscale, st);
             h->cent16_ok = true;
         }
-        launch_two_stage(qdev, nq, h->centroids.get<float>(), static_cast<const f16_t *>(h->cent16.p), h->nlist, h->d,
+        launch_two_stage(qc, nq, cc, static_cast<const f16_t *>(h->cent16.p), h->nlist, dc,
                          nprobe, h->cmax, h->cscale, scores, w.q16, w.qscale, w.rstats, cidx, cdis, pt, st);
         if (fork) MI_HIP(hipStreamWaitEvent(st, w.ev_join, 0));
         else launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
     } else {
     const bool lut_in_gemm = !fork && (h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && !std::getenv("MI_NO_LUT_FUSION");
-    launch_gemm(qdev, nq, h->centroids.get<float>(), h->nlist, h->d, scores, h->nlist, st,
+    launch_gemm(qc, nq, cc, h->nlist, dc, scores, h->nlist, st,
                 lut_in_gemm ? make_lut_args(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut) : LutArgs{});
     launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st, pt);
     if (fork) MI_HIP(hipStreamWaitEvent(st, w.ev_join, 0));
     else if (!lut_in_gemm) launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
     }
     }
+    const float *cscan = cdis;   // the per-(query, probe) term the scan adds
+    if (l2) {
+        MI_REQUIRE(!pre_I, "METRIC_L2: search_preassigned is not implemented");
+        float *cs = w.cscan.as<float>((size_t)nq * nprobe);
+        hipLaunchKernelGGL(l2_coarse_term_kernel, dim3((unsigned)(((size_t)nq * nprobe + 255) / 256)), dim3(256), 0, st, cdis, cs,
+                           cidx, w.qn.get<float>(), nq, nprobe, h->by_residual);
+        MI_HIP(hipGetLastError());
+        cscan = cs;
+    }
+    auto l2_finish = [&] {       // scores -> ascending squared distances (faiss METRIC_L2 results)
+        if (!l2) return;
+        hipLaunchKernelGGL(l2_finish_kernel, dim3((unsigned)(((size_t)nq * k + 255) / 256)), dim3(256), 0, st, Ddev, Idev, nq * (int64_t)k);
+        MI_HIP(hipGetLastError());
+    };
     if (cI_out) MI_HIP(hipMemcpyAsync(cI_out, cidx, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (cD_out) MI_HIP(hipMemcpyAsync(cD_out, cdis, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (lut_out) MI_HIP(hipMemcpyAsync(lut_out, lut, (size_t)nq * M * 256 * 4, hipMemcpyDeviceToHost, st));
@@ -1061,12 +1157,13 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         for (int64_t c0 = 0; c0 < nq; c0 += qc) {
             const int64_t m = std::min(qc, nq - c0);
             ScanArgs a{};
-            a.lut = lut + (size_t)c0 * M * 256; a.coarse_dis = cdis + (size_t)c0 * nprobe;
+            a.lut = lut + (size_t)c0 * M * 256; a.coarse_dis = cscan + (size_t)c0 * nprobe;
+            a.tnorm = l2 ? h->d_tnorm.get<float>() : nullptr;
             a.p_goff = pt.p_goff + (size_t)c0 * nprobe; a.p_len = pt.p_len + (size_t)c0 * nprobe;
             a.p_prefix = pt.p_prefix + (size_t)c0 * (nprobe + 1);
             a.codes = h->d_codes.get<uint8_t>(); a.ids = h->d_ids.get<int64_t>();
             a.nq = (int)m; a.nprobe = nprobe; a.nslice = choose_nslice(h, m, nprobe); a.k = 64;
-            a.by_residual = h->by_residual;
+            a.by_residual = l2 ? 1 : h->by_residual;
             a.nw = 8;
             {
                 const double groups_per_slice = (h->nlist > 0 ? (double)h->ngroups / h->nlist : 0.0) * nprobe / a.nslice;
@@ -1079,17 +1176,19 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
                                a.p_prefix, nprobe, k, Ddev + (size_t)c0 * k, Idev + (size_t)c0 * k, (int64_t)k);
             MI_HIP(hipGetLastError());
         }
+        l2_finish();
         return;
     }
     for (int pass = 0; pass < npass; ++pass) {
         const int kp = std::min(64, k - pass * 64);
         ScanArgs a{};
-        a.lut = lut; a.coarse_dis = cdis;
+        a.lut = lut; a.coarse_dis = cscan;
+        a.tnorm = l2 ? h->d_tnorm.get<float>() : nullptr;
         a.p_goff = pt.p_goff; a.p_len = pt.p_len; a.p_prefix = pt.p_prefix;
         a.codes = h->d_codes.get<uint8_t>(); a.ids = h->d_ids.get<int64_t>();
         a.part_s = ps; a.part_id = pid;
         a.bound_s = pass ? bs : nullptr; a.bound_id = pass ? bid : nullptr;
-        a.nq = (int)nq; a.nprobe = nprobe; a.nslice = nslice; a.k = kp; a.by_residual = h->by_residual;
+        a.nq = (int)nq; a.nprobe = nprobe; a.nslice = nslice; a.k = kp; a.by_residual = l2 ? 1 : h->by_residual;
         a.nw = scan_nw;
         a.debug = 0;
         a.ts = nullptr;
@@ -1121,6 +1220,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
             launch_merge(ps, pid, nslice, kp, (int64_t)nslice * kp, nq, kp, Ddev, Idev, k, pass * 64,
                          npass > 1 ? bs : nullptr, npass > 1 ? bid : nullptr, st);
     }
+    l2_finish();
 }
 
 static int64_t query_chunk_size(const mi_index *h) {
@@ -1189,6 +1289,7 @@ int mi_index_coarse_slice(mi_index *h, int64_t nq, const float *q, int nprobe, i
         MI_REQUIRE(0 <= list_lo && list_lo < list_hi && list_hi <= h->nlist, "bad centroid slice");
         MI_REQUIRE(nprobe >= 1, "nprobe must be >= 1");
         MI_REQUIRE(h->has_coarse, "no coarse centroids set");
+        MI_REQUIRE(h->metric == MI_METRIC_INNER_PRODUCT, "mi_index_coarse_slice: METRIC_INNER_PRODUCT only");
         MI_REQUIRE(is_device_ptr(q) && is_device_ptr(coarse_I) && is_device_ptr(coarse_D),
                    "mi_index_coarse_slice: device pointers only");
         if (nq == 0) return;
@@ -1745,6 +1846,7 @@ int mi_flat_create(int d, int device, mi_flat **out) {
         MI_REQUIRE(device >= 0 && device < ndev, "invalid device ordinal");
         auto h = std::make_unique<mi_flat>();
         h->d = d;
+        h->da = d;
         h->device = device;
         *out = h.release();
     });
@@ -1756,7 +1858,20 @@ int mi_flat_create_ex(int d, int device, int storage, mi_flat **out) {
         return 1;
     }
     int rc = mi_flat_create(d, device, out);
-    if (rc == 0) (*out)->elem = storage == MI_STORE_F16 ? 2 : 4;
+    if (rc == 0) (*out)->elem = storage == MI_STORE_F16 ? 2 : 4;   // (inner product only)
+    return rc;
+}
+
+int mi_flat_create_metric(int d, int metric, int device, mi_flat **out) {
+    if (metric != MI_METRIC_INNER_PRODUCT && metric != MI_METRIC_L2) {
+        last_error() = "mi_flat_create_metric: metric must be MI_METRIC_INNER_PRODUCT or MI_METRIC_L2";
+        return 1;
+    }
+    int rc = mi_flat_create(d, device, out);
+    if (rc == 0 && metric == MI_METRIC_L2) {
+        (*out)->metric = MI_METRIC_L2;
+        (*out)->da = d + 4;
+    }
     return rc;
 }
 
@@ -1773,7 +1888,7 @@ int mi_flat_add(mi_flat *h, int64_t n, const float *x) {
         MI_REQUIRE(h && (n == 0 || x), "null argument");
         if (n == 0) return;
         DeviceGuard dg(h->device);
-        const size_t row = (size_t)h->d * h->elem;
+        const size_t row = (size_t)h->da * h->elem;
         size_t old_bytes = (size_t)h->ntotal * row, add_bytes = (size_t)n * row;
         if (old_bytes + add_bytes > h->base.cap) {
             DevBuf nb;
@@ -1783,7 +1898,21 @@ int mi_flat_add(mi_flat *h, int64_t n, const float *x) {
             std::swap(nb.cap, h->base.cap);
         }
         char *dst = static_cast<char *>(h->base.p) + old_bytes;
-        if (h->elem == 4) {
+        if (h->elem == 4 && h->metric == MI_METRIC_L2) {
+            const int64_t chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)h->d * 4));
+            const bool xdev = is_device_ptr(x);
+            for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+                const int64_t m = std::min(chunk, n - c0);
+                const float *xs = x + (size_t)c0 * h->d;
+                if (!xdev) {
+                    float *stage = h->ws_q.as<float>((size_t)m * h->d);
+                    MI_HIP(hipMemcpy(stage, xs, (size_t)m * h->d * 4, hipMemcpyHostToDevice));
+                    xs = stage;
+                }
+                launch_augment(xs, m, h->d, h->da, 1, reinterpret_cast<float *>(dst + (size_t)c0 * row), nullptr);
+            }
+            MI_HIP(hipStreamSynchronize(nullptr));
+        } else if (h->elem == 4) {
             MI_HIP(hipMemcpy(dst, x, add_bytes, hipMemcpyDefault));
         } else {
             // QT_fp16: every component rounded to nearest-even half, no scaling (faiss ScalarQuantizer)
@@ -1809,7 +1938,7 @@ int mi_flat_reserve(mi_flat *h, int64_t n) {
     return guard([&] {
         MI_REQUIRE(h && n >= 0, "bad argument");
         DeviceGuard dg(h->device);
-        const size_t want = (size_t)n * h->d * h->elem, old_bytes = (size_t)h->ntotal * h->d * h->elem;
+        const size_t want = (size_t)n * h->da * h->elem, old_bytes = (size_t)h->ntotal * h->da * h->elem;
         if (want <= h->base.cap) return;
         DevBuf nb;
         nb.reserve(want);
@@ -1853,11 +1982,24 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
         float *scores = wsb->as<float>((size_t)nq * kc);
         float *Dc = dev ? D : h->ws_D.as<float>((size_t)nq * k);
         int64_t *Ic = dev ? I : h->ws_I.as<int64_t>((size_t)nq * k);
-        if (h->elem == 4) launch_rerank_scores<float>(qs, (int)nq, h->base.get<float>(), h->ntotal, h->d, ci, kc, scores, kc, st);
+        const bool l2 = h->metric == MI_METRIC_L2;
+        if (l2) {   // augmented queries; the candidates rank by S = <q, x> - |x|^2/2, reported as squared distances
+            float *qa = h->ws_qaug.as<float>((size_t)nq * h->da);
+            launch_augment(qs, nq, h->d, h->da, 0, qa, st);
+            hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, qs, nq, h->d, h->ws_qn.as<float>((size_t)nq));
+            MI_HIP(hipGetLastError());
+            qs = qa;
+        }
+        if (h->elem == 4) launch_rerank_scores<float>(qs, (int)nq, h->base.get<float>(), h->ntotal, h->da, ci, kc, scores, kc, st);
         else launch_rerank_scores<f16_t>(qs, (int)nq, h->base.get<f16_t>(), h->ntotal, h->d, ci, kc, scores, kc, st);
         // the candidate list as kc/k "parts" of k entries: the k-way merge ranks them under
         // (score desc, id asc) and skips the negative ids
         launch_merge(scores, ci, kc / k, k, kc, nq, k, Dc, Ic, k, 0, nullptr, nullptr, st, -1, IdMap{}, &h->ws_bigmerge);
+        if (l2) {
+            hipLaunchKernelGGL(l2_flat_finish_kernel, dim3((unsigned)(((size_t)nq * k + 255) / 256)), dim3(256), 0, st, Dc, Ic,
+                               h->ws_qn.get<float>(), nq, k);
+            MI_HIP(hipGetLastError());
+        }
         if (!dev) {
             MI_HIP(hipMemcpyAsync(D, Dc, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
             MI_HIP(hipMemcpyAsync(I, Ic, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
@@ -1872,8 +2014,18 @@ int mi_flat_reconstruct_n(mi_flat *h, int64_t i0, int64_t n, float *out) {
         MI_REQUIRE(i0 >= 0 && n >= 0 && i0 + n <= h->ntotal, "reconstruct_n: range out of bounds");
         if (n == 0) return;
         DeviceGuard dg(h->device);
-        if (h->elem == 4) {
+        if (h->elem == 4 && h->da == h->d) {
             MI_HIP(hipMemcpy(out, h->base.get<float>() + (size_t)i0 * h->d, (size_t)n * h->d * 4, hipMemcpyDefault));
+            return;
+        }
+        if (h->elem == 4) {   // augmented rows (METRIC_L2): drop the extra columns
+            const bool od = is_device_ptr(out);
+            float *dst = od ? out : h->ws_scores.as<float>((size_t)n * h->d);
+            hipLaunchKernelGGL(unaugment_rows_kernel, dim3((unsigned)(((size_t)n * h->d + 255) / 256)), dim3(256), 0, nullptr,
+                               h->base.get<float>() + (size_t)i0 * h->da, n, h->d, h->da, dst);
+            MI_HIP(hipGetLastError());
+            if (!od) MI_HIP(hipMemcpy(out, dst, (size_t)n * h->d * 4, hipMemcpyDeviceToHost));
+            else MI_HIP(hipStreamSynchronize(nullptr));
             return;
         }
         const bool odev = is_device_ptr(out);
@@ -1909,10 +2061,11 @@ int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int6
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);
         const bool qd = is_device_ptr(q), Dd = is_device_ptr(D), Id = is_device_ptr(I);
+        const bool l2 = h->metric == MI_METRIC_L2;
         if (h->ntotal == 0) {  // faiss: all -1
             MI_REQUIRE(!Dd && !Id, "empty flat index: host outputs only");
             for (int64_t i = 0; i < nq * k; ++i) {
-                D[i] = -FLT_MAX;
+                D[i] = l2 ? FLT_MAX : -FLT_MAX;
                 I[i] = -1;
             }
             return;
@@ -1925,8 +2078,20 @@ int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int6
             float *scores = h->ws_scores.as<float>((size_t)m * h->ntotal);
             float *Dc = Dd ? D + (size_t)c0 * k : h->ws_D.as<float>((size_t)m * k);
             int64_t *Ic = Id ? I + (size_t)c0 * k : h->ws_I.as<int64_t>((size_t)m * k);
-            launch_gemm(qs, m, h->base.get<float>(), h->ntotal, h->d, scores, h->ntotal, st);
+            if (l2) {
+                float *qa = h->ws_qaug.as<float>((size_t)m * h->da);
+                launch_augment(qs, m, h->d, h->da, 0, qa, st);
+                hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, qs, m, h->d, h->ws_qn.as<float>((size_t)m));
+                MI_HIP(hipGetLastError());
+                qs = qa;
+            }
+            launch_gemm(qs, m, h->base.get<float>(), h->ntotal, h->da, scores, h->ntotal, st);
             launch_select(scores, h->ntotal, m, (int)h->ntotal, k, nullptr, Ic, Dc, st);
+            if (l2) {
+                hipLaunchKernelGGL(l2_flat_finish_kernel, dim3((unsigned)(((size_t)m * k + 255) / 256)), dim3(256), 0, st, Dc, Ic,
+                                   h->ws_qn.get<float>(), m, k);
+                MI_HIP(hipGetLastError());
+            }
             if (!Dd) MI_HIP(hipMemcpyAsync(D + (size_t)c0 * k, Dc, (size_t)m * k * 4, hipMemcpyDeviceToHost, st));
             if (!Id) MI_HIP(hipMemcpyAsync(I + (size_t)c0 * k, Ic, (size_t)m * k * 8, hipMemcpyDeviceToHost, st));
             if (!qd || !Dd || !Id) MI_HIP(hipStreamSynchronize(st));

@@ -1638,6 +1638,7 @@ struct ScanArgs {
     const int32_t *p_prefix;   // [nq][nprobe+1] exclusive prefix of group counts
     const uint8_t *codes;      // group-interleaved
     const int64_t *ids;        // [ngroups*64]
+    const float *tnorm;        // [ngroups*64], METRIC_L2 only (scan_kernel<..., L2 = true>)
     float *part_s;             // [nq][nslice][k]
     int64_t *part_id;          // [nq][nslice][k]
     const float *bound_s;      // [nq] or null: only entries strictly after
@@ -1781,7 +1782,7 @@ __device__ __forceinline__ void wave_compress(float *buf_s, int64_t *buf_id, int
     thr = (cnt >= k && T != 0u) ? o2f(T) : MI_NEG_INF;
 }
 
-template <int M, int NW, bool ALL = false>
+template <int M, int NW, bool ALL = false, bool L2 = false>
 __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 waves per SIMD = two 512-thread workgroups per CU
     constexpr int NCH = (M + 15) / 16;
     constexpr int SCAN_NW = NW, NT = NW * 64;
@@ -1915,6 +1916,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         int64_t id;
         int nvalid;
         float dis0;
+        float t;      // METRIC_L2 only: the vector's term |r^|^2 + 2<c, r^>
     };
     auto locate_and_load = [&](int tt, Group &g) {
         int gi, gg;
@@ -1946,6 +1948,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) g.c[ch] = gp[ch * 64];
         g.id = a.ids[(size_t)gg * 64 + lane];
+        if constexpr (L2) g.t = a.tnorm[(size_t)gg * 64 + lane];
     };
     // Two groups per wave are requested before the LUT barrier (most of a cfg2-sized
     // slice is then in flight while the LUT is staged) and the loop keeps two in flight,
@@ -1970,7 +1973,10 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
                 }
             }
         }
-        const float s = g.dis0 + acc;
+        // METRIC_L2: s = -|q - x^|^2 through the expansion dis0 + (2 <q, r^> - t)  (oracle: search_l2)
+        float s;
+        if constexpr (L2) s = g.dis0 + (2.0f * acc - g.t);
+        else s = g.dis0 + acc;
         if constexpr (ALL) {
             const size_t o = (size_t)q * a.all_ld + (size_t)t * 64 + lane;   // t: this group's index in the query
             a.all_s[o] = lane < g.nvalid ? s : __builtin_nanf("");
@@ -2567,7 +2573,8 @@ __global__ void __launch_bounds__(256)
     build_image_kernel(const uint8_t *__restrict__ log_codes, const int32_t *__restrict__ log_list,
                        const int32_t *__restrict__ log_pos, const int64_t *__restrict__ log_ids, int64_t n,
                        const int32_t *__restrict__ goff, int M, int NCH, uint8_t *__restrict__ img,
-                       int64_t *__restrict__ img_ids) {
+                       int64_t *__restrict__ img_ids, const float *__restrict__ log_t = nullptr,
+                       float *__restrict__ img_t = nullptr) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t e = t / NCH;
     const int ch = (int)(t - e * NCH);
@@ -2583,7 +2590,10 @@ __global__ void __launch_bounds__(256)
         const int nb = min(16, M - ch * 16);
         for (int i = 0; i < nb; ++i) dst[i] = src[i];
     }
-    if (ch == 0) img_ids[grp * 64 + lane] = log_ids[e];
+    if (ch == 0) {
+        img_ids[grp * 64 + lane] = log_ids[e];
+        if (log_t) img_t[grp * 64 + lane] = log_t[e];
+    }
 }
 
 // log -> the lists [list_lo, list_hi) concatenated, row-major codes, insertion order
@@ -2737,6 +2747,96 @@ __global__ void __launch_bounds__(64)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (; ch < nch; ++ch) consume(ch);
     if (c < kc) S[(size_t)qi * ldS + c] = acc;
+}
+
+
+// ---------------------------------------------------------------------
+// METRIC_L2 through the inner-product machinery (oracle: "METRIC_L2" section of ivfpq_oracle.c).
+// arg min |x - c|^2 = arg max S, S = <x, c> - |c|^2/2, evaluated as ONE ascending-k fmaf chain
+// over vectors augmented to `da` columns: [x, 1, 0..] . [c, -|c|^2/2, 0..] -- the exact-score
+// GEMM, the selects and the two-stage coarse quantiser run unchanged on those.
+// ---------------------------------------------------------------------
+// mode 0: out[r] = [x_r, 1, 0..]   mode 1: out[r] = [x_r, -0.5 * chain(x_r . x_r), 0..]; one workgroup per row
+__global__ void __launch_bounds__(256)
+    augment_rows_kernel(const float *__restrict__ x, int64_t n, int d, int da, int mode, float *__restrict__ out) {
+    const int64_t r = blockIdx.x;
+    if (r >= n) return;
+    const float *xr = x + (size_t)r * d;
+    float *o = out + (size_t)r * da;
+    for (int k = threadIdx.x; k < d; k += 256) o[k] = xr[k];
+    for (int k = d + 1 + threadIdx.x; k < da; k += 256) o[k] = 0.f;
+    if (threadIdx.x == 0) {
+        float v = 1.f;
+        if (mode == 1) {
+            float acc = 0.f;
+            for (int k = 0; k < d; ++k) acc = __builtin_fmaf(xr[k], xr[k], acc);
+            v = -0.5f * acc;
+        }
+        o[d] = v;
+    }
+}
+
+// qn[r] = chain(x_r . x_r), one wave-less thread per row (rows are few: a query batch)
+__global__ void __launch_bounds__(64) row_sqnorm_kernel(const float *__restrict__ x, int64_t n, int d, float *__restrict__ qn) {
+    const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (r >= n) return;
+    const float *p = x + (size_t)r * d;
+    float acc = 0.f;
+    for (int k = 0; k < d; ++k) acc = __builtin_fmaf(p[k], p[k], acc);
+    qn[r] = acc;
+}
+
+// coarse scores S -> dis = 2 S - qn (= -|q - c|^2; unfilled probes keep -FLT_MAX); scan term = dis (by_residual) or -qn
+__global__ void __launch_bounds__(256)
+    l2_coarse_term_kernel(float *__restrict__ cdis, float *__restrict__ cscan, const int32_t *__restrict__ cidx,
+                          const float *__restrict__ qn, int64_t nq, int nprobe, int by_residual) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq * nprobe) return;
+    const float q2 = qn[i / nprobe];
+    const float dis = cidx[i] < 0 ? -FLT_MAX : 2.0f * cdis[i] - q2;
+    cdis[i] = dis;
+    cscan[i] = by_residual ? dis : -q2;
+}
+
+// per-vector term of the L2 expansion: t = chain(r^ . r^) + 2 chain(c . r^)  (k ascending over d),
+// r^ the decoded code; !by_residual: t = chain(x^ . x^).  One thread per vector.
+__global__ void __launch_bounds__(256)
+    l2_term_kernel(const uint8_t *__restrict__ codes, const int32_t *__restrict__ list_no, int64_t n, int d, int M,
+                   const float *__restrict__ codebook, const float *__restrict__ centroids, int by_residual,
+                   float *__restrict__ t) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const int dsub = d / M;
+    const uint8_t *c = codes + (size_t)v * M;
+    const float *cen = centroids + (size_t)list_no[v] * d;
+    float a1 = 0.f, a2 = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float *cw = codebook + ((size_t)m * 256 + c[m]) * dsub;
+        for (int u = 0; u < dsub; ++u) {
+            a1 = __builtin_fmaf(cw[u], cw[u], a1);
+            if (by_residual) a2 = __builtin_fmaf(cen[m * dsub + u], cw[u], a2);
+        }
+    }
+    t[v] = a1 + 2.0f * a2;
+}
+
+// scores (larger = better, -FLT_MAX in unfilled slots) -> squared distances, best first ascending,
+// +FLT_MAX in unfilled slots (faiss CMax neutral)
+__global__ void __launch_bounds__(256) l2_finish_kernel(float *__restrict__ D, const int64_t *__restrict__ I, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) D[i] = I[i] < 0 ? FLT_MAX : -D[i];
+}
+// IndexFlatL2: aug scores S -> D = -(2 S - qn)
+__global__ void __launch_bounds__(256)
+    l2_flat_finish_kernel(float *__restrict__ D, const int64_t *__restrict__ I, const float *__restrict__ qn, int64_t nq, int k) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nq * k) D[i] = I[i] < 0 ? FLT_MAX : -(2.0f * D[i] - qn[i / k]);
+}
+// strided rows -> packed (reconstruct_n of an augmented store)
+__global__ void __launch_bounds__(256)
+    unaugment_rows_kernel(const float *__restrict__ x, int64_t n, int d, int da, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n * d) out[i] = x[(i / d) * da + (i % d)];
 }
 
 }  // namespace mi

@@ -85,6 +85,7 @@ class _Lib:
                 "mi_shards_destroy": [v],
                 "mi_flat_create": [c_int, c_int, POINTER(v)],
                 "mi_flat_create_ex": [c_int, c_int, c_int, POINTER(v)],
+                "mi_flat_create_metric": [c_int, c_int, c_int, POINTER(v)],
                 "mi_flat_destroy": [v],
                 "mi_flat_add": [v, c_int64, v],
                 "mi_flat_reserve": [v, c_int64],
@@ -164,11 +165,15 @@ class IndexFlatIP:
     metric_type = METRIC_INNER_PRODUCT
     is_trained = True
 
-    def __init__(self, d: int, device: int = 0, _storage: int = 0):
+    def __init__(self, d: int, device: int = 0, _storage: int = 0, _metric: int = METRIC_INNER_PRODUCT):
         self.d = int(d)
         self.device = int(device)
         self._h = c_void_p()
-        _check(_Lib.get().mi_flat_create_ex(self.d, self.device, int(_storage), ctypes.byref(self._h)))
+        if _metric == METRIC_L2:
+            _check(_Lib.get().mi_flat_create_metric(self.d, METRIC_L2, self.device, ctypes.byref(self._h)))
+            self.metric_type = METRIC_L2
+        else:
+            _check(_Lib.get().mi_flat_create_ex(self.d, self.device, int(_storage), ctypes.byref(self._h)))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -210,7 +215,6 @@ class IndexFlatIP:
         return self.reconstruct_n(int(i), 1)[0]
 
     def search(self, x, k: int):
-        self._require_ip("search")
         x = _as_f32(x, self.d)
         assert k > 0
         nq = x.shape[0]
@@ -228,17 +232,10 @@ class IndexFlatIP:
         return D, I
 
 
-    def _require_ip(self, what: str):
-        if self.metric_type != METRIC_INNER_PRODUCT:
-            raise NotImplementedError(f"IndexFlatL2.{what}: only METRIC_INNER_PRODUCT is computed on the MI355X path "
-                                      "(an L2 IndexFlat is accepted as a container -- e.g. the quantizer object "
-                                      "handed to IndexIVFPQ -- but not searched)")
-
     def rerank(self, x, cand_I, k: int, D=None, I=None, stream: int | None = None):
         """Exact scores of the candidate ids cand_I [nq, kc] (kc a multiple of k,
         negative = empty) and the k best -- the second stage of IndexRefineFlat.
         numpy in -> numpy out; CUDA tensors in -> CUDA tensors (D / I may be given)."""
-        self._require_ip("rerank")
         x = _as_f32(x, self.d)
         nq, kc = x.shape[0], int(cand_I.shape[1])
         if _is_torch(x) and x.is_cuda:
@@ -259,14 +256,14 @@ class IndexFlatIP:
 
 
 class IndexFlat(IndexFlatIP):
-    """faiss.IndexFlat(d, metric).  METRIC_L2 (faiss's default) gives a storage-only index:
-    add / ntotal / reconstruct_n work -- enough for the `quantizer` argument of the real
-    IndexIVFPQ constructor -- and search raises NotImplementedError."""
+    """faiss.IndexFlat(d, metric=METRIC_L2).  METRIC_L2: squared L2 distances, ascending,
+    +FLT_MAX in unfilled slots, evaluated through the expansion |q|^2 + |x|^2 - 2<q, x>
+    (one ascending-k chain per pair over augmented rows: oracle `flat_l2`)."""
 
     def __init__(self, d: int, metric: int = METRIC_L2, device: int = 0):
         if metric not in (METRIC_INNER_PRODUCT, METRIC_L2):
             raise NotImplementedError("metric must be METRIC_INNER_PRODUCT or METRIC_L2")
-        super().__init__(d, device)
+        super().__init__(d, device, _metric=int(metric))
         self.metric_type = int(metric)
 
 
@@ -334,8 +331,8 @@ class IndexIVFPQ:
 
     def __init__(self, *args, **kw):
         """Two signatures: faiss's own ``IndexIVFPQ(quantizer, d, nlist, M, nbits_per_idx[, metric])``
-        (first argument an IndexFlat; centroids it already holds are taken over, and faiss's default
-        metric there is METRIC_L2, which this path rejects -- pass METRIC_INNER_PRODUCT) and this
+        (first argument an IndexFlat; centroids it already holds are taken over; faiss's default
+        metric there is METRIC_L2) and this
         mirror's ``IndexIVFPQ(d, nlist, M, nbits=8, metric=METRIC_INNER_PRODUCT, by_residual=True, device=0)``."""
         quantizer = None
         if args and isinstance(args[0], IndexFlatIP):
@@ -352,9 +349,6 @@ class IndexIVFPQ:
         d, nlist, M, nbits, metric, by_residual, device = (p[k] for k in ("d", "nlist", "M", "nbits", "metric", "by_residual", "device"))
         if quantizer is not None:
             assert quantizer.d == int(d), f"quantizer.d ({quantizer.d}) != d ({d})"
-            if int(metric) != METRIC_INNER_PRODUCT:
-                raise NotImplementedError("IndexIVFPQ(quantizer, d, nlist, M, nbits): faiss's default metric is METRIC_L2; only "
-                                          "METRIC_INNER_PRODUCT is implemented on the MI355X path -- pass it as the sixth argument")
         self.d, self.nlist, self.device = int(d), int(nlist), int(device)
         self.metric_type = int(metric)
         self.by_residual = bool(by_residual)
@@ -460,7 +454,7 @@ class IndexIVFPQ:
             import torch
             given = torch.from_numpy(self.get_centroids()).to(torch.device("cuda", self.device))
         cent, cb = _train.train_ivfpq(x, self.nlist, self.pq.M, self.by_residual, self.cp,
-                                      self.device, self.verbose, centroids=given)
+                                      self.device, self.verbose, centroids=given, metric=self.metric_type)
         self.set_centroids(cent)
         self.set_codebook(cb)
 
@@ -615,6 +609,8 @@ class IndexIVFPQ:
         cD = np.empty((nq, nprobe), np.float32)
         lut = np.empty((nq, self.pq.M, self.pq.ksub), np.float32) if want_lut else None
         _check(_Lib.get().mi_index_coarse_lut(self._h, nq, _ptr(x), nprobe, _ptr(cI), _ptr(cD), _ptr(lut)))
+        if self.metric_type == METRIC_L2:       # the library hands back -|q - c|^2; faiss reports squared distances
+            cD = np.where(cI < 0, np.float32(np.finfo(np.float32).max), -cD)
         return cI, cD, lut
 
     # -- scan-kernel timing (HIP events on the launch stream) ------------
@@ -682,7 +678,7 @@ class IndexRefine:
     def __init__(self, base_index, refine_index=None):
         self.base_index = base_index
         self.d = base_index.d
-        self.refine_index = refine_index if refine_index is not None else IndexFlatIP(self.d, base_index.device)
+        self.refine_index = refine_index if refine_index is not None else IndexFlat(self.d, base_index.metric_type, base_index.device)
         self.k_factor = 1.0
         self.metric_type = base_index.metric_type
 
@@ -757,17 +753,17 @@ _FACTORY_RE = re.compile(r"^IVF(\d+)(?:_HNSW\d+)?,PQ(\d+)(?:x(\d+))?(,RFlat|,Ref
 
 def index_factory(d: int, description: str, metric: int = METRIC_L2, device: int = 0):
     """faiss.index_factory for the strings this path uses: "IVF{nlist},PQ{M}"
-    (optionally "PQ{M}x8") and "Flat".  Like faiss the default metric is L2,
-    which this path rejects: pass METRIC_INNER_PRODUCT."""
+    (optionally "PQ{M}x8", ",RFlat", ",Refine(SQfp16)") and "Flat".  Like faiss the default
+    metric is METRIC_L2 (the reference's normalised embeddings want METRIC_INNER_PRODUCT)."""
     description = description.replace(" ", "")
     if description == "Flat":
         return IndexFlat(d, metric, device)
+    if metric not in (METRIC_INNER_PRODUCT, METRIC_L2):
+        raise NotImplementedError("metric must be METRIC_INNER_PRODUCT or METRIC_L2")
     m = _FACTORY_RE.match(description)
     if not m:
         raise ValueError(f"index_factory: unsupported description {description!r} "
                          "(supported: 'Flat', 'IVF<nlist>,PQ<M>[x8][,RFlat | ,Refine(SQfp16)]')")
-    if metric != METRIC_INNER_PRODUCT:
-        raise NotImplementedError("only METRIC_INNER_PRODUCT is implemented on the MI355X path")
     nlist, M, nbits = int(m.group(1)), int(m.group(2)), int(m.group(3) or 8)
     index = IndexIVFPQ(d, nlist, M, nbits, metric, device=device)
     if m.group(4) == ",Refine(SQfp16)":          # half-precision refine store: half the HBM and half the bytes per candidate

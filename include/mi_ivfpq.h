@@ -18,8 +18,14 @@
  *     outputs, mi_index_search() only enqueues work on `stream` and returns
  *     without synchronising; with host pointers it stages and synchronises.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
- *   - metric: MI_METRIC_INNER_PRODUCT only in this round (the metric the
- *     reference's normalised stella embeddings use); MI_METRIC_L2 is rejected.
+ *   - Metrics: MI_METRIC_INNER_PRODUCT (the metric the reference's normalised stella
+ *     embeddings use; results best first = largest first, unfilled D = -FLT_MAX) and
+ *     MI_METRIC_L2 (faiss's default: squared L2 distances, smallest first, unfilled
+ *     D = +FLT_MAX), evaluated through the expansion -|q - x|^2 = 2 S - |q|^2 with
+ *     S = <q, x> - |x|^2/2 one ascending-k fmaf chain over vectors augmented by one column
+ *     (oracle/ivfpq_oracle.c, section METRIC_L2) -- the inner-product kernels run unchanged;
+ *     an IVF-PQ vector stores one more f32 (|r^|^2 + 2<c, r^>).  mi_index_coarse_slice /
+ *     mi_index_search_preassigned and the half-precision flat store are inner-product only.
  *   - nbits == 8 only (one byte per sub-quantiser, ksub = 256).
  *   - handles are opaque, freed only by *_destroy; one handle per device.
  *   - one host thread drives a handle.  mi_index_search() keeps one set of
@@ -38,7 +44,7 @@ extern "C" {
 #endif
 
 #define MI_METRIC_INNER_PRODUCT 0 /* faiss.METRIC_INNER_PRODUCT */
-#define MI_METRIC_L2 1            /* faiss.METRIC_L2 (not implemented) */
+#define MI_METRIC_L2 1            /* faiss.METRIC_L2 */
 
 typedef struct mi_index mi_index; /* faiss.IndexIVFPQ */
 typedef struct mi_flat mi_flat;   /* faiss.IndexFlatIP / IndexScalarQuantizer(QT_fp16) */
@@ -196,6 +202,10 @@ int mi_flat_create(int d, int device, mi_flat **out);
 #define MI_STORE_F32 0
 #define MI_STORE_F16 1
 int mi_flat_create_ex(int d, int device, int storage, mi_flat **out);
+/* faiss.IndexFlat(d, metric): MI_METRIC_L2 = IndexFlatL2 -- squared L2 distances, ascending,
+ * unfilled slots +FLT_MAX -- evaluated through the expansion |q|^2 + |x|^2 - 2<q, x> on
+ * augmented rows (see "Metrics" above). */
+int mi_flat_create_metric(int d, int metric, int device, mi_flat **out);
 int mi_flat_destroy(mi_flat *h);
 int mi_flat_add(mi_flat *h, int64_t n, const float *x);
 /* Capacity hint (std::vector::reserve on faiss's IndexFlat::codes): room for n vectors in

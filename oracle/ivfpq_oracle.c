@@ -384,3 +384,138 @@ ORACLE_API void oracle_cluster_means(int64_t n, int d, const float *x, const int
 ORACLE_API void oracle_neg_half_sqnorm(int64_t n, int d, const float *x, float *out) {
     for (int64_t r = 0; r < n; ++r) out[r] = -0.5f * dot_chain(x + (size_t)r * d, x + (size_t)r * d, d);
 }
+
+/* ------------------------------------------------------------------
+ * METRIC_L2 (faiss's default metric; IndexIVFPQ / IndexFlatL2 with squared L2 distances).
+ * faiss evaluates |q - x|^2 either directly or, in its BLAS path, through the expansion
+ * |q|^2 + |x|^2 - 2<q,x>; which one runs -- and in which order it sums -- depends on its
+ * build and on the batch size.  This restatement fixes ONE evaluation, the expansion, so
+ * that the inner-product machinery (and its kernels) carry over unchanged:
+ *
+ *   S(x, c)   = dot(x, c) + (-0.5 * dot(c, c))        one rounding at the "+"; bitwise the
+ *               ascending-k fmaf chain over the augmented vectors [x, 1, 0..] . [c, -|c|^2/2, 0..]
+ *   coarse    = the nprobe lists with the largest S(q, c)  (ties: smaller list number)
+ *   qn        = dot(q, q)
+ *   dis0      = 2 * S(q, c) - qn                       (= -|q - c|^2 up to rounding)
+ *   add       : list = arg max_c S(x, c); r = x - c; codes = nearest codeword per sub-vector
+ *               t(v) = dot(r^, r^) + 2 * dot(c, r^)     r^ = decoded residual (by_residual)
+ *                    = dot(x^, x^), dis0 = -qn           (!by_residual)
+ *   ADC       : acc = sum_m LUT_ip[m][code_m] (m ascending);  s = dis0 + (2 * acc - t)
+ *   result    : the k largest s under (s desc, id asc), reported as D = -s (ascending squared
+ *               distances, best first); unfilled slots I = -1, D = +FLT_MAX (faiss's CMax neutral).
+ * ------------------------------------------------------------------ */
+static inline float aug_score(const float *x, const float *c, float nh_c, int d) {
+    return dot_chain(x, c, d) + nh_c;
+}
+
+ORACLE_API void oracle_flat_l2(int64_t nq, int d, const float *q, int64_t nb, const float *base, int k,
+                               float *D, int64_t *I) {
+    float *nh = (float *)malloc(sizeof(float) * (size_t)(nb > 0 ? nb : 1));
+    for (int64_t i = 0; i < nb; ++i) nh[i] = -0.5f * dot_chain(base + i * d, base + i * d, d);
+#pragma omp parallel
+    {
+        cand_t *L = (cand_t *)malloc(sizeof(cand_t) * (size_t)k);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t qi = 0; qi < nq; ++qi) {
+            const float *qv = q + qi * d;
+            const float qn = dot_chain(qv, qv, d);
+            int n = 0;
+            for (int64_t i = 0; i < nb; ++i) topk_push(L, &n, k, 2.0f * aug_score(qv, base + i * d, nh[i], d) - qn, i);
+            for (int j = 0; j < k; ++j) {
+                D[qi * k + j] = j < n ? -L[j].s : FLT_MAX;
+                I[qi * k + j] = j < n ? L[j].id : -1;
+            }
+        }
+        free(L);
+    }
+    free(nh);
+}
+
+/* Index.add() for METRIC_L2: list numbers, codes and the per-vector term t */
+ORACLE_API void oracle_encode_l2(int64_t n, int d, const float *x, int nlist, const float *centroids, int M, int ksub,
+                                 const float *codebook, int by_residual, int32_t *list_no, uint8_t *codes, float *tnorm) {
+    const int dsub = d / M;
+    float *nh = (float *)malloc(sizeof(float) * (size_t)nlist);
+    for (int c = 0; c < nlist; ++c) nh[c] = -0.5f * dot_chain(centroids + (size_t)c * d, centroids + (size_t)c * d, d);
+#pragma omp parallel
+    {
+        float *r = (float *)malloc(sizeof(float) * (size_t)d);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t i = 0; i < n; ++i) {
+            const float *xi = x + i * d;
+            int best = 0;
+            float bs = aug_score(xi, centroids, nh[0], d);
+            for (int c = 1; c < nlist; ++c) {
+                const float s = aug_score(xi, centroids + (size_t)c * d, nh[c], d);
+                if (s > bs) { bs = s; best = c; }
+            }
+            list_no[i] = best;
+            const float *cen = centroids + (size_t)best * d;
+            for (int t = 0; t < d; ++t) r[t] = by_residual ? xi[t] - cen[t] : xi[t];
+            float a1 = 0.0f, a2 = 0.0f;
+            for (int m = 0; m < M; ++m) {
+                int bj = 0;
+                float bd = l2sqr_chain(r + m * dsub, codebook + (size_t)m * ksub * dsub, dsub);
+                for (int j = 1; j < ksub; ++j) {
+                    const float dj = l2sqr_chain(r + m * dsub, codebook + ((size_t)m * ksub + j) * dsub, dsub);
+                    if (dj < bd) { bd = dj; bj = j; }
+                }
+                codes[i * M + m] = (uint8_t)bj;
+                const float *cw = codebook + ((size_t)m * ksub + bj) * dsub;
+                for (int t = 0; t < dsub; ++t) {
+                    a1 = fmaf(cw[t], cw[t], a1);
+                    if (by_residual) a2 = fmaf(cen[m * dsub + t], cw[t], a2);
+                }
+            }
+            tnorm[i] = a1 + 2.0f * a2;
+        }
+        free(r);
+    }
+    free(nh);
+}
+
+ORACLE_API void oracle_search_l2(int64_t nq, int d, const float *q, int nlist, const float *centroids, int M, int ksub,
+                                 const float *codebook, int by_residual, const int64_t *list_off, const uint8_t *codes,
+                                 const int64_t *ids, const float *tnorm, int nprobe, int k, float *D, int64_t *I,
+                                 int32_t *coarse_I, float *coarse_D) {
+    if (nprobe > nlist) nprobe = nlist;
+    float *nh = (float *)malloc(sizeof(float) * (size_t)nlist);
+    for (int c = 0; c < nlist; ++c) nh[c] = -0.5f * dot_chain(centroids + (size_t)c * d, centroids + (size_t)c * d, d);
+#pragma omp parallel
+    {
+        float *lut = (float *)malloc(sizeof(float) * (size_t)M * ksub);
+        cand_t *P = (cand_t *)malloc(sizeof(cand_t) * (size_t)nprobe);
+        cand_t *L = (cand_t *)malloc(sizeof(cand_t) * (size_t)k);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t qi = 0; qi < nq; ++qi) {
+            const float *qv = q + qi * d;
+            const float qn = dot_chain(qv, qv, d);
+            int np = 0;
+            for (int c = 0; c < nlist; ++c) topk_push(P, &np, nprobe, aug_score(qv, centroids + (size_t)c * d, nh[c], d), c);
+            oracle_lut(d, M, ksub, qv, codebook, lut);
+            int n = 0;
+            for (int p = 0; p < np; ++p) {
+                const int64_t l = P[p].id;
+                const float dis0 = by_residual ? 2.0f * P[p].s - qn : -qn;
+                for (int64_t e = list_off[l]; e < list_off[l + 1]; ++e) {
+                    const uint8_t *c = codes + e * M;
+                    float acc = 0.0f;
+                    for (int m = 0; m < M; ++m) acc += lut[m * ksub + c[m]];
+                    topk_push(L, &n, k, dis0 + (2.0f * acc - tnorm[e]), ids[e]);
+                }
+            }
+            for (int j = 0; j < k; ++j) {
+                D[qi * k + j] = j < n ? -L[j].s : FLT_MAX;
+                I[qi * k + j] = j < n ? L[j].id : -1;
+            }
+            if (coarse_I)
+                for (int p = 0; p < nprobe; ++p) coarse_I[qi * nprobe + p] = p < np ? (int32_t)P[p].id : -1;
+            if (coarse_D)   /* reported as squared distances, like faiss's quantizer.search */
+                for (int p = 0; p < nprobe; ++p) coarse_D[qi * nprobe + p] = p < np ? -(2.0f * P[p].s - qn) : FLT_MAX;
+        }
+        free(lut);
+        free(P);
+        free(L);
+    }
+    free(nh);
+}

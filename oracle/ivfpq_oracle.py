@@ -231,3 +231,73 @@ def neg_half_sqnorm(x):
     lib().oracle_neg_half_sqnorm(ctypes.c_int64(x.shape[0]), ctypes.c_int(x.shape[1]), _p(x, ctypes.c_float),
                                  _p(out, ctypes.c_float))
     return out
+
+
+# ---- METRIC_L2 (see the header of the L2 section in ivfpq_oracle.c) ----
+def flat_l2(q, base, k):
+    """IndexFlatL2.search restatement -> (D squared distances ascending, I)."""
+    q, base = _f32(q), _f32(base)
+    nq, d = q.shape
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    lib().oracle_flat_l2(ctypes.c_int64(nq), ctypes.c_int(d), _p(q, ctypes.c_float), ctypes.c_int64(base.shape[0]),
+                         _p(base, ctypes.c_float), ctypes.c_int(k), _p(D, ctypes.c_float), _p(I, ctypes.c_int64))
+    return D, I
+
+
+def encode_l2(x, centroids, codebook, by_residual=True):
+    """Index.add arithmetic, METRIC_L2 -> (list_no i32, codes u8 [n,M], tnorm f32 [n])."""
+    x, centroids, codebook = _f32(x), _f32(centroids), _f32(codebook)
+    n, d = x.shape
+    M, ksub, _ = codebook.shape
+    list_no = np.empty(n, np.int32)
+    codes = np.empty((n, M), np.uint8)
+    tnorm = np.empty(n, np.float32)
+    lib().oracle_encode_l2(ctypes.c_int64(n), ctypes.c_int(d), _p(x, ctypes.c_float), ctypes.c_int(centroids.shape[0]),
+                           _p(centroids, ctypes.c_float), ctypes.c_int(M), ctypes.c_int(ksub), _p(codebook, ctypes.c_float),
+                           ctypes.c_int(int(by_residual)), _p(list_no, ctypes.c_int32), _p(codes, ctypes.c_uint8),
+                           _p(tnorm, ctypes.c_float))
+    return list_no, codes, tnorm
+
+
+def build_lists_l2(list_no, codes, ids, tnorm, nlist):
+    order = np.argsort(list_no, kind="stable")
+    off, c, i = build_lists(list_no, codes, ids, nlist)
+    return off, c, i, np.ascontiguousarray(tnorm[order])
+
+
+def search_l2(q, centroids, codebook, list_off, codes, ids, tnorm, nprobe, k, by_residual=True, return_coarse=False):
+    q, centroids, codebook = _f32(q), _f32(centroids), _f32(codebook)
+    nq, d = q.shape
+    M, ksub, _ = codebook.shape
+    nlist = centroids.shape[0]
+    npb = min(nprobe, nlist)
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    cI = np.empty((nq, npb), np.int32)
+    cD = np.empty((nq, npb), np.float32)
+    list_off = np.ascontiguousarray(list_off, np.int64)
+    codes = np.ascontiguousarray(codes, np.uint8)
+    ids = np.ascontiguousarray(ids, np.int64)
+    tnorm = _f32(tnorm)
+    lib().oracle_search_l2(ctypes.c_int64(nq), ctypes.c_int(d), _p(q, ctypes.c_float), ctypes.c_int(nlist),
+                           _p(centroids, ctypes.c_float), ctypes.c_int(M), ctypes.c_int(ksub), _p(codebook, ctypes.c_float),
+                           ctypes.c_int(int(by_residual)), _p(list_off, ctypes.c_int64), _p(codes, ctypes.c_uint8),
+                           _p(ids, ctypes.c_int64), _p(tnorm, ctypes.c_float), ctypes.c_int(npb), ctypes.c_int(k),
+                           _p(D, ctypes.c_float), _p(I, ctypes.c_int64), _p(cI, ctypes.c_int32), _p(cD, ctypes.c_float))
+    if return_coarse:
+        return D, I, cI, cD
+    return D, I
+
+
+def brute_force_l2(q, centroids, codebook, list_off, codes, by_residual=True):
+    """float64: exact squared distances |q - x^|^2 to every decoded vector, in storage order
+    (independent check of the expansion search_l2 evaluates)."""
+    centroids, codebook = np.asarray(centroids, np.float64), np.asarray(codebook, np.float64)
+    M = codebook.shape[0]
+    sizes = np.diff(list_off)
+    dec = np.concatenate([codebook[m][codes[:, m]] for m in range(M)], axis=1)
+    if by_residual:
+        dec = dec + centroids[np.repeat(np.arange(len(sizes)), sizes)]
+    qq = np.asarray(q, np.float64)
+    return ((qq[:, None, :] - dec[None]) ** 2).sum(2)

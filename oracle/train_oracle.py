@@ -80,3 +80,28 @@ def train_ivfpq(x: np.ndarray, nlist: int, M: int, by_residual: bool = True, nit
         flat = cb.reshape(M * 256, dsub)
         O.cluster_means(rows, a, flat)
     return cent, cb
+
+
+def train_ivfpq_l2(x: np.ndarray, nlist: int, M: int, by_residual: bool = True, niter: int = 25,
+                   max_points_per_centroid: int = 256, seed: int = 1234):
+    """METRIC_L2: as train_ivfpq, with the residuals taken to the L2-nearest centroid."""
+    x = np.ascontiguousarray(x, np.float32)
+    d = x.shape[1]
+    dsub = d // M
+    cent = kmeans_l2(sample(x, max_points_per_centroid * nlist, seed), nlist, niter, seed)
+    xp = sample(x, max_points_per_centroid * 256, seed + 1)
+    if by_residual:
+        xp = np.ascontiguousarray(xp - cent[assign_l2(xp, cent, 3)])
+    n = xp.shape[0]
+    g = torch.Generator(device="cpu").manual_seed(seed + 2)
+    init = torch.randperm(n, generator=g)[:256]
+    if init.numel() < 256:
+        init = torch.cat([init, torch.randint(0, n, (256 - init.numel(),), generator=g)])
+    cb = np.ascontiguousarray(xp[init.numpy()].reshape(256, M, dsub).transpose(1, 0, 2))
+    rows = xp.reshape(n * M, dsub)
+    zero = np.zeros((1, d), np.float32)
+    offs = (np.arange(M, dtype=np.int32) * 256)[None, :]
+    for _ in range(niter):
+        codes = O.encode(xp, zero, cb, by_residual=False)[1]
+        O.cluster_means(rows, (codes.astype(np.int32) + offs).reshape(-1), cb.reshape(M * 256, dsub))
+    return cent, cb

@@ -44,7 +44,7 @@ def test_index_factory_argument_errors():
     with pytest.raises(ValueError):
         faiss.index_factory(64, "HNSW32", faiss.METRIC_INNER_PRODUCT)
     with pytest.raises(NotImplementedError):
-        faiss.index_factory(64, "IVF16,PQ8")  # faiss default metric is L2: not on this path
+        faiss.index_factory(64, "IVF16,PQ8", 7)   # neither METRIC_INNER_PRODUCT nor METRIC_L2
     assert faiss.METRIC_INNER_PRODUCT == 0 and faiss.METRIC_L2 == 1
 
 

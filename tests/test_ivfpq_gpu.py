@@ -527,8 +527,8 @@ def test_edge_cases(faiss, oracle):
     untrained = faiss.IndexIVFPQ(64, 16, 8, 8, faiss.METRIC_INNER_PRODUCT)
     with pytest.raises(RuntimeError, match="not trained"):
         untrained.add(x)
-    with pytest.raises(RuntimeError):
-        faiss.IndexIVFPQ(64, 16, 8, 8, faiss.METRIC_L2)
+    with pytest.raises(RuntimeError, match="metric"):
+        faiss.IndexIVFPQ(64, 16, 8, 8, 5)           # neither METRIC_INNER_PRODUCT nor METRIC_L2 (L2: tests/test_l2_gpu.py)
 
 
 def test_torch_device_path_equals_host_path(faiss):

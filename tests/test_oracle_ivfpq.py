@@ -139,3 +139,35 @@ def test_rerank_restatement():
     base2 = np.repeat(base[:1], 6, 0)
     D, I = o.rerank(q[:1], base2, np.array([[5, 2, 4, 0, -1, 3]], np.int64), 3)
     assert I.tolist() == [[0, 2, 3]]
+
+
+def test_l2_restatement_against_float64(oracle):
+    """METRIC_L2: the expansion the oracle evaluates agrees with exact float64 squared distances
+    to the decoded vectors (values to rounding, result sets except near-ties)."""
+    rng = np.random.default_rng(11)
+    d, M, nlist, n, nq, k = 32, 4, 8, 1500, 20, 10
+    cent = rng.standard_normal((nlist, d)).astype(np.float32)
+    cb = (0.4 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+    x = (cent[rng.integers(0, nlist, n)] + 0.4 * rng.standard_normal((n, d))).astype(np.float32)
+    q = (x[:nq] + 0.1 * rng.standard_normal((nq, d))).astype(np.float32)
+    for by_res in (True, False):
+        ln, codes, t = oracle.encode_l2(x, cent, cb, by_res)
+        # the list is the L2-nearest centroid
+        d2 = ((x[:, None, :].astype(np.float64) - cent[None].astype(np.float64)) ** 2).sum(2)
+        assert (ln == d2.argmin(1)).mean() > 0.999
+        off, lc, li, lt = oracle.build_lists_l2(ln, codes, np.arange(n), t, nlist)
+        D, I = oracle.search_l2(q, cent, cb, off, lc, li, lt, nlist, k, by_res)     # all lists: exhaustive
+        exact = oracle.brute_force_l2(q, cent, cb, off, lc, by_res)
+        order = np.argsort(exact, axis=1, kind="stable")[:, :k]
+        want = np.take_along_axis(exact, order, 1)
+        assert np.allclose(D, want, rtol=1e-4, atol=1e-4)
+        assert np.mean([len(set(a) & set(li[b])) / k for a, b in zip(I.tolist(), order.tolist())]) > 0.98
+        assert (np.diff(D, axis=1) >= 0).all()
+    Df, If = oracle.flat_l2(q, x, k)
+    ex = ((q[:, None, :].astype(np.float64) - x[None].astype(np.float64)) ** 2).sum(2)
+    assert np.allclose(Df, np.sort(ex, axis=1)[:, :k], rtol=1e-4, atol=1e-4)
+    assert (If[:, 0] == np.arange(nq)).all()
+    # unfilled slots
+    D, I = oracle.search_l2(q, cent, cb, np.zeros(nlist + 1, np.int64), np.zeros((0, M), np.uint8), np.zeros(0, np.int64),
+                            np.zeros(0, np.float32), 3, k)
+    assert (I == -1).all() and (D == np.finfo(np.float32).max).all()
