@@ -65,16 +65,25 @@ def fill_from_parquet(index, data_dir: str, id_col: str = "id", emb_col: str = "
     import pyarrow.parquet as pq
     if not index.is_trained:
         raise RuntimeError("fill_from_parquet: index is not trained")
-    all_ids = []
+    writer = None
     total = 0
-    for ids, emb in iter_row_groups(data_dir, id_col, emb_col, index.d):
-        if len(emb):
-            index.add(emb)
-            total += len(emb)
-            if ids_out is not None:
-                all_ids.extend(ids)
-        if progress:
-            progress(total)
-    if ids_out is not None:
-        pq.write_table(pa.table({id_col: all_ids}), ids_out, row_group_size=65536)
+    try:
+        for ids, emb in iter_row_groups(data_dir, id_col, emb_col, index.d):
+            if len(emb):
+                index.add(emb)
+                total += len(emb)
+                if ids_out is not None:
+                    # the position -> id table is streamed row group by row group: host memory
+                    # stays at one row group whatever the corpus size (207 M ids never sit in a list)
+                    t = pa.table({id_col: ids})
+                    if writer is None:
+                        writer = pq.ParquetWriter(ids_out, t.schema)
+                    writer.write_table(t, row_group_size=65536)
+            if progress:
+                progress(total)
+        if ids_out is not None and writer is None:                      # empty input: an empty table
+            pq.write_table(pa.table({id_col: pa.array([], pa.string())}), ids_out)
+    finally:
+        if writer is not None:
+            writer.close()
     return total
