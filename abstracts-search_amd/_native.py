@@ -27,6 +27,11 @@ _loaded: dict[str, ctypes.CDLL] = {}
 
 
 def lib_path(name: str) -> str:
+    # MI_ENCODER_LIB / MI_IVFPQ_LIB: load another in-tree build of the same library (A/B runs of
+    # compile-time variants, tools/ only); it must sit next to the default one
+    alt = os.environ.get(f"MI_{name.upper()}_LIB")
+    if alt:
+        return os.path.join(_PKG, os.path.basename(alt))
     return os.path.join(_PKG, LIBS[name][0])
 
 

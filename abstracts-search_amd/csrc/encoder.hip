@@ -55,6 +55,26 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
         }
     }
     dim3 grid(nblocks), block(64 * WAVES_M * WAVES_N);
+    // big tiles, whole-K workgroups, more tiles than CUs: one persistent workgroup per CU walks its
+    // tiles and requests the next tile's first K tiles before the epilogue of the current one
+    // Off by default: the extra loop level pushes the 256x256 kernel over its 256 VGPRs (44 B of
+    // scratch per lane) and it measured 5 % slower (976 vs 1 030 TF on gate/up); MI_GEMM_PERSIST=1 keeps
+    // the experiment.  What it would hide is the ~11 us per tile of output write + pipeline fill.
+    static const bool persist_on = std::getenv("MI_GEMM_PERSIST") && std::atoi(std::getenv("MI_GEMM_PERSIST")) != 0;
+    if constexpr (BM * BN >= 256 * 256) {
+        if (persist_on && g.ksplit == 1 && g.tail_split == 1 && 8 * per > 256) {
+            dim3 pgrid(256);
+            switch (epi) {
+                case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_STORE, WMT, WNT, WAVES_M, WAVES_N, ST, true>), pgrid, block, 0, st, g); break;
+                case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_RESID, WMT, WNT, WAVES_M, WAVES_N, ST, true>), pgrid, block, 0, st, g); break;
+                case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_QKV, WMT, WNT, WAVES_M, WAVES_N, ST, true>), pgrid, block, 0, st, g); break;
+                case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_SWIGLU, WMT, WNT, WAVES_M, WAVES_N, ST, true>), pgrid, block, 0, st, g); break;
+                default: throw Error("bad epilogue");
+            }
+            MI_HIP(hipGetLastError());
+            return;
+        }
+    }
     switch (epi) {
         case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_STORE, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
         case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_RESID, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
@@ -164,6 +184,8 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             launch_skinny(epi, g, st);
         } else if (cfg == "big32" && epi != EPI_SWIGLU) {
             launch_ring32<4, 2, 2, 4, 4>(epi, g, st);   // 256x256 on the 32x32x16 MFMA shape (experimental)
+        } else if (cfg == "half") {
+            launch_ring<8, 4, 1, 4, 3>(epi, g, st);   // 128x256, 4 waves, 72 KiB ring: two workgroups per CU
         } else if (cfg == "big" || cfg == "big32") {
             launch_ring<8, 4, 2, 4, 4>(epi, g, st);
         } else if (cfg == "mid") {

@@ -430,15 +430,26 @@ __device__ __forceinline__ void wait_tiles(int tiles, bool lgkm) {
     else wait_vm<0>();
 }
 
-template <int EPI, int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
-__global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(GemmArgs g) {
+// (4-wave workgroups ask for two waves per SIMD: without it hipcc spreads the accumulators over
+// arch + acc registers -- 316 for the 128x256 tile -- and a second workgroup never fits the CU)
+// PERSIST: the grid is one workgroup per CU and a workgroup walks its tiles (virtual block ids
+// blockIdx.x + i * gridDim.x: the same XCD and the same tile window per round as the one-tile-
+// per-workgroup launch).  The first D K tiles of the NEXT tile are requested before the
+// epilogue of the current one, so workgroup launch, pipeline fill and the epilogue's stores --
+// ~15 us of a ~50 us K = 1536 tile when every tile is its own workgroup -- overlap.
+template <int EPI, int WMT, int WNT, int WAVES_M, int WAVES_N, int ST, bool PERSIST = false>
+__global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4 ? 2 : 1)) gemm_bf16_ring_kernel(GemmArgs g) {
     constexpr int BM = 16 * WMT * WAVES_M, BN = 16 * WNT * WAVES_N, BK = 32;
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int PA = BM / 16, PB = BN / 16;       // 1-KiB DMA pieces (16 rows x 64 B) per stage
     static_assert((PA + PB) % NW == 0, "DMA pieces must divide evenly over the waves");
     constexpr int PPW = (PA + PB) / NW;             // pieces per wave per stage
-    constexpr int D = ST - 1;                       // prefetch distance in tiles
-    static_assert((ST & (ST - 1)) == 0 && ST >= 4, "ring size must be a power of two >= 4");
+    // prefetch distance in tiles.  The fragments of tile t are in registers a step before they are
+    // multiplied, so after the barrier at the top of step t the stage of tile t is already free
+    // and tile t + ST may be requested into it (D = ST).  The power-of-two rings keep the distance
+    // ST - 1 they were tuned with; the 3-stage ring (72 KiB: two workgroups per CU) uses ST.
+    constexpr int D = ((ST & (ST - 1)) == 0) ? ST - 1 : ST;
+    static_assert(ST >= 3, "ring size must be >= 3");
     static_assert(EPI != EPI_SWIGLU || WNT % 2 == 0, "SwiGLU pairs gate/up tiles inside a wave");
     __shared__ __attribute__((aligned(16))) bf16_t smem[ST * (BM + BN) * BK];
 
@@ -457,8 +468,8 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
         }
     }
     int tm, tn;
-    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn, vb)) return;
-    const int m0 = tm * BM, n0 = tn * BN;
+    int vbid = PERSIST ? (int)blockIdx.x : vb;
+    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn, vbid)) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -470,6 +481,7 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
     const int scol = ((lane & 3) ^ ((0 - (lane >> 4)) & 3)) * 8;   // row>>2 & 3 == lane>>4 (pieces are 16 rows)
     const bf16_t *src[PPW];
     int dst[PPW], kstride[PPW];   // elements a piece's source advances per K step
+    auto setup = [&](int m0, int n0) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int q = w * PPW + i;
@@ -488,20 +500,18 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
             kstride[i] = BK;
         }
     }
+    };
+    setup(tm * BM, tn * BN);
     const int nk_all = g.K / BK;
     const int kt0 = (nk_all * ks) / ksplit;              // first K tile of this slice
     const int nk = (nk_all * (ks + 1)) / ksplit - kt0;   // tiles in this slice
     auto issue = [&](int tile) {
-        bf16_t *base = smem + (tile & (ST - 1)) * (BM + BN) * BK;
+        bf16_t *base = smem + (tile % ST) * (BM + BN) * BK;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) dma16(src[i] + (size_t)(kt0 + tile) * kstride[i], base + dst[i]);
     };
 
     f32x4 acc[WMT][WNT];
-#pragma unroll
-    for (int i = 0; i < WMT; ++i)
-#pragma unroll
-        for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // f(q) = (-q) & 3 with q = (row >> 2) & 3 makes each hardware 16-lane group of a
     // ds_read_b128 hit 16 distinct 16-byte slots (the groups mix lg values)
@@ -509,7 +519,7 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
     const int a_off = (wm * WMT * 16 + li) * BK + fslot, b_off = BM * BK + (wn * WNT * 16 + li) * BK + fslot;
     bf16x8 a0[WMT], b0[WNT], a1[WMT], b1[WNT];
     auto read_frags = [&](int tile, bf16x8(&a)[WMT], bf16x8(&b)[WNT]) {
-        const bf16_t *base = smem + (tile & (ST - 1)) * (BM + BN) * BK;
+        const bf16_t *base = smem + (tile % ST) * (BM + BN) * BK;
 #pragma unroll
         for (int j = 0; j < WNT; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(base + b_off + j * 16 * BK);
 #pragma unroll
@@ -556,7 +566,16 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
 #pragma unroll
     for (int s_ = 0; s_ < D; ++s_)
         if (s_ < nk) issue(s_);
-    wait_tiles<PPW, D - 1>(min(D - 1, nk - 1), false);
+    bool first_tile = true;
+    for (;;) {   // one pass per output tile (PERSIST: several)
+    const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!PERSIST || first_tile) wait_tiles<PPW, D - 1>(min(D - 1, nk - 1), false);
+    else wait_vm<0>();   // the next tile's first K tiles were requested before the last epilogue, whose stores count too
+    first_tile = false;
     __builtin_amdgcn_s_barrier();
     read_frags(0, a0, b0);
     // steady state, branch-free (so that hipcc counts the prefetch reads as
@@ -593,6 +612,22 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
         }
     }
 
+    bool more = false;
+    int tm2 = 0, tn2 = 0;
+    if constexpr (PERSIST) {
+        vbid += (int)gridDim.x;
+        more = tile_coords(g.tiles_m, g.tiles_n, tm2, tn2, vbid);
+        if (more) {
+            // every wave has read its last fragments (they were in registers a step before their
+            // MFMAs): the ring is free -- request the next tile's first K tiles now
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            setup(tm2 * BM, tn2 * BN);
+#pragma unroll
+            for (int s_ = 0; s_ < D; ++s_)
+                if (s_ < nk) issue(s_);
+        }
+    }
     GemmArgs ge = g;
     ge.ksplit = ksplit;   // this workgroup's share: > 1 = atomic adds
 #pragma unroll
@@ -608,6 +643,10 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring_kernel(G
                 store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
         }
     }
+    if (!more) break;
+    tm = tm2;
+    tn = tn2;
+    }   // tile loop
 }
 
 // ---------------------------------------------------------------------
