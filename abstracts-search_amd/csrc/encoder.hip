@@ -714,6 +714,26 @@ int mi_enc_gemm_bf16(int device, int M, int N, int K, const void *A, const void 
         GemmArgs g{};
         g.A = static_cast<const bf16_t *>(A); g.lda = K; g.W = static_cast<const bf16_t *>(W); g.ldw = K;
         g.M = M; g.N = N; g.K = K; g.C = static_cast<bf16_t *>(C); g.ldc = N;
+        if (std::getenv("MI_GEMM_TS")) {
+            // profile launch: in-kernel s_memtime stamps of every workgroup's phases (big tiles), mean / max to stderr
+            const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nb = 8 * ((tiles + 7) / 8);
+            DevBuf tsb;
+            unsigned long long *dts = tsb.as<unsigned long long>((size_t)nb * 8);
+            MI_HIP(hipMemsetAsync(dts, 0, (size_t)nb * 64, as_stream(stream)));
+            g.ts = dts;
+            launch_gemm(EPI_STORE, g, as_stream(stream));
+            std::vector<unsigned long long> h((size_t)nb * 8);
+            MI_HIP(hipStreamSynchronize(as_stream(stream)));
+            MI_HIP(hipMemcpy(h.data(), dts, h.size() * 8, hipMemcpyDeviceToHost));
+            const char *names[8] = {"", "first K tile landed", "barrier passed", "K loop issued", "epilogue issued", "stores acknowledged", "", ""};
+            std::fprintf(stderr, "[gemm stamps] M %d N %d K %d, %d workgroups, s_memtime ticks (100 MHz) since the workgroup's start\n", M, N, K, nb);
+            for (int i = 1; i <= 5; ++i) {
+                double sum = 0, mx = 0; size_t cnt = 0;
+                for (int b = 0; b < nb; ++b) { const double v = (double)h[(size_t)b * 8 + i]; if (v > 0) { sum += v - 1; mx = std::max(mx, v - 1); ++cnt; } }
+                if (cnt) std::fprintf(stderr, "  %-22s n=%6zu mean %9.1f max %9.1f\n", names[i], cnt, sum / cnt, mx);
+            }
+            return;
+        }
         launch_gemm(EPI_STORE, g, as_stream(stream));
     });
 }

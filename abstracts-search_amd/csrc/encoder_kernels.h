@@ -191,6 +191,7 @@ struct GemmArgs {
     // tail_first) is split tail_split ways along K so that it occupies the whole chip
     // for 1/tail_split of a tile time instead of a few CUs for a full one
     int tail_first, tail_split;
+    unsigned long long *ts;   // null, or [workgroups][8] s_memtime stamps of the first tile (MI_GEMM_TS=1 profile launch)
 };
 
 // W [N][ldw] (N % 16 == 0, K % 32 == 0) -> fragment-major Wt: one 64-thread workgroup per
@@ -312,6 +313,56 @@ __device__ __forceinline__ void store_rows4(const GemmArgs &g, f32x4 v, f32x4 v2
 template <int EPI>
 __device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, f32x4 v2, int trow, int tcol, int lane) {
     store_rows4<EPI>(g, v, v2, trow + (lane >> 4) * 4, tcol + (lane & 15), lane);
+}
+
+// The same epilogues for a tile accumulated with the MFMA operands swapped (acc = W_tile . A_tile^T,
+// the transpose of the output tile): lane (li = lane & 15, lg = lane >> 4) then holds
+// C[trow + li][tcol + 4 lg + r], r = 0..3 -- four consecutive columns of one row, so the 8- or
+// 16-byte store needs no cross-lane transpose at all (the quad transposes were ~40 % of a 6 us
+// epilogue: s_memtime stamps, tools/gemm_stamps.py).  Not for the V part of the QKV projection,
+// whose output is column-major: that epilogue keeps the untransposed tile.
+template <int EPI>
+__device__ __forceinline__ void store_tile_t(const GemmArgs &g, f32x4 v, f32x4 v2, int trow, int tcol, int lane) {
+    static_assert(EPI != EPI_QKV, "the QKV epilogue keeps the untransposed accumulator layout");
+    const int row = trow + (lane & 15), col0 = tcol + (lane >> 4) * 4;
+    if constexpr (EPI == EPI_SWIGLU) {
+        if (row < g.M && col0 < g.ldc) {
+            float h[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) h[c] = v[c] / (1.0f + __expf(-v[c])) * v2[c];
+            uint2 o;
+            o.x = pack2(h[0], h[1]);
+            o.y = pack2(h[2], h[3]);
+            *reinterpret_cast<uint2 *>(g.C + (size_t)row * g.ldc + col0) = o;
+        }
+    } else {
+        if (row >= g.M || col0 >= g.N) return;
+        if constexpr (EPI == EPI_F32H) {
+            *reinterpret_cast<float4 *>(g.X + (size_t)row * g.ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
+            return;
+        }
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias) b = *reinterpret_cast<const float4 *>(g.bias + col0);
+        if constexpr (EPI == EPI_RESID) {
+            if (g.ksplit > 1) {  // several workgroups add their K slice into the same element
+                float *px = g.X + (size_t)row * g.ldc + col0;
+                unsafeAtomicAdd(px + 0, v[0] + b.x);
+                unsafeAtomicAdd(px + 1, v[1] + b.y);
+                unsafeAtomicAdd(px + 2, v[2] + b.z);
+                unsafeAtomicAdd(px + 3, v[3] + b.w);
+            } else {
+                float4 *px = reinterpret_cast<float4 *>(g.X + (size_t)row * g.ldc + col0);
+                float4 x = *px;
+                x.x += v[0] + b.x; x.y += v[1] + b.y; x.z += v[2] + b.z; x.w += v[3] + b.w;
+                *px = x;
+            }
+        } else {
+            uint2 o;
+            o.x = pack2(v[0] + b.x, v[1] + b.y);
+            o.y = pack2(v[2] + b.z, v[3] + b.w);
+            *reinterpret_cast<uint2 *>(g.C + (size_t)row * g.ldc + col0) = o;
+        }
+    }
 }
 
 template <int EPI>
@@ -451,6 +502,7 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
     constexpr int D = ((ST & (ST - 1)) == 0) ? ST - 1 : ST;
     static_assert(ST >= 3, "ring size must be >= 3");
     static_assert(EPI != EPI_SWIGLU || WNT % 2 == 0, "SwiGLU pairs gate/up tiles inside a wave");
+    constexpr bool SWAP = EPI != EPI_QKV;           // accumulate the transposed tile (store_tile_t)
     __shared__ __attribute__((aligned(16))) bf16_t smem[ST * (BM + BN) * BK];
 
     // split-K (small batches, residual GEMMs): workgroup = (tile, K slice)
@@ -469,6 +521,10 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
     }
     int tm, tn;
     int vbid = PERSIST ? (int)blockIdx.x : vb;
+    const unsigned long long ts0 = g.ts ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto stamp = [&](int slot) {   // wave 0 of every workgroup; profile launches only
+        if (g.ts && threadIdx.x == 0) g.ts[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime() - ts0 + 1;
+    };
     if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn, vbid)) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -530,10 +586,14 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
         for (int i = 0; i < WMT; ++i)
 #pragma unroll
             for (int j = 0; j < WNT; ++j) {
+                // SWAP: acc = W_tile . A_tile^T (operand order exchanged; the fragment layouts of the two
+                // operands are the same), i.e. the output tile transposed -- see store_tile_t
                 if constexpr (EPI == EPI_F32H) {
                     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[i]), __builtin_bit_cast(h8, b[j]),
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, b[j]), __builtin_bit_cast(h8, a[i]),
                                                                        acc[i][j], 0, 0, 0);
+                } else if constexpr (SWAP) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
                 } else {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
                 }
@@ -576,7 +636,9 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
     if (!PERSIST || first_tile) wait_tiles<PPW, D - 1>(min(D - 1, nk - 1), false);
     else wait_vm<0>();   // the next tile's first K tiles were requested before the last epilogue, whose stores count too
     first_tile = false;
+    stamp(1);                      // first K tile landed (own pieces)
     __builtin_amdgcn_s_barrier();
+    stamp(2);
     read_frags(0, a0, b0);
     // steady state, branch-free (so that hipcc counts the prefetch reads as
     // allowed-outstanding in front of the MFMAs instead of waiting lgkmcnt(0))
@@ -612,6 +674,7 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
         }
     }
 
+    stamp(3);                      // K loop issued
     bool more = false;
     int tm2 = 0, tn2 = 0;
     if constexpr (PERSIST) {
@@ -636,12 +699,21 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
         if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
             for (int j = 0; j < WNT; j += 2)
-                store_tile<EPI>(ge, acc[i][j], acc[i][j + 1], trow, (n0 + wn * WNT * 16) / 2 + (j / 2) * 16, lane);
+                store_tile_t<EPI>(ge, acc[i][j], acc[i][j + 1], trow, (n0 + wn * WNT * 16) / 2 + (j / 2) * 16, lane);
+        } else if constexpr (SWAP) {
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+                store_tile_t<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
         } else {
 #pragma unroll
             for (int j = 0; j < WNT; ++j)
                 store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
         }
+    }
+    stamp(4);                      // epilogue issued
+    if (g.ts) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(5);                  // output stores acknowledged
     }
     if (!more) break;
     tm = tm2;
