@@ -707,6 +707,19 @@ class IndexRefine:
         self.base_index.add(x)
         self.refine_index.add(x)
 
+    def add_with_ids(self, x, ids):
+        """faiss's IndexRefine keeps its refine index in add() order and looks candidates up by
+        label, so labels must be positions: only ids that continue 0, 1, 2, ... are accepted
+        (anything else would silently re-rank the wrong rows).  For a shard of a larger corpus
+        keep positions here and translate at the exchange (ShardedIndex id_affine / id_map)."""
+        ids_h = ids.cpu().numpy() if _is_torch(ids) else np.asarray(ids)
+        n0 = self.ntotal
+        if ids_h.shape != (len(x),) or not np.array_equal(ids_h, np.arange(n0, n0 + len(x))):
+            raise NotImplementedError("IndexRefine.add_with_ids: ids must be the positions ntotal, ntotal + 1, ... "
+                                      "(the refine index is addressed by position); use add(), and id_affine / id_map "
+                                      "of ShardedIndex for a shard's global numbering")
+        self.add(x)
+
     def reset(self):
         self.base_index.reset()
         self.refine_index.reset()

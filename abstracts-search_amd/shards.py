@@ -40,6 +40,9 @@ class ShardedIndex:
         import torch.distributed as dist
         assert dist.is_initialized(), "ShardedIndex needs an initialised process group"
         self.index = index
+        # the exchange merges under (score desc, id asc): inner-product results only (an L2 index
+        # reports ascending distances; shard it by negating outside, or search its shards unsharded)
+        assert getattr(index, "metric_type", 0) == 0, "ShardedIndex: METRIC_INNER_PRODUCT indexes only"
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)

@@ -878,3 +878,14 @@ def test_refine_sqfp16_matches_oracle(faiss, oracle):
     assert np.array_equal(It.cpu().numpy(), Ie) and np.array_equal(bits(Dt.cpu().numpy()), bits(De))
     with pytest.raises(NotImplementedError):
         idx.refine_index.search(q, k)
+
+
+def test_refine_add_with_ids_only_accepts_positions(faiss):
+    d, M, nlist = 64, 8, 16
+    cent, cb, x, q = random_problem(3, d, M, nlist, 300, 4)
+    idx = faiss.IndexRefineFlat(make_index(faiss, cent, cb))
+    idx.add_with_ids(x[:100], np.arange(100))               # positions: fine
+    idx.add_with_ids(x[100:200], np.arange(100, 200))
+    assert idx.ntotal == 200 and idx.refine_index.ntotal == 200
+    with pytest.raises(NotImplementedError, match="positions"):
+        idx.add_with_ids(x[200:], np.arange(100) * 3)
