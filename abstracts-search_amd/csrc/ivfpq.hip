@@ -198,7 +198,7 @@ bool two_stage_wanted(int64_t nq, int64_t nc, int d, int K) {
 // exact second stage; outputs as launch_select's
 void launch_two_stage(const float *q, int64_t nq, const float *c32, const f16_t *c16, int64_t nc, int d, int K,
                       float cmax, float cscale, float *scores, DevBuf &q16buf, DevBuf &qscalebuf, DevBuf &statbuf,
-                      int32_t *out_i32, float *out_s, ProbeTables pt, hipStream_t st) {
+                      int32_t *out_i32, float *out_s, ProbeTables pt, hipStream_t st, int idx_off = 0) {
     f16_t *q16 = static_cast<f16_t *>(q16buf.reserve((size_t)nq * d * 2));
     float *qscale = static_cast<float *>(qscalebuf.reserve((size_t)nq * 4));
     launch_to_f16_rows(q, nq, d, q16, qscale, 0.f, st);
@@ -210,7 +210,7 @@ void launch_two_stage(const float *q, int64_t nq, const float *c32, const f16_t 
     // second-order term (products of the relative errors, d u / (1 - d u))
     ra.eps_rel = (0x1p-10f + (float)d * (0x1p-22f + 0x1p-24f) + 0x1p-26f * std::sqrt((float)d)) * 1.01f;
     ra.qscale = qscale; ra.cscale = cscale; ra.cmax = cmax;
-    ra.out_i32 = out_i32; ra.out_s = out_s; ra.pt = pt;
+    ra.out_i32 = out_i32; ra.out_s = out_s; ra.pt = pt; ra.idx_off = idx_off;
     if (const char *e = std::getenv("MI_REFINE_DEBUG")) ra.debug = std::atoi(e);
     const bool want_stats = std::getenv("MI_REFINE_STATS") != nullptr;
     if (want_stats) {
@@ -1301,6 +1301,15 @@ int mi_index_coarse_slice(mi_index *h, int64_t nq, const float *q, int nprobe, i
         for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
             const int64_t m = std::min(chunk, nq - c0);
             float *scores = w.scores.as<float>((size_t)m * n);
+            // big slices: the two-stage quantiser on the slice's rows of the f16 image (bit-identical
+            // result; max |c| over the whole table is a valid bound for the slice)
+            if (h->cent16_ok && two_stage_wanted(m, n, h->d, nprobe) && nprobe <= n) {
+                launch_two_stage(q + (size_t)c0 * h->d, m, h->centroids.get<float>() + (size_t)list_lo * h->d,
+                                 static_cast<const f16_t *>(h->cent16.p) + (size_t)list_lo * h->d, n, h->d, nprobe, h->cmax,
+                                 h->cscale, scores, w.q16, w.qscale, w.rstats, coarse_I + (size_t)c0 * nprobe,
+                                 coarse_D + (size_t)c0 * nprobe, ProbeTables{}, st, list_lo);
+                continue;
+            }
             launch_gemm(q + (size_t)c0 * h->d, m, h->centroids.get<float>() + (size_t)list_lo * h->d, n, h->d,
                         scores, n, st);
             // K = nprobe even if the slice is smaller: the tail is -1 / -FLT_MAX padded

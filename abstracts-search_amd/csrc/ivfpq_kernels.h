@@ -1322,6 +1322,7 @@ struct RefineArgs {
     ProbeTables pt;
     unsigned *stats;      // null, or [2]: total candidates, rows that fell back
     int debug;            // timing experiments: 1 = no exact chain
+    int idx_off;          // added to every index written (a slice of a larger centroid table: mi_index_coarse_slice)
 };
 
 __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
@@ -1538,7 +1539,7 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
     if (Sn > SELB_CAP) {
         __syncthreads();
         float *f = reinterpret_cast<float *>(skey);
-        select_by_insertion(r, n, K, row, a.out_i32, nullptr, a.out_s, 0, f, reinterpret_cast<int *>(f + 256),
+        select_by_insertion(r, n, K, row, a.out_i32, nullptr, a.out_s, a.idx_off, f, reinterpret_cast<int *>(f + 256),
                             f + 512, reinterpret_cast<int *>(f + 768));
         if (a.pt.list_goff) emit_probe_tables(a.pt, row, K, a.out_i32 + (size_t)row * K, wtot);
         return;
@@ -1586,7 +1587,7 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
         const int e = tid + i * 256;
         if (e < K) {
             const bool filled = res[i] != 0ull;
-            const int si = filled ? (int)~(unsigned)res[i] : -1;
+            const int si = filled ? (int)~(unsigned)res[i] + a.idx_off : -1;
             const size_t o = (size_t)row * K + e;
             if (a.out_i32) a.out_i32[o] = si;
             if (a.out_s) a.out_s[o] = filled ? o2f((unsigned)(res[i] >> 32)) : -FLT_MAX;

@@ -251,3 +251,24 @@ def test_native_exchange_step_rccl_world1(faiss, cfg4):
     Dr, Ir = shr.search_replicated(q[:128].contiguous(), 10)
     torch.cuda.synchronize()
     assert torch.equal(Dr, De) and torch.equal(Ir, torch.where(Ie < 0, Ie, Ie * 3 + 1))
+
+
+@pytest.mark.parametrize("nslices", [2, 4, 8])
+def test_cfg4_coarse_quantiser_split_by_centroid_range(faiss, cfg4, nslices):
+    """shard_coarse: every rank quantises against its slice of the 65536 centroids (the two-stage
+    quantiser on the slice for 2 / 4 slices, the exact GEMM for 8), the per-slice top-nprobe lists
+    merge to exactly the full quantiser's lists and scores"""
+    import torch
+    idx, q = cfg4["idx"], cfg4["q"]
+    nprobe, nlist = 64, cfg4["nlist"]
+    cI0, cD0, _ = idx.coarse_and_lut(q, nprobe, want_lut=False)
+    per = nlist // nslices
+    parts_I, parts_D = [], []
+    for s_ in range(nslices):
+        cI, cD = idx.coarse_slice(q, nprobe, s_ * per, (s_ + 1) * per)
+        assert int(cI.min()) >= s_ * per and int(cI.max()) < (s_ + 1) * per
+        parts_I.append(cI.to(torch.int64))
+        parts_D.append(cD)
+    D, I = faiss.merge_topk(torch.stack(parts_D), torch.stack(parts_I))
+    assert np.array_equal(I.cpu().numpy(), cI0.astype(np.int64))
+    assert np.array_equal(bits(D.cpu().numpy()), bits(cD0))
