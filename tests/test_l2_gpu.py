@@ -135,3 +135,38 @@ def test_refine_flat_l2(faiss, oracle):
         De, Ie = oracle.flat_l2(q[j:j + 1], x[ids], k)
         assert np.array_equal(I[j], ids[Ie[0]]) or np.array_equal(bits(D[j]), bits(De[0]))
         assert np.array_equal(bits(D[j]), bits(De[0]))
+
+
+def test_ivfpq_l2_two_stage_coarse(faiss, oracle, monkeypatch):
+    """METRIC_L2 on a big coarse table (nlist >= 8192, d % 128 == 0: augmented width d + 128): the
+    two-stage quantiser (f16 MFMA scores + exact re-scoring inside the proven margin) on the
+    augmented vectors gives the oracle's lists, in search and in add"""
+    monkeypatch.setenv("MI_TWO_STAGE", "1")
+    d, M, nlist, n, nq, k = 128, 16, 8192, 30000, 96, 10
+    rng = np.random.default_rng(17)
+    cent = rng.standard_normal((nlist, d)).astype(np.float32)
+    cent *= (0.5 + rng.random((nlist, 1))).astype(np.float32)              # norms differ: L2 order != inner-product order
+    cb = (0.2 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+    x = (cent[rng.integers(0, nlist, n)] + 0.2 * rng.standard_normal((n, d))).astype(np.float32)
+    q = (x[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    idx = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_L2)
+    idx.set_centroids(cent)
+    idx.set_codebook(cb)
+    idx.add(x)
+    ln, codes, t = oracle.encode_l2(x, cent, cb)
+    ln_h, codes_h = idx.encode(x[:2000])
+    assert np.array_equal(ln_h, ln[:2000]) and np.array_equal(codes_h, codes[:2000])
+    off, lc, li, lt = oracle.build_lists_l2(ln, codes, np.arange(n), t, nlist)
+    for nprobe in (1, 32):
+        idx.nprobe = nprobe
+        D, I = idx.search(q, k)
+        De, Ie, cIe, cDe = oracle.search_l2(q, cent, cb, off, lc, li, lt, nprobe, k, return_coarse=True)
+        cI, cD, _ = idx.coarse_and_lut(q, nprobe, want_lut=False)
+        assert np.array_equal(cI, cIe) and np.array_equal(bits(cD), bits(cDe))
+        assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De))
+    # inner-product order would pick other lists for some queries (the test data makes the metrics differ)
+    ip = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT)
+    ip.set_centroids(cent)
+    ip.set_codebook(cb)
+    cI_ip, _, _ = ip.coarse_and_lut(q, 1, want_lut=False)
+    assert (cI_ip[:, 0] != cIe[:, 0]).any()
