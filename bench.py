@@ -204,12 +204,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # BENCH_REHEARSAL=1 (tests/test_bench_multirank_gpu.py): the N ranks share GPU 0 and talk over gloo --
+    # the whole N > 1 control flow (rank != 0 paths, dealt shards, the exchange step) on a one-GPU box.
+    # Never a measurement: the JSON line carries "rehearsal": true.
+    rehearsal = bool(os.environ.get("BENCH_REHEARSAL"))
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("BENCH_FORCE_SHARDED"):
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     ctx = dict(np=np, torch=torch, dist=dist, world=world, rank=rank, local_rank=local_rank, dev=dev,
                clock=Clock(torch, dist, world, dev))
 
@@ -224,6 +233,8 @@ def main():
     else:
         out = cfg4_workload(args, ctx)
     if rank == 0 and out is not None:
+        if rehearsal:
+            out["rehearsal"] = True
         print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         dist.barrier()
@@ -296,6 +307,8 @@ def cfg4_workload(args, ctx):
     want_refine = not args.no_refine_point and not replicas
     relem = 2 if args.refine_store == "f16" else 4
     refine_own = want_refine and per_rank * d * relem <= 0.74 * hbm_total - 40e9
+    if os.environ.get("BENCH_FORCE_SUBSHARD"):                         # rehearsals: the layout of N = 1, 2 at 207 M on a small corpus
+        refine_own = False
     sub_mod = 8 if (want_refine and not refine_own) else 0
     assert not sub_mod or (8 % nsh == 0), "the 1/8 sub-shard needs N in {1, 2, 4, 8}"
     flat_r = sub = None
