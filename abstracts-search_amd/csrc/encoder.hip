@@ -85,6 +85,40 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
     MI_HIP(hipGetLastError());
 }
 
+// 256x256 tiles, slab ring + hand-ordered K loop (gemm_bf16_slab_kernel; WN_ = 4: 8 waves, 2: 4 waves): whole-K workgroups, the same wave-quantisation tail split
+template <int WN_>
+void launch_slab(int epi, GemmArgs g, hipStream_t st) {
+    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_n = (g.N + 255) / 256;
+    const int per = (g.tiles_m * g.tiles_n + 7) / 8;
+    g.ksplit = 1;
+    unsigned nblocks = 8u * per;
+    g.tail_first = 0;
+    g.tail_split = 1;
+    if (epi == EPI_RESID && !g.bias && !std::getenv("MI_NO_TAIL_SPLIT")) {
+        const int ncu = 256, nb = 8 * per;
+        const int main_b = nb / ncu * ncu, rem = nb - main_b;
+        const int nk = g.K / 32;
+        if (main_b > 0 && rem > 0 && rem <= ncu * 5 / 8) {
+            const int sp = std::min({ncu / rem, nk / 8, 16});
+            if (sp >= 2) {
+                g.tail_first = main_b;
+                g.tail_split = sp;
+                nblocks = (unsigned)(main_b + rem * sp);
+            }
+        }
+    }
+    dim3 grid(nblocks), block(128 * WN_);
+    switch (epi) {
+        case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_STORE, WN_>), grid, block, 0, st, g); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, WN_>), grid, block, 0, st, g); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_QKV, WN_>), grid, block, 0, st, g); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_SWIGLU, WN_>), grid, block, 0, st, g); break;
+        default: throw Error("bad epilogue");
+    }
+    MI_HIP(hipGetLastError());
+}
+
 // narrow tiles (WNT = 1): no SwiGLU instantiation (it pairs two N tiles inside a wave)
 template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
 void launch_ring_narrow(int epi, GemmArgs g, hipStream_t st) {
@@ -184,8 +218,17 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             launch_skinny(epi, g, st);
         } else if (cfg == "big32" && epi != EPI_SWIGLU) {
             launch_ring32<4, 2, 2, 4, 4>(epi, g, st);   // 256x256 on the 32x32x16 MFMA shape (experimental)
+        } else if (cfg == "slab8") {
+            launch_slab<4>(epi, g, st);
+        } else if (cfg == "slab4") {
+            launch_slab<2>(epi, g, st);
         } else if (cfg == "half") {
             launch_ring<8, 4, 1, 4, 3>(epi, g, st);   // 128x256, 4 waves, 72 KiB ring: two workgroups per CU
+        } else if (cfg == "big" && !std::getenv("MI_GEMM_RING")) {
+            // measured (tools/gemm_bench.py, 32768 tokens): 8 waves 1051 / 1060 TF on QKV / O, 4 waves 1106 / 1303 on
+            // gate-up / down (ring kernel: 968 / 952 / 1006 / 1166)
+            if (epi == EPI_SWIGLU || g.K >= 4096) launch_slab<2>(epi, g, st);
+            else launch_slab<4>(epi, g, st);
         } else if (cfg == "big" || cfg == "big32") {
             launch_ring<8, 4, 2, 4, 4>(epi, g, st);
         } else if (cfg == "mid") {

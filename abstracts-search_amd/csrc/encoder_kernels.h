@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 namespace mienc {
 
@@ -719,6 +720,204 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
     tm = tm2;
     tn = tn2;
     }   // tile loop
+}
+
+// ---------------------------------------------------------------------
+// 256x256 tile, hand-ordered K loop ("slab" kernel).  Two differences to gemm_bf16_ring_kernel:
+//
+//  * LDS holds a ring of five 32 KiB SLABS, alternately A and W: slab 2T = rows 0..255 of A at
+//    K columns [64 T, 64 T + 64), slab 2T+1 the same of W.  A DMA piece is 8 rows x 128 B -- whole
+//    128-byte cache lines.  (The ring kernel's pieces are 16 rows x 64 B: every line is fetched
+//    into the CU's L1 twice, half used each time; a timing build with contiguous pieces measured
+//    +11 % on the GEMM.)  A K step is still 32 columns: step u multiplies half u & 1 of tile u >> 1.
+//  * The K loop is an ordered sequence of `asm volatile` statements (MFMA, ds_read_b128, LDS-DMA,
+//    s_waitcnt, s_barrier).  The compiler allocates registers and computes addresses; the issue
+//    order and every wait are ours: per step the MFMAs of the fragment set read one step earlier,
+//    with the ds_reads of the next step's set and the DMA pieces of slab u + 4 spread between
+//    them (an LDS-DMA piece costs its wave 60-180 cycles of issue time; a burst of them in front
+//    of the MFMAs is what held the ring kernel at ~78 % MFMA-busy inside its K loop).  The
+//    accumulators are pinned to AGPRs ("+a"): left to hipcc, 256 of them get shuffled through
+//    v_accvgpr_read/write around every MFMA.
+//
+// WN_ = 4: 8 waves (2 x 4) of 128 x 64, two per SIMD;  WN_ = 2: 4 waves (2 x 2) of 128 x 128, one
+// per SIMD, all 256 AGPRs.  Ordering rules (the compiler knows nothing about the asm loads):
+//   - fragments read during step u are first used in step u+1, behind `s_waitcnt lgkmcnt(0)`;
+//   - slab q is requested during step q - 4 and first read during step (q | 1) - 2: the wait in
+//     front of an odd step u leaves at most one slab's pieces in flight (slabs <= u + 2 have landed:
+//     the next tile's pair), and the s_barrier behind it publishes the other waves' pieces; an even
+//     step reads the second half of slabs that landed a step earlier and may leave two in flight;
+//   - slab q's last read is issued during step q | 1 and retired by the lgkmcnt(0) in front of the
+//     next barrier, so its slot (q mod 5) is rewritten from step (q | 1) + 1 at the earliest:
+//     slab q + 5, requested during step q + 1.  Both parities hold.
+// Past the last slab the DMA pieces are skipped behind a uniform branch; the reads stay
+// unconditional (stale LDS into a set nobody multiplies): the accumulators never meet a merge of
+// different instruction sequences, where a failed coalesce would spill AGPRs to scratch.
+// Requires K % 64 == 0.
+// ---------------------------------------------------------------------
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16(bf16x8 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void dma16_off(const void *gptr, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n" ::"s"(lds_off), "v"(gptr) : "memory");
+}
+
+template <int EPI, int WN_>
+__global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, WMT = 8, WNT = 16 / WN_, NW = 2 * WN_;
+    constexpr int PPW = 32 / NW;                             // DMA pieces (1 KiB: 8 rows x 128 B) per wave per slab
+    constexpr int NS = 5, DQ = 4;                            // slabs in the ring, request distance in slabs
+    constexpr unsigned SLAB_B = 256 * 128;                   // 32 KiB
+    constexpr int NMF = WMT * WNT, NRD = WMT + WNT;          // MFMAs / fragment reads per wave per step
+    constexpr int RSTEP = (NMF * 3 / 4) / NRD;               // one read every RSTEP MFMAs, all inside the first 3/4 of the step
+    constexpr int DSTEP = NMF / PPW;                         // one DMA piece every DSTEP MFMAs
+    constexpr bool SWAP = EPI != EPI_QKV;
+    static_assert(RSTEP >= 1 && NW * PPW == 32, "schedule");
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NS * SLAB_B / 2];
+
+    int ksplit = 1, ks = 0, vb = -1;
+    if constexpr (EPI == EPI_RESID) {
+        if (g.tail_split > 1 && (int)blockIdx.x >= g.tail_first) {   // wave-quantisation tail: K split, f32 atomics
+            const int j = (int)blockIdx.x - g.tail_first;
+            ksplit = g.tail_split;
+            ks = j % ksplit;
+            vb = g.tail_first + j / ksplit;
+        }
+    }
+    int tm, tn;
+    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn, vb)) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w & 1, wn = w >> 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)smem;
+
+    const int nt_all = g.K / 64;                             // 64-column tiles
+    const int kt0 = (nt_all * ks) / ksplit;                  // first tile of this K slice
+    const int nk = 2 * ((nt_all * (ks + 1)) / ksplit - kt0); // K steps = slabs of this slice (even)
+
+    // DMA sources of this wave's pieces w*PPW .. of every A slab and every W slab: lane -> row lane >> 3 of the
+    // piece, 16-byte column slot (lane & 7) ^ (row & 7) (the XOR swizzle lives on the source side: the DMA
+    // itself is lane-linear)
+    const int prow = lane >> 3, scol = ((lane & 7) ^ prow) * 8;
+    const bf16_t *srcA[PPW], *srcW[PPW];
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+        const int r = (w * PPW + p) * 8 + prow;
+        srcA[p] = g.A + (size_t)min(m0 + r, g.M - 1) * g.lda + scol + (size_t)kt0 * 64;
+        srcW[p] = g.W + (size_t)min(n0 + r, g.N - 1) * g.ldw + scol + (size_t)kt0 * 64;
+    }
+    const unsigned dma_dst = lds0 + (unsigned)w * PPW * 1024u;       // + slot * SLAB_B + p * 1024
+
+    f32x4 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment (16 rows x 32 k) of K half kk: lane (li, lg) reads row li, global slot 4 kk + lg -> LDS slot ^ (row & 7)
+    const unsigned rdA = lds0 + (unsigned)(wm * 128 + li) * 128u + (unsigned)((lg ^ (li & 7)) * 16);          // kk = 1: ^ 64
+    const unsigned rdB = lds0 + (unsigned)(wn * WNT * 16 + li) * 128u + (unsigned)((lg ^ (li & 7)) * 16);
+    bf16x8 a0[WMT], b0[WNT], a1[WMT], b1[WNT];
+
+    auto mfma = [&](f32x4 &c, const bf16x8 &a, const bf16x8 &b) {
+        if constexpr (EPI == EPI_F32H) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
+        else if constexpr (SWAP) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    };
+    auto wrap = [&](unsigned s) { return s >= (unsigned)NS ? s - NS : s; };
+    // step u (parity PAR): multiply (ac, bc); read the fragments of step u+1 into (an, bn); request slab u + DQ.
+    // c = ring slot of slab 2 (u >> 1), the A slab of the tile step u multiplies.
+    auto step = [&](bf16x8(&ac)[WMT], bf16x8(&bc)[WNT], bf16x8(&an)[WMT], bf16x8(&bn)[WNT], auto PAR, auto STEADY, int u, unsigned c) {
+        constexpr int par = decltype(PAR)::value;
+        // step u+1 reads: odd u+1 -> same tile, half 1; even u+1 -> next tile, half 0
+        const unsigned sa = par == 0 ? c : wrap(c + 2), sb = wrap(sa + 1);
+        const unsigned ra = (rdA ^ (par == 0 ? 64u : 0u)) + sa * SLAB_B, rb = (rdB ^ (par == 0 ? 64u : 0u)) + sb * SLAB_B;
+        // slab u + DQ: DQ even -> an A slab in even steps, a W slab in odd steps; tile (u + DQ) >> 1
+        const unsigned sd = wrap(c + par + DQ);
+        const bool dma_on = decltype(STEADY)::value || u + DQ < nk;
+        const size_t koff = (size_t)((u + DQ) >> 1) * 64;
+        static_for<NMF>([&](auto M_) {
+            constexpr int m = decltype(M_)::value, i = m / WNT, j = m % WNT;
+            mfma(acc[i][j], ac[i], bc[j]);
+            if constexpr (m % RSTEP == RSTEP - 1 && m / RSTEP < NRD) {
+                constexpr int r = m / RSTEP;                          // first the W fragments, then the A fragments
+                if constexpr (r < WNT) lds_read16<r * 2048>(bn[r], rb);
+                else lds_read16<(r - WNT) * 2048>(an[r - WNT], ra);
+            }
+            if constexpr (m % DSTEP == DSTEP - 1) {
+                constexpr int p = m / DSTEP;
+                if (dma_on) dma16_off((par == 0 ? srcA[p] : srcW[p]) + koff, dma_dst + sd * SLAB_B + p * 1024u);
+            }
+        });
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+
+    // prologue: slabs 0 .. DQ-1 requested; slabs 0 and 1 landed; fragments of step 0 read
+#pragma unroll
+    for (int q = 0; q < DQ; ++q)
+        if (q < nk) {
+#pragma unroll
+            for (int p = 0; p < PPW; ++p)
+                dma16_off(((q & 1) ? srcW[p] : srcA[p]) + (size_t)(q >> 1) * 64, dma_dst + q * SLAB_B + p * 1024u);
+        }
+    wait_tiles<PPW, DQ - 2>(max(0, min(DQ - 2, nk - 2)), false);
+    asm volatile("s_barrier" ::: "memory");
+    static_for<WNT>([&](auto R) { lds_read16<decltype(R)::value * 2048>(b0[decltype(R)::value], rdB + SLAB_B); });
+    static_for<WMT>([&](auto R) { lds_read16<decltype(R)::value * 2048>(a0[decltype(R)::value], rdA); });
+
+    unsigned c = 0;                                          // ring slot of the current tile's A slab
+    int u = 0;
+    for (; u + DQ + 1 < nk; u += 2) {                        // steady state, branch-free
+        wait_vm_lgkm0<(DQ - 2) * PPW>();                     // even step: reads the second half of slabs that landed a step ago
+        asm volatile("s_barrier" ::: "memory");
+        step(a0, b0, a1, b1, P0{}, T_{}, u, c);
+        wait_vm_lgkm0<(DQ - 3) * PPW>();
+        asm volatile("s_barrier" ::: "memory");
+        step(a1, b1, a0, b0, P1{}, T_{}, u + 1, c);
+        c = wrap(c + 2);
+    }
+    for (; u < nk; u += 2) {                                 // the last steps: fewer slabs in flight, no new requests
+        wait_tiles<PPW, DQ - 3>(max(0, min(DQ - 3, nk - 3 - u)), true);
+        asm volatile("s_barrier" ::: "memory");
+        step(a0, b0, a1, b1, P0{}, F_{}, u, c);
+        wait_tiles<PPW, DQ - 3>(max(0, min(DQ - 3, nk - 4 - u)), true);
+        asm volatile("s_barrier" ::: "memory");
+        step(a1, b1, a0, b0, P1{}, F_{}, u + 1, c);
+        c = wrap(c + 2);
+    }
+    // the inline-asm MFMAs are opaque to the hazard recogniser: results -> v_accvgpr_read needs wait states
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    GemmArgs ge = g;
+    ge.ksplit = ksplit;
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+        const int trow = m0 + (wm * WMT + i) * 16;
+        if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int j = 0; j < WNT; j += 2)
+                store_tile_t<EPI>(ge, acc[i][j], acc[i][j + 1], trow, (n0 + wn * WNT * 16) / 2 + (j / 2) * 16, lane);
+        } else if constexpr (SWAP) {
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) store_tile_t<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
+        } else {
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------

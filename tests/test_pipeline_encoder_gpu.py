@@ -210,7 +210,7 @@ def test_stella_shape_full_depth_vs_oracle(st):
     assert cos.min() > 1 - 1e-3, cos
 
 
-@pytest.mark.parametrize("tile", ["big", "big32", "mid", "small", "tiny", "128"])
+@pytest.mark.parametrize("tile", ["big", "slab8", "slab4", "big32", "mid", "small", "tiny", "128"])
 def test_gemm_tile_configs_vs_torch(st, tile, monkeypatch):
     """every GEMM tile configuration (forced through MI_GEMM_TILE) against torch fp32"""
     import torch
@@ -225,3 +225,45 @@ def test_gemm_tile_configs_vs_torch(st, tile, monkeypatch):
         ref = A.float() @ W.float().T
         err = (C - ref).abs().max().item()
         assert err <= 1e-2 * ref.abs().max().item() + 1e-3, (tile, M, N, K, err)
+
+
+@pytest.mark.parametrize("tile", ["slab8", "slab4"])
+def test_tiny_model_vs_golden_on_the_slab_kernel(st, gold, tile, monkeypatch):
+    """every fused epilogue of the hand-ordered 256x256 kernel (QKV + bias + V^T, residual, SwiGLU, plain
+    store), forced onto the tiny golden model (tensors from transformers.Qwen2Model)"""
+    from oracle import encoder_oracle as E
+    monkeypatch.setenv("MI_GEMM_TILE", tile)
+    W = E.synth_weights(E.TINY, int(gold["seed"]))
+    model = st.SentenceTransformer(config=E.TINY.to_dict(), weights=W)
+    toks = _split(gold["ids"], gold["cu_seqlens"])
+    hs = model.last_hidden_state(toks)
+    ref = gold["hidden_bidir"]
+    cos = (hs * ref).sum(1) / (np.linalg.norm(hs, axis=1) * np.linalg.norm(ref, axis=1))
+    assert cos.min() > 1 - 1e-3, cos.min()
+    e = model.encode_tokens(toks, batch_size=3, normalize_embeddings=True)
+    assert ((e * gold["embed_bidir"]).sum(1)).min() > 1 - 1e-3
+
+
+def test_large_batch_slab_kernel_with_tail_split_vs_small_tiles(st, monkeypatch):
+    """33 280 tokens through a 2-layer model whose GEMMs take the default big-tile path: the slab kernel on
+    every projection, 260 output tiles on 256 CUs for the residual GEMMs -- the last 8 are split along K
+    with f32 atomics (the wave-quantisation tail).  Same embeddings as the 128x128 ring tiles and as the
+    old 256x256 ring kernel."""
+    from oracle import encoder_oracle as E
+    cfg = E.EncoderConfig(vocab_size=64, hidden=512, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=128,
+                          intermediate=1024, dense_out=64, max_seq_len=128)
+    W = E.synth_weights(cfg, 11)
+    rng = np.random.default_rng(11)
+    toks = [rng.integers(0, 64, 128).tolist() for _ in range(260)]
+    outs = {}
+    for name, env in (("default", {}), ("mid", {"MI_GEMM_TILE": "mid"}), ("ring", {"MI_GEMM_RING": "1"})):
+        for k in ("MI_GEMM_TILE", "MI_GEMM_RING"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model = st.SentenceTransformer(config=cfg.to_dict(), weights=W)
+        outs[name] = model.encode_tokens(toks, batch_size=260, normalize_embeddings=True)
+    for name in ("mid", "ring"):
+        cos = (outs["default"] * outs[name]).sum(1)
+        assert cos.min() > 1 - 1e-3, (name, cos.min())
+        assert np.abs(outs["default"] - outs[name]).max() < 1e-2, name
