@@ -109,6 +109,23 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
         }
     }
     dim3 grid(nblocks), block(128 * WN_);
+    // more work units than CUs: one persistent workgroup per CU could walk its units and request the next unit's first
+    // slabs before the epilogue of the current one.
+    // Off by default: it measured no faster (1 136 vs 1 169 TF on the QKV shape) -- what a tile pays outside its K loop
+    // is the ISSUE of the epilogue's stores, not the relaunch or the pipeline fill.  MI_GEMM_PERSIST=1 keeps the experiment.
+    static const bool persist_on = std::getenv("MI_GEMM_PERSIST") && std::atoi(std::getenv("MI_GEMM_PERSIST")) != 0;
+    if (persist_on && nblocks > 256) {
+        dim3 pgrid(256);
+        switch (epi) {
+            case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_STORE, WN_, true>), pgrid, block, 0, st, g); break;
+            case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, WN_, true>), pgrid, block, 0, st, g); break;
+            case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_QKV, WN_, true>), pgrid, block, 0, st, g); break;
+            case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_SWIGLU, WN_, true>), pgrid, block, 0, st, g); break;
+            default: throw Error("bad epilogue");
+        }
+        MI_HIP(hipGetLastError());
+        return;
+    }
     switch (epi) {
         case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_STORE, WN_>), grid, block, 0, st, g); break;
         case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, WN_>), grid, block, 0, st, g); break;
@@ -218,13 +235,15 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             launch_skinny(epi, g, st);
         } else if (cfg == "big32" && epi != EPI_SWIGLU) {
             launch_ring32<4, 2, 2, 4, 4>(epi, g, st);   // 256x256 on the 32x32x16 MFMA shape (experimental)
+        } else if ((cfg == "slab8" || cfg == "slab4") && !(epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {
+            launch_ring<8, 4, 2, 4, 4>(epi, g, st);          // the slab kernel stores 8 bf16 columns per lane
         } else if (cfg == "slab8") {
             launch_slab<4>(epi, g, st);
         } else if (cfg == "slab4") {
             launch_slab<2>(epi, g, st);
         } else if (cfg == "half") {
             launch_ring<8, 4, 1, 4, 3>(epi, g, st);   // 128x256, 4 waves, 72 KiB ring: two workgroups per CU
-        } else if (cfg == "big" && !std::getenv("MI_GEMM_RING")) {
+        } else if (cfg == "big" && !std::getenv("MI_GEMM_RING") && (epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {   // the slab kernel stores 8 bf16 columns per lane
             // measured (tools/gemm_bench.py, 32768 tokens): 8 waves 1051 / 1060 TF on QKV / O, 4 waves 1106 / 1303 on
             // gate-up / down (ring kernel: 968 / 952 / 1006 / 1166)
             if (epi == EPI_SWIGLU || g.K >= 4096) launch_slab<2>(epi, g, st);

@@ -769,7 +769,21 @@ __device__ __forceinline__ void dma16_off(const void *gptr, unsigned lds_off) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n" ::"s"(lds_off), "v"(gptr) : "memory");
 }
 
-template <int EPI, int WN_>
+// Which W row feeds position p of a wave's MFMA tile j is free -- it only decides which output column a lane ends
+// up holding.  PERM 0: tile j = W rows 16 j + p (a lane holds 4 consecutive columns of tile j).  bf16 outputs
+// choose rows so that a lane's values of two tiles are 8 CONSECUTIVE output columns: one 16-byte store, 64-byte
+// row segments per instruction instead of 32 (tools/micro/store_pattern.hip: 5.3 vs 8.2 us per 128 KiB tile; the
+// 32-byte version was ~10 of the ~52 us of a K = 1536 tile).
+//   PERM 1 (plain store):  row = 32 (j/2) + 8 (p/4) + 4 (j%2) + p%4        -> tiles 2J, 2J+1: columns 32 J + 8 lg + 0..7
+//   PERM 2 (SwiGLU; W rows are 16 gate rows / 16 up rows per 16 outputs; tiles 4Q..4Q+3 = gate, up, gate, up):
+//          row = 64 Q + 32 (p/8) + 8 (p/4 % 2) + 16 (j%2) + 4 (j/2 % 2) + p%4 -> outputs 32 Q + 8 lg + 0..7
+// Returns the byte offset of tile j's rows relative to the lane's base row.
+template <int PERM>
+__host__ __device__ constexpr int slab_w_tile_off(int j) {
+    return (PERM == 1 ? 32 * (j / 2) + 4 * (j % 2) : PERM == 2 ? 64 * (j / 4) + 16 * (j % 2) + 4 * ((j / 2) % 2) : 16 * j) * 128;
+}
+
+template <int EPI, int WN_, bool PERSIST = false>
 __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, WMT = 8, WNT = 16 / WN_, NW = 2 * WN_;
     constexpr int PPW = 32 / NW;                             // DMA pieces (1 KiB: 8 rows x 128 B) per wave per slab
@@ -779,55 +793,73 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     constexpr int RSTEP = (NMF * 3 / 4) / NRD;               // one read every RSTEP MFMAs, all inside the first 3/4 of the step
     constexpr int DSTEP = NMF / PPW;                         // one DMA piece every DSTEP MFMAs
     constexpr bool SWAP = EPI != EPI_QKV;
-    static_assert(RSTEP >= 1 && NW * PPW == 32, "schedule");
+    constexpr int PERM = EPI == EPI_STORE ? 1 : EPI == EPI_SWIGLU ? 2 : 0;
+    static_assert(RSTEP >= 1 && NW * PPW == 32 && PPW % 2 == 0, "schedule");
     __shared__ __attribute__((aligned(16))) bf16_t smem[NS * SLAB_B / 2];
-
-    int ksplit = 1, ks = 0, vb = -1;
-    if constexpr (EPI == EPI_RESID) {
-        if (g.tail_split > 1 && (int)blockIdx.x >= g.tail_first) {   // wave-quantisation tail: K split, f32 atomics
-            const int j = (int)blockIdx.x - g.tail_first;
-            ksplit = g.tail_split;
-            ks = j % ksplit;
-            vb = g.tail_first + j / ksplit;
-        }
-    }
-    int tm, tn;
-    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn, vb)) return;
-    const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w & 1, wn = w >> 1;
     const int li = lane & 15, lg = lane >> 4;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)smem;
-
     const int nt_all = g.K / 64;                             // 64-column tiles
-    const int kt0 = (nt_all * ks) / ksplit;                  // first tile of this K slice
-    const int nk = 2 * ((nt_all * (ks + 1)) / ksplit - kt0); // K steps = slabs of this slice (even)
+
+    // A work unit = an output tile, or (residual epilogue, wave-quantisation tail) a K slice of one: units >=
+    // tail_first are (tile, slice) pairs whose partial sums meet in f32 atomics.  PERSIST: one workgroup per CU walks
+    // units blockIdx.x + i * gridDim.x (the same XCD, the same tile window per round as one-unit workgroups).
+    auto decode = [&](int unit, int &tm_, int &tn_, int &ksplit_, int &kt0_, int &nk_) -> bool {
+        int ks = 0, vb = unit;
+        ksplit_ = 1;
+        if constexpr (EPI == EPI_RESID) {
+            if (g.tail_split > 1 && unit >= g.tail_first) {
+                const int j = unit - g.tail_first;
+                ksplit_ = g.tail_split;
+                ks = j % ksplit_;
+                vb = g.tail_first + j / ksplit_;
+            }
+        }
+        if (!tile_coords(g.tiles_m, g.tiles_n, tm_, tn_, vb)) return false;
+        kt0_ = (nt_all * ks) / ksplit_;                      // first 64-column tile of this K slice
+        nk_ = 2 * ((nt_all * (ks + 1)) / ksplit_ - kt0_);    // K steps = slabs of this slice (even)
+        return true;
+    };
 
     // DMA sources of this wave's pieces w*PPW .. of every A slab and every W slab: lane -> row lane >> 3 of the
-    // piece, 16-byte column slot (lane & 7) ^ (row & 7) (the XOR swizzle lives on the source side: the DMA
-    // itself is lane-linear)
+    // piece, 16-byte column slot (lane & 7) ^ key(row) (the XOR swizzle lives on the source side: the DMA itself
+    // is lane-linear).  A slabs: key = row & 7.  W slabs: key = (row & 3) | (bit 3 of row) << 2 -- the 16 rows a
+    // ds_read_b128 lane group touches are {0-3, 8-11, 16-19, 24-27} (+ multiples of 4) under the permuted tile
+    // maps above and {0..15} under the plain one; this key keeps all of them on 16 distinct 16-byte LDS granules.
     const int prow = lane >> 3, scol = ((lane & 7) ^ prow) * 8;
+    const int scolW[2] = {((lane & 7) ^ (prow & 3)) * 8, ((lane & 7) ^ ((prow & 3) | 4)) * 8};   // even / odd piece (bit 3 of the row)
     const bf16_t *srcA[PPW], *srcW[PPW];
-#pragma unroll
-    for (int p = 0; p < PPW; ++p) {
-        const int r = (w * PPW + p) * 8 + prow;
-        srcA[p] = g.A + (size_t)min(m0 + r, g.M - 1) * g.lda + scol + (size_t)kt0 * 64;
-        srcW[p] = g.W + (size_t)min(n0 + r, g.N - 1) * g.ldw + scol + (size_t)kt0 * 64;
-    }
     const unsigned dma_dst = lds0 + (unsigned)w * PPW * 1024u;       // + slot * SLAB_B + p * 1024
-
-    f32x4 acc[WMT][WNT];
+    auto set_sources = [&](int tm_, int tn_, int kt0_) {
 #pragma unroll
-    for (int i = 0; i < WMT; ++i)
+        for (int p = 0; p < PPW; ++p) {
+            const int r = (w * PPW + p) * 8 + prow;
+            srcA[p] = g.A + (size_t)min(tm_ * BM + r, g.M - 1) * g.lda + scol + (size_t)kt0_ * 64;
+            srcW[p] = g.W + (size_t)min(tn_ * BN + r, g.N - 1) * g.ldw + scolW[p & 1] + (size_t)kt0_ * 64;   // PPW is even: piece parity = p & 1
+        }
+    };
+    auto request_first = [&](int nk_) {                      // slabs 0 .. DQ-1 into ring slots 0 .. DQ-1
 #pragma unroll
-        for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < DQ; ++q)
+            if (q < nk_) {
+#pragma unroll
+                for (int p = 0; p < PPW; ++p)
+                    dma16_off(((q & 1) ? srcW[p] : srcA[p]) + (size_t)(q >> 1) * 64, dma_dst + q * SLAB_B + p * 1024u);
+            }
+    };
 
     // fragment (16 rows x 32 k) of K half kk: lane (li, lg) reads row li, global slot 4 kk + lg -> LDS slot ^ (row & 7)
     const unsigned rdA = lds0 + (unsigned)(wm * 128 + li) * 128u + (unsigned)((lg ^ (li & 7)) * 16);          // kk = 1: ^ 64
-    const unsigned rdB = lds0 + (unsigned)(wn * WNT * 16 + li) * 128u + (unsigned)((lg ^ (li & 7)) * 16);
+    const int bsub = li >> 2, bc = li & 3;
+    const int brow = PERM == 1 ? 8 * bsub + bc : PERM == 2 ? 32 * (bsub >> 1) + 8 * (bsub & 1) + bc : li;   // W row of tile position li
+    const int bkey = (brow & 3) | (((brow >> 3) & 1) << 2);
+    const unsigned rdB = lds0 + (unsigned)(wn * WNT * 16 + brow) * 128u + (unsigned)((lg ^ bkey) * 16);
+    f32x4 acc[WMT][WNT];
     bf16x8 a0[WMT], b0[WNT], a1[WMT], b1[WNT];
+    int nk = 0;                                              // K steps of the current unit
 
     auto mfma = [&](f32x4 &c, const bf16x8 &a, const bf16x8 &b) {
         if constexpr (EPI == EPI_F32H) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
@@ -851,7 +883,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
             mfma(acc[i][j], ac[i], bc[j]);
             if constexpr (m % RSTEP == RSTEP - 1 && m / RSTEP < NRD) {
                 constexpr int r = m / RSTEP;                          // first the W fragments, then the A fragments
-                if constexpr (r < WNT) lds_read16<r * 2048>(bn[r], rb);
+                if constexpr (r < WNT) lds_read16<slab_w_tile_off<PERM>(r)>(bn[r], rb);
                 else lds_read16<(r - WNT) * 2048>(an[r - WNT], ra);
             }
             if constexpr (m % DSTEP == DSTEP - 1) {
@@ -865,17 +897,22 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
 
-    // prologue: slabs 0 .. DQ-1 requested; slabs 0 and 1 landed; fragments of step 0 read
+    int unit = (int)blockIdx.x;
+    int tm, tn, ksplit, kt0;
+    if (!decode(unit, tm, tn, ksplit, kt0, nk)) return;
+    set_sources(tm, tn, kt0);
+    request_first(nk);
+    for (;;) {   // one pass per work unit
 #pragma unroll
-    for (int q = 0; q < DQ; ++q)
-        if (q < nk) {
+    for (int i = 0; i < WMT; ++i)
 #pragma unroll
-            for (int p = 0; p < PPW; ++p)
-                dma16_off(((q & 1) ? srcW[p] : srcA[p]) + (size_t)(q >> 1) * 64, dma_dst + q * SLAB_B + p * 1024u);
-        }
+        for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // slabs 0 and 1 landed (after a previous unit's epilogue its stores count as well: more conservative, never less --
+    // loads return in order among themselves); fragments of step 0 read
     wait_tiles<PPW, DQ - 2>(max(0, min(DQ - 2, nk - 2)), false);
     asm volatile("s_barrier" ::: "memory");
-    static_for<WNT>([&](auto R) { lds_read16<decltype(R)::value * 2048>(b0[decltype(R)::value], rdB + SLAB_B); });
+    static_for<WNT>([&](auto R) { lds_read16<slab_w_tile_off<PERM>(decltype(R)::value)>(b0[decltype(R)::value], rdB + SLAB_B); });
     static_for<WMT>([&](auto R) { lds_read16<decltype(R)::value * 2048>(a0[decltype(R)::value], rdA); });
 
     unsigned c = 0;                                          // ring slot of the current tile's A slab
@@ -901,15 +938,62 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     // the inline-asm MFMAs are opaque to the hazard recogniser: results -> v_accvgpr_read needs wait states
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
+    // PERSIST: request the next unit's first slabs before this unit's epilogue -- the workgroup relaunch, the
+    // pipeline fill (the first slabs' trip from HBM / L2) and the drain of the epilogue's stores overlap
+    bool more = false;
+    int tm2 = 0, tn2 = 0, ksplit2 = 1, kt02 = 0, nk2 = 0;
+    if constexpr (PERSIST) {
+        unit += (int)gridDim.x;
+        more = decode(unit, tm2, tn2, ksplit2, kt02, nk2);
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last step's (unused) fragment reads: the ring is free
+            asm volatile("s_barrier" ::: "memory");              // ... in every wave
+            set_sources(tm2, tn2, kt02);
+            request_first(nk2);
+        }
+    }
+
+    const int m0 = tm * BM, n0 = tn * BN;
     GemmArgs ge = g;
     ge.ksplit = ksplit;
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         const int trow = m0 + (wm * WMT + i) * 16;
-        if constexpr (EPI == EPI_SWIGLU) {
+        const int row = trow + li;
+        if constexpr (PERM == 2) {          // 8 consecutive SwiGLU outputs per lane from tiles (gate, up, gate, up)
 #pragma unroll
-            for (int j = 0; j < WNT; j += 2)
-                store_tile_t<EPI>(ge, acc[i][j], acc[i][j + 1], trow, (n0 + wn * WNT * 16) / 2 + (j / 2) * 16, lane);
+            for (int q = 0; q < WNT / 4; ++q) {
+                const int col0 = (n0 + wn * WNT * 16) / 2 + 32 * q + 8 * lg;
+                if (row < g.M && col0 < g.ldc) {
+                    float h[8];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float ga = acc[i][4 * q][c], gb = acc[i][4 * q + 2][c];
+                        h[c] = ga * __builtin_amdgcn_rcpf(1.0f + __expf(-ga)) * acc[i][4 * q + 1][c];
+                        h[4 + c] = gb * __builtin_amdgcn_rcpf(1.0f + __expf(-gb)) * acc[i][4 * q + 3][c];
+                    }
+                    uint4 o;
+                    o.x = pack2(h[0], h[1]); o.y = pack2(h[2], h[3]); o.z = pack2(h[4], h[5]); o.w = pack2(h[6], h[7]);
+                    *reinterpret_cast<uint4 *>(g.C + (size_t)row * g.ldc + col0) = o;
+                }
+            }
+        } else if constexpr (PERM == 1) {   // 8 consecutive columns per lane from tiles 2J, 2J+1
+#pragma unroll
+            for (int J = 0; J < WNT / 2; ++J) {
+                const int col0 = n0 + wn * WNT * 16 + 32 * J + 8 * lg;
+                if (row < g.M && col0 < g.N) {
+                    float4 b0v = make_float4(0.f, 0.f, 0.f, 0.f), b1v = b0v;
+                    if (g.bias) {
+                        b0v = *reinterpret_cast<const float4 *>(g.bias + col0);
+                        b1v = *reinterpret_cast<const float4 *>(g.bias + col0 + 4);
+                    }
+                    const f32x4 v0 = acc[i][2 * J], v1 = acc[i][2 * J + 1];
+                    uint4 o;
+                    o.x = pack2(v0[0] + b0v.x, v0[1] + b0v.y); o.y = pack2(v0[2] + b0v.z, v0[3] + b0v.w);
+                    o.z = pack2(v1[0] + b1v.x, v1[1] + b1v.y); o.w = pack2(v1[2] + b1v.z, v1[3] + b1v.w);
+                    *reinterpret_cast<uint4 *>(g.C + (size_t)row * g.ldc + col0) = o;
+                }
+            }
         } else if constexpr (SWAP) {
 #pragma unroll
             for (int j = 0; j < WNT; ++j) store_tile_t<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
@@ -918,6 +1002,9 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
             for (int j = 0; j < WNT; ++j) store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
         }
     }
+    if (!more) break;
+    tm = tm2; tn = tn2; ksplit = ksplit2; kt0 = kt02; nk = nk2;
+    }   // unit loop
 }
 
 // ---------------------------------------------------------------------
