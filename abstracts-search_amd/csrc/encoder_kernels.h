@@ -994,6 +994,46 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     *reinterpret_cast<uint4 *>(g.C + (size_t)row * g.ldc + col0) = o;
                 }
             }
+        } else if constexpr (EPI == EPI_RESID && !PERSIST) {
+            if (ksplit == 1) {
+                // X += acc through a wave-private LDS staging block: straight from the MFMA layout an instruction
+                // touches 16 rows x 64 B, and the memory pipe charges ~3.5 cycles per (instruction, 128-byte line)
+                // whatever the bytes (tools/micro/store_pattern.hip: 128 KiB in 4.3 us as 64-byte segments, 1.6 us
+                // as whole lines) -- the read-modify-write of a 256 KiB f32 tile was ~17 us of a 55 us O-projection
+                // tile.  Staged, a wave's 16 x CW block goes out (and X comes in) as 256 / CW rows x CW*4 B per
+                // instruction.  Rows are padded by 16 B: the 8 lanes of a ds_write_b128 group sit on 8 rows.
+                constexpr int CW = WNT * 16, ROWF = CW + 4, LPR = CW / 4, RPI = 64 / LPR;   // floats per staged row, lanes per row, rows per instruction
+                float *stg = reinterpret_cast<float *>(smem) + w * 16 * ROWF;
+                if (i == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done with the ring
+                    asm volatile("s_barrier" ::: "memory");
+                }
+#pragma unroll
+                for (int j = 0; j < WNT; ++j)
+                    *reinterpret_cast<f32x4 *>(stg + li * ROWF + j * 16 + 4 * lg) = acc[i][j];
+                const int c4 = lane % LPR, col = n0 + wn * CW + c4 * 4;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g.bias && col < g.N) bv = *reinterpret_cast<const float4 *>(g.bias + col);
+                float4 xs[16 / RPI];
+#pragma unroll
+                for (int it = 0; it < 16 / RPI; ++it) {
+                    const int r = it * RPI + lane / LPR;
+                    if (trow + r < g.M && col < g.N) xs[it] = *reinterpret_cast<const float4 *>(g.X + (size_t)(trow + r) * g.ldc + col);
+                }
+#pragma unroll
+                for (int it = 0; it < 16 / RPI; ++it) {
+                    const int r = it * RPI + lane / LPR;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + r * ROWF + c4 * 4);
+                    if (trow + r < g.M && col < g.N) {
+                        float4 x = xs[it];
+                        x.x += v[0] + bv.x; x.y += v[1] + bv.y; x.z += v[2] + bv.z; x.w += v[3] + bv.w;
+                        *reinterpret_cast<float4 *>(g.X + (size_t)(trow + r) * g.ldc + col) = x;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) store_tile_t<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
+            }
         } else if constexpr (SWAP) {
 #pragma unroll
             for (int j = 0; j < WNT; ++j) store_tile_t<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);

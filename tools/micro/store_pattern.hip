@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256) k(unsigned short *C, int ldc, int tiles_n
         }
     }
 }
-int main() {
+int main(int argc, char **argv) {
+    const int nwg = argc > 1 ? atoi(argv[1]) : 256;
     const int M = 32768, N = 2048, tiles_n = N / 256, ntiles = (M / 256) * tiles_n, rounds = 8;
     unsigned short *C;
     hipMalloc(&C, (size_t)M * N * 2);
@@ -52,17 +53,17 @@ int main() {
         for (int rep = 0; rep < 5; ++rep) {
             hipEventRecord(e0);
             switch (pat) {
-                case 0: hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, C, N, tiles_n, ntiles, rounds); break;
-                case 1: hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), 0, 0, C, N, tiles_n, ntiles, rounds); break;
-                case 2: hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, C, N, tiles_n, ntiles, rounds); break;
-                default: hipLaunchKernelGGL(k<3>, dim3(256), dim3(256), 0, 0, C, N, tiles_n, ntiles, rounds); break;
+                case 0: hipLaunchKernelGGL(k<0>, dim3(nwg), dim3(256), 0, 0, C, N, tiles_n, ntiles, rounds); break;
+                case 1: hipLaunchKernelGGL(k<1>, dim3(nwg), dim3(256), 0, 0, C, N, tiles_n, ntiles, rounds); break;
+                case 2: hipLaunchKernelGGL(k<2>, dim3(nwg), dim3(256), 0, 0, C, N, tiles_n, ntiles, rounds); break;
+                default: hipLaunchKernelGGL(k<3>, dim3(nwg), dim3(256), 0, 0, C, N, tiles_n, ntiles, rounds); break;
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) best = ms;
         }
-        printf("pattern %d: %.2f us per 128 KiB tile per CU (%.2f TB/s aggregate)\n", pat, best * 1e3 / rounds,
-               256.0 * rounds * 131072 / (best * 1e-3) / 1e12);
+        printf("%d workgroups, pattern %d: %.2f us per 128 KiB tile per CU (%.2f TB/s aggregate)\n", nwg, pat, best * 1e3 / rounds,
+               (double)nwg * rounds * 131072 / (best * 1e-3) / 1e12);
     }
     return 0;
 }
