@@ -790,7 +790,8 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     constexpr int NS = 5, DQ = 4;                            // slabs in the ring, request distance in slabs
     constexpr unsigned SLAB_B = 256 * 128;                   // 32 KiB
     constexpr int NMF = WMT * WNT, NRD = WMT + WNT;          // MFMAs / fragment reads per wave per step
-    constexpr int RSTEP = (NMF * 3 / 4) / NRD;               // one read every RSTEP MFMAs, all inside the first 3/4 of the step
+    constexpr int RSTEP = (NMF * 3 / 4) / NRD;               // one read every RSTEP MFMAs, all inside the first 3/4 of the step (placement
+                                                             // of reads and DMA pieces inside the step measured +-2 %: noise)
     constexpr int DSTEP = NMF / PPW;                         // one DMA piece every DSTEP MFMAs
     constexpr bool SWAP = EPI != EPI_QKV;
     constexpr int PERM = EPI == EPI_STORE ? 1 : EPI == EPI_SWIGLU ? 2 : 0;
@@ -994,7 +995,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     *reinterpret_cast<uint4 *>(g.C + (size_t)row * g.ldc + col0) = o;
                 }
             }
-        } else if constexpr (EPI == EPI_RESID && !PERSIST) {
+        } else if constexpr ((EPI == EPI_RESID || EPI == EPI_F32H) && !PERSIST) {
             if (ksplit == 1) {
                 // X += acc through a wave-private LDS staging block: straight from the MFMA layout an instruction
                 // touches 16 rows x 64 B, and the memory pipe charges ~3.5 cycles per (instruction, 128-byte line)
@@ -1012,6 +1013,15 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 for (int j = 0; j < WNT; ++j)
                     *reinterpret_cast<f32x4 *>(stg + li * ROWF + j * 16 + 4 * lg) = acc[i][j];
                 const int c4 = lane % LPR, col = n0 + wn * CW + c4 * 4;
+                if constexpr (EPI == EPI_F32H) {          // plain f32 store (the index library's approximate scores)
+#pragma unroll
+                    for (int it = 0; it < 16 / RPI; ++it) {
+                        const int r = it * RPI + lane / LPR;
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + r * ROWF + c4 * 4);
+                        if (trow + r < g.M && col < g.N)
+                            *reinterpret_cast<float4 *>(g.X + (size_t)(trow + r) * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                } else {
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (g.bias && col < g.N) bv = *reinterpret_cast<const float4 *>(g.bias + col);
                 float4 xs[16 / RPI];
@@ -1029,6 +1039,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                         x.x += v[0] + bv.x; x.y += v[1] + bv.y; x.z += v[2] + bv.z; x.w += v[3] + bv.w;
                         *reinterpret_cast<float4 *>(g.X + (size_t)(trow + r) * g.ldc + col) = x;
                     }
+                }
                 }
             } else {
 #pragma unroll

@@ -144,6 +144,21 @@ void launch_ring_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int
     MI_HIP(hipGetLastError());
 }
 
+// the encoder's slab kernel (256 x 256 tiles, hand-ordered K loop, staged whole-line f32 stores), f16 instantiation
+void launch_slab_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int K, float *S, int64_t ldS, hipStream_t st) {
+    mienc::GemmArgs g{};
+    g.A = reinterpret_cast<const mienc::bf16_t *>(A);
+    g.W = reinterpret_cast<const mienc::bf16_t *>(B);
+    g.lda = K; g.ldw = K; g.M = (int)na; g.N = (int)nb; g.K = K;
+    g.X = S; g.ldc = (int)ldS;
+    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_n = (g.N + 255) / 256;
+    g.ksplit = 1; g.tail_first = 0; g.tail_split = 1;
+    const int per = (g.tiles_m * g.tiles_n + 7) / 8;
+    hipLaunchKernelGGL((mienc::gemm_bf16_slab_kernel<mienc::EPI_F32H, 4>), dim3(8u * per), dim3(512), 0, st, g);
+    MI_HIP(hipGetLastError());
+}
+
 void launch_gemm_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int K, float *S, int64_t ldS,
                      hipStream_t st) {
     MI_REQUIRE(K % 64 == 0 && ldS % 4 == 0, "f16 gemm: K % 64 and ldS % 4");
@@ -152,7 +167,8 @@ void launch_gemm_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int
     const char *e = std::getenv("MI_F16_GEMM");
     if (!(e && std::string(e) == "simple") && ldS < ((int64_t)1 << 31)) {
         const int64_t tiles_big = ((na + 255) / 256) * ((nb + 255) / 256);
-        if (tiles_big >= 512) launch_ring_f16<8, 4, 2, 4, 4>(A, na, B, nb, K, S, ldS, st);   // 256 x 256, 8 waves
+        if (tiles_big >= 512 && !(e && std::string(e) == "ring")) launch_slab_f16(A, na, B, nb, K, S, ldS, st);   // 256 x 256, 8 waves
+        else if (tiles_big >= 512) launch_ring_f16<8, 4, 2, 4, 4>(A, na, B, nb, K, S, ldS, st);   // MI_F16_GEMM=ring: the older kernel (A/B runs)
         else launch_ring_f16<4, 4, 2, 2, 4>(A, na, B, nb, K, S, ldS, st);                    // 128 x 128, 4 waves
         return;
     }
