@@ -1048,6 +1048,39 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
         } else if constexpr (SWAP) {
 #pragma unroll
             for (int j = 0; j < WNT; ++j) store_tile_t<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
+        } else if constexpr (EPI == EPI_QKV && !PERSIST) {
+            if (n0 + BN <= g.qk_cols) {
+                // Q / K columns (row-major bf16): the untransposed accumulator tile gives 32-byte row segments per store;
+                // staged like the residual epilogue, a wave's 16 x CW block leaves as whole 128-byte lines.  (The V
+                // columns keep the direct path: their output is V^T, 4 consecutive tokens per lane.)
+                constexpr int CW = WNT * 16, ROWH = CW + 8, LPR = CW / 8, RPI = 64 / LPR;   // bf16 per staged row (+16 B pad), lanes per row, rows per instruction
+                bf16_t *stg = smem + w * 16 * ROWH;
+                if (i == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done with the ring
+                    asm volatile("s_barrier" ::: "memory");
+                }
+                const int srow = 4 * lg + (li & 3), scol0 = 4 * (li >> 2);
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) {
+                    const f32x4 v = quad_transpose(acc[i][j], lane);
+                    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g.bias) b = *reinterpret_cast<const float4 *>(g.bias + n0 + wn * CW + j * 16 + scol0);
+                    uint2 o;
+                    o.x = pack2(v[0] + b.x, v[1] + b.y);
+                    o.y = pack2(v[2] + b.z, v[3] + b.w);
+                    *reinterpret_cast<uint2 *>(stg + srow * ROWH + j * 16 + scol0) = o;
+                }
+                const int c8 = lane % LPR, col = n0 + wn * CW + c8 * 8;
+#pragma unroll
+                for (int it = 0; it < 16 / RPI; ++it) {
+                    const int r = it * RPI + lane / LPR;
+                    const uint4 o = *reinterpret_cast<const uint4 *>(stg + r * ROWH + c8 * 8);
+                    if (trow + r < g.M) *reinterpret_cast<uint4 *>(g.C + (size_t)(trow + r) * g.ldc + col) = o;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < WNT; ++j) store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);

@@ -865,7 +865,7 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True):
     pr = model.profile_read()
     model.profile(False)
     tf = pr["gemm_flops"] / (pr["gemm_ms"] * 1e-3) / 1e12
-    roofline = {"kernel": "gemm_bf16_ring_kernel (QKV / O / gate-up+SwiGLU / down, 112 launches per step)",
+    roofline = {"kernel": "gemm_bf16_slab_kernel (QKV / O / gate-up+SwiGLU / down, 112 launches per step)",
                 "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(tf / 2500.0, 4), "traffic": None,
                 "flops_per_step": pr["gemm_flops"], "gemm_ms_per_step": round(pr["gemm_ms"], 3)}
