@@ -508,7 +508,7 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     relem = 2 if isinstance(flat_r, faiss.IndexScalarQuantizer) else 4
     store = "IEEE-half (SQfp16)" if relem == 2 else "raw f32"
     sharded = ShardedIndex(ref, id_affine=(nsh, 0, 1)) if (refine_own and nsh > 1) else None
-    cands = [(8, 64), (8, 80), (8, 100), (16, 100), (16, 160), (32, 200), (64, 256), (64, 400)]
+    cands = [(8, 64), (8, 72), (8, 80), (8, 100), (16, 100), (16, 160), (32, 200), (64, 256), (64, 400)]
     best = None
     for nprobe, kf in cands:
         base.nprobe, ref.k_factor = nprobe, kf
