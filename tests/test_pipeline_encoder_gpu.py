@@ -216,7 +216,9 @@ def test_gemm_tile_configs_vs_torch(st, tile, monkeypatch):
     import torch
     monkeypatch.setenv("MI_GEMM_TILE", tile)
     g = torch.Generator(device="cuda").manual_seed(3)
-    for M, N, K in ((1024, 512, 1536), (40, 1536, 256), (777, 260, 128)):
+    # (777, 260, 128): N % 8 != 0 sends the slab configurations to the ring kernel; (300, 264, 64) and (513, 520, 192)
+    # are ragged in M and N on the slab kernel itself, with 2 and 6 K steps (shorter than its pipeline)
+    for M, N, K in ((1024, 512, 1536), (40, 1536, 256), (777, 260, 128), (300, 264, 64), (513, 520, 192)):
         A = torch.randn((M, K), generator=g, device="cuda").bfloat16()
         W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).bfloat16()
         A[:, 0] += 3.0
