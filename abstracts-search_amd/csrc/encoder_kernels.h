@@ -193,6 +193,8 @@ struct GemmArgs {
     // for 1/tail_split of a tile time instead of a few CUs for a full one
     int tail_first, tail_split;
     unsigned long long *ts;   // null, or [workgroups][8] s_memtime stamps of the first tile (MI_GEMM_TS=1 profile launch)
+    float *gmax;       // EPI_F32H on the 8-wave slab kernel: null, or [M][ld_gmax] maxima of every 64-column group of a
+    int ld_gmax;       // score row (+inf if the group holds a non-finite score) -- what select_refine_kernel's cut needs
 };
 
 // W [N][ldw] (N % 16 == 0, K % 32 == 0) -> fragment-major Wt: one 64-thread workgroup per
@@ -1020,6 +1022,17 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                         const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + r * ROWF + c4 * 4);
                         if (trow + r < g.M && col < g.N)
                             *reinterpret_cast<float4 *>(g.X + (size_t)(trow + r) * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                        if constexpr (CW == 64) {
+                            // the staged row of this wave is one 64-column group: its maximum rides along (16 lanes per row)
+                            if (g.gmax) {
+                                const bool okc = col < g.N;
+                                const bool fin = fabsf(v[0]) <= 3.0e38f && fabsf(v[1]) <= 3.0e38f && fabsf(v[2]) <= 3.0e38f && fabsf(v[3]) <= 3.0e38f;
+                                float m = !okc ? -__builtin_inff() : !fin ? __builtin_inff() : fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                                m = row16_max(m);
+                                const int grp = (n0 + wn * CW) >> 6;
+                                if (c4 == 0 && trow + r < g.M && grp < g.ld_gmax) g.gmax[(size_t)(trow + r) * g.ld_gmax + grp] = m;
+                            }
+                        }
                     }
                 } else {
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -145,7 +145,8 @@ void launch_ring_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int
 }
 
 // the encoder's slab kernel (256 x 256 tiles, hand-ordered K loop, staged whole-line f32 stores), f16 instantiation
-void launch_slab_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int K, float *S, int64_t ldS, hipStream_t st) {
+void launch_slab_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int K, float *S, int64_t ldS, hipStream_t st,
+                     float *gmax = nullptr, int ld_gmax = 0) {
     mienc::GemmArgs g{};
     g.A = reinterpret_cast<const mienc::bf16_t *>(A);
     g.W = reinterpret_cast<const mienc::bf16_t *>(B);
@@ -154,29 +155,36 @@ void launch_slab_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int
     g.tiles_m = (g.M + 255) / 256;
     g.tiles_n = (g.N + 255) / 256;
     g.ksplit = 1; g.tail_first = 0; g.tail_split = 1;
+    g.gmax = gmax; g.ld_gmax = ld_gmax;
     const int per = (g.tiles_m * g.tiles_n + 7) / 8;
     hipLaunchKernelGGL((mienc::gemm_bf16_slab_kernel<mienc::EPI_F32H, 4>), dim3(8u * per), dim3(512), 0, st, g);
     MI_HIP(hipGetLastError());
 }
 
-void launch_gemm_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int K, float *S, int64_t ldS,
-                     hipStream_t st) {
+// gmax (optional, [na][nb / 64]): filled with the 64-column group maxima when the slab kernel runs; returns whether it was
+bool launch_gemm_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int K, float *S, int64_t ldS,
+                     hipStream_t st, float *gmax = nullptr) {
     MI_REQUIRE(K % 64 == 0 && ldS % 4 == 0, "f16 gemm: K % 64 and ldS % 4");
     // the encoder's ring-pipelined kernel, f16 instantiation (MI_F16_GEMM=simple: the two-stage
     // 128 x 128 kernel of ivfpq_kernels.h, for A/B runs)
     const char *e = std::getenv("MI_F16_GEMM");
     if (!(e && std::string(e) == "simple") && ldS < ((int64_t)1 << 31)) {
         const int64_t tiles_big = ((na + 255) / 256) * ((nb + 255) / 256);
-        if (tiles_big >= 512 && !(e && std::string(e) == "ring")) launch_slab_f16(A, na, B, nb, K, S, ldS, st);   // 256 x 256, 8 waves
-        else if (tiles_big >= 512) launch_ring_f16<8, 4, 2, 4, 4>(A, na, B, nb, K, S, ldS, st);   // MI_F16_GEMM=ring: the older kernel (A/B runs)
+        if (tiles_big >= 512 && !(e && std::string(e) == "ring")) {                               // 256 x 256, 8 waves
+            const bool with_gmax = gmax && nb % 64 == 0;
+            launch_slab_f16(A, na, B, nb, K, S, ldS, st, with_gmax ? gmax : nullptr, (int)(nb / 64));
+            return with_gmax;
+        }
+        if (tiles_big >= 512) launch_ring_f16<8, 4, 2, 4, 4>(A, na, B, nb, K, S, ldS, st);   // MI_F16_GEMM=ring: the older kernel (A/B runs)
         else launch_ring_f16<4, 4, 2, 2, 4>(A, na, B, nb, K, S, ldS, st);                    // 128 x 128, 4 waves
-        return;
+        return false;
     }
     const int tiles_m = (int)((na + 127) / 128), tiles_n = (int)((nb + 127) / 128);
     const int per = (tiles_m * tiles_n + 7) / 8;
     hipLaunchKernelGGL(ip_gemm_f16_kernel, dim3((unsigned)(per * 8)), dim3(256), 0, st, A, (int)na, B, (int)nb, K, S,
                        ldS, tiles_m, tiles_n);
     MI_HIP(hipGetLastError());
+    return false;
 }
 
 // ---- two-stage coarse quantiser (select_refine_kernel): shared by search, add and k-means ----
@@ -216,10 +224,15 @@ void launch_two_stage(const float *q, int64_t nq, const float *c32, const f16_t 
                       float cmax, float cscale, float *scores, DevBuf &q16buf, DevBuf &qscalebuf, DevBuf &statbuf,
                       int32_t *out_i32, float *out_s, ProbeTables pt, hipStream_t st, int idx_off = 0) {
     f16_t *q16 = static_cast<f16_t *>(q16buf.reserve((size_t)nq * d * 2));
-    float *qscale = static_cast<float *>(qscalebuf.reserve((size_t)nq * 4));
+    // behind the per-row scales: the 64-column group maxima of the approximate scores (MI_REFINE_GMAX=0: without)
+    const bool want_gmax = nc % 64 == 0 && nc / 64 <= 1024 && !(std::getenv("MI_REFINE_GMAX") && std::atoi(std::getenv("MI_REFINE_GMAX")) == 0);
+    const size_t qs_bytes = (((size_t)nq * 4 + 255) / 256) * 256;
+    float *qscale = static_cast<float *>(qscalebuf.reserve(qs_bytes + (want_gmax ? (size_t)nq * (nc / 64) * 4 : 0)));
+    float *gmax = want_gmax ? reinterpret_cast<float *>(reinterpret_cast<char *>(qscale) + qs_bytes) : nullptr;
     launch_to_f16_rows(q, nq, d, q16, qscale, 0.f, st);
-    launch_gemm_f16(q16, nq, c16, nc, d, scores, nc, st);
+    const bool have_gmax = launch_gemm_f16(q16, nq, c16, nc, d, scores, nc, st, gmax);
     RefineArgs ra{};
+    ra.gmax = have_gmax ? gmax : nullptr; ra.ngroups = (int)(nc / 64);
     ra.q = q; ra.cent = c32; ra.Sa = scores; ra.ldS = nc;
     ra.n = (int)nc; ra.d = d; ra.K = K;
     // |approx - exact| <= eps_rel |q| |c|  (derivation: ivfpq_kernels.h); the 1 % covers every

@@ -1323,6 +1323,9 @@ struct RefineArgs {
     unsigned *stats;      // null, or [2]: total candidates, rows that fell back
     int debug;            // timing experiments: 1 = no exact chain
     int idx_off;          // added to every index written (a slice of a larger centroid table: mi_index_coarse_slice)
+    const float *gmax;    // null, or [rows][ngroups]: maxima of the approximate row over 64-column groups, written by the
+    int ngroups;          // f16 GEMM's epilogue (+inf marks a group with a non-finite score): the row itself is then read
+                          // only where a group can hold a candidate (268 MB of scores at 1024 x 65536 otherwise)
 };
 
 __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
@@ -1332,6 +1335,8 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
     __shared__ float wred[4];
     __shared__ int wtot[4];
     __shared__ int c_cnt;
+    __shared__ int g_cnt;
+    __shared__ unsigned short glist[1024];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = uniform_i(tid >> 6);
     const int64_t row = blockIdx.x;
@@ -1348,7 +1353,7 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor(nrm, off);
     if (lane == 0) wred[w] = nrm;
-    if (tid == 0) c_cnt = 0;
+    if (tid == 0) { c_cnt = 0; g_cnt = 0; }
     __syncthreads();
     const float qn = sqrtf(wred[0] + wred[1] + wred[2] + wred[3]) * 1.001f;   // an upper bound of |q| (f32 sum: d 2^-25 relative)
     float margin = 2.f * a.eps_rel * qn * a.cmax;
@@ -1405,8 +1410,22 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
         unsigned key[VPT];
         unsigned gm[VPT];
         int nonfinite = 0;
+        // group maxima from the GEMM epilogue: enough groups that the K-th largest of them is a useful cut
+        const bool ext = a.gmax != nullptr && !exact_row && K <= 256 && a.ngroups <= 1024 && a.ngroups >= 4 * K && n == a.ngroups * 64;
+        unsigned gq[4] = {0u, 0u, 0u, 0u};
+        if (ext) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int gi = g * 256 + tid;
+                const float v = a.gmax[row * a.ngroups + min(gi, a.ngroups - 1)] * inv;
+                const bool fin = fabsf(v) <= 3.0e38f;
+                nonfinite |= (gi < a.ngroups && !fin);
+                gq[g] = (gi < a.ngroups && fin) ? f2o(v) : 0u;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < VPT; ++j) gm[j] = 0u;
+        if (!ext)
         for (int base = 0; base < n; base += TILE) {
 #pragma unroll
             for (int j = 0; j < VPT; ++j) {
@@ -1429,7 +1448,7 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
             unsigned *gk = reinterpret_cast<unsigned *>(skey);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                gk[g * 256 + tid] = max(max(gm[g], gm[g + 4]), max(gm[g + 8], gm[g + 12]));
+                gk[g * 256 + tid] = ext ? gq[g] : max(max(gm[g], gm[g + 4]), max(gm[g + 8], gm[g + 12]));
             __syncthreads();
             unsigned kk[16];
 #pragma unroll
@@ -1468,7 +1487,24 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
         }
         // cut in the score domain; T0 == 0: fewer than K finite entries, keep all
         const float cut = T0 ? o2f(T0) - (exact_row ? 0.f : margin) : -__builtin_inff();
-        if ((!bad || exact_row) && n > TILE) {
+        if (ext) {
+            if (!bad) {
+                // the groups that can hold a candidate (a few dozen of the 1024), then one wave per group: 256-byte reads
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (gq[g] != 0u && o2f(gq[g]) >= cut) glist[atomicAdd(&g_cnt, 1)] = (unsigned short)(g * 256 + tid);
+                __syncthreads();
+                const int ng = g_cnt;
+                for (int i = w; i < ng; i += 4) {
+                    const int c = (int)glist[i] * 64 + lane;
+                    const float v = r[c] * inv;
+                    if (v >= cut) {
+                        const int pos = atomicAdd(&c_cnt, 1);
+                        if (pos < SELB_CAP) skey[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)c;
+                    }
+                }
+            }
+        } else if ((!bad || exact_row) && n > TILE) {
             // long rows: only the thread groups whose maximum reaches the cut hold candidates
             // (a few dozen of the 4096), so the second pass touches a few cache lines instead
             // of re-reading the row

@@ -324,6 +324,27 @@ def test_two_stage_coarse_is_bit_identical(faiss, oracle, monkeypatch):
         monkeypatch.setenv("MI_TWO_STAGE", "0")
         cI0, cD0, _ = idx.coarse_and_lut(q32, nprobe, want_lut=False)
         assert np.array_equal(cI0, cI1) and np.array_equal(bits(cD0), bits(cD1)), nprobe
+    # the same size with rows that overflow f16 (a centroid x 1e5, a query x 1e6), a NaN query and duplicated
+    # centroids: here the approximate GEMM is the slab kernel, whose epilogue hands the second stage the maxima
+    # of every 64-column group -- a group with a non-finite score must send its row to the exact fallback
+    cent33 = cent32.copy()
+    cent33[77] *= 1e5
+    cent33[20001, 5] = 7e4
+    cent33[1::2][:4000] = cent33[0::2][:4000]
+    q33 = q32.copy()
+    q33[5] *= 1e6
+    q33[9, 0] = np.nan
+    idx = make_index(faiss, cent33, cb)
+    for gm in ("1", "0"):
+        monkeypatch.setenv("MI_REFINE_GMAX", gm)
+        for nprobe in (1, 8, 64):
+            monkeypatch.setenv("MI_TWO_STAGE", "1")
+            cI1, cD1, _ = idx.coarse_and_lut(q33, nprobe, want_lut=False)
+            monkeypatch.setenv("MI_TWO_STAGE", "0")
+            cI0, cD0, _ = idx.coarse_and_lut(q33, nprobe, want_lut=False)
+            assert np.array_equal(cI0, cI1) and np.array_equal(bits(cD0), bits(cD1)), (gm, nprobe)
+            assert (cI1[9] == -1).all()
+    monkeypatch.delenv("MI_REFINE_GMAX")
 
 
 def test_lut_matches_oracle(faiss, oracle):
