@@ -524,17 +524,23 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
             break
     nprobe, kf, r = best
     kb = k * kf
-    D = torch.empty((batch, k), dtype=torch.float32, device=dev)
-    I = torch.empty((batch, k), dtype=torch.int64, device=dev)
-    cD = torch.empty((batch, kb), dtype=torch.float32, device=dev)
-    cI = torch.empty((batch, kb), dtype=torch.int64, device=dev)
+    # batches are independent: like the main line, the unsharded loop issues them round-robin on 2 streams (the library
+    # keeps a workspace set per stream) -- the HBM-bound re-rank of one batch overlaps the MFMA-bound coarse stage of the next
+    S2 = 1 if sharded is not None else max(1, int(os.environ.get("BENCH_REFINE_STREAMS", "0")) or (2 if args.streams is None else args.streams))
+    rstreams = [torch.cuda.Stream(device=dev) for _ in range(S2)] if S2 > 1 else [torch.cuda.current_stream(dev)]
+    rptr = [int(s_.cuda_stream) for s_ in rstreams]
+    D = [torch.empty((batch, k), dtype=torch.float32, device=dev) for _ in range(S2)]
+    I = [torch.empty((batch, k), dtype=torch.int64, device=dev) for _ in range(S2)]
+    cD = [torch.empty((batch, kb), dtype=torch.float32, device=dev) for _ in range(S2)]
+    cI = [torch.empty((batch, kb), dtype=torch.int64, device=dev) for _ in range(S2)]
     NBq = len(my_q)
 
     def step(b):
         if sharded is not None:
             sharded.search_replicated(my_q[b % NBq], k)
         else:
-            ref.search_into(my_q[b % NBq], k, D, I, cD, cI)
+            j = b % S2
+            ref.search_into(my_q[b % NBq], k, D[j], I[j], cD[j], cI[j], rptr[j])
 
     settle(step, args.settle_ms)
     dt, blocks, _ = clock.measure(step, steps, warmup)
@@ -553,7 +559,7 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
         recall_note = "against exact search over the same sub-shard"
     return {"index": "IVF%d,PQ64,%s" % (base.nlist, "Refine(SQfp16)" if relem == 2 else "RFlat"), "nprobe": nprobe, "k_factor_rf": kf, "recall_at_10": round(r, 4),
             "reached": bool(r >= 0.95), "qps": round(steps * batch / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
-            "timed_blocks": len(blocks), "scope": scope, "recall_note": recall_note}
+            "timed_blocks": len(blocks), "streams": S2, "scope": scope, "recall_note": recall_note}
 
 
 # ======================================================================
