@@ -938,8 +938,9 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
         step(a1, b1, a0, b0, P1{}, F_{}, u + 1, c);
         c = wrap(c + 2);
     }
-    // the inline-asm MFMAs are opaque to the hazard recogniser: results -> v_accvgpr_read needs wait states
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // the inline-asm MFMAs are opaque to the hazard recogniser: results -> v_accvgpr_read needs wait states; the last
+    // step's (unused) fragment reads are retired here too, so nothing of the asm stream is in flight past this point
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
     // PERSIST: request the next unit's first slabs before this unit's epilogue -- the workgroup relaunch, the
     // pipeline fill (the first slabs' trip from HBM / L2) and the drain of the epilogue's stores overlap

@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 # Steps are issued round-robin on several HIP streams; the runtime maps streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4, one of which torch's own stream takes), and
 # two streams sharing a queue serialise.  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2" if os.environ.get("BENCH_REHEARSAL") else "8")   # rehearsal: several processes share one GPU
 
 D_MODEL, PQ_M = 1024, 64
 CH = 1 << 20                      # corpus rows per generated chunk
