@@ -68,8 +68,12 @@ class ShardedIndex:
 
     # -- helpers -----------------------------------------------------------
     def _buf(self, name, nbytes, device):
+        # one buffer set per (CUDA) stream the search is issued on: batches issued on different streams overlap, and
+        # the next batch's local search must not write the send buffer the previous batch's all-gather is reading
         import torch
-        key = (name, int(nbytes), str(device))
+        dev = torch.device(device)
+        sid = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        key = (name, int(nbytes), str(device), int(sid))
         b = self._bufs.get(key)
         if b is None:
             b = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

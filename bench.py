@@ -387,7 +387,14 @@ def cfg4_workload(args, ctx):
         sharded = NativeShardedIndex(index, id_affine=(nsh, 0, 1))
     elif use_shards:
         sharded = ShardedIndex(index, shard_coarse=bool(args.shard_coarse), id_affine=(nsh, 0, 1))
-    S = 1 if sharded is not None else max(1, 2 if args.streams is None else args.streams)
+    # batches are independent: 2 streams, also on the sharded path (the exchange of one batch and the coarse stage of
+    # the next overlap the other's scan; ShardedIndex keeps a buffer set per stream, torch.distributed orders the
+    # collectives by issue order on every rank).  BENCH_SHARD_STREAMS=1 issues the sharded steps on one stream.
+    S = max(1, 2 if args.streams is None else args.streams)
+    if sharded is not None:
+        S = max(1, int(os.environ.get("BENCH_SHARD_STREAMS", "0")) or S)
+        if isinstance(sharded, ShardedIndex) is False:
+            S = 1                                                     # the native exchange binds one stream at a time
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
     sptr = [int(s_.cuda_stream) for s_ in streams]
     Ds = [torch.empty((batch, k), dtype=torch.float32, device=dev) for _ in range(S)]
@@ -398,6 +405,9 @@ def cfg4_workload(args, ctx):
         if sharded is None:
             j = b % S
             index.search_into(my_q[b % NB], k, Ds[j], Is[j], None, sptr[j])
+        elif S > 1:
+            with torch.cuda.stream(streams[b % S]):
+                sharded.search_replicated(my_q[b % NB], k)
         else:
             sharded.search_replicated(my_q[b % NB], k)
 

@@ -831,6 +831,20 @@ def test_sharded_index_with_refine_and_id_map_rccl_world1(faiss, oracle):
         D, I = sh.search(qd, k)
         Dr, Ir = sh.search_replicated(qd, k)
         torch.cuda.synchronize()
+        # batches issued round-robin on two streams (bench.py's sharded loop): one buffer set per stream, the
+        # collectives ordered by issue order -- every batch still gets its own answer
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        qs = [qd, qd.flip(0).contiguous(), (qd * 0.5).contiguous(), qd.roll(3, 0).contiguous()]
+        outs = []
+        for rep in range(3):
+            for b, qb in enumerate(qs):
+                with torch.cuda.stream(streams[b % 2]):
+                    outs.append((b, sh.search_replicated(qb, k)))
+        torch.cuda.synchronize()
+        want = [sh.search_replicated(qb, k) for qb in qs]
+        torch.cuda.synchronize()
+        for b, (Db, Ib) in outs:
+            assert torch.equal(Ib, want[b][1]) and torch.equal(Db, want[b][0]), b
     finally:
         dist.destroy_process_group()
     ln, codes = oracle.encode(x, cent, cb, True)
