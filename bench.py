@@ -536,7 +536,9 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     kb = k * kf
     # batches are independent: like the main line, the unsharded loop issues them round-robin on 2 streams (the library
     # keeps a workspace set per stream) -- the HBM-bound re-rank of one batch overlaps the MFMA-bound coarse stage of the next
-    S2 = 1 if sharded is not None else max(1, int(os.environ.get("BENCH_REFINE_STREAMS", "0")) or (2 if args.streams is None else args.streams))
+    S2 = max(1, int(os.environ.get("BENCH_REFINE_STREAMS", "0")) or (2 if args.streams is None else args.streams))
+    if sharded is not None:
+        S2 = max(1, int(os.environ.get("BENCH_SHARD_STREAMS", "0")) or S2)
     rstreams = [torch.cuda.Stream(device=dev) for _ in range(S2)] if S2 > 1 else [torch.cuda.current_stream(dev)]
     rptr = [int(s_.cuda_stream) for s_ in rstreams]
     D = [torch.empty((batch, k), dtype=torch.float32, device=dev) for _ in range(S2)]
@@ -546,7 +548,10 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     NBq = len(my_q)
 
     def step(b):
-        if sharded is not None:
+        if sharded is not None and S2 > 1:
+            with torch.cuda.stream(rstreams[b % S2]):
+                sharded.search_replicated(my_q[b % NBq], k)
+        elif sharded is not None:
             sharded.search_replicated(my_q[b % NBq], k)
         else:
             j = b % S2
