@@ -293,11 +293,35 @@ class SentenceTransformer:
             emb = emb[0]
         return emb
 
+    # Tokens one forward pass takes when the caller hands over more than one batch: 32 768 = 128 row tiles of
+    # 256, with which every GEMM of the stack fills whole rounds of the 256 CUs (N = 1536: 768 tiles = 3.0 rounds,
+    # 2048: 4.0, 17 920: 35.0).  `batch_size` (sentence-transformers' memory knob: 32 by default, `-b 32` in the
+    # reference's Makefile) then only bounds a pass from above when it is the smaller one in tokens; embeddings
+    # do not depend on which sequences share a pass (tests: batching invariance).  None: batch_size alone.
+    token_budget = 32768
+
+    def _passes(self, order, token_lists, batch_size):
+        """the sorted sequence indices cut into forward passes"""
+        if not self.token_budget:
+            return [order[b0:b0 + batch_size] for b0 in range(0, len(order), batch_size)]
+        passes, cur, tok = [], [], 0
+        for i in order:
+            t = (len(token_lists[i]) + 7) & ~7                    # a sequence starts at a multiple of 8 tokens
+            if cur and tok + t > self.token_budget:
+                passes.append(cur)
+                cur, tok = [], 0
+            cur.append(i)
+            tok += t
+        if cur:
+            passes.append(cur)
+        return passes
+
     def encode_tokens(self, token_lists, batch_size: int = 32, normalize_embeddings: bool = False,
                       as_tensor: bool = False):
         """list of token-id lists -> float32 [n, dim].  Like sentence-transformers,
         inputs are sorted by length (longest first) before batching and the
-        result is put back in input order; a batch is packed, not padded."""
+        result is put back in input order; a batch is packed, not padded, and sized by
+        `token_budget` (see above) rather than by a sequence count."""
         import torch
         n = len(token_lists)
         dim = self.get_sentence_embedding_dimension()
@@ -306,8 +330,7 @@ class SentenceTransformer:
         order = sorted(range(n), key=lambda i: -len(token_lists[i]))
         stream = c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         lib = _Lib.get()
-        for b0 in range(0, n, batch_size):
-            sel = order[b0:b0 + batch_size]
+        for sel in self._passes(order, token_lists, batch_size):
             lens = [len(token_lists[i]) for i in sel]
             cu = np.zeros(len(sel) + 1, np.int32)
             np.cumsum(lens, out=cu[1:])

@@ -99,7 +99,9 @@ def test_tiny_model_vs_golden(st, gold, causal):
     cos = (hs * ref).sum(1) / (np.linalg.norm(hs, axis=1) * np.linalg.norm(ref, axis=1))
     assert cos.min() > 1 - 1e-3, cos.min()
     assert np.abs(hs - ref).max() < 0.08 * np.abs(ref).max()
+    model.token_budget = None
     e = model.encode_tokens(toks, batch_size=3, normalize_embeddings=True)   # several batches, re-ordered by length
+    model.token_budget = 32768
     cos = (e * gold[f"embed_{tag}"]).sum(1)
     assert cos.min() > 1 - 1e-3, cos
     assert np.allclose(np.linalg.norm(e, axis=1), 1.0, atol=1e-4)
@@ -114,11 +116,20 @@ def test_batching_invariance(st, gold):
     W = E.synth_weights(E.TINY, 7)
     model = st.SentenceTransformer(config=E.TINY.to_dict(), weights=W)
     toks = _split(gold["ids"], gold["cu_seqlens"])
-    a = model.encode_tokens(toks, batch_size=32, normalize_embeddings=True)
+    a = model.encode_tokens(toks, batch_size=32, normalize_embeddings=True)     # one pass (token budget 32 768)
+    model.token_budget = None                                                   # passes cut by batch_size alone
     b = model.encode_tokens(toks, batch_size=1, normalize_embeddings=True)
     assert np.abs(a - b).max() < 2e-3
     c = model.encode_tokens(toks[::-1], batch_size=2, normalize_embeddings=True)[::-1]
     assert np.abs(a - c).max() < 2e-3
+    # passes cut by a token budget: a few sequences each, never an empty pass, every sequence exactly once
+    model.token_budget = 40
+    order = sorted(range(len(toks)), key=lambda i: -len(toks[i]))
+    passes = model._passes(order, toks, 32)
+    assert sorted(i for p in passes for i in p) == list(range(len(toks))) and len(passes) > 1 and all(passes)
+    assert all(sum((len(toks[i]) + 7) & ~7 for i in p) <= 40 or len(p) == 1 for p in passes)
+    e = model.encode_tokens(toks, batch_size=32, normalize_embeddings=True)
+    assert np.abs(a - e).max() < 2e-3
 
 
 def test_errors(st):
