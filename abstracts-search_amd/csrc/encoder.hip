@@ -518,8 +518,13 @@ void run_stack(mi_encoder *h, const Batch &b, hipStream_t st) {
         a.seq_start = b.seq_start; a.seq_len = b.seq_len; a.ldqk = h->qk_cols; a.ldvt = ldvt;
         a.n_heads = c.n_heads; a.n_kv = c.n_kv_heads; a.causal = c.causal;
         a.scale = 1.0f / std::sqrt((float)hd);
-        if (hd == 128) hipLaunchKernelGGL((attn_kernel<128>), dim3(b.nwork, c.n_heads), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attn_kernel<64>), dim3(b.nwork, c.n_heads), dim3(256), 0, st, a);
+        // two query heads of one K/V head per workgroup when the GQA group allows it (MI_ATTN_HPW=1: one head per workgroup)
+        static const bool hpw1 = std::getenv("MI_ATTN_HPW") && std::atoi(std::getenv("MI_ATTN_HPW")) == 1;
+        const bool pair = !hpw1 && c.n_heads % 2 == 0 && (c.n_heads / c.n_kv_heads) % 2 == 0;
+        if (hd == 128 && pair) hipLaunchKernelGGL((attn_kernel<128, 2>), dim3(b.nwork, c.n_heads / 2), dim3(512), 0, st, a);
+        else if (hd == 128) hipLaunchKernelGGL((attn_kernel<128, 1>), dim3(b.nwork, c.n_heads), dim3(256), 0, st, a);
+        else if (pair) hipLaunchKernelGGL((attn_kernel<64, 2>), dim3(b.nwork, c.n_heads / 2), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((attn_kernel<64, 1>), dim3(b.nwork, c.n_heads), dim3(256), 0, st, a);
         MI_HIP(hipGetLastError());
         GemmArgs o{};
         o.A = att; o.lda = h->q_cols; o.W = w.wo.get<bf16_t>(); o.ldw = h->q_cols; o.M = T; o.N = H; o.K = h->q_cols;

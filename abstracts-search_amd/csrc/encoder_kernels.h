@@ -1421,8 +1421,11 @@ struct AttnArgs {
     float scale;
 };
 
-template <int HD>
-__global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
+// HPW heads per workgroup (4 waves each) that share one K/V head (GQA): the chunk a workgroup stages serves all of
+// them.  A 64-key iteration is bound by the latency of its K/V pieces, not by its 32 MFMAs per wave, so two heads on
+// one staged chunk cost about what one did (stella: 12 query heads on 2 K/V heads; 80 KiB of LDS, two workgroups per CU).
+template <int HD, int HPW = 1>
+__global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
     constexpr int KC = 64;          // keys per chunk
     constexpr int NKK = HD / 32;    // MFMA k-steps over the head dimension
     constexpr int NDT = HD / 16;    // 16-wide output tiles over the head dimension
@@ -1431,14 +1434,17 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
     constexpr int STG = 2 * KC * HD;  // elements per stage: K tile + V^T tile
     // one LDS array: [2 stages][K: key x HD, slot ^= key&7 | V^T: d x 64 keys, slot ^= d&7]
     // followed by the per-wave P tiles [4][16][64] (slot ^= row&7)
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STG + 4 * 16 * KC];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STG + 4 * HPW * 16 * KC];
+    static_assert((HD / 32) % HPW == 0, "DMA pieces must divide over the waves");
 
-    const int item = blockIdx.x, h = blockIdx.y;
+    const int item = blockIdx.x;
     const int seq = a.work_seq[item], q0 = a.work_q0[item];
     const int s0 = a.seq_start[seq], L = a.seq_len[seq];
-    const int kvh = h / (a.n_heads / a.n_kv);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: head w / 4 of this workgroup, query rows 16 (w % 4) ..
+    const int wq = w & 3;
+    const int h = (int)blockIdx.y * HPW + (w >> 2);
+    const int kvh = ((int)blockIdx.y * HPW) / (a.n_heads / a.n_kv);   // the same for every head of the workgroup (host checks)
     const int li = lane & 15, lg = lane >> 4;
 
     // K and V^T chunks arrive by LDS-DMA (1 KiB per wave instruction), double
@@ -1446,16 +1452,16 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
     auto issue = [&](int stage, int kc) {
         bf16_t *Ks = smem + stage * STG, *Vs = Ks + KC * HD;
 #pragma unroll
-        for (int i = 0; i < HD / 32; ++i) {   // HD/8 K pieces over 4 waves
-            const int p = w * (HD / 32) + i;
+        for (int i = 0; i < HD / 32 / HPW; ++i) {   // HD/8 K pieces over the 4 HPW waves
+            const int p = w * (HD / 32 / HPW) + i;
             const int key = p * KRPP + lane / KSL, sl = lane % KSL;
             const int krow = min(kc + key, L - 1);
             dma16(a.QK + (size_t)(s0 + krow) * a.ldqk + (a.n_heads + kvh) * HD + ((sl ^ (key & 7)) * 8),
                   Ks + p * 512);
         }
 #pragma unroll
-        for (int i = 0; i < HD / 32; ++i) {   // HD/8 V^T pieces of 8 rows x 128 B
-            const int p = w * (HD / 32) + i;
+        for (int i = 0; i < HD / 32 / HPW; ++i) {   // HD/8 V^T pieces of 8 rows x 128 B
+            const int p = w * (HD / 32 / HPW) + i;
             const int d = p * 8 + (lane >> 3), sl = lane & 7;
             dma16(a.Vt + (size_t)(kvh * HD + d) * a.ldvt + s0 + kc + ((sl ^ (d & 7)) * 8), Vs + p * 512);
         }
@@ -1464,7 +1470,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
     // Q fragments of this wave's 16 rows (A operand: row li, 8 dims at 32*kk + 8*lg)
     bf16x8 qf[NKK];
     {
-        const int qrow = min(q0 + w * 16 + li, L - 1);
+        const int qrow = min(q0 + wq * 16 + li, L - 1);
         const bf16_t *qp = a.QK + (size_t)(s0 + qrow) * a.ldqk + h * HD + lg * 8;
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8 *>(qp + kk * 32);
@@ -1518,7 +1524,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
             const int kidx = kc + j * 16 + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qidx = q0 + w * 16 + lg * 4 + r;
+                const int qidx = q0 + wq * 16 + lg * 4 + r;
                 float v = s[j][r] * scale2;   // scores in log2 units: exp2 is the native v_exp_f32
                 if (need_mask && (kidx >= L || (a.causal && kidx > qidx))) v = -__builtin_huge_valf();
                 s[j][r] = v;
@@ -1579,7 +1585,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= (lrow[r] > 0.f ? 1.0f / lrow[r] : 0.f);
         v = quad_transpose(v, lane);
-        const int qidx = q0 + w * 16 + lg * 4 + (li & 3);
+        const int qidx = q0 + wq * 16 + lg * 4 + (li & 3);
         if (qidx < L) {
             uint2 pk;
             pk.x = pack2(v[0], v[1]);
