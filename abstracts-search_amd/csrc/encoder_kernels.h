@@ -1404,12 +1404,19 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------------
-// Varlen attention.  grid = (work items, n_heads); a work item is a 64-row
-// query block of one sequence; 4 waves x 16 query rows.  Per 64-key chunk:
-// K rows and V^T rows are staged in XOR-swizzled LDS, S = Q K^T (16 MFMA per
-// wave), online softmax in registers (row statistics reduced over the 16 lanes
-// of a DPP row), P goes through a per-wave LDS tile to become the A operand,
-// O += P V (16 MFMA per wave).
+// Varlen attention.  grid = (work items, n_heads / HPW); a work item is a 64-row query block of one
+// sequence; a head takes 4 waves x 16 query rows.  Everything is computed TRANSPOSED so that a lane owns
+// one query row: per 64-key chunk S^T = K Q^T (A operand = K rows, 16 MFMA per wave), the lane holds 16
+// scores of its query (row statistics: in-lane + two cross-lane steps over the 4 lanes that share the row),
+// online softmax in registers, and O^T += V^T P^T (A operand = V^T rows, B operand = P) -- 16 MFMA per wave.
+// Which key an MFMA row position of S^T stands for is free: tile j, position p <-> key
+// 32 (j/2) + 8 (p/4) + 4 (j%2) + p%4, so that the lane's values of tiles 2J, 2J+1 are the 8 consecutive keys
+// 32 J + 8 lg .. -- exactly the B fragment of the PV MFMA: P never leaves the registers (no LDS round trip,
+// no cross-lane transposes; the untransposed version spent 70 % of its issue slots on VALU work).
+// K rows sit in LDS with their 16-byte slots XORed by a key of row bits {0, 1, 3, 4} (HD = 64: {0, 1, 3}): the
+// 16 rows a ds_read_b128 lane group touches under that map fall on 16 distinct slots.
+// HPW heads per workgroup (4 waves each) share one K/V head (GQA): the chunk a workgroup stages serves all
+// of them (stella: 12 query heads on 2 K/V heads; 64 KiB of LDS, two workgroups per CU).
 // ---------------------------------------------------------------------
 struct AttnArgs {
     const bf16_t *QK;   // [T_pad][ldqk]: q heads then k heads (RoPE applied)
@@ -1421,9 +1428,6 @@ struct AttnArgs {
     float scale;
 };
 
-// HPW heads per workgroup (4 waves each) that share one K/V head (GQA): the chunk a workgroup stages serves all of
-// them.  A 64-key iteration is bound by the latency of its K/V pieces, not by its 32 MFMAs per wave, so two heads on
-// one staged chunk cost about what one did (stella: 12 query heads on 2 K/V heads; 80 KiB of LDS, two workgroups per CU).
 template <int HD, int HPW = 1>
 __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
     constexpr int KC = 64;          // keys per chunk
@@ -1432,10 +1436,10 @@ __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
     constexpr int KSL = HD / 8;     // 16-byte slots per K row
     constexpr int KRPP = 64 / KSL;  // K rows per 1-KiB DMA piece
     constexpr int STG = 2 * KC * HD;  // elements per stage: K tile + V^T tile
-    // one LDS array: [2 stages][K: key x HD, slot ^= key&7 | V^T: d x 64 keys, slot ^= d&7]
-    // followed by the per-wave P tiles [4][16][64] (slot ^= row&7)
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STG + 4 * HPW * 16 * KC];
+    // one LDS array: [2 stages][K: key x HD, slot ^= kswz(key) | V^T: d x 64 keys, slot ^= d&7]
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STG];
     static_assert((HD / 32) % HPW == 0, "DMA pieces must divide over the waves");
+    auto kswz = [](int key) { return (key & 3) | (((key >> 3) & (KSL / 4 - 1)) << 2); };
 
     const int item = blockIdx.x;
     const int seq = a.work_seq[item], q0 = a.work_q0[item];
@@ -1456,7 +1460,7 @@ __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
             const int p = w * (HD / 32 / HPW) + i;
             const int key = p * KRPP + lane / KSL, sl = lane % KSL;
             const int krow = min(kc + key, L - 1);
-            dma16(a.QK + (size_t)(s0 + krow) * a.ldqk + (a.n_heads + kvh) * HD + ((sl ^ (key & 7)) * 8),
+            dma16(a.QK + (size_t)(s0 + krow) * a.ldqk + (a.n_heads + kvh) * HD + ((sl ^ kswz(key)) * 8),
                   Ks + p * 512);
         }
 #pragma unroll
@@ -1467,10 +1471,11 @@ __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
         }
     };
 
-    // Q fragments of this wave's 16 rows (A operand: row li, 8 dims at 32*kk + 8*lg)
+    // Q fragments of this wave's 16 rows (B operand of S^T: query row li, 8 dims at 32*kk + 8*lg)
+    const int qidx = q0 + wq * 16 + li;             // the query this lane owns
     bf16x8 qf[NKK];
     {
-        const int qrow = min(q0 + wq * 16 + li, L - 1);
+        const int qrow = min(qidx, L - 1);
         const bf16_t *qp = a.QK + (size_t)(s0 + qrow) * a.ldqk + h * HD + lg * 8;
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8 *>(qp + kk * 32);
@@ -1481,18 +1486,16 @@ __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]));
     }
-    f32x4 o[NDT];
+    f32x4 o[NDT];                                   // O^T tiles: dims 16 n + 4 lg + r of query li
 #pragma unroll
     for (int n = 0; n < NDT; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrow[4], lrow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        mrow[r] = -__builtin_huge_valf();
-        lrow[r] = 0.f;
-    }
+    float mrow = -__builtin_huge_valf(), lrow = 0.f;   // running maximum (log2 units) and denominator of query li
     const int kend = a.causal ? min(L, q0 + 64) : L;
     const float scale2 = a.scale * 1.4426950408889634f;
-    bf16_t *pw = smem + 2 * STG + w * 16 * KC;
+    const int x16 = (lane ^ 16) << 2, x32 = (lane ^ 32) << 2;   // ds_bpermute addresses of the lanes that share the row
+    // LDS row of tile position li (tile j adds 32 (j/2) + 4 (j%2)), and the slot key of those rows
+    const int krow0 = 8 * (li >> 2) + (li & 3);
+    const int kkey = kswz(krow0);                   // 32 (j/2) and 4 (j%2) leave bits {0,1,3,4} of the row alone... (4 (j%2) sets bit 2 only)
 
     issue(0, 0);
     for (int kc = 0, c = 0; kc < kend; kc += KC, ++c) {
@@ -1501,96 +1504,82 @@ __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
         if (kc + KC < kend) issue((c + 1) & 1, kc + KC);
         const bf16_t *Ks = smem + (c & 1) * STG, *Vs = Ks + KC * HD;
 
-        // S = Q K^T for 4 tiles of 16 keys
+        // S^T = K Q^T for 4 tiles of 16 keys
         f32x4 s[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const bf16_t *kb = Ks + (j * 16 + li) * HD;
+            const bf16_t *kb = Ks + (32 * (j >> 1) + 4 * (j & 1) + krow0) * HD;
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kb + (((kk * 4 + lg) ^ (li & 7)) * 8));
-                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], kf, s[j], 0, 0, 0);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kb + (((kk * 4 + lg) ^ kkey) * 8));
+                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[j], 0, 0, 0);
             }
         }
-        // scale, mask, online softmax (lane holds rows lg*4+r, key column j*16+li)
-        float pmax[4];
+        // scale, mask, online softmax: the lane holds keys kc + 32 (j/2) + 8 lg + 4 (j%2) + r of query li
+        const bool need_mask = a.causal || kc + KC > L;   // wave-uniform: the last (partial) chunk, or causal
+        float pmax = -__builtin_huge_valf();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pmax[r] = -__builtin_huge_valf();
-        // masking only where it can bite: the last (partial) chunk of the sequence, or causal
-        const bool need_mask = a.causal || kc + KC > L;   // wave-uniform
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kidx = kc + j * 16 + li;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qidx = q0 + wq * 16 + lg * 4 + r;
                 float v = s[j][r] * scale2;   // scores in log2 units: exp2 is the native v_exp_f32
-                if (need_mask && (kidx >= L || (a.causal && kidx > qidx))) v = -__builtin_huge_valf();
+                if (need_mask) {
+                    const int kidx = kc + 32 * (j >> 1) + 8 * lg + 4 * (j & 1) + r;
+                    if (kidx >= L || (a.causal && kidx > qidx)) v = -__builtin_huge_valf();
+                }
                 s[j][r] = v;
-                pmax[r] = fmaxf(pmax[r], v);
+                pmax = fmaxf(pmax, v);
             }
-        }
-        float alpha[4];
+        pmax = fmaxf(pmax, __int_as_float(__builtin_amdgcn_ds_bpermute(x16, __float_as_int(pmax))));
+        pmax = fmaxf(pmax, __int_as_float(__builtin_amdgcn_ds_bpermute(x32, __float_as_int(pmax))));
+        const float mnew = fmaxf(mrow, pmax);
+        const float alpha = (mrow == -__builtin_huge_valf()) ? 0.f : __builtin_amdgcn_exp2f(mrow - mnew);
+        mrow = mnew;
+        float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float m = row16_max(pmax[r]);
-            const float mnew = fmaxf(mrow[r], m);
-            alpha[r] = (mrow[r] == -__builtin_huge_valf()) ? 0.f : __builtin_amdgcn_exp2f(mrow[r] - mnew);
-            mrow[r] = mnew;
-        }
-        float psum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = (mrow[r] == -__builtin_huge_valf()) ? 0.f : __builtin_amdgcn_exp2f(s[j][r] - mrow[r]);
-                psum[r] += p;
+                const float p = (mrow == -__builtin_huge_valf()) ? 0.f : __builtin_amdgcn_exp2f(s[j][r] - mrow);
+                psum += p;
                 s[j][r] = p;
             }
-            // P tile for the PV A operand: transposed across lane quads so that a lane
-            // writes 4 consecutive keys of one row (one 8-byte store instead of four
-            // 2-byte ones); element (row, key) at row*64 + ((key/8)^(row&7))*8 + key%8
-            const f32x4 pt = quad_transpose(s[j], lane);
-            const int row = lg * 4 + (li & 3), key = j * 16 + (li & ~3);
-            uint2 pk;
-            pk.x = pack2(pt[0], pt[1]);
-            pk.y = pack2(pt[2], pt[3]);
-            *reinterpret_cast<uint2 *>(pw + row * KC + (((key >> 3) ^ (row & 7)) << 3) + (key & 7)) = pk;
+        psum += __int_as_float(__builtin_amdgcn_ds_bpermute(x16, __float_as_int(psum)));
+        psum += __int_as_float(__builtin_amdgcn_ds_bpermute(x32, __float_as_int(psum)));
+        lrow = lrow * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {   // the running maxima settle after the first chunks
+#pragma unroll
+            for (int n = 0; n < NDT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[n][r] *= alpha;
         }
+        // O^T += V^T P^T  (A: V^T[d = 16n+li][keys 32 J + 8 lg ..], B: P[query li][the same keys] = tiles 2J, 2J+1 of this lane)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            lrow[r] = lrow[r] * alpha[r] + row16_sum(psum[r]);
-        }
-#pragma unroll
-        for (int n = 0; n < NDT; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[n][r] *= alpha[r];
-        // O += P V  (A: P[row li][keys 32*kk2 + 8*lg ..], B: V^T[d = 16n+li][same keys])
-#pragma unroll
-        for (int kk2 = 0; kk2 < 2; ++kk2) {
-            const bf16x8 pf = *reinterpret_cast<const bf16x8 *>(pw + li * KC + (((kk2 * 4 + lg) ^ (li & 7)) * 8));
+        for (int J = 0; J < 2; ++J) {
+            union { bf16x8 v; unsigned u[4]; } pf;
+            pf.u[0] = pack2(s[2 * J][0], s[2 * J][1]);
+            pf.u[1] = pack2(s[2 * J][2], s[2 * J][3]);
+            pf.u[2] = pack2(s[2 * J + 1][0], s[2 * J + 1][1]);
+            pf.u[3] = pack2(s[2 * J + 1][2], s[2 * J + 1][3]);
 #pragma unroll
             for (int n = 0; n < NDT; ++n) {
                 const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(
-                    Vs + (n * 16 + li) * KC + (((kk2 * 4 + lg) ^ (li & 7)) * 8));
-                o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[n], 0, 0, 0);
+                    Vs + (n * 16 + li) * KC + (((J * 4 + lg) ^ (li & 7)) * 8));
+                o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf.v, o[n], 0, 0, 0);
             }
         }
     }
-    // normalise and write rows < L: quad-transposed, 4 consecutive dims per lane
+    // normalise and write row qidx: 4 consecutive dims per lane and tile
+    if (qidx < L) {
+        const float inv = lrow > 0.f ? 1.0f / lrow : 0.f;
+        bf16_t *op = a.O + (size_t)(s0 + qidx) * (a.n_heads * HD) + h * HD + 4 * lg;
 #pragma unroll
-    for (int n = 0; n < NDT; ++n) {
-        f32x4 v = o[n];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= (lrow[r] > 0.f ? 1.0f / lrow[r] : 0.f);
-        v = quad_transpose(v, lane);
-        const int qidx = q0 + wq * 16 + lg * 4 + (li & 3);
-        if (qidx < L) {
+        for (int n = 0; n < NDT; ++n) {
             uint2 pk;
-            pk.x = pack2(v[0], v[1]);
-            pk.y = pack2(v[2], v[3]);
-            *reinterpret_cast<uint2 *>(a.O + (size_t)(s0 + qidx) * (a.n_heads * HD) + h * HD + n * 16 + (li & ~3)) = pk;
+            pk.x = pack2(o[n][0] * inv, o[n][1] * inv);
+            pk.y = pack2(o[n][2] * inv, o[n][3] * inv);
+            *reinterpret_cast<uint2 *>(op + n * 16) = pk;
         }
     }
 }
