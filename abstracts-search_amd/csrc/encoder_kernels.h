@@ -1692,6 +1692,35 @@ __global__ void __launch_bounds__(256) pool_kernel(PoolArgs a) {
     for (int c = j0 + tid; c < j1; c += 256) a.out[(size_t)seq * a.out_dim + c] = outv[c] * scale;
 }
 
+// Mean over the real tokens of every sequence of the (final-norm) bf16 rows xn [T_pad][H] -> bf16 [nseq][H]: the
+// pooling step when there are many sequences (grid: nseq x H / 512; a thread owns two columns and walks the tokens
+// with four independent accumulators per column, summed in a fixed order).
+__global__ void __launch_bounds__(256) meanpool_kernel(const bf16_t *__restrict__ xn, const int32_t *__restrict__ seq_start,
+                                                       const int32_t *__restrict__ seq_len, int H, bf16_t *__restrict__ out) {
+    const int seq = blockIdx.x, c = (blockIdx.y * 256 + threadIdx.x) * 2;
+    if (c >= H) return;
+    const int s0 = seq_start[seq], L = seq_len[seq];
+    const bf16_t *p = xn + (size_t)s0 * H + c;
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+    int t = 0;
+    for (; t + 4 <= L; t += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned v = *reinterpret_cast<const unsigned *>(p + (size_t)(t + u) * H);
+            a0[u] += __uint_as_float(v << 16);
+            a1[u] += __uint_as_float(v & 0xffff0000u);
+        }
+    }
+    for (; t < L; ++t) {
+        const unsigned v = *reinterpret_cast<const unsigned *>(p + (size_t)t * H);
+        a0[0] += __uint_as_float(v << 16);
+        a1[0] += __uint_as_float(v & 0xffff0000u);
+    }
+    const float inv = 1.0f / (float)max(L, 1);
+    *reinterpret_cast<unsigned *>(out + (size_t)seq * H + c) =
+        pack2(((a0[0] + a0[1]) + (a0[2] + a0[3])) * inv, ((a1[0] + a1[1]) + (a1[2] + a1[3])) * inv);
+}
+
 // L2 normalisation of the rows of out[nseq][n] (second step of a split pool_kernel)
 __global__ void __launch_bounds__(256) l2norm_rows_kernel(float *__restrict__ out, int n) {
     __shared__ float red[4];

@@ -280,3 +280,31 @@ def test_large_batch_slab_kernel_with_tail_split_vs_small_tiles(st, monkeypatch)
         cos = (outs["default"] * outs[name]).sum(1)
         assert cos.min() > 1 - 1e-3, (name, cos.min())
         assert np.abs(outs["default"] - outs[name]).max() < 1e-2, name
+
+
+def test_many_sequences_pool_through_the_gemm_path(st, monkeypatch):
+    """>= 64 sequences: final norm over all tokens + mean-pool kernel + Dense as one GEMM + row normalisation; the same
+    embeddings as the per-sequence pool kernel (MI_POOL_GEMM=0) and as the fp32 oracle, raw and normalised."""
+    import torch
+    from oracle import encoder_oracle as E
+    cfg = E.EncoderConfig(vocab_size=64, hidden=256, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=64,
+                          intermediate=384, dense_out=64, max_seq_len=128)
+    W = E.synth_weights(cfg, 21)
+    rng = np.random.default_rng(21)
+    lens = rng.integers(1, 60, 90)
+    toks = [rng.integers(0, 64, int(L)).tolist() for L in lens]
+    model = st.SentenceTransformer(config=cfg.to_dict(), weights=W)
+    outs = {}
+    for norm in (True, False):
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MI_POOL_GEMM", mode)
+            outs[(norm, mode)] = model.encode_tokens(toks, batch_size=90, normalize_embeddings=norm)
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    Wc = {k: v.float().cpu() if hasattr(v, "float") else v for k, v in W.items()}
+    with torch.no_grad():
+        ref = E.encode(cfg, Wc, np.concatenate(toks), cu, True).numpy()
+    for mode in ("1", "0"):
+        assert ((outs[(True, mode)] * ref).sum(1)).min() > 1 - 1e-3, mode
+    assert np.abs(outs[(True, "1")] - outs[(True, "0")]).max() < 2e-3
+    a, b = outs[(False, "1")], outs[(False, "0")]
+    assert np.abs(a - b).max() < 0.01 * np.abs(b).max() + 1e-3
