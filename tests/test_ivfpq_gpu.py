@@ -845,6 +845,20 @@ def test_sharded_index_with_refine_and_id_map_rccl_world1(faiss, oracle):
         torch.cuda.synchronize()
         for b, (Db, Ib) in outs:
             assert torch.equal(Ib, want[b][1]) and torch.equal(Db, want[b][0]), b
+        # the same with the coarse quantiser split by centroid range (two exchanges per batch: probe lists, then results),
+        # bench.py's layout from 4 ranks: on two streams, every batch equals the plain search of the base index
+        base = idx.base_index
+        base.nprobe = 6
+        shc = ShardedIndex(base, shard_coarse=True)
+        outs = []
+        for rep in range(3):
+            for b, qb in enumerate(qs):
+                with torch.cuda.stream(streams[b % 2]):
+                    outs.append((b, shc.search_replicated(qb, k)))
+        torch.cuda.synchronize()
+        for b, (Db, Ib) in outs:
+            D0, I0 = base.search(qs[b], k)
+            assert torch.equal(Ib, I0) and torch.equal(Db, D0), b
     finally:
         dist.destroy_process_group()
     ln, codes = oracle.encode(x, cent, cb, True)
