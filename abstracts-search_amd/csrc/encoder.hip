@@ -100,11 +100,22 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
         const int main_b = nb / ncu * ncu, rem = nb - main_b;
         const int nk = g.K / 32;
         if (main_b > 0 && rem > 0 && rem <= ncu * 5 / 8) {
-            const int sp = std::min({ncu / rem, nk / 8, 16});
-            if (sp >= 2) {
+            // split the tail only where it pays: a slice saves tile_time (1 - 1/sp) of the last round, and its partial
+            // tile goes through 65 536 f32 atomics -- the chip retires ~115 G of those per second (measured with a
+            // stream-K tail experiment: 22 M atomics per GEMM cost 0.2 ms), i.e. ~0.57 us per slice
+            const int sp_max = std::min({ncu / rem, nk / 8, 16});
+            const double tile_us = 0.77 * nk + 12.0;
+            int best = 1;
+            double best_gain = 10.0;                                   // a split must buy more than 10 us
+            for (int sp = 2; sp <= sp_max; ++sp) {
+                const double gain = tile_us * (1.0 - 1.0 / sp) - 0.57 * rem * sp - 6.0;
+                if (gain > best_gain) { best_gain = gain; best = sp; }
+            }
+            if (std::getenv("MI_TAIL_SPLIT_FORCE") && sp_max >= 2) best = sp_max;   // tests: the split whatever the model says
+            if (best >= 2) {
                 g.tail_first = main_b;
-                g.tail_split = sp;
-                nblocks = (unsigned)(main_b + rem * sp);
+                g.tail_split = best;
+                nblocks = (unsigned)(main_b + rem * best);
             }
         }
     }

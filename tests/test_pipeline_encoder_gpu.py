@@ -269,14 +269,16 @@ def test_large_batch_slab_kernel_with_tail_split_vs_small_tiles(st, monkeypatch)
     rng = np.random.default_rng(11)
     toks = [rng.integers(0, 64, 128).tolist() for _ in range(260)]
     outs = {}
-    for name, env in (("default", {}), ("mid", {"MI_GEMM_TILE": "mid"}), ("ring", {"MI_GEMM_RING": "1"})):
-        for k in ("MI_GEMM_TILE", "MI_GEMM_RING"):
+    for name, env in (("default", {"MI_TAIL_SPLIT_FORCE": "1"}), ("mid", {"MI_GEMM_TILE": "mid"}), ("ring", {"MI_GEMM_RING": "1"}),
+                      ("nosplit", {})):
+        for k in ("MI_GEMM_TILE", "MI_GEMM_RING", "MI_TAIL_SPLIT_FORCE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         model = st.SentenceTransformer(config=cfg.to_dict(), weights=W)
         outs[name] = model.encode_tokens(toks, batch_size=260, normalize_embeddings=True)
-    for name in ("mid", "ring"):
+    # (the cost model of the launcher would not split these short-K tails: MI_TAIL_SPLIT_FORCE exercises the path)
+    for name in ("mid", "ring", "nosplit"):
         cos = (outs["default"] * outs[name]).sum(1)
         assert cos.min() > 1 - 1e-3, (name, cos.min())
         assert np.abs(outs["default"] - outs[name]).max() < 1e-2, name
