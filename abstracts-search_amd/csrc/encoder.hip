@@ -3,11 +3,13 @@
 #include "../../include/mi_encoder.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -20,6 +22,9 @@ using namespace mienc;
 namespace {
 
 hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// launches that took the K-split tail (f32 atomics into the residual stream): tests assert the path ran
+std::atomic<int64_t> g_tail_split_launches{0};
 
 struct LayerW {
     DevBuf wqkv, bqkv, wo, wgu, wd, ln1, ln2;
@@ -51,6 +56,7 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
                 g.tail_first = main_b;
                 g.tail_split = sp;
                 nblocks = (unsigned)(main_b + rem * sp);
+                ++g_tail_split_launches;
             }
         }
     }
@@ -116,6 +122,7 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
                 g.tail_first = main_b;
                 g.tail_split = best;
                 nblocks = (unsigned)(main_b + rem * best);
+                ++g_tail_split_launches;
             }
         }
     }
@@ -318,9 +325,16 @@ struct mi_encoder {
     DevBuf embed, norm_w, dense_w, dense_b, rope_cos, rope_sin;
     std::vector<LayerW> layers;
     std::map<std::string, bool> loaded;
-    // workspaces
-    DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_ids, ws_pos, ws_meta, ws_out, ws_stage;
-    size_t vt_zeroed = 0, att_zeroed = 0;
+    // activations and staging buffers, one set per stream an encode is issued on: calls on different streams overlap on
+    // the GPU and concurrent host threads (one stream each) never share a buffer; threads that share a stream take turns
+    struct WS {
+        std::mutex mu;
+        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_ids, ws_pos, ws_meta, ws_out, ws_stage;
+        size_t vt_zeroed = 0, att_zeroed = 0;
+    };
+    std::vector<std::pair<void *, std::unique_ptr<WS>>> ws_sets;
+    std::mutex mu;           // guards ws_sets, the lazily built fragment-major weights and the profiling events
+    DevBuf ws_stage;         // load_tensor staging (exclusive calls)
     bool tiled_ok = false;   // fragment-major weight copies are current
     // profiling
     bool prof = false;
@@ -335,6 +349,25 @@ struct mi_encoder {
 };
 
 namespace {
+
+struct EncLease {
+    mi_encoder::WS &w;
+    std::unique_lock<std::mutex> lk;
+};
+EncLease lease_ws(mi_encoder *h, void *stream) {
+    mi_encoder::WS *w = nullptr;
+    {
+        std::lock_guard<std::mutex> hl(h->mu);
+        for (auto &kv : h->ws_sets)
+            if (kv.first == stream) w = kv.second.get();
+        if (!w) {
+            MI_REQUIRE(h->ws_sets.size() < 64, "too many distinct streams on one encoder handle (max 64)");
+            h->ws_sets.emplace_back(stream, std::make_unique<mi_encoder::WS>());
+            w = h->ws_sets.back().second.get();
+        }
+    }
+    return EncLease{*w, std::unique_lock<std::mutex>(w->mu)};
+}
 
 void register_params(mi_encoder *h) {
     auto &L = h->loaded;
@@ -380,7 +413,7 @@ struct Batch {
 
 // Build the padded-packed layout (every sequence starts at a multiple of 8
 // tokens, T_pad a multiple of 32) and upload ids / positions / work lists.
-Batch prepare_batch(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu, hipStream_t st) {
+Batch prepare_batch(mi_encoder *h, mi_encoder::WS &ws, int nseq, const int32_t *ids, const int32_t *cu, hipStream_t st) {
     MI_REQUIRE(nseq > 0, "encode: nseq must be positive");
     std::vector<int32_t> cu_h((size_t)nseq + 1);
     if (is_device_ptr(cu)) MI_HIP(hipMemcpy(cu_h.data(), cu, cu_h.size() * 4, hipMemcpyDeviceToHost));
@@ -419,10 +452,10 @@ Batch prepare_batch(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *
             pos[(size_t)start[i] + t] = t;
             tok_map[(size_t)cu_h[i] + t] = start[i] + t;
         }
-    int32_t *d_ids = h->ws_ids.as<int32_t>((size_t)b.T_pad);
-    int32_t *d_pos = h->ws_pos.as<int32_t>((size_t)b.T_pad);
+    int32_t *d_ids = ws.ws_ids.as<int32_t>((size_t)b.T_pad);
+    int32_t *d_pos = ws.ws_pos.as<int32_t>((size_t)b.T_pad);
     const size_t meta_n = (size_t)nseq * 2 + (size_t)b.nwork * 2 + (size_t)T_real;
-    int32_t *d_meta = h->ws_meta.as<int32_t>(meta_n);
+    int32_t *d_meta = ws.ws_meta.as<int32_t>(meta_n);
     std::vector<int32_t> meta;
     meta.reserve(meta_n);
     meta.insert(meta.end(), start.begin(), start.end());
@@ -453,43 +486,46 @@ void timed_gemm(mi_encoder *h, int epi, const GemmArgs &g, hipStream_t st) {
     MI_HIP(hipEventRecord(e0, st));
     launch_gemm(epi, g, st);
     MI_HIP(hipEventRecord(e1, st));
+    std::lock_guard<std::mutex> hl(h->mu);
     h->evs.emplace_back(e0, e1);
     h->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
 }
 
 // the decoder stack: leaves the residual stream (before the final norm) in ws_x
-void run_stack(mi_encoder *h, const Batch &b, hipStream_t st) {
+void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st) {
     const mi_encoder_cfg &c = h->cfg;
     for (auto &kv : h->loaded) MI_REQUIRE(kv.second, std::string("encoder parameter not loaded: ") + kv.first);
     const int H = c.hidden, I = c.intermediate, T = b.T_pad, hd = c.head_dim;
     const int ldvt = T + 64;
-    float *x = h->ws_x.as<float>((size_t)T * H);
-    bf16_t *xn = h->ws_xn.as<bf16_t>((size_t)T * H);
-    bf16_t *qk = h->ws_qk.as<bf16_t>((size_t)T * h->qk_cols);
+    float *x = ws.ws_x.as<float>((size_t)T * H);
+    bf16_t *xn = ws.ws_xn.as<bf16_t>((size_t)T * H);
+    bf16_t *qk = ws.ws_qk.as<bf16_t>((size_t)T * h->qk_cols);
     const size_t vt_bytes = (size_t)h->v_cols * ldvt * 2;
-    bf16_t *vt = static_cast<bf16_t *>(h->ws_vt.reserve(vt_bytes));
-    if (h->vt_zeroed != h->ws_vt.cap) {  // fresh allocation: the 64-token slack must hold finite values
-        MI_HIP(hipMemsetAsync(h->ws_vt.p, 0, h->ws_vt.cap, st));
-        h->vt_zeroed = h->ws_vt.cap;
+    bf16_t *vt = static_cast<bf16_t *>(ws.ws_vt.reserve(vt_bytes));
+    if (ws.vt_zeroed != ws.ws_vt.cap) {  // fresh allocation: the 64-token slack must hold finite values
+        MI_HIP(hipMemsetAsync(ws.ws_vt.p, 0, ws.ws_vt.cap, st));
+        ws.vt_zeroed = ws.ws_vt.cap;
     }
-    bf16_t *att = h->ws_att.as<bf16_t>((size_t)T * h->q_cols);
-    if (h->att_zeroed != h->ws_att.cap) {
+    bf16_t *att = ws.ws_att.as<bf16_t>((size_t)T * h->q_cols);
+    if (ws.att_zeroed != ws.ws_att.cap) {
         // The attention kernel writes the rows of real tokens only; the rows of padding tokens
         // (between packed sequences, up to T_pad) feed the output projection and from there the
         // padding rows of the residual stream, K and V^T -- which neighbouring real tokens do
         // multiply by their masked (exactly zero) probabilities: 0 x NaN = NaN.  Recycled device
         // memory is not zero, so a fresh buffer is cleared once; afterwards it only ever holds
         // finite values.
-        MI_HIP(hipMemsetAsync(h->ws_att.p, 0, h->ws_att.cap, st));
-        h->att_zeroed = h->ws_att.cap;
+        MI_HIP(hipMemsetAsync(ws.ws_att.p, 0, ws.ws_att.cap, st));
+        ws.att_zeroed = ws.ws_att.cap;
     }
-    bf16_t *hb = h->ws_h.as<bf16_t>((size_t)T * I);
+    bf16_t *hb = ws.ws_h.as<bf16_t>((size_t)T * I);
 
     // few tokens (a query, or a handful): the GEMMs stream the weights once and are bound by how
     // they read them -- use the fragment-major copies (a second copy of the layer weights, built
     // on first use: 16-row x 64-byte fragments of a row-major matrix are 16 DRAM pages per wave-load)
     const bool few = T <= 64 && H % 32 == 0 && I % 32 == 0 && h->q_cols % 32 == 0 &&
                      (h->qk_cols + h->v_cols) % 16 == 0 && (2 * I) % 16 == 0 && H % 16 == 0;
+    std::unique_lock<std::mutex> tiled_lk(h->mu, std::defer_lock);
+    if (few) tiled_lk.lock();                            // the copies are built once; other streams wait for them
     if (few && !h->tiled_ok) {
         auto tile = [&](const DevBuf &src, int N, int K, DevBuf &dstb) {
             bf16_t *d = dstb.as<bf16_t>((size_t)N * K);
@@ -503,9 +539,11 @@ void run_stack(mi_encoder *h, const Batch &b, hipStream_t st) {
             tile(w.wgu, 2 * I, H, w.wgu_t);
             tile(w.wd, H, I, w.wd_t);
         }
+        MI_HIP(hipStreamSynchronize(st));
         h->tiled_ok = true;
     }
-    hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, st, h->ws_ids.get<int32_t>(),
+    if (few) tiled_lk.unlock();
+    hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, st, ws.ws_ids.get<int32_t>(),
                        h->embed.get<bf16_t>(), H, T, x);
     MI_HIP(hipGetLastError());
     for (int l = 0; l < c.n_layers; ++l) {
@@ -521,7 +559,7 @@ void run_stack(mi_encoder *h, const Batch &b, hipStream_t st) {
             const int nh_qk = c.n_heads + c.n_kv_heads;
             const int64_t n = (int64_t)T * nh_qk * (hd / 16);
             hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, qk, h->qk_cols,
-                               nh_qk, hd, h->ws_pos.get<int32_t>(), h->rope_cos.get<float>(),
+                               nh_qk, hd, ws.ws_pos.get<int32_t>(), h->rope_cos.get<float>(),
                                h->rope_sin.get<float>(), T);
         }
         AttnArgs a{};
@@ -709,14 +747,16 @@ int mi_encoder_encode(mi_encoder *h, int nseq, const int32_t *ids, const int32_t
         MI_REQUIRE(h && ids && cu && out, "null argument");
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);
-        Batch b = prepare_batch(h, nseq, ids, cu, st);
-        run_stack(h, b, st);
+        EncLease lease = lease_ws(h, stream);
+        mi_encoder::WS &ws = lease.w;
+        Batch b = prepare_batch(h, ws, nseq, ids, cu, st);
+        run_stack(h, ws, b, st);
         const mi_encoder_cfg &c = h->cfg;
         const int od = c.dense_out ? c.dense_out : c.hidden;
         const bool od_dev = is_device_ptr(out);
-        float *o = od_dev ? out : h->ws_out.as<float>((size_t)nseq * od);
+        float *o = od_dev ? out : ws.ws_out.as<float>((size_t)nseq * od);
         PoolArgs p{};
-        p.x = h->ws_x.get<float>(); p.norm_w = h->norm_w.get<float>();
+        p.x = ws.ws_x.get<float>(); p.norm_w = h->norm_w.get<float>();
         p.dense_w = c.dense_out ? h->dense_w.get<bf16_t>() : nullptr;
         p.dense_b = c.dense_out ? h->dense_b.get<float>() : nullptr;
         p.seq_start = b.seq_start; p.seq_len = b.seq_len; p.out = o; p.H = c.hidden; p.out_dim = od;
@@ -730,11 +770,11 @@ int mi_encoder_encode(mi_encoder *h, int nseq, const int32_t *ids, const int32_t
         const bool pool_gemm_off = std::getenv("MI_POOL_GEMM") && std::atoi(std::getenv("MI_POOL_GEMM")) == 0;
         if (c.dense_out && nseq >= 64 && !pool_gemm_off && c.hidden % 64 == 0 && od % 4 == 0) {
             const int H = c.hidden, T = b.T_pad;
-            bf16_t *xn = h->ws_xn.as<bf16_t>((size_t)T * H);
-            hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, h->ws_x.get<float>(), h->norm_w.get<float>(), H, T,
+            bf16_t *xn = ws.ws_xn.as<bf16_t>((size_t)T * H);
+            hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, ws.ws_x.get<float>(), h->norm_w.get<float>(), H, T,
                                c.rms_eps, xn);
             MI_HIP(hipGetLastError());
-            bf16_t *pb = h->ws_stage.as<bf16_t>((size_t)nseq * H);
+            bf16_t *pb = ws.ws_stage.as<bf16_t>((size_t)nseq * H);
             hipLaunchKernelGGL(meanpool_kernel, dim3(nseq, (H + 511) / 512), dim3(256), 0, st, xn, b.seq_start, b.seq_len, H, pb);
             MI_HIP(hipGetLastError());
             MI_HIP(hipMemsetAsync(o, 0, (size_t)nseq * od * 4, st));
@@ -772,12 +812,14 @@ int mi_encoder_hidden(mi_encoder *h, int nseq, const int32_t *ids, const int32_t
         MI_REQUIRE(h && ids && cu && out, "null argument");
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);
-        Batch b = prepare_batch(h, nseq, ids, cu, st);
-        run_stack(h, b, st);
+        EncLease lease = lease_ws(h, stream);
+        mi_encoder::WS &ws = lease.w;
+        Batch b = prepare_batch(h, ws, nseq, ids, cu, st);
+        run_stack(h, ws, b, st);
         const int H = h->cfg.hidden;
         const bool od_dev = is_device_ptr(out);
-        float *o = od_dev ? out : h->ws_out.as<float>((size_t)b.T_real * H);
-        hipLaunchKernelGGL(final_norm_kernel, dim3((b.T_real + 3) / 4), dim3(256), 0, st, h->ws_x.get<float>(),
+        float *o = od_dev ? out : ws.ws_out.as<float>((size_t)b.T_real * H);
+        hipLaunchKernelGGL(final_norm_kernel, dim3((b.T_real + 3) / 4), dim3(256), 0, st, ws.ws_x.get<float>(),
                            h->norm_w.get<float>(), H, b.T_real, b.tok_map, h->cfg.rms_eps, o);
         MI_HIP(hipGetLastError());
         if (!od_dev) {
@@ -798,6 +840,7 @@ int mi_encoder_profile_read(mi_encoder *h, double *gemm_ms, double *gemm_flops) 
     return guard([&] {
         MI_REQUIRE(h, "null argument");
         DeviceGuard dg(h->device);
+        std::lock_guard<std::mutex> hl(h->mu);
         double tot = 0.0;
         for (auto &e : h->evs) {
             MI_HIP(hipEventSynchronize(e.second));
@@ -811,6 +854,14 @@ int mi_encoder_profile_read(mi_encoder *h, double *gemm_ms, double *gemm_flops) 
         if (gemm_ms) *gemm_ms = tot;
         if (gemm_flops) *gemm_flops = h->prof_flops;
         h->prof_flops = 0.0;
+    });
+}
+
+int mi_enc_debug_counter(const char *name, int64_t *value) {
+    return guard([&] {
+        MI_REQUIRE(name && value, "null argument");
+        if (std::string(name) == "tail_split_launches") *value = g_tail_split_launches.load();
+        else throw Error(std::string("unknown debug counter: ") + name);
     });
 }
 

@@ -1640,10 +1640,21 @@ __global__ void __launch_bounds__(256) pool_kernel(PoolArgs a) {
         if (lane == 0) inv[t] = rsqrtf(ss / (float)H + a.eps);
     }
     __syncthreads();
+    // the same rounding points and summation order as the many-sequence path (rmsnorm_kernel -> meanpool_kernel): the
+    // normalised hidden state of a token is a bf16 value, a column is summed with four accumulators by token mod 4, the
+    // pooled vector is rounded to bf16 (it is the Dense GEMM's A operand there) -- an embedding then depends on how many
+    // sequences share a pass only through the f32 summation order of the Dense dot products (~1e-7)
     for (int c = tid; c < H; c += 256) {
-        float acc = 0.f;
-        for (int t = 0; t < L; ++t) acc += a.x[(size_t)(s0 + t) * H + c] * inv[t];
-        pooled[c] = acc * a.norm_w[c] / (float)L;
+        const float g = a.norm_w[c];
+        const float *col = a.x + (size_t)s0 * H + c;
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        int t = 0;
+        for (; t + 4 <= L; t += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] += bf2f(f2bf(col[(size_t)(t + u) * H] * inv[t + u] * g));
+        }
+        for (; t < L; ++t) a4[0] += bf2f(f2bf(col[(size_t)t * H] * inv[t] * g));
+        pooled[c] = bf2f(f2bf(((a4[0] + a4[1]) + (a4[2] + a4[3])) * (1.0f / (float)max(L, 1))));
     }
     __syncthreads();
     const int parts = max(1, a.parts), part = blockIdx.y;

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -86,6 +87,28 @@ void launch_rerank_scores(const float *q, int nq, const TB *base, int64_t nb, in
         return;
     }
     launch_gemm_gather<TB>(q, nq, base, nb, d, idx, kc, S, ldS, st);
+}
+
+// the same over a QT_8bit store (rerank_sq8_kernel; rows that are not whole 128-byte pieces: one thread per candidate)
+void launch_rerank_sq8(const float *q, int nq, const uint8_t *base, int64_t nb, int d, const float *trained,
+                       const int64_t *idx, int kc, float *S, int64_t ldS, hipStream_t st) {
+    const int tiles = (kc + 63) / 64;
+    const char *e = std::getenv("MI_RERANK");
+    if (d % 128 == 0 && (int64_t)nq * tiles < ((int64_t)1 << 31) && !(e && std::string(e) == "simple")) {
+        int nst = 3;
+        if (e && std::atoi(e) > 0) nst = std::atoi(e);
+        const unsigned grid = (unsigned)((int64_t)nq * tiles);
+        if (nst == 2) hipLaunchKernelGGL((rerank_sq8_kernel<2>), dim3(grid), dim3(64), 0, st, q, base, nb, d, trained, idx, kc, S, ldS, tiles);
+        else if (nst == 4) hipLaunchKernelGGL((rerank_sq8_kernel<4>), dim3(grid), dim3(64), 0, st, q, base, nb, d, trained, idx, kc, S, ldS, tiles);
+        else if (nst == 6) hipLaunchKernelGGL((rerank_sq8_kernel<6>), dim3(grid), dim3(64), 0, st, q, base, nb, d, trained, idx, kc, S, ldS, tiles);
+        else hipLaunchKernelGGL((rerank_sq8_kernel<3>), dim3(grid), dim3(64), 0, st, q, base, nb, d, trained, idx, kc, S, ldS, tiles);
+        MI_HIP(hipGetLastError());
+        return;
+    }
+    const int64_t total = (int64_t)nq * kc;
+    hipLaunchKernelGGL(rerank_sq8_simple_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q, base, nb, d, trained,
+                       idx, kc, total, S, ldS);
+    MI_HIP(hipGetLastError());
 }
 
 // S[na][nb] = A . B^T (exact f32).  Tile shape by the number of A rows: small
@@ -442,6 +465,7 @@ const void *to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t 
 
 // per-stream search workspaces (see mi_index::ws_sets)
 struct SearchWS {
+    std::mutex mu;   // held by the one call that is enqueuing work through this set (two host threads on one stream take turns)
     DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters, all_s, all_id, q16, qscale, rstats, qaug, qn, cscan;
     size_t counters_zeroed = 0;  // bytes of `counters` known to be zero
     // most recent scan launch on this stream (mi_index_profile_scan replays it)
@@ -492,6 +516,10 @@ struct mi_index {
     // batches issued on different streams overlap on the GPU (a serving loop
     // round-robins 2-4 streams; each kernel of one batch leaves most CUs idle)
     std::vector<std::pair<void *, std::unique_ptr<SearchWS>>> ws_sets;
+    // Concurrent readers (mi_ivfpq.h "Threading"): `mu` guards the list of workspace sets and every piece of state a
+    // search builds lazily (the scan image after an add, the f16 centroid image, the all-scores row capacity); the
+    // arithmetic of a search only reads the index.
+    std::mutex mu;
     // add()/encode() workspaces
     DevBuf ws_scores, ws_x, ws_assign, ws_codes, ws_ids, ws_count, ws_x16, ws_xscale, ws_rstats;
 
@@ -500,26 +528,74 @@ struct mi_index {
 
 struct mi_flat {
     int d = 0, device = 0;
-    int elem = 4;          // bytes per stored component: 4 = f32 (IndexFlat), 2 = IEEE half (IndexScalarQuantizer QT_fp16)
+    int elem = 4;          // bytes per stored component: 4 = f32 (IndexFlat), 2 = IEEE half (IndexScalarQuantizer QT_fp16),
+                           // 1 = QT_8bit codes with per-dimension ranges in `sq_trained`
+    DevBuf sq_trained, sq_lohi;   // QT_8bit: vmin | vdiff (what the kernels read); min | max as trained so far
+    bool sq_ok = false;
     int metric = MI_METRIC_INNER_PRODUCT;
     int da = 0;            // stored row width: d, or d + 4 for METRIC_L2 ([x, -|x|^2/2, 0, 0, 0]: oracle flat_l2)
-    DevBuf ws_qaug, ws_qn;
     int64_t ntotal = 0;
     DevBuf base;
-    DevBuf ws_q, ws_scores, ws_D, ws_I, ws_cand, ws_bigmerge;
-    // score workspaces of mi_flat_rerank, one per stream it is called on (batches on
-    // different streams overlap)
-    std::vector<std::pair<void *, std::unique_ptr<DevBuf>>> ws_rerank;
+    DevBuf ws_q, ws_scores;   // add() / reconstruct_n() staging (exclusive calls)
+    // search / re-rank workspaces, one set per stream a call is issued on: batches on different streams overlap on the
+    // GPU, and concurrent host threads (one stream each) never share a buffer
+    struct WS {
+        std::mutex mu;
+        DevBuf q, cand, scores, D, I, qaug, qn, bigmerge, rerank;
+    };
+    std::vector<std::pair<void *, std::unique_ptr<WS>>> ws_sets;
+    std::mutex mu;            // guards ws_sets
 };
 
 namespace {
 
+constexpr size_t MAX_STREAMS = 64;   // distinct streams one handle keeps workspaces for
+
+// caller holds h->mu
 SearchWS &ws_for(mi_index *h, void *stream) {
     for (auto &kv : h->ws_sets)
         if (kv.first == stream) return *kv.second;
-    MI_REQUIRE(h->ws_sets.size() < 16, "too many distinct streams on one index handle (max 16)");
+    MI_REQUIRE(h->ws_sets.size() < MAX_STREAMS, "too many distinct streams on one index handle (max 64)");
     h->ws_sets.emplace_back(stream, std::make_unique<SearchWS>());
     return *h->ws_sets.back().second;
+}
+
+void sync_lists(mi_index *h);
+
+// The workspace set of `stream`, leased to the calling thread until the lease dies.  Threads on distinct streams run
+// concurrently; threads that share a stream take turns enqueuing (the GPU serialises their work anyway).  `sync`: also
+// bring the scan image up to date (the first search after an add builds it, once, under the handle lock).
+struct WsLease {
+    SearchWS &w;
+    std::unique_lock<std::mutex> lk;
+};
+WsLease lease_ws(mi_index *h, void *stream, bool sync) {
+    SearchWS *w;
+    {
+        std::lock_guard<std::mutex> hl(h->mu);
+        w = &ws_for(h, stream);
+        if (sync) sync_lists(h);
+    }
+    return WsLease{*w, std::unique_lock<std::mutex>(w->mu)};
+}
+
+struct FlatLease {
+    mi_flat::WS &w;
+    std::unique_lock<std::mutex> lk;
+};
+FlatLease lease_ws(mi_flat *h, void *stream) {
+    mi_flat::WS *w = nullptr;
+    {
+        std::lock_guard<std::mutex> hl(h->mu);
+        for (auto &kv : h->ws_sets)
+            if (kv.first == stream) w = kv.second.get();
+        if (!w) {
+            MI_REQUIRE(h->ws_sets.size() < MAX_STREAMS, "too many distinct streams on one flat index handle (max 64)");
+            h->ws_sets.emplace_back(stream, std::make_unique<mi_flat::WS>());
+            w = h->ws_sets.back().second.get();
+        }
+    }
+    return FlatLease{*w, std::unique_lock<std::mutex>(w->mu)};
 }
 
 void require_trained(mi_index *h) {
@@ -960,7 +1036,8 @@ int mi_index_get_list(mi_index *h, int list_no, uint8_t *codes, int64_t *ids) {
 int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_avg, int64_t *scan_bytes) {
     return guard([&] {
         MI_REQUIRE(h && reps >= 1, "bad argument");
-        SearchWS &w = ws_for(h, stream);
+        WsLease lease = lease_ws(h, stream, false);
+        SearchWS &w = lease.w;
         MI_REQUIRE(w.have_last_scan, "mi_index_profile_scan: no search has run on this stream yet");
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);
@@ -1101,9 +1178,13 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     // error margin of the cut (bit-identical result, see select_refine_kernel) instead of the
     // exact f32 GEMM over all of them.
     if (two_stage_wanted(nq, h->nlist, dc, nprobe)) {
-        if (!h->cent16_ok) {
-            prepare_cent16(cc, h->nlist, dc, h->cent16, h->cmax_dev, h->cmax, h->cscale, st);
-            h->cent16_ok = true;
+        {
+            std::lock_guard<std::mutex> hl(h->mu);       // (set_coarse builds it for the shapes that qualify; this is the fallback)
+            if (!h->cent16_ok) {
+                prepare_cent16(cc, h->nlist, dc, h->cent16, h->cmax_dev, h->cmax, h->cscale, st);
+                MI_HIP(hipStreamSynchronize(st));        // other streams may read it as soon as the flag is up
+                h->cent16_ok = true;
+            }
         }
         launch_two_stage(qc, nq, cc, static_cast<const f16_t *>(h->cent16.p), h->nlist, dc,
                          nprobe, h->cmax, h->cscale, scores, w.q16, w.qscale, w.rstats, cidx, cdis, pt, st);
@@ -1165,16 +1246,20 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         // then the k best of each row (select_pairs_kernel) -- instead of one scan per 64
         // results.  Row capacity = the groups of the nprobe longest lists; queries go in
         // sub-batches so that the rows stay under 2 GiB.
-        if (h->cap_nprobe != nprobe) {
-            std::vector<int64_t> g((size_t)h->nlist);
-            for (int l = 0; l < h->nlist; ++l) g[(size_t)l] = ((int64_t)h->h_len[(size_t)l] + 63) / 64;   // valid: sync_lists ran
-            std::nth_element(g.begin(), g.begin() + (nprobe - 1), g.end(), std::greater<int64_t>());
-            int64_t tot = 0;
-            for (int i = 0; i < nprobe; ++i) tot += g[(size_t)i];
-            h->cap_groups = std::max<int64_t>(tot, 1);
-            h->cap_nprobe = nprobe;
+        int64_t R;
+        {
+            std::lock_guard<std::mutex> hl(h->mu);
+            if (h->cap_nprobe != nprobe) {
+                std::vector<int64_t> g((size_t)h->nlist);
+                for (int l = 0; l < h->nlist; ++l) g[(size_t)l] = ((int64_t)h->h_len[(size_t)l] + 63) / 64;   // valid: sync_lists ran
+                std::nth_element(g.begin(), g.begin() + (nprobe - 1), g.end(), std::greater<int64_t>());
+                int64_t tot = 0;
+                for (int i = 0; i < nprobe; ++i) tot += g[(size_t)i];
+                h->cap_groups = std::max<int64_t>(tot, 1);
+                h->cap_nprobe = nprobe;
+            }
+            R = h->cap_groups * 64;
         }
-        int64_t R = h->cap_groups * 64;
         if (pre_I) {   // caller-assigned lists may repeat: nprobe times the longest list
             int64_t gmax = 1;
             for (int l = 0; l < h->nlist; ++l) gmax = std::max(gmax, ((int64_t)h->h_len[(size_t)l] + 63) / 64);
@@ -1268,9 +1353,9 @@ int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe, 
         if (nq == 0) return;
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);
-        SearchWS &w = ws_for(h, stream);
+        WsLease lease = lease_ws(h, stream, true);
+        SearchWS &w = lease.w;
         nprobe = std::min(nprobe, h->nlist);
-        sync_lists(h);
         const bool qd = is_device_ptr(q), Dd = is_device_ptr(D), Id = is_device_ptr(I);
         const int64_t chunk = query_chunk_size(h);
         for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
@@ -1295,7 +1380,8 @@ int mi_index_coarse_lut(mi_index *h, int64_t nq, const float *q, int nprobe, int
         require_trained(h);
         if (nq == 0) return;
         DeviceGuard dg(h->device);
-        SearchWS &w = ws_for(h, nullptr);
+        WsLease lease = lease_ws(h, nullptr, false);
+        SearchWS &w = lease.w;
         nprobe = std::min(nprobe, h->nlist);
         const int64_t chunk = query_chunk_size(h);
         const bool qd = is_device_ptr(q);
@@ -1324,7 +1410,8 @@ int mi_index_coarse_slice(mi_index *h, int64_t nq, const float *q, int nprobe, i
         if (nq == 0) return;
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);
-        SearchWS &w = ws_for(h, stream);
+        WsLease lease = lease_ws(h, stream, false);
+        SearchWS &w = lease.w;
         const int n = list_hi - list_lo;
         const int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(4096, ((int64_t)1 << 28) / n));
         for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
@@ -1362,8 +1449,8 @@ int mi_index_search_preassigned(mi_index *h, int64_t nq, const float *q, int k, 
                    "mi_index_search_preassigned: device pointers only");
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);
-        SearchWS &w = ws_for(h, stream);
-        sync_lists(h);
+        WsLease lease = lease_ws(h, stream, true);
+        SearchWS &w = lease.w;
         const int64_t chunk = query_chunk_size(h);
         for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
             const int64_t m = std::min(chunk, nq - c0);
@@ -1445,6 +1532,8 @@ struct Id128 { char b[128]; };
 
 RcclApi &rccl(const char *path) {
     static RcclApi api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     if (api.lib) return api;
     const char *cands[] = {path, std::getenv("MI_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *c : cands) {
@@ -1452,10 +1541,17 @@ RcclApi &rccl(const char *path) {
         api.lib = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
         if (api.lib) break;
     }
-    if (!api.lib) throw Error(std::string("cannot load RCCL (librccl.so): ") + (dlerror() ? dlerror() : "not found"));
+    if (!api.lib) {
+        const char *why = dlerror();                     // one call: dlerror() clears the message it returns
+        throw Error(std::string("cannot load RCCL (librccl.so): ") + (why ? why : "not found"));
+    }
     auto sym = [&](const char *n) {
         void *p = dlsym(api.lib, n);
-        if (!p) throw Error(std::string("RCCL symbol missing: ") + n);
+        if (!p) {
+            dlclose(api.lib);
+            api = RcclApi{};                             // a half-bound table must not look loaded to the next call
+            throw Error(std::string("RCCL symbol missing: ") + n);
+        }
         return p;
     };
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -1479,7 +1575,15 @@ struct mi_shards {
     int rank = 0, world = 1, device = 0;
     IdMap im;
     void *comm = nullptr;
-    DevBuf send, recv, cand_D, cand_I, big;
+    // exchange buffers, one set per stream a search is issued on (two batches in flight on two streams must not share
+    // a send buffer).  Collectives on one communicator must be issued in the same order on every rank, so ONE host
+    // thread drives a mi_shards handle; the set is still leased under a mutex.
+    struct Bufs {
+        std::mutex mu;
+        DevBuf send, recv, cand_D, cand_I, big;
+    };
+    std::vector<std::pair<void *, std::unique_ptr<Bufs>>> bufs;
+    std::mutex mu;
 };
 
 extern "C" {
@@ -1529,16 +1633,28 @@ int mi_shards_search(mi_shards *s, int64_t nq, const float *q, int k, int nprobe
         DeviceGuard dg(s->device);
         hipStream_t st = as_stream(stream);
         const size_t d_bytes = (((size_t)nq * k * 4 + 7) / 8) * 8, blk = d_bytes + (size_t)nq * k * 8;
-        char *send = static_cast<char *>(s->send.reserve(blk));
-        char *recv = static_cast<char *>(s->recv.reserve(blk * s->world));
+        mi_shards::Bufs *b = nullptr;
+        {
+            std::lock_guard<std::mutex> hl(s->mu);
+            for (auto &kv : s->bufs)
+                if (kv.first == stream) b = kv.second.get();
+            if (!b) {
+                MI_REQUIRE(s->bufs.size() < MAX_STREAMS, "too many distinct streams on one shards handle (max 64)");
+                s->bufs.emplace_back(stream, std::make_unique<mi_shards::Bufs>());
+                b = s->bufs.back().second.get();
+            }
+        }
+        std::lock_guard<std::mutex> bl(b->mu);
+        char *send = static_cast<char *>(b->send.reserve(blk));
+        char *recv = static_cast<char *>(b->recv.reserve(blk * s->world));
         float *Dl = reinterpret_cast<float *>(send);
         int64_t *Il = reinterpret_cast<int64_t *>(send + d_bytes);
         // this shard, all queries: straight into the two halves of the send buffer
         if (s->refine) {
             const int kb = k * s->k_factor;
             MI_REQUIRE(kb <= 4096, "k * k_factor must be <= 4096");
-            float *cD = s->cand_D.as<float>((size_t)nq * kb);
-            int64_t *cI = s->cand_I.as<int64_t>((size_t)nq * kb);
+            float *cD = b->cand_D.as<float>((size_t)nq * kb);
+            int64_t *cI = b->cand_I.as<int64_t>((size_t)nq * kb);
             if (mi_index_search(s->local, nq, q, kb, nprobe, cD, cI, stream)) throw Error(last_error());
             if (mi_flat_rerank(s->refine, nq, q, kb, cI, k, Dl, Il, stream)) throw Error(last_error());
         } else {
@@ -1548,7 +1664,7 @@ int mi_shards_search(mi_shards *s, int64_t nq, const float *q, int k, int nprobe
         RcclApi &r = rccl(nullptr);
         nccl_check(r, r.AllGather(send, recv, blk, /* ncclInt8 */ 0, s->comm, st), "ncclAllGather");
         launch_merge(reinterpret_cast<const float *>(recv), reinterpret_cast<const int64_t *>(recv + d_bytes), s->world,
-                     (int64_t)(blk / 4), k, nq, k, D, I, k, 0, nullptr, nullptr, st, (int64_t)(blk / 8), s->im, &s->big);
+                     (int64_t)(blk / 4), k, nq, k, D, I, k, 0, nullptr, nullptr, st, (int64_t)(blk / 8), s->im, &b->big);
     });
 }
 
@@ -1680,7 +1796,7 @@ int mi_index_save(mi_index *h, const char *fname, const char *ondisk_data) {
                 w.cc("full"); w.one<uint64_t>((uint64_t)nlist);
                 for (int l = 0; l < nlist; ++l) w.one<uint64_t>((uint64_t)h->h_len[(size_t)l]);
             } else {
-                w.cc("sprs"); w.one<uint64_t>((uint64_t)nz);
+                w.cc("sprs"); w.one<uint64_t>((uint64_t)2 * (uint64_t)nz);   // faiss WRITEVECTORs the flattened {list, size} pairs
                 for (int l = 0; l < nlist; ++l)
                     if (h->h_len[(size_t)l]) { w.one<uint64_t>((uint64_t)l); w.one<uint64_t>((uint64_t)h->h_len[(size_t)l]); }
             }
@@ -1764,7 +1880,8 @@ int mi_index_load(const char *fname, int device, mi_index **out) {
                     if (n != nlist) throw Error(name + ": " + std::to_string(n) + " list sizes for " + std::to_string(nlist) + " lists");
                     r.raw(sizes.data(), (size_t)n * 8);
                 } else if (kind == "sprs") {
-                    for (uint64_t i = 0; i < n; ++i) {
+                    if (n % 2 || n / 2 > nlist) throw Error(name + ": sparse list sizes are " + std::to_string(n) + " words (pairs expected)");
+                    for (uint64_t i = 0; i < n / 2; ++i) {
                         const uint64_t l = r.one<uint64_t>(), k = r.one<uint64_t>();
                         if (l >= nlist) throw Error(name + ": sparse list number out of range");
                         sizes[(size_t)l] = k;
@@ -1891,13 +2008,82 @@ int mi_flat_create(int d, int device, mi_flat **out) {
 }
 
 int mi_flat_create_ex(int d, int device, int storage, mi_flat **out) {
-    if (storage != MI_STORE_F32 && storage != MI_STORE_F16) {
-        last_error() = "mi_flat_create_ex: storage must be MI_STORE_F32 or MI_STORE_F16";
+    if (storage != MI_STORE_F32 && storage != MI_STORE_F16 && storage != MI_STORE_SQ8) {
+        last_error() = "mi_flat_create_ex: storage must be MI_STORE_F32, MI_STORE_F16 or MI_STORE_SQ8";
         return 1;
     }
     int rc = mi_flat_create(d, device, out);
-    if (rc == 0) (*out)->elem = storage == MI_STORE_F16 ? 2 : 4;   // (inner product only)
+    if (rc == 0) (*out)->elem = storage == MI_STORE_F16 ? 2 : storage == MI_STORE_SQ8 ? 1 : 4;   // (inner product only)
     return rc;
+}
+
+int mi_flat_sq_train(mi_flat *h, int64_t n, const float *x, int merge) {
+    return guard([&] {
+        MI_REQUIRE(h && x && n > 0, "bad argument");
+        MI_REQUIRE(h->elem == 1, "mi_flat_sq_train: not a QT_8bit store");
+        MI_REQUIRE(h->ntotal == 0, "mi_flat_sq_train: the store already holds vectors encoded with the current ranges");
+        DeviceGuard dg(h->device);
+        const int d = h->d;
+        float *lohi = h->sq_lohi.as<float>((size_t)2 * d);
+        const bool have = merge && h->sq_ok;
+        const int64_t chunk_rows = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)d * 4));
+        const bool xdev = is_device_ptr(x);
+        DevBuf part;
+        bool first = !have;
+        for (int64_t c0 = 0; c0 < n; c0 += chunk_rows) {
+            const int64_t m = std::min(chunk_rows, n - c0);
+            const float *xs = x + (size_t)c0 * d;
+            if (!xdev) {
+                float *stage = h->ws_q.as<float>((size_t)m * d);
+                MI_HIP(hipMemcpy(stage, xs, (size_t)m * d * 4, hipMemcpyHostToDevice));
+                xs = stage;
+            }
+            const int chunks = (int)std::min<int64_t>(1024, (m + 255) / 256);
+            const int64_t rpc = (m + chunks - 1) / chunks;
+            float *pp = part.as<float>((size_t)chunks * 2 * d);
+            hipLaunchKernelGGL(sq8_minmax_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)chunks), dim3(256), 0, nullptr, xs, m, d, rpc, pp);
+            hipLaunchKernelGGL(sq8_minmax_fold_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, nullptr, pp, chunks, d, lohi, first ? 0 : 1);
+            MI_HIP(hipGetLastError());
+            MI_HIP(hipStreamSynchronize(nullptr));   // the staging buffer and `part` are reused
+            first = false;
+        }
+        hipLaunchKernelGGL(sq8_ranges_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, nullptr, lohi, d,
+                           h->sq_trained.as<float>((size_t)2 * d));
+        MI_HIP(hipGetLastError());
+        MI_HIP(hipStreamSynchronize(nullptr));
+        h->sq_ok = true;
+    });
+}
+
+int mi_flat_sq_get_trained(mi_flat *h, float *trained) {
+    return guard([&] {
+        MI_REQUIRE(h && trained, "null argument");
+        MI_REQUIRE(h->elem == 1 && h->sq_ok, "mi_flat_sq_get_trained: not a trained QT_8bit store");
+        DeviceGuard dg(h->device);
+        MI_HIP(hipMemcpy(trained, h->sq_trained.p, (size_t)2 * h->d * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int mi_flat_sq_set_trained(mi_flat *h, const float *trained) {
+    return guard([&] {
+        MI_REQUIRE(h && trained, "null argument");
+        MI_REQUIRE(h->elem == 1, "mi_flat_sq_set_trained: not a QT_8bit store");
+        MI_REQUIRE(h->ntotal == 0, "mi_flat_sq_set_trained: the store already holds vectors encoded with the current ranges");
+        DeviceGuard dg(h->device);
+        const int d = h->d;
+        std::vector<float> t(trained, trained + 2 * (size_t)d), lohi(2 * (size_t)d);
+        for (int i = 0; i < d; ++i) { lohi[(size_t)i] = t[(size_t)i]; lohi[(size_t)d + i] = t[(size_t)i] + t[(size_t)d + i]; }
+        MI_HIP(hipMemcpy(h->sq_trained.reserve(t.size() * 4), t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        MI_HIP(hipMemcpy(h->sq_lohi.reserve(t.size() * 4), lohi.data(), t.size() * 4, hipMemcpyHostToDevice));
+        h->sq_ok = true;
+    });
+}
+
+int mi_flat_sq_is_trained(mi_flat *h, int *out) {
+    return guard([&] {
+        MI_REQUIRE(h && out, "null argument");
+        *out = (h->elem != 1 || h->sq_ok) ? 1 : 0;
+    });
 }
 
 int mi_flat_create_metric(int d, int metric, int device, mi_flat **out) {
@@ -1952,6 +2138,25 @@ int mi_flat_add(mi_flat *h, int64_t n, const float *x) {
             MI_HIP(hipStreamSynchronize(nullptr));
         } else if (h->elem == 4) {
             MI_HIP(hipMemcpy(dst, x, add_bytes, hipMemcpyDefault));
+        } else if (h->elem == 1) {
+            MI_REQUIRE(h->sq_ok, "add: the QT_8bit store is not trained (mi_flat_sq_train / mi_flat_sq_set_trained)");
+            const int64_t chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)h->d * 4));
+            const bool xdev = is_device_ptr(x);
+            for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+                const int64_t m = std::min(chunk, n - c0);
+                const float *xs = x + (size_t)c0 * h->d;
+                if (!xdev) {
+                    float *stage = h->ws_q.as<float>((size_t)m * h->d);
+                    MI_HIP(hipMemcpy(stage, xs, (size_t)m * h->d * 4, hipMemcpyHostToDevice));
+                    xs = stage;
+                }
+                const int64_t n4 = m * h->d / 4;
+                hipLaunchKernelGGL(sq8_encode_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, nullptr, xs, n4, h->d,
+                                   h->sq_trained.get<float>(), reinterpret_cast<uint8_t *>(dst + (size_t)c0 * row));
+                MI_HIP(hipGetLastError());
+                if (!xdev) MI_HIP(hipStreamSynchronize(nullptr));   // the staging buffer is reused
+            }
+            MI_HIP(hipStreamSynchronize(nullptr));
         } else {
             // QT_fp16: every component rounded to nearest-even half, no scaling (faiss ScalarQuantizer)
             const int64_t chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)h->d * 4));
@@ -1999,6 +2204,8 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
         const bool dev = is_device_ptr(q);
         MI_REQUIRE(is_device_ptr(cand_I) == dev && is_device_ptr(D) == dev && is_device_ptr(I) == dev,
                    "rerank: q, cand_I, D and I must be all host or all device pointers");
+        FlatLease lease = lease_ws(h, stream);
+        mi_flat::WS &w = lease.w;
         const float *qs = q;
         const int64_t *ci = cand_I;
         if (!dev) {
@@ -2006,36 +2213,29 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
             // the base index over the same vectors)
             for (int64_t i = 0; i < nq * kc; ++i)
                 MI_REQUIRE(cand_I[i] < h->ntotal, "rerank: candidate id out of range");
-            qs = static_cast<const float *>(to_device(q, (size_t)nq * h->d * 4, h->ws_q, st));
-            ci = static_cast<const int64_t *>(to_device(cand_I, (size_t)nq * kc * 8, h->ws_cand, st));
+            qs = static_cast<const float *>(to_device(q, (size_t)nq * h->d * 4, w.q, st));
+            ci = static_cast<const int64_t *>(to_device(cand_I, (size_t)nq * kc * 8, w.cand, st));
         }
-        DevBuf *wsb = nullptr;
-        for (auto &kv : h->ws_rerank)
-            if (kv.first == stream) wsb = kv.second.get();
-        if (!wsb) {
-            MI_REQUIRE(h->ws_rerank.size() < 16, "too many distinct streams on one flat index handle (max 16)");
-            h->ws_rerank.emplace_back(stream, std::make_unique<DevBuf>());
-            wsb = h->ws_rerank.back().second.get();
-        }
-        float *scores = wsb->as<float>((size_t)nq * kc);
-        float *Dc = dev ? D : h->ws_D.as<float>((size_t)nq * k);
-        int64_t *Ic = dev ? I : h->ws_I.as<int64_t>((size_t)nq * k);
+        float *scores = w.rerank.as<float>((size_t)nq * kc);
+        float *Dc = dev ? D : w.D.as<float>((size_t)nq * k);
+        int64_t *Ic = dev ? I : w.I.as<int64_t>((size_t)nq * k);
         const bool l2 = h->metric == MI_METRIC_L2;
         if (l2) {   // augmented queries; the candidates rank by S = <q, x> - |x|^2/2, reported as squared distances
-            float *qa = h->ws_qaug.as<float>((size_t)nq * h->da);
+            float *qa = w.qaug.as<float>((size_t)nq * h->da);
             launch_augment(qs, nq, h->d, h->da, 0, qa, st);
-            hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, qs, nq, h->d, h->ws_qn.as<float>((size_t)nq));
+            hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, qs, nq, h->d, w.qn.as<float>((size_t)nq));
             MI_HIP(hipGetLastError());
             qs = qa;
         }
         if (h->elem == 4) launch_rerank_scores<float>(qs, (int)nq, h->base.get<float>(), h->ntotal, h->da, ci, kc, scores, kc, st);
+        else if (h->elem == 1) launch_rerank_sq8(qs, (int)nq, h->base.get<uint8_t>(), h->ntotal, h->d, h->sq_trained.get<float>(), ci, kc, scores, kc, st);
         else launch_rerank_scores<f16_t>(qs, (int)nq, h->base.get<f16_t>(), h->ntotal, h->d, ci, kc, scores, kc, st);
         // the candidate list as kc/k "parts" of k entries: the k-way merge ranks them under
         // (score desc, id asc) and skips the negative ids
-        launch_merge(scores, ci, kc / k, k, kc, nq, k, Dc, Ic, k, 0, nullptr, nullptr, st, -1, IdMap{}, &h->ws_bigmerge);
+        launch_merge(scores, ci, kc / k, k, kc, nq, k, Dc, Ic, k, 0, nullptr, nullptr, st, -1, IdMap{}, &w.bigmerge);
         if (l2) {
             hipLaunchKernelGGL(l2_flat_finish_kernel, dim3((unsigned)(((size_t)nq * k + 255) / 256)), dim3(256), 0, st, Dc, Ic,
-                               h->ws_qn.get<float>(), nq, k);
+                               w.qn.get<float>(), nq, k);
             MI_HIP(hipGetLastError());
         }
         if (!dev) {
@@ -2068,6 +2268,14 @@ int mi_flat_reconstruct_n(mi_flat *h, int64_t i0, int64_t n, float *out) {
         }
         const bool odev = is_device_ptr(out);
         float *dst = odev ? out : h->ws_scores.as<float>((size_t)n * h->d);
+        if (h->elem == 1) {
+            hipLaunchKernelGGL(sq8_decode_kernel, dim3((unsigned)(((size_t)n * h->d + 255) / 256)), dim3(256), 0, nullptr,
+                               h->base.get<uint8_t>() + (size_t)i0 * h->d, n, h->d, h->sq_trained.get<float>(), dst);
+            MI_HIP(hipGetLastError());
+            if (!odev) MI_HIP(hipMemcpy(out, dst, (size_t)n * h->d * 4, hipMemcpyDeviceToHost));
+            else MI_HIP(hipStreamSynchronize(nullptr));
+            return;
+        }
         hipLaunchKernelGGL(f16_to_f32_kernel, dim3((unsigned)(((size_t)n * h->d + 255) / 256)), dim3(256), 0, nullptr,
                            h->base.get<f16_t>() + (size_t)i0 * h->d, (int64_t)n * h->d, dst);
         MI_HIP(hipGetLastError());
@@ -2109,17 +2317,19 @@ int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int6
             return;
         }
         int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(4096, ((int64_t)1 << 28) / h->ntotal));
+        FlatLease lease = lease_ws(h, stream);
+        mi_flat::WS &w = lease.w;
         for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
             const int64_t m = std::min(chunk, nq - c0);
             const float *qs = q + (size_t)c0 * h->d;
-            if (!qd) qs = static_cast<const float *>(to_device(qs, (size_t)m * h->d * 4, h->ws_q, st));
-            float *scores = h->ws_scores.as<float>((size_t)m * h->ntotal);
-            float *Dc = Dd ? D + (size_t)c0 * k : h->ws_D.as<float>((size_t)m * k);
-            int64_t *Ic = Id ? I + (size_t)c0 * k : h->ws_I.as<int64_t>((size_t)m * k);
+            if (!qd) qs = static_cast<const float *>(to_device(qs, (size_t)m * h->d * 4, w.q, st));
+            float *scores = w.scores.as<float>((size_t)m * h->ntotal);
+            float *Dc = Dd ? D + (size_t)c0 * k : w.D.as<float>((size_t)m * k);
+            int64_t *Ic = Id ? I + (size_t)c0 * k : w.I.as<int64_t>((size_t)m * k);
             if (l2) {
-                float *qa = h->ws_qaug.as<float>((size_t)m * h->da);
+                float *qa = w.qaug.as<float>((size_t)m * h->da);
                 launch_augment(qs, m, h->d, h->da, 0, qa, st);
-                hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, qs, m, h->d, h->ws_qn.as<float>((size_t)m));
+                hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, qs, m, h->d, w.qn.as<float>((size_t)m));
                 MI_HIP(hipGetLastError());
                 qs = qa;
             }
@@ -2127,7 +2337,7 @@ int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int6
             launch_select(scores, h->ntotal, m, (int)h->ntotal, k, nullptr, Ic, Dc, st);
             if (l2) {
                 hipLaunchKernelGGL(l2_flat_finish_kernel, dim3((unsigned)(((size_t)m * k + 255) / 256)), dim3(256), 0, st, Dc, Ic,
-                                   h->ws_qn.get<float>(), m, k);
+                                   w.qn.get<float>(), m, k);
                 MI_HIP(hipGetLastError());
             }
             if (!Dd) MI_HIP(hipMemcpyAsync(D + (size_t)c0 * k, Dc, (size_t)m * k * 4, hipMemcpyDeviceToHost, st));

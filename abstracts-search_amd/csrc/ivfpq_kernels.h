@@ -2788,6 +2788,166 @@ __global__ void __launch_bounds__(64)
 
 
 // ---------------------------------------------------------------------
+// ScalarQuantizer QT_8bit refine store (faiss ",Refine(SQ8)"; oracle: "ScalarQuantizer QT_8bit" section of
+// ivfpq_oracle.c): one byte per component, per-dimension ranges `trained` = [vmin | vdiff].  It is what lets the
+// recall >= 0.95 operating point keep ALL 207 M vectors beside the index in one GPU's HBM (212 GB).
+// ---------------------------------------------------------------------
+// train, pass 1: per-dimension min / max of rows [r0, r1) of a row chunk -> part[chunk][2][d] (min | max).  min / max
+// are exact whatever the order, so chunking changes nothing.  grid (d / 256, chunks), a thread owns one column.
+__global__ void __launch_bounds__(256)
+    sq8_minmax_kernel(const float *__restrict__ x, int64_t n, int d, int64_t rows_per_chunk, float *__restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    float lo = HUGE_VALF, hi = -HUGE_VALF;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float v = x[(size_t)r * d + c];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    part[((size_t)blockIdx.y * 2 + 0) * d + c] = lo;
+    part[((size_t)blockIdx.y * 2 + 1) * d + c] = hi;
+}
+// train, pass 2: fold the chunk partials (and, `merge` != 0, the ranges already in `trained`, as lo | hi) -> lo | hi
+__global__ void __launch_bounds__(256)
+    sq8_minmax_fold_kernel(const float *__restrict__ part, int chunks, int d, float *__restrict__ lohi, int merge) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    float lo = merge ? lohi[c] : HUGE_VALF, hi = merge ? lohi[d + c] : -HUGE_VALF;
+    for (int k = 0; k < chunks; ++k) {
+        lo = fminf(lo, part[((size_t)k * 2 + 0) * d + c]);
+        hi = fmaxf(hi, part[((size_t)k * 2 + 1) * d + c]);
+    }
+    lohi[c] = lo;
+    lohi[d + c] = hi;
+}
+// lo | hi -> vmin | vdiff
+__global__ void __launch_bounds__(256) sq8_ranges_kernel(const float *__restrict__ lohi, int d, float *__restrict__ trained) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    trained[c] = lohi[c];
+    trained[d + c] = lohi[d + c] - lohi[c];
+}
+
+// encode: code = (int)(255 * clip((x - vmin) / vdiff, 0, 1)), 0 where vdiff == 0 (IEEE division: hipcc's default).
+// A thread encodes 4 consecutive components (one float4 in, 4 bytes out).
+__global__ void __launch_bounds__(256)
+    sq8_encode_kernel(const float *__restrict__ x, int64_t n4, int d, const float *__restrict__ trained, uint8_t *__restrict__ codes) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // float4 index
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % d);
+    const float4 v = reinterpret_cast<const float4 *>(x)[i];
+    const float4 lo = *reinterpret_cast<const float4 *>(trained + c), df = *reinterpret_cast<const float4 *>(trained + d + c);
+    auto one = [](float xv, float vmin, float vdiff) -> unsigned {
+        float xi = 0.f;
+        if (vdiff != 0.f) {
+            xi = (xv - vmin) / vdiff;
+            if (xi < 0.f) xi = 0.f;
+            if (xi > 1.f) xi = 1.f;
+        }
+        return (unsigned)(int)(255.f * xi);
+    };
+    reinterpret_cast<unsigned *>(codes)[i] = one(v.x, lo.x, df.x) | (one(v.y, lo.y, df.y) << 8) | (one(v.z, lo.z, df.z) << 16) |
+                                             (one(v.w, lo.w, df.w) << 24);
+}
+
+__device__ __forceinline__ float sq8_component(unsigned c, float vmin, float vdiff) {
+    const float t = __builtin_fmaf((float)c, 1.0f / 255.0f, 0.5f / 255.0f);
+    return __builtin_fmaf(t, vdiff, vmin);
+}
+
+// decode (IndexScalarQuantizer.reconstruct_n)
+__global__ void __launch_bounds__(256)
+    sq8_decode_kernel(const uint8_t *__restrict__ codes, int64_t n, int d, const float *__restrict__ trained, float *__restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * d) return;
+    const int c = (int)(i % d);
+    x[i] = sq8_component(codes[i], trained[c], trained[d + c]);
+}
+
+// Re-ranking over the SQ8 store: rerank_rows_kernel's scheme (one wave per (query, 64 candidates), lane r owns
+// candidate r, rows stream through an NST-stage LDS ring filled by LDS-DMA, one ascending-i fmaf chain per lane) with
+// 128 components per 128-byte piece.  Per component: byte -> float, two fmas decode it (t = fma(c, 1/255, 0.5/255),
+// x^ = fma(t, vdiff, vmin)), one fma feeds the chain; q, vmin and vdiff are wave-uniform (scalar loads).
+// Requires d % 128 == 0.
+template <int NST>
+__global__ void __launch_bounds__(64)
+    rerank_sq8_kernel(const float *__restrict__ q, const uint8_t *__restrict__ base, int64_t nb, int d,
+                      const float *__restrict__ trained, const int64_t *__restrict__ cand, int kc, float *__restrict__ S,
+                      int64_t ldS, int tiles) {
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[NST][8192];
+    __shared__ const unsigned char *rowp[64];
+    const int lane = threadIdx.x;
+    const int qi = blockIdx.x / tiles, t = blockIdx.x - qi * tiles;
+    const int c = t * 64 + lane;
+    int64_t id = cand[(size_t)qi * kc + min(c, kc - 1)];
+    id = max(min(id, nb - 1), (int64_t)0);
+    rowp[lane] = base + (size_t)id * d;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned char *src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 8 * i + (lane >> 3);
+        src[i] = rowp[row] + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    const int nch = d / 128;
+    auto issue = [&](int ch) {
+        unsigned char *st = ring[ch % NST];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma16_lds(src[i] + (size_t)ch * 128, st + i * 1024);
+    };
+    for (int ch = 0; ch < NST - 1 && ch < nch; ++ch) issue(ch);
+    const float *qrow = q + (size_t)qi * d;
+    const float *vmin = trained, *vdiff = trained + d;
+    const int sw = (lane >> 1) & 7;
+    float acc = 0.f;
+    auto consume = [&](int ch) {
+        const unsigned char *mine = ring[ch % NST] + lane * 128;
+        const int k0 = ch * 128;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(mine + ((p ^ sw) << 4));
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = k0 + p * 16 + e * 4 + b;
+                    acc = __builtin_fmaf(qrow[i], sq8_component((w[e] >> (8 * b)) & 0xffu, vmin[i], vdiff[i]), acc);
+                }
+            }
+        }
+    };
+    int ch = 0;
+    for (; ch + NST - 1 < nch; ++ch) {
+        issue(ch + NST - 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NST - 1)) : "memory");
+        consume(ch);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (; ch < nch; ++ch) consume(ch);
+    if (c < kc) S[(size_t)qi * ldS + c] = acc;
+}
+
+// the same scores without the streaming layout's d % 128 requirement (small test shapes): one thread per (query, candidate)
+__global__ void __launch_bounds__(256)
+    rerank_sq8_simple_kernel(const float *__restrict__ q, const uint8_t *__restrict__ base, int64_t nb, int d,
+                             const float *__restrict__ trained, const int64_t *__restrict__ cand, int kc, int64_t total,
+                             float *__restrict__ S, int64_t ldS) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int64_t qi = g / kc;
+    const int c = (int)(g - qi * kc);
+    int64_t id = cand[g];
+    id = max(min(id, nb - 1), (int64_t)0);
+    const uint8_t *row = base + (size_t)id * d;
+    const float *qrow = q + (size_t)qi * d;
+    float acc = 0.f;
+    for (int i = 0; i < d; ++i) acc = __builtin_fmaf(qrow[i], sq8_component(row[i], trained[i], trained[d + i]), acc);
+    S[(size_t)qi * ldS + c] = acc;
+}
+
+// ---------------------------------------------------------------------
 // METRIC_L2 through the inner-product machinery (oracle: "METRIC_L2" section of ivfpq_oracle.c).
 // arg min |x - c|^2 = arg max S, S = <x, c> - |c|^2/2, evaluated as ONE ascending-k fmaf chain
 // over vectors augmented to `da` columns: [x, 1, 0..] . [c, -|c|^2/2, 0..] -- the exact-score

@@ -86,6 +86,10 @@ class _Lib:
                 "mi_flat_create": [c_int, c_int, POINTER(v)],
                 "mi_flat_create_ex": [c_int, c_int, c_int, POINTER(v)],
                 "mi_flat_create_metric": [c_int, c_int, c_int, POINTER(v)],
+                "mi_flat_sq_train": [v, c_int64, v, c_int],
+                "mi_flat_sq_get_trained": [v, v],
+                "mi_flat_sq_set_trained": [v, v],
+                "mi_flat_sq_is_trained": [v, POINTER(c_int)],
                 "mi_flat_destroy": [v],
                 "mi_flat_add": [v, c_int64, v],
                 "mi_flat_reserve": [v, c_int64],
@@ -273,27 +277,76 @@ class IndexFlatL2(IndexFlat):
 
 
 class ScalarQuantizer:
-    """faiss.ScalarQuantizer's quantiser-type constants (only QT_fp16 is implemented)."""
+    """faiss.ScalarQuantizer's quantiser-type constants (QT_fp16 and QT_8bit are implemented)."""
     QT_8bit, QT_4bit, QT_8bit_uniform, QT_4bit_uniform, QT_fp16, QT_8bit_direct, QT_6bit = range(7)
 
 
+class _SQView:
+    """index.sq: faiss's ScalarQuantizer member (qtype, d, code_size, trained)."""
+
+    def __init__(self, index):
+        self._index = index
+        self.qtype, self.d = index.qtype, index.d
+        self.code_size = index.d * (2 if index.qtype == ScalarQuantizer.QT_fp16 else 1)
+
+    @property
+    def trained(self) -> np.ndarray:
+        """QT_8bit: float32 [2 d] = vmin | vdiff (faiss's layout); QT_fp16: empty."""
+        if self.qtype != ScalarQuantizer.QT_8bit:
+            return np.empty(0, np.float32)
+        out = np.empty(2 * self.d, np.float32)
+        _check(_Lib.get().mi_flat_sq_get_trained(self._index._h, _ptr(out)))
+        return out
+
+    @trained.setter
+    def trained(self, t):
+        t = np.ascontiguousarray(t, np.float32)
+        assert t.shape == (2 * self.d,)
+        _check(_Lib.get().mi_flat_sq_set_trained(self._index._h, _ptr(t)))
+
+
 class IndexScalarQuantizer(IndexFlatIP):
-    """faiss.IndexScalarQuantizer(d, ScalarQuantizer.QT_fp16, METRIC_INNER_PRODUCT): the vectors
-    are kept as IEEE half (round to nearest even at add(), no scaling) and scored as
-    <q, (float)x16> in the same f32 chain as IndexFlatIP -- half the bytes per re-ranked
-    candidate.  On this path it is the refine index of "...,Refine(SQfp16)": rerank() and
-    reconstruct_n() work, a full search() is not implemented."""
+    """faiss.IndexScalarQuantizer(d, qtype, METRIC_INNER_PRODUCT), the refine index of
+    "...,Refine(SQfp16)" / "...,Refine(SQ8)": rerank() and reconstruct_n() work, a full search() is
+    not implemented.
+
+    QT_fp16: the vectors are kept as IEEE half (round to nearest even at add(), no scaling) and
+    scored as <q, (float)x16> in the same f32 chain as IndexFlatIP -- half the bytes per re-ranked
+    candidate.
+
+    QT_8bit: one byte per component with per-dimension ranges -- train(x) takes vmin / vdiff = the
+    minimum and the span of every dimension over x (faiss's RS_minmax with rangestat_arg 0),
+    add() stores (int)(255 * clip((x - vmin) / vdiff)), a candidate is scored against vmin +
+    (code + 0.5) / 255 * vdiff.  A quarter of the f32 bytes: the whole 207 M-vector refine store
+    of BASELINE.json configs[3] (212 GB) fits one MI355X beside the index."""
 
     def __init__(self, d: int, qtype: int = ScalarQuantizer.QT_fp16, metric: int = METRIC_INNER_PRODUCT, device: int = 0):
-        if qtype != ScalarQuantizer.QT_fp16:
-            raise NotImplementedError("IndexScalarQuantizer: only ScalarQuantizer.QT_fp16 is implemented on the MI355X path")
+        if qtype not in (ScalarQuantizer.QT_fp16, ScalarQuantizer.QT_8bit):
+            raise NotImplementedError("IndexScalarQuantizer: ScalarQuantizer.QT_fp16 and QT_8bit are implemented on the MI355X path")
         if metric != METRIC_INNER_PRODUCT:
             raise NotImplementedError("only METRIC_INNER_PRODUCT is implemented on the MI355X path")
-        super().__init__(d, device, _storage=1)
+        super().__init__(d, device, _storage=1 if qtype == ScalarQuantizer.QT_fp16 else 2)
         self.qtype = qtype
+        self.sq = _SQView(self)
+
+    @property
+    def is_trained(self) -> bool:
+        t = c_int(0)
+        _check(_Lib.get().mi_flat_sq_is_trained(self._h, ctypes.byref(t)))
+        return bool(t.value)
+
+    def train(self, x, merge: bool = False):
+        """ScalarQuantizer.train (a no-op for QT_fp16).  merge=True widens the trained ranges
+        with another chunk of training rows instead of replacing them."""
+        if self.qtype != ScalarQuantizer.QT_8bit:
+            return
+        x = _as_f32(x, self.d)
+        if _is_torch(x) and not x.is_cuda:
+            x = x.numpy()
+        _check(_Lib.get().mi_flat_sq_train(self._h, x.shape[0], _ptr(x), int(merge)))
 
     def search(self, x, k: int):
-        raise NotImplementedError("IndexScalarQuantizer.search: the half-precision store serves re-ranking only")
+        raise NotImplementedError("IndexScalarQuantizer.search: the scalar-quantised store serves re-ranking only")
 
 
 # ----------------------------------------------------------------------
@@ -687,10 +740,6 @@ class IndexRefine:
         return self.base_index.ntotal
 
     @property
-    def is_trained(self) -> bool:
-        return self.base_index.is_trained
-
-    @property
     def nprobe(self):
         return self.base_index.nprobe
 
@@ -698,8 +747,15 @@ class IndexRefine:
     def nprobe(self, v):
         self.base_index.nprobe = v
 
+    @property
+    def is_trained(self) -> bool:
+        return self.base_index.is_trained and self.refine_index.is_trained
+
     def train(self, x):
-        self.base_index.train(x)
+        """faiss IndexRefine::train: both indexes see the training set."""
+        if not self.base_index.is_trained:
+            self.base_index.train(x)
+        self.refine_index.train(x)
 
     def add(self, x):
         if self.base_index.ntotal != self.refine_index.ntotal:
@@ -761,12 +817,12 @@ class IndexRefineSearchParameters(SearchParameters):
         self.k_factor, self.base_index_params = float(k_factor), base_index_params
 
 
-_FACTORY_RE = re.compile(r"^IVF(\d+)(?:_HNSW\d+)?,PQ(\d+)(?:x(\d+))?(,RFlat|,Refine\(SQfp16\)|,Refine\(Flat\))?$")
+_FACTORY_RE = re.compile(r"^IVF(\d+)(?:_HNSW\d+)?,PQ(\d+)(?:x(\d+))?(,RFlat|,Refine\(SQfp16\)|,Refine\(SQ8\)|,Refine\(Flat\))?$")
 
 
 def index_factory(d: int, description: str, metric: int = METRIC_L2, device: int = 0):
     """faiss.index_factory for the strings this path uses: "IVF{nlist},PQ{M}"
-    (optionally "PQ{M}x8", ",RFlat", ",Refine(SQfp16)") and "Flat".  Like faiss the default
+    (optionally "PQ{M}x8", ",RFlat", ",Refine(SQfp16)", ",Refine(SQ8)") and "Flat".  Like faiss the default
     metric is METRIC_L2 (the reference's normalised embeddings want METRIC_INNER_PRODUCT)."""
     description = description.replace(" ", "")
     if description == "Flat":
@@ -776,11 +832,13 @@ def index_factory(d: int, description: str, metric: int = METRIC_L2, device: int
     m = _FACTORY_RE.match(description)
     if not m:
         raise ValueError(f"index_factory: unsupported description {description!r} "
-                         "(supported: 'Flat', 'IVF<nlist>,PQ<M>[x8][,RFlat | ,Refine(SQfp16)]')")
+                         "(supported: 'Flat', 'IVF<nlist>,PQ<M>[x8][,RFlat | ,Refine(SQfp16) | ,Refine(SQ8)]')")
     nlist, M, nbits = int(m.group(1)), int(m.group(2)), int(m.group(3) or 8)
     index = IndexIVFPQ(d, nlist, M, nbits, metric, device=device)
     if m.group(4) == ",Refine(SQfp16)":          # half-precision refine store: half the HBM and half the bytes per candidate
         return IndexRefine(index, IndexScalarQuantizer(d, ScalarQuantizer.QT_fp16, metric, device))
+    if m.group(4) == ",Refine(SQ8)":             # 8-bit refine store with per-dimension ranges: a quarter of the f32 bytes
+        return IndexRefine(index, IndexScalarQuantizer(d, ScalarQuantizer.QT_8bit, metric, device))
     return IndexRefineFlat(index) if m.group(4) else index
 
 

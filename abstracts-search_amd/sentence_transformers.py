@@ -59,6 +59,7 @@ class _Lib:
                 "mi_encoder_profile_enable": [v, c_int],
                 "mi_encoder_profile_read": [v, POINTER(c_double), POINTER(c_double)],
                 "mi_enc_gemm_bf16": [c_int, c_int, c_int, c_int, v, v, v, v],
+                "mi_enc_debug_counter": [c_char_p, POINTER(c_int64)],
             }
             for name, args in sigs.items():
                 fn = getattr(lib, name)
@@ -293,11 +294,13 @@ class SentenceTransformer:
             emb = emb[0]
         return emb
 
-    # Tokens one forward pass takes when the caller hands over more than one batch: 32 768 = 128 row tiles of
-    # 256, with which every GEMM of the stack fills whole rounds of the 256 CUs (N = 1536: 768 tiles = 3.0 rounds,
-    # 2048: 4.0, 17 920: 35.0).  `batch_size` (sentence-transformers' memory knob: 32 by default, `-b 32` in the
-    # reference's Makefile) then only bounds a pass from above when it is the smaller one in tokens; embeddings
-    # do not depend on which sequences share a pass (tests: batching invariance).  None: batch_size alone.
+    # Tokens one forward pass takes: 32 768 = 128 row tiles of 256, with which every GEMM of the stack fills whole
+    # rounds of the 256 CUs (N = 1536: 768 tiles = 3.0 rounds, 2048: 4.0, 17 920: 35.0).  While it is set,
+    # `batch_size` is IGNORED: sentence-transformers' batch_size (32 by default, `-b 32` in the reference's
+    # Makefile:65) is a memory knob of its hardware, and the token budget is the memory bound here (activations of
+    # 32 768 tokens are ~1.2 GB).  Embeddings do not depend on which sequences share a pass beyond f32 summation
+    # order (tests: batching invariance).  `token_budget = None` restores sentence-transformers' behaviour: passes
+    # of exactly `batch_size` length-sorted sequences -- the latency / memory knob for callers who want it.
     token_budget = 32768
 
     def _passes(self, order, token_lists, batch_size):
@@ -321,7 +324,8 @@ class SentenceTransformer:
         """list of token-id lists -> float32 [n, dim].  Like sentence-transformers,
         inputs are sorted by length (longest first) before batching and the
         result is put back in input order; a batch is packed, not padded, and sized by
-        `token_budget` (see above) rather than by a sequence count."""
+        `token_budget` (see above) rather than by a sequence count: `batch_size` only takes
+        effect when `token_budget` is None."""
         import torch
         n = len(token_lists)
         dim = self.get_sentence_embedding_dimension()
@@ -362,6 +366,13 @@ class SentenceTransformer:
         ms, fl = c_double(0), c_double(0)
         _check(_Lib.get().mi_encoder_profile_read(self._h, ctypes.byref(ms), ctypes.byref(fl)))
         return {"gemm_ms": ms.value, "gemm_flops": fl.value}
+
+
+def debug_counter(name: str) -> int:
+    """process-wide counters of dispatcher decisions (tests): 'tail_split_launches'"""
+    v = c_int64(0)
+    _check(_Lib.get().mi_enc_debug_counter(name.encode(), ctypes.byref(v)))
+    return v.value
 
 
 def gemm_bf16(A, W):

@@ -82,7 +82,10 @@ class Clock:
             dt = float(tt.item())
         return dt, t_issue
 
-    def measure(self, step, steps, warmup, min_region_s=0.05, max_blocks=15, max_total_s=2.0):
+    def measure(self, step, steps, warmup, min_region_s=0.05, min_blocks=3, max_blocks=15, max_total_s=2.0):
+        """W warmup steps, then blocks of exactly K steps (barrier + synchronize on both sides, max over ranks);
+        at least `min_blocks` of them, more while a block is shorter than `min_region_s` (inside the noise of a clock
+        ramp); the MEDIAN block is reported.  Every rank takes the same decisions: the times are all-reduced."""
         for i in range(warmup):
             step(i)
         times, issue = [], []
@@ -92,7 +95,9 @@ class Clock:
             first += steps
             times.append(dt)
             issue.append(ti)
-            if len(times) == 1 and dt >= min_region_s:
+            if len(times) < min_blocks:
+                continue
+            if statistics.median(times) >= min_region_s and len(times) % 2 == 1:
                 break
             if len(times) >= max_blocks or (sum(times) >= max_total_s and len(times) % 2 == 1):
                 break
@@ -143,6 +148,42 @@ def real_faiss():
         return None
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1 (the container's hostname may not resolve) -- the command line the driver would have typed."""
+    import socket
+    if not os.environ.get("BENCH_REHEARSAL"):
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            log(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
+            sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                 # RCCL / IPC across processes: dmabuf handles only
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: WORLD_SIZE unset, launching " + " ".join(cmd[1:8]) + " ...")
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def rank_census(torch, dist, world, dev, ntotal):
+    """What the collective library itself sees: the ranks an all-reduce on the job's backend reaches and every rank's
+    share of the index (one all-gather) -- so that the line shows N ranks took part, not N copies of rank 0."""
+    if world == 1 or not dist.is_initialized():
+        return {"backend": None, "ranks": 1, "index_vectors_per_rank": [int(ntotal)]}
+    one = torch.ones(1, device=dev, dtype=torch.int64)
+    dist.all_reduce(one)
+    mine = torch.tensor([int(ntotal)], device=dev, dtype=torch.int64)
+    allv = torch.empty(world, device=dev, dtype=torch.int64)
+    dist.all_gather_into_tensor(allv, mine)
+    return {"backend": dist.get_backend(), "ranks": int(one.item()), "index_vectors_per_rank": [int(v) for v in allv.tolist()]}
+
+
 # ----------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -167,9 +208,11 @@ def main():
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-refine-point", action="store_true", help="cfg4: skip the recall >= 0.95 operating point")
     ap.add_argument("--no-encode", action="store_true", help="cfg4: skip the encode half of the metric")
-    ap.add_argument("--refine-store", choices=["f32", "f16"], default="f16",
+    ap.add_argument("--refine-store", choices=["auto", "f32", "f16", "sq8"], default="auto",
                     help="cfg4 refine stage: f32 = IndexRefineFlat over the raw vectors (faiss ',RFlat'); f16 = "
-                         "',Refine(SQfp16)': IEEE-half store, half the HBM and half the bytes per re-ranked candidate")
+                         "',Refine(SQfp16)': IEEE-half store, half the HBM and half the bytes per re-ranked candidate; sq8 = "
+                         "',Refine(SQ8)': one byte per component with per-dimension ranges -- all 207 M rows (212 GB) beside "
+                         "the index on ONE GPU; auto (default): f16 when this rank's whole shard fits its HBM, else sq8")
     ap.add_argument("--encode-batch", type=int, default=128,
                     help="abstracts per encode step (default 128); 0 = the library's own batching: as many abstracts as fit "
                          "32 768 padded tokens per forward pass (~135; +1 % tokens/s: every GEMM fills whole rounds of the CUs)")
@@ -189,6 +232,8 @@ def main():
     args = ap.parse_args()
     if args.workload == "search":
         args.workload = "cfg2"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                                        # does not return
     if args.shard_coarse is None:
         args.shard_coarse = 1 if (args.gpus >= 4 and args.workload == "cfg4") else 0
     # stdout carries exactly one JSON line: whatever native libraries print to fd 1 (RCCL's
@@ -274,12 +319,14 @@ def cfg4_workload(args, ctx):
     index.cp.niter = train_iters
     cent = torch.empty((nlist, d), dtype=torch.float32, device=dev)
     cb = torch.empty((M, 256, d // M), dtype=torch.float32, device=dev)
+    sq_train_rows = None
     if rank == 0:
         ntrain = min(N, max(4 * CH, 64 * nlist))
         xs = synth.corpus_cuda(ntrain, d, device=local_rank)
         index.train(xs)
         cent.copy_(torch.from_numpy(index.get_centroids()))
         cb.copy_(torch.from_numpy(index.get_codebook()))
+        sq_train_rows = xs                                             # also the ScalarQuantizer's training set (',Refine(SQ8)')
         del xs
     if dist.is_initialized() and world > 1:
         dist.broadcast(cent, 0)
@@ -307,16 +354,35 @@ def cfg4_workload(args, ctx):
     per_rank = (N + nsh - 1) // nsh
     hbm_total = torch.cuda.mem_get_info()[1]
     want_refine = not args.no_refine_point and not replicas
-    relem = 2 if args.refine_store == "f16" else 4
-    refine_own = want_refine and per_rank * d * relem <= 0.74 * hbm_total - 40e9
-    if os.environ.get("BENCH_FORCE_SUBSHARD"):                         # rehearsals: the layout of N = 1, 2 at 207 M on a small corpus
+    # what this rank's HBM has left for the refine store: the index itself is 152 B per vector (append log 80 + scan image
+    # 72), plus ~25 GB of corpus chunks, ground-truth store and search workspaces (measured: 257 of 309 GB in use at N = 1)
+    room = hbm_total - per_rank * 152 - 25e9
+    store = args.refine_store
+    if store == "auto":
+        store = "f16" if per_rank * d * 2 <= room else "sq8"
+    relem = {"f32": 4, "f16": 2, "sq8": 1}[store]
+    refine_own = want_refine and per_rank * d * relem <= room
+    if os.environ.get("BENCH_FORCE_SUBSHARD"):                         # rehearsals: the sub-shard layout on a small corpus
         refine_own = False
     sub_mod = 8 if (want_refine and not refine_own) else 0
     assert not sub_mod or (8 % nsh == 0), "the 1/8 sub-shard needs N in {1, 2, 4, 8}"
     flat_r = sub = None
     if want_refine:
-        flat_r = (faiss.IndexScalarQuantizer(d, faiss.ScalarQuantizer.QT_fp16, faiss.METRIC_INNER_PRODUCT, device=local_rank)
-                  if relem == 2 else faiss.IndexFlatIP(d, device=local_rank))
+        if store == "sq8":
+            flat_r = faiss.IndexScalarQuantizer(d, faiss.ScalarQuantizer.QT_8bit, faiss.METRIC_INNER_PRODUCT, device=local_rank)
+            # ScalarQuantizer.train on the index's own training sample (rank 0), the ranges broadcast like the other tables
+            tr = torch.empty(2 * d, dtype=torch.float32, device=dev)
+            if rank == 0:
+                flat_r.train(sq_train_rows)
+                tr.copy_(torch.from_numpy(flat_r.sq.trained))
+            if dist.is_initialized() and world > 1:
+                dist.broadcast(tr, 0)
+                flat_r.sq.trained = tr.cpu().numpy()
+            del tr
+        elif store == "f16":
+            flat_r = faiss.IndexScalarQuantizer(d, faiss.ScalarQuantizer.QT_fp16, faiss.METRIC_INNER_PRODUCT, device=local_rank)
+        else:
+            flat_r = faiss.IndexFlatIP(d, device=local_rank)
         n_r = per_rank if refine_own else (N + 7) // 8
         flat_r.reserve(n_r + 1)
         if sub_mod:
@@ -324,6 +390,7 @@ def cfg4_workload(args, ctx):
             sub.set_centroids(torch.from_numpy(index.get_centroids()).to(dev))
             sub.set_codebook(torch.from_numpy(index.get_codebook()).to(dev))
             sub.reserve(n_r + 1)
+    del sq_train_rows
     index.reserve(per_rank + 1)
 
     # ---- build: regenerate the corpus chunk by chunk; add this rank's rows; exact top-k of the
@@ -367,6 +434,7 @@ def cfg4_workload(args, ctx):
     torch.cuda.synchronize()
     t_build = time.time() - t1
     del flat_gt
+    torch.cuda.empty_cache()                                           # the chunk buffers: the scan image needs the room at N = 1
     if want_gt and use_shards and world > 1:                           # exact top-k over all shards
         Dall = torch.empty((world, batch, k), dtype=torch.float32, device=dev)
         Iall = torch.empty((world, batch, k), dtype=torch.int64, device=dev)
@@ -463,6 +531,8 @@ def cfg4_workload(args, ctx):
         at095 = refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own, nsh, my_q, q_gt,
                              gt if refine_own else gt_sub, batch, k, steps, warmup, settle)
 
+    census = rank_census(torch, dist, world, dev, index.ntotal)
+
     # ---- CPU baseline + parity spot check (rank 0, N = 1): the oracle on the same index / queries
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -489,7 +559,10 @@ def cfg4_workload(args, ctx):
                        "timing": "median of the K-step blocks" if len(blocks) > 1 else "one K-step block",
                        "setup_s": {"train": round(t_train, 1), "generate+add+ground_truth": round(t_build, 1),
                                    "scan_image": round(t_image, 2)},
-                       "index_vectors_this_rank": index.ntotal, "hbm_in_use_gb": round(used, 1)},
+                       "index_vectors_this_rank": index.ntotal, "index_vectors_per_rank": census["index_vectors_per_rank"],
+                       "collective_backend": census["backend"], "rccl_ranks": census["ranks"],
+                       "rccl_ranks_note": "ranks one all-reduce on the job's process group reached (backend nccl = RCCL; 1 = no collective, single GPU)",
+                       "hbm_in_use_gb": round(used, 1)},
             "recall_at_10": None if recall is None else round(recall, 4),
             "recall_note": "against exact inner-product search over all %d rows, %d queries" % (N, batch),
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
@@ -504,7 +577,8 @@ def cfg4_workload(args, ctx):
             out["encode"] = {"abstracts_per_s": enc["value"], "tokens_per_s": enc["config"]["tokens_per_sec"],
                              "ms_per_step": enc["ms_per_step"], "steps": enc["steps"], "batch": enc["config"]["batch"],
                              "sample": enc["config"]["sample"], "dtype": enc["dtype"], "data": enc["data"],
-                             "roofline": enc["roofline"], "cpu_baseline": enc["cpu_baseline"]}
+                             "roofline": enc["roofline"], "cpu_baseline": enc["cpu_baseline"],
+                             "parity_vs_oracle": enc["parity_vs_oracle"]}
     return out
 
 
@@ -517,11 +591,13 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     base = index if refine_own else sub
     args_nprobe = index.nprobe                                         # restored below
     ref = faiss.IndexRefine(base, flat_r)
-    relem = 2 if isinstance(flat_r, faiss.IndexScalarQuantizer) else 4
-    store = "IEEE-half (SQfp16)" if relem == 2 else "raw f32"
+    qt = getattr(flat_r, "qtype", None)
+    relem = 1 if qt == faiss.ScalarQuantizer.QT_8bit else 2 if qt == faiss.ScalarQuantizer.QT_fp16 else 4
+    store = {1: "8-bit (SQ8, per-dimension ranges)", 2: "IEEE-half (SQfp16)", 4: "raw f32"}[relem]
+    suffix = {1: "Refine(SQ8)", 2: "Refine(SQfp16)", 4: "RFlat"}[relem]
     sharded = ShardedIndex(ref, id_affine=(nsh, 0, 1)) if (refine_own and nsh > 1) else None
-    cands = [(8, 64), (8, 72), (8, 80), (8, 100), (16, 100), (16, 160), (32, 200), (64, 256), (64, 400)]
-    best = None
+    cands = [(8, 64), (8, 72), (8, 80), (8, 100), (8, 128), (16, 128), (16, 160), (16, 200), (32, 200), (32, 256), (64, 256), (64, 400)]
+    best, curve = None, []
     for nprobe, kf in cands:
         base.nprobe, ref.k_factor = nprobe, kf
         _, Ia = (sharded.search_replicated(q_gt, k) if sharded is not None else ref.search(q_gt, k))
@@ -532,6 +608,7 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
             r = float(t.item())
         log(f"  refine point nprobe={nprobe} k_factor_rf={kf}: recall@10 {r:.4f}")
         best = (nprobe, kf, r)
+        curve.append([nprobe, kf, round(r, 4)])
         if r >= 0.95:
             break
     nprobe, kf, r = best
@@ -566,7 +643,7 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     if refine_own:
         scope = (f"the whole job: every rank re-ranks k*k_factor candidates of its own shard against the shard's {store} "
                  f"vectors ({gb:.0f} GB per GPU), one all-gather of the exact per-shard lists"
-                 if nsh > 1 else f"whole index + {store} vectors on one GPU")
+                 if nsh > 1 else f"whole index: all {index.ntotal} vectors + their {store} refine store ({gb:.0f} GB) on one GPU")
         recall_note = "against exact search over the whole corpus"
     else:
         scope = (f"one GPU's share of the 8-GPU job: the 1/8 sub-shard (rows i mod 8 = rank, {flat_r.ntotal} vectors + their "
@@ -574,38 +651,56 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
                  f"({index.ntotal * nsh * D_MODEL * relem / 1e9:.0f} GB) does not fit {world} GPU(s); every GPU of the 8-GPU job "
                  f"sees every query, so its job rate is this rate less one all-gather")
         recall_note = "against exact search over the same sub-shard"
-    return {"index": "IVF%d,PQ64,%s" % (base.nlist, "Refine(SQfp16)" if relem == 2 else "RFlat"), "nprobe": nprobe, "k_factor_rf": kf, "recall_at_10": round(r, 4),
+    return {"index": "IVF%d,PQ64,%s" % (base.nlist, suffix), "nprobe": nprobe, "k_factor_rf": kf, "recall_at_10": round(r, 4),
             "reached": bool(r >= 0.95), "qps": round(steps * batch / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
-            "timed_blocks": len(blocks), "streams": S2, "scope": scope, "recall_note": recall_note}
+            "timed_blocks": len(blocks), "streams": S2, "scope": scope, "recall_note": recall_note,
+            "explored": curve, "explored_note": "[nprobe, k_factor_rf, recall@10] in ascending cost; the first point at or above 0.95 is timed"}
 
 
 # ======================================================================
 # cfg5: end to end -- encode + search over the cfg4 index, query batches 1 / 16 / 256
 # ======================================================================
-def stella_random_model(args, ctx):
-    """stella_en_1.5B_v5 architecture with random-init bf16 weights (no checkpoint on these boxes)."""
-    torch, dev, local_rank = ctx["torch"], ctx["dev"], ctx["local_rank"]
-    import abstracts_search_amd.sentence_transformers as st
-    cfg = dict(st.STELLA_EN_1_5B_V5)
-    model = st.SentenceTransformer(config=cfg, device=f"cuda:{local_rank}")
-    g = torch.Generator(device=dev).manual_seed(7)
+def stella_random_weights(cfg, torch, dev, seed=7):
+    """Random-init bf16 weights of a stella-shaped configuration, generated on the GPU, as (name, tensor) pairs in load
+    order (no checkpoint is reachable from the build / bench boxes)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
 
     def rnd(shape, scale):
         return (torch.randn(shape, generator=g, device=dev) * scale).bfloat16()
 
     H, I = cfg["hidden"], cfg["intermediate"]
     qc, kc = cfg["n_heads"] * cfg["head_dim"], cfg["n_kv_heads"] * cfg["head_dim"]
-    model.load_weights({"embed_tokens.weight": rnd((cfg["vocab_size"], H), 0.3), "norm.weight": torch.ones(H, device=dev),
-                        "dense.weight": rnd((cfg["dense_out"], H), H ** -0.5), "dense.bias": torch.zeros(cfg["dense_out"], device=dev)})
+    yield "embed_tokens.weight", rnd((cfg["vocab_size"], H), 0.3)
+    yield "norm.weight", torch.ones(H, device=dev)
+    yield "dense.weight", rnd((cfg["dense_out"], H), H ** -0.5)
+    yield "dense.bias", torch.zeros(cfg["dense_out"], device=dev)
     for l in range(cfg["n_layers"]):
         p = f"layers.{l}."
-        model.load_weights({
-            p + "input_layernorm.weight": torch.ones(H, device=dev), p + "post_attention_layernorm.weight": torch.ones(H, device=dev),
-            p + "self_attn.q_proj.weight": rnd((qc, H), H ** -0.5), p + "self_attn.q_proj.bias": rnd((qc,), 0.1),
-            p + "self_attn.k_proj.weight": rnd((kc, H), H ** -0.5), p + "self_attn.k_proj.bias": rnd((kc,), 0.1),
-            p + "self_attn.v_proj.weight": rnd((kc, H), H ** -0.5), p + "self_attn.v_proj.bias": rnd((kc,), 0.1),
-            p + "self_attn.o_proj.weight": rnd((H, qc), qc ** -0.5), p + "mlp.gate_proj.weight": rnd((I, H), H ** -0.5),
-            p + "mlp.up_proj.weight": rnd((I, H), H ** -0.5), p + "mlp.down_proj.weight": rnd((H, I), I ** -0.5)})
+        yield p + "input_layernorm.weight", torch.ones(H, device=dev)
+        yield p + "post_attention_layernorm.weight", torch.ones(H, device=dev)
+        yield p + "self_attn.q_proj.weight", rnd((qc, H), H ** -0.5)
+        yield p + "self_attn.q_proj.bias", rnd((qc,), 0.1)
+        yield p + "self_attn.k_proj.weight", rnd((kc, H), H ** -0.5)
+        yield p + "self_attn.k_proj.bias", rnd((kc,), 0.1)
+        yield p + "self_attn.v_proj.weight", rnd((kc, H), H ** -0.5)
+        yield p + "self_attn.v_proj.bias", rnd((kc,), 0.1)
+        yield p + "self_attn.o_proj.weight", rnd((H, qc), qc ** -0.5)
+        yield p + "mlp.gate_proj.weight", rnd((I, H), H ** -0.5)
+        yield p + "mlp.up_proj.weight", rnd((I, H), H ** -0.5)
+        yield p + "mlp.down_proj.weight", rnd((H, I), I ** -0.5)
+
+
+def stella_random_model(args, ctx, keep=None):
+    """stella_en_1.5B_v5 architecture with random-init bf16 weights; `keep`: a dict that receives fp32 host copies of
+    the weights (what the CPU oracle multiplies: the same bf16-representable values)."""
+    torch, dev, local_rank = ctx["torch"], ctx["dev"], ctx["local_rank"]
+    import abstracts_search_amd.sentence_transformers as st
+    cfg = dict(st.STELLA_EN_1_5B_V5)
+    model = st.SentenceTransformer(config=cfg, device=f"cuda:{local_rank}")
+    for name, t in stella_random_weights(cfg, torch, dev, 7):
+        model.load_weights({name: t})
+        if keep is not None:
+            keep[name] = t.float().cpu()
     return model, cfg
 
 
@@ -847,26 +942,9 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True):
     np, torch, dist = ctx["np"], ctx["torch"], ctx["dist"]
     world, rank, local_rank, dev, clock = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["dev"], ctx["clock"]
     import abstracts_search_amd.sentence_transformers as st
-    cfg = dict(st.STELLA_EN_1_5B_V5)
-    model = st.SentenceTransformer(config=cfg, device=f"cuda:{local_rank}")
-    g = torch.Generator(device=dev).manual_seed(7)
-
-    def rnd(shape, scale):
-        return (torch.randn(shape, generator=g, device=dev) * scale).bfloat16()
-
-    H, I = cfg["hidden"], cfg["intermediate"]
-    qc, kc = cfg["n_heads"] * cfg["head_dim"], cfg["n_kv_heads"] * cfg["head_dim"]
-    model.load_weights({"embed_tokens.weight": rnd((cfg["vocab_size"], H), 0.3), "norm.weight": torch.ones(H, device=dev),
-                        "dense.weight": rnd((cfg["dense_out"], H), H ** -0.5), "dense.bias": torch.zeros(cfg["dense_out"], device=dev)})
-    for l in range(cfg["n_layers"]):
-        p = f"layers.{l}."
-        model.load_weights({
-            p + "input_layernorm.weight": torch.ones(H, device=dev), p + "post_attention_layernorm.weight": torch.ones(H, device=dev),
-            p + "self_attn.q_proj.weight": rnd((qc, H), H ** -0.5), p + "self_attn.q_proj.bias": rnd((qc,), 0.1),
-            p + "self_attn.k_proj.weight": rnd((kc, H), H ** -0.5), p + "self_attn.k_proj.bias": rnd((kc,), 0.1),
-            p + "self_attn.v_proj.weight": rnd((kc, H), H ** -0.5), p + "self_attn.v_proj.bias": rnd((kc,), 0.1),
-            p + "self_attn.o_proj.weight": rnd((H, qc), qc ** -0.5), p + "mlp.gate_proj.weight": rnd((I, H), H ** -0.5),
-            p + "mlp.up_proj.weight": rnd((I, H), H ** -0.5), p + "mlp.down_proj.weight": rnd((H, I), I ** -0.5)})
+    do_cpu = rank == 0 and world == 1 and with_cpu
+    host_w = {} if do_cpu else None                                   # fp32 host copies for the full-depth oracle leg
+    model, cfg = stella_random_model(args, ctx, keep=host_w)
     bs = args.encode_batch
     rng = np.random.default_rng(7 + rank)
     NBATCH = 8
@@ -907,14 +985,22 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True):
     pr = model.profile_read()
     model.profile(False)
     tf = pr["gemm_flops"] / (pr["gemm_ms"] * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    try:                                                               # separate --pmc passes of `bench.py --workload encode`
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_cfg3_encoder_gemm_pmc.json")))
+        if pmc.get("batch") == bs and pmc.get("tokens_step0") == ntok[0]:
+            traffic, traffic_src = int(pmc["hbm_bytes_per_step"]), pmc["source"]
+    except Exception:
+        pass
     roofline = {"kernel": "gemm_bf16_slab_kernel (QKV / O / gate-up+SwiGLU / down, 112 launches per step)",
                 "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(tf / 2500.0, 4), "traffic": None,
-                "flops_per_step": pr["gemm_flops"], "gemm_ms_per_step": round(pr["gemm_ms"], 3)}
-    cpu = None
-    if rank == 0 and with_cpu:
-        cpu = encode_cpu_baseline(model, cfg, batches, torch, np)
-    del model
+                "frac": round(tf / 2500.0, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "flops_per_step": pr["gemm_flops"], "gemm_ms_per_step": round(pr["gemm_ms"], 3),
+                "timing": "HIP events on the launch stream around each of the step's GEMM launches, one profiled step after the timed blocks"}
+    cpu = parity = None
+    if do_cpu:
+        cpu, parity = encode_cpu_baseline(model, cfg, host_w, batches, ctx)
+    del model, host_w
     torch.cuda.empty_cache()
     if rank != 0:
         return None
@@ -929,35 +1015,65 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True):
                              % (n_abs, steps),
                    "tokens_per_sec": round(toks * world / dt, 0), "parallelism": "replicas" if world > 1 else "1 GPU",
                    "timed_blocks": len(blocks)},
-        "roofline": roofline, "cpu_baseline": cpu, "reference_oracles": reference_oracles()}
+        "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "reference_oracles": reference_oracles()}
 
 
-def encode_cpu_baseline(model, cfg, batches, torch, np):
-    """sentence-transformers on the host cores when it is importable here (it needs the
-    stella checkpoint too, which no box of this pool has); otherwise the oracle port (torch
-    fp32 on the host cores) on a bounded sample: the same architecture cut to 2 layers and a
-    4096-row vocabulary (a 1.5 B-parameter fp32 copy is 6 GB and tens of seconds per batch),
-    scaled by 28/2 layers."""
+def encode_cpu_baseline(model, cfg, host_w, batches, ctx):
+    """The oracle port (oracle/encoder_oracle.py, torch fp32 on the host cores; sentence-transformers and the stella
+    checkpoint are on no box of this pool -- `reference` records the attempt), two legs:
+
+    full depth   the bench's own 28-layer model on 4 abstracts of the timed workload: the CPU baseline (abstracts/s,
+                 nothing extrapolated) and the parity of the whole stack at depth;
+    bulk path    the forward pass bench.py TIMES -- one 128-abstract batch (~29 k tokens, sequences up to 512: the
+                 256x256 slab GEMMs at K = 1536 / 8960, >= 8 attention chunks, GEMM pooling) -- through a model of
+                 stella's widths cut to 2 layers and a 4096-row vocabulary (what bounds the oracle's time), default
+                 dispatch, against the oracle on the same batch.
+    Tolerance: cosine >= 1 - 1e-3 per embedding (BASELINE.json north star)."""
+    np, torch, dev, local_rank = ctx["np"], ctx["torch"], ctx["dev"], ctx["local_rank"]
+    import abstracts_search_amd.sentence_transformers as st
     from oracle import encoder_oracle as E
-    small = dict(cfg)
-    small["n_layers"], small["vocab_size"] = 2, 4096
-    W = E.synth_weights(E.EncoderConfig(**small), 3)
-    toks = [[t % 4096 for t in s] for s in batches[0][:16]]
+    st_state = reference_oracles()["sentence_transformers"]
+    # ---- full depth
+    toks = batches[0][:4]
     cu = np.concatenate([[0], np.cumsum([len(t) for t in toks])])
     ids = np.concatenate(toks)
+    ocfg = E.EncoderConfig(**cfg)
+    e_gpu = model.encode_tokens(toks, batch_size=len(toks), normalize_embeddings=True)
     with torch.no_grad():
-        E.encode(E.EncoderConfig(**small), W, ids, cu, True)
         t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            E.encode(E.EncoderConfig(**small), W, ids, cu, True)
-        dt = (time.perf_counter() - t0) / reps
-    full = dt * cfg["n_layers"] / 2
-    st_state = reference_oracles()["sentence_transformers"]
-    return {"value": round(len(toks) / full, 2), "unit": "abstracts/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"16 abstracts through 2 of 28 layers (oracle/encoder_oracle.py, torch fp32), "
-                                      f"{dt:.2f}s per pass, scaled x14 to full depth",
-            "reference": "sentence_transformers " + st_state + "; the stella_en_1.5B_v5 checkpoint is not on this box"}
+        ref = E.encode(ocfg, host_w, ids, cu, True).numpy()
+        dt = time.perf_counter() - t0
+    cos_full = (e_gpu * ref).sum(1)
+    cpu = {"value": round(len(toks) / dt, 3), "unit": "abstracts/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{len(toks)} abstracts ({int(cu[-1])} tokens) of the timed workload through all {cfg['n_layers']} layers "
+                     f"(oracle/encoder_oracle.py, torch fp32), {dt:.1f}s, nothing extrapolated",
+           "reference": "sentence_transformers " + st_state + "; the stella_en_1.5B_v5 checkpoint is not on this box"}
+    # ---- the bulk path
+    small = dict(cfg)
+    small["n_layers"], small["vocab_size"] = 2, 4096
+    w2 = dict(stella_random_weights(small, torch, dev, 11))
+    m2 = st.SentenceTransformer(config=small, weights=w2, device=f"cuda:{local_rank}")
+    m2.token_budget = model.token_budget
+    b0 = [[t % 4096 for t in s] for s in batches[0]]
+    before = st.debug_counter("tail_split_launches")
+    e2 = m2.encode_tokens(b0, batch_size=len(b0), normalize_embeddings=True)
+    tails = st.debug_counter("tail_split_launches") - before
+    cu2 = np.concatenate([[0], np.cumsum([len(t) for t in b0])])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ref2 = E.encode(E.EncoderConfig(**small), {k: v.float().cpu() for k, v in w2.items()}, np.concatenate(b0), cu2, True).numpy()
+        dt2 = time.perf_counter() - t0
+    cos_bulk = (e2 * ref2).sum(1)
+    del m2, w2
+    parity = {"against": "oracle/encoder_oracle.py (torch fp32 on the host; sentence_transformers " + st_state + ")",
+              "tolerance": "cosine >= 1 - 1e-3",
+              "full_depth": {"abstracts": len(toks), "tokens": int(cu[-1]), "layers": cfg["n_layers"], "min_cosine": round(float(cos_full.min()), 7),
+                             "ok": bool(cos_full.min() >= 1 - 1e-3)},
+              "bulk_path": {"abstracts": len(b0), "tokens": int(cu2[-1]), "longest": int(max(len(t) for t in b0)), "layers": 2,
+                            "min_cosine": round(float(cos_bulk.min()), 7), "ok": bool(cos_bulk.min() >= 1 - 1e-3),
+                            "k_split_tail_launches": int(tails), "oracle_s": round(dt2, 1),
+                            "path": "default dispatch: 256x256 slab GEMMs (K = 1536 and 8960), paired-head attention, GEMM pooling"}}
+    return cpu, parity
 
 
 def cpu_baseline_ivfpq(index, queries, nprobe, k, np, torch, tag):

@@ -10,7 +10,11 @@
  * sentence-transformers surface is abstracts-search_amd/sentence_transformers.py.
  *
  * Conventions: as in mi_ivfpq.h (int status, mi_enc_last_error(), opaque
- * handle, plain pointers, hipStream_t as void*).  Token ids arrive PACKED:
+ * handle, plain pointers, hipStream_t as void*).  Threading: mi_encoder_encode /
+ * mi_encoder_hidden are safe to call from several host threads on one handle --
+ * activations live in one workspace set per stream, leased for the duration of a
+ * call (threads on distinct streams overlap on the GPU, threads sharing a stream
+ * take turns); create / load_tensor / destroy are exclusive.  Token ids arrive PACKED:
  * ids[T] with cu_seqlens[nseq+1] (sequence i is ids[cu[i] .. cu[i+1])), host or
  * device pointers.  Weights are stored and multiplied in bf16 with f32
  * accumulation (MFMA); norms, softmax, pooling, Dense and the final
@@ -80,6 +84,10 @@ int mi_encoder_hidden(mi_encoder *h, int nseq, const int32_t *ids, const int32_t
  * the FLOPs those launches performed. */
 int mi_encoder_profile_enable(mi_encoder *h, int on);
 int mi_encoder_profile_read(mi_encoder *h, double *gemm_ms, double *gemm_flops);
+
+/* Test hook: process-wide counters of code paths the dispatcher takes on its own.  "tail_split_launches" = GEMM
+ * launches whose last (partial) round of 256x256 tiles was split along K with f32 atomics into the residual stream. */
+int mi_enc_debug_counter(const char *name, int64_t *value);
 
 /* Building block exposed for numerics tests: C[M][N] = A[M][K] . W[N][K]^T in
  * bf16 with f32 accumulation (device pointers; C bf16 row-major). */

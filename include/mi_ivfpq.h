@@ -28,9 +28,16 @@
  *     mi_index_search_preassigned and the half-precision flat store are inner-product only.
  *   - nbits == 8 only (one byte per sub-quantiser, ksub = 256).
  *   - handles are opaque, freed only by *_destroy; one handle per device.
- *   - one host thread drives a handle.  mi_index_search() keeps one set of
- *     workspaces per stream it is called with (up to 16), so batches issued on
- *     different streams overlap on the GPU; add/train-type calls are exclusive.
+ *   - Threading (faiss: "search is thread-safe for concurrent readers, add/train are
+ *     exclusive"): the search-type calls -- mi_index_search, mi_index_search_preassigned,
+ *     mi_index_coarse_slice, mi_flat_search, mi_flat_rerank -- may be issued on one
+ *     handle from several host threads at once.  Every call leases the workspace set of the
+ *     stream it is given (one set per stream, up to 64 per handle) for as long as it enqueues
+ *     work: threads on distinct streams run concurrently and overlap on the GPU, threads that
+ *     share a stream (e.g. NULL) take turns.  State a search builds lazily (the scan image after
+ *     an add) is built once under the handle's lock.  add / train / set_* / reset / save /
+ *     destroy are exclusive: no other call may run on the handle meanwhile.  mi_shards_search
+ *     issues a collective: one host thread per handle (every rank must issue in the same order).
  *   - result semantics (faiss): best first; unfilled slots I = -1,
  *     D = -FLT_MAX.  Exact score ties are ordered by ascending id.
  */
@@ -201,7 +208,23 @@ int mi_flat_create(int d, int device, mi_flat **out);
  * the bytes per re-ranked candidate.  Such a store serves mi_flat_rerank / reconstruct_n only. */
 #define MI_STORE_F32 0
 #define MI_STORE_F16 1
+/* storage = MI_STORE_SQ8: faiss's IndexScalarQuantizer(d, QT_8bit), the refine index of "...,Refine(SQ8)": one
+ * byte per component with per-dimension ranges.  The ranges must be trained (mi_flat_sq_train = faiss
+ * ScalarQuantizer::train with RS_minmax, rangestat_arg 0: vmin[i] = min, vdiff[i] = max - min over the training
+ * rows) or set (mi_flat_sq_set_trained) before add(); add() stores code = (int)(255 * clip((x - vmin) / vdiff));
+ * re-ranking scores <q, x^> with x^[i] = fma(fma(code, 1/255, 0.5/255), vdiff[i], vmin[i]) in the same ascending
+ * f32 chain as the other stores (oracle/ivfpq_oracle.c, section "ScalarQuantizer QT_8bit").  207 M x 1024
+ * components are 212 GB: the whole refine store of BASELINE.json configs[3] beside the index in one GPU's HBM.
+ * Inner product only; serves mi_flat_rerank / reconstruct_n only. */
+#define MI_STORE_SQ8 2
 int mi_flat_create_ex(int d, int device, int storage, mi_flat **out);
+/* ScalarQuantizer.train(x): x float32 [n][d], host or device.  `merge` != 0 widens the ranges already trained
+ * instead of replacing them (training over a corpus that arrives in chunks). */
+int mi_flat_sq_train(mi_flat *h, int64_t n, const float *x, int merge);
+/* ScalarQuantizer.trained: float32 [2 d] = vmin[d] | vdiff[d] (host pointers). */
+int mi_flat_sq_get_trained(mi_flat *h, float *trained);
+int mi_flat_sq_set_trained(mi_flat *h, const float *trained);
+int mi_flat_sq_is_trained(mi_flat *h, int *out);
 /* faiss.IndexFlat(d, metric): MI_METRIC_L2 = IndexFlatL2 -- squared L2 distances, ascending,
  * unfilled slots +FLT_MAX -- evaluated through the expansion |q|^2 + |x|^2 - 2<q, x> on
  * augmented rows (see "Metrics" above). */

@@ -195,6 +195,89 @@ ORACLE_API void oracle_rerank(int64_t nq, int d, const float *q, const float *ba
     }
 }
 
+/* ---- ScalarQuantizer QT_8bit (faiss index_factory "...,Refine(SQ8)": the refine store that lets
+ * the recall >= 0.95 operating point keep ALL 207 M vectors of BASELINE.json configs[3] beside the index in one
+ * GPU's HBM: 1 byte per component, 212 GB).  Reference call site: `sidecar-search index ... tune`
+ * (reference Makefile:32) explores the index's search parameters, README.md:28 the query-time app; the
+ * arithmetic is faiss's ScalarQuantizer, restated from its published behaviour:
+ *
+ *   train  (ScalarQuantizer::train, QT_8bit = per-dimension ranges, RangeStat RS_minmax, rangestat_arg 0):
+ *          vmin[i] = min_r x[r][i], vdiff[i] = max_r x[r][i] - vmin[i]; trained = [vmin | vdiff] (2 d floats)
+ *   encode (QuantizerTemplate<Codec8bit, non-uniform>::encode_vector):
+ *          xi = (x[i] - vmin[i]) / vdiff[i] clipped to [0, 1] (0 when vdiff[i] == 0); code[i] = (int)(255 * xi)
+ *   decode (reconstruct_component; faiss's SIMD build evaluates it with two fused multiply-adds):
+ *          t = fmaf((float)code[i], 1/255, 0.5/255);  x^[i] = fmaf(t, vdiff[i], vmin[i])
+ *   score  (DCTemplate<..., SimilarityIP>::query_to_code): <q, x^>.  faiss's SIMD build keeps 8 lane
+ *          accumulators; this file keeps its ONE evaluation order -- the ascending-i fmaf chain from +0 --
+ *          like every other dot product here (see the header).
+ */
+ORACLE_API void oracle_sq8_train(int64_t n, int d, const float *x, float *trained /* [2 d]: vmin | vdiff */) {
+    for (int i = 0; i < d; ++i) {
+        float lo = HUGE_VALF, hi = -HUGE_VALF;
+        for (int64_t r = 0; r < n; ++r) {
+            const float v = x[r * (int64_t)d + i];
+            if (v < lo) lo = v;
+            if (v > hi) hi = v;
+        }
+        trained[i] = lo;
+        trained[d + i] = hi - lo;
+    }
+}
+
+ORACLE_API void oracle_sq8_encode(int64_t n, int d, const float *x, const float *trained, uint8_t *codes) {
+    const float *vmin = trained, *vdiff = trained + d;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r)
+        for (int i = 0; i < d; ++i) {
+            float xi = 0.f;
+            if (vdiff[i] != 0.f) {
+                xi = (x[r * (int64_t)d + i] - vmin[i]) / vdiff[i];
+                if (xi < 0.f) xi = 0.f;
+                if (xi > 1.f) xi = 1.f;
+            }
+            codes[r * (int64_t)d + i] = (uint8_t)(int)(255.f * xi);
+        }
+}
+
+static inline float sq8_component(uint8_t c, float vmin, float vdiff) {
+    const float t = fmaf((float)c, 1.0f / 255.0f, 0.5f / 255.0f);
+    return fmaf(t, vdiff, vmin);
+}
+
+ORACLE_API void oracle_sq8_decode(int64_t n, int d, const uint8_t *codes, const float *trained, float *x) {
+    const float *vmin = trained, *vdiff = trained + d;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r)
+        for (int i = 0; i < d; ++i) x[r * (int64_t)d + i] = sq8_component(codes[r * (int64_t)d + i], vmin[i], vdiff[i]);
+}
+
+/* IndexRefine(base, IndexScalarQuantizer(QT_8bit)) re-ranking step: like oracle_rerank over the decoded rows */
+ORACLE_API void oracle_rerank_sq8(int64_t nq, int d, const float *q, const uint8_t *codes, const float *trained, int kc,
+                                  const int64_t *cand_I, int k, float *D, int64_t *I) {
+    const float *vmin = trained, *vdiff = trained + d;
+#pragma omp parallel
+    {
+        cand_t *L = (cand_t *)malloc(sizeof(cand_t) * (size_t)k);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t qi = 0; qi < nq; ++qi) {
+            int n = 0;
+            for (int c = 0; c < kc; ++c) {
+                const int64_t id = cand_I[qi * kc + c];
+                if (id < 0) continue;
+                const uint8_t *row = codes + id * (int64_t)d;
+                float acc = 0.f;
+                for (int i = 0; i < d; ++i) acc = fmaf(q[qi * d + i], sq8_component(row[i], vmin[i], vdiff[i]), acc);
+                topk_push(L, &n, k, acc, id);
+            }
+            for (int j = 0; j < k; ++j) {
+                D[qi * k + j] = j < n ? L[j].s : -FLT_MAX;
+                I[qi * k + j] = j < n ? L[j].id : -1;
+            }
+        }
+        free(L);
+    }
+}
+
 /* ADC look-up table for one query: lut[m*ksub + j] = <q_m, codebook[m][j]> */
 ORACLE_API void oracle_lut(int d, int M, int ksub, const float *q,
                            const float *codebook, float *lut) {

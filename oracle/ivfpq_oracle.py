@@ -164,6 +164,49 @@ def rerank(q, base, cand_I, k):
     return D, I
 
 
+def sq8_train(x):
+    """faiss ScalarQuantizer(QT_8bit).train restatement -> trained [2 d] = vmin | vdiff."""
+    x = _f32(x)
+    n, d = x.shape
+    tr = np.empty(2 * d, np.float32)
+    lib().oracle_sq8_train(ctypes.c_int64(n), ctypes.c_int(d), _p(x, ctypes.c_float), _p(tr, ctypes.c_float))
+    return tr
+
+
+def sq8_encode(x, trained):
+    x, trained = _f32(x), _f32(trained)
+    n, d = x.shape
+    codes = np.empty((n, d), np.uint8)
+    lib().oracle_sq8_encode(ctypes.c_int64(n), ctypes.c_int(d), _p(x, ctypes.c_float), _p(trained, ctypes.c_float),
+                            _p(codes, ctypes.c_uint8))
+    return codes
+
+
+def sq8_decode(codes, trained):
+    codes, trained = np.ascontiguousarray(codes, np.uint8), _f32(trained)
+    n, d = codes.shape
+    x = np.empty((n, d), np.float32)
+    lib().oracle_sq8_decode(ctypes.c_int64(n), ctypes.c_int(d), _p(codes, ctypes.c_uint8), _p(trained, ctypes.c_float),
+                            _p(x, ctypes.c_float))
+    return x
+
+
+def rerank_sq8(q, codes, trained, cand_I, k):
+    """IndexRefine over an IndexScalarQuantizer(QT_8bit) store: scores of the candidate ids against the
+    decoded rows, k best under (score desc, id asc)."""
+    q, trained = _f32(q), _f32(trained)
+    codes = np.ascontiguousarray(codes, np.uint8)
+    cand_I = np.ascontiguousarray(cand_I, np.int64)
+    nq, d = q.shape
+    kc = cand_I.shape[1]
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    lib().oracle_rerank_sq8(ctypes.c_int64(nq), ctypes.c_int(d), _p(q, ctypes.c_float), _p(codes, ctypes.c_uint8),
+                            _p(trained, ctypes.c_float), ctypes.c_int(kc), _p(cand_I, ctypes.c_int64), ctypes.c_int(k),
+                            _p(D, ctypes.c_float), _p(I, ctypes.c_int64))
+    return D, I
+
+
 def merge(D_parts, I_parts):
     """k-way merge of per-shard results [nparts,nq,k] -> (D[nq,k], I[nq,k])."""
     D_parts = _f32(D_parts)

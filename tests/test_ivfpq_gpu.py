@@ -650,6 +650,47 @@ def test_write_read_roundtrip(faiss, tmp_path, kind):
     assert np.array_equal(I, I2) and np.array_equal(bits(D), bits(D2))
 
 
+def test_sparse_lists_through_the_c_abi_match_the_documented_layout(faiss, tmp_path):
+    """A non-empty index with at most half of its lists filled takes faiss's 'sprs' size encoding:
+    a vector of 2 * non_empty words ({list, size} pairs flattened).  The C ABI writer
+    (mi_index_save) must emit the bytes the independent pure-Python writer (faiss_io.dump, pinned
+    to a hand-assembled file in tests/test_faiss_io.py) emits, and mi_index_load must read both."""
+    import importlib
+    fio = importlib.import_module("abstracts_search_amd.faiss_io")
+    rng = np.random.default_rng(5)
+    d, nlist, M = 64, 16, 8
+    cent = rng.standard_normal((nlist, d)).astype(np.float32)
+    cb = (0.3 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+    idx = make_index(faiss, cent, cb)
+    lists = np.repeat(np.array([2, 5, 11], np.int32), [7, 1, 4])        # 3 of 16 lists non-empty -> "sprs"
+    codes = rng.integers(0, 256, (len(lists), M)).astype(np.uint8)
+    ids = rng.integers(0, 1 << 40, len(lists)).astype(np.int64)
+    idx.add_codes(lists, codes, ids)
+    idx.nprobe = 16
+    q = rng.standard_normal((5, d)).astype(np.float32)
+    D, I = idx.search(q, 10)
+    f, g = str(tmp_path / "abi.faiss"), str(tmp_path / "py.faiss")
+    faiss.write_index(idx, f)
+    raw = open(f, "rb").read()
+    assert b"sprs" in raw
+    sizes = np.bincount(lists, minlength=nlist).astype(np.int64)
+    fio.dump(g, d=d, nlist=nlist, M=M, nbits=8, metric=fio.METRIC_INNER_PRODUCT, by_residual=True, nprobe=16,
+             is_trained=True, centroids=cent, codebook=cb, sizes=sizes, codes=codes, ids=ids)
+    assert raw == open(g, "rb").read()
+    z = fio.parse(f)
+    assert np.array_equal(z["sizes"], sizes) and np.array_equal(z["codes"], codes) and np.array_equal(z["ids"], ids)
+    for path in (f, g):
+        idx2 = faiss.read_index(path)
+        assert idx2.ntotal == len(lists)
+        D2, I2 = idx2.search(q, 10)
+        assert np.array_equal(I, I2) and np.array_equal(bits(D), bits(D2))
+    # an odd word count cannot be a list of pairs
+    bad = raw.replace(b"sprs" + np.uint64(6).tobytes(), b"sprs" + np.uint64(5).tobytes())
+    open(f, "wb").write(bad)
+    with pytest.raises(Exception):
+        faiss.read_index(f)
+
+
 def test_train_builds_a_usable_index(faiss):
     """train() is setup (not bit-pinned): check it yields a working quantiser
     with good recall on clustered data."""
@@ -927,6 +968,52 @@ def test_refine_sqfp16_matches_oracle(faiss, oracle):
     assert np.array_equal(It.cpu().numpy(), Ie) and np.array_equal(bits(Dt.cpu().numpy()), bits(De))
     with pytest.raises(NotImplementedError):
         idx.refine_index.search(q, k)
+
+
+@pytest.mark.parametrize("d,M", [(128, 16), (96, 8), (1024, 64)])
+def test_refine_sq8_matches_oracle(faiss, oracle, d, M):
+    """factory "IVF..,PQ..,Refine(SQ8)" (faiss IndexScalarQuantizer QT_8bit: per-dimension ranges trained as min /
+    span, one byte per component): trained ranges, code bytes, decoded rows and re-ranked (D, I) all bit-equal to the
+    oracle's restatement.  d = 128 / 1024 take the streaming kernel (whole 128-byte pieces), d = 96 the simple one."""
+    import torch
+    nlist, n, nq, k = 32, 6000, 40, 10
+    cent, cb, x, q = random_problem(78 + d, d, M, nlist, n, nq)
+    x[:, 7] = 0.5                                              # a constant dimension: vdiff == 0
+    idx = faiss.index_factory(d, f"IVF{nlist},PQ{M},Refine(SQ8)", faiss.METRIC_INNER_PRODUCT)
+    sqi = idx.refine_index
+    assert isinstance(sqi, faiss.IndexScalarQuantizer) and sqi.qtype == faiss.ScalarQuantizer.QT_8bit and not idx.is_trained
+    idx.base_index.set_centroids(cent)
+    idx.base_index.set_codebook(cb)
+    with pytest.raises(RuntimeError, match="not trained"):
+        sqi.add(x[:4])
+    # training in two chunks (host rows, then device rows merged in) = training on all rows at once
+    tr_rows = x[: n // 2]
+    sqi.train(tr_rows[:1000])
+    sqi.train(torch.from_numpy(tr_rows[1000:]).cuda(), merge=True)
+    tr = oracle.sq8_train(tr_rows)
+    assert np.array_equal(bits(sqi.sq.trained), bits(tr)) and idx.is_trained
+    idx.add(x[: n // 3])                                       # rows outside the trained ranges clip
+    idx.add(torch.from_numpy(x[n // 3:]).cuda())
+    codes = oracle.sq8_encode(x, tr)
+    xd = oracle.sq8_decode(codes, tr)
+    assert np.array_equal(bits(sqi.reconstruct_n(0, n)), bits(xd))
+    ln, pq = oracle.encode(x, cent, cb, True)
+    off, lc, li = oracle.build_lists(ln, pq, np.arange(n), nlist)
+    for nprobe, kf in ((4, 4), (8, 16), (32, 30)):
+        faiss.ParameterSpace().set_index_parameters(idx, f"nprobe={nprobe},k_factor_rf={kf}")
+        D, I = idx.search(q, k)
+        _, cand = oracle.search(q, cent, cb, off, lc, li, nprobe, k * kf, True)
+        De, Ie = oracle.rerank_sq8(q, codes, tr, cand, k)
+        assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De)), (nprobe, kf)
+    Dt, It = idx.search(torch.from_numpy(q).cuda(), k)
+    assert np.array_equal(It.cpu().numpy(), Ie) and np.array_equal(bits(Dt.cpu().numpy()), bits(De))
+    # the ranges travel: a second store given the trained vector encodes the same bytes
+    other = faiss.IndexScalarQuantizer(d, faiss.ScalarQuantizer.QT_8bit, faiss.METRIC_INNER_PRODUCT)
+    other.sq.trained = tr
+    other.add(x[:100])
+    assert np.array_equal(bits(other.reconstruct_n(0, 100)), bits(xd[:100]))
+    with pytest.raises(RuntimeError, match="already holds"):
+        other.train(x[:10])
 
 
 def test_refine_add_with_ids_only_accepts_positions(faiss):

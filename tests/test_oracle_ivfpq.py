@@ -171,3 +171,53 @@ def test_l2_restatement_against_float64(oracle):
     D, I = oracle.search_l2(q, cent, cb, np.zeros(nlist + 1, np.int64), np.zeros((0, M), np.uint8), np.zeros(0, np.int64),
                             np.zeros(0, np.float32), 3, k)
     assert (I == -1).all() and (D == np.finfo(np.float32).max).all()
+
+
+def test_sq8_restatement_against_float64_and_the_documented_formulas(oracle):
+    """ScalarQuantizer QT_8bit (faiss ',Refine(SQ8)'): per-dimension min / max training, code =
+    (int)(255 * clip((x - vmin) / vdiff)), decode = vmin + (code + 0.5) / 255 * vdiff, inner-product
+    re-rank over the decoded rows.  Pinned here against numpy restatements of those published formulas
+    (float64 for the values, float32 step by step for the bits of the codes)."""
+    rng = np.random.default_rng(12)
+    n, d, nq, kc, k = 3000, 64, 9, 40, 10
+    x = (rng.standard_normal((n, d)) * rng.uniform(0.01, 2.0, d)).astype(np.float32)
+    x[:, 5] = 0.25                                   # a constant dimension: vdiff == 0 -> code 0, decodes to vmin
+    tr = oracle.sq8_train(x)
+    assert np.array_equal(tr[:d], x.min(0)) and np.array_equal(tr[d:], x.max(0) - x.min(0))
+    # encode: float32 step by step, as faiss's scalar code does; out-of-range inputs clip
+    y = np.concatenate([x[:500], x[:50] * 3.0])
+    codes = oracle.sq8_encode(y, tr)
+    vmin, vdiff = tr[:d], tr[d:]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xi = ((y - vmin).astype(np.float32) / vdiff).astype(np.float32)
+    xi = np.where(vdiff == 0, np.float32(0), np.clip(xi, np.float32(0), np.float32(1))).astype(np.float32)
+    want = (np.float32(255) * xi).astype(np.float32).astype(np.int64)
+    assert np.array_equal(codes, want.astype(np.uint8))
+    assert codes.min() == 0 and codes.max() == 255 and (codes[:, 5] == 0).all()
+    # decode: within an ulp or two of the float64 value of the published formula, and the quantisation error is <= half a step
+    xd = oracle.sq8_decode(codes, tr)
+    ref = vmin.astype(np.float64) + (codes.astype(np.float64) + 0.5) / 255.0 * vdiff.astype(np.float64)
+    assert np.abs(xd - ref).max() <= 4e-7 * max(1.0, np.abs(ref).max())
+    inside = np.abs(xd[:500] - x[:500])
+    assert (inside <= 0.5 * vdiff / 255.0 * (1 + 1e-4) + 2e-6 * np.abs(x).max()).all()
+    # re-rank: scores against float64 dot products of the decoded rows; order = (score desc, id asc); -1 slots skipped
+    allc = oracle.sq8_encode(x, tr)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    cand = rng.integers(0, n, (nq, kc))
+    cand[:, 3] = cand[:, 7]                          # a duplicated candidate: both copies rank, adjacent
+    cand[0, 10:] = -1
+    D, I = oracle.rerank_sq8(q, allc, tr, cand, k)
+    dec = oracle.sq8_decode(allc, tr).astype(np.float64)
+    for qi in range(nq):
+        ids = cand[qi][cand[qi] >= 0]
+        sc = dec[ids] @ q[qi].astype(np.float64)
+        order = sorted(range(len(ids)), key=lambda j: (-sc[j], ids[j]))[:k]
+        got = I[qi][I[qi] >= 0]
+        # float64 may order near-ties differently from the f32 chain: compare as sets of (id) and the scores closely
+        assert sorted(got.tolist()) == sorted(ids[order].tolist()) or np.abs(np.sort(sc[order])[::-1] - D[qi][:len(order)]).max() < 1e-4
+        assert np.abs(np.sort(sc[order])[::-1] - D[qi][:len(order)]).max() < 1e-4 * max(1.0, np.abs(sc).max())
+        assert all(D[qi][j] > D[qi][j + 1] or (D[qi][j] == D[qi][j + 1] and I[qi][j] <= I[qi][j + 1]) for j in range(len(got) - 1))
+    assert sorted(I[0].tolist()) == sorted(cand[0][:10].tolist())      # 10 live candidates (one id twice): all of them, no -1
+    cand[1, 4:] = -1
+    D, I = oracle.rerank_sq8(q, allc, tr, cand, k)
+    assert (I[1][4:] == -1).all() and (D[1][4:] == -np.finfo(np.float32).max).all() and (I[1][:4] >= 0).all()
