@@ -4,8 +4,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -96,6 +99,44 @@ inline bool is_device_ptr(const void *ptr) {
     }
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
+
+// roctx ranges around the stages of a call (coarse / lut / scan / rerank / exchange; embed / layer / pool), so that a
+// rocprofv3 --marker-trace summary groups the launches by stage.  The roctx library is bound at run time and only when a
+// profiler brought it into the process (or MI_ROCTX=1 asks for it): without one a Range is a branch on a cached flag.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    bool on = false;
+    Roctx() {
+        const char *names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+        const char *e = std::getenv("MI_ROCTX");
+        if (e && e[0] == '0') return;
+        const bool force = e && e[0] != '0';
+        for (const char *n : names) {
+            void *lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (force ? 0 : RTLD_NOLOAD));
+            if (!lib) continue;
+            push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+            on = push && pop;
+            if (on) return;
+        }
+    }
+};
+inline Roctx &roctx() {
+    static Roctx r;
+    return r;
+}
+struct Range {
+    bool on;
+    explicit Range(const char *name) : on(roctx().on) {
+        if (on) roctx().push(name);
+    }
+    ~Range() {
+        if (on) roctx().pop();
+    }
+    Range(const Range &) = delete;
+    Range &operator=(const Range &) = delete;
+};
 
 struct DeviceGuard {
     int prev = 0;

@@ -101,6 +101,8 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
     unsigned nblocks = 8u * per;
     g.tail_first = 0;
     g.tail_split = 1;
+    static const int order_env = std::getenv("MI_TILE_ORDER") ? std::atoi(std::getenv("MI_TILE_ORDER")) : -1;
+    g.order = order_env >= 0 ? order_env : 0;
     if (epi == EPI_RESID && !g.bias && !std::getenv("MI_NO_TAIL_SPLIT")) {
         const int ncu = 256, nb = 8 * per;
         const int main_b = nb / ncu * ncu, rem = nb - main_b;
@@ -543,11 +545,13 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         h->tiled_ok = true;
     }
     if (few) tiled_lk.unlock();
+    Range stack_range("mi_encoder:stack");
     hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, st, ws.ws_ids.get<int32_t>(),
                        h->embed.get<bf16_t>(), H, T, x);
     MI_HIP(hipGetLastError());
     for (int l = 0; l < c.n_layers; ++l) {
         LayerW &w = h->layers[l];
+        Range layer_range("mi_encoder:layer");
         hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln1.get<float>(), H, T,
                            c.rms_eps, xn);
         GemmArgs g{};
@@ -751,6 +755,7 @@ int mi_encoder_encode(mi_encoder *h, int nseq, const int32_t *ids, const int32_t
         mi_encoder::WS &ws = lease.w;
         Batch b = prepare_batch(h, ws, nseq, ids, cu, st);
         run_stack(h, ws, b, st);
+        Range pool_range("mi_encoder:pool+dense+normalise");
         const mi_encoder_cfg &c = h->cfg;
         const int od = c.dense_out ? c.dense_out : c.hidden;
         const bool od_dev = is_device_ptr(out);

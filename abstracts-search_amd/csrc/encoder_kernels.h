@@ -157,10 +157,45 @@ __device__ __forceinline__ void dma16(const void *gptr, void *lds_wave_base) {
 // itself is "grouped": GM consecutive M tiles are walked together along N, so
 // the ~32 tiles an XCD has in flight form a GM x 4 patch that shares GM A row
 // blocks and 4 W strips in L2 instead of streaming a different W strip per tile.
-__device__ __forceinline__ bool tile_coords(int tiles_m, int tiles_n, int &tm, int &tn, int vb = -1) {
+//
+// order 1 ("chip patches", big tiles): what the 256 CUs have in flight at one time is ONE 16 x 16 patch of tiles, of
+// which XCD x holds the 8 (M) x 4 (N) sub-patch (x & 1, x >> 1) -- block b of a full patch is tile j = b % 256 with
+// XCD j % 8 and slot j / 8 inside the sub-patch.  The per-XCD L2 sharing is that of order 0, but the eight XCDs now
+// fetch the SAME 16 A row blocks and 16 W strips at about the same time instead of eight unrelated sets, and
+// consecutive patches walk down M under the same W strips: what misses an L2 is then mostly in the memory-side cache.
+// Full patches first (256 tiles each: XCD alignment holds), then the right edge (N remainder) and the bottom edge
+// (M remainder) in grouped order.
+__device__ __forceinline__ bool tile_coords_patch(int tiles_m, int tiles_n, int &tm, int &tn, int b) {
+    const int ntiles = tiles_m * tiles_n;
+    if (b >= ntiles) return false;
+    const int fm = tiles_m >> 4, fn = tiles_n >> 4, rm = tiles_m & 15, rn = tiles_n & 15;
+    const int nfull = fm * fn * 256;
+    if (b < nfull) {
+        const int p = b >> 8, j = b & 255, x = j & 7, i = j >> 3;
+        const int pn = p / fm, pm = p - pn * fm;
+        tm = pm * 16 + (x & 1) * 8 + (i & 7);
+        tn = pn * 16 + (x >> 1) * 4 + (i >> 3);
+        return true;
+    }
+    int r = b - nfull;
+    const int right = fm * 16 * rn;                      // rows [0, 16 fm) x columns [16 fn, tiles_n)
+    if (r < right) {
+        const int g = r / (16 * rn), within = r - g * (16 * rn);
+        tn = fn * 16 + within / 16;
+        tm = g * 16 + (within & 15);
+        return true;
+    }
+    r -= right;                                          // rows [16 fm, tiles_m) x all columns
+    tn = r / rm;
+    tm = fm * 16 + (r - tn * rm);
+    return true;
+}
+
+__device__ __forceinline__ bool tile_coords(int tiles_m, int tiles_n, int &tm, int &tn, int vb = -1, int order = 0) {
     constexpr int GM = 8;
     const int ntiles = tiles_m * tiles_n;
     const int bid = vb < 0 ? (int)blockIdx.x : vb;
+    if (order == 1) return tile_coords_patch(tiles_m, tiles_n, tm, tn, bid);
     const int per = (ntiles + 7) / 8;
     const int t = (bid & 7) * per + (bid >> 3);
     if (t >= ntiles || (bid >> 3) >= per) return false;
@@ -192,6 +227,7 @@ struct GemmArgs {
     // tail_first) is split tail_split ways along K so that it occupies the whole chip
     // for 1/tail_split of a tile time instead of a few CUs for a full one
     int tail_first, tail_split;
+    int order;         // tile order of the 256x256 slab kernel: 0 = per-XCD grouped eighths, 1 = chip patches (tile_coords)
     unsigned long long *ts;   // null, or [workgroups][8] s_memtime stamps of the first tile (MI_GEMM_TS=1 profile launch)
     float *gmax;       // EPI_F32H on the 8-wave slab kernel: null, or [M][ld_gmax] maxima of every 64-column group of a
     int ld_gmax;       // score row (+inf if the group holds a non-finite score) -- what select_refine_kernel's cut needs
@@ -821,7 +857,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 vb = g.tail_first + j / ksplit_;
             }
         }
-        if (!tile_coords(g.tiles_m, g.tiles_n, tm_, tn_, vb)) return false;
+        if (!tile_coords(g.tiles_m, g.tiles_n, tm_, tn_, vb, g.order)) return false;
         kt0_ = (nt_all * ks) / ksplit_;                      // first 64-column tile of this K slice
         nk_ = 2 * ((nt_all * (ks + 1)) / ksplit_ - kt0_);    // K steps = slabs of this slice (even)
         return true;

@@ -1132,6 +1132,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
                          const float *pre_D = nullptr) {
     const int M = h->M;
     const bool l2 = h->metric == MI_METRIC_L2;
+    std::unique_ptr<Range> stage = std::make_unique<Range>("mi_ivfpq:coarse+lut");
     int32_t *cidx = w.cidx.as<int32_t>((size_t)nq * nprobe);
     float *cdis = w.cdis.as<float>((size_t)nq * nprobe);
     float *lut = w.lut.as<float>((size_t)nq * M * 256);
@@ -1217,6 +1218,8 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     if (cD_out) MI_HIP(hipMemcpyAsync(cD_out, cdis, (size_t)nq * nprobe * 4, hipMemcpyDeviceToHost, st));
     if (lut_out) MI_HIP(hipMemcpyAsync(lut_out, lut, (size_t)nq * M * 256 * 4, hipMemcpyDeviceToHost, st));
     if (stop_after_lut) return;
+    stage.reset();
+    stage = std::make_unique<Range>("mi_ivfpq:scan+topk");
 
     const int nslice = choose_nslice(h, nq, nprobe, std::min(k, 64));
     const int npass = (k + 63) / 64;
@@ -1661,6 +1664,7 @@ int mi_shards_search(mi_shards *s, int64_t nq, const float *q, int k, int nprobe
             if (mi_index_search(s->local, nq, q, k, nprobe, Dl, Il, stream)) throw Error(last_error());
         }
         // the path's one exchange step
+        Range stage("mi_ivfpq:exchange+merge");
         RcclApi &r = rccl(nullptr);
         nccl_check(r, r.AllGather(send, recv, blk, /* ncclInt8 */ 0, s->comm, st), "ncclAllGather");
         launch_merge(reinterpret_cast<const float *>(recv), reinterpret_cast<const int64_t *>(recv + d_bytes), s->world,
@@ -2206,6 +2210,7 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
                    "rerank: q, cand_I, D and I must be all host or all device pointers");
         FlatLease lease = lease_ws(h, stream);
         mi_flat::WS &w = lease.w;
+        Range stage("mi_ivfpq:rerank");
         const float *qs = q;
         const int64_t *ci = cand_I;
         if (!dev) {
@@ -2319,6 +2324,7 @@ int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int6
         int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(4096, ((int64_t)1 << 28) / h->ntotal));
         FlatLease lease = lease_ws(h, stream);
         mi_flat::WS &w = lease.w;
+        Range stage("mi_ivfpq:flat_search");
         for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
             const int64_t m = std::min(chunk, nq - c0);
             const float *qs = q + (size_t)c0 * h->d;

@@ -317,7 +317,7 @@ int main(int argc, char **argv) {
         if (fb) {
             const size_t n0 = carry.n, limit = n0 + block_bytes;
             if (fb->cap < limit + 1) { fb->in = (char *)realloc(fb->in, limit + 1); fb->cap = limit + 1; if (!fb->in) { perror("realloc"); return 2; } }
-            memcpy(fb->in, carry.p, n0);
+            if (n0) memcpy(fb->in, carry.p, n0);        /* (memcpy's arguments may not be NULL even for 0 bytes: UBSan) */
             size_t n = n0;
             carry.n = 0;
             while (n < limit) {                         /* fill the block (a pipe hands over 64 KiB at a time) */
@@ -367,5 +367,6 @@ int main(int argc, char **argv) {
     pthread_cond_broadcast(&cv_work);
     pthread_mutex_unlock(&mu);
     if (!stopped) for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
+    free(th);   /* (the block buffers die with the process; the workers of an early-stopped stream may still hold theirs) */
     return 0;
 }

@@ -34,9 +34,10 @@ def build(force: bool = False) -> str:
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
+        so = os.environ.get("MI_ORACLE_SO") or _SO        # tests/test_sanitizers.py: an ASan + UBSan build of the same source
+        if so == _SO and not os.path.exists(_SO):
             build()
-        _lib = ctypes.CDLL(_SO)
+        _lib = ctypes.CDLL(so)
         _lib.oracle_num_threads.restype = ctypes.c_int
     return _lib
 

@@ -970,11 +970,11 @@ def test_refine_sqfp16_matches_oracle(faiss, oracle):
         idx.refine_index.search(q, k)
 
 
-@pytest.mark.parametrize("d,M", [(128, 16), (96, 8), (1024, 64)])
+@pytest.mark.parametrize("d,M", [(128, 16), (192, 48), (1024, 64)])
 def test_refine_sq8_matches_oracle(faiss, oracle, d, M):
     """factory "IVF..,PQ..,Refine(SQ8)" (faiss IndexScalarQuantizer QT_8bit: per-dimension ranges trained as min /
     span, one byte per component): trained ranges, code bytes, decoded rows and re-ranked (D, I) all bit-equal to the
-    oracle's restatement.  d = 128 / 1024 take the streaming kernel (whole 128-byte pieces), d = 96 the simple one."""
+    oracle's restatement.  d = 128 / 1024 take the streaming kernel (whole 128-byte pieces), d = 192 the simple one."""
     import torch
     nlist, n, nq, k = 32, 6000, 40, 10
     cent, cb, x, q = random_problem(78 + d, d, M, nlist, n, nq)
