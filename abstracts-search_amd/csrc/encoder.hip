@@ -102,7 +102,9 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
     g.tail_first = 0;
     g.tail_split = 1;
     static const int order_env = std::getenv("MI_TILE_ORDER") ? std::atoi(std::getenv("MI_TILE_ORDER")) : -1;
-    g.order = order_env >= 0 ? order_env : 0;
+    // measured at 29 312 tokens (tools/gemm_bench.py, profiles/r03_gemm_tile_order.txt): chip patches +3 / +5 / +5 % on the
+    // QKV / O / down shapes (N <= 2048), -1.5 % on gate-up (N = 17 920: 70 tile columns) -- so by the width of the GEMM
+    g.order = order_env >= 0 ? order_env : (g.tiles_n <= 16 ? 1 : 0);
     if (epi == EPI_RESID && !g.bias && !std::getenv("MI_NO_TAIL_SPLIT")) {
         const int ncu = 256, nb = 8 * per;
         const int main_b = nb / ncu * ncu, rem = nb - main_b;
@@ -329,9 +331,24 @@ struct mi_encoder {
     std::map<std::string, bool> loaded;
     // activations and staging buffers, one set per stream an encode is issued on: calls on different streams overlap on
     // the GPU and concurrent host threads (one stream each) never share a buffer; threads that share a stream take turns
+    // A pinned host staging slot for one call's token ids / positions / work lists: the upload is ONE asynchronous copy
+    // out of it, the slot's event says when the GPU has consumed it.  Three slots in rotation: a call never waits for the
+    // GPU unless three earlier calls on the stream have not even started -- mi_encoder_encode only enqueues work.
+    struct Pinned {
+        int32_t *p = nullptr;
+        size_t cap = 0;          // int32 elements
+        hipEvent_t ev = nullptr;
+        bool in_flight = false;
+        ~Pinned() {
+            if (ev) (void)hipEventDestroy(ev);
+            if (p) (void)hipHostFree(p);
+        }
+    };
     struct WS {
         std::mutex mu;
-        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_ids, ws_pos, ws_meta, ws_out, ws_stage;
+        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_up, ws_out, ws_stage;
+        Pinned pin[3];
+        int pin_next = 0;
         size_t vt_zeroed = 0, att_zeroed = 0;
     };
     std::vector<std::pair<void *, std::unique_ptr<WS>>> ws_sets;
@@ -409,71 +426,95 @@ void import_tensor(mi_encoder *h, const void *data, int dtype, int64_t rows, int
 
 struct Batch {
     int nseq = 0, T_real = 0, T_pad = 0, Lmax = 0, nwork = 0;
-    // device pointers into ws_meta
-    int32_t *seq_start = nullptr, *seq_len = nullptr, *work_seq = nullptr, *work_q0 = nullptr, *tok_map = nullptr;
+    // device pointers into ws_up
+    int32_t *ids = nullptr, *pos = nullptr;
+    int32_t *seq_start = nullptr, *seq_len = nullptr, *work_seq = nullptr, *work_q0 = nullptr, *tok_map = nullptr, *out_rows = nullptr;
 };
 
-// Build the padded-packed layout (every sequence starts at a multiple of 8
-// tokens, T_pad a multiple of 32) and upload ids / positions / work lists.
-Batch prepare_batch(mi_encoder *h, mi_encoder::WS &ws, int nseq, const int32_t *ids, const int32_t *cu, hipStream_t st) {
+// Build the padded-packed layout (every sequence starts at a multiple of 8 tokens, T_pad a multiple of 32) straight into a
+// pinned staging slot and upload ids / positions / work lists (/ output rows) with one asynchronous copy.  Host `ids` /
+// `cu_seqlens` / `out_rows` are consumed before the call returns; nothing here waits for the GPU.
+Batch prepare_batch(mi_encoder *h, mi_encoder::WS &ws, int nseq, const int32_t *ids, const int32_t *cu, const int32_t *out_rows,
+                    hipStream_t st) {
     MI_REQUIRE(nseq > 0, "encode: nseq must be positive");
-    std::vector<int32_t> cu_h((size_t)nseq + 1);
-    if (is_device_ptr(cu)) MI_HIP(hipMemcpy(cu_h.data(), cu, cu_h.size() * 4, hipMemcpyDeviceToHost));
-    else std::memcpy(cu_h.data(), cu, cu_h.size() * 4);
-    MI_REQUIRE(cu_h[0] == 0, "encode: cu_seqlens[0] must be 0");
-    const int T_real = cu_h[nseq];
-    std::vector<int32_t> ids_h((size_t)T_real);
-    if (is_device_ptr(ids)) MI_HIP(hipMemcpy(ids_h.data(), ids, ids_h.size() * 4, hipMemcpyDeviceToHost));
-    else std::memcpy(ids_h.data(), ids, ids_h.size() * 4);
+    std::vector<int32_t> cu_dev, ids_dev;                 // device-resident inputs (rare): fetched, which does synchronise
+    if (is_device_ptr(cu)) {
+        cu_dev.resize((size_t)nseq + 1);
+        MI_HIP(hipMemcpy(cu_dev.data(), cu, cu_dev.size() * 4, hipMemcpyDeviceToHost));
+        cu = cu_dev.data();
+    }
+    MI_REQUIRE(cu[0] == 0, "encode: cu_seqlens[0] must be 0");
+    const int T_real = cu[nseq];
+    MI_REQUIRE(T_real >= nseq, "encode: cu_seqlens must be increasing");
+    if (is_device_ptr(ids)) {
+        ids_dev.resize((size_t)T_real);
+        MI_HIP(hipMemcpy(ids_dev.data(), ids, ids_dev.size() * 4, hipMemcpyDeviceToHost));
+        ids = ids_dev.data();
+    }
     Batch b;
     b.nseq = nseq;
     b.T_real = T_real;
-    std::vector<int32_t> start(nseq), len(nseq), wseq, wq0, tok_map((size_t)T_real);
-    int cur = 0;
+    int cur = 0, nwork = 0;
     for (int i = 0; i < nseq; ++i) {
-        const int L = cu_h[i + 1] - cu_h[i];
+        const int L = cu[i + 1] - cu[i];
         MI_REQUIRE(L >= 1, "encode: empty sequence");
         MI_REQUIRE(L <= h->cfg.max_seq_len, "encode: sequence longer than max_seq_len");
-        start[i] = cur;
-        len[i] = L;
         b.Lmax = std::max(b.Lmax, L);
-        for (int q0 = 0; q0 < L; q0 += 64) {
-            wseq.push_back(i);
-            wq0.push_back(q0);
-        }
+        nwork += (L + 63) / 64;
         cur += (L + 7) & ~7;
     }
     b.T_pad = (cur + 31) & ~31;   // GEMM rows are clamped / guarded, no tile multiple needed
-    b.nwork = (int)wseq.size();
-    std::vector<int32_t> ids_pad((size_t)b.T_pad, 0), pos((size_t)b.T_pad, 0);
-    for (int i = 0; i < nseq; ++i)
-        for (int t = 0; t < len[i]; ++t) {
-            const int32_t id = ids_h[(size_t)cu_h[i] + t];
-            MI_REQUIRE(id >= 0 && id < h->cfg.vocab_size, "encode: token id out of range");
-            ids_pad[(size_t)start[i] + t] = id;
-            pos[(size_t)start[i] + t] = t;
-            tok_map[(size_t)cu_h[i] + t] = start[i] + t;
+    b.nwork = nwork;
+    const size_t n_up = (size_t)b.T_pad * 2 + (size_t)nseq * 3 + (size_t)nwork * 2 + (size_t)T_real;
+    mi_encoder::Pinned &pin = ws.pin[ws.pin_next];
+    ws.pin_next = (ws.pin_next + 1) % 3;
+    if (pin.in_flight) {                                  // (three calls ago: long consumed unless the stream is that far behind)
+        MI_HIP(hipEventSynchronize(pin.ev));
+        pin.in_flight = false;
+    }
+    if (!pin.ev) MI_HIP(hipEventCreateWithFlags(&pin.ev, hipEventDisableTiming));
+    if (pin.cap < n_up) {
+        if (pin.p) MI_HIP(hipHostFree(pin.p));
+        pin.p = nullptr;
+        pin.cap = n_up + n_up / 4 + 1024;
+        MI_HIP(hipHostMalloc(reinterpret_cast<void **>(&pin.p), pin.cap * 4, hipHostMallocDefault));
+    }
+    int32_t *ids_pad = pin.p, *pos = ids_pad + b.T_pad, *start = pos + b.T_pad, *len = start + nseq, *wseq = len + nseq,
+            *wq0 = wseq + nwork, *tok_map = wq0 + nwork, *rows = tok_map + T_real;
+    std::memset(ids_pad, 0, (size_t)b.T_pad * 8);         // ids and positions of the padding tokens
+    cur = 0;
+    int wk = 0;
+    const int vocab = h->cfg.vocab_size;
+    for (int i = 0; i < nseq; ++i) {
+        const int c0 = cu[i], L = cu[i + 1] - c0;
+        start[i] = cur;
+        len[i] = L;
+        rows[i] = out_rows ? out_rows[i] : i;
+        for (int q0 = 0; q0 < L; q0 += 64) {
+            wseq[wk] = i;
+            wq0[wk++] = q0;
         }
-    int32_t *d_ids = ws.ws_ids.as<int32_t>((size_t)b.T_pad);
-    int32_t *d_pos = ws.ws_pos.as<int32_t>((size_t)b.T_pad);
-    const size_t meta_n = (size_t)nseq * 2 + (size_t)b.nwork * 2 + (size_t)T_real;
-    int32_t *d_meta = ws.ws_meta.as<int32_t>(meta_n);
-    std::vector<int32_t> meta;
-    meta.reserve(meta_n);
-    meta.insert(meta.end(), start.begin(), start.end());
-    meta.insert(meta.end(), len.begin(), len.end());
-    meta.insert(meta.end(), wseq.begin(), wseq.end());
-    meta.insert(meta.end(), wq0.begin(), wq0.end());
-    meta.insert(meta.end(), tok_map.begin(), tok_map.end());
-    MI_HIP(hipMemcpyAsync(d_ids, ids_pad.data(), ids_pad.size() * 4, hipMemcpyHostToDevice, st));
-    MI_HIP(hipMemcpyAsync(d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, st));
-    MI_HIP(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st));
-    MI_HIP(hipStreamSynchronize(st));  // the host vectors die with this scope
-    b.seq_start = d_meta;
-    b.seq_len = d_meta + nseq;
-    b.work_seq = d_meta + 2 * (size_t)nseq;
-    b.work_q0 = b.work_seq + b.nwork;
-    b.tok_map = b.work_q0 + b.nwork;
+        for (int t = 0; t < L; ++t) {
+            const int32_t id = ids[(size_t)c0 + t];
+            MI_REQUIRE(id >= 0 && id < vocab, "encode: token id out of range");
+            ids_pad[(size_t)cur + t] = id;
+            pos[(size_t)cur + t] = t;
+            tok_map[(size_t)c0 + t] = cur + t;
+        }
+        cur += (L + 7) & ~7;
+    }
+    int32_t *d = ws.ws_up.as<int32_t>(n_up);
+    MI_HIP(hipMemcpyAsync(d, pin.p, n_up * 4, hipMemcpyHostToDevice, st));
+    MI_HIP(hipEventRecord(pin.ev, st));
+    pin.in_flight = true;
+    b.ids = d;
+    b.pos = d + b.T_pad;
+    b.seq_start = b.pos + b.T_pad;
+    b.seq_len = b.seq_start + nseq;
+    b.work_seq = b.seq_len + nseq;
+    b.work_q0 = b.work_seq + nwork;
+    b.tok_map = b.work_q0 + nwork;
+    b.out_rows = b.tok_map + T_real;
     return b;
 }
 
@@ -546,7 +587,7 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
     }
     if (few) tiled_lk.unlock();
     Range stack_range("mi_encoder:stack");
-    hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, st, ws.ws_ids.get<int32_t>(),
+    hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, st, b.ids,
                        h->embed.get<bf16_t>(), H, T, x);
     MI_HIP(hipGetLastError());
     for (int l = 0; l < c.n_layers; ++l) {
@@ -563,7 +604,7 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
             const int nh_qk = c.n_heads + c.n_kv_heads;
             const int64_t n = (int64_t)T * nh_qk * (hd / 16);
             hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, qk, h->qk_cols,
-                               nh_qk, hd, ws.ws_pos.get<int32_t>(), h->rope_cos.get<float>(),
+                               nh_qk, hd, b.pos, h->rope_cos.get<float>(),
                                h->rope_sin.get<float>(), T);
         }
         AttnArgs a{};
@@ -745,21 +786,37 @@ int mi_encoder_out_dim(mi_encoder *h, int *out) {
     });
 }
 
-int mi_encoder_encode(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu, int normalize, float *out,
-                      void *stream) {
-    return guard([&] {
+}  // extern "C"
+
+namespace {
+
+// out_rows != null: embedding i goes to row out_rows[i] of `out` (device pointer) -- the caller's un-sort, done by the
+// last kernel of the call instead of an indexing pass behind it
+void encode_impl(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu, int normalize, float *out,
+                 const int32_t *out_rows, void *stream) {
+    {
         MI_REQUIRE(h && ids && cu && out, "null argument");
         DeviceGuard dg(h->device);
         hipStream_t st = as_stream(stream);
         EncLease lease = lease_ws(h, stream);
         mi_encoder::WS &ws = lease.w;
-        Batch b = prepare_batch(h, ws, nseq, ids, cu, st);
+        const bool od_dev = is_device_ptr(out);
+        MI_REQUIRE(!out_rows || od_dev, "encode: out_rows needs a device output");
+        Batch b = prepare_batch(h, ws, nseq, ids, cu, out_rows, st);
         run_stack(h, ws, b, st);
         Range pool_range("mi_encoder:pool+dense+normalise");
         const mi_encoder_cfg &c = h->cfg;
         const int od = c.dense_out ? c.dense_out : c.hidden;
-        const bool od_dev = is_device_ptr(out);
-        float *o = od_dev ? out : ws.ws_out.as<float>((size_t)nseq * od);
+        float *o = (od_dev && !out_rows) ? out : ws.ws_out.as<float>((size_t)nseq * od);
+        auto finish = [&] {
+            if (out_rows) {
+                hipLaunchKernelGGL(scatter_rows_kernel, dim3(nseq), dim3(256), 0, st, o, od, b.out_rows, out);
+                MI_HIP(hipGetLastError());
+            } else if (!od_dev) {
+                MI_HIP(hipMemcpyAsync(out, o, (size_t)nseq * od * 4, hipMemcpyDeviceToHost, st));
+                MI_HIP(hipStreamSynchronize(st));
+            }
+        };
         PoolArgs p{};
         p.x = ws.ws_x.get<float>(); p.norm_w = h->norm_w.get<float>();
         p.dense_w = c.dense_out ? h->dense_w.get<bf16_t>() : nullptr;
@@ -791,10 +848,7 @@ int mi_encoder_encode(mi_encoder *h, int nseq, const int32_t *ids, const int32_t
                 hipLaunchKernelGGL(l2norm_rows_kernel, dim3(nseq), dim3(256), 0, st, o, od);
                 MI_HIP(hipGetLastError());
             }
-            if (!od_dev) {
-                MI_HIP(hipMemcpyAsync(out, o, (size_t)nseq * od * 4, hipMemcpyDeviceToHost, st));
-                MI_HIP(hipStreamSynchronize(st));
-            }
+            finish();
             return;
         }
         // few sequences: split the Dense rows of each over several workgroups (256 CUs to fill)
@@ -805,10 +859,25 @@ int mi_encoder_encode(mi_encoder *h, int nseq, const int32_t *ids, const int32_t
             hipLaunchKernelGGL(l2norm_rows_kernel, dim3(nseq), dim3(256), 0, st, o, od);
             MI_HIP(hipGetLastError());
         }
-        if (!od_dev) {
-            MI_HIP(hipMemcpyAsync(out, o, (size_t)nseq * od * 4, hipMemcpyDeviceToHost, st));
-            MI_HIP(hipStreamSynchronize(st));
-        }
+        finish();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_encoder_encode(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu, int normalize, float *out,
+                      void *stream) {
+    return guard([&] { encode_impl(h, nseq, ids, cu, normalize, out, nullptr, stream); });
+}
+
+int mi_encoder_encode_rows(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu, int normalize, float *out,
+                           const int32_t *out_rows, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(out_rows, "null argument");
+        MI_REQUIRE(!is_device_ptr(out_rows), "mi_encoder_encode_rows: out_rows is a host array");
+        encode_impl(h, nseq, ids, cu, normalize, out, out_rows, stream);
     });
 }
 
@@ -819,7 +888,7 @@ int mi_encoder_hidden(mi_encoder *h, int nseq, const int32_t *ids, const int32_t
         hipStream_t st = as_stream(stream);
         EncLease lease = lease_ws(h, stream);
         mi_encoder::WS &ws = lease.w;
-        Batch b = prepare_batch(h, ws, nseq, ids, cu, st);
+        Batch b = prepare_batch(h, ws, nseq, ids, cu, nullptr, st);
         run_stack(h, ws, b, st);
         const int H = h->cfg.hidden;
         const bool od_dev = is_device_ptr(out);

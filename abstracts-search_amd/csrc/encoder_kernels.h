@@ -1782,6 +1782,14 @@ __global__ void __launch_bounds__(256) l2norm_rows_kernel(float *__restrict__ ou
     for (int c = tid; c < n; c += 256) row[c] *= scale;
 }
 
+// dst[rows[i]][:] = src[i][:] (the un-sort of a length-sorted pass, one workgroup per row)
+__global__ void __launch_bounds__(256) scatter_rows_kernel(const float *__restrict__ src, int n, const int32_t *__restrict__ rows,
+                                                           float *__restrict__ dst) {
+    const float *s = src + (size_t)blockIdx.x * n;
+    float *d = dst + (size_t)rows[blockIdx.x] * n;
+    for (int c = threadIdx.x; c < n; c += 256) d[c] = s[c];
+}
+
 // ---------------------------------------------------------------------
 // weight import: dst_bf16[map(r)][c] = convert(src[r][c]),
 // map(r) = (r / blk) * stride + off + r % blk

@@ -400,6 +400,15 @@ void launch_scan(int M, const ScanArgs &a, hipStream_t st) {
 // one query per workgroup in up to 160 KiB (gfx950's LDS per CU); beyond that the candidates are
 // laid out as one row of pairs per query in `scratch` and reduced by select_pairs_kernel
 // (k <= 4096).  8 shards x k = 4096, or re-ranking k * k_factor = 50 000 candidates, all work.
+// the K best pairs of every row (K <= 4096: 48 KiB of LDS per workgroup; K <= 8192: 96 KiB)
+void launch_select_pairs(const float *S, const int64_t *IDS, int64_t ld, const int32_t *p_prefix, int nprobe, int K, int64_t rows,
+                         float *D, int64_t *I, int64_t ldo, hipStream_t st) {
+    MI_REQUIRE(K <= SELP_CAP, "select_pairs: K too large (max 8192)");
+    if (K <= SELB_CAP) hipLaunchKernelGGL(select_pairs_kernel<16>, dim3((unsigned)rows), dim3(256), 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
+    else hipLaunchKernelGGL(select_pairs_kernel<32>, dim3((unsigned)rows), dim3(256), 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
+    MI_HIP(hipGetLastError());
+}
+
 void launch_merge(const float *ps, const int64_t *pid, int nparts, int64_t stride_p,
                   int64_t stride_q, int64_t nq, int k, float *D, int64_t *I, int64_t ldo,
                   int out_off, float *bs, int64_t *bid, hipStream_t st, int64_t stride_p_id = -1,
@@ -427,7 +436,7 @@ void launch_merge(const float *ps, const int64_t *pid, int nparts, int64_t strid
         MI_HIP(hipGetLastError());
         return;
     }
-    MI_REQUIRE(k <= SELB_CAP, "merge: k too large (max 4096)");
+    MI_REQUIRE(k <= SELP_CAP, "merge: k too large (max 8192)");
     MI_REQUIRE(!bs && !bid, "internal: bounded merge on the large path");
     const int64_t ld = (((int64_t)nparts * k + 63) / 64) * 64;
     DevBuf local;
@@ -442,8 +451,7 @@ void launch_merge(const float *ps, const int64_t *pid, int nparts, int64_t strid
         const int64_t m = std::min(qc, nq - c0);
         hipLaunchKernelGGL(gather_parts_kernel, dim3((unsigned)m), dim3(256), 0, st, ps + (size_t)c0 * stride_q,
                            pid + (size_t)c0 * stride_q, nparts, stride_p, stride_p_id, stride_q, k, ld, rs, rid, prefix, im);
-        hipLaunchKernelGGL(select_pairs_kernel, dim3((unsigned)m), dim3(256), 0, st, rs, rid, ld, prefix, 1, k,
-                           D + (size_t)c0 * ldo + out_off, I + (size_t)c0 * ldo + out_off, ldo);
+        launch_select_pairs(rs, rid, ld, prefix, 1, k, m, D + (size_t)c0 * ldo + out_off, I + (size_t)c0 * ldo + out_off, ldo, st);
         MI_HIP(hipGetLastError());
     }
     if (!scratch) MI_HIP(hipStreamSynchronize(st));   // `local` dies with this scope
@@ -1289,8 +1297,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
             if (const char *e = std::getenv("MI_SCAN_NW")) a.nw = std::atoi(e) == 16 ? 16 : 8;
             a.all_s = all_s; a.all_id = all_id; a.all_ld = R;
             launch_scan(M, a, st);
-            hipLaunchKernelGGL(select_pairs_kernel, dim3((unsigned)m), dim3(256), 0, st, all_s, all_id, R,
-                               a.p_prefix, nprobe, k, Ddev + (size_t)c0 * k, Idev + (size_t)c0 * k, (int64_t)k);
+            launch_select_pairs(all_s, all_id, R, a.p_prefix, nprobe, k, m, Ddev + (size_t)c0 * k, Idev + (size_t)c0 * k, (int64_t)k, st);
             MI_HIP(hipGetLastError());
         }
         l2_finish();
@@ -1350,7 +1357,7 @@ int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe, 
                     void *stream) {
     return guard([&] {
         MI_REQUIRE(h && (nq == 0 || (q && D && I)), "null argument");
-        MI_REQUIRE(k >= 1 && k <= 4096, "k must be in [1, 4096]");
+        MI_REQUIRE(k >= 1 && k <= SELP_CAP, "k must be in [1, 8192]");
         MI_REQUIRE(nprobe >= 1, "nprobe must be >= 1");
         require_trained(h);
         if (nq == 0) return;
@@ -1443,7 +1450,7 @@ int mi_index_search_preassigned(mi_index *h, int64_t nq, const float *q, int k, 
                                 void *stream) {
     return guard([&] {
         MI_REQUIRE(h && (nq == 0 || (q && D && I && coarse_I && coarse_D)), "null argument");
-        MI_REQUIRE(k >= 1 && k <= 4096, "k must be in [1, 4096]");
+        MI_REQUIRE(k >= 1 && k <= SELP_CAP, "k must be in [1, 8192]");
         MI_REQUIRE(nprobe >= 1, "nprobe must be >= 1");
         require_trained(h);
         if (nq == 0) return;
@@ -1655,7 +1662,7 @@ int mi_shards_search(mi_shards *s, int64_t nq, const float *q, int k, int nprobe
         // this shard, all queries: straight into the two halves of the send buffer
         if (s->refine) {
             const int kb = k * s->k_factor;
-            MI_REQUIRE(kb <= 4096, "k * k_factor must be <= 4096");
+            MI_REQUIRE(kb <= SELP_CAP, "k * k_factor must be <= 8192");
             float *cD = b->cand_D.as<float>((size_t)nq * kb);
             int64_t *cI = b->cand_I.as<int64_t>((size_t)nq * kb);
             if (mi_index_search(s->local, nq, q, kb, nprobe, cD, cI, stream)) throw Error(last_error());

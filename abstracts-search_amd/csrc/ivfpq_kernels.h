@@ -804,6 +804,7 @@ __global__ void __launch_bounds__(256)
 // More than SELB_CAP survivors (masses of tied scores): select_by_insertion.
 // ---------------------------------------------------------------------
 constexpr int SELB_CAP = 4096;
+constexpr int SELP_CAP = 8192;   // select_pairs_kernel<32>: the largest k of an IVF-PQ search (candidate lists of the refine stage)
 
 __global__ void __launch_bounds__(256)
     select_big_kernel(const float *__restrict__ S, int64_t ldS, int n, int K, int32_t *__restrict__ out_i32,
@@ -942,12 +943,16 @@ __global__ void __launch_bounds__(256)
 // tied at T still do not fit -- the id of the last tied entry to keep by a descent over
 // the id bits; exactly K entries survive.
 // ---------------------------------------------------------------------
+// VPT_ = 16: K <= 4096 (CAP = 256 VPT_ survivor slots, as many group maxima); VPT_ = 32: K <= 8192 -- the refine stage's
+// candidate lists at the recall >= 0.95 operating point of the whole 207 M index (k * k_factor_rf of several thousand).
+template <int VPT_>
 __global__ void __launch_bounds__(256)
     select_pairs_kernel(const float *__restrict__ S, const int64_t *__restrict__ IDS, int64_t ld,
                         const int32_t *__restrict__ p_prefix, int nprobe, int K, float *__restrict__ D,
                         int64_t *__restrict__ I, int64_t ldo) {
-    __shared__ unsigned sk[SELB_CAP];
-    __shared__ int64_t sid[SELB_CAP];
+    constexpr int CAP = 256 * VPT_;
+    __shared__ unsigned sk[CAP];
+    __shared__ int64_t sid[CAP];
     __shared__ int wcnt[2][4];
     __shared__ int c_cnt, c_eq;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -956,7 +961,7 @@ __global__ void __launch_bounds__(256)
     const int n = p_prefix[row * (nprobe + 1) + nprobe] * 64;
     const float *r = S + row * ld;
     const int64_t *ids = IDS + row * ld;
-    constexpr int VPT = 16, TILE = 256 * VPT;
+    constexpr int VPT = VPT_, TILE = 256 * VPT;
     const bool one_tile = n <= TILE;
     unsigned key[VPT];
     auto load_tile = [&](int base) {
@@ -1016,7 +1021,7 @@ __global__ void __launch_bounds__(256)
                 for (int j = 0; j < VPT; ++j) {
                     if (m[j]) {
                         const int pos = o + lane_prefix_count(m[j]);
-                        if (((m[j] >> lane) & 1ull) && pos < SELB_CAP) {
+                        if (((m[j] >> lane) & 1ull) && pos < CAP) {
                             sk[pos] = key[j];
                             sid[pos] = ids[base + j * 256 + tid];
                         }
@@ -1029,7 +1034,7 @@ __global__ void __launch_bounds__(256)
     };
     compact([&](unsigned kx, int) { return kx >= T0; });
     int Sn = c_cnt;
-    if (Sn > SELB_CAP) {   // workgroup-uniform
+    if (Sn > CAP) {   // workgroup-uniform
         // exact route: counts over the whole row, streamed (rare: masses of tied scores)
         auto count_row = [&](auto pred) -> int {
             int c = 0;
@@ -1056,7 +1061,7 @@ __global__ void __launch_bounds__(256)
         const int ceq = count_row([&](unsigned kx, int) { return kx == T; });
         if (tid == 0) c_cnt = 0;
         __syncthreads();
-        if (cgt + ceq <= SELB_CAP) {
+        if (cgt + ceq <= CAP) {
             compact([&](unsigned kx, int) { return kx >= T; });
         } else {
             // the (K - cgt)-th smallest id among the entries tied at T: the largest U with
@@ -1079,7 +1084,7 @@ __global__ void __launch_bounds__(256)
                 return atomicAdd(&c_eq, 1) < take_eq;
             });
         }
-        Sn = c_cnt;   // <= SELB_CAP now
+        Sn = c_cnt;   // <= CAP now
     }
     int P = 64;
     while (P < Sn) P <<= 1;

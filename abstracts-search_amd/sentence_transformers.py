@@ -55,6 +55,7 @@ class _Lib:
                 "mi_encoder_missing": [v, POINTER(c_int)],
                 "mi_encoder_out_dim": [v, POINTER(c_int)],
                 "mi_encoder_encode": [v, c_int, v, v, c_int, v, v],
+                "mi_encoder_encode_rows": [v, c_int, v, v, c_int, v, v, v],
                 "mi_encoder_hidden": [v, c_int, v, v, v, v],
                 "mi_encoder_profile_enable": [v, c_int],
                 "mi_encoder_profile_read": [v, POINTER(c_double), POINTER(c_double)],
@@ -326,6 +327,7 @@ class SentenceTransformer:
         result is put back in input order; a batch is packed, not padded, and sized by
         `token_budget` (see above) rather than by a sequence count: `batch_size` only takes
         effect when `token_budget` is None."""
+        import itertools
         import torch
         n = len(token_lists)
         dim = self.get_sentence_embedding_dimension()
@@ -334,15 +336,16 @@ class SentenceTransformer:
         order = sorted(range(n), key=lambda i: -len(token_lists[i]))
         stream = c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         lib = _Lib.get()
+        # every pass only ENQUEUES work (the C ABI stages the token ids through pinned memory and writes embedding i
+        # straight to row sel[i] of `out`): the packing of the next pass overlaps the GPU running this one
         for sel in self._passes(order, token_lists, batch_size):
-            lens = [len(token_lists[i]) for i in sel]
             cu = np.zeros(len(sel) + 1, np.int32)
-            np.cumsum(lens, out=cu[1:])
-            ids = np.fromiter((t for i in sel for t in token_lists[i]), np.int32, count=int(cu[-1]))
-            part = torch.empty((len(sel), dim), dtype=torch.float32, device=dev)
-            _check(lib.mi_encoder_encode(self._h, len(sel), c_void_p(ids.ctypes.data), c_void_p(cu.ctypes.data),
-                                         int(normalize_embeddings), c_void_p(part.data_ptr()), stream))
-            out[torch.as_tensor(sel, device=dev)] = part
+            np.cumsum([len(token_lists[i]) for i in sel], out=cu[1:])
+            ids = np.fromiter(itertools.chain.from_iterable(token_lists[i] for i in sel), np.int32, count=int(cu[-1]))
+            rows = np.asarray(sel, np.int32)
+            _check(lib.mi_encoder_encode_rows(self._h, len(sel), c_void_p(ids.ctypes.data), c_void_p(cu.ctypes.data),
+                                              int(normalize_embeddings), c_void_p(out.data_ptr()), c_void_p(rows.ctypes.data),
+                                              stream))
         if as_tensor:
             return out
         return out.cpu().numpy()

@@ -73,6 +73,14 @@ int mi_encoder_out_dim(mi_encoder *h, int *out);
 int mi_encoder_encode(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu_seqlens,
                       int normalize, float *out, void *stream);
 
+/* The same with the caller's un-sort folded in: embedding i is written to row out_rows[i] of `out` (a device pointer;
+ * out_rows a host int32 [nseq]).  sentence-transformers sorts its inputs by length and restores the input order
+ * afterwards; here the last kernel of the call does that.  With host `ids` / `cu_seqlens` both encode calls only ENQUEUE
+ * work on `stream` and return (token ids travel through pinned staging slots): the host prepares the next pass while the
+ * GPU runs this one. */
+int mi_encoder_encode_rows(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu_seqlens,
+                           int normalize, float *out, const int32_t *out_rows, void *stream);
+
 /* Parity hook: the stack's last hidden state after the final norm,
  * float32 [T][hidden] (host or device), packed like ids. */
 int mi_encoder_hidden(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu_seqlens,

@@ -121,7 +121,8 @@ int mi_index_get_params(mi_index *h, int *d, int *nlist, int *M, int *nbits, int
 int mi_index_set_nprobe(mi_index *h, int nprobe);
 
 /* IndexIVFPQ.search with index.nprobe = nprobe.
- * q float32 [nq][d]; D float32 [nq][k]; I int64 [nq][k].  1 <= k <= 4096. */
+ * q float32 [nq][d]; D float32 [nq][k]; I int64 [nq][k].  1 <= k <= 8192 (k > 64: every (score, id) of the
+ * probed lists is stored in one pass and the k best kept: the candidate lists of the refine stage). */
 int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe,
                     float *D, int64_t *I, void *stream);
 

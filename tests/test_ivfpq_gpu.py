@@ -413,12 +413,17 @@ def test_large_k(faiss, oracle, monkeypatch, multipass):
     idx.add_with_ids(x, ids)
     ln, codes = oracle.encode(x, cent, cb)
     off, lc, li = oracle.build_lists(ln, codes, ids, 40)
-    for k, nprobe in ((100, 17), (640, 40), (70, 1)):
+    # 4096 < k <= 8192: the 8192-slot instantiation of select_pairs_kernel (the refine stage's candidate lists at the
+    # whole-index recall >= 0.95 point); k = 8192 of 30 000 at nprobe 40, and k larger than what 17 probes hold
+    big = () if multipass else ((4097, 40), (6000, 40), (8192, 40), (8000, 17))
+    for k, nprobe in ((100, 17), (640, 40), (70, 1)) + big:
         idx.nprobe = nprobe
         D, I = idx.search(q, k)
         De, Ie = oracle.search(q, cent, cb, off, lc, li, nprobe, k)
         assert np.array_equal(I, Ie), (k, nprobe)
         assert np.array_equal(bits(D), bits(De)), (k, nprobe)
+    with pytest.raises(RuntimeError, match="8192"):
+        idx.search(q, 8193)
     # masses of tied scores: 7000 copies of one vector (one list, identical codes) next to
     # 500 others, first with distinct ids (the cut falls inside the tie: lowest ids win),
     # then with every id used twice
@@ -434,7 +439,7 @@ def test_large_k(faiss, oracle, monkeypatch, multipass):
         idx.add_with_ids(x, ids)
         ln, codes = oracle.encode(x, cent, cb)
         off, lc, li = oracle.build_lists(ln, codes, ids, 4)
-        for k in (65, 300, 1024):
+        for k in (65, 300, 1024) + (() if multipass else (5000, 7100, 8000)):   # 7100: the cut falls inside the 7000-way tie
             idx.nprobe = 4
             D, I = idx.search(q, k)
             De, Ie = oracle.search(q, cent, cb, off, lc, li, 4, k)
@@ -544,7 +549,7 @@ def test_edge_cases(faiss, oracle):
     with pytest.raises(AssertionError):
         idx.search(q[:, :32], 3)
     with pytest.raises(RuntimeError):
-        idx.search(q, 5000)
+        idx.search(q, 9000)                      # k <= 8192
     untrained = faiss.IndexIVFPQ(64, 16, 8, 8, faiss.METRIC_INNER_PRODUCT)
     with pytest.raises(RuntimeError, match="not trained"):
         untrained.add(x)

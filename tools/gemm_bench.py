@@ -6,6 +6,8 @@ import abstracts_search_amd.sentence_transformers as st
 M = int(os.environ.get("M", 32768))
 for name, N, K in (("qkv", 2048, 1536), ("o", 1536, 1536), ("gate_up", 17920, 1536), ("down", 1536, 8960), ("square", 4096, 4096)):
     A = torch.randn((M, K), device="cuda").bfloat16(); W = (torch.randn((N, K), device="cuda") / K ** 0.5).bfloat16()
+    if os.environ.get("ZERO") == "1":          # zero operands toggle no data lines: what the same schedule does without the power throttle
+        A.zero_(); W.zero_()
     for _ in range(3): C = st.gemm_bf16(A, W)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
