@@ -101,6 +101,8 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
     unsigned nblocks = 8u * per;
     g.tail_first = 0;
     g.tail_split = 1;
+    float *part = g.part;
+    g.part = nullptr;                                     // set again below if every tile is split
     static const int order_env = std::getenv("MI_TILE_ORDER") ? std::atoi(std::getenv("MI_TILE_ORDER")) : -1;
     // measured at 29 312 tokens (tools/gemm_bench.py, profiles/r03_gemm_tile_order.txt): chip patches +3 / +5 / +5 % on the
     // QKV / O / down shapes (N <= 2048), -1.5 % on gate-up (N = 17 920: 70 tile columns) -- so by the width of the GEMM
@@ -130,7 +132,31 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
             }
         }
     }
+    // Too few tiles to fill the chip (a few hundred tokens through a residual GEMM: 18 tiles at 576 x 1536): split EVERY
+    // tile along K so that ~256 workgroups run, the slices' partial tiles through a workspace (whole-line f32 stores) and one
+    // reduction pass -- no atomics (576 x 1536 x 14 of them would take ~110 us at the chip's 115 G atomic adds per second).
+    int split_all = 1;
+    if (epi == EPI_RESID && part && g.tail_split == 1 && nblocks < 200) {
+        const int ntiles = g.tiles_m * g.tiles_n, nt64 = g.K / 64;
+        int S = std::min({16, 256 / std::max(1, ntiles), nt64 / 4});      // >= 4 K tiles (8 steps) per slice
+        static const int s_env = std::getenv("MI_SPLITK") ? std::atoi(std::getenv("MI_SPLITK")) : -1;
+        if (s_env >= 0) S = std::min(s_env, nt64);
+        if (S >= 2 && (size_t)S * g.M * g.N * 4 <= g.part_bytes) {
+            split_all = S;
+            g.part = part;
+            g.tail_first = 0;
+            g.tail_split = S;
+            nblocks = (unsigned)(ntiles * S);
+        }
+    }
     dim3 grid(nblocks), block(128 * WN_);
+    auto finish_split = [&] {
+        if (split_all == 1) return;
+        const int64_t n4 = (int64_t)g.M * (g.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, g.X, (int64_t)g.ldc, g.part, split_all,
+                           g.M, g.N, g.bias);
+        MI_HIP(hipGetLastError());
+    };
     // more work units than CUs: one persistent workgroup per CU could walk its units and request the next unit's first
     // slabs before the epilogue of the current one.
     // Off by default: it measured no faster (1 136 vs 1 169 TF on the QKV shape) -- what a tile pays outside its K loop
@@ -156,6 +182,7 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
         default: throw Error("bad epilogue");
     }
     MI_HIP(hipGetLastError());
+    finish_split();
 }
 
 // narrow tiles (WNT = 1): no SwiGLU instantiation (it pairs two N tiles inside a wave)
@@ -231,6 +258,14 @@ void launch_ring32(int epi, GemmArgs g, hipStream_t st) {
     MI_HIP(hipGetLastError());
 }
 
+// whether splitting every 256x256 tile of a residual GEMM along K (launch_slab's workspace path) fills the chip
+bool mid_split_pays(const GemmArgs &g) {
+    const int ntiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), nt64 = g.K / 64;
+    const int S = std::min({16, 256 / std::max(1, ntiles), nt64 / 4});
+    static const int min_wg = std::getenv("MI_MID_MIN_WG") ? std::atoi(std::getenv("MI_MID_MIN_WG")) : 96;
+    return g.M > 64 && S >= 2 && ntiles * S >= min_wg && (size_t)S * g.M * g.N * 4 <= g.part_bytes;
+}
+
 void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
     MI_REQUIRE(g.K % 64 == 0, "encoder GEMM: K must be a multiple of 64");
     MI_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "encoder GEMM: leading dimensions must be multiples of 8");
@@ -274,6 +309,13 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             launch_ring<8, 4, 2, 4, 4>(epi, g, st);
         } else if (cfg == "mid") {
             launch_ring<4, 4, 2, 2, 4>(epi, g, st);
+        } else if (cfg == "small" && !force && epi == EPI_RESID && g.part && g.N % 8 == 0 && mid_split_pays(g) &&
+                   !(std::getenv("MI_MID") && std::string(std::getenv("MI_MID")) == "old")) {
+            // a few hundred tokens through a residual GEMM: the 256x256 slab kernel with EVERY tile split along K through the
+            // workspace (launch_slab) -- 576 x 1536 x 8960: 18 tiles x 14 slices = 252 workgroups of 20 K steps + one reduction
+            // pass, where 128x128 tiles with K split three ways by f32 atomics took 76 us
+            if (g.K >= 4096) launch_slab<2>(epi, g, st);
+            else launch_slab<4>(epi, g, st);
         } else if (cfg == "small") {
             if (epi == EPI_RESID && !g.bias && g.K >= 4096 && !force) {
                 // a few hundred tokens through the down projection (K = 8960): 128x32 tiles are one
@@ -346,7 +388,7 @@ struct mi_encoder {
     };
     struct WS {
         std::mutex mu;
-        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_up, ws_out, ws_stage;
+        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_up, ws_out, ws_stage, ws_part;
         Pinned pin[3];
         int pin_next = 0;
         size_t vt_zeroed = 0, att_zeroed = 0;
@@ -355,16 +397,14 @@ struct mi_encoder {
     std::mutex mu;           // guards ws_sets, the lazily built fragment-major weights and the profiling events
     DevBuf ws_stage;         // load_tensor staging (exclusive calls)
     bool tiled_ok = false;   // fragment-major weight copies are current
-    // profiling
+    // profiling: the GEMM launches of the most recent encode (arguments as launched), replayed back to back between two
+    // HIP events by mi_encoder_profile_read -- like the index library's scan replay; per-launch event pairs measured
+    // 3-4 % short of rocprofv3's per-kernel durations in the same run
     bool prof = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    struct Launch { int epi; GemmArgs g; };
+    std::vector<Launch> prof_launches;
+    hipStream_t prof_stream = nullptr;
     double prof_flops = 0.0;
-    ~mi_encoder() {
-        for (auto &e : evs) {
-            (void)hipEventDestroy(e.first);
-            (void)hipEventDestroy(e.second);
-        }
-    }
 };
 
 namespace {
@@ -519,18 +559,11 @@ Batch prepare_batch(mi_encoder *h, mi_encoder::WS &ws, int nseq, const int32_t *
 }
 
 void timed_gemm(mi_encoder *h, int epi, const GemmArgs &g, hipStream_t st) {
-    if (!h->prof) {
-        launch_gemm(epi, g, st);
-        return;
-    }
-    hipEvent_t e0, e1;
-    MI_HIP(hipEventCreate(&e0));
-    MI_HIP(hipEventCreate(&e1));
-    MI_HIP(hipEventRecord(e0, st));
     launch_gemm(epi, g, st);
-    MI_HIP(hipEventRecord(e1, st));
+    if (!h->prof) return;
     std::lock_guard<std::mutex> hl(h->mu);
-    h->evs.emplace_back(e0, e1);
+    h->prof_launches.push_back({epi, g});
+    h->prof_stream = st;
     h->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
 }
 
@@ -561,7 +594,19 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         ws.att_zeroed = ws.ws_att.cap;
     }
     bf16_t *hb = ws.ws_h.as<bf16_t>((size_t)T * I);
+    // split-K workspace of the residual GEMMs when the tokens are too few for their tiles to fill the chip (launch_slab)
+    float *part = nullptr;
+    size_t part_bytes = 0;
+    if (T > 64 && T <= 4096) {
+        part_bytes = (size_t)16 * T * H * 4;
+        part = static_cast<float *>(ws.ws_part.reserve(part_bytes));
+    }
 
+    if (h->prof) {
+        std::lock_guard<std::mutex> hl(h->mu);
+        h->prof_launches.clear();
+        h->prof_flops = 0.0;
+    }
     // few tokens (a query, or a handful): the GEMMs stream the weights once and are bound by how
     // they read them -- use the fragment-major copies (a second copy of the layer weights, built
     // on first use: 16-row x 64-byte fragments of a row-major matrix are 16 DRAM pages per wave-load)
@@ -622,7 +667,7 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         MI_HIP(hipGetLastError());
         GemmArgs o{};
         o.A = att; o.lda = h->q_cols; o.W = w.wo.get<bf16_t>(); o.ldw = h->q_cols; o.M = T; o.N = H; o.K = h->q_cols;
-        o.X = x; o.ldc = H;
+        o.X = x; o.ldc = H; o.part = part; o.part_bytes = part_bytes;
         if (few) o.Wt = w.wo_t.get<bf16_t>();
         timed_gemm(h, EPI_RESID, o, st);
         hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln2.get<float>(), H, T,
@@ -633,6 +678,7 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         timed_gemm(h, EPI_SWIGLU, u, st);
         GemmArgs d{};
         d.A = hb; d.lda = I; d.W = w.wd.get<bf16_t>(); d.ldw = I; d.M = T; d.N = H; d.K = I; d.X = x; d.ldc = H;
+        d.part = part; d.part_bytes = part_bytes;
         if (few) d.Wt = w.wd_t.get<bf16_t>();
         timed_gemm(h, EPI_RESID, d, st);
     }
@@ -915,18 +961,27 @@ int mi_encoder_profile_read(mi_encoder *h, double *gemm_ms, double *gemm_flops) 
         MI_REQUIRE(h, "null argument");
         DeviceGuard dg(h->device);
         std::lock_guard<std::mutex> hl(h->mu);
-        double tot = 0.0;
-        for (auto &e : h->evs) {
-            MI_HIP(hipEventSynchronize(e.second));
-            float ms = 0.f;
-            MI_HIP(hipEventElapsedTime(&ms, e.first, e.second));
-            tot += ms;
-            (void)hipEventDestroy(e.first);
-            (void)hipEventDestroy(e.second);
-        }
-        h->evs.clear();
-        if (gemm_ms) *gemm_ms = tot;
+        MI_REQUIRE(!h->prof_launches.empty(), "mi_encoder_profile_read: no encode has run with profiling on");
+        hipStream_t st = h->prof_stream;
+        // the launches of that encode again, back to back on its stream (its workspaces are still in place; the residual
+        // GEMMs add into the stream once more, which nobody reads afterwards): one warm pass, then `reps` timed ones
+        const int reps = 3;
+        hipEvent_t e0, e1;
+        MI_HIP(hipEventCreate(&e0));
+        MI_HIP(hipEventCreate(&e1));
+        for (auto &l : h->prof_launches) launch_gemm(l.epi, l.g, st);
+        MI_HIP(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r)
+            for (auto &l : h->prof_launches) launch_gemm(l.epi, l.g, st);
+        MI_HIP(hipEventRecord(e1, st));
+        MI_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        MI_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (gemm_ms) *gemm_ms = (double)ms / reps;
         if (gemm_flops) *gemm_flops = h->prof_flops;
+        h->prof_launches.clear();
         h->prof_flops = 0.0;
     });
 }

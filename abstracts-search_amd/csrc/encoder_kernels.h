@@ -228,6 +228,10 @@ struct GemmArgs {
     // for 1/tail_split of a tile time instead of a few CUs for a full one
     int tail_first, tail_split;
     int order;         // tile order of the 256x256 slab kernel: 0 = per-XCD grouped eighths, 1 = chip patches (tile_coords)
+    size_t part_bytes; // capacity of `part`
+    float *part;       // EPI_RESID slab kernel with tail_first == 0 (EVERY tile split tail_split ways along K: too few tiles to fill
+                       // the chip): slice ks writes its partial tile to part[ks][M][N] (plain whole-line stores, no atomics) and
+                       // splitk_reduce_kernel adds the slices to X in ascending order -- bit-reproducible, unlike atomics
     unsigned long long *ts;   // null, or [workgroups][8] s_memtime stamps of the first tile (MI_GEMM_TS=1 profile launch)
     float *gmax;       // EPI_F32H on the 8-wave slab kernel: null, or [M][ld_gmax] maxima of every 64-column group of a
     int ld_gmax;       // score row (+inf if the group holds a non-finite score) -- what select_refine_kernel's cut needs
@@ -846,6 +850,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     // A work unit = an output tile, or (residual epilogue, wave-quantisation tail) a K slice of one: units >=
     // tail_first are (tile, slice) pairs whose partial sums meet in f32 atomics.  PERSIST: one workgroup per CU walks
     // units blockIdx.x + i * gridDim.x (the same XCD, the same tile window per round as one-unit workgroups).
+    int ks_cur = 0;                                          // K slice of the current unit
     auto decode = [&](int unit, int &tm_, int &tn_, int &ksplit_, int &kt0_, int &nk_) -> bool {
         int ks = 0, vb = unit;
         ksplit_ = 1;
@@ -858,6 +863,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
             }
         }
         if (!tile_coords(g.tiles_m, g.tiles_n, tm_, tn_, vb, g.order)) return false;
+        ks_cur = ks;
         kt0_ = (nt_all * ks) / ksplit_;                      // first 64-column tile of this K slice
         nk_ = 2 * ((nt_all * (ks + 1)) / ksplit_ - kt0_);    // K steps = slabs of this slice (even)
         return true;
@@ -1035,7 +1041,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 }
             }
         } else if constexpr ((EPI == EPI_RESID || EPI == EPI_F32H) && !PERSIST) {
-            if (ksplit == 1) {
+            if (ksplit == 1 || (EPI == EPI_RESID && g.part)) {
                 // X += acc through a wave-private LDS staging block: straight from the MFMA layout an instruction
                 // touches 16 rows x 64 B, and the memory pipe charges ~3.5 cycles per (instruction, 128-byte line)
                 // whatever the bytes (tools/micro/store_pattern.hip: 128 KiB in 4.3 us as 64-byte segments, 1.6 us
@@ -1052,6 +1058,17 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 for (int j = 0; j < WNT; ++j)
                     *reinterpret_cast<f32x4 *>(stg + li * ROWF + j * 16 + 4 * lg) = acc[i][j];
                 const int c4 = lane % LPR, col = n0 + wn * CW + c4 * 4;
+                if (EPI == EPI_RESID && ksplit > 1) {     // a K slice's partial tile -> its plane of the workspace (whole lines)
+                    float *pp = g.part + (size_t)ks_cur * g.M * g.N;
+#pragma unroll
+                    for (int it = 0; it < 16 / RPI; ++it) {
+                        const int r = it * RPI + lane / LPR;
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + r * ROWF + c4 * 4);
+                        if (trow + r < g.M && col < g.N)
+                            *reinterpret_cast<float4 *>(pp + (size_t)(trow + r) * g.N + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                    continue;
+                }
                 if constexpr (EPI == EPI_F32H) {          // plain f32 store (the index library's approximate scores)
 #pragma unroll
                     for (int it = 0; it < 16 / RPI; ++it) {
@@ -1139,6 +1156,32 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     if (!more) break;
     tm = tm2; tn = tn2; ksplit = ksplit2; kt0 = kt02; nk = nk2;
     }   // unit loop
+}
+
+// X[m][n] += bias[n] + sum_s part[s][m][n], s ascending (a fixed order: the split-K result is bit-reproducible).  One
+// float4 per thread; the planes are read once, X read and written once.
+__global__ void __launch_bounds__(256)
+    splitk_reduce_kernel(float *__restrict__ X, int64_t ldx, const float *__restrict__ part, int S, int M, int N,
+                         const float *__restrict__ bias) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // float4 index inside [M][N]
+    const int n4 = N >> 2;
+    if (i >= (int64_t)M * n4) return;
+    const int m = (int)(i / n4), c = (int)(i - (int64_t)m * n4) * 4;
+    const size_t plane = (size_t)M * N;
+    const float *p = part + (size_t)m * N + c;
+    float4 acc = *reinterpret_cast<const float4 *>(p);
+    for (int sidx = 1; sidx < S; ++sidx) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + sidx * plane);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(bias + c);
+        acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    float4 *px = reinterpret_cast<float4 *>(X + (size_t)m * ldx + c);
+    float4 x = *px;
+    x.x += acc.x; x.y += acc.y; x.z += acc.z; x.w += acc.w;
+    *px = x;
 }
 
 // ---------------------------------------------------------------------

@@ -515,7 +515,7 @@ def cfg4_workload(args, ctx):
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic, traffic_src = None, None
     try:                                                               # separate --pmc passes of this same command
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_cfg4_scan_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_cfg4_scan_pmc.json")))
         if (N, nlist, batch, nprobe, k, nsh) == tuple(pmc["config"]):
             traffic, traffic_src = int(pmc["corrected_bytes_per_launch"]), pmc["source"]
     except Exception:
@@ -750,11 +750,18 @@ def cfg5_workload(args, ctx):
     torch.cuda.synchronize()
     log(f"[rank {rank}] index ntotal={index.ntotal} built in {time.time() - t0:.0f}s")
     sharded = ShardedIndex(index, id_affine=(nsh, 0, 1)) if world > 1 else None
-    model, cfg = stella_random_model(args, ctx)
+    do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    host_w = {} if do_cpu else None
+    model, cfg = stella_random_model(args, ctx, keep=host_w)
+    H, I = cfg["hidden"], cfg["intermediate"]
+    qc, kc = cfg["n_heads"] * cfg["head_dim"], cfg["n_kv_heads"] * cfg["head_dim"]
+    # what one forward pass must stream at least once: the bf16 weights of the 28 layers + the Dense module
+    weight_bytes = 2 * (cfg["n_layers"] * ((qc + 2 * kc) * H + H * qc + 3 * I * H) + cfg["dense_out"] * H)
     rng = np.random.default_rng(1)                                      # the same queries on every rank
-    curve = []
+    curve, batch_toks = [], {}
     for batch in (1, 16, 256):
         toks = [rng.integers(0, cfg["vocab_size"], int(rng.integers(16, 49))).tolist() for _ in range(batch)]
+        batch_toks[batch] = toks
 
         def once(_=0):
             e = model.encode_tokens(toks, batch_size=batch, normalize_embeddings=True, as_tensor=True)
@@ -779,10 +786,37 @@ def cfg5_workload(args, ctx):
         curve.append({"batch": batch, "latency_ms_p50": round(lat[len(lat) // 2] * 1e3, 3),
                       "latency_ms_p95": round(lat[min(len(lat) - 1, int(0.95 * len(lat)))] * 1e3, 3),
                       "queries_per_s": round(steps * batch / dt, 1), "encode_alone_ms": round(enc * 1e3, 3),
-                      "tokens": sum(len(t) for t in toks)})
+                      "tokens": sum(len(t) for t in toks),
+                      # the encoder is the whole cost of these batches and its floor is one pass over the weights
+                      "weight_stream_gbs": round(weight_bytes / enc / 1e9, 1), "weight_stream_frac_of_8tbs": round(weight_bytes / enc / 8e12, 4)})
         log(f"  batch {batch}: {curve[-1]}")
     if rank != 0:
         return None
+    # roofline of the dominant kernel family at these batch sizes -- the encoder's weight-streaming GEMMs: the batch-16 point
+    # (BASELINE.json configs[4]'s middle point; batch 256 is MFMA-bound like the bulk encode, batch 1 launch-latency-bound)
+    mid = curve[1]
+    roofline = {"kernel": "encoder GEMMs at 16 queries (~570 tokens): every weight matrix streamed once per forward pass",
+                "bound": "hbm", "achieved": mid["weight_stream_gbs"], "peak": 8000.0, "unit": "GB/s", "frac": mid["weight_stream_frac_of_8tbs"],
+                "traffic": None, "bytes_per_launch": int(weight_bytes),
+                "algorithmic_bytes": "bf16 weights of the 28 decoder layers + Dense, read once per forward pass (activations and the search are < 2 % of it)",
+                "avg_launch_ms": mid["encode_alone_ms"]}
+    cpu = parity = None
+    if do_cpu:
+        from oracle import encoder_oracle as E
+        toks = batch_toks[16]
+        cu = np.concatenate([[0], np.cumsum([len(t) for t in toks])])
+        e_gpu = model.encode_tokens(toks, batch_size=16, normalize_embeddings=True, as_tensor=True)
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            ref = E.encode(E.EncoderConfig(**cfg), host_w, np.concatenate(toks), cu, True).numpy()
+            t_enc = time.perf_counter() - t1
+        cos = (e_gpu.cpu().numpy() * ref).sum(1)
+        cpu_s, par_s = cpu_baseline_ivfpq(index, e_gpu, nprobe, k, np, torch, "cfg5")
+        t_search = 16.0 / cpu_s["value"]
+        cpu = {"value": round(16.0 / (t_enc + t_search), 3), "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"the batch of 16 queries ({int(cu[-1])} tokens) end to end on the host cores: oracle encode at full depth {t_enc:.1f}s "
+                         f"(oracle/encoder_oracle.py, torch fp32) + oracle search {t_search * 1e3:.0f} ms ({cpu_s['sample'][:60]}...)"}
+        parity = {"encode_min_cosine_vs_oracle": round(float(cos.min()), 7), "encode_ok": bool(cos.min() >= 1 - 1e-3), "search": par_s}
     return {"metric": "queries/sec end to end (stella_en_1.5B_v5 encode + IVF%d,PQ64 search over %dx1024-d, batch 256)" % (nlist, N),
             "value": curve[-1]["queries_per_s"], "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(256e3 / curve[-1]["queries_per_s"], 4), "higher_is_better": True, "scaling": "strong",
@@ -790,7 +824,7 @@ def cfg5_workload(args, ctx):
             "config": {"workload": "cfg5: end-to-end encode + search, %dx1024 IVF%d,PQ64 index, query batches 1/16/256 (BASELINE.json configs[4])" % (N, nlist),
                        "nprobe": nprobe, "k": k, "query_tokens": "16-48 per query (prompt + question)",
                        "parallelism": "1 GPU" if world == 1 else f"index vector-sharded x{world}, queries replicated, one all-gather of top-k"},
-            "curve": curve, "reference_oracles": reference_oracles()}
+            "curve": curve, "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "reference_oracles": reference_oracles()}
 
 
 # ======================================================================
@@ -999,7 +1033,8 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True):
                 "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(tf / 2500.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_step": pr["gemm_flops"], "gemm_ms_per_step": round(pr["gemm_ms"], 3),
-                "timing": "HIP events on the launch stream around each of the step's GEMM launches, one profiled step after the timed blocks"}
+                "timing": "the GEMM launches of one profiled step replayed back to back on the launch stream between two HIP events "
+                          "(one warm pass, three timed; mi_encoder_profile_read), after the timed blocks"}
     cpu = parity = None
     if do_cpu:
         cpu, parity = encode_cpu_baseline(model, cfg, host_w, batches, ctx)

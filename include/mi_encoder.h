@@ -86,10 +86,10 @@ int mi_encoder_encode_rows(mi_encoder *h, int nseq, const int32_t *ids, const in
 int mi_encoder_hidden(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu_seqlens,
                       float *out, void *stream);
 
-/* Timing of the dominant kernel for the roofline: the device time (ms) spent in
- * the bf16 MFMA GEMM kernels during the most recent mi_encoder_encode() with
- * profiling on (HIP events on the launch stream around the GEMM launches), and
- * the FLOPs those launches performed. */
+/* Timing of the dominant kernel family for the roofline: with profiling on, mi_encoder_encode() records the arguments of
+ * its bf16 MFMA GEMM launches; mi_encoder_profile_read() re-issues exactly those launches back to back on the same
+ * stream between two HIP events (one warm pass, three timed) and returns the device time of one pass (ms) and the FLOPs
+ * the launches perform.  (The residual GEMMs add into the activations again: call it after the embeddings were read.) */
 int mi_encoder_profile_enable(mi_encoder *h, int on);
 int mi_encoder_profile_read(mi_encoder *h, double *gemm_ms, double *gemm_flops);
 

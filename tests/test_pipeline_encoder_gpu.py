@@ -264,6 +264,30 @@ def test_bulk_encode_path_at_stella_widths_vs_oracle(st):
     assert np.abs(e2[:128] - e).max() < 2e-3 and ((e2[:128] * ref).sum(1)).min() > 1 - 1e-3
 
 
+@pytest.mark.parametrize("nq,layers", [(1, 28), (16, 28), (256, 3)])
+def test_query_batches_at_stella_widths_vs_oracle(st, nq, layers):
+    """BASELINE.json configs[4]'s query batches (1 / 16 / 256 prompted queries of 16-48 tokens: ~30, ~570 and ~8 200
+    tokens) at stella's widths against the fp32 oracle -- the few-token path (fragment-major weights, skinny / split-K
+    tiles), the few-hundred-token path (128-row tiles, K-split down projection) and the first sizes that take the
+    256x256 slab kernel.  Full depth for 1 and 16 queries, 3 layers for 256 (the oracle's time).  (reference
+    README.md:28: the query-time app encodes with prompt_name s2p_query.)"""
+    import torch
+    from oracle import encoder_oracle as E
+    cfg = dict(st.STELLA_EN_1_5B_V5)
+    cfg["vocab_size"], cfg["n_layers"] = 4096, layers
+    W = _rand_weights_gpu(cfg, 31 + nq)
+    rng = np.random.default_rng(nq)
+    lens = rng.integers(16, 49, nq)
+    toks = [rng.integers(0, cfg["vocab_size"], int(L)).tolist() for L in lens]
+    model = st.SentenceTransformer(config=cfg, weights=W)
+    e = model.encode_tokens(toks, batch_size=nq, normalize_embeddings=True)
+    Wc = {k: v.float().cpu() for k, v in W.items()}
+    with torch.no_grad():
+        ref = E.encode(E.EncoderConfig(**cfg), Wc, np.concatenate(toks), np.concatenate([[0], np.cumsum(lens)]), True).numpy()
+    cos = (e * ref).sum(1)
+    assert cos.min() > 1 - 1e-3, (nq, cos.min())
+
+
 @pytest.mark.parametrize("tile", ["big", "slab8", "slab4", "big32", "mid", "small", "tiny", "128"])
 def test_gemm_tile_configs_vs_torch(st, tile, monkeypatch):
     """every GEMM tile configuration (forced through MI_GEMM_TILE) against torch fp32"""
