@@ -89,25 +89,30 @@ void launch_rerank_scores(const float *q, int nq, const TB *base, int64_t nb, in
     launch_gemm_gather<TB>(q, nq, base, nb, d, idx, kc, S, ldS, st);
 }
 
-// the same over a QT_8bit store (rerank_sq8_kernel; rows that are not whole 128-byte pieces: one thread per candidate)
+// the same over a QT_8bit store: the per-query table of the asymmetric score (w | A, in `tab`), then rerank_sq8_kernel (rows
+// that are not whole 128-byte pieces: one thread per candidate)
 void launch_rerank_sq8(const float *q, int nq, const uint8_t *base, int64_t nb, int d, const float *trained,
-                       const int64_t *idx, int kc, float *S, int64_t ldS, hipStream_t st) {
+                       const int64_t *idx, int kc, float *S, int64_t ldS, DevBuf &tab, hipStream_t st) {
+    float *wq = tab.as<float>((size_t)nq * d + (size_t)nq);
+    float *Aq = wq + (size_t)nq * d;
+    hipLaunchKernelGGL(sq8_query_table_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, q, (int64_t)nq, d, trained, wq, Aq);
+    MI_HIP(hipGetLastError());
     const int tiles = (kc + 63) / 64;
     const char *e = std::getenv("MI_RERANK");
     if (d % 128 == 0 && (int64_t)nq * tiles < ((int64_t)1 << 31) && !(e && std::string(e) == "simple")) {
         int nst = 3;
         if (e && std::atoi(e) > 0) nst = std::atoi(e);
         const unsigned grid = (unsigned)((int64_t)nq * tiles);
-        if (nst == 2) hipLaunchKernelGGL((rerank_sq8_kernel<2>), dim3(grid), dim3(64), 0, st, q, base, nb, d, trained, idx, kc, S, ldS, tiles);
-        else if (nst == 4) hipLaunchKernelGGL((rerank_sq8_kernel<4>), dim3(grid), dim3(64), 0, st, q, base, nb, d, trained, idx, kc, S, ldS, tiles);
-        else if (nst == 6) hipLaunchKernelGGL((rerank_sq8_kernel<6>), dim3(grid), dim3(64), 0, st, q, base, nb, d, trained, idx, kc, S, ldS, tiles);
-        else hipLaunchKernelGGL((rerank_sq8_kernel<3>), dim3(grid), dim3(64), 0, st, q, base, nb, d, trained, idx, kc, S, ldS, tiles);
+        if (nst == 2) hipLaunchKernelGGL((rerank_sq8_kernel<2>), dim3(grid), dim3(64), 0, st, wq, Aq, base, nb, d, idx, kc, S, ldS, tiles);
+        else if (nst == 4) hipLaunchKernelGGL((rerank_sq8_kernel<4>), dim3(grid), dim3(64), 0, st, wq, Aq, base, nb, d, idx, kc, S, ldS, tiles);
+        else if (nst == 6) hipLaunchKernelGGL((rerank_sq8_kernel<6>), dim3(grid), dim3(64), 0, st, wq, Aq, base, nb, d, idx, kc, S, ldS, tiles);
+        else hipLaunchKernelGGL((rerank_sq8_kernel<3>), dim3(grid), dim3(64), 0, st, wq, Aq, base, nb, d, idx, kc, S, ldS, tiles);
         MI_HIP(hipGetLastError());
         return;
     }
     const int64_t total = (int64_t)nq * kc;
-    hipLaunchKernelGGL(rerank_sq8_simple_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q, base, nb, d, trained,
-                       idx, kc, total, S, ldS);
+    hipLaunchKernelGGL(rerank_sq8_simple_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wq, Aq, base, nb, d, idx, kc,
+                       total, S, ldS);
     MI_HIP(hipGetLastError());
 }
 
@@ -395,27 +400,39 @@ void launch_scan(int M, const ScanArgs &a, hipStream_t st) {
     }
 }
 
-// k-way merge of nparts candidate lists per query.  Three tiers by the LDS one query needs
-// (12 B per candidate + 16 B per result): several queries per workgroup in the default 64 KiB;
-// one query per workgroup in up to 160 KiB (gfx950's LDS per CU); beyond that the candidates are
-// laid out as one row of pairs per query in `scratch` and reduced by select_pairs_kernel
-// (k <= 4096).  8 shards x k = 4096, or re-ranking k * k_factor = 50 000 candidates, all work.
 // the K best pairs of every row (K <= 4096: 48 KiB of LDS per workgroup; K <= 8192: 96 KiB)
+// as_set: ids only (D may be null), in no particular order -- what the first stage of a refine search needs
 void launch_select_pairs(const float *S, const int64_t *IDS, int64_t ld, const int32_t *p_prefix, int nprobe, int K, int64_t rows,
-                         float *D, int64_t *I, int64_t ldo, hipStream_t st) {
+                         float *D, int64_t *I, int64_t ldo, hipStream_t st, bool as_set = false) {
     MI_REQUIRE(K <= SELP_CAP, "select_pairs: K too large (max 8192)");
-    if (K <= SELB_CAP) hipLaunchKernelGGL(select_pairs_kernel<16>, dim3((unsigned)rows), dim3(256), 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
-    else hipLaunchKernelGGL(select_pairs_kernel<32>, dim3((unsigned)rows), dim3(256), 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
+    MI_REQUIRE(as_set || D, "select_pairs: scores requested without a buffer");
+    const dim3 grid((unsigned)rows), block(256);
+    if (as_set) {
+        if (K <= SELB_CAP) hipLaunchKernelGGL((select_pairs_kernel<16, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
+        else hipLaunchKernelGGL((select_pairs_kernel<32, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
+    } else {
+        if (K <= SELB_CAP) hipLaunchKernelGGL((select_pairs_kernel<16, false>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
+        else hipLaunchKernelGGL((select_pairs_kernel<32, false>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
+    }
     MI_HIP(hipGetLastError());
 }
 
+// k-way merge of nparts candidate lists per query.  Three tiers by the LDS one query needs
+// (12 B per candidate + 16 B per result): several queries per workgroup in the default 64 KiB;
+// one query per workgroup in up to 160 KiB (gfx950's LDS per CU); beyond that -- and for long candidate
+// lists whatever their LDS need -- the candidates are laid out as one row of pairs per query in `scratch`
+// and reduced by select_pairs_kernel.  8 shards x k = 4096, or re-ranking k * k_factor = 50 000 candidates, all work.
 void launch_merge(const float *ps, const int64_t *pid, int nparts, int64_t stride_p,
                   int64_t stride_q, int64_t nq, int k, float *D, int64_t *I, int64_t ldo,
                   int out_off, float *bs, int64_t *bid, hipStream_t st, int64_t stride_p_id = -1,
                   IdMap im = IdMap{}, DevBuf *scratch = nullptr) {
     if (stride_p_id < 0) stride_p_id = stride_p;
     const size_t per_wave = merge_wave_bytes(nparts, k);
-    if (per_wave <= 64 * 1024) {
+    // the counting tiers rank every candidate against every other one -- (nparts k)^2 / 64 steps per lane: a re-rank of 5 120
+    // candidates took 0.77 ms of a 4.6 ms step there -- so long candidate lists go to the selection tier (linear in nparts k)
+    static const int64_t big_from = std::getenv("MI_MERGE_SELECT_FROM") ? std::atoll(std::getenv("MI_MERGE_SELECT_FROM")) : 2048;
+    const bool by_selection = !bs && !bid && (int64_t)nparts * k >= big_from && k <= SELB_CAP;
+    if (per_wave <= 64 * 1024 && !by_selection) {
         int qpb = (int)std::min<size_t>(4, (64 * 1024) / per_wave);   // queries (waves) per workgroup
         if (qpb == 3) qpb = 2;
         hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((nq + qpb - 1) / qpb)), dim3(64 * qpb),
@@ -424,7 +441,7 @@ void launch_merge(const float *ps, const int64_t *pid, int nparts, int64_t strid
         MI_HIP(hipGetLastError());
         return;
     }
-    if (per_wave <= 160 * 1024) {
+    if (per_wave <= 160 * 1024 && !by_selection) {
         static bool attr_set = false;
         if (!attr_set) {
             MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_kernel),
@@ -1137,7 +1154,7 @@ static int choose_nslice(const mi_index *h, int64_t nq, int nprobe, int k = 10) 
 static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev, int k, int nprobe, float *Ddev,
                          int64_t *Idev, hipStream_t st, int32_t *cI_out, float *cD_out,
                          float *lut_out, bool stop_after_lut, const int32_t *pre_I = nullptr,
-                         const float *pre_D = nullptr) {
+                         const float *pre_D = nullptr, bool cand_set = false) {
     const int M = h->M;
     const bool l2 = h->metric == MI_METRIC_L2;
     std::unique_ptr<Range> stage = std::make_unique<Range>("mi_ivfpq:coarse+lut");
@@ -1297,7 +1314,8 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
             if (const char *e = std::getenv("MI_SCAN_NW")) a.nw = std::atoi(e) == 16 ? 16 : 8;
             a.all_s = all_s; a.all_id = all_id; a.all_ld = R;
             launch_scan(M, a, st);
-            launch_select_pairs(all_s, all_id, R, a.p_prefix, nprobe, k, m, Ddev + (size_t)c0 * k, Idev + (size_t)c0 * k, (int64_t)k, st);
+            launch_select_pairs(all_s, all_id, R, a.p_prefix, nprobe, k, m, Ddev ? Ddev + (size_t)c0 * k : nullptr, Idev + (size_t)c0 * k,
+                                (int64_t)k, st, cand_set && !l2);
             MI_HIP(hipGetLastError());
         }
         l2_finish();
@@ -1378,6 +1396,31 @@ int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe, 
             if (!Dd) MI_HIP(hipMemcpyAsync(D + (size_t)c0 * k, Dc, (size_t)m * k * 4, hipMemcpyDeviceToHost, st));
             if (!Id) MI_HIP(hipMemcpyAsync(I + (size_t)c0 * k, Ic, (size_t)m * k * 8, hipMemcpyDeviceToHost, st));
             if (!qd || !Dd || !Id) MI_HIP(hipStreamSynchronize(st));
+        }
+    });
+}
+
+int mi_index_search_candidates(mi_index *h, int64_t nq, const float *q, int kc, int nprobe, int64_t *I, void *stream) {
+    return guard([&] {
+        MI_REQUIRE(h && (nq == 0 || (q && I)), "null argument");
+        MI_REQUIRE(kc >= 1 && kc <= SELP_CAP, "kc must be in [1, 8192]");
+        MI_REQUIRE(nprobe >= 1, "nprobe must be >= 1");
+        require_trained(h);
+        if (nq == 0) return;
+        MI_REQUIRE(is_device_ptr(q) && is_device_ptr(I), "mi_index_search_candidates: device pointers only");
+        DeviceGuard dg(h->device);
+        hipStream_t st = as_stream(stream);
+        WsLease lease = lease_ws(h, stream, true);
+        SearchWS &w = lease.w;
+        nprobe = std::min(nprobe, h->nlist);
+        const int64_t chunk = query_chunk_size(h);
+        for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
+            const int64_t m = std::min(chunk, nq - c0);
+            // kc <= 64 (selected inside the scan) and METRIC_L2 (scores are finished in place) keep the sorted path
+            const bool set = kc > 64 && h->metric == MI_METRIC_INNER_PRODUCT && !std::getenv("MI_NO_ALLSCORES");
+            float *Dc = set ? nullptr : w.D.as<float>((size_t)m * kc);
+            search_chunk(h, w, m, q + (size_t)c0 * h->d, kc, nprobe, Dc, I + (size_t)c0 * kc, st, nullptr, nullptr, nullptr, false,
+                         nullptr, nullptr, set);
         }
     });
 }
@@ -1665,7 +1708,8 @@ int mi_shards_search(mi_shards *s, int64_t nq, const float *q, int k, int nprobe
             MI_REQUIRE(kb <= SELP_CAP, "k * k_factor must be <= 8192");
             float *cD = b->cand_D.as<float>((size_t)nq * kb);
             int64_t *cI = b->cand_I.as<int64_t>((size_t)nq * kb);
-            if (mi_index_search(s->local, nq, q, kb, nprobe, cD, cI, stream)) throw Error(last_error());
+            (void)cD;
+            if (mi_index_search_candidates(s->local, nq, q, kb, nprobe, cI, stream)) throw Error(last_error());
             if (mi_flat_rerank(s->refine, nq, q, kb, cI, k, Dl, Il, stream)) throw Error(last_error());
         } else {
             if (mi_index_search(s->local, nq, q, k, nprobe, Dl, Il, stream)) throw Error(last_error());
@@ -2240,7 +2284,7 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
             qs = qa;
         }
         if (h->elem == 4) launch_rerank_scores<float>(qs, (int)nq, h->base.get<float>(), h->ntotal, h->da, ci, kc, scores, kc, st);
-        else if (h->elem == 1) launch_rerank_sq8(qs, (int)nq, h->base.get<uint8_t>(), h->ntotal, h->d, h->sq_trained.get<float>(), ci, kc, scores, kc, st);
+        else if (h->elem == 1) launch_rerank_sq8(qs, (int)nq, h->base.get<uint8_t>(), h->ntotal, h->d, h->sq_trained.get<float>(), ci, kc, scores, kc, w.qaug, st);
         else launch_rerank_scores<f16_t>(qs, (int)nq, h->base.get<f16_t>(), h->ntotal, h->d, ci, kc, scores, kc, st);
         // the candidate list as kc/k "parts" of k entries: the k-way merge ranks them under
         // (score desc, id asc) and skips the negative ids

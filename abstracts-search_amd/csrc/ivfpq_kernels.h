@@ -78,6 +78,11 @@ __device__ __forceinline__ float wave_shr1_f(float v) {
     return __int_as_float(wave_shr1_i(__float_as_int(v)));
 }
 // number of set bits of `mask` below this lane
+__device__ __forceinline__ int wave_reduce_add_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
 __device__ __forceinline__ int lane_prefix_count(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
@@ -945,7 +950,11 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------
 // VPT_ = 16: K <= 4096 (CAP = 256 VPT_ survivor slots, as many group maxima); VPT_ = 32: K <= 8192 -- the refine stage's
 // candidate lists at the recall >= 0.95 operating point of the whole 207 M index (k * k_factor_rf of several thousand).
-template <int VPT_>
+// SET_ (the first stage of IndexRefine: the candidate list only feeds the re-rank, whose result does not depend on the
+// order of its candidates): the same K entries, written in no particular order and without their scores -- the exact
+// K-th key by a descent over the survivors in LDS instead of the 91-stage bitonic sort of 8192 slots (1.24 ms of the
+// 4.6 ms whole-index refine step).  Ties at the cut that do not all fit keep the sorted route (ids decide).
+template <int VPT_, bool SET_ = false>
 __global__ void __launch_bounds__(256)
     select_pairs_kernel(const float *__restrict__ S, const int64_t *__restrict__ IDS, int64_t ld,
                         const int32_t *__restrict__ p_prefix, int nprobe, int K, float *__restrict__ D,
@@ -1086,6 +1095,50 @@ __global__ void __launch_bounds__(256)
         }
         Sn = c_cnt;   // <= CAP now
     }
+    if constexpr (SET_) {
+        // unordered output: everything when the survivors are no more than K, else the entries above the exact K-th key T
+        // plus the ties at T when they all fit (the usual case: K - cgt == ceq); otherwise fall through to the sort
+        bool done = false;
+        unsigned T = 0;
+        int take_eq = 0;
+        if (Sn <= K) {
+            done = true;
+        } else {
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned t = T | (1u << bit);
+                int c = 0;
+                for (int e = tid; e < Sn; e += 256) c += sk[e] >= t;
+                c = block_sum(wave_reduce_add_i(c));
+                if (c >= K) T = t;
+                if (c == K) break;
+            }
+            int cg = 0, ce = 0;
+            for (int e = tid; e < Sn; e += 256) {
+                cg += sk[e] > T;
+                ce += sk[e] == T;
+            }
+            const int cgt = block_sum(wave_reduce_add_i(cg)), ceq = block_sum(wave_reduce_add_i(ce));
+            take_eq = K - cgt;
+            done = take_eq == ceq;
+        }
+        if (done) {   // workgroup-uniform
+            if (tid == 0) c_cnt = 0;
+            __syncthreads();
+            const int all = Sn <= K;
+            for (int base = 0; base < Sn; base += 256) {
+                const int e = base + tid;
+                const bool keep = e < Sn && sk[e] != 0u && (all || sk[e] >= T);
+                const unsigned long long m = __ballot(keep);
+                int o = 0;
+                if (lane == 0 && m) o = atomicAdd(&c_cnt, __popcll(m));
+                o = uniform_i(o);
+                if (keep) I[row * ldo + o + lane_prefix_count(m)] = sid[e];
+            }
+            __syncthreads();
+            for (int e = c_cnt + tid; e < K; e += 256) I[row * ldo + e] = (int64_t)-1;
+            return;
+        }
+    }
     int P = 64;
     while (P < Sn) P <<= 1;
     for (int e = Sn + tid; e < P; e += 256) {
@@ -1113,7 +1166,7 @@ __global__ void __launch_bounds__(256)
         }
     for (int e = tid; e < K; e += 256) {
         const bool filled = e < Sn && sk[e] != 0u;
-        D[row * ldo + e] = filled ? o2f(sk[e]) : -FLT_MAX;
+        if (D) D[row * ldo + e] = filled ? o2f(sk[e]) : -FLT_MAX;
         I[row * ldo + e] = filled ? sid[e] : (int64_t)-1;
     }
 }
@@ -2870,16 +2923,35 @@ __global__ void __launch_bounds__(256)
     x[i] = sq8_component(codes[i], trained[c], trained[d + c]);
 }
 
+// per-query table of the asymmetric SQ8 score (oracle_sq8_query_table): w[q][i] = q[i] * (vdiff[i] / 255) and
+// A[q] = chain_i fmaf(q[i], vmin[i] + vdiff[i] 0.5/255, .) -- one thread per query runs the chain (queries are few)
+__global__ void __launch_bounds__(64)
+    sq8_query_table_kernel(const float *__restrict__ q, int64_t nq, int d, const float *__restrict__ trained, float *__restrict__ w,
+                           float *__restrict__ A) {
+    const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (r >= nq) return;
+    const float *qr = q + (size_t)r * d;
+    float *wr = w + (size_t)r * d;
+    float acc = 0.f;
+    for (int i = 0; i < d; ++i) {
+        const float vmin = trained[i], vdiff = trained[d + i];
+        const float a = __builtin_fmaf(vdiff, 0.5f / 255.0f, vmin), b = vdiff / 255.0f;
+        acc = __builtin_fmaf(qr[i], a, acc);
+        wr[i] = qr[i] * b;
+    }
+    A[r] = acc;
+}
+
 // Re-ranking over the SQ8 store: rerank_rows_kernel's scheme (one wave per (query, 64 candidates), lane r owns
 // candidate r, rows stream through an NST-stage LDS ring filled by LDS-DMA, one ascending-i fmaf chain per lane) with
-// 128 components per 128-byte piece.  Per component: byte -> float, two fmas decode it (t = fma(c, 1/255, 0.5/255),
-// x^ = fma(t, vdiff, vmin)), one fma feeds the chain; q, vmin and vdiff are wave-uniform (scalar loads).
-// Requires d % 128 == 0.
+// 128 components per 128-byte piece, scored in the asymmetric form score = A(q) + sum_i w(q)[i] code[i] (oracle: "ScalarQuantizer
+// QT_8bit"): per component one byte -> float conversion and one fma whose multiplier w(q)[i] is wave-uniform (scalar
+// loads) -- 2 VALU operations per byte where decoding every component took 5 and made the kernel VALU-bound (1.86 ms for
+// 1024 x 5 120 rows; the rows are 5.4 GB).  Requires d % 128 == 0.
 template <int NST>
 __global__ void __launch_bounds__(64)
-    rerank_sq8_kernel(const float *__restrict__ q, const uint8_t *__restrict__ base, int64_t nb, int d,
-                      const float *__restrict__ trained, const int64_t *__restrict__ cand, int kc, float *__restrict__ S,
-                      int64_t ldS, int tiles) {
+    rerank_sq8_kernel(const float *__restrict__ wq, const float *__restrict__ Aq, const uint8_t *__restrict__ base, int64_t nb, int d,
+                      const int64_t *__restrict__ cand, int kc, float *__restrict__ S, int64_t ldS, int tiles) {
     __shared__ __attribute__((aligned(1024))) unsigned char ring[NST][8192];
     __shared__ const unsigned char *rowp[64];
     const int lane = threadIdx.x;
@@ -2902,10 +2974,9 @@ __global__ void __launch_bounds__(64)
         for (int i = 0; i < 8; ++i) dma16_lds(src[i] + (size_t)ch * 128, st + i * 1024);
     };
     for (int ch = 0; ch < NST - 1 && ch < nch; ++ch) issue(ch);
-    const float *qrow = q + (size_t)qi * d;
-    const float *vmin = trained, *vdiff = trained + d;
+    const float *wrow = wq + (size_t)qi * d;
     const int sw = (lane >> 1) & 7;
-    float acc = 0.f;
+    float acc = Aq[qi];
     auto consume = [&](int ch) {
         const unsigned char *mine = ring[ch % NST] + lane * 128;
         const int k0 = ch * 128;
@@ -2918,7 +2989,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int i = k0 + p * 16 + e * 4 + b;
-                    acc = __builtin_fmaf(qrow[i], sq8_component((w[e] >> (8 * b)) & 0xffu, vmin[i], vdiff[i]), acc);
+                    acc = __builtin_fmaf(wrow[i], (float)((w[e] >> (8 * b)) & 0xffu), acc);
                 }
             }
         }
@@ -2936,9 +3007,8 @@ __global__ void __launch_bounds__(64)
 
 // the same scores without the streaming layout's d % 128 requirement (small test shapes): one thread per (query, candidate)
 __global__ void __launch_bounds__(256)
-    rerank_sq8_simple_kernel(const float *__restrict__ q, const uint8_t *__restrict__ base, int64_t nb, int d,
-                             const float *__restrict__ trained, const int64_t *__restrict__ cand, int kc, int64_t total,
-                             float *__restrict__ S, int64_t ldS) {
+    rerank_sq8_simple_kernel(const float *__restrict__ wq, const float *__restrict__ Aq, const uint8_t *__restrict__ base, int64_t nb, int d,
+                             const int64_t *__restrict__ cand, int kc, int64_t total, float *__restrict__ S, int64_t ldS) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
     const int64_t qi = g / kc;
@@ -2946,9 +3016,9 @@ __global__ void __launch_bounds__(256)
     int64_t id = cand[g];
     id = max(min(id, nb - 1), (int64_t)0);
     const uint8_t *row = base + (size_t)id * d;
-    const float *qrow = q + (size_t)qi * d;
-    float acc = 0.f;
-    for (int i = 0; i < d; ++i) acc = __builtin_fmaf(qrow[i], sq8_component(row[i], trained[i], trained[d + i]), acc);
+    const float *wrow = wq + (size_t)qi * d;
+    float acc = Aq[qi];
+    for (int i = 0; i < d; ++i) acc = __builtin_fmaf(wrow[i], (float)row[i], acc);
     S[(size_t)qi * ldS + c] = acc;
 }
 

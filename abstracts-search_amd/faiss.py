@@ -74,6 +74,7 @@ class _Lib:
                 "mi_index_search": [v, c_int64, v, c_int, c_int, v, v, v],
                 "mi_index_coarse_lut": [v, c_int64, v, c_int, v, v, v],
                 "mi_index_profile_scan": [v, c_int, v, POINTER(c_double), POINTER(c_int64)],
+                "mi_index_search_candidates": [v, c_int64, v, c_int, c_int, v, v],
                 "mi_index_coarse_slice": [v, c_int64, v, c_int, c_int, c_int, v, v, v],
                 "mi_index_search_preassigned": [v, c_int64, v, c_int, c_int, v, v, v, v, v],
                 "mi_merge_topk": [c_int, c_int, c_int64, c_int, v, v, v, v, v],
@@ -624,6 +625,16 @@ class IndexIVFPQ:
         if rc:
             _check(rc)
 
+    def search_candidates_into(self, x, kc: int, I, nprobe: int | None = None, stream: int | None = None):
+        """The kc best entries of every query as an unordered SET of ids (CUDA tensors; -1 = unfilled): the first
+        stage of an IndexRefine search, whose re-rank does not depend on the order of its candidates."""
+        nprobe = self.nprobe if nprobe is None else nprobe
+        st = _current_stream() if stream is None else c_void_p(stream)
+        rc = _Lib.get().mi_index_search_candidates(self._h, x.shape[0], c_void_p(x.data_ptr()), int(kc), int(nprobe),
+                                                   c_void_p(I.data_ptr()), st)
+        if rc:
+            _check(rc)
+
     def coarse_slice(self, x, nprobe: int, list_lo: int, list_hi: int):
         """quantizer.search restricted to centroids [list_lo, list_hi) with global
         list numbers -> (coarse_I int32, coarse_D f32) CUDA tensors [nq, nprobe]."""
@@ -785,12 +796,25 @@ class IndexRefine:
         k_factor = self.k_factor if params is None else getattr(params, "k_factor", self.k_factor)
         k_base = int(k * k_factor)
         k_base = max(k, k_base - k_base % k)      # the re-ranking step takes whole multiples of k
-        _, cand = self.base_index.search(x, k_base, params=getattr(params, "base_index_params", None))
+        bp = getattr(params, "base_index_params", None)
+        if _is_torch(x) and x.is_cuda and hasattr(self.base_index, "search_candidates_into") and self.metric_type == METRIC_INNER_PRODUCT:
+            import torch
+            x = _as_f32(x, self.d)
+            if bp is not None and (getattr(bp, "sel", None) is not None or getattr(bp, "max_codes", 0)):
+                raise NotImplementedError("SearchParametersIVF: only nprobe is implemented on the MI355X path")
+            cand = torch.empty((x.shape[0], k_base), dtype=torch.int64, device=x.device)
+            self.base_index.search_candidates_into(x, k_base, cand, getattr(bp, "nprobe", None))
+            return self.refine_index.rerank(x, cand, k)
+        _, cand = self.base_index.search(x, k_base, params=bp)
         return self.refine_index.rerank(x, cand, k)
 
     def search_into(self, x, k: int, D, I, cand_D, cand_I, stream: int | None = None):
-        """search() into caller-owned CUDA tensors (cand_D / cand_I: [nq, k_base] scratch)."""
-        self.base_index.search_into(x, int(cand_I.shape[1]), cand_D, cand_I, None, stream)
+        """search() into caller-owned CUDA tensors (cand_I: [nq, k_base] scratch; cand_D is only written when the base
+        index has no unordered-candidates entry point)."""
+        if hasattr(self.base_index, "search_candidates_into") and self.metric_type == METRIC_INNER_PRODUCT:
+            self.base_index.search_candidates_into(x, int(cand_I.shape[1]), cand_I, None, stream)
+        else:
+            self.base_index.search_into(x, int(cand_I.shape[1]), cand_D, cand_I, None, stream)
         self.refine_index.rerank(x, cand_I, k, D, I, stream)
 
 

@@ -126,6 +126,14 @@ int mi_index_set_nprobe(mi_index *h, int nprobe);
 int mi_index_search(mi_index *h, int64_t nq, const float *q, int k, int nprobe,
                     float *D, int64_t *I, void *stream);
 
+/* The first stage of IndexRefine::search (base_index->search(n, x, k * k_factor, ...) whose labels feed the re-rank):
+ * the kc best entries of every query under the same total order as mi_index_search, as a SET -- ids only, in no
+ * particular order, -1 in unfilled slots.  The re-rank's result does not depend on the order of its candidates, and
+ * skipping the sort of a several-thousand-entry list is 1 ms of a 4.6 ms step at the recall >= 0.95 point of the 207 M
+ * index.  Device pointers only; 1 <= kc <= 8192. */
+int mi_index_search_candidates(mi_index *h, int64_t nq, const float *q, int kc, int nprobe,
+                               int64_t *I, void *stream);
+
 /* Steps 1-2 of search exposed for parity tests: quantizer.search(q, nprobe)
  * -> coarse_I int32 [nq][nprobe], coarse_D float32 [nq][nprobe] (host), and the
  * ADC table pq.compute_inner_prod_tables -> lut float32 [nq][M][256] (host).
@@ -213,8 +221,9 @@ int mi_flat_create(int d, int device, mi_flat **out);
  * byte per component with per-dimension ranges.  The ranges must be trained (mi_flat_sq_train = faiss
  * ScalarQuantizer::train with RS_minmax, rangestat_arg 0: vmin[i] = min, vdiff[i] = max - min over the training
  * rows) or set (mi_flat_sq_set_trained) before add(); add() stores code = (int)(255 * clip((x - vmin) / vdiff));
- * re-ranking scores <q, x^> with x^[i] = fma(fma(code, 1/255, 0.5/255), vdiff[i], vmin[i]) in the same ascending
- * f32 chain as the other stores (oracle/ivfpq_oracle.c, section "ScalarQuantizer QT_8bit").  207 M x 1024
+ * reconstruct_n decodes x^[i] = fma(fma(code, 1/255, 0.5/255), vdiff[i], vmin[i]); re-ranking scores <q, x^> in the
+ * asymmetric form A(q) + sum_i (q[i] vdiff[i] / 255) code[i] -- a per-query table, then one ascending f32 fma chain over
+ * the stored bytes (oracle/ivfpq_oracle.c, section "ScalarQuantizer QT_8bit").  207 M x 1024
  * components are 212 GB: the whole refine store of BASELINE.json configs[3] beside the index in one GPU's HBM.
  * Inner product only; serves mi_flat_rerank / reconstruct_n only. */
 #define MI_STORE_SQ8 2

@@ -207,9 +207,16 @@ ORACLE_API void oracle_rerank(int64_t nq, int d, const float *q, const float *ba
  *          xi = (x[i] - vmin[i]) / vdiff[i] clipped to [0, 1] (0 when vdiff[i] == 0); code[i] = (int)(255 * xi)
  *   decode (reconstruct_component; faiss's SIMD build evaluates it with two fused multiply-adds):
  *          t = fmaf((float)code[i], 1/255, 0.5/255);  x^[i] = fmaf(t, vdiff[i], vmin[i])
- *   score  (DCTemplate<..., SimilarityIP>::query_to_code): <q, x^>.  faiss's SIMD build keeps 8 lane
- *          accumulators; this file keeps its ONE evaluation order -- the ascending-i fmaf chain from +0 --
- *          like every other dot product here (see the header).
+ *   score  (DCTemplate<..., SimilarityIP>::query_to_code): <q, x^>, with x^[i] = a[i] + b[i] code[i] the same affine
+ *          map written out (a[i] = vmin[i] + vdiff[i] 0.5/255, b[i] = vdiff[i] / 255).  Like the PQ scan, which adds
+ *          look-up-table entries precomputed per query instead of decoding every code, the score is evaluated in its
+ *          asymmetric form: a per-query table first, then one multiply-add per stored byte --
+ *              A(q)   = chain_i fmaf(q[i], a[i], .)   from +0, i ascending      (once per query)
+ *              w(q)[i] = q[i] * b[i]                                             (once per query)
+ *              score  = chain_i fmaf(w(q)[i], (float)code[i], .)  from A(q), i ascending
+ *          = sum_i q[i] (a[i] + b[i] code[i]) exactly in real arithmetic; the rounding sequence is this file's ONE fixed
+ *          order for it (faiss's own order is its SIMD build's: 8 lane accumulators over decoded components).  Two VALU
+ *          operations per byte instead of five: the re-rank kernel streams 1 KiB rows at HBM speed.
  */
 ORACLE_API void oracle_sq8_train(int64_t n, int d, const float *x, float *trained /* [2 d]: vmin | vdiff */) {
     for (int i = 0; i < d; ++i) {
@@ -244,6 +251,18 @@ static inline float sq8_component(uint8_t c, float vmin, float vdiff) {
     return fmaf(t, vdiff, vmin);
 }
 
+/* per-query table of the asymmetric score: w [d] and the constant A (see the section header) */
+ORACLE_API void oracle_sq8_query_table(int d, const float *q, const float *trained, float *w, float *A) {
+    const float *vmin = trained, *vdiff = trained + d;
+    float acc = 0.f;
+    for (int i = 0; i < d; ++i) {
+        const float a = fmaf(vdiff[i], 0.5f / 255.0f, vmin[i]), b = vdiff[i] / 255.0f;
+        acc = fmaf(q[i], a, acc);
+        w[i] = q[i] * b;
+    }
+    *A = acc;
+}
+
 ORACLE_API void oracle_sq8_decode(int64_t n, int d, const uint8_t *codes, const float *trained, float *x) {
     const float *vmin = trained, *vdiff = trained + d;
 #pragma omp parallel for schedule(static)
@@ -254,19 +273,21 @@ ORACLE_API void oracle_sq8_decode(int64_t n, int d, const uint8_t *codes, const 
 /* IndexRefine(base, IndexScalarQuantizer(QT_8bit)) re-ranking step: like oracle_rerank over the decoded rows */
 ORACLE_API void oracle_rerank_sq8(int64_t nq, int d, const float *q, const uint8_t *codes, const float *trained, int kc,
                                   const int64_t *cand_I, int k, float *D, int64_t *I) {
-    const float *vmin = trained, *vdiff = trained + d;
 #pragma omp parallel
     {
         cand_t *L = (cand_t *)malloc(sizeof(cand_t) * (size_t)k);
+        float *w = (float *)malloc(sizeof(float) * (size_t)d);
 #pragma omp for schedule(dynamic, 1)
         for (int64_t qi = 0; qi < nq; ++qi) {
             int n = 0;
+            float A;
+            oracle_sq8_query_table(d, q + qi * d, trained, w, &A);
             for (int c = 0; c < kc; ++c) {
                 const int64_t id = cand_I[qi * kc + c];
                 if (id < 0) continue;
                 const uint8_t *row = codes + id * (int64_t)d;
-                float acc = 0.f;
-                for (int i = 0; i < d; ++i) acc = fmaf(q[qi * d + i], sq8_component(row[i], vmin[i], vdiff[i]), acc);
+                float acc = A;
+                for (int i = 0; i < d; ++i) acc = fmaf(w[i], (float)row[i], acc);
                 topk_push(L, &n, k, acc, id);
             }
             for (int j = 0; j < k; ++j) {
@@ -274,6 +295,7 @@ ORACLE_API void oracle_rerank_sq8(int64_t nq, int d, const float *q, const uint8
                 I[qi * k + j] = j < n ? L[j].id : -1;
             }
         }
+        free(w);
         free(L);
     }
 }

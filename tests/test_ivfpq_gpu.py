@@ -975,6 +975,42 @@ def test_refine_sqfp16_matches_oracle(faiss, oracle):
         idx.refine_index.search(q, k)
 
 
+def test_search_candidates_is_the_topk_set(faiss, oracle):
+    """mi_index_search_candidates (the first stage of a refine search): the same kc entries as search(x, kc) -- the
+    oracle's top kc under (score desc, id asc) -- as an unordered set of ids; ties at the cut are decided by id, rows
+    with fewer than kc entries are padded with -1.  And IndexRefine over it equals IndexRefine over the sorted list."""
+    import torch
+    cent, cb, x, q = random_problem(31, 32, 4, 40, 30000, 11)
+    x[20000:24000] = x[5]                                      # 4001 identical vectors: cuts that fall inside a tie
+    q[0] = x[5]
+    ids = np.random.default_rng(8).permutation(1 << 20)[:len(x)].astype(np.int64)
+    idx = make_index(faiss, cent, cb)
+    idx.add_with_ids(x, ids)
+    ln, codes = oracle.encode(x, cent, cb)
+    off, lc, li = oracle.build_lists(ln, codes, ids, 40)
+    qd = torch.from_numpy(q).cuda()
+    for kc, nprobe in ((65, 40), (640, 17), (2000, 40), (4096, 40), (5120, 40), (8192, 40), (3000, 2), (50, 8)):
+        I = torch.empty((len(q), kc), dtype=torch.int64, device="cuda")
+        idx.search_candidates_into(qd, kc, I, nprobe)
+        _, Ie = oracle.search(q, cent, cb, off, lc, li, nprobe, kc)
+        got = I.cpu().numpy()
+        for r in range(len(q)):
+            a, b = np.sort(got[r]), np.sort(Ie[r])
+            assert np.array_equal(a, b), (kc, nprobe, r, int((a != b).sum()))
+    # the refine result through the unordered candidates (device path) == through the sorted list (host path) == oracle
+    ref = faiss.IndexRefineFlat(make_index(faiss, cent, cb))
+    ref.add(x)
+    ref.nprobe, ref.k_factor = 40, 300
+    Dh, Ih = ref.search(q, 10)
+    Dd, Id = ref.search(qd, 10)
+    assert np.array_equal(Id.cpu().numpy(), Ih) and np.array_equal(bits(Dd.cpu().numpy()), bits(Dh))
+    ln, codes = oracle.encode(x, cent, cb)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(len(x)), 40)
+    _, cand = oracle.search(q, cent, cb, off, lc, li, 40, 3000)
+    De, Ie = oracle.rerank(q, x, cand, 10)
+    assert np.array_equal(Ih, Ie) and np.array_equal(bits(Dh), bits(De))
+
+
 @pytest.mark.parametrize("d,M", [(128, 16), (192, 48), (1024, 64)])
 def test_refine_sq8_matches_oracle(faiss, oracle, d, M):
     """factory "IVF..,PQ..,Refine(SQ8)" (faiss IndexScalarQuantizer QT_8bit: per-dimension ranges trained as min /
