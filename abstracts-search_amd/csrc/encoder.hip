@@ -263,7 +263,10 @@ bool mid_split_pays(const GemmArgs &g) {
     const int ntiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), nt64 = g.K / 64;
     const int S = std::min({16, 256 / std::max(1, ntiles), nt64 / 4});
     static const int min_wg = std::getenv("MI_MID_MIN_WG") ? std::atoi(std::getenv("MI_MID_MIN_WG")) : 96;
-    return g.M > 64 && S >= 2 && ntiles * S >= min_wg && (size_t)S * g.M * g.N * 4 <= g.part_bytes;
+    // long K only (the down projection): at K = 1536 a slice is 4 K tiles and the tile's fixed cost plus the reduction pass
+    // (17.2 + 7.5 us at 576 tokens) lose to the 128-row ring tiles (20 us) -- profiles/r03_encode_nq16_kernel_stats_v1.csv
+    static const int min_k = std::getenv("MI_MID_MIN_K") ? std::atoi(std::getenv("MI_MID_MIN_K")) : 4096;
+    return g.M > 64 && g.K >= min_k && S >= 2 && ntiles * S >= min_wg && (size_t)S * g.M * g.N * 4 <= g.part_bytes;
 }
 
 void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
@@ -316,6 +319,11 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             // pass, where 128x128 tiles with K split three ways by f32 atomics took 76 us
             if (g.K >= 4096) launch_slab<2>(epi, g, st);
             else launch_slab<4>(epi, g, st);
+        } else if (cfg == "mid64" || (cfg == "small" && !force && epi != EPI_SWIGLU && g.M > 256 && g.K < 4096 && !std::getenv("MI_NO_MID64"))) {
+            // a few hundred to ~1500 tokens through the QKV / O projections: 128x64 tiles, 4 waves of 64x32 -- 3 DMA pieces per
+            // wave per K step where the 128x32 / 2-wave tiles issue 5 (they are DMA-issue-bound): QKV 16.0 -> 13.5 us at 576
+            // tokens, 35.8 -> 24.6 at 1152; O 21.8 -> 14.8 at 1152 (profiles/r03_gemm_mid_bench_v2.txt)
+            launch_ring<4, 2, 2, 2, 6>(epi, g, st);
         } else if (cfg == "small") {
             if (epi == EPI_RESID && !g.bias && g.K >= 4096 && !force) {
                 // a few hundred tokens through the down projection (K = 8960): 128x32 tiles are one

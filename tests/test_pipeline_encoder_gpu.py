@@ -288,7 +288,7 @@ def test_query_batches_at_stella_widths_vs_oracle(st, nq, layers):
     assert cos.min() > 1 - 1e-3, (nq, cos.min())
 
 
-@pytest.mark.parametrize("tile", ["big", "slab8", "slab4", "big32", "mid", "small", "tiny", "128"])
+@pytest.mark.parametrize("tile", ["big", "slab8", "slab4", "big32", "mid", "mid64", "small", "tiny", "128"])
 def test_gemm_tile_configs_vs_torch(st, tile, monkeypatch):
     """every GEMM tile configuration (forced through MI_GEMM_TILE) against torch fp32"""
     import torch

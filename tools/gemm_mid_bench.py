@@ -6,7 +6,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
     import torch
     import abstracts_search_amd.sentence_transformers as st
-    for M in (576, 2048, 8448):
+    for M in (576, 1152, 2048):
         for name, N, K in (("qkv", 2048, 1536), ("o", 1536, 1536), ("gate_up", 17920, 1536), ("down", 1536, 8960)):
             A = torch.randn((M, K), device="cuda").bfloat16(); W = (torch.randn((N, K), device="cuda") / K ** 0.5).bfloat16()
             for _ in range(3): C = st.gemm_bf16(A, W)
@@ -19,7 +19,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             us = e0.elapsed_time(e1) / reps * 1e3
             print(f"{os.environ.get('MI_GEMM_TILE','default'):8s} M={M:5d} {name:8s} {us:8.1f} us {2*M*N*K/us/1e6:7.1f} TF  (weights once at 5 TB/s: {N*K*2/5e6:5.1f} us)", flush=True)
     sys.exit(0)
-for tile in ("", "slab8", "slab4", "mid", "half", "small"):
+for tile in ("", "mid64", "small"):
     env = dict(os.environ)
     if tile: env["MI_GEMM_TILE"] = tile
     else: env.pop("MI_GEMM_TILE", None)
