@@ -352,11 +352,18 @@ def cfg4_workload(args, ctx):
     # shard's own rows when they fit beside the index, else the 1/8 sub-shard a GPU of the
     # 8-GPU job would hold (rows i = rank mod 8)
     per_rank = (N + nsh - 1) // nsh
-    hbm_total = torch.cuda.mem_get_info()[1]
+    torch.cuda.empty_cache()
+    hbm_free = torch.cuda.mem_get_info()[0] + (sq_train_rows.numel() * 4 if sq_train_rows is not None else 0)   # the training sample is freed below
+    if dist.is_initialized() and world > 1:                           # every rank must take the same layout decision
+        t = torch.tensor([float(hbm_free)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        hbm_free = float(t.item())
     want_refine = not args.no_refine_point and not replicas
     # what this rank's HBM has left for the refine store: the index itself is 152 B per vector (append log 80 + scan image
-    # 72), plus ~25 GB of corpus chunks, ground-truth store and search workspaces (measured: 257 of 309 GB in use at N = 1)
-    room = hbm_total - per_rank * 152 - 25e9
+    # 72), plus ~25 GB of corpus chunks, ground-truth store and search workspaces (measured: 277 of 309 GB in use at N = 1).
+    # From the memory that is FREE now (another tenant of the GPU shrinks the store's choice, it does not break the run:
+    # without room for the whole shard the point falls back to the 1/8 sub-shard layout)
+    room = hbm_free - per_rank * 152 - 25e9
     store = args.refine_store
     if store == "auto":
         store = "f16" if per_rank * d * 2 <= room else "sq8"
