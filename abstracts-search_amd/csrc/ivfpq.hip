@@ -95,7 +95,8 @@ void launch_rerank_sq8(const float *q, int nq, const uint8_t *base, int64_t nb, 
                        const int64_t *idx, int kc, float *S, int64_t ldS, DevBuf &tab, hipStream_t st) {
     float *wq = tab.as<float>((size_t)nq * d + (size_t)nq);
     float *Aq = wq + (size_t)nq * d;
-    hipLaunchKernelGGL(sq8_query_table_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, q, (int64_t)nq, d, trained, wq, Aq);
+    MI_REQUIRE((size_t)d * 8 <= 64 * 1024, "SQ8 re-rank: d too large for the query-table kernel's LDS row");
+    hipLaunchKernelGGL(sq8_query_table_kernel, dim3((unsigned)nq), dim3(64), (size_t)d * 8, st, q, (int64_t)nq, d, trained, wq, Aq);
     MI_HIP(hipGetLastError());
     const int tiles = (kc + 63) / 64;
     const char *e = std::getenv("MI_RERANK");

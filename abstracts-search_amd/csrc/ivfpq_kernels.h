@@ -1032,13 +1032,18 @@ __global__ void __launch_bounds__(256)
                         const int pos = o + lane_prefix_count(m[j]);
                         if (((m[j] >> lane) & 1ull) && pos < CAP) {
                             sk[pos] = key[j];
-                            sid[pos] = ids[base + j * 256 + tid];
+                            sid[pos] = (int64_t)(base + j * 256 + tid);   // the column; its id is fetched below
                         }
                         o += __popcll(m[j]);
                     }
                 }
             }
         }
+        __syncthreads();
+        // ids of the survivors: independent loads, all of a thread's in flight at once (fetched inside the loop above
+        // every load sat in front of its own LDS store: a DRAM latency per survivor column)
+        const int got = min(c_cnt, CAP);
+        for (int e = tid; e < got; e += 256) sid[e] = ids[sid[e]];
         __syncthreads();
     };
     compact([&](unsigned kx, int) { return kx >= T0; });
@@ -1104,20 +1109,26 @@ __global__ void __launch_bounds__(256)
         if (Sn <= K) {
             done = true;
         } else {
+            // the survivors' keys in registers (CAP / 256 per thread): the descent is ballots + popcounts, no LDS traffic
+            unsigned mine[VPT_];
+#pragma unroll
+            for (int j = 0; j < VPT_; ++j) mine[j] = (j * 256 + tid) < Sn ? sk[j * 256 + tid] : 0u;
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned t = T | (1u << bit);
                 int c = 0;
-                for (int e = tid; e < Sn; e += 256) c += sk[e] >= t;
-                c = block_sum(wave_reduce_add_i(c));
+#pragma unroll
+                for (int j = 0; j < VPT_; ++j) c += __popcll(__ballot(mine[j] >= t));
+                c = block_sum(c);
                 if (c >= K) T = t;
                 if (c == K) break;
             }
             int cg = 0, ce = 0;
-            for (int e = tid; e < Sn; e += 256) {
-                cg += sk[e] > T;
-                ce += sk[e] == T;
+#pragma unroll
+            for (int j = 0; j < VPT_; ++j) {
+                cg += __popcll(__ballot(mine[j] > T));
+                ce += __popcll(__ballot(mine[j] == T && mine[j] != 0u));
             }
-            const int cgt = block_sum(wave_reduce_add_i(cg)), ceq = block_sum(wave_reduce_add_i(ce));
+            const int cgt = block_sum(cg), ceq = block_sum(ce);
             take_eq = K - cgt;
             done = take_eq == ceq;
         }
@@ -2924,22 +2935,37 @@ __global__ void __launch_bounds__(256)
 }
 
 // per-query table of the asymmetric SQ8 score (oracle_sq8_query_table): w[q][i] = q[i] * (vdiff[i] / 255) and
-// A[q] = chain_i fmaf(q[i], vmin[i] + vdiff[i] 0.5/255, .) -- one thread per query runs the chain (queries are few)
+// A[q] = chain_i fmaf(q[i], vmin[i] + vdiff[i] 0.5/255, .).  One wave per query: the lanes compute a, b and w for
+// their components and park the chain's operands (q, a) in LDS, then lane 0 runs the 1024-link chain out of LDS
+// (a thread per query walking global memory took 217 us for 1024 queries: two dependent cache misses per link).
 __global__ void __launch_bounds__(64)
     sq8_query_table_kernel(const float *__restrict__ q, int64_t nq, int d, const float *__restrict__ trained, float *__restrict__ w,
                            float *__restrict__ A) {
-    const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    extern __shared__ float2 sq8_qa[];                    // [d]: (q[i], a[i])
+    const int64_t r = blockIdx.x;
     if (r >= nq) return;
     const float *qr = q + (size_t)r * d;
     float *wr = w + (size_t)r * d;
-    float acc = 0.f;
-    for (int i = 0; i < d; ++i) {
-        const float vmin = trained[i], vdiff = trained[d + i];
+    for (int i = threadIdx.x; i < d; i += 64) {
+        const float vmin = trained[i], vdiff = trained[d + i], qi = qr[i];
         const float a = __builtin_fmaf(vdiff, 0.5f / 255.0f, vmin), b = vdiff / 255.0f;
-        acc = __builtin_fmaf(qr[i], a, acc);
-        wr[i] = qr[i] * b;
+        wr[i] = qi * b;
+        sq8_qa[i] = make_float2(qi, a);
     }
-    A[r] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        int i = 0;
+        for (; i + 4 <= d; i += 4) {
+            const float4 p0 = *reinterpret_cast<const float4 *>(&sq8_qa[i]), p1 = *reinterpret_cast<const float4 *>(&sq8_qa[i + 2]);
+            acc = __builtin_fmaf(p0.x, p0.y, acc);
+            acc = __builtin_fmaf(p0.z, p0.w, acc);
+            acc = __builtin_fmaf(p1.x, p1.y, acc);
+            acc = __builtin_fmaf(p1.z, p1.w, acc);
+        }
+        for (; i < d; ++i) acc = __builtin_fmaf(sq8_qa[i].x, sq8_qa[i].y, acc);
+        A[r] = acc;
+    }
 }
 
 // Re-ranking over the SQ8 store: rerank_rows_kernel's scheme (one wave per (query, 64 candidates), lane r owns
