@@ -955,13 +955,17 @@ __global__ void __launch_bounds__(256)
 // K-th key by a descent over the survivors in LDS instead of the 91-stage bitonic sort of 8192 slots (1.24 ms of the
 // 4.6 ms whole-index refine step).  Ties at the cut that do not all fit keep the sorted route (ids decide).
 template <int VPT_, bool SET_ = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, SET_ ? 2 : 1)
     select_pairs_kernel(const float *__restrict__ S, const int64_t *__restrict__ IDS, int64_t ld,
                         const int32_t *__restrict__ p_prefix, int nprobe, int K, float *__restrict__ D,
                         int64_t *__restrict__ I, int64_t ldo) {
     constexpr int CAP = 256 * VPT_;
+    // the survivors: key + id (sorted mode: the sort moves both), or key + 32-bit column in the set mode, whose ids are
+    // fetched when they are written out -- 64 instead of 96 KiB of LDS at 8192 slots: two workgroups per CU, and this
+    // kernel spends two thirds of its wave cycles waiting (memory round trips, 70 block-wide barriers)
+    using SlotT = std::conditional_t<SET_, int32_t, int64_t>;
     __shared__ unsigned sk[CAP];
-    __shared__ int64_t sid[CAP];
+    __shared__ SlotT sid[CAP];
     __shared__ int wcnt[2][4];
     __shared__ int c_cnt, c_eq;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1032,7 +1036,7 @@ __global__ void __launch_bounds__(256)
                         const int pos = o + lane_prefix_count(m[j]);
                         if (((m[j] >> lane) & 1ull) && pos < CAP) {
                             sk[pos] = key[j];
-                            sid[pos] = (int64_t)(base + j * 256 + tid);   // the column; its id is fetched below
+                            sid[pos] = (SlotT)(base + j * 256 + tid);   // the column; its id is fetched below (set mode: on output)
                         }
                         o += __popcll(m[j]);
                     }
@@ -1042,9 +1046,11 @@ __global__ void __launch_bounds__(256)
         __syncthreads();
         // ids of the survivors: independent loads, all of a thread's in flight at once (fetched inside the loop above
         // every load sat in front of its own LDS store: a DRAM latency per survivor column)
-        const int got = min(c_cnt, CAP);
-        for (int e = tid; e < got; e += 256) sid[e] = ids[sid[e]];
-        __syncthreads();
+        if constexpr (!SET_) {
+            const int got = min(c_cnt, CAP);
+            for (int e = tid; e < got; e += 256) sid[e] = ids[sid[e]];
+            __syncthreads();
+        }
     };
     compact([&](unsigned kx, int) { return kx >= T0; });
     int Sn = c_cnt;
@@ -1102,13 +1108,13 @@ __global__ void __launch_bounds__(256)
     }
     if constexpr (SET_) {
         // unordered output: everything when the survivors are no more than K, else the entries above the exact K-th key T
-        // plus the ties at T when they all fit (the usual case: K - cgt == ceq); otherwise fall through to the sort
-        bool done = false;
+        // plus, of the ties at T, the take_eq with the smallest ids (usually all of them: K - cgt == ceq)
         unsigned T = 0;
-        int take_eq = 0;
-        if (Sn <= K) {
-            done = true;
-        } else {
+        int take_eq = 0, ceq = 0;
+        int64_t U = INT64_MAX;      // ties at T with id < U are kept, of those with id == U the first take_u
+        int take_u = 0;
+        const bool all = Sn <= K;
+        if (!all) {
             // the survivors' keys in registers (CAP / 256 per thread): the descent is ballots + popcounts, no LDS traffic
             unsigned mine[VPT_];
 #pragma unroll
@@ -1128,28 +1134,50 @@ __global__ void __launch_bounds__(256)
                 cg += __popcll(__ballot(mine[j] > T));
                 ce += __popcll(__ballot(mine[j] == T && mine[j] != 0u));
             }
-            const int cgt = block_sum(cg), ceq = block_sum(ce);
+            const int cgt = block_sum(cg);
+            ceq = block_sum(ce);
             take_eq = K - cgt;
-            done = take_eq == ceq;
-        }
-        if (done) {   // workgroup-uniform
-            if (tid == 0) c_cnt = 0;
-            __syncthreads();
-            const int all = Sn <= K;
-            for (int base = 0; base < Sn; base += 256) {
-                const int e = base + tid;
-                const bool keep = e < Sn && sk[e] != 0u && (all || sk[e] >= T);
-                const unsigned long long m = __ballot(keep);
-                int o = 0;
-                if (lane == 0 && m) o = atomicAdd(&c_cnt, __popcll(m));
-                o = uniform_i(o);
-                if (keep) I[row * ldo + o + lane_prefix_count(m)] = sid[e];
+            if (take_eq != ceq) {   // workgroup-uniform, rare: the cut falls inside a run of equal scores -- ids decide
+                auto count_ties = [&](auto pred) -> int {
+                    int c = 0;
+                    for (int base = 0; base < Sn; base += 256) {
+                        const int e = base + tid;
+                        c += __popcll(__ballot(e < Sn && sk[e] == T && pred(ids[sid[min(e, Sn - 1)]])));
+                    }
+                    return block_sum(c);
+                };
+                U = 0;
+                for (int bit = 62; bit >= 0; --bit) {
+                    const int64_t t = U | ((int64_t)1 << bit);
+                    if (count_ties([&](int64_t id) { return id < t; }) < take_eq) U = t;
+                }
+                take_u = take_eq - count_ties([&](int64_t id) { return id < U; });
             }
-            __syncthreads();
-            for (int e = c_cnt + tid; e < K; e += 256) I[row * ldo + e] = (int64_t)-1;
-            return;
         }
-    }
+        if (tid == 0) {
+            c_cnt = 0;
+            c_eq = 0;
+        }
+        __syncthreads();
+        for (int base = 0; base < Sn; base += 256) {
+            const int e = base + tid;
+            bool keep = e < Sn && sk[e] != 0u;
+            int64_t id = 0;
+            if (keep) id = ids[sid[e]];
+            if (keep && !all) {
+                const unsigned kx = sk[e];
+                keep = kx > T || (kx == T && (take_eq == ceq || id < U || (id == U && atomicAdd(&c_eq, 1) < take_u)));
+            }
+            const unsigned long long m = __ballot(keep);
+            int o = 0;
+            if (lane == 0 && m) o = atomicAdd(&c_cnt, __popcll(m));
+            o = uniform_i(o);
+            if (keep) I[row * ldo + o + lane_prefix_count(m)] = id;
+        }
+        __syncthreads();
+        for (int e = c_cnt + tid; e < K; e += 256) I[row * ldo + e] = (int64_t)-1;
+        return;
+    } else {
     int P = 64;
     while (P < Sn) P <<= 1;
     for (int e = Sn + tid; e < P; e += 256) {
@@ -1178,8 +1206,9 @@ __global__ void __launch_bounds__(256)
     for (int e = tid; e < K; e += 256) {
         const bool filled = e < Sn && sk[e] != 0u;
         if (D) D[row * ldo + e] = filled ? o2f(sk[e]) : -FLT_MAX;
-        I[row * ldo + e] = filled ? sid[e] : (int64_t)-1;
+        I[row * ldo + e] = filled ? (int64_t)sid[e] : (int64_t)-1;
     }
+    }   // sorted mode
 }
 
 // =====================================================================
