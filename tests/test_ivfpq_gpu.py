@@ -810,6 +810,56 @@ def test_fuzz_against_oracle(faiss, oracle):
         assert np.array_equal(bits(D), bits(De)), ctx
 
 
+def test_fuzz_refine_stores_against_oracle(faiss, oracle):
+    """seeded fuzz over the refine stage: store (f32 / half / SQ8), shapes, candidate-list lengths from a few dozen to
+    beyond 4096, duplicates (ties at the cut of the candidate list and in the final ranking), host and device queries --
+    the device path goes through the unordered candidate sets, the host path through the sorted lists; both == oracle."""
+    import torch
+    rng = np.random.default_rng(909)
+    for trial in range(18):
+        M = int(rng.choice([4, 8, 16]))
+        d = M * int(rng.choice([8, 16]))
+        nlist = int(rng.integers(4, 24))
+        n = int(rng.choice([300, 2000, 9000]))
+        nq = int(rng.integers(1, 24))
+        k = int(rng.choice([1, 5, 10]))
+        kf = int(rng.choice([3, 16, 100, 450, 700]))
+        kf = min(kf, 8192 // k)
+        nprobe = int(rng.integers(1, nlist + 1))
+        store = ("flat", "sqfp16", "sq8")[trial % 3]
+        cent = rng.standard_normal((nlist, d)).astype(np.float32)
+        cb = (0.3 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+        x = (cent[rng.integers(0, nlist, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+        if trial % 2 == 0:
+            x[n // 2:] = x[: n - n // 2]                    # every vector twice: ties everywhere
+        q = (x[rng.integers(0, n, nq)] + 0.1 * rng.standard_normal((nq, d))).astype(np.float32)
+        base = make_index(faiss, cent, cb)
+        if store == "flat":
+            idx = faiss.IndexRefineFlat(base)
+        else:
+            qt = faiss.ScalarQuantizer.QT_fp16 if store == "sqfp16" else faiss.ScalarQuantizer.QT_8bit
+            r = faiss.IndexScalarQuantizer(d, qt, faiss.METRIC_INNER_PRODUCT)
+            r.train(x[: n // 2 + 1])
+            idx = faiss.IndexRefine(base, r)
+        idx.add(x)
+        idx.nprobe, idx.k_factor = nprobe, kf
+        ln, codes = oracle.encode(x, cent, cb)
+        off, lc, li = oracle.build_lists(ln, codes, np.arange(n), nlist)
+        _, cand = oracle.search(q, cent, cb, off, lc, li, nprobe, k * kf)
+        if store == "flat":
+            De, Ie = oracle.rerank(q, x, cand, k)
+        elif store == "sqfp16":
+            De, Ie = oracle.rerank(q, x.astype(np.float16).astype(np.float32), cand, k)
+        else:
+            tr = oracle.sq8_train(x[: n // 2 + 1])
+            De, Ie = oracle.rerank_sq8(q, oracle.sq8_encode(x, tr), tr, cand, k)
+        ctx = dict(trial=trial, store=store, d=d, M=M, nlist=nlist, n=n, nq=nq, k=k, kf=kf, nprobe=nprobe)
+        Dh, Ih = idx.search(q, k)
+        assert np.array_equal(Ih, Ie) and np.array_equal(bits(Dh), bits(De)), ("host", ctx)
+        Dd, Id = idx.search(torch.from_numpy(q).cuda(), k)
+        assert np.array_equal(Id.cpu().numpy(), Ie) and np.array_equal(bits(Dd.cpu().numpy()), bits(De)), ("device", ctx)
+
+
 def test_fuzz_large_paths(faiss, oracle, monkeypatch):
     """seeded fuzz over the large-parameter paths: nprobe in the hundreds (select_big_kernel /
     the block-wide descent), k > 64 (all-pairs pass + select_pairs_kernel), the two-stage
