@@ -479,7 +479,7 @@ struct Batch {
     int32_t *seq_start = nullptr, *seq_len = nullptr, *work_seq = nullptr, *work_q0 = nullptr, *tok_map = nullptr, *out_rows = nullptr;
 };
 
-// Build the padded-packed layout (every sequence starts at a multiple of 8 tokens, T_pad a multiple of 32) straight into a
+// Build the packed layout (sequences back to back, T_pad = the total rounded up to a multiple of 32) straight into a
 // pinned staging slot and upload ids / positions / work lists (/ output rows) with one asynchronous copy.  Host `ids` /
 // `cu_seqlens` / `out_rows` are consumed before the call returns; nothing here waits for the GPU.
 Batch prepare_batch(mi_encoder *h, mi_encoder::WS &ws, int nseq, const int32_t *ids, const int32_t *cu, const int32_t *out_rows,
@@ -509,7 +509,7 @@ Batch prepare_batch(mi_encoder *h, mi_encoder::WS &ws, int nseq, const int32_t *
         MI_REQUIRE(L <= h->cfg.max_seq_len, "encode: sequence longer than max_seq_len");
         b.Lmax = std::max(b.Lmax, L);
         nwork += (L + 63) / 64;
-        cur += (L + 7) & ~7;
+        cur += L;                 // back to back: the attention kernel masks the < 8 foreign keys in front of a sequence
     }
     b.T_pad = (cur + 31) & ~31;   // GEMM rows are clamped / guarded, no tile multiple needed
     b.nwork = nwork;
@@ -549,7 +549,7 @@ Batch prepare_batch(mi_encoder *h, mi_encoder::WS &ws, int nseq, const int32_t *
             pos[(size_t)cur + t] = t;
             tok_map[(size_t)c0 + t] = cur + t;
         }
-        cur += (L + 7) & ~7;
+        cur += L;
     }
     int32_t *d = ws.ws_up.as<int32_t>(n_up);
     MI_HIP(hipMemcpyAsync(d, pin.p, n_up * 4, hipMemcpyHostToDevice, st));

@@ -1523,6 +1523,10 @@ __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
     const int item = blockIdx.x;
     const int seq = a.work_seq[item], q0 = a.work_q0[item];
     const int s0 = a.seq_start[seq], L = a.seq_len[seq];
+    // Sequences are packed back to back (no alignment padding between them), but the V^T rows are fetched in 16-byte
+    // pieces: the key axis of this sequence therefore starts at the aligned-down token sa; its first `off` (< 8) keys
+    // belong to the previous sequence and are masked out like the keys past the end.  Le = keys on that axis.
+    const int sa = s0 & ~7, off = s0 - sa, Le = off + L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: head w / 4 of this workgroup, query rows 16 (w % 4) ..
     const int wq = w & 3;
@@ -1538,15 +1542,15 @@ __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
         for (int i = 0; i < HD / 32 / HPW; ++i) {   // HD/8 K pieces over the 4 HPW waves
             const int p = w * (HD / 32 / HPW) + i;
             const int key = p * KRPP + lane / KSL, sl = lane % KSL;
-            const int krow = min(kc + key, L - 1);
-            dma16(a.QK + (size_t)(s0 + krow) * a.ldqk + (a.n_heads + kvh) * HD + ((sl ^ kswz(key)) * 8),
+            const int krow = min(kc + key, Le - 1);
+            dma16(a.QK + (size_t)(sa + krow) * a.ldqk + (a.n_heads + kvh) * HD + ((sl ^ kswz(key)) * 8),
                   Ks + p * 512);
         }
 #pragma unroll
         for (int i = 0; i < HD / 32 / HPW; ++i) {   // HD/8 V^T pieces of 8 rows x 128 B
             const int p = w * (HD / 32 / HPW) + i;
             const int d = p * 8 + (lane >> 3), sl = lane & 7;
-            dma16(a.Vt + (size_t)(kvh * HD + d) * a.ldvt + s0 + kc + ((sl ^ (d & 7)) * 8), Vs + p * 512);
+            dma16(a.Vt + (size_t)(kvh * HD + d) * a.ldvt + sa + kc + ((sl ^ (d & 7)) * 8), Vs + p * 512);
         }
     };
 
@@ -1569,7 +1573,7 @@ __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int n = 0; n < NDT; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float mrow = -__builtin_huge_valf(), lrow = 0.f;   // running maximum (log2 units) and denominator of query li
-    const int kend = a.causal ? min(L, q0 + 64) : L;
+    const int kend = a.causal ? min(Le, off + q0 + 64) : Le;
     const float scale2 = a.scale * 1.4426950408889634f;
     const int x16 = (lane ^ 16) << 2, x32 = (lane ^ 32) << 2;   // ds_bpermute addresses of the lanes that share the row
     // LDS row of tile position li (tile j adds 32 (j/2) + 4 (j%2)), and the slot key of those rows
@@ -1596,7 +1600,7 @@ __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
             }
         }
         // scale, mask, online softmax: the lane holds keys kc + 32 (j/2) + 8 lg + 4 (j%2) + r of query li
-        const bool need_mask = a.causal || kc + KC > L;   // wave-uniform: the last (partial) chunk, or causal
+        const bool need_mask = a.causal || kc + KC > Le || (kc == 0 && off != 0);   // wave-uniform: the first / last (partial) chunk, or causal
         float pmax = -__builtin_huge_valf();
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -1604,8 +1608,8 @@ __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
             for (int r = 0; r < 4; ++r) {
                 float v = s[j][r] * scale2;   // scores in log2 units: exp2 is the native v_exp_f32
                 if (need_mask) {
-                    const int kidx = kc + 32 * (j >> 1) + 8 * lg + 4 * (j & 1) + r;
-                    if (kidx >= L || (a.causal && kidx > qidx)) v = -__builtin_huge_valf();
+                    const int kidx = kc + 32 * (j >> 1) + 8 * lg + 4 * (j & 1) + r - off;   // key index inside the sequence
+                    if (kidx < 0 || kidx >= L || (a.causal && kidx > qidx)) v = -__builtin_huge_valf();
                 }
                 s[j][r] = v;
                 pmax = fmaxf(pmax, v);

@@ -310,7 +310,7 @@ class SentenceTransformer:
             return [order[b0:b0 + batch_size] for b0 in range(0, len(order), batch_size)]
         passes, cur, tok = [], [], 0
         for i in order:
-            t = (len(token_lists[i]) + 7) & ~7                    # a sequence starts at a multiple of 8 tokens
+            t = len(token_lists[i])                               # sequences are packed back to back
             if cur and tok + t > self.token_budget:
                 passes.append(cur)
                 cur, tok = [], 0

@@ -1022,7 +1022,7 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True):
         cur, tok = [], 0
         while len(batches) < NBATCH:
             L = int(np.clip(np.exp(rng.normal(np.log(220), 0.45)), 8, 512))
-            t = (L + 7) & ~7
+            t = L
             if cur and tok + t > budget:
                 batches.append(cur)
                 cur, tok = [], 0
