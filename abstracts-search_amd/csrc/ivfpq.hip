@@ -1526,7 +1526,8 @@ int mi_merge_topk(int device, int nparts, int64_t nq, int k, const float *D_part
         const bool all_dev = is_device_ptr(D_parts) && is_device_ptr(I_parts) && is_device_ptr(D) && is_device_ptr(I);
         const size_t n_in = (size_t)nparts * nq * k, n_out = (size_t)nq * k;
         if (all_dev) {
-            launch_merge(D_parts, I_parts, nparts, nq * k, k, nq, k, D, I, k, 0, nullptr, nullptr, st);
+            static thread_local DevBuf scratch;   // the selection tier's rows (long lists): kept, so the call only enqueues
+            launch_merge(D_parts, I_parts, nparts, nq * k, k, nq, k, D, I, k, 0, nullptr, nullptr, st, -1, IdMap{}, &scratch);
             return;
         }
         MI_REQUIRE(!is_device_ptr(D_parts) && !is_device_ptr(I_parts) && !is_device_ptr(D) && !is_device_ptr(I),
