@@ -25,6 +25,7 @@ hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // launches that took the K-split tail (f32 atomics into the residual stream): tests assert the path ran
 std::atomic<int64_t> g_tail_split_launches{0};
+std::atomic<int64_t> g_splitk_launches{0};
 
 struct LayerW {
     DevBuf wqkv, bqkv, wo, wgu, wd, ln1, ln2;
@@ -143,6 +144,7 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
         if (s_env >= 0) S = std::min(s_env, nt64);
         if (S >= 2 && (size_t)S * g.M * g.N * 4 <= g.part_bytes) {
             split_all = S;
+            ++g_splitk_launches;
             g.part = part;
             g.tail_first = 0;
             g.tail_split = S;
@@ -286,6 +288,8 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         std::string cfg = force ? std::string(force) : "";
         if (cfg.empty()) cfg = g.M <= 64 ? "tiny" : tiles_big >= 100 ? "big" : tiles_mid >= 150 ? "mid" : "small";
         g.ksplit = 1;
+        const bool split_k = !force && epi == EPI_RESID && g.part && g.N % 8 == 0 && mid_split_pays(g) && !std::getenv("MI_NO_SPLITK");
+        if (!split_k) g.part = nullptr;
         if (cfg != "tiny" || std::getenv("MI_NO_TILED_W")) g.Wt = nullptr;   // only the few-token path streams fragment-major weights
         const bool skinny_ok = g.Wt && g.M <= 32 && g.N % 16 == 0 && (g.K <= SKINNY_KS_MAX || (epi == EPI_RESID && !g.bias));
         // measured per launch for one query: gate/up 14.5 vs 17.3 us (ring tiles), but QKV 10.7 vs 8.1
@@ -303,6 +307,12 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             launch_slab<2>(epi, g, st);
         } else if (cfg == "half") {
             launch_ring<8, 4, 1, 4, 3>(epi, g, st);   // 128x256, 4 waves, 72 KiB ring: two workgroups per CU
+        } else if (split_k && (cfg == "small" || cfg == "mid" || cfg == "big")) {
+            // ~100 to ~5000 tokens through the down projection: the 256x256 slab kernel with EVERY tile split along K through the
+            // workspace (launch_slab) -- 576 x 1536 x 8960: 18 tiles x 14 slices = 252 workgroups of 20 K steps + one reduction
+            // pass, where 128x128 tiles with K split three ways by f32 atomics took 76 us; at 1558 / 2097 tokens the forward
+            // pass went 7.91 -> 6.46 / 9.21 -> 7.82 ms against the 128x128 ring tiles
+            launch_slab<2>(epi, g, st);
         } else if (cfg == "big" && !std::getenv("MI_GEMM_RING") && (epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {   // the slab kernel stores 8 bf16 columns per lane
             // measured (tools/gemm_bench.py, 32768 tokens): 8 waves 1051 / 1060 TF on QKV / O, 4 waves 1106 / 1303 on
             // gate-up / down (ring kernel: 968 / 952 / 1006 / 1166)
@@ -312,13 +322,6 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             launch_ring<8, 4, 2, 4, 4>(epi, g, st);
         } else if (cfg == "mid") {
             launch_ring<4, 4, 2, 2, 4>(epi, g, st);
-        } else if (cfg == "small" && !force && epi == EPI_RESID && g.part && g.N % 8 == 0 && mid_split_pays(g) &&
-                   !(std::getenv("MI_MID") && std::string(std::getenv("MI_MID")) == "old")) {
-            // a few hundred tokens through a residual GEMM: the 256x256 slab kernel with EVERY tile split along K through the
-            // workspace (launch_slab) -- 576 x 1536 x 8960: 18 tiles x 14 slices = 252 workgroups of 20 K steps + one reduction
-            // pass, where 128x128 tiles with K split three ways by f32 atomics took 76 us
-            if (g.K >= 4096) launch_slab<2>(epi, g, st);
-            else launch_slab<4>(epi, g, st);
         } else if (cfg == "mid64" || (cfg == "small" && !force && epi != EPI_SWIGLU && g.M > 256 && g.K < 4096 && !std::getenv("MI_NO_MID64"))) {
             // a few hundred to ~1500 tokens through the QKV / O projections: 128x64 tiles, 4 waves of 64x32 -- 3 DMA pieces per
             // wave per K step where the 128x32 / 2-wave tiles issue 5 (they are DMA-issue-bound): QKV 16.0 -> 13.5 us at 576
@@ -605,8 +608,9 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
     // split-K workspace of the residual GEMMs when the tokens are too few for their tiles to fill the chip (launch_slab)
     float *part = nullptr;
     size_t part_bytes = 0;
-    if (T > 64 && T <= 4096) {
-        part_bytes = (size_t)16 * T * H * 4;
+    const int part_slices = std::min(16, 256 / (((T + 255) / 256) * ((H + 255) / 256)));   // launch_slab's slice count for T x H
+    if (T > 64 && part_slices >= 2) {
+        part_bytes = (size_t)part_slices * T * H * 4;
         part = static_cast<float *>(ws.ws_part.reserve(part_bytes));
     }
 
@@ -998,6 +1002,7 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
     return guard([&] {
         MI_REQUIRE(name && value, "null argument");
         if (std::string(name) == "tail_split_launches") *value = g_tail_split_launches.load();
+        else if (std::string(name) == "splitk_launches") *value = g_splitk_launches.load();
         else throw Error(std::string("unknown debug counter: ") + name);
     });
 }
