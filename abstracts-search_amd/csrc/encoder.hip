@@ -26,6 +26,7 @@ hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 // launches that took the K-split tail (f32 atomics into the residual stream): tests assert the path ran
 std::atomic<int64_t> g_tail_split_launches{0};
 std::atomic<int64_t> g_splitk_launches{0};
+std::atomic<int64_t> g_reduce_norm_launches{0};
 
 struct LayerW {
     DevBuf wqkv, bqkv, wo, wgu, wd, ln1, ln2;
@@ -94,7 +95,7 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
 
 // 256x256 tiles, slab ring + hand-ordered K loop (gemm_bf16_slab_kernel; WN_ = 4: 8 waves, 2: 4 waves): whole-K workgroups, the same wave-quantisation tail split
 template <int WN_>
-void launch_slab(int epi, GemmArgs g, hipStream_t st) {
+bool launch_slab(int epi, GemmArgs g, hipStream_t st) {
     g.tiles_m = (g.M + 255) / 256;
     g.tiles_n = (g.N + 255) / 256;
     const int per = (g.tiles_m * g.tiles_n + 7) / 8;
@@ -152,11 +153,20 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
         }
     }
     dim3 grid(nblocks), block(128 * WN_);
+    bool normed = false;                                  // the reduction pass also wrote the RMSNorm the caller asked for
     auto finish_split = [&] {
         if (split_all == 1) return;
-        const int64_t n4 = (int64_t)g.M * (g.N / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, g.X, (int64_t)g.ldc, g.part, split_all,
-                           g.M, g.N, g.bias);
+        static const bool no_fuse = std::getenv("MI_NO_REDUCE_NORM") != nullptr;
+        if (g.norm_w && g.norm_y && g.ldc == g.N && g.N <= 2048 && !no_fuse) {
+            hipLaunchKernelGGL(splitk_reduce_norm_kernel, dim3((unsigned)g.M), dim3(256), 0, st, g.X, g.part, split_all, g.M, g.N, g.bias,
+                               g.norm_w, g.norm_eps, g.norm_y);
+            normed = true;
+            ++g_reduce_norm_launches;
+        } else {
+            const int64_t n4 = (int64_t)g.M * (g.N / 4);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, g.X, (int64_t)g.ldc, g.part,
+                               split_all, g.M, g.N, g.bias);
+        }
         MI_HIP(hipGetLastError());
     };
     // more work units than CUs: one persistent workgroup per CU could walk its units and request the next unit's first
@@ -174,7 +184,7 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
             default: throw Error("bad epilogue");
         }
         MI_HIP(hipGetLastError());
-        return;
+        return false;
     }
     switch (epi) {
         case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_STORE, WN_>), grid, block, 0, st, g); break;
@@ -185,6 +195,7 @@ void launch_slab(int epi, GemmArgs g, hipStream_t st) {
     }
     MI_HIP(hipGetLastError());
     finish_split();
+    return normed;
 }
 
 // narrow tiles (WNT = 1): no SwiGLU instantiation (it pairs two N tiles inside a wave)
@@ -271,7 +282,8 @@ bool mid_split_pays(const GemmArgs &g) {
     return g.M > 64 && g.K >= min_k && S >= 2 && ntiles * S >= min_wg && (size_t)S * g.M * g.N * 4 <= g.part_bytes;
 }
 
-void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
+// returns true when the launch also wrote the RMSNorm of the updated stream the caller asked for (GemmArgs::norm_w / norm_y)
+bool launch_gemm(int epi, GemmArgs g, hipStream_t st) {
     MI_REQUIRE(g.K % 64 == 0, "encoder GEMM: K must be a multiple of 64");
     MI_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "encoder GEMM: leading dimensions must be multiples of 8");
     MI_REQUIRE(g.N % 4 == 0 && g.ldc % 4 == 0, "encoder GEMM: N and ldc must be multiples of 4");
@@ -312,7 +324,7 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             // workspace (launch_slab) -- 576 x 1536 x 8960: 18 tiles x 14 slices = 252 workgroups of 20 K steps + one reduction
             // pass, where 128x128 tiles with K split three ways by f32 atomics took 76 us; at 1558 / 2097 tokens the forward
             // pass went 7.91 -> 6.46 / 9.21 -> 7.82 ms against the 128x128 ring tiles
-            launch_slab<2>(epi, g, st);
+            return launch_slab<2>(epi, g, st);
         } else if (cfg == "big" && !std::getenv("MI_GEMM_RING") && (epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {   // the slab kernel stores 8 bf16 columns per lane
             // measured (tools/gemm_bench.py, 32768 tokens): 8 waves 1051 / 1060 TF on QKV / O, 4 waves 1106 / 1303 on
             // gate-up / down (ring kernel: 968 / 952 / 1006 / 1166)
@@ -355,7 +367,7 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
                 launch_ring<2, 2, 1, 2, 8>(epi, g, st);
             }
         }
-        return;
+        return false;
     }
     g.Wt = nullptr;
     g.tiles_m = (g.M + 127) / 128;
@@ -371,6 +383,7 @@ void launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         default: throw Error("bad epilogue");
     }
     MI_HIP(hipGetLastError());
+    return false;
 }
 
 }  // namespace
@@ -569,13 +582,14 @@ Batch prepare_batch(mi_encoder *h, mi_encoder::WS &ws, int nseq, const int32_t *
     return b;
 }
 
-void timed_gemm(mi_encoder *h, int epi, const GemmArgs &g, hipStream_t st) {
-    launch_gemm(epi, g, st);
-    if (!h->prof) return;
+bool timed_gemm(mi_encoder *h, int epi, const GemmArgs &g, hipStream_t st) {
+    const bool normed = launch_gemm(epi, g, st);
+    if (!h->prof) return normed;
     std::lock_guard<std::mutex> hl(h->mu);
     h->prof_launches.push_back({epi, g});
     h->prof_stream = st;
     h->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
+    return normed;
 }
 
 // the decoder stack: leaves the residual stream (before the final norm) in ws_x
@@ -647,11 +661,13 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
     hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, st, b.ids,
                        h->embed.get<bf16_t>(), H, T, x);
     MI_HIP(hipGetLastError());
+    bool normed = false;
     for (int l = 0; l < c.n_layers; ++l) {
         LayerW &w = h->layers[l];
         Range layer_range("mi_encoder:layer");
-        hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln1.get<float>(), H, T,
-                           c.rms_eps, xn);
+        if (!normed)                                 // (else the previous layer's split-K reduction pass wrote it)
+            hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln1.get<float>(), H, T,
+                               c.rms_eps, xn);
         GemmArgs g{};
         g.A = xn; g.lda = H; g.W = w.wqkv.get<bf16_t>(); g.ldw = H; g.M = T; g.N = h->qk_cols + h->v_cols; g.K = H;
         g.bias = w.bqkv.get<float>(); g.C = qk; g.ldc = h->qk_cols; g.Vt = vt; g.ldvt = ldvt; g.qk_cols = h->qk_cols;
@@ -692,7 +708,10 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         d.A = hb; d.lda = I; d.W = w.wd.get<bf16_t>(); d.ldw = I; d.M = T; d.N = H; d.K = I; d.X = x; d.ldc = H;
         d.part = part; d.part_bytes = part_bytes;
         if (few) d.Wt = w.wd_t.get<bf16_t>();
-        timed_gemm(h, EPI_RESID, d, st);
+        if (l + 1 < c.n_layers) {                    // the next layer's first RMSNorm can ride in a split-K reduction pass
+            d.norm_w = h->layers[l + 1].ln1.get<float>(); d.norm_y = xn; d.norm_eps = c.rms_eps;
+        }
+        normed = timed_gemm(h, EPI_RESID, d, st);
     }
 }
 
@@ -1003,6 +1022,7 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
         MI_REQUIRE(name && value, "null argument");
         if (std::string(name) == "tail_split_launches") *value = g_tail_split_launches.load();
         else if (std::string(name) == "splitk_launches") *value = g_splitk_launches.load();
+        else if (std::string(name) == "reduce_norm_launches") *value = g_reduce_norm_launches.load();
         else throw Error(std::string("unknown debug counter: ") + name);
     });
 }

@@ -235,6 +235,12 @@ struct GemmArgs {
     unsigned long long *ts;   // null, or [workgroups][8] s_memtime stamps of the first tile (MI_GEMM_TS=1 profile launch)
     float *gmax;       // EPI_F32H on the 8-wave slab kernel: null, or [M][ld_gmax] maxima of every 64-column group of a
     int ld_gmax;       // score row (+inf if the group holds a non-finite score) -- what select_refine_kernel's cut needs
+    // host side only (EPI_RESID): the RMSNorm that reads the updated stream next -- y = bf16(X * rsqrt(mean(X^2) + eps) * w).
+    // A launch that ends in the split-K reduction pass folds it into that pass (splitk_reduce_norm_kernel) and says so
+    // (launch_gemm returns true); any other launch leaves it to the caller's rmsnorm_kernel.
+    const float *norm_w;
+    bf16_t *norm_y;
+    float norm_eps;
 };
 
 // W [N][ldw] (N % 16 == 0, K % 32 == 0) -> fragment-major Wt: one 64-thread workgroup per
@@ -1182,6 +1188,62 @@ __global__ void __launch_bounds__(256)
     float4 x = *px;
     x.x += acc.x; x.y += acc.y; x.z += acc.z; x.w += acc.w;
     *px = x;
+}
+
+// The same reduction with the RMSNorm that reads the updated row folded in (N <= 2048, ldx == N): one workgroup per row,
+// thread t owns the float4 chunks at columns 4 t and 4 t + 1024; the row's sum of squares goes wave -> LDS -> a fixed-order
+// sum, so the result does not depend on anything but the row.  Saves the separate pass over X (and its launch) for the
+// few-hundred-token batches the split-K path serves.
+__global__ void __launch_bounds__(256)
+    splitk_reduce_norm_kernel(float *__restrict__ X, const float *__restrict__ part, int S, int M, int N,
+                              const float *__restrict__ bias, const float *__restrict__ w, float eps, bf16_t *__restrict__ y) {
+    __shared__ float wsum[4];
+    const int m = blockIdx.x, t = threadIdx.x;
+    const size_t plane = (size_t)M * N;
+    float4 v[2];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = t * 4 + 1024 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < N) {
+            const float *p = part + (size_t)m * N + c;
+            float4 *px = reinterpret_cast<float4 *>(X + (size_t)m * N + c);
+            float4 x = *px;
+            float4 acc = *reinterpret_cast<const float4 *>(p);
+            for (int s0 = 1; s0 < S; s0 += 8) {          // eight planes' loads in flight, added in ascending order
+                float4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = *reinterpret_cast<const float4 *>(p + (size_t)min(s0 + u, S - 1) * plane);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (s0 + u < S) { acc.x += q[u].x; acc.y += q[u].y; acc.z += q[u].z; acc.w += q[u].w; }
+            }
+            if (bias) {
+                const float4 b = *reinterpret_cast<const float4 *>(bias + c);
+                acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+            }
+            x.x += acc.x; x.y += acc.y; x.z += acc.z; x.w += acc.w;
+            *px = x;
+            v[j] = x;
+            ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((t & 63) == 0) wsum[t >> 6] = ss;
+    __syncthreads();
+    const float inv = rsqrtf((((wsum[0] + wsum[1]) + wsum[2]) + wsum[3]) / (float)N + eps);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = t * 4 + 1024 * j;
+        if (c < N) {
+            const float4 g = *reinterpret_cast<const float4 *>(w + c);
+            uint2 o;
+            o.x = pack2(v[j].x * inv * g.x, v[j].y * inv * g.y);
+            o.y = pack2(v[j].z * inv * g.z, v[j].w * inv * g.w);
+            *reinterpret_cast<uint2 *>(y + (size_t)m * N + c) = o;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------

@@ -280,11 +280,12 @@ def test_query_batches_at_stella_widths_vs_oracle(st, nq, layers):
     lens = rng.integers(16, 49, nq)
     toks = [rng.integers(0, cfg["vocab_size"], int(L)).tolist() for L in lens]
     model = st.SentenceTransformer(config=cfg, weights=W)
-    before = st.debug_counter("splitk_launches")
+    before, before_n = st.debug_counter("splitk_launches"), st.debug_counter("reduce_norm_launches")
     e = model.encode_tokens(toks, batch_size=nq, normalize_embeddings=True)
     # ~100 to ~5000 tokens: the down projection of every layer runs K-split through the workspace (16 / 64 / 132 queries:
-    # 18 x 14, 54 x 4 and 102 x 2 workgroups)
+    # 18 x 14, 54 x 4 and 102 x 2 workgroups), and its reduction pass writes the next layer's first RMSNorm
     assert st.debug_counter("splitk_launches") - before == (layers if nq in (16, 64, 132) else 0)
+    assert st.debug_counter("reduce_norm_launches") - before_n == (layers - 1 if nq in (16, 64, 132) else 0)
     Wc = {k: v.float().cpu() for k, v in W.items()}
     with torch.no_grad():
         ref = E.encode(E.EncoderConfig(**cfg), Wc, np.concatenate(toks), np.concatenate([[0], np.cumsum(lens)]), True).numpy()
