@@ -109,6 +109,12 @@ bool launch_slab(int epi, GemmArgs g, hipStream_t st) {
     // measured at 29 312 tokens (tools/gemm_bench.py, profiles/r03_gemm_tile_order.txt): chip patches +3 / +5 / +5 % on the
     // QKV / O / down shapes (N <= 2048), -1.5 % on gate-up (N = 17 920: 70 tile columns) -- so by the width of the GEMM
     g.order = order_env >= 0 ? order_env : (g.tiles_n <= 16 ? 1 : 0);
+    // staggered start (gemm_bf16_slab_kernel): for the epilogues that move the most bytes per tile, when the launch runs several rounds
+    static const int stagger_env = std::getenv("MI_GEMM_STAGGER") ? std::atoi(std::getenv("MI_GEMM_STAGGER")) : -1;
+    static const int stagger_qkv = std::getenv("MI_GEMM_STAGGER_QKV") ? std::atoi(std::getenv("MI_GEMM_STAGGER_QKV")) : -1;
+    g.stagger = 0;
+    if (nblocks > 256u && epi == EPI_RESID) g.stagger = stagger_env >= 0 ? stagger_env : 0;
+    if (nblocks > 256u && epi == EPI_QKV) g.stagger = stagger_qkv >= 0 ? stagger_qkv : 0;
     if (epi == EPI_RESID && !g.bias && !std::getenv("MI_NO_TAIL_SPLIT")) {
         const int ncu = 256, nb = 8 * per;
         const int main_b = nb / ncu * ncu, rem = nb - main_b;
@@ -173,7 +179,8 @@ bool launch_slab(int epi, GemmArgs g, hipStream_t st) {
     // slabs before the epilogue of the current one.
     // Off by default: it measured no faster (1 136 vs 1 169 TF on the QKV shape) -- what a tile pays outside its K loop
     // is the ISSUE of the epilogue's stores, not the relaunch or the pipeline fill.  MI_GEMM_PERSIST=1 keeps the experiment.
-    static const bool persist_on = std::getenv("MI_GEMM_PERSIST") && std::atoi(std::getenv("MI_GEMM_PERSIST")) != 0;
+    static const int persist_env = std::getenv("MI_GEMM_PERSIST") ? std::atoi(std::getenv("MI_GEMM_PERSIST")) : 0;   // 1: every epilogue, 2: SwiGLU only
+    const bool persist_on = persist_env == 1 || (persist_env == 2 && epi == EPI_SWIGLU);
     if (persist_on && nblocks > 256) {
         dim3 pgrid(256);
         switch (epi) {
@@ -582,7 +589,48 @@ Batch prepare_batch(mi_encoder *h, mi_encoder::WS &ws, int nseq, const int32_t *
     return b;
 }
 
+// profile launch (MI_GEMM_TS=1): in-kernel s_memtime stamps of every workgroup's phases (256x256 tiles), mean / max to stderr
+void stamped_launch(int epi, GemmArgs g, hipStream_t stream) {
+    const int M = g.M, N = g.N, K = g.K;
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nb = 8 * ((tiles + 7) / 8) * 2;   // (tail-split launches have more workgroups than tiles)
+    DevBuf tsb;
+    unsigned long long *dts = tsb.as<unsigned long long>((size_t)nb * 8);
+    MI_HIP(hipMemsetAsync(dts, 0, (size_t)nb * 64, stream));
+    g.ts = dts;
+    launch_gemm(epi, g, stream);
+    std::vector<unsigned long long> h((size_t)nb * 8);
+    MI_HIP(hipStreamSynchronize(stream));
+    MI_HIP(hipMemcpy(h.data(), dts, h.size() * 8, hipMemcpyDeviceToHost));
+    const char *names[8] = {"", "first K tile landed", "barrier passed", "K loop issued", "epilogue issued", "stores acknowledged", "", ""};
+    std::fprintf(stderr, "[gemm stamps] epilogue %d M %d N %d K %d, %d workgroup slots, s_memtime ticks since the workgroup's start\n", epi, M, N, K, nb);
+    const bool slab = h[5] > 4096;           // the slab kernel writes the CU identity into slot 5 and the absolute start into slot 0
+    for (int i = 1; i <= (slab ? 4 : 5); ++i) {
+        double sum = 0, mx = 0; size_t cnt = 0;
+        for (int b = 0; b < nb; ++b) { const double v = (double)h[(size_t)b * 8 + i]; if (v > 0) { sum += v - 1; mx = std::max(mx, v - 1); ++cnt; } }
+        if (cnt) std::fprintf(stderr, "  %-22s n=%6zu mean %9.1f max %9.1f\n", slab ? (i == 1 ? "first slabs landed" : i == 2 ? "K loop done" : i == 3 ? "epilogue issued" : "stores acknowledged") : names[i], cnt, sum / cnt, mx);
+    }
+    if (slab) {
+        // per CU: the gap between a workgroup's last stamp and the start of the next workgroup on the same CU
+        std::map<unsigned long long, std::vector<std::pair<unsigned long long, unsigned long long>>> cu;
+        for (int b = 0; b < nb; ++b)
+            if (h[(size_t)b * 8 + 4] && h[(size_t)b * 8]) cu[h[(size_t)b * 8 + 5] & 0xf0000ff00ull].push_back({h[(size_t)b * 8], h[(size_t)b * 8] + h[(size_t)b * 8 + 4] - 1});
+        double gs = 0, gmax = 0; size_t gn = 0; unsigned long long t_first = ~0ull, t_last = 0;
+        for (auto &kv : cu) {
+            std::sort(kv.second.begin(), kv.second.end());
+            for (size_t i = 0; i < kv.second.size(); ++i) {
+                t_first = std::min(t_first, kv.second[i].first); t_last = std::max(t_last, kv.second[i].second);
+                if (i) { const double gap = (double)kv.second[i].first - (double)kv.second[i - 1].second; gs += gap; gmax = std::max(gmax, gap); ++gn; }
+            }
+        }
+        std::fprintf(stderr, "  %zu CU identities; gap between consecutive workgroups of a CU: n=%zu mean %.1f max %.1f; first start -> last end %.1f\n",
+                     cu.size(), gn, gn ? gs / gn : 0.0, gmax, (double)(t_last - t_first));
+    }
+}
+
 bool timed_gemm(mi_encoder *h, int epi, const GemmArgs &g, hipStream_t st) {
+    static const bool enc_ts = std::getenv("MI_ENC_TS") != nullptr;      // stamps of the first layer's four GEMMs, in place
+    static std::atomic<int> ts_left{4};
+    if (enc_ts && g.M > 4096 && ts_left.fetch_sub(1) > 0) stamped_launch(epi, g, st);
     const bool normed = launch_gemm(epi, g, st);
     if (!h->prof) return normed;
     std::lock_guard<std::mutex> hl(h->mu);
@@ -1036,23 +1084,7 @@ int mi_enc_gemm_bf16(int device, int M, int N, int K, const void *A, const void 
         g.A = static_cast<const bf16_t *>(A); g.lda = K; g.W = static_cast<const bf16_t *>(W); g.ldw = K;
         g.M = M; g.N = N; g.K = K; g.C = static_cast<bf16_t *>(C); g.ldc = N;
         if (std::getenv("MI_GEMM_TS")) {
-            // profile launch: in-kernel s_memtime stamps of every workgroup's phases (big tiles), mean / max to stderr
-            const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nb = 8 * ((tiles + 7) / 8);
-            DevBuf tsb;
-            unsigned long long *dts = tsb.as<unsigned long long>((size_t)nb * 8);
-            MI_HIP(hipMemsetAsync(dts, 0, (size_t)nb * 64, as_stream(stream)));
-            g.ts = dts;
-            launch_gemm(EPI_STORE, g, as_stream(stream));
-            std::vector<unsigned long long> h((size_t)nb * 8);
-            MI_HIP(hipStreamSynchronize(as_stream(stream)));
-            MI_HIP(hipMemcpy(h.data(), dts, h.size() * 8, hipMemcpyDeviceToHost));
-            const char *names[8] = {"", "first K tile landed", "barrier passed", "K loop issued", "epilogue issued", "stores acknowledged", "", ""};
-            std::fprintf(stderr, "[gemm stamps] M %d N %d K %d, %d workgroups, s_memtime ticks (100 MHz) since the workgroup's start\n", M, N, K, nb);
-            for (int i = 1; i <= 5; ++i) {
-                double sum = 0, mx = 0; size_t cnt = 0;
-                for (int b = 0; b < nb; ++b) { const double v = (double)h[(size_t)b * 8 + i]; if (v > 0) { sum += v - 1; mx = std::max(mx, v - 1); ++cnt; } }
-                if (cnt) std::fprintf(stderr, "  %-22s n=%6zu mean %9.1f max %9.1f\n", names[i], cnt, sum / cnt, mx);
-            }
+            stamped_launch(EPI_STORE, g, as_stream(stream));
             return;
         }
         launch_gemm(EPI_STORE, g, as_stream(stream));

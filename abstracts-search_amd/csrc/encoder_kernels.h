@@ -43,8 +43,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+// two f32 -> packed bf16, round to nearest even: gfx950's v_cvt_pk_bf16_f32 (one instruction where the integer
+// formulation above takes nine -- the epilogue of a 256x256 tile converts 65 536 values)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return *reinterpret_cast<bf16x8 *>(&v); }
 
@@ -241,6 +246,7 @@ struct GemmArgs {
     const float *norm_w;
     bf16_t *norm_y;
     float norm_eps;
+    int stagger;       // slab kernel: the first round's workgroups start up to stagger x 1024 cycles apart (0 = together)
 };
 
 // W [N][ldw] (N % 16 == 0, K % 32 == 0) -> fragment-major Wt: one 64-thread workgroup per
@@ -817,6 +823,22 @@ __device__ __forceinline__ void dma16_off(const void *gptr, unsigned lds_off) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n" ::"s"(lds_off), "v"(gptr) : "memory");
 }
 
+// The same piece addressed through a buffer resource: one 32-bit VGPR offset per lane + a scalar offset (the K position),
+// the base and the extent in four SGPRs.  Rows past the end of the matrix read zeros (range-checked on the VGPR offset).
+typedef int __attribute__((ext_vector_type(4))) i32x4;
+__device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));   // stride 0: a raw buffer
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void dma16_buf(const i32x4 &srd, unsigned voff, unsigned soff, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n" ::"s"(lds_off), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
 // Which W row feeds position p of a wave's MFMA tile j is free -- it only decides which output column a lane ends
 // up holding.  PERM 0: tile j = W rows 16 j + p (a lane holds 4 consecutive columns of tile j).  bf16 outputs
 // choose rows so that a lane's values of two tiles are 8 CONSECUTIVE output columns: one 16-byte store, 64-byte
@@ -882,8 +904,33 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     // maps above and {0..15} under the plain one; this key keeps all of them on 16 distinct 16-byte LDS granules.
     const int prow = lane >> 3, scol = ((lane & 7) ^ prow) * 8;
     const int scolW[2] = {((lane & 7) ^ (prow & 3)) * 8, ((lane & 7) ^ ((prow & 3) | 4)) * 8};   // even / odd piece (bit 3 of the row)
-    const bf16_t *srcA[PPW], *srcW[PPW];
     const unsigned dma_dst = lds0 + (unsigned)w * PPW * 1024u;       // + slot * SLAB_B + p * 1024
+#ifdef MI_DMA_BUFFER
+    // buffer-addressed pieces (the launcher guarantees M * lda and N * ldw < 2^31 elements): byte offset of this lane's
+    // 16 bytes of piece p inside A / W at K column 0; the K position is the scalar offset
+    const i32x4 srdA = make_srd(g.A, (unsigned)((size_t)g.M * g.lda * 2)), srdW = make_srd(g.W, (unsigned)((size_t)g.N * g.ldw * 2));
+    unsigned voA[PPW], voW[PPW];
+    unsigned so0 = 0;                                        // byte offset of the unit's first K column
+    auto set_sources = [&](int tm_, int tn_, int kt0_) {
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            const int r = (w * PPW + p) * 8 + prow;
+            voA[p] = ((unsigned)(tm_ * BM + r) * (unsigned)g.lda + (unsigned)scol) * 2u;
+            voW[p] = ((unsigned)(tn_ * BN + r) * (unsigned)g.ldw + (unsigned)scolW[p & 1]) * 2u;
+        }
+        so0 = (unsigned)kt0_ * 128u;
+    };
+    auto request_first = [&](int nk_) {                      // slabs 0 .. DQ-1 into ring slots 0 .. DQ-1
+#pragma unroll
+        for (int q = 0; q < DQ; ++q)
+            if (q < nk_) {
+#pragma unroll
+                for (int p = 0; p < PPW; ++p)
+                    dma16_buf((q & 1) ? srdW : srdA, (q & 1) ? voW[p] : voA[p], so0 + (unsigned)(q >> 1) * 128u, dma_dst + q * SLAB_B + p * 1024u);
+            }
+    };
+#else
+    const bf16_t *srcA[PPW], *srcW[PPW];
     auto set_sources = [&](int tm_, int tn_, int kt0_) {
 #pragma unroll
         for (int p = 0; p < PPW; ++p) {
@@ -901,6 +948,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     dma16_off(((q & 1) ? srcW[p] : srcA[p]) + (size_t)(q >> 1) * 64, dma_dst + q * SLAB_B + p * 1024u);
             }
     };
+#endif
 
     // fragment (16 rows x 32 k) of K half kk: lane (li, lg) reads row li, global slot 4 kk + lg -> LDS slot ^ (row & 7)
     const unsigned rdA = lds0 + (unsigned)(wm * 128 + li) * 128u + (unsigned)((lg ^ (li & 7)) * 16);          // kk = 1: ^ 64
@@ -928,9 +976,17 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
         // slab u + DQ: DQ even -> an A slab in even steps, a W slab in odd steps; tile (u + DQ) >> 1
         const unsigned sd = wrap(c + par + DQ);
         const bool dma_on = decltype(STEADY)::value || u + DQ < nk;
+#ifdef MI_DMA_BUFFER
+        const unsigned soff = so0 + (unsigned)((u + DQ) >> 1) * 128u;
+#else
         const size_t koff = (size_t)((u + DQ) >> 1) * 64;
+#endif
         static_for<NMF>([&](auto M_) {
+#ifdef MI_MFMA_JOUTER   // experiment: hold the W fragment (the MFMA's first source under SWAP) across WMT consecutive MFMAs instead of the A fragment
+            constexpr int m = decltype(M_)::value, i = m % WMT, j = m / WMT;
+#else
             constexpr int m = decltype(M_)::value, i = m / WNT, j = m % WNT;
+#endif
             mfma(acc[i][j], ac[i], bc[j]);
             if constexpr (m % RSTEP == RSTEP - 1 && m / RSTEP < NRD) {
                 constexpr int r = m / RSTEP;                          // first the W fragments, then the A fragments
@@ -939,7 +995,11 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
             }
             if constexpr (m % DSTEP == DSTEP - 1) {
                 constexpr int p = m / DSTEP;
+#ifdef MI_DMA_BUFFER
+                if (dma_on) dma16_buf(par == 0 ? srdA : srdW, par == 0 ? voA[p] : voW[p], soff, dma_dst + sd * SLAB_B + p * 1024u);
+#else
                 if (dma_on) dma16_off((par == 0 ? srcA[p] : srcW[p]) + koff, dma_dst + sd * SLAB_B + p * 1024u);
+#endif
             }
         });
     };
@@ -950,7 +1010,26 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
 
     int unit = (int)blockIdx.x;
     int tm, tn, ksplit, kt0;
+    // profile launches (MI_GEMM_TS=1): slot 0 = absolute start, 1..4 = ticks since the start at: first slabs landed, K loop
+    // issued, epilogue issued, stores acknowledged; 5 = which CU (HW_ID | XCC_ID << 32)
+    const unsigned long long ts0 = g.ts ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto stamp = [&](int slot) {
+        if (g.ts && threadIdx.x == 0) g.ts[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime() - ts0 + 1;
+    };
+    if (g.ts && threadIdx.x == 0) {
+        g.ts[(size_t)blockIdx.x * 8] = ts0;
+        g.ts[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_REG_HW_ID
+                                           ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);   // HW_REG_XCC_ID
+    }
     if (!decode(unit, tm, tn, ksplit, kt0, nk)) return;
+    if (g.stagger > 0 && blockIdx.x < 256u) {
+        // De-synchronise the CUs: the workgroups of a round otherwise leave their K loops together and their epilogues hit
+        // the memory system as one burst (a residual epilogue reads and writes 512 KiB per tile: 128 MiB at once, ~45 000
+        // cycles where a lone tile takes ~10 000).  The first round's workgroups start 0 .. stagger x 1024 cycles apart, in
+        // dispatch order; later workgroups inherit the phase of the CU they land on.
+        const int q = (int)(blockIdx.x * (unsigned)g.stagger) >> 8;
+        for (int i = 0; i < q; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     set_sources(tm, tn, kt0);
     request_first(nk);
     for (;;) {   // one pass per work unit
@@ -963,6 +1042,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     // loads return in order among themselves); fragments of step 0 read
     wait_tiles<PPW, DQ - 2>(max(0, min(DQ - 2, nk - 2)), false);
     asm volatile("s_barrier" ::: "memory");
+    stamp(1);
     static_for<WNT>([&](auto R) { lds_read16<slab_w_tile_off<PERM>(decltype(R)::value)>(b0[decltype(R)::value], rdB + SLAB_B); });
     static_for<WMT>([&](auto R) { lds_read16<decltype(R)::value * 2048>(a0[decltype(R)::value], rdA); });
 
@@ -989,6 +1069,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     // the inline-asm MFMAs are opaque to the hazard recogniser: results -> v_accvgpr_read needs wait states; the last
     // step's (unused) fragment reads are retired here too, so nothing of the asm stream is in flight past this point
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    stamp(2);
 
     // PERSIST: request the next unit's first slabs before this unit's epilogue -- the workgroup relaunch, the
     // pipeline fill (the first slabs' trip from HBM / L2) and the drain of the epilogue's stores overlap
@@ -1097,6 +1178,9 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 } else {
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (g.bias && col < g.N) bv = *reinterpret_cast<const float4 *>(g.bias + col);
+                // (requesting X two or four 16-row blocks ahead, so that the eight blocks of a wave are not eight dependent round
+                // trips, measured no better: the in-kernel stamps put this epilogue at ~45 000 cycles of a ~110 000-cycle
+                // O-projection tile because all 256 tiles of a round move 128 MiB at once -- HBM-bound, not latency-bound)
                 float4 xs[16 / RPI];
 #pragma unroll
                 for (int it = 0; it < 16 / RPI; ++it) {
@@ -1158,6 +1242,11 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
 #pragma unroll
             for (int j = 0; j < WNT; ++j) store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
         }
+    }
+    stamp(3);
+    if (g.ts) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(4);
     }
     if (!more) break;
     tm = tm2; tn = tn2; ksplit = ksplit2; kt0 = kt02; nk = nk2;

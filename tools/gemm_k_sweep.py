@@ -9,6 +9,11 @@ tiles = ((M + 255) // 256) * ((N + 255) // 256)
 pts = []
 for K in [int(k) for k in os.environ.get("KS", "512,1024,1536,3072,6144,8960").split(",")]:
     A = torch.randn((M, K), device="cuda").bfloat16(); W = (torch.randn((N, K), device="cuda") / K ** 0.5).bfloat16()
+    if os.environ.get("ZERO") == "1":           # no data toggling: the schedule alone, at the unthrottled clock
+        A.zero_(); W.zero_()
+    if os.environ.get("BLASLT") == "1":         # the vendor library on the same shapes (comparison point only)
+        C_ = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+        st.gemm_bf16 = lambda a, w: torch.matmul(a, w.T, out=C_)
     for _ in range(3): st.gemm_bf16(A, W)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,12 +1,15 @@
-"""In-kernel phase stamps of the 256x256 ring GEMM (MI_GEMM_TS=1): where a tile's time goes.
-usage: python tools/gemm_stamps.py   (GPU box; prints to stderr)"""
+"""In-kernel phase stamps of the 256x256 GEMM kernels (MI_GEMM_TS=1): where a tile's time goes -- pipeline fill, K loop,
+epilogue, store drain, and (slab kernel) the gap between consecutive workgroups of a CU.
+usage: [ZERO=1] [M=32768] python tools/gemm_stamps.py   (GPU box; prints to stderr)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MI_GEMM_TS"] = "1"
 import torch
 import abstracts_search_amd.sentence_transformers as st
-M = 29696
-for N, K in ((17920, 64), (17920, 512), (17920, 1536), (2048, 1536)):
+M = int(os.environ.get("M", 32768))
+for N, K in ((1536, 1536), (1536, 8960), (4096, 4096), (17920, 1536)):
     A = torch.randn((M, K), device="cuda").bfloat16(); W = (torch.randn((N, K), device="cuda") / K ** 0.5).bfloat16()
+    if os.environ.get("ZERO") == "1":
+        A.zero_(); W.zero_()
     for _ in range(2): st.gemm_bf16(A, W)
     torch.cuda.synchronize()

@@ -1,0 +1,35 @@
+"""Sustained (power-settled) throughput of the slab GEMM against hipBLASLt on the encoder's shapes (GPU box): each
+contender runs back to back for SECS seconds, alternating A B A B, and every block reports its own rate -- the short
+10-launch bursts of tools/gemm_bench.py start from whatever power state the previous contender left behind."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import abstracts_search_amd.sentence_transformers as st
+M = int(os.environ.get("M", 29312))
+SECS = float(os.environ.get("SECS", 0.4))
+shapes = {"qkv": (2048, 1536), "o": (1536, 1536), "gate_up": (17920, 1536), "down": (1536, 8960), "square": (4096, 4096)}
+for name in os.environ.get("SHAPES", "gate_up,down,square,qkv,o").split(","):
+    N, K = shapes[name]
+    A = torch.randn((M, K), device="cuda").bfloat16(); W = (torch.randn((N, K), device="cuda") / K ** 0.5).bfloat16()
+    C = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    fns = {"slab": lambda: st.gemm_bf16(A, W), "hipblaslt": lambda: torch.matmul(A, W.T, out=C)}
+    for f in fns.values():
+        f()
+    torch.cuda.synchronize()
+    line = []
+    for rnd in range(3):
+        for who in ("slab", "hipblaslt"):
+            f = fns[who]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 0
+            t0 = time.time()
+            e0.record()
+            while time.time() - t0 < SECS:
+                for _ in range(20):
+                    f()
+                reps += 20
+                torch.cuda.current_stream().synchronize() if reps % 200 == 0 else None
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            line.append(f"{who} {2*M*N*K/ms/1e9:6.0f}")
+    print(f"{name:8s} M={M} N={N:6d} K={K:5d} TFLOP/s per {SECS:.1f}-s block: " + " | ".join(line), flush=True)
