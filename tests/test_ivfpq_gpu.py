@@ -7,6 +7,9 @@ import os
 import numpy as np
 import pytest
 
+# extended fuzz runs: MI_FUZZ_SEED=n shifts every fuzz test's seed (the committed suite runs n = 0)
+FUZZ_SEED = int(__import__("os").environ.get("MI_FUZZ_SEED", "0"))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -777,7 +780,7 @@ def test_cfg2_full_size_properties(faiss, oracle):
 
 def test_fuzz_against_oracle(faiss, oracle):
     """seeded fuzz over shapes / parameters / degenerate inputs: HIP == oracle, bit for bit"""
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(2026 + FUZZ_SEED)
     for trial in range(40):
         M = int(rng.choice([4, 8, 16]))
         d = M * int(rng.choice([4, 8, 16]))
@@ -815,7 +818,7 @@ def test_fuzz_refine_stores_against_oracle(faiss, oracle):
     beyond 4096, duplicates (ties at the cut of the candidate list and in the final ranking), host and device queries --
     the device path goes through the unordered candidate sets, the host path through the sorted lists; both == oracle."""
     import torch
-    rng = np.random.default_rng(909)
+    rng = np.random.default_rng(909 + FUZZ_SEED)
     for trial in range(18):
         M = int(rng.choice([4, 8, 16]))
         d = M * int(rng.choice([8, 16]))
@@ -865,7 +868,7 @@ def test_fuzz_large_paths(faiss, oracle, monkeypatch):
     the block-wide descent), k > 64 (all-pairs pass + select_pairs_kernel), the two-stage
     coarse quantiser forced on half of the trials (search and add), duplicated / rounded
     data for ties: HIP == oracle, bit for bit"""
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(777 + FUZZ_SEED)
     for trial in range(24):
         d = int(rng.choice([128, 256]))
         M = int(rng.choice([d // 16, d // 8, d // 4]))

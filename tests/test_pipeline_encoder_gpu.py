@@ -390,3 +390,46 @@ def test_many_sequences_pool_through_the_gemm_path(st, monkeypatch):
     assert np.abs(outs[(True, "1")] - outs[(True, "0")]).max() < 2e-6
     a, b = outs[(False, "1")], outs[(False, "0")]
     assert np.abs(a - b).max() < 1e-5 * np.abs(b).max() + 1e-6
+
+
+
+
+@pytest.mark.parametrize("shape", ["hd64_pair", "hd128_pair", "hd128_single", "hd64_single"])
+def test_fuzz_packed_batches_vs_oracle(st, shape):
+    """seeded fuzz over what the packed layout can look like: sequences of 1 .. max_seq_len tokens back to back with no
+    alignment (every start offset mod 8, lengths across the 64-key chunk and 64-query block boundaries), 1 .. 60 sequences
+    per pass, both head dims, paired and single query heads per workgroup, bidirectional and causal -- last hidden state
+    and embedding against the fp32 oracle.  (reference Makefile:65: the batch encode of arbitrary abstracts.)"""
+    import os as _os
+    import torch
+    from oracle import encoder_oracle as E
+    seed = int(_os.environ.get("MI_FUZZ_SEED", "0"))
+    hd = 64 if shape.startswith("hd64") else 128
+    heads, kv = (4, 2) if shape.endswith("pair") else (2, 2)
+    rng = np.random.default_rng(4242 + seed + (hd + heads))
+    for trial in range(6):
+        cfg = replace(E.TINY, head_dim=hd, n_heads=heads, n_kv_heads=kv, max_seq_len=200, causal=bool(trial % 2))
+        W = E.synth_weights(cfg, 100 + trial)
+        model = st.SentenceTransformer(config=cfg.to_dict(), weights=W)
+        nseq = int(rng.choice([1, 2, 5, 17, 60]))
+        kind = trial % 3
+        if kind == 0:
+            lens = rng.integers(1, 12, nseq)                     # many tiny sequences: several per 64-row block
+        elif kind == 1:
+            lens = rng.integers(1, 201, nseq)                    # anything
+        else:
+            lens = rng.choice([1, 7, 8, 9, 63, 64, 65, 127, 128, 129, 191, 192, 193, 200], nseq)
+        toks = [rng.integers(0, cfg.vocab_size, int(L)).tolist() for L in lens]
+        ids = np.concatenate(toks)
+        cu = np.concatenate([[0], np.cumsum(lens)])
+        with torch.no_grad():
+            ref_h = E.stack_forward(cfg, W, ids, cu).numpy()
+            ref_e = E.encode(cfg, W, ids, cu, True).numpy()
+        ctx = dict(shape=shape, trial=trial, nseq=nseq, lens=[int(v) for v in lens][:20])
+        hs = model.last_hidden_state(toks)
+        assert hs.shape == ref_h.shape and np.isfinite(hs).all(), ctx
+        cos = (hs * ref_h).sum(1) / (np.linalg.norm(hs, axis=1) * np.linalg.norm(ref_h, axis=1))
+        assert cos.min() > 1 - 1e-3, (cos.min(), int(cos.argmin()), ctx)
+        model.token_budget = None
+        e = model.encode_tokens(toks, batch_size=int(rng.choice([1, 4, 64])), normalize_embeddings=True)
+        assert ((e * ref_e).sum(1)).min() > 1 - 1e-3, ctx
