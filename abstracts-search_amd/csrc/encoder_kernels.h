@@ -1089,6 +1089,10 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     const int m0 = tm * BM, n0 = tn * BN;
     GemmArgs ge = g;
     ge.ksplit = ksplit;
+    constexpr int VROW = WMT * 16 + 8;                       // bf16 per staged V^T channel row (128 tokens + 16 B pad)
+    static_assert(NW * WNT * 16 * VROW * 2 <= NS * (int)SLAB_B, "the V^T staging blocks fit the ring");
+    // QKV: a tile that lies wholly inside the V columns (and whole 8-token chunks: M % 8 == 0, ldvt % 8 == 0) leaves through LDS
+    [[maybe_unused]] const bool vt_staged = EPI == EPI_QKV && n0 >= g.qk_cols && n0 + BN <= g.N && (g.M & 7) == 0 && (g.ldvt & 7) == 0;
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         const int trow = m0 + (wm * WMT + i) * 16;
@@ -1234,6 +1238,23 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     const uint4 o = *reinterpret_cast<const uint4 *>(stg + r * ROWH + c8 * 8);
                     if (trow + r < g.M) *reinterpret_cast<uint4 *>(g.C + (size_t)(trow + r) * g.ldc + col) = o;
                 }
+            } else if (vt_staged) {
+                // V columns, a whole tile of them: the lane's 4 consecutive tokens of one channel go to the wave's LDS block
+                // [channel][128 tokens]; the block leaves below as whole 256-byte channel rows of V^T
+                if (i == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done with the ring
+                    asm volatile("s_barrier" ::: "memory");
+                }
+                bf16_t *stg = smem + w * (WNT * 16) * VROW;
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) {
+                    const float bv = g.bias ? g.bias[n0 + (wn * WNT + j) * 16 + li] : 0.f;
+                    const f32x4 v = acc[i][j];
+                    uint2 o;
+                    o.x = pack2(v[0] + bv, v[1] + bv);
+                    o.y = pack2(v[2] + bv, v[3] + bv);
+                    *reinterpret_cast<uint2 *>(stg + (j * 16 + li) * VROW + i * 16 + 4 * lg) = o;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < WNT; ++j) store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
@@ -1241,6 +1262,21 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
         } else {
 #pragma unroll
             for (int j = 0; j < WNT; ++j) store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
+        }
+    }
+    if constexpr (EPI == EPI_QKV && !PERSIST) {
+        if (vt_staged) {
+            // straight from the accumulators a store is 16 channels x 32 bytes (the V tiles' epilogue measured ~50 000 cycles
+            // against the Q / K tiles' ~12 000: in-kernel stamps, profiles/r03_encoder_gemm_stamps.txt); from the block, 4 channels x 256 bytes
+            const bf16_t *stg = smem + w * (WNT * 16) * VROW;
+            const int chunk = lane & 15, tok0 = m0 + wm * WMT * 16 + chunk * 8;
+#pragma unroll
+            for (int it = 0; it < WNT * 4; ++it) {
+                const int ch = it * 4 + (lane >> 4);
+                const uint4 o = *reinterpret_cast<const uint4 *>(stg + ch * VROW + chunk * 8);
+                if (tok0 < g.M)
+                    *reinterpret_cast<uint4 *>(g.Vt + (size_t)(n0 - g.qk_cols + wn * WNT * 16 + ch) * g.ldvt + tok0) = o;
+            }
         }
     }
     stamp(3);
