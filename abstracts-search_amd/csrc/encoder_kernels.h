@@ -1097,7 +1097,53 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     for (int i = 0; i < WMT; ++i) {
         const int trow = m0 + (wm * WMT + i) * 16;
         const int row = trow + li;
-        if constexpr (PERM == 2) {          // 8 consecutive SwiGLU outputs per lane from tiles (gate, up, gate, up)
+        if constexpr (PERM == 1 && !PERSIST) {
+            // plain bf16 store: the lane's 8 consecutive columns (one 16-byte value per tile pair) go through a wave-private LDS
+            // block of 16 rows x OW columns and leave as whole rows -- 8 rows x 128 B (or 4 x 256 B) per store instruction
+            // where the MFMA layout gives 16 rows x 64 B: the memory pipe charges per (instruction, line); +1.3 ... 2.5 % on
+            // the K = 1536 shapes.  (The SwiGLU epilogue measured 7 200 cycles staged against 6 300 direct: its 128 outputs
+            // per lane are v_exp / v_rcp time, not store issue -- it keeps the direct stores below.)
+            constexpr int OW = PERM == 2 ? WNT * 8 : WNT * 16, ROWH = OW + 8, LPR = OW / 8, RPI = 64 / LPR;
+            bf16_t *stg = smem + w * 16 * ROWH;
+            if (i == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done with the ring
+                asm volatile("s_barrier" ::: "memory");
+            }
+#pragma unroll
+            for (int q = 0; q < OW / 32; ++q) {
+                uint4 o;
+                if constexpr (PERM == 2) {  // SwiGLU outputs from tiles (gate, up, gate, up)
+                    float h[8];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float ga = acc[i][4 * q][c], gb = acc[i][4 * q + 2][c];
+                        h[c] = ga * __builtin_amdgcn_rcpf(1.0f + __expf(-ga)) * acc[i][4 * q + 1][c];
+                        h[4 + c] = gb * __builtin_amdgcn_rcpf(1.0f + __expf(-gb)) * acc[i][4 * q + 3][c];
+                    }
+                    o.x = pack2(h[0], h[1]); o.y = pack2(h[2], h[3]); o.z = pack2(h[4], h[5]); o.w = pack2(h[6], h[7]);
+                } else {                    // plain store (+ bias) from tiles 2q, 2q+1
+                    const int col0 = n0 + wn * WNT * 16 + 32 * q + 8 * lg;
+                    float4 b0v = make_float4(0.f, 0.f, 0.f, 0.f), b1v = b0v;
+                    if (g.bias && col0 < g.N) {
+                        b0v = *reinterpret_cast<const float4 *>(g.bias + col0);
+                        b1v = *reinterpret_cast<const float4 *>(g.bias + col0 + 4);
+                    }
+                    const f32x4 v0 = acc[i][2 * q], v1 = acc[i][2 * q + 1];
+                    o.x = pack2(v0[0] + b0v.x, v0[1] + b0v.y); o.y = pack2(v0[2] + b0v.z, v0[3] + b0v.w);
+                    o.z = pack2(v1[0] + b1v.x, v1[1] + b1v.y); o.w = pack2(v1[2] + b1v.z, v1[3] + b1v.w);
+                }
+                *reinterpret_cast<uint4 *>(stg + li * ROWH + 32 * q + 8 * lg) = o;
+            }
+            const int c8 = lane % LPR;
+            const int col = (PERM == 2 ? (n0 + wn * WNT * 16) / 2 : n0 + wn * WNT * 16) + c8 * 8;
+            const int ncols = PERM == 2 ? g.ldc : g.N;
+#pragma unroll
+            for (int it = 0; it < 16 / RPI; ++it) {
+                const int r = it * RPI + lane / LPR;
+                const uint4 o = *reinterpret_cast<const uint4 *>(stg + r * ROWH + c8 * 8);
+                if (trow + r < g.M && col < ncols) *reinterpret_cast<uint4 *>(g.C + (size_t)(trow + r) * g.ldc + col) = o;
+            }
+        } else if constexpr (PERM == 2) {   // 8 consecutive SwiGLU outputs per lane from tiles (gate, up, gate, up)
 #pragma unroll
             for (int q = 0; q < WNT / 4; ++q) {
                 const int col0 = (n0 + wn * WNT * 16) / 2 + 32 * q + 8 * lg;
