@@ -977,7 +977,8 @@ void encode_impl(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu,
             return;
         }
         // few sequences: split the Dense rows of each over several workgroups (256 CUs to fill)
-        p.parts = c.dense_out ? std::max(1, std::min(od / 64, 256 / std::max(1, nseq))) : 1;
+        static const int rows_per_part = std::getenv("MI_POOL_ROWS") ? std::max(16, std::atoi(std::getenv("MI_POOL_ROWS"))) : 16;
+        p.parts = c.dense_out ? std::max(1, std::min(od / rows_per_part, 256 / std::max(1, nseq))) : 1;
         hipLaunchKernelGGL(pool_kernel, dim3(nseq, p.parts), dim3(256), smem, st, p);
         MI_HIP(hipGetLastError());
         if (p.parts > 1 && normalize) {
