@@ -27,6 +27,7 @@ hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 std::atomic<int64_t> g_tail_split_launches{0};
 std::atomic<int64_t> g_splitk_launches{0};
 std::atomic<int64_t> g_reduce_norm_launches{0};
+std::atomic<int64_t> g_n192_launches{0};
 
 struct LayerW {
     DevBuf wqkv, bqkv, wo, wgu, wd, ln1, ln2;
@@ -205,6 +206,36 @@ bool launch_slab(int epi, GemmArgs g, hipStream_t st) {
     return normed;
 }
 
+// 256 x 192 tiles of the slab kernel (residual epilogue): N = 1536 is 8 tile columns instead of 6 -- at 5 400 .. 8 192
+// tokens that is one full round of <= 256 workgroups where 256-column tiles leave a quarter of the CUs idle
+void launch_slab_n192(GemmArgs g, hipStream_t st) {
+    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_n = (g.N + 191) / 192;
+    const int per = (g.tiles_m * g.tiles_n + 7) / 8;
+    g.ksplit = 1;
+    g.tail_first = 0;
+    g.tail_split = 1;
+    g.part = nullptr;
+    g.stagger = 0;
+    g.order = g.tiles_n <= 16 ? 1 : 0;
+    hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, 2, false, 6>), dim3(8u * per), dim3(256), 0, st, g);
+    MI_HIP(hipGetLastError());
+    ++g_n192_launches;
+}
+
+// whether 192-column tiles beat 256-column tiles for this residual GEMM: rounds of workgroups on 256 CUs, a 192-column
+// tile costing ~0.8 of a 256-column one (48 MFMAs per step against 64; the A side of the step is unchanged)
+bool n192_pays(const GemmArgs &g) {
+    const long tm = (g.M + 255) / 256;
+    const long t256 = tm * ((g.N + 255) / 256);
+    const long r256 = (t256 + 255) / 256, r192 = (tm * ((g.N + 191) / 192) + 255) / 256;
+    static const double rel = std::getenv("MI_N192_COST") ? std::atof(std::getenv("MI_N192_COST")) : 0.8;
+    // a short last round of 256-column tiles is split along K by launch_slab (nearly free): measured at 11 290 tokens
+    // (270 tiles) the 256-column tiles win by 28 us per layer, at 13 205 (312 tiles) the 192-column ones by 66
+    if (r256 >= 2 && t256 % 256 != 0 && t256 % 256 <= 48) return false;
+    return g.N % 8 == 0 && (double)r192 * rel < (double)r256 - 0.05;
+}
+
 // narrow tiles (WNT = 1): no SwiGLU instantiation (it pairs two N tiles inside a wave)
 template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
 void launch_ring_narrow(int epi, GemmArgs g, hipStream_t st) {
@@ -332,6 +363,8 @@ bool launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             // pass, where 128x128 tiles with K split three ways by f32 atomics took 76 us; at 1558 / 2097 tokens the forward
             // pass went 7.91 -> 6.46 / 9.21 -> 7.82 ms against the 128x128 ring tiles
             return launch_slab<2>(epi, g, st);
+        } else if (cfg == "big" && !force && epi == EPI_RESID && n192_pays(g) && !std::getenv("MI_NO_N192")) {
+            launch_slab_n192(g, st);
         } else if (cfg == "big" && !std::getenv("MI_GEMM_RING") && (epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {   // the slab kernel stores 8 bf16 columns per lane
             // measured (tools/gemm_bench.py, 32768 tokens): 8 waves 1051 / 1060 TF on QKV / O, 4 waves 1106 / 1303 on
             // gate-up / down (ring kernel: 968 / 952 / 1006 / 1166)
@@ -1072,6 +1105,7 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
         if (std::string(name) == "tail_split_launches") *value = g_tail_split_launches.load();
         else if (std::string(name) == "splitk_launches") *value = g_splitk_launches.load();
         else if (std::string(name) == "reduce_norm_launches") *value = g_reduce_norm_launches.load();
+        else if (std::string(name) == "n192_launches") *value = g_n192_launches.load();
         else throw Error(std::string("unknown debug counter: ") + name);
     });
 }

@@ -853,9 +853,14 @@ __host__ __device__ constexpr int slab_w_tile_off(int j) {
     return (PERM == 1 ? 32 * (j / 2) + 4 * (j % 2) : PERM == 2 ? 64 * (j / 4) + 16 * (j % 2) + 4 * ((j / 2) % 2) : 16 * j) * 128;
 }
 
-template <int EPI, int WN_, bool PERSIST = false>
+// WNT_ (16-column MFMA tiles per wave along N): 16 / WN_ gives the 256-column tile; WN_ = 2, WNT_ = 6 is a 256 x 192 tile
+// (residual epilogue only) for the token counts at which N = 1536 yields 130-190 tiles of 256 columns on 256 CUs and
+// exactly <= 256 tiles of 192 -- the W slabs keep their 32 KiB slots and all 32 pieces (rows 192..255 are never read), so
+// nothing of the DMA / wait schedule changes; a step is 48 MFMAs and 14 fragment reads.
+template <int EPI, int WN_, bool PERSIST = false, int WNT_ = 16 / WN_>
 __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, WMT = 8, WNT = 16 / WN_, NW = 2 * WN_;
+    constexpr int BM = 256, WMT = 8, WNT = WNT_, BN = WN_ * WNT * 16, NW = 2 * WN_;
+    static_assert(BN <= 256 && (WNT_ == 16 / WN_ || EPI == EPI_RESID), "narrower tiles: residual epilogue only");
     constexpr int PPW = 32 / NW;                             // DMA pieces (1 KiB: 8 rows x 128 B) per wave per slab
     constexpr int NS = 5, DQ = 4;                            // slabs in the ring, request distance in slabs
     constexpr unsigned SLAB_B = 256 * 128;                   // 32 KiB
@@ -1186,6 +1191,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 // tile.  Staged, a wave's 16 x CW block goes out (and X comes in) as 256 / CW rows x CW*4 B per
                 // instruction.  Rows are padded by 16 B: the 8 lanes of a ds_write_b128 group sit on 8 rows.
                 constexpr int CW = WNT * 16, ROWF = CW + 4, LPR = CW / 4, RPI = 64 / LPR;   // floats per staged row, lanes per row, rows per instruction
+                const bool lane_on = lane < RPI * LPR;               // CW = 96: 2 rows x 24 lanes per instruction, 16 lanes idle
                 float *stg = reinterpret_cast<float *>(smem) + w * 16 * ROWF;
                 if (i == 0) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done with the ring
@@ -1201,7 +1207,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     for (int it = 0; it < 16 / RPI; ++it) {
                         const int r = it * RPI + lane / LPR;
                         const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + r * ROWF + c4 * 4);
-                        if (trow + r < g.M && col < g.N)
+                        if (lane_on && trow + r < g.M && col < g.N)
                             *reinterpret_cast<float4 *>(pp + (size_t)(trow + r) * g.N + col) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                     continue;
@@ -1235,13 +1241,13 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
 #pragma unroll
                 for (int it = 0; it < 16 / RPI; ++it) {
                     const int r = it * RPI + lane / LPR;
-                    if (trow + r < g.M && col < g.N) xs[it] = *reinterpret_cast<const float4 *>(g.X + (size_t)(trow + r) * g.ldc + col);
+                    if (lane_on && trow + r < g.M && col < g.N) xs[it] = *reinterpret_cast<const float4 *>(g.X + (size_t)(trow + r) * g.ldc + col);
                 }
 #pragma unroll
                 for (int it = 0; it < 16 / RPI; ++it) {
                     const int r = it * RPI + lane / LPR;
                     const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + r * ROWF + c4 * 4);
-                    if (trow + r < g.M && col < g.N) {
+                    if (lane_on && trow + r < g.M && col < g.N) {
                         float4 x = xs[it];
                         x.x += v[0] + bv.x; x.y += v[1] + bv.y; x.z += v[2] + bv.z; x.w += v[3] + bv.w;
                         *reinterpret_cast<float4 *>(g.X + (size_t)(trow + r) * g.ldc + col) = x;

@@ -96,7 +96,8 @@ int mi_encoder_profile_read(mi_encoder *h, double *gemm_ms, double *gemm_flops);
 /* Test hook: process-wide counters of code paths the dispatcher takes on its own.  "tail_split_launches" = GEMM
  * launches whose last (partial) round of 256x256 tiles was split along K with f32 atomics into the residual stream;
  * "splitk_launches" = residual GEMMs whose every tile was split along K through the workspace (a few hundred to ~5 000
- * tokens); "reduce_norm_launches" = those whose reduction pass also wrote the next RMSNorm. */
+ * tokens); "reduce_norm_launches" = those whose reduction pass also wrote the next RMSNorm; "n192_launches" = residual
+ * GEMMs run on 256 x 192 tiles. */
 int mi_enc_debug_counter(const char *name, int64_t *value);
 
 /* Building block exposed for numerics tests: C[M][N] = A[M][K] . W[N][K]^T in
