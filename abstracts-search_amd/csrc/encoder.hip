@@ -769,10 +769,15 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         // two query heads of one K/V head per workgroup when the GQA group allows it (MI_ATTN_HPW=1: one head per workgroup)
         static const bool hpw1 = std::getenv("MI_ATTN_HPW") && std::atoi(std::getenv("MI_ATTN_HPW")) == 1;
         const bool pair = !hpw1 && c.n_heads % 2 == 0 && (c.n_heads / c.n_kv_heads) % 2 == 0;
-        if (hd == 128 && pair) hipLaunchKernelGGL((attn_kernel<128, 2>), dim3(b.nwork, c.n_heads / 2), dim3(512), 0, st, a);
-        else if (hd == 128) hipLaunchKernelGGL((attn_kernel<128, 1>), dim3(b.nwork, c.n_heads), dim3(256), 0, st, a);
-        else if (pair) hipLaunchKernelGGL((attn_kernel<64, 2>), dim3(b.nwork, c.n_heads / 2), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((attn_kernel<64, 1>), dim3(b.nwork, c.n_heads), dim3(256), 0, st, a);
+        a.nwork = b.nwork;
+        // persistent workgroups: two per CU (64 KiB of LDS each at head dim 128 x 2 heads), or one per item when there are fewer
+        static const int wgs_cu = std::getenv("MI_ATTN_WGS_PER_CU") ? std::max(1, std::atoi(std::getenv("MI_ATTN_WGS_PER_CU"))) : 2;
+        const int hpw = pair ? 2 : 1;
+        const unsigned nwg = (unsigned)std::min<long>((long)b.nwork * (c.n_heads / hpw), 256L * wgs_cu);
+        if (hd == 128 && pair) hipLaunchKernelGGL((attn_kernel<128, 2>), dim3(nwg), dim3(512), 0, st, a);
+        else if (hd == 128) hipLaunchKernelGGL((attn_kernel<128, 1>), dim3(nwg), dim3(256), 0, st, a);
+        else if (pair) hipLaunchKernelGGL((attn_kernel<64, 2>), dim3(nwg), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((attn_kernel<64, 1>), dim3(nwg), dim3(256), 0, st, a);
         MI_HIP(hipGetLastError());
         GemmArgs o{};
         o.A = att; o.lda = h->q_cols; o.W = w.wo.get<bf16_t>(); o.ldw = h->q_cols; o.M = T; o.N = H; o.K = h->q_cols;

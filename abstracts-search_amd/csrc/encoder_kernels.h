@@ -1722,8 +1722,8 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------------
-// Varlen attention.  grid = (work items, n_heads / HPW); a work item is a 64-row query block of one
-// sequence; a head takes 4 waves x 16 query rows.  Everything is computed TRANSPOSED so that a lane owns
+// Varlen attention.  A work item is a 64-row query block of one sequence x a group of HPW heads; a head takes
+// 4 waves x 16 query rows; the workgroups are persistent (see the kernel).  Everything is computed TRANSPOSED so that a lane owns
 // one query row: per 64-key chunk S^T = K Q^T (A operand = K rows, 16 MFMA per wave), the lane holds 16
 // scores of its query (row statistics: in-lane + two cross-lane steps over the 4 lanes that share the row),
 // online softmax in registers, and O^T += V^T P^T (A operand = V^T rows, B operand = P) -- 16 MFMA per wave.
@@ -1744,10 +1744,11 @@ struct AttnArgs {
     const int32_t *seq_start, *seq_len;  // [nseq] (padded-packed token offsets)
     int ldqk, ldvt, n_heads, n_kv, causal;
     float scale;
+    int nwork;          // work items (64-row query blocks); the launch is 1-D and persistent: min(nwork * n_heads / HPW, 2 per CU) workgroups
 };
 
 template <int HD, int HPW = 1>
-__global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(256 * HPW, 4) attn_kernel(AttnArgs a) {   // (HIP: min waves per SIMD) four waves per SIMD = two 8-wave workgroups per CU: at most 128 VGPRs
     constexpr int KC = 64;          // keys per chunk
     constexpr int NKK = HD / 32;    // MFMA k-steps over the head dimension
     constexpr int NDT = HD / 16;    // 16-wide output tiles over the head dimension
@@ -1759,149 +1760,203 @@ __global__ void __launch_bounds__(256 * HPW) attn_kernel(AttnArgs a) {
     static_assert((HD / 32) % HPW == 0, "DMA pieces must divide over the waves");
     auto kswz = [](int key) { return (key & 3) | (((key >> 3) & (KSL / 4 - 1)) << 2); };
 
-    const int item = blockIdx.x;
-    const int seq = a.work_seq[item], q0 = a.work_q0[item];
-    const int s0 = a.seq_start[seq], L = a.seq_len[seq];
-    // Sequences are packed back to back (no alignment padding between them), but the V^T rows are fetched in 16-byte
-    // pieces: the key axis of this sequence therefore starts at the aligned-down token sa; its first `off` (< 8) keys
-    // belong to the previous sequence and are masked out like the keys past the end.  Le = keys on that axis.
-    const int sa = s0 & ~7, off = s0 - sa, Le = off + L;
+    // PERSISTENT: the launch is gridDim.x workgroups (two per CU) that walk the items it, it + gridDim.x, ...; an item =
+    // (64-row query block of a sequence, group of HPW heads), head group fastest (neighbouring workgroups share the
+    // sequence's K / V in L2).  While the LAST key chunk of an item is multiplied, the first chunk and the Q fragments of the
+    // next item are already in flight: a 220-token abstract is 4 chunks per item, and with one item per workgroup the first of
+    // them was fetched with nothing to overlap it (SQ counters: 46 % of the wave cycles waiting, profiles/r03_attn_pmc.txt).
+    const int nhp = a.n_heads / HPW, nitems = a.nwork * nhp;
+    int it = blockIdx.x;
+    if (it >= nitems) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: head w / 4 of this workgroup, query rows 16 (w % 4) ..
     const int wq = w & 3;
-    const int h = (int)blockIdx.y * HPW + (w >> 2);
-    const int kvh = ((int)blockIdx.y * HPW) / (a.n_heads / a.n_kv);   // the same for every head of the workgroup (host checks)
     const int li = lane & 15, lg = lane >> 4;
+
+    // Sequences are packed back to back (no alignment padding between them), but the V^T rows are fetched in 16-byte
+    // pieces: the key axis of a sequence therefore starts at the aligned-down token sa; its first `off` (< 8) keys
+    // belong to the previous sequence and are masked out like the keys past the end.  Le = keys on that axis.
+    struct Item { int s0, L, sa, off, Le, q0, h, kvh, kend; };
+    auto decode = [&](int it_) {
+        Item t;
+        const int wi = it_ / nhp, hp = it_ - wi * nhp;
+        const int seq = a.work_seq[wi];
+        t.q0 = a.work_q0[wi];
+        t.s0 = a.seq_start[seq]; t.L = a.seq_len[seq];
+        t.sa = t.s0 & ~7; t.off = t.s0 - t.sa; t.Le = t.off + t.L;
+        t.h = hp * HPW + (w >> 2);
+        t.kvh = (hp * HPW) / (a.n_heads / a.n_kv);               // the same for every head of the workgroup (host checks)
+        t.kend = a.causal ? min(t.Le, t.off + t.q0 + 64) : t.Le;
+        return t;
+    };
 
     // K and V^T chunks arrive by LDS-DMA (1 KiB per wave instruction), double
     // buffered: chunk c+1 is in flight while chunk c is multiplied
-    auto issue = [&](int stage, int kc) {
+    auto issue = [&](const Item &t, int stage, int kc) {
         bf16_t *Ks = smem + stage * STG, *Vs = Ks + KC * HD;
 #pragma unroll
         for (int i = 0; i < HD / 32 / HPW; ++i) {   // HD/8 K pieces over the 4 HPW waves
             const int p = w * (HD / 32 / HPW) + i;
             const int key = p * KRPP + lane / KSL, sl = lane % KSL;
-            const int krow = min(kc + key, Le - 1);
-            dma16(a.QK + (size_t)(sa + krow) * a.ldqk + (a.n_heads + kvh) * HD + ((sl ^ kswz(key)) * 8),
+            const int krow = min(kc + key, t.Le - 1);
+            dma16(a.QK + (size_t)(t.sa + krow) * a.ldqk + (a.n_heads + t.kvh) * HD + ((sl ^ kswz(key)) * 8),
                   Ks + p * 512);
         }
 #pragma unroll
         for (int i = 0; i < HD / 32 / HPW; ++i) {   // HD/8 V^T pieces of 8 rows x 128 B
             const int p = w * (HD / 32 / HPW) + i;
             const int d = p * 8 + (lane >> 3), sl = lane & 7;
-            dma16(a.Vt + (size_t)(kvh * HD + d) * a.ldvt + sa + kc + ((sl ^ (d & 7)) * 8), Vs + p * 512);
+            dma16(a.Vt + (size_t)(t.kvh * HD + d) * a.ldvt + t.sa + kc + ((sl ^ (d & 7)) * 8), Vs + p * 512);
         }
     };
-
     // Q fragments of this wave's 16 rows (B operand of S^T: query row li, 8 dims at 32*kk + 8*lg)
-    const int qidx = q0 + wq * 16 + li;             // the query this lane owns
-    bf16x8 qf[NKK];
-    {
-        const int qrow = min(qidx, L - 1);
-        const bf16_t *qp = a.QK + (size_t)(s0 + qrow) * a.ldqk + h * HD + lg * 8;
+    auto load_q = [&](const Item &t, bf16x8(&q)[NKK]) {
+        const int qrow = min(t.q0 + wq * 16 + li, t.L - 1);
+        const bf16_t *qp = a.QK + (size_t)(t.s0 + qrow) * a.ldqk + t.h * HD + lg * 8;
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8 *>(qp + kk * 32);
-        // Pin the wait for these loads HERE.  Left to the compiler it sits in front of the
-        // first MFMA inside the loop as `s_waitcnt vmcnt(3..0)` -- counted without the LDS-DMA
-        // pieces (issued from asm, invisible to it), so every iteration it would drain the
-        // chunk that was just requested and the double buffering would be gone.
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]));
-    }
-    f32x4 o[NDT];                                   // O^T tiles: dims 16 n + 4 lg + r of query li
-#pragma unroll
-    for (int n = 0; n < NDT; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrow = -__builtin_huge_valf(), lrow = 0.f;   // running maximum (log2 units) and denominator of query li
-    const int kend = a.causal ? min(Le, off + q0 + 64) : Le;
+        for (int kk = 0; kk < NKK; ++kk) q[kk] = *reinterpret_cast<const bf16x8 *>(qp + kk * 32);
+    };
+
     const float scale2 = a.scale * 1.4426950408889634f;
     const int x16 = (lane ^ 16) << 2, x32 = (lane ^ 32) << 2;   // ds_bpermute addresses of the lanes that share the row
     // LDS row of tile position li (tile j adds 32 (j/2) + 4 (j%2)), and the slot key of those rows
     const int krow0 = 8 * (li >> 2) + (li & 3);
     const int kkey = kswz(krow0);                   // 32 (j/2) and 4 (j%2) leave bits {0,1,3,4} of the row alone... (4 (j%2) sets bit 2 only)
 
-    issue(0, 0);
-    for (int kc = 0, c = 0; kc < kend; kc += KC, ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own DMA pieces of chunk c
-        __syncthreads();                                   // everyone's pieces; chunk c-1 fully consumed
-        if (kc + KC < kend) issue((c + 1) & 1, kc + KC);
-        const bf16_t *Ks = smem + (c & 1) * STG, *Vs = Ks + KC * HD;
+    Item cur = decode(it);
+    bf16x8 qf[NKK];
+    load_q(cur, qf);
+    // Pin the wait for these loads HERE.  Left to the compiler it sits in front of the first MFMA inside the loop as
+    // `s_waitcnt vmcnt(3..0)` -- counted without the LDS-DMA pieces (issued from asm, invisible to it), so every iteration
+    // it would drain the chunk that was just requested and the double buffering would be gone.
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]));
+    int c = 0;                                      // chunks so far, across items: chunk c sits in stage c & 1
+    issue(cur, 0, 0);
+    bool prewaited = false;                         // the first chunk of the current item was waited for at the end of the previous one
+    for (;;) {
+        const int itn = it + (int)gridDim.x;
+        const bool more = itn < nitems;
+        Item nxt = cur;
+        if (more) nxt = decode(itn);
+        bf16x8 qn[NKK];
+        const int L = cur.L, off = cur.off, Le = cur.Le, kend = cur.kend;
+        const int qidx = cur.q0 + wq * 16 + li;     // the query this lane owns
+        f32x4 o[NDT];                               // O^T tiles: dims 16 n + 4 lg + r of query li
+#pragma unroll
+        for (int n = 0; n < NDT; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float mrow = -__builtin_huge_valf(), lrow = 0.f;   // running maximum (log2 units) and denominator of query li
 
-        // S^T = K Q^T for 4 tiles of 16 keys
-        f32x4 s[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const bf16_t *kb = Ks + (32 * (j >> 1) + 4 * (j & 1) + krow0) * HD;
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kb + (((kk * 4 + lg) ^ kkey) * 8));
-                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[j], 0, 0, 0);
+        // one key chunk: wait for its pieces, request what comes next, multiply
+        auto chunk = [&](int kc, auto LAST) {
+            if (!(kc == 0 && prewaited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces of chunk c
+            __syncthreads();                                   // everyone's pieces; chunk c-1 fully consumed
+            if constexpr (!decltype(LAST)::value) issue(cur, (c + 1) & 1, kc + KC);
+            else if (more) {                                   // last chunk of this item: the next item's first chunk and Q rows
+                issue(nxt, (c + 1) & 1, 0);
+                load_q(nxt, qn);                               // (requested from inline asm instead, so that no compiler wait sits
+                                                               // between here and the stores: measured the same, 118 us)
             }
-        }
-        // scale, mask, online softmax: the lane holds keys kc + 32 (j/2) + 8 lg + 4 (j%2) + r of query li
-        const bool need_mask = a.causal || kc + KC > Le || (kc == 0 && off != 0);   // wave-uniform: the first / last (partial) chunk, or causal
-        float pmax = -__builtin_huge_valf();
+            const bf16_t *Ks = smem + (c & 1) * STG, *Vs = Ks + KC * HD;
+
+            // S^T = K Q^T for 4 tiles of 16 keys
+            f32x4 s[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const bf16_t *kb = Ks + (32 * (j >> 1) + 4 * (j & 1) + krow0) * HD;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = s[j][r] * scale2;   // scores in log2 units: exp2 is the native v_exp_f32
-                if (need_mask) {
-                    const int kidx = kc + 32 * (j >> 1) + 8 * lg + 4 * (j & 1) + r - off;   // key index inside the sequence
-                    if (kidx < 0 || kidx >= L || (a.causal && kidx > qidx)) v = -__builtin_huge_valf();
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kb + (((kk * 4 + lg) ^ kkey) * 8));
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[j], 0, 0, 0);
                 }
-                s[j][r] = v;
-                pmax = fmaxf(pmax, v);
             }
-        pmax = fmaxf(pmax, __int_as_float(__builtin_amdgcn_ds_bpermute(x16, __float_as_int(pmax))));
-        pmax = fmaxf(pmax, __int_as_float(__builtin_amdgcn_ds_bpermute(x32, __float_as_int(pmax))));
-        const float mnew = fmaxf(mrow, pmax);
-        const float alpha = (mrow == -__builtin_huge_valf()) ? 0.f : __builtin_amdgcn_exp2f(mrow - mnew);
-        mrow = mnew;
-        float psum = 0.f;
+            // mask, online softmax: the lane holds keys kc + 32 (j/2) + 8 lg + 4 (j%2) + r of query li
+            const bool need_mask = a.causal || kc + KC > Le || (kc == 0 && off != 0);   // wave-uniform: the first / last (partial) chunk, or causal
+            float pmax = -__builtin_huge_valf();
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = (mrow == -__builtin_huge_valf()) ? 0.f : __builtin_amdgcn_exp2f(s[j][r] - mrow);
-                psum += p;
-                s[j][r] = p;
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[j][r];            // raw scores; the scale to log2 units rides in the fma of the exponent below
+                    if (need_mask) {
+                        const int kidx = kc + 32 * (j >> 1) + 8 * lg + 4 * (j & 1) + r - off;   // key index inside the sequence
+                        if (kidx < 0 || kidx >= L || (a.causal && kidx > qidx)) v = -__builtin_huge_valf();
+                    }
+                    s[j][r] = v;
+                    pmax = fmaxf(pmax, v);
+                }
+            pmax = fmaxf(pmax, __int_as_float(__builtin_amdgcn_ds_bpermute(x16, __float_as_int(pmax))));
+            pmax = fmaxf(pmax, __int_as_float(__builtin_amdgcn_ds_bpermute(x32, __float_as_int(pmax))));
+            const float mnew = fmaxf(mrow, pmax * scale2);          // log2 units (scale2 > 0: the maximum commutes with the scale)
+            const float alpha = (mrow == -__builtin_huge_valf()) ? 0.f : __builtin_amdgcn_exp2f(mrow - mnew);
+            mrow = mnew;
+            const float msub = (mrow == -__builtin_huge_valf()) ? 0.f : mrow;   // a row that has seen no key yet: exp2(-inf - 0) = 0
+            float psum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // one fma per score (scale and subtract) instead of a multiply, a subtract and a select: the softmax of a
+                    // 64-key chunk is ~800 VALU cycles per wave against 512 of MFMA (SQ counters: profiles/r03_attn_pmc.txt)
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][r], scale2, -msub));
+                    psum += p;
+                    s[j][r] = p;
+                }
+            psum += __int_as_float(__builtin_amdgcn_ds_bpermute(x16, __float_as_int(psum)));
+            psum += __int_as_float(__builtin_amdgcn_ds_bpermute(x32, __float_as_int(psum)));
+            lrow = lrow * alpha + psum;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {   // the running maxima settle after the first chunks
+#pragma unroll
+                for (int n = 0; n < NDT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[n][r] *= alpha;
             }
-        psum += __int_as_float(__builtin_amdgcn_ds_bpermute(x16, __float_as_int(psum)));
-        psum += __int_as_float(__builtin_amdgcn_ds_bpermute(x32, __float_as_int(psum)));
-        lrow = lrow * alpha + psum;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {   // the running maxima settle after the first chunks
+            // O^T += V^T P^T  (A: V^T[d = 16n+li][keys 32 J + 8 lg ..], B: P[query li][the same keys] = tiles 2J, 2J+1 of this lane)
 #pragma unroll
-            for (int n = 0; n < NDT; ++n)
+            for (int J = 0; J < 2; ++J) {
+                union { bf16x8 v; unsigned u[4]; } pf;
+                pf.u[0] = pack2(s[2 * J][0], s[2 * J][1]);
+                pf.u[1] = pack2(s[2 * J][2], s[2 * J][3]);
+                pf.u[2] = pack2(s[2 * J + 1][0], s[2 * J + 1][1]);
+                pf.u[3] = pack2(s[2 * J + 1][2], s[2 * J + 1][3]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[n][r] *= alpha;
-        }
-        // O^T += V^T P^T  (A: V^T[d = 16n+li][keys 32 J + 8 lg ..], B: P[query li][the same keys] = tiles 2J, 2J+1 of this lane)
-#pragma unroll
-        for (int J = 0; J < 2; ++J) {
-            union { bf16x8 v; unsigned u[4]; } pf;
-            pf.u[0] = pack2(s[2 * J][0], s[2 * J][1]);
-            pf.u[1] = pack2(s[2 * J][2], s[2 * J][3]);
-            pf.u[2] = pack2(s[2 * J + 1][0], s[2 * J + 1][1]);
-            pf.u[3] = pack2(s[2 * J + 1][2], s[2 * J + 1][3]);
+                for (int n = 0; n < NDT; ++n) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(
+                        Vs + (n * 16 + li) * KC + (((J * 4 + lg) ^ (li & 7)) * 8));
+                    o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf.v, o[n], 0, 0, 0);
+                }
+            }
+            ++c;
+        };
+        int kc = 0;
+        for (; kc + KC < kend; kc += KC) chunk(kc, std::false_type{});
+        chunk(kc, std::true_type{});
+        // normalise and write row qidx: 4 consecutive dims per lane and tile
+        const bool stores_behind = __builtin_amdgcn_ballot_w64(qidx < L) != 0;   // wave-uniform: NDT stores follow, or none
+        if (qidx < L) {
+            const float inv = lrow > 0.f ? 1.0f / lrow : 0.f;
+            bf16_t *op = a.O + (size_t)(cur.s0 + qidx) * (a.n_heads * HD) + cur.h * HD + 4 * lg;
 #pragma unroll
             for (int n = 0; n < NDT; ++n) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(
-                    Vs + (n * 16 + li) * KC + (((J * 4 + lg) ^ (li & 7)) * 8));
-                o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf.v, o[n], 0, 0, 0);
+                uint2 pk;
+                pk.x = pack2(o[n][0] * inv, o[n][1] * inv);
+                pk.y = pack2(o[n][2] * inv, o[n][3] * inv);
+                *reinterpret_cast<uint2 *>(op + n * 16) = pk;
             }
         }
-    }
-    // normalise and write row qidx: 4 consecutive dims per lane and tile
-    if (qidx < L) {
-        const float inv = lrow > 0.f ? 1.0f / lrow : 0.f;
-        bf16_t *op = a.O + (size_t)(s0 + qidx) * (a.n_heads * HD) + h * HD + 4 * lg;
+        if (!more) break;
+        cur = nxt;
+        it = itn;
+        // The next item's first chunk and Q rows were requested during the last chunk, in front of the stores above; vmcnt
+        // counts in issue order, so the NDT stores may stay in flight.
+        if (stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        prewaited = true;
 #pragma unroll
-        for (int n = 0; n < NDT; ++n) {
-            uint2 pk;
-            pk.x = pack2(o[n][0] * inv, o[n][1] * inv);
-            pk.y = pack2(o[n][2] * inv, o[n][3] * inv);
-            *reinterpret_cast<uint2 *>(op + n * 16) = pk;
+        for (int kk = 0; kk < NKK; ++kk) {
+            asm volatile("" : "+v"(qn[kk]));
+            qf[kk] = qn[kk];
         }
     }
 }
