@@ -1055,7 +1055,7 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True):
             xcheck = {"gemm_ms_per_step": kt, "achieved": round(pr["gemm_flops"] / (kt * 1e-3) / 1e12, 1),
                       "frac": round(pr["gemm_flops"] / (kt * 1e-3) / 1e12 / 2500.0, 4),
                       "what": "the same FLOPs over the SUM of rocprofv3's per-kernel durations of the four GEMM kernels in the committed "
-                              "kernel-trace run of this workload (profiles/r03_cfg3_encoder_kernel_stats_v3.csv): a kernel's traced duration "
+                              "kernel-trace run of this workload (profiles/r03_cfg3_encoder_kernel_stats_v4.csv): a kernel's traced duration "
                               "includes its drain tail and end-of-kernel cache write-back, during which the next launch already runs -- the "
                               "sum reads 3-4 % above what the launches occupy back to back, and bounds `frac` from below"}
     except Exception:

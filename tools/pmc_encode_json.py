@@ -12,8 +12,8 @@ def parse(fn):
             d.setdefault(k, {})[m.group(1)] = (int(m.group(2)), float(m.group(3)))
     return d
 F, W = parse(out + "/encode_gemm_FETCH_SIZE.txt"), parse(out + "/encode_gemm_WRITE_SIZE.txt")
-names = {"<2, 4, false>": "QKV (+bias, V^T)  N 2048 K 1536", "<1, 4, false>": "O (residual)  N 1536 K 1536",
-         "<3, 2, false>": "gate/up + SwiGLU  N 17920 K 1536", "<1, 2, false>": "down (residual)  N 1536 K 8960"}
+names = {"<2, 4, false": "QKV (+bias, V^T)  N 2048 K 1536", "<1, 4, false": "O (residual)  N 1536 K 1536",   # (prefixes: the kernel has a 4th template argument since the 192-column tiles)
+         "<3, 2, false": "gate/up + SwiGLU  N 17920 K 1536", "<1, 2, false": "down (residual)  N 1536 K 8960"}
 stats = {r["Name"]: r for r in csv.DictReader(open(out + "/encode_kernel_stats.csv"))}
 kern, tot = {}, 0
 for k, v in F.items():
