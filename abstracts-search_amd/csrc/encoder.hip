@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "encoder_kernels.h"
+#include "encoder_few.h"
 
 using namespace mi;
 using namespace mienc;
@@ -28,10 +29,12 @@ std::atomic<int64_t> g_tail_split_launches{0};
 std::atomic<int64_t> g_splitk_launches{0};
 std::atomic<int64_t> g_reduce_norm_launches{0};
 std::atomic<int64_t> g_n192_launches{0};
+std::atomic<int64_t> g_few_passes{0};     // forward passes that took the query-time path (encoder_few.h)
 
 struct LayerW {
     DevBuf wqkv, bqkv, wo, wgu, wd, ln1, ln2;
-    DevBuf wqkv_t, wo_t, wgu_t, wd_t;   // fragment-major copies for the few-token GEMM path (built lazily)
+    DevBuf wqkv_t, wo_t, wgu_t, wd_t;   // fragment-major copies for the general path's few-token tiles (MI_NO_FEW=1; built lazily)
+    DevBuf few_qkv, few_o, few_gu, few_d;   // 1-KiB pieces of the query-time path (encoder_few.h; built lazily)
 };
 
 template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
@@ -461,6 +464,7 @@ struct mi_encoder {
     std::mutex mu;           // guards ws_sets, the lazily built fragment-major weights and the profiling events
     DevBuf ws_stage;         // load_tensor staging (exclusive calls)
     bool tiled_ok = false;   // fragment-major weight copies are current
+    bool few_ok = false;     // the query-time path's weight pieces are current
     // profiling: the GEMM launches of the most recent encode (arguments as launched), replayed back to back between two
     // HIP events by mi_encoder_profile_read -- like the index library's scan replay; per-launch event pairs measured
     // 3-4 % short of rocprofv3's per-kernel durations in the same run
@@ -673,6 +677,173 @@ bool timed_gemm(mi_encoder *h, int epi, const GemmArgs &g, hipStream_t st) {
     return normed;
 }
 
+void launch_attention(mi_encoder *h, const Batch &b, const bf16_t *qk, const bf16_t *vt, bf16_t *att, int ldvt, hipStream_t st,
+                      bf16_t *att_frag = nullptr, int frag_mt = 0) {
+    const mi_encoder_cfg &c = h->cfg;
+    const int hd = c.head_dim;
+    AttnArgs a{};
+    a.QK = qk; a.Vt = vt; a.O = att; a.Ofrag = att_frag; a.frag_mt = frag_mt; a.work_seq = b.work_seq; a.work_q0 = b.work_q0;
+    a.seq_start = b.seq_start; a.seq_len = b.seq_len; a.ldqk = h->qk_cols; a.ldvt = ldvt;
+    a.n_heads = c.n_heads; a.n_kv = c.n_kv_heads; a.causal = c.causal;
+    a.scale = 1.0f / std::sqrt((float)hd);
+    // two query heads of one K/V head per workgroup when the GQA group allows it (MI_ATTN_HPW=1: one head per workgroup)
+    static const bool hpw1 = std::getenv("MI_ATTN_HPW") && std::atoi(std::getenv("MI_ATTN_HPW")) == 1;
+    const bool pair = !hpw1 && c.n_heads % 2 == 0 && (c.n_heads / c.n_kv_heads) % 2 == 0;
+    a.nwork = b.nwork;
+    // persistent workgroups: two per CU (64 KiB of LDS each at head dim 128 x 2 heads), or one per item when there are fewer
+    static const int wgs_cu = std::getenv("MI_ATTN_WGS_PER_CU") ? std::max(1, std::atoi(std::getenv("MI_ATTN_WGS_PER_CU"))) : 2;
+    const int hpw = pair ? 2 : 1;
+    const unsigned nwg = (unsigned)std::min<long>((long)b.nwork * (c.n_heads / hpw), 256L * wgs_cu);
+    if (hd == 128 && pair) hipLaunchKernelGGL((attn_kernel<128, 2>), dim3(nwg), dim3(512), 0, st, a);
+    else if (hd == 128) hipLaunchKernelGGL((attn_kernel<128, 1>), dim3(nwg), dim3(256), 0, st, a);
+    else if (pair) hipLaunchKernelGGL((attn_kernel<64, 2>), dim3(nwg), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((attn_kernel<64, 1>), dim3(nwg), dim3(256), 0, st, a);
+    MI_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The query-time path (encoder_few.h): T <= 48 tokens, six launches per layer, no atomics.
+// ---------------------------------------------------------------------------------------------------------------
+bool few_eligible(const mi_encoder *h, const Batch &b) {
+    static const bool off = std::getenv("MI_NO_FEW") != nullptr;
+    const mi_encoder_cfg &c = h->cfg;
+    const int mt = (b.T_real + 15) / 16;
+    return !off && b.T_real <= FEW_MAX_T && c.hidden % 32 == 0 && c.hidden <= 4096 && c.intermediate % 32 == 0 && h->q_cols % 32 == 0 &&
+           (h->qk_cols + h->v_cols) % 16 == 0 && c.head_dim % 32 == 0 &&
+           (size_t)std::max({c.hidden / 32, h->q_cols / 32, 2 * FEW_NW}) * mt * 1024 + FEW_NW * 64 * 4 <= 160 * 1024;
+}
+
+template <int MT>
+void few_set_attributes() {
+    const int lim = 160 * 1024;
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_gemm_kernel<FEW_QKV, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_gemm_kernel<FEW_GU, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_o_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_d_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+}
+
+// the weight pieces of every layer, built once per handle (and again after a load_tensor); caller holds h->mu
+void few_build_weights(mi_encoder *h, hipStream_t st) {
+    const mi_encoder_cfg &c = h->cfg;
+    const int H = c.hidden, I = c.intermediate;
+    auto tile = [&](const DevBuf &src, int N, int K, int rope_blocks, DevBuf &dstb, bool half) {
+        bf16_t *d = dstb.as<bf16_t>((size_t)N * K);
+        if (half)
+            hipLaunchKernelGGL(few_tile_kernel<8>, dim3((unsigned)((N / 8) * (K / 32))), dim3(64), 0, st, src.get<bf16_t>(), N, K, K, 0, c.head_dim, d);
+        else
+            hipLaunchKernelGGL(few_tile_kernel<16>, dim3((unsigned)((N / 16) * (K / 32))), dim3(64), 0, st, src.get<bf16_t>(), N, K, K,
+                               rope_blocks, c.head_dim, d);
+        MI_HIP(hipGetLastError());
+    };
+    for (auto &w : h->layers) {
+        tile(w.wqkv, h->qk_cols + h->v_cols, H, h->qk_cols / 16, w.few_qkv, false);
+        tile(w.wo, H, h->q_cols, 0, w.few_o, true);
+        tile(w.wgu, 2 * I, H, 0, w.few_gu, false);
+        tile(w.wd, H, I, 0, w.few_d, false);
+    }
+    few_set_attributes<1>();
+    few_set_attributes<2>();
+    few_set_attributes<3>();
+    MI_HIP(hipStreamSynchronize(st));
+    h->few_ok = true;
+}
+
+// leaves the residual stream (before the final norm) in x
+template <int MT>
+void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16_t *qk, bf16_t *vt, int ldvt, hipStream_t st) {
+    const mi_encoder_cfg &c = h->cfg;
+    const int H = c.hidden, I = c.intermediate, T = b.T_real, T_pad = b.T_pad;
+    // fragments: the normalised stream (H / 32 steps), the attention output (q_cols / 32), h (I / 32); MT KiB per step
+    bf16_t *xfrag = ws.ws_xn.as<bf16_t>((size_t)T_pad * H);
+    bf16_t *afrag = ws.ws_att.as<bf16_t>((size_t)T_pad * h->q_cols);
+    bf16_t *hfrag = ws.ws_h.as<bf16_t>((size_t)T_pad * I);
+    float *ssq = ws.ws_stage.as<float>((size_t)(H / 8) * FEW_SSQ_LD);
+    auto gemm_grid = [](int nunits) { return std::max(std::min(nunits, 256), (nunits + 2) / 3); };
+    auto gemm_smem = [&](int nk, int wn) { return (size_t)std::max(nk, FEW_NW * wn) * MT * 1024 + (size_t)FEW_NW * 64 * 4; };
+    // K slices of the down projection: about one workgroup per CU
+    FewArgs d0{};
+    d0.nk = I / 32; d0.nunits = H / 16;
+    const int ugroups = (d0.nunits + 3) / 4;
+    {
+        const int ns = std::max(1, std::min(d0.nk, (248 + ugroups / 2) / ugroups));
+        d0.ks_per_slice = (d0.nk + ns - 1) / ns;
+        while ((size_t)d0.ks_per_slice * MT * 1024 > 128 * 1024) d0.ks_per_slice = (d0.ks_per_slice + 1) / 2;
+        d0.nslices = (d0.nk + d0.ks_per_slice - 1) / d0.ks_per_slice;
+    }
+    float *part = static_cast<float *>(ws.ws_part.reserve((size_t)d0.nslices * T_pad * H * 4));
+    // MI_FEW_SYNC=1 (debugging): wait after every launch and name the stage on stderr
+    static const bool dbg_sync = std::getenv("MI_FEW_SYNC") != nullptr;
+    // MI_FEW_TS=1 (profiling): s_memtime stamps of every workgroup of the first layer's two fragment GEMMs, mean / max per phase
+    static const bool dbg_ts = std::getenv("MI_FEW_TS") != nullptr;
+    DevBuf tsb;
+    auto stamps = [&](const char *name, int nwg) {
+        std::vector<unsigned long long> hts((size_t)nwg * 8);
+        MI_HIP(hipStreamSynchronize(st));
+        MI_HIP(hipMemcpy(hts.data(), tsb.p, hts.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int g = 0; g < nwg; ++g) { t0 = std::min(t0, hts[(size_t)g * 8]); t1 = std::max(t1, hts[(size_t)g * 8 + 7]); }
+        std::fprintf(stderr, "[few stamps] %s: %d workgroups, first start -> last end %llu ticks; per phase (since the workgroup's start) mean / max; start skew mean / max\n", name, nwg, t1 - t0);
+        const char *ph[8] = {"start", "requests issued", "fragments stored", "barrier 1", "stream done", "barrier 2", "partials stored+barrier 3", "end"};
+        for (int i = 1; i < 8; ++i) {
+            double sum = 0, mx = 0;
+            for (int g = 0; g < nwg; ++g) { const double v = (double)(hts[(size_t)g * 8 + i] - hts[(size_t)g * 8]); sum += v; mx = std::max(mx, v); }
+            std::fprintf(stderr, "  %-26s %9.0f %9.0f\n", ph[i], sum / nwg, mx);
+        }
+        double ssum = 0, smx = 0;
+        for (int g = 0; g < nwg; ++g) { const double v = (double)(hts[(size_t)g * 8] - t0); ssum += v; smx = std::max(smx, v); }
+        std::fprintf(stderr, "  %-26s %9.0f %9.0f\n", "start skew", ssum / nwg, smx);
+    };
+    auto chk = [&](const char *stage) {
+        MI_HIP(hipGetLastError());
+        if (dbg_sync) {
+            const hipError_t e = hipStreamSynchronize(st);
+            std::fprintf(stderr, "[few] %s: %s\n", stage, hipGetErrorString(e));
+        }
+    };
+
+    FewArgs e{};
+    e.T = T; e.H = H; e.x = x; e.norm_w = h->layers[0].ln1.get<float>(); e.eps = c.rms_eps; e.xfrag = xfrag; e.ids = b.ids;
+    e.table = h->embed.get<bf16_t>();
+    hipLaunchKernelGGL((few_row_kernel<true, MT>), dim3((unsigned)T), dim3(256), 0, st, e);
+    chk("embed");
+    for (int l = 0; l < c.n_layers; ++l) {
+        LayerW &w = h->layers[l];
+        Range layer_range("mi_encoder:layer");
+        FewArgs q{};
+        q.T = T; q.H = H; q.nk = H / 32; q.nunits = (h->qk_cols + h->v_cols) / 16; q.W = w.few_qkv.get<bf16_t>(); q.afrag = xfrag;
+        q.eps = c.rms_eps; q.bias = w.bqkv.get<float>(); q.qk = qk; q.vt = vt;
+        q.ldqk = h->qk_cols; q.ldvt = ldvt; q.qk_cols = h->qk_cols; q.hd = c.head_dim; q.rope_blocks = h->qk_cols / 16;
+        q.pos = b.pos; q.cos_t = h->rope_cos.get<float>(); q.sin_t = h->rope_sin.get<float>();
+        if (dbg_ts && l == 0) q.ts = tsb.as<unsigned long long>((size_t)gemm_grid(q.nunits) * 8);
+        hipLaunchKernelGGL((few_gemm_kernel<FEW_QKV, MT>), dim3((unsigned)gemm_grid(q.nunits)), dim3(64 * FEW_NW), gemm_smem(q.nk, 1), st, q);
+        if (q.ts) stamps("qkv", gemm_grid(q.nunits));
+        chk("qkv");
+        launch_attention(h, b, qk, vt, nullptr, ldvt, st, afrag, MT);
+        chk("attention");
+        FewArgs o{};
+        o.T = T; o.H = H; o.nk = h->q_cols / 32; o.nunits = H / 8; o.W = w.few_o.get<bf16_t>(); o.afrag = afrag; o.x = x;
+        o.norm_w = w.ln2.get<float>(); o.ssq_out = ssq; o.xfrag = xfrag;
+        hipLaunchKernelGGL((few_o_kernel<MT>), dim3((unsigned)o.nunits), dim3(64 * FEW_OW), (size_t)std::max(o.nk, FEW_OW) * MT * 1024, st, o);
+        chk("o");
+        FewArgs u{};
+        u.T = T; u.H = H; u.nk = H / 32; u.nunits = I / 16; u.W = w.few_gu.get<bf16_t>(); u.afrag = xfrag; u.eps = c.rms_eps;
+        u.ssq = ssq; u.nparts = H / 8; u.hfrag = hfrag;
+        if (dbg_ts && l == 0) u.ts = tsb.as<unsigned long long>((size_t)gemm_grid(u.nunits) * 8);
+        hipLaunchKernelGGL((few_gemm_kernel<FEW_GU, MT>), dim3((unsigned)gemm_grid(u.nunits)), dim3(64 * FEW_NW), gemm_smem(u.nk, 2), st, u);
+        if (u.ts) stamps("gate/up", gemm_grid(u.nunits));
+        chk("gu");
+        FewArgs d = d0;
+        d.T = T; d.H = H; d.W = w.few_d.get<bf16_t>(); d.afrag = hfrag; d.part = part; d.T_pad = T_pad;
+        hipLaunchKernelGGL((few_d_kernel<MT>), dim3((unsigned)(ugroups * d.nslices)), dim3(256), (size_t)d.ks_per_slice * MT * 1024, st, d);
+        chk("d");
+        FewArgs r{};
+        r.T = T; r.H = H; r.x = x; r.part = part; r.T_pad = T_pad; r.nslices = d.nslices; r.eps = c.rms_eps; r.xfrag = xfrag;
+        r.norm_w = l + 1 < c.n_layers ? h->layers[l + 1].ln1.get<float>() : nullptr;
+        hipLaunchKernelGGL((few_row_kernel<false, MT>), dim3((unsigned)T), dim3(256), 0, st, r);
+        chk("reduce");
+    }
+}
+
 // the decoder stack: leaves the residual stream (before the final norm) in ws_x
 void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st) {
     const mi_encoder_cfg &c = h->cfg;
@@ -713,6 +884,19 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         std::lock_guard<std::mutex> hl(h->mu);
         h->prof_launches.clear();
         h->prof_flops = 0.0;
+    }
+    if (few_eligible(h, b)) {
+        {
+            std::lock_guard<std::mutex> hl(h->mu);         // the pieces are built once; other streams wait for them
+            if (!h->few_ok) few_build_weights(h, st);
+        }
+        Range stack_range("mi_encoder:stack(few)");
+        g_few_passes.fetch_add(1);
+        const int mt = (b.T_real + 15) / 16;
+        if (mt == 1) few_stack<1>(h, ws, b, x, qk, vt, ldvt, st);
+        else if (mt == 2) few_stack<2>(h, ws, b, x, qk, vt, ldvt, st);
+        else few_stack<3>(h, ws, b, x, qk, vt, ldvt, st);
+        return;
     }
     // few tokens (a query, or a handful): the GEMMs stream the weights once and are bound by how
     // they read them -- use the fragment-major copies (a second copy of the layer weights, built
@@ -761,24 +945,7 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
                                nh_qk, hd, b.pos, h->rope_cos.get<float>(),
                                h->rope_sin.get<float>(), T);
         }
-        AttnArgs a{};
-        a.QK = qk; a.Vt = vt; a.O = att; a.work_seq = b.work_seq; a.work_q0 = b.work_q0;
-        a.seq_start = b.seq_start; a.seq_len = b.seq_len; a.ldqk = h->qk_cols; a.ldvt = ldvt;
-        a.n_heads = c.n_heads; a.n_kv = c.n_kv_heads; a.causal = c.causal;
-        a.scale = 1.0f / std::sqrt((float)hd);
-        // two query heads of one K/V head per workgroup when the GQA group allows it (MI_ATTN_HPW=1: one head per workgroup)
-        static const bool hpw1 = std::getenv("MI_ATTN_HPW") && std::atoi(std::getenv("MI_ATTN_HPW")) == 1;
-        const bool pair = !hpw1 && c.n_heads % 2 == 0 && (c.n_heads / c.n_kv_heads) % 2 == 0;
-        a.nwork = b.nwork;
-        // persistent workgroups: two per CU (64 KiB of LDS each at head dim 128 x 2 heads), or one per item when there are fewer
-        static const int wgs_cu = std::getenv("MI_ATTN_WGS_PER_CU") ? std::max(1, std::atoi(std::getenv("MI_ATTN_WGS_PER_CU"))) : 2;
-        const int hpw = pair ? 2 : 1;
-        const unsigned nwg = (unsigned)std::min<long>((long)b.nwork * (c.n_heads / hpw), 256L * wgs_cu);
-        if (hd == 128 && pair) hipLaunchKernelGGL((attn_kernel<128, 2>), dim3(nwg), dim3(512), 0, st, a);
-        else if (hd == 128) hipLaunchKernelGGL((attn_kernel<128, 1>), dim3(nwg), dim3(256), 0, st, a);
-        else if (pair) hipLaunchKernelGGL((attn_kernel<64, 2>), dim3(nwg), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((attn_kernel<64, 1>), dim3(nwg), dim3(256), 0, st, a);
-        MI_HIP(hipGetLastError());
+        launch_attention(h, b, qk, vt, att, ldvt, st);
         GemmArgs o{};
         o.A = att; o.lda = h->q_cols; o.W = w.wo.get<bf16_t>(); o.ldw = h->q_cols; o.M = T; o.N = H; o.K = h->q_cols;
         o.X = x; o.ldc = H; o.part = part; o.part_bytes = part_bytes;
@@ -881,6 +1048,7 @@ int mi_encoder_load_tensor(mi_encoder *h, const char *name_c, const void *data, 
         MI_REQUIRE(h && name_c && data && shape, "null argument");
         MI_REQUIRE(dtype >= 0 && dtype <= 2, "bad dtype");
         h->tiled_ok = false;   // any new weight invalidates the fragment-major copies
+        h->few_ok = false;
         std::string name(name_c);
         if (name.rfind("model.", 0) == 0) name = name.substr(6);
         auto it = h->loaded.find(name);
@@ -1111,6 +1279,7 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
         else if (std::string(name) == "splitk_launches") *value = g_splitk_launches.load();
         else if (std::string(name) == "reduce_norm_launches") *value = g_reduce_norm_launches.load();
         else if (std::string(name) == "n192_launches") *value = g_n192_launches.load();
+        else if (std::string(name) == "few_passes") *value = g_few_passes.load();
         else throw Error(std::string("unknown debug counter: ") + name);
     });
 }

@@ -1,0 +1,544 @@
+// encoder_few.h -- the query-time encoder: a forward pass over a handful of tokens (one prompted query, T <= 48) is a
+// pass over the 93.6 MB of bf16 weights of every layer and nothing else, so every kernel here is a WEIGHT STREAM with the
+// arithmetic hanging off it (reference call site: README.md:28, the query-time app; arithmetic restated in
+// oracle/encoder_oracle.py).  Six launches per layer instead of the general path's ten, no atomics (bit-reproducible):
+//
+//   few_row_kernel<EMBED>          token ids -> f32 stream + the first RMSNorm as bf16 fragments
+//   few_gemm_kernel<FEW_QKV>       QKV projection of the normalised fragments -> +bias -> RoPE -> Q|K rows, V^T
+//   attn_kernel                    (encoder_kernels.h) with its output written as fragments
+//   few_o_kernel                   O projection + residual add, 8 output features per workgroup over ALL of K:
+//                                  writes the stream, bf16(x g) fragments for the next RMSNorm and the per-token
+//                                  partial sums of squares of its 8 columns
+//   few_gemm_kernel<FEW_GU>        gate/up projection of those fragments, 1/rms applied to the accumulators -> SwiGLU -> h fragments
+//   few_d_kernel                   down projection, K split over workgroups -> partial planes (plain stores)
+//   few_row_kernel<REDUCE>         stream += planes (fixed order), next layer's first RMSNorm as fragments
+//
+// Layout.  A weight matrix W[N][K] is stored as 1-KiB PIECES: piece (16-row block rb, K step ks) holds, at lane l's 16
+// bytes, W'[16 rb + (l & 15)][32 ks + 8 (l >> 4) .. +8] -- the A operand of v_mfma_f32_16x16x32_bf16, so a wave's load
+// of a piece is ONE contiguous 1 KiB and a row block's K run is one contiguous stream (few_tile_kernel builds the
+// copies once; the O projection uses 8-row half pieces of 512 B).  Activations are FRAGMENTS in the same sense: piece
+// (K step ks, token tile mt) holds at lane l the 8 values [token 16 mt + (l & 15)][32 ks + 8 (l >> 4) ..] -- the B
+// operand; every producer writes its output directly in that form, so every consumer's staging is a straight copy of
+// whole 128-byte lines.  The accumulator tile is D[feature 4 (l >> 4) + r][token l & 15]: a lane owns FOUR CONSECUTIVE
+// FEATURES OF ONE TOKEN -- 8-byte bf16 stores, 16-byte f32 stores, and (with the Q/K rows of a block permuted to
+// {8b..8b+7} u {hd/2 + 8b..}) the RoPE partner of a value sits in lane l ^ 32 of the same tile.  The columns of a tile
+// are independent: what the padding tokens of the last tile hold (never written: anything) reaches no real token.
+//
+// What bounds it (tools/micro/stream_bw.hip -> profiles/r04_stream_bw.txt, and the first version of this file):
+//   * a CU pulls ~45-50 GB/s from HBM whatever its waves have in flight, so a stream needs >= ~200 CUs to reach the
+//     chip's ~5.2 TB/s: hence 8-feature workgroups for the O projection (192 of them) and a K split for the down
+//     projection (whose activations are too long to give every workgroup all of K);
+//   * the memory pipe of a CU charges ~3.5 cycles per (instruction, 128-byte line): a workgroup that reads the
+//     T x H f32 stream for its own RMSNorm (16 rows x 64 B per instruction) spent 4.5 us there at 32 tokens -- the
+//     first version's QKV kernel took 11.6 us for a 1.3 us stream -- so the norm is computed ONCE by whoever completes
+//     the stream's rows and handed on as fragments (98 KB per consumer workgroup, whole lines);
+//   * f32 atomics into the stream ran at ~70 per ns chip-wide: 491 k of them (32 tokens x 1536 x 10 K slices) were
+//     7 us of a 10 us O projection.  No atomics anywhere now;
+//   * a launch that streams 5-6 MB costs ~2.9 us whatever it does (boundary + ramp): the launch COUNT is the lever.
+#pragma once
+#include "encoder_kernels.h"
+
+namespace mienc {
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+enum { FEW_QKV = 0, FEW_GU = 1 };
+constexpr int FEW_NW = 6;          // waves of a few_gemm workgroup: 1, 2 or 3 row units x 6, 3 or 2 K ranges
+constexpr int FEW_OW = 8;          // waves of a few_o workgroup (K ranges)
+constexpr int FEW_MAX_T = 48;
+constexpr int FEW_SSQ_LD = 64;     // tokens per row of the sum-of-squares partials
+
+struct FewArgs {
+    int T, H;                      // real tokens (packed back to back), model width
+    int nk;                        // K steps of 32 of this GEMM
+    int nunits;                    // row units: 16-row blocks (QKV, D), gate/up pairs of blocks (GU), 8-row halves (O)
+    int nslices, ks_per_slice;     // D: K slices over workgroups (reduce: planes to add)
+    const bf16_t *W;               // pieces
+    const bf16_t *afrag;           // activation fragments [nk][MT] KiB
+    float *x;                      // residual stream [T_pad][H]
+    const float *norm_w;           // [H]: the RMSNorm gains applied to what this kernel hands on (O, reduce, embed)
+    float eps;
+    const float *ssq;              // GU: [nparts][FEW_SSQ_LD] partial sums of squares of the stream's rows (nparts = 0: operand already normalised)
+    float *ssq_out;                // O: the same, written
+    int nparts;
+    bf16_t *xfrag;                 // O / reduce / embed: bf16 fragments of the (gain-scaled / normalised) stream, [H / 32][MT] KiB
+    // QKV epilogue
+    const float *bias;             // [qk_cols + v_cols], original feature order
+    bf16_t *qk;                    // [T_pad][ldqk]
+    bf16_t *vt;                    // [v_cols][ldvt]
+    int ldqk, ldvt, qk_cols, hd, rope_blocks;   // rope_blocks = (n_heads + n_kv) * hd / 16
+    const int32_t *pos;
+    const float *cos_t, *sin_t;    // [max_seq][hd / 2]
+    bf16_t *hfrag;                 // GU epilogue: h as fragments (K step of the down projection, token tile)
+    float *part;                   // D: [nslices][T_pad][H] partial planes; reduce: the same, read
+    int T_pad;
+    // embed
+    const int32_t *ids;
+    const bf16_t *table;
+    unsigned long long *ts;        // MI_FEW_TS (profiling): [workgroup][8] s_memtime stamps of wave 0
+};
+
+__device__ __forceinline__ void few_stamp(const FewArgs &a, int slot) {
+    if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
+}
+
+// W [N][ldw] row-major bf16 -> pieces of RB rows (16, or 8 for the O projection: lane l then carries row l & 7, so a
+// half piece is 512 B).  rope_blocks > 0 (RB = 16): the first rope_blocks blocks are Q / K head rows, permuted inside each
+// head so that block b of a head holds the features {8 b .. 8 b + 7} and {hd/2 + 8 b .. hd/2 + 8 b + 7}.
+template <int RB>
+__global__ void __launch_bounds__(64) few_tile_kernel(const bf16_t *__restrict__ W, int N, int K, int ldw, int rope_blocks,
+                                                      int hd, bf16_t *__restrict__ out) {
+    const int nk = K / 32, piece = blockIdx.x, rb = piece / nk, ks = piece - rb * nk, l = threadIdx.x;
+    const int i = l & 15, lg = l >> 4;
+    if (RB == 8 && i >= 8) return;
+    int row = rb * RB + i;
+    if (RB == 16 && rb < rope_blocks) {
+        const int bph = hd / 16, head = rb / bph, b = rb - head * bph;
+        row = head * hd + (i < 8 ? 8 * b + i : hd / 2 + 8 * b + (i - 8));
+    }
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < N) v = *reinterpret_cast<const uint4 *>(W + (size_t)row * ldw + ks * 32 + lg * 8);
+    *reinterpret_cast<uint4 *>(out + (size_t)piece * (RB * 32) + (lg * RB + i) * 8) = v;
+}
+
+// One piece of the weight stream -> registers; non-temporal: a piece is read by one wave once per forward pass
+// (MI355X_MICROARCH: nt-weights).  Plain loads the compiler tracks, with a scheduling barrier behind every one of them:
+// left to itself hipcc (a) gathers the U loads of an unrolled round behind the round's U steps and (b) orders the first U
+// loads by address, so that the wait in front of the round's first MFMA, which must hold for the entry AND the back edge,
+// becomes vmcnt(1) -- a drained ring, one HBM latency per round (the first version: 14 us for the down projection).
+// Pinned to ring order, its own counted waits are the right ones (vmcnt((U - 1) WN)).  (Loads issued from inline asm with
+// hand-placed waits are NOT an option here: for a tied operand the compiler copies the destination registers of a load
+// that has not landed and recycles them -- the late data then overwrote an address: memory access fault.)
+__device__ __forceinline__ void few_wload(bf16x8 &dst, const bf16_t *p) {
+    dst = __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const i32x4_t *>(p)));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The stream: `nsteps` K steps of one row unit (WN row blocks; consecutive steps STEP elements apart) against the
+// activation fragments in LDS, U steps of pieces in flight per wave.  `ring` arrives requested (few_ring_start, before
+// the prologue's work); every step issues exactly WN loads (a clamped step index past the end).
+template <int WN, int U, int STEP>
+__device__ __forceinline__ void few_ring_start(const bf16_t *wp, size_t blk_stride, int nsteps, bf16x8 (&ring)[U][WN]) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) few_wload(ring[u][j], wp + j * blk_stride + (size_t)min(u, max(nsteps - 1, 0)) * STEP);
+}
+
+template <int WN, int MT, int U, int STEP>
+__device__ __forceinline__ void few_stream(const bf16_t *wp, size_t blk_stride, int nsteps, const uint4 *afr,
+                                           bf16x8 (&ring)[U][WN], f32x4 (&acc)[WN][MT]) {
+    bf16x8 an[MT];                                       // activation fragments one step ahead of their MFMAs
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) an[mt] = as_bf16x8(afr[mt * 64]);
+    auto step = [&](int s, bf16x8(&b)[WN]) {
+        bf16x8 a[MT];
+        const int sn = min(s + 1, nsteps - 1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            a[mt] = an[mt];
+            an[mt] = as_bf16x8(afr[(sn * MT + mt) * 64]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[mt], acc[j][mt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int sl = min(s + U, nsteps - 1);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) few_wload(b[j], wp + j * blk_stride + (size_t)sl * STEP);
+    };
+    int s0 = 0;
+    for (; s0 + U <= nsteps; s0 += U) {                  // whole rounds: no branch between the steps
+#pragma unroll
+        for (int u = 0; u < U; ++u) step(s0 + u, ring[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (s0 + u < nsteps) step(s0 + u, ring[u]);
+}
+
+// `npieces` contiguous 1-KiB fragments global -> LDS by NWV waves: few_stage_load requests the first AB pieces of every
+// wave (the caller requests its weight ring next: loads return in order, so what is requested before the ring is usable
+// before the ring has landed), few_stage_store writes them and copies whatever is left piece by piece (shapes beyond the
+// one-batch sizes: H > 1536).  Unconditional accesses -- a clamped piece index rewrites the last piece with its own data;
+// a guarded store is a branch.  (Plain arrays and free functions: as members of a struct the registers went to scratch.)
+template <int NWV, int AB>
+__device__ __forceinline__ void few_stage_load(i32x4_t (&av)[AB], const bf16_t *src, int npieces, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < AB; ++i)
+        av[i] = *reinterpret_cast<const i32x4_t *>(src + (size_t)min(w + NWV * i, npieces - 1) * 512 + lane * 8);
+}
+template <int NWV, int AB>
+__device__ __forceinline__ void few_stage_store(i32x4_t (&av)[AB], const bf16_t *src, uint4 *lds, int npieces, int w, int lane) {
+    i32x4_t *l4 = reinterpret_cast<i32x4_t *>(lds);
+#pragma unroll
+    for (int i = 0; i < AB; ++i) l4[min(w + NWV * i, npieces - 1) * 64 + lane] = av[i];
+    for (int p = NWV * AB + w; p < npieces; p += NWV)
+        l4[p * 64 + lane] = *reinterpret_cast<const i32x4_t *>(src + (size_t)p * 512 + lane * 8);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM over the full K = H of (already gain-scaled or normalised) fragments -> epilogue (QKV: bias + RoPE + stores;
+// GU: 1/rms, SwiGLU -> h fragments).
+// grid: G workgroups of 6 waves; workgroup b owns the row units [b nunits / G, (b + 1) nunits / G) (1, 2 or 3 of them:
+// the host sizes G so), unit j of it is streamed by waves [j wpu, (j + 1) wpu), wpu = 6 / count, each over a K range;
+// the partial tiles meet in LDS (a fixed summation order).
+// dynamic LDS: max(nk, 6 WN) x MT KiB (the fragments, later the partial tiles) | ssw[6][64] f32
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE, int MT>
+__global__ void __launch_bounds__(64 * FEW_NW) few_gemm_kernel(FewArgs a) {
+    constexpr int WN = MODE == FEW_GU ? 2 : 1;
+    constexpr int U = MODE == FEW_GU ? (MT == 3 ? 12 : 16) : 8;   // K steps in flight per wave: ALL of a 2-unit workgroup's (the memory pipe of the CU must never idle: 47 GB/s is all it has)
+    extern __shared__ __attribute__((aligned(16))) uint4 few_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int nk = a.nk, H = a.H, T = a.T;
+    const int area = max(nk, FEW_NW * WN) * MT * 64;           // uint4 units
+    float *ssw = reinterpret_cast<float *>(few_lds + area);
+
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int u0 = (int)((long)b * a.nunits / G), u1 = (int)((long)(b + 1) * a.nunits / G);
+    const int nu = u1 - u0;                                      // 1..3 (0: nothing to do)
+    if (nu <= 0) return;
+    const int wpu = FEW_NW / nu;
+    const int ul = min(w / wpu, nu - 1), kp = w - ul * wpu;      // (nu = 1..3 divides 6: every wave has a unit)
+    const int kper = (nk + wpu - 1) / wpu;
+    const int k0 = min(nk, kp * kper), k1 = min(nk, k0 + kper);
+    const int nsteps = k1 - k0;
+    const int unit = u0 + ul;
+    const bf16_t *wp = a.W + ((size_t)unit * WN * nk + min(k0, nk - 1)) * 512 + lane * 8;
+    const size_t blk_stride = (size_t)nk * 512;
+    few_stamp(a, 0);
+
+    // ---- prologue: the fragments -> LDS (8 MT pieces per wave at H = 1536: one batch), the head of the weight stream
+    // requested behind them; the sums of squares of the stream's rows from the producer's partials
+    // (requested in the order they are needed: loads return in order, and the first thing behind the ring is an HBM latency away)
+    // QKV: the epilogue operands of this wave's first item (bias, position -> rotary table rows) ride in front of everything
+    f32x4 pre_b = (f32x4){0.f, 0.f, 0.f, 0.f}, pre_c = pre_b, pre_s = pre_b;
+    if (MODE == FEW_QKV && w < nu * MT) {
+        const int eu = w / MT, mt = w - eu * MT, eunit = u0 + eu;
+        if (eunit < a.rope_blocks) {
+            const int bph = a.hd / 16, head = eunit / bph, bb = eunit - head * bph, half = a.hd / 2;
+            const int jf = 8 * bb + 4 * (lg & 1);
+            const int ps = a.pos[min(16 * mt + li, T - 1)];
+            pre_b = *reinterpret_cast<const f32x4 *>(a.bias + head * a.hd + (lg < 2 ? 0 : half) + jf);
+            pre_c = *reinterpret_cast<const f32x4 *>(a.cos_t + (size_t)ps * half + jf);
+            pre_s = *reinterpret_cast<const f32x4 *>(a.sin_t + (size_t)ps * half + jf);
+        } else {
+            pre_b = *reinterpret_cast<const f32x4 *>(a.bias + a.qk_cols + 16 * (eunit - a.rope_blocks) + 4 * lg);
+        }
+    }
+    constexpr int SQ = MODE == FEW_GU ? 32 : 1;                 // partials per wave requested at once (192 = H / 8 at H = 1536)
+    float sq[SQ];
+    if (MODE == FEW_GU && a.nparts > 0) {                       // wave w adds the partials w, w + 6, ... of token `lane`
+#pragma unroll
+        for (int i = 0; i < SQ; ++i) sq[i] = a.ssq[min(w + FEW_NW * i, a.nparts - 1) * FEW_SSQ_LD + lane];
+    }
+    i32x4_t av[8 * MT];
+    few_stage_load<FEW_NW, 8 * MT>(av, a.afrag, nk * MT, w, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 ring[U][WN];
+    few_ring_start<WN, U, 512>(wp, blk_stride, nsteps, ring);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE == FEW_GU && a.nparts > 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < SQ; ++i) s += w + FEW_NW * i < a.nparts ? sq[i] : 0.f;
+        for (int p = w + FEW_NW * SQ; p < a.nparts; p += FEW_NW) s += a.ssq[p * FEW_SSQ_LD + lane];
+        ssw[w * 64 + lane] = s;
+    }
+    few_stamp(a, 1);
+    few_stage_store<FEW_NW, 8 * MT>(av, a.afrag, few_lds, nk * MT, w, lane);
+    few_stamp(a, 2);
+    __syncthreads();
+    few_stamp(a, 3);
+
+    // ---- the stream
+    f32x4 acc[WN][MT];
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (nsteps > 0) few_stream<WN, MT, U, 512>(wp, blk_stride, nsteps, few_lds + (size_t)k0 * MT * 64 + lane, ring, acc);
+    few_stamp(a, 4);
+    __syncthreads();                                           // every wave is done with the fragments: the area is reused
+    few_stamp(a, 5);
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            reinterpret_cast<f32x4 *>(few_lds)[((w * WN + j) * MT + mt) * 64 + lane] = acc[j][mt];
+    __syncthreads();
+
+    // ---- epilogue: item = (unit of the workgroup, token tile); a wave takes whole tiles (the lane keeps its tile position)
+    few_stamp(a, 6);
+    const f32x4 *part = reinterpret_cast<const f32x4 *>(few_lds);
+    for (int it = w; it < nu * MT; it += FEW_NW) {
+        const int eu = it / MT, mt = it - eu * MT;
+        const int m = 16 * mt + li;
+        float inv = 1.f;
+        if (a.nparts > 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < FEW_NW; ++ww) tot += ssw[ww * 64 + m];
+            inv = rsqrtf(tot / (float)H + a.eps);
+        }
+        f32x4 v[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < wpu; ++c) {                     // ascending K ranges: a fixed order
+                const f32x4 p = part[(((eu * wpu + c) * WN + j) * MT + mt) * 64 + lane];
+                v[j][0] += p[0]; v[j][1] += p[1]; v[j][2] += p[2]; v[j][3] += p[3];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j][r] *= inv;
+        }
+        const int eunit = u0 + eu;
+        if constexpr (MODE == FEW_GU) {
+            float hq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hq[r] = v[0][r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[0][r])) * v[1][r];
+            uint2 o;
+            o.x = pack2(hq[0], hq[1]);
+            o.y = pack2(hq[2], hq[3]);
+            // feature 16 eunit + 4 lg + r of token m -> piece (K step eunit / 2, tile mt), lane (2 (eunit & 1) + lg / 2, li), half lg & 1
+            bf16_t *dst = a.hfrag + ((size_t)((eunit >> 1) * MT + mt) * 64 + ((2 * (eunit & 1) + (lg >> 1)) * 16 + li)) * 8 + 4 * (lg & 1);
+            *reinterpret_cast<uint2 *>(dst) = o;
+        } else {
+            if (eunit < a.rope_blocks) {
+                const int bph = a.hd / 16, head = eunit / bph, bb = eunit - head * bph, half = a.hd / 2;
+                const int jf = 8 * bb + 4 * (lg & 1);              // index inside the half
+                const int fih = (lg < 2 ? 0 : half) + jf;          // feature inside the head (r added below)
+                f32x4 bv = pre_b, c4 = pre_c, s4 = pre_s;
+                if (it != w) {                                     // (only the wave's first item was prefetched)
+                    const int ps = a.pos[min(m, T - 1)];
+                    bv = *reinterpret_cast<const f32x4 *>(a.bias + head * a.hd + fih);
+                    c4 = *reinterpret_cast<const f32x4 *>(a.cos_t + (size_t)ps * half + jf);
+                    s4 = *reinterpret_cast<const f32x4 *>(a.sin_t + (size_t)ps * half + jf);
+                }
+                float q[4] = {v[0][0] + bv[0], v[0][1] + bv[1], v[0][2] + bv[2], v[0][3] + bv[3]};
+                float p[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] = __shfl_xor(q[r], 32);
+                const float cs[4] = {c4[0], c4[1], c4[2], c4[3]}, sn[4] = {s4[0], s4[1], s4[2], s4[3]};
+                float o4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o4[r] = lg < 2 ? q[r] * cs[r] - p[r] * sn[r] : q[r] * cs[r] + p[r] * sn[r];
+                if (m < T) {
+                    uint2 o;
+                    o.x = pack2(o4[0], o4[1]);
+                    o.y = pack2(o4[2], o4[3]);
+                    *reinterpret_cast<uint2 *>(a.qk + (size_t)m * a.ldqk + head * a.hd + fih) = o;
+                }
+            } else {
+                const int vf = 16 * (eunit - a.rope_blocks) + 4 * lg;   // V feature (r added below)
+                f32x4 bv = pre_b;
+                if (it != w) bv = *reinterpret_cast<const f32x4 *>(a.bias + a.qk_cols + vf);
+                const float bb[4] = {bv[0], bv[1], bv[2], bv[3]};
+                if (m < T) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a.vt[(size_t)(vf + r) * a.ldvt + m] = f2bf(v[0][r] + bb[r]);
+                }
+            }
+        }
+    }
+    few_stamp(a, 7);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// O projection + residual add: workgroup = 8 output features (a half unit) over ALL of K -- 192 workgroups at H = 1536,
+// every one of which finishes its columns of the stream (no cross-workgroup sum).  8 waves = 8 K ranges, half pieces of
+// 512 B (lanes l and l + 8 of a 16-lane group fetch the same row: the MFMA's rows 8..15 repeat rows 0..7).  Epilogue:
+// x += sum; bf16(x g) fragments and this workgroup's part of the rows' sums of squares for the next RMSNorm.
+// dynamic LDS: max(nk, 8) x MT KiB
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ void __launch_bounds__(64 * FEW_OW) few_o_kernel(FewArgs a) {
+    constexpr int U = 6;
+    extern __shared__ __attribute__((aligned(16))) uint4 few_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int nk = a.nk, T = a.T, H = a.H;
+    const int hu = (int)blockIdx.x;
+    const int kper = (nk + FEW_OW - 1) / FEW_OW;
+    const int k0 = min(nk, w * kper), k1 = min(nk, k0 + kper), nsteps = k1 - k0;
+    const bf16_t *wp = a.W + ((size_t)hu * nk + min(k0, nk - 1)) * 256 + (lg * 8 + (li & 7)) * 8;
+
+    // the lanes that will finish a tile (wave mt, lg < 2) request their 4 columns of the stream and the gains first
+    const int em = 16 * w + li, ef = 8 * hu + 4 * (lg & 1);
+    const bool eown = w < MT && lg < 2 && em < T;
+    float *px = a.x + (size_t)min(em, T - 1) * H + ef;
+    f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f}, gv = xv;
+    if (eown) xv = *reinterpret_cast<const f32x4 *>(px);
+    if (w < MT) gv = *reinterpret_cast<const f32x4 *>(a.norm_w + ef);
+    i32x4_t av[6 * MT];
+    few_stage_load<FEW_OW, 6 * MT>(av, a.afrag, nk * MT, w, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 ring[U][1];
+    few_ring_start<1, U, 256>(wp, 0, nsteps, ring);
+    __builtin_amdgcn_sched_barrier(0);
+    few_stage_store<FEW_OW, 6 * MT>(av, a.afrag, few_lds, nk * MT, w, lane);
+    __syncthreads();
+    f32x4 acc[1][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[0][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (nsteps > 0) few_stream<1, MT, U, 256>(wp, 0, nsteps, few_lds + (size_t)k0 * MT * 64 + lane, ring, acc);
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) reinterpret_cast<f32x4 *>(few_lds)[(w * MT + mt) * 64 + lane] = acc[0][mt];
+    __syncthreads();
+    // tile mt is finished by wave mt; lanes lg < 2 hold the 8 real features (4 lg + r), token li
+    if (w < MT) {
+        const int mt = w, m = 16 * mt + li;
+        const f32x4 *part = reinterpret_cast<const f32x4 *>(few_lds);
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < FEW_OW; ++c) {
+            const f32x4 p = part[(c * MT + mt) * 64 + lane];
+            v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+        }
+        float ss = 0.f;                                         // (lanes lg >= 2 repeat lg - 2; they store nothing)
+        if (eown) {
+            xv[0] += v[0]; xv[1] += v[1]; xv[2] += v[2]; xv[3] += v[3];
+            *reinterpret_cast<f32x4 *>(px) = xv;
+            ss = xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2] + xv[3] * xv[3];
+        }
+        ss += __shfl_xor(ss, 16);                               // the two halves of the 8 features
+        if (lg == 0) a.ssq_out[hu * FEW_SSQ_LD + m] = ss;       // (padding tokens: 0)
+        if (lg < 2) {                                           // fragments: every token of the tile (padding tokens: zeros)
+            uint2 o;
+            o.x = pack2(xv[0] * gv[0], xv[1] * gv[1]);
+            o.y = pack2(xv[2] * gv[2], xv[3] * gv[3]);
+            // feature ef + r of token m -> piece (K step hu / 4, tile mt), lane (hu & 3, li), half lg
+            bf16_t *dst = a.xfrag + ((size_t)((hu >> 2) * MT + mt) * 64 + ((hu & 3) * 16 + li)) * 8 + 4 * lg;
+            *reinterpret_cast<uint2 *>(dst) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Down projection: h (T x I) is too long to give every workgroup all of K, so K is split over workgroups and slice s
+// writes its partial tile into plane s (plain 16-byte stores; few_row_kernel adds the planes in order).
+// grid: (ceil(nunits / 4) unit groups) x nslices, 4 waves; wave w streams unit 4 ug + w over the slice, whose activation
+// fragments are staged in LDS once.   dynamic LDS: ks_per_slice x MT KiB
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ void __launch_bounds__(256) few_d_kernel(FewArgs a) {
+    constexpr int U = 14;
+    extern __shared__ __attribute__((aligned(16))) uint4 few_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int nk = a.nk, T = a.T;
+    const int sl = (int)blockIdx.x % a.nslices, ug = (int)blockIdx.x / a.nslices;
+    const int k0 = sl * a.ks_per_slice, k1 = min(nk, k0 + a.ks_per_slice), nsteps = k1 - k0;
+    if (nsteps <= 0) return;
+    const int unit = ug * 4 + w;
+    const bool live = unit < a.nunits;
+    const bf16_t *wp = a.W + ((size_t)min(unit, a.nunits - 1) * nk + k0) * 512 + lane * 8;
+    const bf16_t *asrc = a.afrag + (size_t)k0 * MT * 512;
+    i32x4_t av[7 * MT];                                          // the default slice (28 K steps) in one batch
+    few_stage_load<4, 7 * MT>(av, asrc, nsteps * MT, w, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 ring[U][1];
+    few_ring_start<1, U, 512>(wp, 0, nsteps, ring);
+    __builtin_amdgcn_sched_barrier(0);
+    few_stage_store<4, 7 * MT>(av, asrc, few_lds, nsteps * MT, w, lane);
+    __syncthreads();
+    if (!live) return;
+    f32x4 acc[1][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[0][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    few_stream<1, MT, U, 512>(wp, 0, nsteps, few_lds + lane, ring, acc);
+    float *plane = a.part + (size_t)sl * a.T_pad * a.H;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + li;
+        if (m < T)
+            *reinterpret_cast<float4 *>(plane + (size_t)m * a.H + unit * 16 + lg * 4) =
+                make_float4(acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One workgroup per token: the row of the stream is completed here (embedding lookup, or += the down projection's
+// planes in ascending order), so its RMSNorm is too: bf16(x / rms * g) fragments for the next QKV projection.
+// norm_w == null (after the last layer): the stream only.   H <= 4096.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool EMBED, int MT>
+__global__ void __launch_bounds__(256) few_row_kernel(FewArgs a) {
+    __shared__ float red[4];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int H = a.H, nch = H / 8;                              // chunks of 8 columns; a thread owns chunks tid, tid + 256
+    float v[2][8];
+    float ss = 0.f;
+    float *xr = a.x + (size_t)t * H;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[i][q] = 0.f;
+        if (c < nch) {
+            if constexpr (EMBED) {
+                const uint4 e = *reinterpret_cast<const uint4 *>(a.table + (size_t)a.ids[t] * H + c * 8);
+                const unsigned u[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[i][2 * q] = __uint_as_float(u[q] << 16);
+                    v[i][2 * q + 1] = __uint_as_float(u[q] & 0xffff0000u);
+                }
+            } else {
+                const float4 x0 = *reinterpret_cast<const float4 *>(xr + c * 8), x1 = *reinterpret_cast<const float4 *>(xr + c * 8 + 4);
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const float *p = a.part + (size_t)t * H + c * 8;
+                const size_t plane = (size_t)a.T_pad * H;
+                for (int s0 = 0; s0 < a.nslices; s0 += 8) {       // eight planes' loads in flight, added in ascending order
+                    f32x4 q0[8], q1[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float *pp = p + (size_t)min(s0 + u, a.nslices - 1) * plane;
+                        q0[u] = *reinterpret_cast<const f32x4 *>(pp);
+                        q1[u] = *reinterpret_cast<const f32x4 *>(pp + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (s0 + u < a.nslices) {
+                            acc[0] += q0[u][0]; acc[1] += q0[u][1]; acc[2] += q0[u][2]; acc[3] += q0[u][3];
+                            acc[4] += q1[u][0]; acc[5] += q1[u][1]; acc[6] += q1[u][2]; acc[7] += q1[u][3];
+                        }
+                }
+                v[i][0] = x0.x + acc[0]; v[i][1] = x0.y + acc[1]; v[i][2] = x0.z + acc[2]; v[i][3] = x0.w + acc[3];
+                v[i][4] = x1.x + acc[4]; v[i][5] = x1.y + acc[5]; v[i][6] = x1.z + acc[6]; v[i][7] = x1.w + acc[7];
+            }
+            *reinterpret_cast<float4 *>(xr + c * 8) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+            *reinterpret_cast<float4 *>(xr + c * 8 + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ss += v[i][q] * v[i][q];
+        }
+    }
+    if (!a.norm_w) return;
+    ss = wave_sum(ss);
+    if (lane == 0) red[w] = ss;
+    __syncthreads();
+    const float inv = rsqrtf((((red[0] + red[1]) + red[2]) + red[3]) / (float)H + a.eps);
+    const int mt = t >> 4, li = t & 15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nch) {
+            const float4 g0 = *reinterpret_cast<const float4 *>(a.norm_w + c * 8), g1 = *reinterpret_cast<const float4 *>(a.norm_w + c * 8 + 4);
+            uint4 o;
+            o.x = pack2(v[i][0] * inv * g0.x, v[i][1] * inv * g0.y); o.y = pack2(v[i][2] * inv * g0.z, v[i][3] * inv * g0.w);
+            o.z = pack2(v[i][4] * inv * g1.x, v[i][5] * inv * g1.y); o.w = pack2(v[i][6] * inv * g1.z, v[i][7] * inv * g1.w);
+            // columns 8 c .. of token t -> piece (K step c / 4, tile mt), lane (c & 3, li)
+            *reinterpret_cast<uint4 *>(a.xfrag + ((size_t)((c >> 2) * MT + mt) * 64 + ((c & 3) * 16 + li)) * 8) = o;
+        }
+    }
+}
+
+}  // namespace mienc

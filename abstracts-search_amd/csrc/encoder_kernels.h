@@ -1745,6 +1745,8 @@ struct AttnArgs {
     int ldqk, ldvt, n_heads, n_kv, causal;
     float scale;
     int nwork;          // work items (64-row query blocks); the launch is 1-D and persistent: min(nwork * n_heads / HPW, 2 per CU) workgroups
+    bf16_t *Ofrag;      // non-null (the query-time path, encoder_few.h): the output goes here as B-operand fragments instead of O --
+    int frag_mt;        // piece (K step d / 32, token tile t / 16) of frag_mt tiles per step: lane ((d % 32) / 8, t % 16) holds 8 dims
 };
 
 template <int HD, int HPW = 1>
@@ -1936,13 +1938,18 @@ __global__ void __launch_bounds__(256 * HPW, 4) attn_kernel(AttnArgs a) {   // (
         const bool stores_behind = __builtin_amdgcn_ballot_w64(qidx < L) != 0;   // wave-uniform: NDT stores follow, or none
         if (qidx < L) {
             const float inv = lrow > 0.f ? 1.0f / lrow : 0.f;
-            bf16_t *op = a.O + (size_t)(cur.s0 + qidx) * (a.n_heads * HD) + cur.h * HD + 4 * lg;
+            const int tok = cur.s0 + qidx;
+            // fragments: dims h HD + 16 n + 4 lg + r -> piece (step (h HD + 16 n) / 32, tile tok / 16), lane (2 (n & 1) + lg / 2, tok % 16), half lg & 1
+            bf16_t *op = a.Ofrag ? a.Ofrag + (((size_t)(cur.h * (HD / 32)) * a.frag_mt + (tok >> 4)) * 64 + (lg >> 1) * 16 + (tok & 15)) * 8 + 4 * (lg & 1)
+                                 : a.O + (size_t)tok * (a.n_heads * HD) + cur.h * HD + 4 * lg;
+            const size_t nstride = a.Ofrag ? 0 : 16;
 #pragma unroll
             for (int n = 0; n < NDT; ++n) {
                 uint2 pk;
                 pk.x = pack2(o[n][0] * inv, o[n][1] * inv);
                 pk.y = pack2(o[n][2] * inv, o[n][3] * inv);
-                *reinterpret_cast<uint2 *>(op + n * 16) = pk;
+                const size_t foff = a.Ofrag ? ((size_t)(n >> 1) * a.frag_mt * 64 + (n & 1) * 32) * 8 : 0;
+                *reinterpret_cast<uint2 *>(op + n * nstride + foff) = pk;
             }
         }
         if (!more) break;

@@ -120,9 +120,12 @@ def test_batching_invariance(st, gold):
     a = model.encode_tokens(toks, batch_size=32, normalize_embeddings=True)     # one pass (token budget 32 768)
     model.token_budget = None                                                   # passes cut by batch_size alone
     b = model.encode_tokens(toks, batch_size=1, normalize_embeddings=True)
-    assert np.abs(a - b).max() < 2e-3
+    # (passes of <= 48 tokens take the query-time kernels of csrc/encoder_few.h, whose bf16 rounding points differ from the
+    # general path's -- 1/rms applied to the accumulator instead of the operand, f32 RoPE: two bf16 computations of the same
+    # embedding, each within the 1e-3 cosine budget of the fp32 oracle, agree to ~3e-3 per component on this 64-d model)
+    assert np.abs(a - b).max() < 4e-3 and ((a * b).sum(1)).min() > 1 - 1e-4
     c = model.encode_tokens(toks[::-1], batch_size=2, normalize_embeddings=True)[::-1]
-    assert np.abs(a - c).max() < 2e-3
+    assert np.abs(a - c).max() < 4e-3 and ((a * c).sum(1)).min() > 1 - 1e-4
     # passes cut by a token budget: a few sequences each, never an empty pass, every sequence exactly once
     model.token_budget = 40
     order = sorted(range(len(toks)), key=lambda i: -len(toks[i]))
@@ -130,7 +133,7 @@ def test_batching_invariance(st, gold):
     assert sorted(i for p in passes for i in p) == list(range(len(toks))) and len(passes) > 1 and all(passes)
     assert all(sum(len(toks[i]) for i in p) <= 40 or len(p) == 1 for p in passes)
     e = model.encode_tokens(toks, batch_size=32, normalize_embeddings=True)
-    assert np.abs(a - e).max() < 2e-3
+    assert np.abs(a - e).max() < 4e-3
 
 
 def test_errors(st):
@@ -294,6 +297,37 @@ def test_query_batches_at_stella_widths_vs_oracle(st, nq, layers):
         ref = E.encode(E.EncoderConfig(**cfg), Wc, np.concatenate(toks), np.concatenate([[0], np.cumsum(lens)]), True).numpy()
     cos = (e * ref).sum(1)
     assert cos.min() > 1 - 1e-3, (nq, cos.min())
+
+
+@pytest.mark.parametrize("lens", [[1], [3], [16], [17], [32], [33], [48], [5, 9, 20], [1] * 7, [16, 16, 16], [2, 46]])
+def test_few_token_path_at_stella_widths_vs_oracle(st, lens):
+    """The query-time path (csrc/encoder_few.h: RMSNorm in the GEMM prologue, RoPE / SwiGLU / residual atomics in the
+    epilogues, weights as 1-KiB pieces) for every token-tile count it serves (1..48 tokens = 1, 2 or 3 tiles of 16, the
+    tile edges, several sequences in one pass) at stella's widths, 3 layers deep: last hidden state per token and the
+    embedding against the fp32 oracle.  (reference README.md:28: one prompted query per call.)"""
+    import torch
+    from oracle import encoder_oracle as E
+    cfg = dict(st.STELLA_EN_1_5B_V5)
+    cfg["vocab_size"], cfg["n_layers"] = 4096, 3
+    W = _rand_weights_gpu(cfg, 77)
+    rng = np.random.default_rng(sum(lens) * 31 + len(lens))
+    toks = [rng.integers(0, cfg["vocab_size"], int(L)).tolist() for L in lens]
+    model = st.SentenceTransformer(config=cfg, weights=W)
+    before = st.debug_counter("few_passes")
+    hs = model.last_hidden_state(toks)
+    e = model.encode_tokens(toks, batch_size=len(lens), normalize_embeddings=True)
+    assert st.debug_counter("few_passes") - before == 2
+    Wc = {k: v.float().cpu() for k, v in W.items()}
+    ids, cu = np.concatenate(toks), np.concatenate([[0], np.cumsum(lens)])
+    with torch.no_grad():
+        ref_h = E.stack_forward(E.EncoderConfig(**cfg), Wc, ids, cu).numpy()
+        ref_e = E.encode(E.EncoderConfig(**cfg), Wc, ids, cu, True).numpy()
+    assert hs.shape == ref_h.shape and np.isfinite(hs).all()
+    cos = (hs * ref_h).sum(1) / (np.linalg.norm(hs, axis=1) * np.linalg.norm(ref_h, axis=1))
+    assert cos.min() > 1 - 1e-3, (cos.min(), int(cos.argmin()))
+    rel = np.linalg.norm(hs - ref_h, axis=1) / np.linalg.norm(ref_h, axis=1)
+    assert rel.max() < 3e-2, rel.max()
+    assert ((e * ref_e).sum(1)).min() > 1 - 1e-3
 
 
 @pytest.mark.parametrize("tile", ["big", "slab8", "slab4", "big32", "mid", "mid64", "small", "tiny", "128"])
