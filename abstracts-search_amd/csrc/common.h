@@ -9,8 +9,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
+#include <utility>
 
 namespace mi {
 
@@ -137,6 +140,20 @@ struct Range {
     Range(const Range &) = delete;
     Range &operator=(const Range &) = delete;
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device): several host threads may launch through one
+// handle, and a second device's first launch needs the attribute as much as the first one's (a plain `static bool` was
+// both a data race and process-wide).
+inline void set_max_dynamic_lds(const void *fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    MI_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({fn, dev})) return;
+    MI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({fn, dev});
+}
 
 struct DeviceGuard {
     int prev = 0;

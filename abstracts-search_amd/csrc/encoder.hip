@@ -263,12 +263,7 @@ void launch_ring_narrow(int epi, GemmArgs g, hipStream_t st) {
 // skinny GEMM (M <= 32, fragment-major weights): W streamed global -> registers, A slice in LDS
 template <int EPI, int WN>
 void launch_skinny_e(GemmArgs g, int wpb, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_skinny_kernel<EPI, WN>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
+    set_max_dynamic_lds(reinterpret_cast<const void *>(&gemm_bf16_skinny_kernel<EPI, WN>), 128 * 1024);
     // K slices: as few as the LDS-resident A slice allows, more (residual epilogue only) when
     // the N dimension alone does not give every CU a wave
     const int waves_n = (g.N + WN * 16 - 1) / (WN * 16);
@@ -1246,19 +1241,25 @@ int mi_encoder_profile_read(mi_encoder *h, double *gemm_ms, double *gemm_flops) 
     return guard([&] {
         MI_REQUIRE(h, "null argument");
         DeviceGuard dg(h->device);
-        std::lock_guard<std::mutex> hl(h->mu);
-        MI_REQUIRE(!h->prof_launches.empty(), "mi_encoder_profile_read: no encode has run with profiling on");
-        hipStream_t st = h->prof_stream;
+        std::vector<mi_encoder::Launch> launches;
+        hipStream_t st = nullptr;
+        {
+            std::lock_guard<std::mutex> hl(h->mu);
+            MI_REQUIRE(!h->prof_launches.empty(), "mi_encoder_profile_read: no encode has run with profiling on");
+            launches = h->prof_launches;
+            st = h->prof_stream;
+        }
+        EncLease lease = lease_ws(h, st);                // the replay writes that stream's workspaces: no encode on it meanwhile
         // the launches of that encode again, back to back on its stream (its workspaces are still in place; the residual
         // GEMMs add into the stream once more, which nobody reads afterwards): one warm pass, then `reps` timed ones
         const int reps = 3;
         hipEvent_t e0, e1;
         MI_HIP(hipEventCreate(&e0));
         MI_HIP(hipEventCreate(&e1));
-        for (auto &l : h->prof_launches) launch_gemm(l.epi, l.g, st);
+        for (auto &l : launches) launch_gemm(l.epi, l.g, st);
         MI_HIP(hipEventRecord(e0, st));
         for (int r = 0; r < reps; ++r)
-            for (auto &l : h->prof_launches) launch_gemm(l.epi, l.g, st);
+            for (auto &l : launches) launch_gemm(l.epi, l.g, st);
         MI_HIP(hipEventRecord(e1, st));
         MI_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -1266,6 +1267,7 @@ int mi_encoder_profile_read(mi_encoder *h, double *gemm_ms, double *gemm_flops) 
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         if (gemm_ms) *gemm_ms = (double)ms / reps;
+        std::lock_guard<std::mutex> hl(h->mu);
         if (gemm_flops) *gemm_flops = h->prof_flops;
         h->prof_launches.clear();
         h->prof_flops = 0.0;

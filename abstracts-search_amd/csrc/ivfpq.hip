@@ -343,12 +343,7 @@ template <int M, int NW, bool ALL>
 void launch_scan_mw(const ScanArgs &a, hipStream_t st) {
     const size_t smem = scan_smem_bytes(M, a.nprobe, NW);
     MI_REQUIRE(smem <= 160 * 1024, "nprobe too large for the LDS probe tables");
-    static bool attr_set = false;
-    if (!attr_set) {
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<M, NW, ALL>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    set_max_dynamic_lds(reinterpret_cast<const void *>(&scan_kernel<M, NW, ALL>), 160 * 1024);
     hipLaunchKernelGGL((scan_kernel<M, NW, ALL>), dim3(scan_grid(a.nq, a.nslice)), dim3(NW * 64), smem,
                        st, a);
     MI_HIP(hipGetLastError());
@@ -357,12 +352,7 @@ template <int M, bool ALL>
 void launch_scan_l2(const ScanArgs &a, hipStream_t st) {
     const size_t smem = scan_smem_bytes(M, a.nprobe, 8);
     MI_REQUIRE(smem <= 160 * 1024, "nprobe too large for the LDS probe tables");
-    static bool attr_set = false;
-    if (!attr_set) {
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<M, 8, ALL, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    set_max_dynamic_lds(reinterpret_cast<const void *>(&scan_kernel<M, 8, ALL, true>), 160 * 1024);
     hipLaunchKernelGGL((scan_kernel<M, 8, ALL, true>), dim3(scan_grid(a.nq, a.nslice)), dim3(8 * 64), smem, st, a);
     MI_HIP(hipGetLastError());
 }
@@ -432,7 +422,9 @@ void launch_merge(const float *ps, const int64_t *pid, int nparts, int64_t strid
     // the counting tiers rank every candidate against every other one -- (nparts k)^2 / 64 steps per lane: a re-rank of 5 120
     // candidates took 0.77 ms of a 4.6 ms step there -- so long candidate lists go to the selection tier (linear in nparts k)
     static const int64_t big_from = std::getenv("MI_MERGE_SELECT_FROM") ? std::atoll(std::getenv("MI_MERGE_SELECT_FROM")) : 2048;
-    const bool by_selection = !bs && !bid && (int64_t)nparts * k >= big_from && k <= SELB_CAP;
+    // (only for callers that bring a kept scratch buffer: without one the tier would hipMalloc + synchronise + hipFree on every
+    // call -- a single query's cross-slice merge must stay enqueue-only)
+    const bool by_selection = scratch && !bs && !bid && (int64_t)nparts * k >= big_from && k <= SELB_CAP;
     if (per_wave <= 64 * 1024 && !by_selection) {
         int qpb = (int)std::min<size_t>(4, (64 * 1024) / per_wave);   // queries (waves) per workgroup
         if (qpb == 3) qpb = 2;
@@ -443,12 +435,7 @@ void launch_merge(const float *ps, const int64_t *pid, int nparts, int64_t strid
         return;
     }
     if (per_wave <= 160 * 1024 && !by_selection) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        set_max_dynamic_lds(reinterpret_cast<const void *>(&merge_kernel), 160 * 1024);
         hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(64), per_wave, st, ps, pid, nparts, stride_p,
                            stride_p_id, stride_q, nq, k, D, I, ldo, out_off, bs, bid, im);
         MI_HIP(hipGetLastError());
@@ -1515,6 +1502,25 @@ int mi_index_search_preassigned(mi_index *h, int64_t nq, const float *q, int k, 
     });
 }
 
+namespace {
+// Scratch rows of the merge's selection tier for the two handle-less entry points, one buffer per (device, stream) of the
+// calling thread: a host thread that round-robins several streams (the documented serving pattern) has merges in flight
+// on all of them, and a buffer shared between streams -- or left on the first device the thread used -- would be written
+// by two launches at once.  Never shrinks; at most 64 pairs per thread (the oldest entry is recycled after a device sync).
+DevBuf *merge_scratch(int device, void *stream) {
+    struct Slot { int device; void *stream; std::unique_ptr<DevBuf> buf; };
+    static thread_local std::vector<Slot> slots;
+    for (auto &sl : slots)
+        if (sl.device == device && sl.stream == stream) return sl.buf.get();
+    if (slots.size() >= 64) {
+        (void)hipDeviceSynchronize();
+        slots.erase(slots.begin());
+    }
+    slots.push_back(Slot{device, stream, std::make_unique<DevBuf>()});
+    return slots.back().buf.get();
+}
+}  // namespace
+
 int mi_merge_topk(int device, int nparts, int64_t nq, int k, const float *D_parts,
                   const int64_t *I_parts, float *D, int64_t *I, void *stream) {
     return guard([&] {
@@ -1526,8 +1532,8 @@ int mi_merge_topk(int device, int nparts, int64_t nq, int k, const float *D_part
         const bool all_dev = is_device_ptr(D_parts) && is_device_ptr(I_parts) && is_device_ptr(D) && is_device_ptr(I);
         const size_t n_in = (size_t)nparts * nq * k, n_out = (size_t)nq * k;
         if (all_dev) {
-            static thread_local DevBuf scratch;   // the selection tier's rows (long lists): kept, so the call only enqueues
-            launch_merge(D_parts, I_parts, nparts, nq * k, k, nq, k, D, I, k, 0, nullptr, nullptr, st, -1, IdMap{}, &scratch);
+            // the selection tier's rows (long lists): kept per (device, stream), so the call only enqueues
+            launch_merge(D_parts, I_parts, nparts, nq * k, k, nq, k, D, I, k, 0, nullptr, nullptr, st, -1, IdMap{}, merge_scratch(device, stream));
             return;
         }
         MI_REQUIRE(!is_device_ptr(D_parts) && !is_device_ptr(I_parts) && !is_device_ptr(D) && !is_device_ptr(I),
@@ -1558,10 +1564,9 @@ int mi_merge_topk_gathered(int device, int nparts, int64_t nq, int k, const void
         const char *base = static_cast<const char *>(gathered);
         IdMap im;
         im.mul = id_mul; im.add = id_add; im.step = id_step;
-        static thread_local DevBuf scratch;   // only the > 160 KiB tier uses it
         launch_merge(reinterpret_cast<const float *>(base) + (size_t)q_lo * k,
                      reinterpret_cast<const int64_t *>(base + d_bytes) + (size_t)q_lo * k, nparts, blk_bytes / 4, k, nq_out, k,
-                     D, I, k, 0, nullptr, nullptr, as_stream(stream), blk_bytes / 8, im, &scratch);
+                     D, I, k, 0, nullptr, nullptr, as_stream(stream), blk_bytes / 8, im, merge_scratch(device, stream));   // (the selection tier and the > 160 KiB tier use it)
     });
 }
 

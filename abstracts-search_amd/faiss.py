@@ -763,9 +763,9 @@ class IndexRefine:
         return self.base_index.is_trained and self.refine_index.is_trained
 
     def train(self, x):
-        """faiss IndexRefine::train: both indexes see the training set."""
-        if not self.base_index.is_trained:
-            self.base_index.train(x)
+        """faiss IndexRefine::train: both indexes see the training set, always (an IVF-PQ base retrains its codebooks
+        on a new sample exactly like faiss's, whose IndexRefine::train calls base_index->train unconditionally)."""
+        self.base_index.train(x)
         self.refine_index.train(x)
 
     def add(self, x):

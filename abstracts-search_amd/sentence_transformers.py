@@ -94,7 +94,9 @@ def _cfg_from_hf(hf: dict) -> dict:
                 n_heads=nh, n_kv_heads=int(hf.get("num_key_value_heads", nh)),
                 head_dim=int(hf.get("head_dim") or hidden // nh), intermediate=int(hf["intermediate_size"]),
                 rms_eps=float(hf.get("rms_norm_eps", 1e-6)), rope_theta=float(hf.get("rope_theta", 1e6)),
-                causal=bool(hf.get("is_causal", False)), dense_out=0, dense_bias=True,
+                # `is_causal` is the key of the gte-Qwen2 / stella remote code (false there: bidirectional attention); a plain
+                # Qwen2 config.json has no such key and IS causal
+                causal=bool(hf.get("is_causal", True)), dense_out=0, dense_bias=True,
                 max_seq_len=int(hf.get("max_position_embeddings", 512)))
 
 
@@ -166,12 +168,10 @@ class SentenceTransformer:
             s = str(device)
             self._device_index = int(s.split(":")[1]) if ":" in s else 0
         cfg = dict(config) if config is not None else None
+        if model_name_or_path is not None and not os.path.isdir(model_name_or_path) and cfg is None:
+            model_name_or_path = self._resolve_hub_id(model_name_or_path, _ignored)
         if model_name_or_path is not None and os.path.isdir(model_name_or_path):
             cfg, weights = self._read_model_dir(model_name_or_path, cfg, weights)
-        elif model_name_or_path is not None and cfg is None:
-            raise FileNotFoundError(
-                f"{model_name_or_path!r} is not a local model directory (no network / hub access on this path); "
-                "pass a directory, or config= and weights=")
         if cfg is None:
             raise ValueError("SentenceTransformer: need a model directory or config=")
         if hasattr(cfg, "to_dict"):
@@ -194,6 +194,34 @@ class SentenceTransformer:
                 pass
 
     # -- loading -------------------------------------------------------
+    @staticmethod
+    def _resolve_hub_id(name: str, kw: dict) -> str:
+        """A Hugging Face hub id the way the reference names its model (README.md:28
+        MODEL_NAME="NovaSearch/stella_en_1.5B_v5", README.md:60 SIDECARSEARCH_MODEL=...) -> the snapshot directory:
+        the local hub cache first (HF_HOME / HF_HUB_CACHE / cache_folder=, exactly sentence-transformers' lookup),
+        then the network unless HF_HUB_OFFLINE is set.  No silent fallback: a model that cannot be found is an error
+        that says where it was looked for."""
+        try:
+            from huggingface_hub import snapshot_download
+        except ImportError as e:                                           # pragma: no cover
+            raise FileNotFoundError(f"{name!r} is not a local model directory and huggingface_hub is not installed") from e
+        common = dict(repo_id=name, cache_dir=kw.get("cache_folder"), revision=kw.get("revision"),
+                      token=kw.get("token", kw.get("use_auth_token")))
+        try:
+            return snapshot_download(local_files_only=True, **common)
+        except Exception as local_err:
+            if os.environ.get("HF_HUB_OFFLINE", "").strip() not in ("", "0") or kw.get("local_files_only"):
+                raise FileNotFoundError(
+                    f"{name!r} is neither a local model directory nor in the Hugging Face cache "
+                    f"(HF_HOME={os.environ.get('HF_HOME', '~/.cache/huggingface')}, cache_folder={kw.get('cache_folder')}) "
+                    f"and the hub is offline: {local_err}") from local_err
+            try:
+                return snapshot_download(**common)
+            except Exception as net_err:
+                raise FileNotFoundError(
+                    f"{name!r} is neither a local model directory nor in the Hugging Face cache, and the download "
+                    f"failed: {net_err}") from net_err
+
     def _read_model_dir(self, path, cfg, weights):
         from safetensors import safe_open
         with open(os.path.join(path, "config.json")) as f:
@@ -271,11 +299,15 @@ class SentenceTransformer:
         return self._host_tok(texts, self.max_seq_length)
 
     def encode(self, sentences, prompt_name: str | None = None, prompt: str | None = None,
-               batch_size: int = 32, show_progress_bar=None, output_value: str = "sentence_embedding",
+               batch_size: int | None = None, show_progress_bar=None, output_value: str | None = "sentence_embedding",
                precision: str = "float32", convert_to_numpy: bool = True, convert_to_tensor: bool = False,
                device=None, normalize_embeddings: bool = False, **_ignored):
-        if output_value != "sentence_embedding" or precision != "float32":
-            raise NotImplementedError("only sentence embeddings in float32 are implemented")
+        """batch_size: sentence-transformers' default is 32; here None (the default) leaves the size of a forward pass to
+        `token_budget`, and a value the caller PASSES bounds a pass from above (at most that many sequences, and at most
+        token_budget tokens) -- `sidecar-search build -b 32` (reference Makefile:65) therefore means 32, as it says."""
+        if output_value not in (None, "sentence_embedding") or precision != "float32":
+            raise NotImplementedError("only sentence embeddings in float32 are implemented "
+                                      f"(output_value={output_value!r}, precision={precision!r})")
         single = isinstance(sentences, str)
         if single:
             sentences = [sentences]
@@ -296,22 +328,24 @@ class SentenceTransformer:
         return emb
 
     # Tokens one forward pass takes: 32 768 = 128 row tiles of 256, with which every GEMM of the stack fills whole
-    # rounds of the 256 CUs (N = 1536: 768 tiles = 3.0 rounds, 2048: 4.0, 17 920: 35.0).  While it is set,
-    # `batch_size` is IGNORED: sentence-transformers' batch_size (32 by default, `-b 32` in the reference's
-    # Makefile:65) is a memory knob of its hardware, and the token budget is the memory bound here (activations of
-    # 32 768 tokens are ~1.2 GB).  Embeddings do not depend on which sequences share a pass beyond f32 summation
-    # order (tests: batching invariance).  `token_budget = None` restores sentence-transformers' behaviour: passes
-    # of exactly `batch_size` length-sorted sequences -- the latency / memory knob for callers who want it.
+    # rounds of the 256 CUs (N = 1536: 768 tiles = 3.0 rounds, 2048: 4.0, 17 920: 35.0).  sentence-transformers'
+    # batch_size (32 by default) is a memory knob of its hardware; the token budget is the memory bound here
+    # (activations of 32 768 tokens are ~1.2 GB).  A batch_size the caller passes explicitly still bounds a pass from
+    # above (`-b 32` in the reference's Makefile:65 means 32); encode()'s default (None) leaves it to the budget.
+    # Embeddings do not depend on which sequences share a pass beyond bf16 / f32 rounding order (tests: batching
+    # invariance).  `token_budget = None`: passes of exactly `batch_size` length-sorted sequences.
     token_budget = 32768
 
     def _passes(self, order, token_lists, batch_size):
-        """the sorted sequence indices cut into forward passes"""
+        """the sorted sequence indices cut into forward passes: at most `batch_size` sequences (None: no bound) and
+        at most `token_budget` tokens (None: no bound) each, never empty"""
         if not self.token_budget:
-            return [order[b0:b0 + batch_size] for b0 in range(0, len(order), batch_size)]
+            bs = batch_size or 32
+            return [order[b0:b0 + bs] for b0 in range(0, len(order), bs)]
         passes, cur, tok = [], [], 0
         for i in order:
             t = len(token_lists[i])                               # sequences are packed back to back
-            if cur and tok + t > self.token_budget:
+            if cur and (tok + t > self.token_budget or (batch_size and len(cur) >= batch_size)):
                 passes.append(cur)
                 cur, tok = [], 0
             cur.append(i)
@@ -320,13 +354,12 @@ class SentenceTransformer:
             passes.append(cur)
         return passes
 
-    def encode_tokens(self, token_lists, batch_size: int = 32, normalize_embeddings: bool = False,
+    def encode_tokens(self, token_lists, batch_size: int | None = None, normalize_embeddings: bool = False,
                       as_tensor: bool = False):
         """list of token-id lists -> float32 [n, dim].  Like sentence-transformers,
         inputs are sorted by length (longest first) before batching and the
-        result is put back in input order; a batch is packed, not padded, and sized by
-        `token_budget` (see above) rather than by a sequence count: `batch_size` only takes
-        effect when `token_budget` is None."""
+        result is put back in input order; a batch is packed, not padded, and holds at most
+        `token_budget` tokens (see above) and at most `batch_size` sequences (None: no bound)."""
         import itertools
         import torch
         n = len(token_lists)
