@@ -2347,6 +2347,32 @@ int mi_flat_reconstruct_n(mi_flat *h, int64_t i0, int64_t n, float *out) {
     });
 }
 
+int mi_flat_get_rows(mi_flat *h, int64_t n, const int64_t *ids, void *out) {
+    return guard([&] {
+        MI_REQUIRE(h && (n == 0 || (ids && out)), "null argument");
+        if (n == 0) return;
+        DeviceGuard dg(h->device);
+        const size_t row = (size_t)h->da * h->elem;                     // bytes per stored row
+        std::vector<int64_t> hid;
+        const int64_t *hi = ids;
+        if (is_device_ptr(ids)) {
+            hid.resize((size_t)n);
+            MI_HIP(hipMemcpy(hid.data(), ids, (size_t)n * 8, hipMemcpyDeviceToHost));
+            hi = hid.data();
+        }
+        for (int64_t i = 0; i < n; ++i) MI_REQUIRE(hi[i] >= 0 && hi[i] < h->ntotal, "mi_flat_get_rows: id out of range");
+        // the test / parity hook of the stores (no kernel: n row copies grouped into runs of consecutive ids)
+        const char *base = h->base.get<char>();
+        char *dst = static_cast<char *>(out);
+        for (int64_t i = 0; i < n;) {
+            int64_t j = i + 1;
+            while (j < n && hi[j] == hi[j - 1] + 1) ++j;
+            MI_HIP(hipMemcpy(dst + (size_t)i * row, base + (size_t)hi[i] * row, (size_t)(j - i) * row, hipMemcpyDefault));
+            i = j;
+        }
+    });
+}
+
 int mi_flat_ntotal(mi_flat *h, int64_t *out) {
     return guard([&] {
         MI_REQUIRE(h && out, "null argument");

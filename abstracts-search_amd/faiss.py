@@ -96,6 +96,7 @@ class _Lib:
                 "mi_flat_reserve": [v, c_int64],
                 "mi_flat_ntotal": [v, POINTER(c_int64)],
                 "mi_flat_reconstruct_n": [v, c_int64, c_int64, v],
+                "mi_flat_get_rows": [v, c_int64, v, v],
                 "mi_flat_reset": [v],
                 "mi_flat_search": [v, c_int64, v, c_int, v, v, v],
                 "mi_flat_rerank": [v, c_int64, v, c_int, v, c_int, v, v, v],
@@ -214,6 +215,18 @@ class IndexFlatIP:
         ni = self.ntotal - i0 if ni < 0 else ni
         out = np.empty((ni, self.d), np.float32)
         _check(_Lib.get().mi_flat_reconstruct_n(self._h, int(i0), int(ni), _ptr(out)))
+        return out
+
+    def get_rows(self, ids) -> np.ndarray:
+        """The stored bytes of the rows `ids`, uint8 [len(ids), row_bytes]: d float32 (IndexFlat), d IEEE halves
+        (QT_fp16) or d codes (QT_8bit) per row -- what faiss exposes as IndexFlatCodes.codes; the hook that hands a
+        sample of a store too large to export to the oracle."""
+        ids = np.ascontiguousarray(ids.cpu().numpy() if _is_torch(ids) else ids, np.int64).ravel()
+        qt = getattr(self, "qtype", None)
+        elem = 1 if qt == ScalarQuantizer.QT_8bit else 2 if qt == ScalarQuantizer.QT_fp16 else 4
+        width = self.d + (4 if getattr(self, "metric_type", METRIC_INNER_PRODUCT) == METRIC_L2 else 0)
+        out = np.empty((ids.shape[0], width * elem), np.uint8)
+        _check(_Lib.get().mi_flat_get_rows(self._h, ids.shape[0], _ptr(ids), _ptr(out)))
         return out
 
     def reconstruct(self, i: int) -> np.ndarray:

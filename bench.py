@@ -207,12 +207,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-refine-point", action="store_true", help="cfg4: skip the recall >= 0.95 operating point")
-    ap.add_argument("--no-encode", action="store_true", help="cfg4: skip the encode half of the metric")
+    ap.add_argument("--no-encode", action="store_true", help="cfg4: skip the encode half of the metric (and the cfg5 curve)")
+    ap.add_argument("--no-cfg5", action="store_true", help="cfg4: skip the end-to-end query curve (BASELINE.json configs[4])")
     ap.add_argument("--refine-store", choices=["auto", "f32", "f16", "sq8"], default="auto",
                     help="cfg4 refine stage: f32 = IndexRefineFlat over the raw vectors (faiss ',RFlat'); f16 = "
                          "',Refine(SQfp16)': IEEE-half store, half the HBM and half the bytes per re-ranked candidate; sq8 = "
                          "',Refine(SQ8)': one byte per component with per-dimension ranges -- all 207 M rows (212 GB) beside "
-                         "the index on ONE GPU; auto (default): f16 when this rank's whole shard fits its HBM, else sq8")
+                         "the index on ONE GPU; auto (default) = sq8 at EVERY N: the one store that holds the whole corpus on one "
+                         "GPU, so that the points of a 1 -> 8 GPU curve are the same index (the line records the store)")
     ap.add_argument("--encode-batch", type=int, default=128,
                     help="abstracts per encode step (default 128); 0 = the library's own batching: as many abstracts as fit "
                          "32 768 padded tokens per forward pass (~135; +1 % tokens/s: every GEMM fills whole rounds of the CUs)")
@@ -347,6 +349,8 @@ def cfg4_workload(args, ctx):
         g = torch.Generator(device=dev).manual_seed(977 + rank)
         qpool = qpool[torch.randperm(NB, generator=g, device=dev)].contiguous()
     q_gt = qpool[0].contiguous()                                       # recall is measured on this batch
+    q_sel = qpool[1].contiguous()                                      # held out: the recall >= 0.95 point's (nprobe, k_factor) is chosen on this one
+    q_gt2 = torch.cat([q_gt, q_sel])                                   # exact top-k is kept for both
 
     # ---- the refine stage's raw vectors (recall >= 0.95 operating point, IndexRefineFlat): the
     # shard's own rows when they fit beside the index, else the 1/8 sub-shard a GPU of the
@@ -365,8 +369,8 @@ def cfg4_workload(args, ctx):
     # without room for the whole shard the point falls back to the 1/8 sub-shard layout)
     room = hbm_free - per_rank * 152 - 25e9
     store = args.refine_store
-    if store == "auto":
-        store = "f16" if per_rank * d * 2 <= room else "sq8"
+    if store == "auto":                                                # the same index at every N (a curve compares like with like)
+        store = "sq8"
     relem = {"f32": 4, "f16": 2, "sq8": 1}[store]
     refine_own = want_refine and per_rank * d * relem <= room
     if os.environ.get("BENCH_FORCE_SUBSHARD"):                         # rehearsals: the sub-shard layout on a small corpus
@@ -408,13 +412,13 @@ def cfg4_workload(args, ctx):
     neg = -torch.finfo(torch.float32).max
 
     def empty_gt():
-        return (torch.full((batch, k), neg, dtype=torch.float32, device=dev),
-                torch.full((batch, k), -1, dtype=torch.int64, device=dev))
+        return (torch.full((2 * batch, k), neg, dtype=torch.float32, device=dev),
+                torch.full((2 * batch, k), -1, dtype=torch.int64, device=dev))
 
     def fold(run, rows, gid_of):
         flat_gt.reset()
         flat_gt.add(rows)
-        Dg, Ig = flat_gt.search(q_gt, k)
+        Dg, Ig = flat_gt.search(q_gt2, k)
         Ig = torch.where(Ig < 0, Ig, gid_of(Ig))
         return faiss.merge_topk(torch.stack([run[0], Dg]), torch.stack([run[1], Ig]))
 
@@ -443,8 +447,8 @@ def cfg4_workload(args, ctx):
     del flat_gt
     torch.cuda.empty_cache()                                           # the chunk buffers: the scan image needs the room at N = 1
     if want_gt and use_shards and world > 1:                           # exact top-k over all shards
-        Dall = torch.empty((world, batch, k), dtype=torch.float32, device=dev)
-        Iall = torch.empty((world, batch, k), dtype=torch.int64, device=dev)
+        Dall = torch.empty((world, 2 * batch, k), dtype=torch.float32, device=dev)
+        Iall = torch.empty((world, 2 * batch, k), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(Dall.view(-1, k), gt[0].contiguous())
         dist.all_gather_into_tensor(Iall.view(-1, k), gt[1].contiguous())
         gt = faiss.merge_topk(Dall, Iall)
@@ -510,7 +514,7 @@ def cfg4_workload(args, ctx):
             _, Ia = index.search(q_gt, k)
         else:
             _, Ia = sharded.search_replicated(q_gt, k)
-        recall = recall_at_k(Ia, gt[1])
+        recall = recall_at_k(Ia, gt[1][:batch])
 
     # ---- roofline of the dominant kernel (PQ-code scan): the library re-launches the scan of
     # the last step back to back between two HIP events recorded on the launch stream
@@ -535,8 +539,8 @@ def cfg4_workload(args, ctx):
     # ---- recall >= 0.95 operating point: IVF-PQ proposes k * k_factor candidates, exact re-ranking
     at095 = None
     if want_refine:
-        at095 = refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own, nsh, my_q, q_gt,
-                             gt if refine_own else gt_sub, batch, k, steps, warmup, settle)
+        at095 = refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own, nsh, my_q, q_gt, q_sel,
+                             gt if refine_own else gt_sub, batch, k, steps, warmup, settle, store)
 
     census = rank_census(torch, dist, world, dev, index.ntotal)
 
@@ -575,11 +579,24 @@ def cfg4_workload(args, ctx):
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
             "at_recall_095": at095, "reference_oracles": reference_oracles(),
         }
+    # ---- BASELINE.json configs[4] in the same line: encode + search at query batches 1 / 16 / 256 over THIS index (before it
+    # is freed); the model is the one the encode half below times
+    pack = None
+    if not args.no_encode:
+        do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+        host_w = {} if do_cpu else None
+        model, mcfg = stella_random_model(args, ctx, keep=host_w)
+        pack = (model, mcfg, host_w)
+        if not args.no_cfg5 and not replicas:
+            c5 = cfg5_curve(args, ctx, model, mcfg, host_w, index, sharded, nprobe, k, 20, 3, do_cpu)
+            if out is not None:
+                out["cfg5"] = dict(c5, workload="cfg5: end-to-end encode + search over the cfg4 index above, query batches 1 / 16 / 256 "
+                                                "(BASELINE.json configs[4]); latency of one call, throughput of back-to-back calls")
     # ---- the other half of the metric: embed abstracts/sec (cfg3), in the same line
     del sharded, index, sub, flat_r
     torch.cuda.empty_cache()
     if not args.no_encode:
-        enc = encode_workload(args, ctx, args.encode_steps, 2, with_cpu=not args.no_cpu_baseline)
+        enc = encode_workload(args, ctx, args.encode_steps, 2, with_cpu=not args.no_cpu_baseline, pack=pack)
         if out is not None and enc is not None:
             out["encode"] = {"abstracts_per_s": enc["value"], "tokens_per_s": enc["config"]["tokens_per_sec"],
                              "ms_per_step": enc["ms_per_step"], "steps": enc["steps"], "batch": enc["config"]["batch"],
@@ -589,12 +606,13 @@ def cfg4_workload(args, ctx):
     return out
 
 
-def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own, nsh, my_q, q_gt, gt, batch, k,
-                 steps, warmup, settle):
-    """Smallest-cost (nprobe, k_factor_rf) from a short ascending list that reaches recall@10 >= 0.95,
-    timed with the same loop.  refine_own: the job's real layout (every rank re-ranks its own shard,
-    one exchange of the exact lists); otherwise the 1/8 sub-shard one GPU of the 8-GPU job holds."""
-    torch, dist, world, rank, dev, clock = ctx["torch"], ctx["dist"], ctx["world"], ctx["rank"], ctx["dev"], ctx["clock"]
+def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own, nsh, my_q, q_gt, q_sel, gt, batch, k,
+                 steps, warmup, settle, store_name):
+    """Smallest-cost (nprobe, k_factor_rf) from a short ascending list that reaches recall@10 >= 0.95 ON A HELD-OUT
+    QUERY BATCH (q_sel; its exact top-k are rows [batch, 2 batch) of gt), timed with the same loop; the recall the line
+    reports is then measured on q_gt, which took no part in the choice.  refine_own: the job's real layout (every rank
+    re-ranks its own shard, one exchange of the exact lists); otherwise the 1/8 sub-shard one GPU of the 8-GPU job holds."""
+    np, torch, dist, world, rank, dev, clock = ctx["np"], ctx["torch"], ctx["dist"], ctx["world"], ctx["rank"], ctx["dev"], ctx["clock"]
     base = index if refine_own else sub
     args_nprobe = index.nprobe                                         # restored below
     ref = faiss.IndexRefine(base, flat_r)
@@ -609,10 +627,13 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     kfs = [f for f in (64, 72, 80, 100, 128, 160, 200, 256, 320, 400, 512, 640, 800) if k * f <= 8192]
     best, curve, i_kf, done = None, [], 0, False
 
+    def recall_on(qs, rows):
+        _, Ia = (sharded.search_replicated(qs, k) if sharded is not None else ref.search(qs, k))
+        return recall_at_k(Ia, gt[1][rows])
+
     def evaluate(nprobe, kf):
         base.nprobe, ref.k_factor = nprobe, kf
-        _, Ia = (sharded.search_replicated(q_gt, k) if sharded is not None else ref.search(q_gt, k))
-        r = recall_at_k(Ia, gt[1])
+        r = recall_on(q_sel, slice(batch, 2 * batch))
         if world > 1 and not refine_own:                               # sub-shards differ per rank: agree on the worst
             t = torch.tensor([r], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -638,7 +659,14 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
             i_kf += 1
         if done:
             break
-    nprobe, kf, r = best
+    nprobe, kf, r_sel = best
+    base.nprobe, ref.k_factor = nprobe, kf
+    r = recall_on(q_gt, slice(0, batch))                               # the reported recall: a batch the choice never saw
+    if world > 1 and not refine_own:
+        t = torch.tensor([r], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        r = float(t.item())
+    log(f"  refine point chosen on the held-out batch: nprobe={nprobe} k_factor_rf={kf} (recall {r_sel:.4f} there); reported batch: {r:.4f}")
     kb = k * kf
     # batches are independent: like the main line, the unsharded loop issues them round-robin on 2 streams (the library
     # keeps a workspace set per stream) -- the HBM-bound re-rank of one batch overlaps the MFMA-bound coarse stage of the next
@@ -665,6 +693,70 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
 
     settle(step, args.settle_ms)
     dt, blocks, _ = clock.measure(step, steps, warmup)
+
+    # ---- roofline of the step's dominant kernel (the streaming re-rank: HBM-bound) and the step's split: each stage alone,
+    # back to back on one launch stream between two HIP events recorded on that stream
+    def stage_ms(fn, reps=10):
+        with torch.cuda.stream(rstreams[0]):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    qs0 = my_q[0]
+    have_cand = hasattr(base, "search_candidates_into")
+    roofline = None
+    if have_cand:
+        ms_cand = stage_ms(lambda: base.search_candidates_into(qs0, kb, cI[0], None, rptr[0]))
+        ms_rr = stage_ms(lambda: flat_r.rerank(qs0, cI[0], k, D[0], I[0], rptr[0]))
+        ms_both = stage_ms(lambda: ref.search_into(qs0, k, D[0], I[0], cD[0], cI[0], rptr[0]))
+        torch.cuda.synchronize()
+        ncand = int((cI[0] >= 0).sum().item())
+        rr_bytes = ncand * D_MODEL * relem                               # every candidate's stored row, read once
+        ach = rr_bytes / (ms_rr * 1e-3) / 1e9
+        roofline = {"kernel": {1: "rerank_sq8_kernel", 2: "rerank_f16_kernel", 4: "rerank_f32_kernel"}[relem] + " (streaming re-rank of k*k_factor candidates per query)",
+                    "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                    "traffic": None, "bytes_per_launch": int(rr_bytes), "avg_launch_ms": round(ms_rr, 5),
+                    "algorithmic_bytes": "candidates x d x %d B (the stored row of every candidate, read once)" % relem,
+                    "step_split_ms": {"candidates (coarse + LUT + all-scores scan + set selection)": round(ms_cand, 4),
+                                      "re-rank (query table + streaming kernel + top-k)": round(ms_rr, 4),
+                                      "both stages on one stream": round(ms_both, 4),
+                                      "timed step (batches round-robin on %d streams)" % S2: round(dt / steps * 1e3, 4)},
+                    "timing": "each stage alone, 10 launches back to back on one launch stream between two HIP events recorded on that stream"}
+
+    # ---- parity of the timed shape: the re-rank of the first 128 timed queries recomputed by the oracle from nothing but
+    # the candidate rows' STORED bytes (mi_flat_get_rows: the 212 GB store cannot be exported) and the trained ranges
+    parity = None
+    if rank == 0 and have_cand and relem in (1, 4) and not args.no_cpu_baseline and (sharded is None):
+        from oracle import ivfpq_oracle as O
+        O.build()
+        nqp = min(128, batch)
+        ref.search_into(qs0, k, D[0], I[0], cD[0], cI[0], rptr[0])
+        torch.cuda.synchronize()
+        cs = cI[0][:nqp].cpu().numpy()
+        Dh, Ih = D[0][:nqp].cpu().numpy(), I[0][:nqp].cpu().numpy()
+        valid = cs >= 0
+        uniq, inv = np.unique(cs[valid], return_inverse=True)            # sorted: the remap keeps the (score desc, id asc) order
+        cl = np.full(cs.shape, -1, np.int64)
+        cl[valid] = inv
+        rows = flat_r.get_rows(uniq)
+        t0 = time.perf_counter()
+        if relem == 1:
+            De, Ie = O.rerank_sq8(qs0[:nqp].cpu().numpy(), rows, flat_r.sq.trained, cl, k)
+        else:
+            De, Ie = O.rerank(qs0[:nqp].cpu().numpy(), rows.view(np.float32), cl, k)
+        t_or = time.perf_counter() - t0
+        Ie = np.where(Ie >= 0, uniq[np.maximum(Ie, 0)], -1)
+        parity = {"against": "oracle/ivfpq_oracle.c " + ("oracle_rerank_sq8" if relem == 1 else "oracle_rerank") + " on the candidate rows' stored bytes",
+                  "queries": int(nqp), "candidates_per_query": int(kb), "distinct_rows_exported": int(uniq.shape[0]),
+                  "ids_equal": bool(np.array_equal(Ih, Ie)),
+                  "scores_bit_equal": bool(np.array_equal(Dh.view(np.uint32), De.view(np.uint32))), "oracle_s": round(t_or, 1),
+                  "note": "the candidate SETS themselves are the PQ scan's, whose parity is the main line's parity_vs_oracle "
+                          "(tests/test_ivfpq_gpu.py::test_refine_sq8_at_the_timed_shape_matches_oracle checks both at this shape)"}
     base.nprobe = index.nprobe = args_nprobe
     gb = flat_r.ntotal * D_MODEL * relem / 1e9
     if refine_own:
@@ -678,10 +770,15 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
                  f"({index.ntotal * nsh * D_MODEL * relem / 1e9:.0f} GB) does not fit {world} GPU(s); every GPU of the 8-GPU job "
                  f"sees every query, so its job rate is this rate less one all-gather")
         recall_note = "against exact search over the same sub-shard"
-    return {"index": "IVF%d,PQ64,%s" % (base.nlist, suffix), "nprobe": nprobe, "k_factor_rf": kf, "recall_at_10": round(r, 4),
+    return {"index": "IVF%d,PQ64,%s" % (base.nlist, suffix), "refine_store": store_name,
+            "refine_store_note": "--refine-store auto = sq8 at every N: the points of a 1 -> 8 GPU curve are the same index",
+            "nprobe": nprobe, "k_factor_rf": kf, "recall_at_10": round(r, 4),
+            "recall_at_10_selection_batch": round(r_sel, 4),
             "reached": bool(r >= 0.95), "qps": round(steps * batch / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
-            "timed_blocks": len(blocks), "streams": S2, "scope": scope, "recall_note": recall_note,
-            "explored": curve, "explored_note": "[nprobe, k_factor_rf, recall@10] in ascending cost; the first point at or above 0.95 is timed"}
+            "timed_blocks": len(blocks), "streams": S2, "scope": scope,
+            "recall_note": recall_note + "; (nprobe, k_factor_rf) chosen on a held-out query batch, recall reported on another",
+            "roofline": roofline, "parity_vs_oracle": parity,
+            "explored": curve, "explored_note": "[nprobe, k_factor_rf, recall@10 on the held-out batch] in ascending cost; the first point at or above 0.95 is timed"}
 
 
 # ======================================================================
@@ -731,6 +828,94 @@ def stella_random_model(args, ctx, keep=None):
     return model, cfg
 
 
+def cfg5_curve(args, ctx, model, cfg, host_w, index, sharded, nprobe, k, steps, warmup, do_cpu):
+    """The query-time path at batches 1 / 16 / 256 (BASELINE.json configs[4]): prompted queries of 16-48 tokens arrive as
+    token ids on the host, are encoded (batch 1: the weight-streaming kernels of csrc/encoder_few.h) and searched over
+    `index` at `nprobe`.  Per batch: latency of one call, throughput of back-to-back calls, and the encoder's roofline
+    with the bound that applies -- below ~312 tokens a forward pass is a pass over the weights (HBM: 2 FLOP per weight
+    byte and token against 2.5 PFLOP/s : 8 TB/s), above it the MFMA rate."""
+    np, torch = ctx["np"], ctx["torch"]
+    clock, rank = ctx["clock"], ctx["rank"]
+    H, I = cfg["hidden"], cfg["intermediate"]
+    qc, kc = cfg["n_heads"] * cfg["head_dim"], cfg["n_kv_heads"] * cfg["head_dim"]
+    # what one forward pass must stream at least once: the bf16 weights of the 28 layers + the Dense module
+    nparams = cfg["n_layers"] * ((qc + 2 * kc) * H + H * qc + 3 * I * H) + cfg["dense_out"] * H
+    weight_bytes = 2 * nparams
+    budget0 = model.token_budget
+    model.token_budget = 32768
+    rng = np.random.default_rng(1)                                      # the same queries on every rank
+    curve, batch_toks = [], {}
+    for batch in (1, 16, 256):
+        toks = [rng.integers(0, cfg["vocab_size"], int(rng.integers(16, 49))).tolist() for _ in range(batch)]
+        batch_toks[batch] = toks
+
+        def once(_=0):
+            e = model.encode_tokens(toks, batch_size=batch, normalize_embeddings=True, as_tensor=True)
+            return index.search(e, k) if sharded is None else sharded.search_replicated(e, k)
+
+        for i in range(warmup):
+            once()
+        lat = []
+        for i in range(steps):                                          # latency: one call at a time
+            clock.barrier()
+            t1 = time.perf_counter()
+            once()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        dt, blocks, _ = clock.measure(once, steps, 1)                   # throughput: back to back
+        t1 = time.perf_counter()
+        for i in range(steps):
+            model.encode_tokens(toks, batch_size=batch, normalize_embeddings=True, as_tensor=True)
+        torch.cuda.synchronize()
+        enc = (time.perf_counter() - t1) / steps
+        lat.sort()
+        ntok = sum(len(t) for t in toks)
+        flops = 2.0 * nparams * ntok + 4.0 * cfg["n_layers"] * qc * sum(len(t) ** 2 for t in toks)
+        hbm_bound = ntok < 312                                          # 2 FLOP per weight byte and token vs 2.5 PF / 8 TB/s
+        if hbm_bound:
+            roof = {"bound": "hbm", "achieved": round(weight_bytes / enc / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(weight_bytes / enc / 8e12, 4), "bytes_per_launch": int(weight_bytes),
+                    "algorithmic_bytes": "the bf16 weights of the 28 decoder layers + Dense, read once per forward pass"}
+        else:
+            roof = {"bound": "mfma", "achieved": round(flops / enc / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                    "frac": round(flops / enc / 2.5e15, 4), "flops_per_launch": flops,
+                    "algorithmic_flops": "2 x parameters x tokens + 4 x layers x q_cols x sum(len^2) (attention)"}
+        roof.update({"kernel": "the encoder forward pass (%s)" % ("csrc/encoder_few.h: six weight-streaming launches per layer" if ntok <= 48 else
+                                                                    "general path: MFMA GEMM tiles by token count"),
+                     "traffic": None, "avg_launch_ms": round(enc * 1e3, 4), "what": "encode alone, back-to-back calls"})
+        curve.append({"batch": batch, "latency_ms_p50": round(lat[len(lat) // 2] * 1e3, 3),
+                      "latency_ms_p95": round(lat[min(len(lat) - 1, int(0.95 * len(lat)))] * 1e3, 3),
+                      "queries_per_s": round(steps * batch / dt, 1), "encode_alone_ms": round(enc * 1e3, 3),
+                      "tokens": ntok, "roofline": roof})
+        log(f"  cfg5 batch {batch}: {curve[-1]}")
+    model.token_budget = budget0
+    cpu = parity = None
+    if do_cpu and rank == 0:
+        from oracle import encoder_oracle as E
+        par = {}
+        t_enc = None
+        for bsz in (1, 16):                                             # the two batches the query-time kernels / mid-batch tiles serve
+            toks = batch_toks[bsz]
+            cu = np.concatenate([[0], np.cumsum([len(t) for t in toks])])
+            e_gpu = model.encode_tokens(toks, batch_size=bsz, normalize_embeddings=True, as_tensor=True)
+            with torch.no_grad():
+                t1 = time.perf_counter()
+                ref = E.encode(E.EncoderConfig(**cfg), host_w, np.concatenate(toks), cu, True).numpy()
+                t_e = time.perf_counter() - t1
+            cos = (e_gpu.cpu().numpy() * ref).sum(1)
+            par["batch_%d" % bsz] = {"tokens": int(cu[-1]), "min_cosine_vs_oracle": round(float(cos.min()), 7), "ok": bool(cos.min() >= 1 - 1e-3)}
+            if bsz == 16:
+                t_enc, e16, cu16 = t_e, e_gpu, cu
+        cpu_s, par_s = cpu_baseline_ivfpq(index, e16, nprobe, k, np, torch, "cfg5")
+        t_search = 16.0 / cpu_s["value"]
+        cpu = {"value": round(16.0 / (t_enc + t_search), 3), "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"the batch of 16 queries ({int(cu16[-1])} tokens) end to end on the host cores: oracle encode at full depth {t_enc:.1f}s "
+                         f"(oracle/encoder_oracle.py, torch fp32) + oracle search {t_search * 1e3:.0f} ms ({cpu_s['sample'][:60]}...)"}
+        parity = {"encode": par, "tolerance": "cosine >= 1 - 1e-3, full depth", "search": par_s}
+    return {"curve": curve, "cpu_baseline": cpu, "parity_vs_oracle": parity,
+            "query_tokens": "16-48 per query (prompt + question)", "nprobe": nprobe, "k": k, "steps": steps}
+
+
 def cfg5_workload(args, ctx):
     """BASELINE.json configs[4]: a query batch arrives as token ids on the host (what the tokenizer
     hands over), is encoded (prompted query, 16-48 tokens) and searched over the cfg4 index
@@ -777,70 +962,11 @@ def cfg5_workload(args, ctx):
     do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     host_w = {} if do_cpu else None
     model, cfg = stella_random_model(args, ctx, keep=host_w)
-    H, I = cfg["hidden"], cfg["intermediate"]
-    qc, kc = cfg["n_heads"] * cfg["head_dim"], cfg["n_kv_heads"] * cfg["head_dim"]
-    # what one forward pass must stream at least once: the bf16 weights of the 28 layers + the Dense module
-    weight_bytes = 2 * (cfg["n_layers"] * ((qc + 2 * kc) * H + H * qc + 3 * I * H) + cfg["dense_out"] * H)
-    rng = np.random.default_rng(1)                                      # the same queries on every rank
-    curve, batch_toks = [], {}
-    for batch in (1, 16, 256):
-        toks = [rng.integers(0, cfg["vocab_size"], int(rng.integers(16, 49))).tolist() for _ in range(batch)]
-        batch_toks[batch] = toks
-
-        def once(_=0):
-            e = model.encode_tokens(toks, batch_size=batch, normalize_embeddings=True, as_tensor=True)
-            return index.search(e, k) if sharded is None else sharded.search_replicated(e, k)
-
-        for i in range(warmup):
-            once()
-        lat = []
-        for i in range(steps):                                          # latency: one call at a time
-            clock.barrier()
-            t1 = time.perf_counter()
-            once()
-            torch.cuda.synchronize()
-            lat.append(time.perf_counter() - t1)
-        dt, blocks, _ = clock.measure(once, steps, 1)                   # throughput: back to back
-        t1 = time.perf_counter()
-        for i in range(steps):
-            model.encode_tokens(toks, batch_size=batch, normalize_embeddings=True, as_tensor=True)
-        torch.cuda.synchronize()
-        enc = (time.perf_counter() - t1) / steps
-        lat.sort()
-        curve.append({"batch": batch, "latency_ms_p50": round(lat[len(lat) // 2] * 1e3, 3),
-                      "latency_ms_p95": round(lat[min(len(lat) - 1, int(0.95 * len(lat)))] * 1e3, 3),
-                      "queries_per_s": round(steps * batch / dt, 1), "encode_alone_ms": round(enc * 1e3, 3),
-                      "tokens": sum(len(t) for t in toks),
-                      # the encoder is the whole cost of these batches and its floor is one pass over the weights
-                      "weight_stream_gbs": round(weight_bytes / enc / 1e9, 1), "weight_stream_frac_of_8tbs": round(weight_bytes / enc / 8e12, 4)})
-        log(f"  batch {batch}: {curve[-1]}")
+    c5 = cfg5_curve(args, ctx, model, cfg, host_w, index, sharded, nprobe, k, steps, warmup, do_cpu)
     if rank != 0:
         return None
-    # roofline of the dominant kernel family at these batch sizes -- the encoder's weight-streaming GEMMs: the batch-16 point
-    # (BASELINE.json configs[4]'s middle point; batch 256 is MFMA-bound like the bulk encode, batch 1 launch-latency-bound)
-    mid = curve[1]
-    roofline = {"kernel": "encoder GEMMs at 16 queries (~570 tokens): every weight matrix streamed once per forward pass",
-                "bound": "hbm", "achieved": mid["weight_stream_gbs"], "peak": 8000.0, "unit": "GB/s", "frac": mid["weight_stream_frac_of_8tbs"],
-                "traffic": None, "bytes_per_launch": int(weight_bytes),
-                "algorithmic_bytes": "bf16 weights of the 28 decoder layers + Dense, read once per forward pass (activations and the search are < 2 % of it)",
-                "avg_launch_ms": mid["encode_alone_ms"]}
-    cpu = parity = None
-    if do_cpu:
-        from oracle import encoder_oracle as E
-        toks = batch_toks[16]
-        cu = np.concatenate([[0], np.cumsum([len(t) for t in toks])])
-        e_gpu = model.encode_tokens(toks, batch_size=16, normalize_embeddings=True, as_tensor=True)
-        with torch.no_grad():
-            t1 = time.perf_counter()
-            ref = E.encode(E.EncoderConfig(**cfg), host_w, np.concatenate(toks), cu, True).numpy()
-            t_enc = time.perf_counter() - t1
-        cos = (e_gpu.cpu().numpy() * ref).sum(1)
-        cpu_s, par_s = cpu_baseline_ivfpq(index, e_gpu, nprobe, k, np, torch, "cfg5")
-        t_search = 16.0 / cpu_s["value"]
-        cpu = {"value": round(16.0 / (t_enc + t_search), 3), "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"the batch of 16 queries ({int(cu[-1])} tokens) end to end on the host cores: oracle encode at full depth {t_enc:.1f}s "
-                         f"(oracle/encoder_oracle.py, torch fp32) + oracle search {t_search * 1e3:.0f} ms ({cpu_s['sample'][:60]}...)"}
-        parity = {"encode_min_cosine_vs_oracle": round(float(cos.min()), 7), "encode_ok": bool(cos.min() >= 1 - 1e-3), "search": par_s}
+    curve, cpu, parity = c5["curve"], c5["cpu_baseline"], c5["parity_vs_oracle"]
+    roofline = dict(curve[1]["roofline"], note="the batch-16 point (BASELINE.json configs[4]'s middle point); every batch carries its own in `curve`")
     return {"metric": "queries/sec end to end (stella_en_1.5B_v5 encode + IVF%d,PQ64 search over %dx1024-d, batch 256)" % (nlist, N),
             "value": curve[-1]["queries_per_s"], "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(256e3 / curve[-1]["queries_per_s"], 4), "higher_is_better": True, "scaling": "strong",
@@ -993,7 +1119,7 @@ def cfg2_workload(args, ctx):
 # ======================================================================
 # cfg3: stella_en_1.5B_v5 bf16 batch encode
 # ======================================================================
-def encode_workload(args, ctx, steps, warmup, with_cpu=True):
+def encode_workload(args, ctx, steps, warmup, with_cpu=True, pack=None):
     """stella_en_1.5B_v5 architecture (random-init bf16 weights -- no checkpoint is reachable
     from the build/bench boxes), synthetic abstracts with clipped log-normal token counts
     (median 220, max 512).  A step encodes one batch of `--encode-batch` abstracts: embedding
@@ -1004,8 +1130,13 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True):
     world, rank, local_rank, dev, clock = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["dev"], ctx["clock"]
     import abstracts_search_amd.sentence_transformers as st
     do_cpu = rank == 0 and world == 1 and with_cpu
-    host_w = {} if do_cpu else None                                   # fp32 host copies for the full-depth oracle leg
-    model, cfg = stella_random_model(args, ctx, keep=host_w)
+    if pack is not None:                                              # the caller's model (the cfg4 line builds it once)
+        model, cfg, host_w = pack
+        do_cpu = do_cpu and host_w is not None
+    else:
+        host_w = {} if do_cpu else None                               # fp32 host copies for the full-depth oracle leg
+        model, cfg = stella_random_model(args, ctx, keep=host_w)
+    model.token_budget = 32768
     bs = args.encode_batch
     rng = np.random.default_rng(7 + rank)
     NBATCH = 8

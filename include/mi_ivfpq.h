@@ -247,6 +247,12 @@ int mi_flat_reserve(mi_flat *h, int64_t n);
 /* IndexFlat.reconstruct_n: vectors [i0, i0 + n) as stored, float32 [n][d] (host or device
  * output) -- e.g. the centroids of an IndexFlat handed to IndexIVFPQ as its quantizer. */
 int mi_flat_reconstruct_n(mi_flat *h, int64_t i0, int64_t n, float *out);
+/* The STORED bytes of the rows `ids` (int64 [n], host or device, each in [0, ntotal)) -> out (host or device):
+ * d floats (f32 store; d + 4 for METRIC_L2's augmented rows), d IEEE halves (QT_fp16) or d code bytes (QT_8bit) per
+ * row, in the order of `ids`.  faiss reads the same bytes through IndexFlatCodes::codes / sa_encode; here it is
+ * the parity hook that hands a sample of a store too large to export (212 GB at cfg4) to the oracle
+ * (bench.py at_recall_095.parity_vs_oracle; reference call site Makefile:32 `tune` -> the operating point). */
+int mi_flat_get_rows(mi_flat *h, int64_t n, const int64_t *ids, void *out);
 int mi_flat_ntotal(mi_flat *h, int64_t *out);
 int mi_flat_reset(mi_flat *h);
 int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int64_t *I,

@@ -1091,6 +1091,8 @@ def test_refine_sq8_matches_oracle(faiss, oracle, d, M):
     codes = oracle.sq8_encode(x, tr)
     xd = oracle.sq8_decode(codes, tr)
     assert np.array_equal(bits(sqi.reconstruct_n(0, n)), bits(xd))
+    some = np.array([n - 1, 0, 1, 2, 77, 76, 5000, 5001], np.int64)       # the stored bytes of any rows (bench parity hook)
+    assert np.array_equal(sqi.get_rows(some), codes[some]) and np.array_equal(sqi.get_rows(torch.from_numpy(some).cuda()), codes[some])
     ln, pq = oracle.encode(x, cent, cb, True)
     off, lc, li = oracle.build_lists(ln, pq, np.arange(n), nlist)
     for nprobe, kf in ((4, 4), (8, 16), (32, 30)):
@@ -1108,6 +1110,42 @@ def test_refine_sq8_matches_oracle(faiss, oracle, d, M):
     assert np.array_equal(bits(other.reconstruct_n(0, 100)), bits(xd[:100]))
     with pytest.raises(RuntimeError, match="already holds"):
         other.train(x[:10])
+
+
+def test_refine_sq8_at_the_timed_shape_matches_oracle(faiss, oracle):
+    """The shape bench.py's at_recall_095 point times on the 207 M index -- d 1024, k 10, k_factor 512: 5120 candidates
+    per query through the unordered-candidates scan, select_pairs_kernel<32,true> and the streaming SQ8 re-rank -- for a
+    batch of 256 queries against the oracle: candidate SETS equal, re-ranked ids and score bits equal (duplicated rows:
+    ties at every rank).  (reference Makefile:32 `tune` -> the (nprobe, k_factor) operating point.)"""
+    import torch
+    d, M, nlist, n, nq, k, kf, nprobe = 1024, 64, 64, 40000, 256, 10, 512, 24
+    cent, cb, x, q = random_problem(4242, d, M, nlist, n, nq)
+    x[n // 2:] = x[: n - n // 2]                                        # every vector twice
+    base = make_index(faiss, cent, cb)
+    r = faiss.IndexScalarQuantizer(d, faiss.ScalarQuantizer.QT_8bit, faiss.METRIC_INNER_PRODUCT)
+    r.train(x[:20000])
+    idx = faiss.IndexRefine(base, r)
+    idx.add(torch.from_numpy(x).cuda())
+    idx.nprobe, idx.k_factor = nprobe, kf
+    qd = torch.from_numpy(q).cuda()
+    cI = torch.empty((nq, k * kf), dtype=torch.int64, device="cuda")
+    base.search_candidates_into(qd, k * kf, cI)
+    D, I = idx.search(qd, k)
+    tr = r.sq.trained
+    codes = oracle.sq8_encode(x, tr)
+    ln, pq = oracle.encode(x, cent, cb, True)
+    off, lc, li = oracle.build_lists(ln, pq, np.arange(n), nlist)
+    _, cand = oracle.search(q, cent, cb, off, lc, li, nprobe, k * kf, True)
+    assert (cand >= 0).all()                                            # the lists hold more than 5120 codes per query
+    assert np.array_equal(np.sort(cI.cpu().numpy(), axis=1), np.sort(cand, axis=1))
+    De, Ie = oracle.rerank_sq8(q, codes, tr, cand, k)
+    assert np.array_equal(I.cpu().numpy(), Ie) and np.array_equal(bits(D.cpu().numpy()), bits(De))
+    # the bench's parity leg: the oracle fed with nothing but the candidate rows' stored bytes (ids remapped order-preservingly)
+    sub = slice(0, 32)
+    cs = cI[sub].cpu().numpy()
+    uniq, inv = np.unique(cs, return_inverse=True)
+    D2, I2 = oracle.rerank_sq8(q[sub], r.get_rows(uniq), tr, inv.reshape(cs.shape), k)
+    assert np.array_equal(uniq[I2], Ie[sub]) and np.array_equal(bits(D2), bits(De[sub]))
 
 
 def test_refine_add_with_ids_only_accepts_positions(faiss):
