@@ -66,6 +66,59 @@ class ShardedIndex:
         self._id_map = id_map
         self._id_affine = tuple(int(v) for v in id_affine) if id_affine is not None else (1, 0, 0)
 
+    # -- diagnostics ---------------------------------------------------------
+    _probe = None
+
+    def _mark(self, what):
+        """(probe_split only) a time stamp on the issuing stream: a CUDA event, or the host clock on CPU tensors"""
+        if self._probe is None:
+            return
+        import time
+        import torch
+        if self._probe["cuda"]:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._probe["marks"].append((what, e))
+        else:
+            self._probe["marks"].append((what, time.perf_counter()))
+
+    def probe_split(self, q, k, reps=5):
+        """Where this rank's step goes: milliseconds per stage of search_replicated(q, k) -- the local search (with
+        shard_coarse: the coarse slice, its exchange and merge as stages of their own), the all-gather as THIS rank sees
+        it (a rank that finishes its scan early waits here for the slowest one: the number to look at when a scaling
+        run disappoints), the merge -- averaged over `reps` calls, by events on the issuing stream.  A diagnostic: one
+        call at a time, nothing else in flight."""
+        import torch
+        cuda = q.is_cuda
+        self.search_replicated(q, k)                                # warm: buffers, communicator
+        if cuda:
+            torch.cuda.synchronize()
+        acc = {}
+        for _ in range(reps):
+            self._probe = {"cuda": cuda, "marks": []}
+            try:
+                self.search_replicated(q, k)
+                if cuda:
+                    torch.cuda.synchronize()
+                marks = self._probe["marks"]
+            finally:
+                self._probe = None
+            # one exchange, or two with a sharded coarse quantiser (the probe lists first): name the intervals between marks
+            n_ex, prev = 0, None
+            for what, t in marks:
+                if prev is not None:
+                    dt = prev[1].elapsed_time(t) if cuda else (t - prev[1]) * 1e3
+                    if what == "begin":
+                        n_ex += 1
+                        name = ("coarse_slice" if n_ex == 1 else "scan_preassigned") if self.shard_coarse else "setup"
+                    else:
+                        name = {"local": "pack" if self.shard_coarse else "local_search", "exchange": "all_gather", "merge": "merge"}[what]
+                        if self.shard_coarse:
+                            name = ("coarse_" if n_ex == 1 else "scan_") + name
+                    acc[name + "_ms"] = acc.get(name + "_ms", 0.0) + dt / reps
+                prev = (what, t)
+        return {k2: round(v, 4) for k2, v in acc.items()}
+
     # -- helpers -----------------------------------------------------------
     def _buf(self, name, nbytes, device):
         # one buffer set per (CUDA) stream the search is issued on: batches issued on different streams overlap, and
@@ -114,11 +167,17 @@ class ShardedIndex:
         recv = self._buf("recv", blk * self.world, device)
         Dv = send[:nq * k * 4].view(torch.float32).view(nq, k)
         Iv = send[dbytes:].view(torch.int64).view(nq, k)
+        mark = self._mark
+        mark("begin")
         fill(Dv, Iv)
+        mark("local")
         dist.all_gather_into_tensor(recv, send, group=self.group)      # the path's one exchange step
+        mark("exchange")
         if self._merge is None:
             from . import faiss
-            return faiss.merge_topk_gathered(recv, self.world, nq, k, blk, affine, q_lo, nq_out)
+            out = faiss.merge_topk_gathered(recv, self.world, nq, k, blk, affine, q_lo, nq_out)
+            mark("merge")
+            return out
         # injected merge (CPU tests): the same views, ids translated with torch
         parts = recv.view(self.world, blk)
         Dg = torch.stack([parts[p, :nq * k * 4].view(torch.float32).view(nq, k) for p in range(self.world)])
@@ -127,10 +186,13 @@ class ShardedIndex:
         if (mul, add, step) != (1, 0, 0):
             off = (add + step * torch.arange(self.world, dtype=torch.int64, device=Ig.device)).view(-1, 1, 1)
             Ig = torch.where(Ig < 0, Ig, Ig * mul + off)
-        return self._merge(Dg[:, q_lo:q_lo + nq_out].contiguous(), Ig[:, q_lo:q_lo + nq_out].contiguous())
+        out = self._merge(Dg[:, q_lo:q_lo + nq_out].contiguous(), Ig[:, q_lo:q_lo + nq_out].contiguous())
+        mark("merge")
+        return out
 
     def _search_all(self, qall, k, q_lo, nq_out):
         nq = qall.shape[0]
+        self._mark("start")
         if self.shard_coarse:
             Dl, Il = self._search_sharded_coarse(qall, k)
 

@@ -244,6 +244,10 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    import faulthandler
+    import signal
+    faulthandler.register(signal.SIGUSR1, all_threads=True)            # a stalled rank says where: kill -USR1 <pid> (tests do on a timeout)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -474,8 +478,8 @@ def cfg4_workload(args, ctx):
     S = max(1, 2 if args.streams is None else args.streams)
     if sharded is not None:
         S = max(1, int(os.environ.get("BENCH_SHARD_STREAMS", "0")) or S)
-        if isinstance(sharded, ShardedIndex) is False:
-            S = 1                                                     # the native exchange binds one stream at a time
+        # (the native exchange keeps a buffer set per stream too -- mi_shards::Bufs -- and RCCL orders the collectives of one
+        # communicator by issue order: two batches in flight like the torch path)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
     sptr = [int(s_.cuda_stream) for s_ in streams]
     Ds = [torch.empty((batch, k), dtype=torch.float32, device=dev) for _ in range(S)]
@@ -544,6 +548,24 @@ def cfg4_workload(args, ctx):
 
     census = rank_census(torch, dist, world, dev, index.ntotal)
 
+    # ---- N > 1: where every rank's step goes, measured, beside what the single-GPU numbers predict -- so that a scaling
+    # run that disappoints can be read from its one line (a slow rank shows as the OTHER ranks' all-gather time)
+    split = None
+    if sharded is not None and hasattr(sharded, "probe_split"):
+        mine_split = dict(sharded.probe_split(my_q[0], k, reps=5), rank=rank, index_vectors=index.ntotal,
+                          scan_bytes=int(scan_bytes), scan_ms=round(scan_ms, 4))
+        gathered = [None] * world
+        if dist.is_initialized() and world > 1:
+            dist.all_gather_object(gathered, mine_split)
+        else:
+            gathered = [mine_split]
+        coarse_pred = 0.23 / (world if args.shard_coarse else 1)       # ms: the measured N = 1 coarse stage (f16 slab GEMM + selection) at batch 1024
+        split = {"per_rank": gathered,
+                 "predicted_ms": {"scan": round(scan_bytes / (0.72 * 8e12) * 1e3, 4), "coarse": round(coarse_pred, 4), "all_gather": 0.05, "merge": 0.02,
+                                  "model": "scan = this rank's scanned bytes / (0.72 x 8 TB/s: the fraction measured at N = 1); coarse = 0.23 ms at N = 1 "
+                                           "(/ N with --shard-coarse); all-gather of nq*k*12 B per rank: latency-bound, ~50 us over xGMI"},
+                 "note": "one call at a time (events on the issuing stream); the timed loop overlaps two batches, so ms_per_step is below the sum"}
+
     # ---- CPU baseline + parity spot check (rank 0, N = 1): the oracle on the same index / queries
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -577,7 +599,7 @@ def cfg4_workload(args, ctx):
             "recall_at_10": None if recall is None else round(recall, 4),
             "recall_note": "against exact inner-product search over all %d rows, %d queries" % (N, batch),
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
-            "at_recall_095": at095, "reference_oracles": reference_oracles(),
+            "at_recall_095": at095, "step_split": split, "reference_oracles": reference_oracles(),
         }
     # ---- BASELINE.json configs[4] in the same line: encode + search at query batches 1 / 16 / 256 over THIS index (before it
     # is freed); the model is the one the encode half below times

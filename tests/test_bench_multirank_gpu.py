@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # under torch.distributed.run) runs in the default `-m gpu` suite under a hard timeout.  The wider ones (4 ranks, replicas,
 # the forced sub-shard layout) stay opt-in (MI_RUN_REHEARSAL=1): several processes sharing one GPU is not a configuration
 # the job ever runs in, and with FOUR of them the ROCm runtime stalled once in four runs on this pool (every rank parked
-# inside the driver, not killable) -- two ranks never did in any run.
+# inside the driver, not killable) -- two ranks never did in any run.  A run that does not finish within 300 s FAILS and
+# prints every rank's Python stacks (faulthandler on SIGUSR1): a hang on a real node must never read as a skip.
 opt_in = pytest.mark.skipif(os.environ.get("MI_RUN_REHEARSAL") != "1",
                             reason="the wider multi-process-per-GPU rehearsals are opt-in: MI_RUN_REHEARSAL=1")
 
@@ -39,11 +40,18 @@ def _run(n, extra, self_launch=False, **env_extra):
     cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1"] + extra
     p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
-        out, err = p.communicate(timeout=240)
+        out, err = p.communicate(timeout=300)
     except subprocess.TimeoutExpired:
+        # a stall is a FAILURE, and it says where: bench.py registers faulthandler on SIGUSR1, so every rank (and the
+        # launcher) dumps the stack of every thread to stderr before the group is killed
         import signal
-        os.killpg(p.pid, signal.SIGKILL)
-        pytest.skip("the shared-GPU rehearsal stalled (a runtime stall with several processes on one GPU, not a bench.py error)")
+        os.killpg(p.pid, signal.SIGUSR1)
+        try:
+            out, err = p.communicate(timeout=10)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            out, err = p.communicate()
+        pytest.fail("the %d-rank rehearsal did not finish within 300 s; stacks of the ranks at the time:\n%s" % (n, err[-12000:]))
     assert p.returncode == 0, err[-3000:]
     lines = [ln for ln in out.splitlines() if ln.strip()]
     assert len(lines) == 1, out[-2000:]                                # exactly one JSON line, from rank 0
@@ -83,6 +91,11 @@ def test_cfg4_line_at_n_ranks(n, one_gpu_line):
     # what the collective library saw: n ranks answered an all-reduce, every rank holds its share of the index
     assert cfg["rccl_ranks"] == n and cfg["index_vectors_per_rank"] == [2 * 1048576 // n] * n and cfg["collective_backend"] == "gloo"
     assert cfg["timed_blocks"] >= 3
+    # the per-rank step split (one entry per rank, every stage named) and the single-GPU prediction beside it
+    sp = out["step_split"]
+    assert [r["rank"] for r in sp["per_rank"]] == list(range(n)) and all(r["index_vectors"] == 2 * 1048576 // n for r in sp["per_rank"])
+    key = "scan_all_gather_ms" if n >= 4 else "all_gather_ms"
+    assert all(r[key] >= 0 and r["scan_ms"] > 0 for r in sp["per_rank"]) and sp["predicted_ms"]["scan"] > 0
     # sharded top-k == unsharded top-k, so recall against the exact search is the same number
     assert out["recall_at_10"] == one_gpu_line["recall_at_10"], (out["recall_at_10"], one_gpu_line["recall_at_10"])
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0

@@ -118,11 +118,21 @@ def _worker(rank, world, port, mode, ret):
     else:
         D, I = sh.search_replicated(torch.from_numpy(qall), k)
         qs = qall
+    ok2 = True
+    if mode.startswith("replicated"):
+        # the per-rank step split bench.py prints at N > 1 (every stage named, every rank answers; the probe leaves no state behind)
+        sp = sh.probe_split(torch.from_numpy(qall), k, reps=2)
+        want = ({"coarse_slice_ms", "coarse_pack_ms", "coarse_all_gather_ms", "coarse_merge_ms", "scan_preassigned_ms", "scan_pack_ms",
+                 "scan_all_gather_ms", "scan_merge_ms"} if mode.endswith("+coarse") else {"setup_ms", "local_search_ms", "all_gather_ms", "merge_ms"})
+        D2, I2 = sh.search_replicated(torch.from_numpy(qall), k)
+        ok2 = set(sp) == want and all(v >= 0 for v in sp.values()) and sh._probe is None and torch.equal(I2, I)
+        if not ok2:
+            print("probe_split:", sp, sh._probe, torch.equal(I2, I), file=sys.stderr)
     # unsharded expectation
     ln, codes = O.encode(x, cent, cb)
     off, lc, li = O.build_lists(ln, codes, np.arange(n), nlist)
     De, Ie = O.search(qs, cent, cb, off, lc, li, nprobe, k)
-    ok = np.array_equal(I.numpy(), Ie) and np.array_equal(D.numpy().view(np.uint32), De.view(np.uint32))
+    ok = ok2 and np.array_equal(I.numpy(), Ie) and np.array_equal(D.numpy().view(np.uint32), De.view(np.uint32))
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
