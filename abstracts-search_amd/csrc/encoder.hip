@@ -150,7 +150,9 @@ bool launch_slab(int epi, GemmArgs g, hipStream_t st) {
     int split_all = 1;
     if (epi == EPI_RESID && part && g.tail_split == 1 && nblocks < 200) {
         const int ntiles = g.tiles_m * g.tiles_n, nt64 = g.K / 64;
-        int S = std::min({16, 256 / std::max(1, ntiles), nt64 / 4});      // >= 4 K tiles (8 steps) per slice
+        // (>= 4 K tiles (8 steps) per slice; at most 10 slices: every slice writes an M x N f32 plane that the reduction pass
+        // reads back -- 14 slices of 576 x 1536 are 49 MB each way; 16 queries 3.85 -> 3.71 ms with 10: profiles/r04 notes)
+        int S = std::min({10, 256 / std::max(1, ntiles), nt64 / 4});
         static const int s_env = std::getenv("MI_SPLITK") ? std::atoi(std::getenv("MI_SPLITK")) : -1;
         if (s_env >= 0) S = std::min(s_env, nt64);
         if (S >= 2 && (size_t)S * g.M * g.N * 4 <= g.part_bytes) {
@@ -318,8 +320,54 @@ bool mid_split_pays(const GemmArgs &g) {
     return g.M > 64 && g.K >= min_k && S >= 2 && ntiles * S >= min_wg && (size_t)S * g.M * g.N * 4 <= g.part_bytes;
 }
 
-// returns true when the launch also wrote the RMSNorm of the updated stream the caller asked for (GemmArgs::norm_w / norm_y)
-bool launch_gemm(int epi, GemmArgs g, hipStream_t st) {
+enum { GEMM_NORMED = 1, GEMM_ROPED = 2 };
+
+// A few hundred tokens through the K = 1536 projections (QKV, O): 128 x 128 tiles are too few to fill the chip (80 / 60 at
+// 576 tokens) and a CU's memory pipe bounds what one workgroup can pull (~590 KB per 128 x 64 x 1536 tile: 17-19 us a launch,
+// profiles/r04_encode_nq16_kernel_stats_v1.csv).  K split S ways over ~240 workgroups, partial tiles as plain f32 planes,
+// and ONE reduction pass that also finishes the epilogue: bias + RoPE + Q|K rows + V^T (QKV: rope_kernel disappears), or
+// residual add + the next RMSNorm (O: rmsnorm_kernel disappears).  Returns the GEMM_* flags of what the pass did; 0 with
+// nothing launched when the shape does not fit.
+int launch_mid_part(int epi, GemmArgs g, hipStream_t st) {
+    static const bool off = std::getenv("MI_NO_MID_PART") != nullptr;
+    if (off || !g.part || (epi != EPI_QKV && epi != EPI_RESID) || g.N % 8 != 0 || g.N > 4096) return 0;
+    if (epi == EPI_QKV && !(g.rope_pos && g.rope_cos && g.rope_sin && g.rope_hd % 8 == 0 && g.qk_cols % g.rope_hd == 0)) return 0;
+    if (epi == EPI_RESID && (g.ldc != g.N)) return 0;
+    constexpr int BM = 128, BN = 128;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const int ntiles = g.tiles_m * g.tiles_n, nk = g.K / 32;
+    const int S = std::min({8, 256 / std::max(1, ntiles), nk / 8});       // >= 8 K steps per slice
+    if (S < 2 || (size_t)S * g.M * g.N * 4 > g.part_bytes) return 0;
+    g.ksplit = S;
+    g.Wt = nullptr;
+    g.tail_first = 0; g.tail_split = 1;
+    const int per = (ntiles + 7) / 8;                                    // tile_coords: eight per-XCD eighths
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_PART, 4, 4, 2, 2, 4>), dim3((unsigned)(8 * per * S)), dim3(256), 0, st, g);
+    MI_HIP(hipGetLastError());
+    ++g_splitk_launches;
+    if (epi == EPI_QKV) {
+        hipLaunchKernelGGL(splitk_reduce_qkv_kernel, dim3((unsigned)g.M), dim3(256), (size_t)g.N * 4, st, g.part, S, g.M, g.N, g.bias, g.C, g.ldc,
+                           g.qk_cols, g.Vt, g.ldvt, g.rope_hd, g.rope_pos, g.rope_cos, g.rope_sin);
+        MI_HIP(hipGetLastError());
+        return GEMM_ROPED;
+    }
+    if (g.norm_w && g.norm_y && g.N <= 2048) {
+        hipLaunchKernelGGL(splitk_reduce_norm_kernel, dim3((unsigned)g.M), dim3(256), 0, st, g.X, g.part, S, g.M, g.N, g.bias,
+                           g.norm_w, g.norm_eps, g.norm_y);
+        MI_HIP(hipGetLastError());
+        ++g_reduce_norm_launches;
+        return GEMM_NORMED;
+    }
+    const int64_t n4 = (int64_t)g.M * (g.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, g.X, (int64_t)g.ldc, g.part, S, g.M, g.N, g.bias);
+    MI_HIP(hipGetLastError());
+    return 0x100;                                                        // launched, nothing extra folded in
+}
+
+// returns the GEMM_* flags: GEMM_NORMED when the launch also wrote the RMSNorm of the updated stream the caller asked for
+// (GemmArgs::norm_w / norm_y), GEMM_ROPED when the QKV epilogue already rotated Q and K
+int launch_gemm(int epi, GemmArgs g, hipStream_t st) {
     MI_REQUIRE(g.K % 64 == 0, "encoder GEMM: K must be a multiple of 64");
     MI_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "encoder GEMM: leading dimensions must be multiples of 8");
     MI_REQUIRE(g.N % 4 == 0 && g.ldc % 4 == 0, "encoder GEMM: N and ldc must be multiples of 4");
@@ -337,6 +385,10 @@ bool launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         if (cfg.empty()) cfg = g.M <= 64 ? "tiny" : tiles_big >= 100 ? "big" : tiles_mid >= 150 ? "mid" : "small";
         g.ksplit = 1;
         const bool split_k = !force && epi == EPI_RESID && g.part && g.N % 8 == 0 && mid_split_pays(g) && !std::getenv("MI_NO_SPLITK");
+        if (!force && cfg == "small" && g.M > 64 && g.K < 4096 && g.part) {
+            const int fl = launch_mid_part(epi, g, st);
+            if (fl) return fl & 0xff;
+        }
         if (!split_k) g.part = nullptr;
         if (cfg != "tiny" || std::getenv("MI_NO_TILED_W")) g.Wt = nullptr;   // only the few-token path streams fragment-major weights
         const bool skinny_ok = g.Wt && g.M <= 32 && g.N % 16 == 0 && (g.K <= SKINNY_KS_MAX || (epi == EPI_RESID && !g.bias));
@@ -360,7 +412,7 @@ bool launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             // workspace (launch_slab) -- 576 x 1536 x 8960: 18 tiles x 14 slices = 252 workgroups of 20 K steps + one reduction
             // pass, where 128x128 tiles with K split three ways by f32 atomics took 76 us; at 1558 / 2097 tokens the forward
             // pass went 7.91 -> 6.46 / 9.21 -> 7.82 ms against the 128x128 ring tiles
-            return launch_slab<2>(epi, g, st);
+            return launch_slab<2>(epi, g, st) ? GEMM_NORMED : 0;
         } else if (cfg == "big" && !force && epi == EPI_RESID && n192_pays(g) && !std::getenv("MI_NO_N192")) {
             launch_slab_n192(g, st);
         } else if (cfg == "big" && !std::getenv("MI_GEMM_RING") && (epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {   // the slab kernel stores 8 bf16 columns per lane
@@ -405,7 +457,7 @@ bool launch_gemm(int epi, GemmArgs g, hipStream_t st) {
                 launch_ring<2, 2, 1, 2, 8>(epi, g, st);
             }
         }
-        return false;
+        return 0;
     }
     g.Wt = nullptr;
     g.tiles_m = (g.M + 127) / 128;
@@ -421,7 +473,7 @@ bool launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         default: throw Error("bad epilogue");
     }
     MI_HIP(hipGetLastError());
-    return false;
+    return 0;
 }
 
 }  // namespace
@@ -659,11 +711,11 @@ void stamped_launch(int epi, GemmArgs g, hipStream_t stream) {
     }
 }
 
-bool timed_gemm(mi_encoder *h, int epi, const GemmArgs &g, hipStream_t st) {
+int timed_gemm(mi_encoder *h, int epi, const GemmArgs &g, hipStream_t st) {
     static const bool enc_ts = std::getenv("MI_ENC_TS") != nullptr;      // stamps of the first layer's four GEMMs, in place
     static std::atomic<int> ts_left{4};
     if (enc_ts && g.M > 4096 && ts_left.fetch_sub(1) > 0) stamped_launch(epi, g, st);
-    const bool normed = launch_gemm(epi, g, st);
+    const int normed = launch_gemm(epi, g, st);
     if (!h->prof) return normed;
     std::lock_guard<std::mutex> hl(h->mu);
     h->prof_launches.push_back({epi, g});
@@ -932,8 +984,9 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         g.A = xn; g.lda = H; g.W = w.wqkv.get<bf16_t>(); g.ldw = H; g.M = T; g.N = h->qk_cols + h->v_cols; g.K = H;
         g.bias = w.bqkv.get<float>(); g.C = qk; g.ldc = h->qk_cols; g.Vt = vt; g.ldvt = ldvt; g.qk_cols = h->qk_cols;
         if (few) g.Wt = w.wqkv_t.get<bf16_t>();
-        timed_gemm(h, EPI_QKV, g, st);
-        {
+        g.part = part; g.part_bytes = part_bytes;    // (a few hundred tokens: K split + one pass that also rotates Q and K)
+        g.rope_pos = b.pos; g.rope_cos = h->rope_cos.get<float>(); g.rope_sin = h->rope_sin.get<float>(); g.rope_hd = hd;
+        if (!(timed_gemm(h, EPI_QKV, g, st) & GEMM_ROPED)) {
             const int nh_qk = c.n_heads + c.n_kv_heads;
             const int64_t n = (int64_t)T * nh_qk * (hd / 16);
             hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, qk, h->qk_cols,
@@ -945,9 +998,10 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         o.A = att; o.lda = h->q_cols; o.W = w.wo.get<bf16_t>(); o.ldw = h->q_cols; o.M = T; o.N = H; o.K = h->q_cols;
         o.X = x; o.ldc = H; o.part = part; o.part_bytes = part_bytes;
         if (few) o.Wt = w.wo_t.get<bf16_t>();
-        timed_gemm(h, EPI_RESID, o, st);
-        hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln2.get<float>(), H, T,
-                           c.rms_eps, xn);
+        o.norm_w = w.ln2.get<float>(); o.norm_y = xn; o.norm_eps = c.rms_eps;   // (rides in a split-K reduction pass when there is one)
+        if (!(timed_gemm(h, EPI_RESID, o, st) & GEMM_NORMED))
+            hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln2.get<float>(), H, T,
+                               c.rms_eps, xn);
         GemmArgs u{};
         u.A = xn; u.lda = H; u.W = w.wgu.get<bf16_t>(); u.ldw = H; u.M = T; u.N = 2 * I; u.K = H; u.C = hb; u.ldc = I;
         if (few) u.Wt = w.wgu_t.get<bf16_t>();
@@ -959,7 +1013,7 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         if (l + 1 < c.n_layers) {                    // the next layer's first RMSNorm can ride in a split-K reduction pass
             d.norm_w = h->layers[l + 1].ln1.get<float>(); d.norm_y = xn; d.norm_eps = c.rms_eps;
         }
-        normed = timed_gemm(h, EPI_RESID, d, st);
+        normed = (timed_gemm(h, EPI_RESID, d, st) & GEMM_NORMED) != 0;
     }
 }
 

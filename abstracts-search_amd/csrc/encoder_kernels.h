@@ -212,7 +212,10 @@ __device__ __forceinline__ bool tile_coords(int tiles_m, int tiles_n, int &tm, i
 }
 
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3,
-       EPI_F32H = 4 };   // f16 (not bf16) operands, plain f32 store to X: the index library's approximate score GEMM
+       EPI_F32H = 4,     // f16 (not bf16) operands, plain f32 store to X: the index library's approximate score GEMM
+       EPI_PART = 5 };   // K split over workgroups, slice ks stores its partial tile (plain f32) into plane ks of `part`; a
+                         // reduction kernel adds the planes in order and finishes the epilogue (splitk_reduce_norm_kernel: residual
+                         // add + next RMSNorm; splitk_reduce_qkv_kernel: bias + RoPE + Q|K rows + V^T) -- the few-hundred-token path
 
 struct GemmArgs {
     const bf16_t *A;   // [M][lda]
@@ -247,6 +250,11 @@ struct GemmArgs {
     bf16_t *norm_y;
     float norm_eps;
     int stagger;       // slab kernel: the first round's workgroups start up to stagger x 1024 cycles apart (0 = together)
+    // host side only (EPI_QKV): what the reduction pass of a K-split QKV projection needs to finish the epilogue
+    // (splitk_reduce_qkv_kernel: RoPE in the same pass) -- null pos: the caller runs rope_kernel itself
+    const int32_t *rope_pos;
+    const float *rope_cos, *rope_sin;
+    int rope_hd;
 };
 
 // W [N][ldw] (N % 16 == 0, K % 32 == 0) -> fragment-major Wt: one 64-thread workgroup per
@@ -392,7 +400,7 @@ __device__ __forceinline__ void store_tile_t(const GemmArgs &g, f32x4 v, f32x4 v
         }
     } else {
         if (row >= g.M || col0 >= g.N) return;
-        if constexpr (EPI == EPI_F32H) {
+        if constexpr (EPI == EPI_F32H || EPI == EPI_PART) {
             *reinterpret_cast<float4 *>(g.X + (size_t)row * g.ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
             return;
         }
@@ -562,8 +570,8 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
 
     // split-K (small batches, residual GEMMs): workgroup = (tile, K slice)
     int ksplit = 1, ks = 0, vb = -1;
-    if constexpr (EPI == EPI_RESID) {
-        if (g.ksplit > 1) {
+    if constexpr (EPI == EPI_RESID || EPI == EPI_PART) {
+        if (g.ksplit > 1 || EPI == EPI_PART) {
             ksplit = g.ksplit;
             ks = (int)blockIdx.x % ksplit;
             vb = (int)blockIdx.x / ksplit;
@@ -748,6 +756,10 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
     }
     GemmArgs ge = g;
     ge.ksplit = ksplit;   // this workgroup's share: > 1 = atomic adds
+    if constexpr (EPI == EPI_PART) {   // this slice's plane of the workspace
+        ge.X = g.part + (size_t)ks * g.M * g.N;
+        ge.ldc = g.N;
+    }
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         const int trow = m0 + (wm * WMT + i) * 16;
@@ -1419,6 +1431,56 @@ __global__ void __launch_bounds__(256)
             o.x = pack2(v[j].x * inv * g.x, v[j].y * inv * g.y);
             o.y = pack2(v[j].z * inv * g.z, v[j].w * inv * g.w);
             *reinterpret_cast<uint2 *>(y + (size_t)m * N + c) = o;
+        }
+    }
+}
+
+// The QKV projection's reduction pass: one workgroup per token sums the S planes of its row (ascending: a fixed order),
+// adds the bias, rotates the Q / K heads (the pair (j, j + hd/2) of a head lives in the same row: f32, no second pass over
+// bf16 values) and writes the Q|K row and the token's column of V^T.  N <= 4096 (a thread owns columns 4 t .. and + 1024 ..).
+__global__ void __launch_bounds__(256)
+    splitk_reduce_qkv_kernel(const float *__restrict__ part, int S, int M, int N, const float *__restrict__ bias,
+                             bf16_t *__restrict__ qk, int ldqk, int qk_cols, bf16_t *__restrict__ vt, int ldvt, int hd,
+                             const int32_t *__restrict__ pos, const float *__restrict__ cos_t, const float *__restrict__ sin_t) {
+    extern __shared__ __attribute__((aligned(16))) float row[];      // [N] the summed row (+ bias)
+    const int m = blockIdx.x, t = threadIdx.x;
+    const size_t plane = (size_t)M * N;
+    for (int c = t * 4; c < N; c += 1024) {
+        const float *p = part + (size_t)m * N + c;
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(p);
+        for (int s0 = 1; s0 < S; s0 += 4) {                       // four planes' loads in flight, added in ascending order
+            f32x4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const f32x4 *>(p + (size_t)min(s0 + u, S - 1) * plane);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s0 + u < S) { acc[0] += q[u][0]; acc[1] += q[u][1]; acc[2] += q[u][2]; acc[3] += q[u][3]; }
+        }
+        if (bias) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + c);
+            acc[0] += b[0]; acc[1] += b[1]; acc[2] += b[2]; acc[3] += b[3];
+        }
+        *reinterpret_cast<f32x4 *>(row + c) = acc;
+    }
+    __syncthreads();
+    const int half = hd / 2, ps = pos[m];
+    for (int c = t * 4; c < N; c += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
+        if (c < qk_cols) {
+            const int j = c % hd, jj = j % half;                  // 4 consecutive features never straddle a half (hd % 8 == 0)
+            const f32x4 pv = *reinterpret_cast<const f32x4 *>(row + (j < half ? c + half : c - half));
+            const f32x4 cs = *reinterpret_cast<const f32x4 *>(cos_t + (size_t)ps * half + jj);
+            const f32x4 sn = *reinterpret_cast<const f32x4 *>(sin_t + (size_t)ps * half + jj);
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = j < half ? v[r] * cs[r] - pv[r] * sn[r] : v[r] * cs[r] + pv[r] * sn[r];
+            uint2 w;
+            w.x = pack2(o[0], o[1]);
+            w.y = pack2(o[2], o[3]);
+            *reinterpret_cast<uint2 *>(qk + (size_t)m * ldqk + c) = w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vt[(size_t)(c - qk_cols + r) * ldvt + m] = f2bf(v[r]);
         }
     }
 }
