@@ -1,7 +1,7 @@
 """Time of the first stage of a refine search (mi_index_search_candidates) at a whole-index-like shape: ~25 k pairs per
 query, the best 5120 kept (CAND_KC); run under rocprofv3 --kernel-trace --stats for the per-kernel split."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import abstracts_search_amd.faiss as faiss
 import abstracts_search_amd.synth as synth

@@ -2,7 +2,7 @@
 batch-1024 search + the scan kernel under launch variants (MI_NSLICE, MI_SCAN_NW, nprobe).
 GPU box; ~2.5 min.  usage: python tools/cfg4_scan_sweep.py [N]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 import abstracts_search_amd.faiss as faiss

@@ -4,7 +4,7 @@ queries (batch 1024) over its shard.  Builds the shard from the synthetic
 generator in chunks (never holding more than one chunk of raw vectors), then
 times search and the scan kernel.  GPU box; ~2-3 minutes."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import abstracts_search_amd.faiss as faiss
 import abstracts_search_amd.synth as synth

@@ -4,7 +4,7 @@
 the exact search over the same 25.9M vectors, and at what rate.  GPU box; ~4 minutes.
 usage: python tools/cfg4_tune.py [nq] [batch] [target]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import abstracts_search_amd.faiss as faiss
 import abstracts_search_amd.autotune as autotune

@@ -2,7 +2,7 @@
 batch 1024, nprobe 64: (a) whole searches round-robin on 2 streams (bench.py's loop); (b) coarse quantiser of batch i+1
 on a high-priority stream, LUT + scan (search_preassigned) on a normal one, chained by events."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 import abstracts_search_amd.faiss as faiss

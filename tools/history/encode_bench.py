@@ -1,7 +1,7 @@
 """Encoder throughput on synthetic abstracts (cfg3 shape: stella_en_1.5B_v5
 architecture, random-init bf16 weights, clipped log-normal lengths).  GPU box."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import abstracts_search_amd.sentence_transformers as st
 

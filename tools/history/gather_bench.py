@@ -4,7 +4,7 @@ scattered-row rate)?  Candidates: uniformly random over the store, or clustered 
 contiguous regions per query (what a list-ordered store would give).
 usage: python tools/gather_bench.py [n_rows ...]   (GPU box)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import abstracts_search_amd.faiss as faiss
 import abstracts_search_amd.synth as synth

@@ -1,7 +1,7 @@
 """bf16 ring GEMM time vs K at fixed M, N (big 256x256 tiles): slope = per-K-step cost, intercept =
 per-tile fixed cost (launch, pipeline fill, epilogue).  GPU box."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import abstracts_search_amd.sentence_transformers as st
 M, N = int(os.environ.get("M", 29696)), int(os.environ.get("N", 2048))

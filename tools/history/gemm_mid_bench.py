@@ -1,7 +1,7 @@
 """bf16 GEMM time at the encoder's shapes for few-hundred- to few-thousand-token batches (cfg5's batch 16 / 256),
 per tile configuration (MI_GEMM_TILE): which existing kernel is the best starting point for the mid-batch path."""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
     import torch

@@ -2,7 +2,7 @@
 epilogue, store drain, and (slab kernel) the gap between consecutive workgroups of a CU.
 usage: [ZERO=1] [M=32768] python tools/gemm_stamps.py   (GPU box; prints to stderr)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["MI_GEMM_TS"] = "1"
 import torch
 import abstracts_search_amd.sentence_transformers as st

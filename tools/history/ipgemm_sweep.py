@@ -7,7 +7,7 @@ usage: python tools/ipgemm_sweep.py [nq] [nb]
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 import abstracts_search_amd.faiss as faiss

@@ -1,7 +1,7 @@
 """Search steps at a large nprobe on the cfg2 index (per-kernel profile target: run under
 tools/prof_cmd.sh).  usage: python tools/nprobe_prof.py [nprobe[,nprobe...]] [k] [batch] [reps]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import abstracts_search_amd.faiss as faiss
 import abstracts_search_amd.synth as synth

@@ -1,6 +1,6 @@
 """recall@10 vs nprobe on the cfg2 synthetic corpus (GPU box)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import abstracts_search_amd.faiss as faiss
 import abstracts_search_amd.synth as synth

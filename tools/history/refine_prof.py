@@ -2,7 +2,7 @@
 store), timed per configuration; run under tools/prof_cmd.sh for the per-kernel split.
 usage: python tools/refine_prof.py [f16|f32] [nprobe] [k_factor] [N]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 import abstracts_search_amd.faiss as faiss

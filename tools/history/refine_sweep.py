@@ -1,7 +1,7 @@
 """Recall@10 and step time of IVF4096,PQ64 + RFlat (IndexRefineFlat) on the bench corpus:
 k_factor x nprobe sweep against exact search.  GPU box."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import abstracts_search_amd.faiss as faiss
 import abstracts_search_amd.synth as synth

@@ -1,6 +1,6 @@
 """Repeat the N-rank rehearsal of bench.py and, when a run stalls, dump every rank's Python stack (SIGABRT + faulthandler)."""
 import os, signal, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 limit = int(sys.argv[3]) if len(sys.argv) > 3 else 150

@@ -1,7 +1,7 @@
 """Ablation / tuning harness for the scan kernel (GPU box): builds cfg2 once and
 times scan_kernel (HIP events inside the library) under MI_NSLICE / MI_SCAN_DEBUG."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import abstracts_search_amd.faiss as faiss
 import abstracts_search_amd.synth as synth

@@ -2,7 +2,7 @@
 mi_index_profile_scan replay the last scan once with s_memtime stamps and print the
 per-phase statistics (stderr)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["MI_SCAN_TS"] = "1"
 import torch
 import abstracts_search_amd.faiss as faiss

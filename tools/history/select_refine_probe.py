@@ -1,7 +1,7 @@
 """select_refine_kernel at the cfg4 coarse size (1024 queries x 65536 centroids): time by nprobe, with and without
 the exact chains (MI_REFINE_DEBUG=1), through mi_index_coarse (GPU box)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import abstracts_search_amd.faiss as faiss
 import abstracts_search_amd.synth as synth

@@ -2,7 +2,7 @@
 margin its second stage assumes (eps_rel |q| max|c|).  MI_REFINE_DEBUG=1 makes the second stage
 report the approximate scores of the selected centroids instead of their exact ones.  GPU box."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import abstracts_search_amd.faiss as faiss
 
