@@ -865,7 +865,19 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         hipLaunchKernelGGL((few_gemm_kernel<FEW_QKV, MT>), dim3((unsigned)gemm_grid(q.nunits)), dim3(64 * FEW_NW), gemm_smem(q.nk, 1), st, q);
         if (q.ts) stamps("qkv", gemm_grid(q.nunits));
         chk("qkv");
-        launch_attention(h, b, qk, vt, nullptr, ldvt, st, afrag, MT);
+        static const bool old_attn = std::getenv("MI_FEW_ATTN_OLD") != nullptr;
+        if (old_attn || b.Lmax > FEW_MAX_T || (c.head_dim != 64 && c.head_dim != 128)) {
+            launch_attention(h, b, qk, vt, nullptr, ldvt, st, afrag, MT);
+        } else {
+            AttnArgs aa{};
+            aa.QK = qk; aa.Vt = vt; aa.Ofrag = afrag; aa.frag_mt = MT; aa.work_seq = b.work_seq; aa.work_q0 = b.work_q0;
+            aa.seq_start = b.seq_start; aa.seq_len = b.seq_len; aa.ldqk = h->qk_cols; aa.ldvt = ldvt;
+            aa.n_heads = c.n_heads; aa.n_kv = c.n_kv_heads; aa.causal = c.causal; aa.scale = 1.0f / std::sqrt((float)c.head_dim);
+            aa.nwork = b.nwork;
+            const dim3 ga((unsigned)c.n_heads, (unsigned)(b.nwork * 3));
+            if (c.head_dim == 128) hipLaunchKernelGGL((few_attn_kernel<128>), ga, dim3(64), 0, st, aa);
+            else hipLaunchKernelGGL((few_attn_kernel<64>), ga, dim3(64), 0, st, aa);
+        }
         chk("attention");
         FewArgs o{};
         o.T = T; o.H = H; o.nk = h->q_cols / 32; o.nunits = H / 8; o.W = w.few_o.get<bf16_t>(); o.afrag = afrag; o.x = x;

@@ -541,4 +541,105 @@ __global__ void __launch_bounds__(256) few_row_kernel(FewArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Attention of a few short sequences (every sequence <= 48 tokens: the whole key axis is ONE pass, no online softmax):
+// one wave per (head, 16-query tile of a sequence).  Computed transposed like attn_kernel (encoder_kernels.h): S^T = K Q^T
+// with MFMA row position p of key tile j standing for key 32 (j / 2) + 8 (p / 4) + 4 (j % 2) + p % 4, so that the lane's
+// probabilities of tiles 2 J, 2 J + 1 are the B fragment of the P V product as they stand; O^T = V^T P^T leaves four
+// consecutive dims of one query per lane, written as fragments of the O projection's operand.  Q, K rows and V^T rows come
+// straight from global memory (all 36 loads of a lane requested at once: the kernel is one latency chain).  The key axis
+// starts at the sequence's first token rounded down to 8 (V^T rows are fetched in 16-byte pieces); the < 8 foreign keys in
+// front and the keys past the end are masked.
+// grid: (n_heads, nwork * 3): blockIdx.y = work item (a sequence) x 16-query tile
+// ---------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(64) few_attn_kernel(AttnArgs a) {
+    constexpr int NKD = HD / 32, NDT = HD / 16, NJ = 4;            // K steps over the head dim, output tiles, key tiles (64 keys)
+    const int h = blockIdx.x, wi = blockIdx.y / 3, qt = blockIdx.y % 3;
+    const int seq = a.work_seq[wi], s0 = a.seq_start[seq], L = a.seq_len[seq];
+    if (16 * qt >= L) return;
+    const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+    const int sa = s0 & ~7, off = s0 - sa, Le = off + L;            // the key axis and the sequence's span on it
+    const int kvh = h / (a.n_heads / a.n_kv);
+    const int qidx = 16 * qt + li;                                   // this lane's query (inside the sequence)
+    // ---- every load of the wave, requested together
+    bf16x8 qf[NKD], kf[NJ][NKD], vf[NDT][2];
+    const bf16_t *qp = a.QK + (size_t)(s0 + min(qidx, L - 1)) * a.ldqk + h * HD + lg * 8;
+#pragma unroll
+    for (int kd = 0; kd < NKD; ++kd) qf[kd] = *reinterpret_cast<const bf16x8 *>(qp + kd * 32);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int key = 32 * (j >> 1) + 8 * (li >> 2) + 4 * (j & 1) + (li & 3);
+        const bf16_t *kp = a.QK + (size_t)(sa + min(key, Le - 1)) * a.ldqk + (a.n_heads + kvh) * HD + lg * 8;
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd) kf[j][kd] = *reinterpret_cast<const bf16x8 *>(kp + kd * 32);
+    }
+#pragma unroll
+    for (int n = 0; n < NDT; ++n) {
+        const bf16_t *vp = a.Vt + (size_t)(kvh * HD + 16 * n + li) * a.ldvt + sa + lg * 8;
+#pragma unroll
+        for (int J = 0; J < 2; ++J) vf[n][J] = *reinterpret_cast<const bf16x8 *>(vp + 32 * J);
+    }
+    // ---- S^T = K Q^T
+    f32x4 sc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        sc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd) sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j][kd], qf[kd], sc[j], 0, 0, 0);
+    }
+    // ---- softmax over the keys of query li: the lane holds keys 32 (j / 2) + 8 lg + 4 (j % 2) + r
+    const float scale2 = a.scale * 1.4426950408889634f;
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kidx = 32 * (j >> 1) + 8 * lg + 4 * (j & 1) + r - off;      // key index inside the sequence
+            if (kidx < 0 || kidx >= L || (a.causal && kidx > qidx)) sc[j][r] = -__builtin_huge_valf();
+            mx = fmaxf(mx, sc[j][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float msub = mx == -__builtin_huge_valf() ? 0.f : mx * scale2;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j][r], scale2, -msub));
+            sum += p;
+            sc[j][r] = p;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    // ---- O^T = V^T P^T
+    f32x4 o[NDT];
+#pragma unroll
+    for (int n = 0; n < NDT; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int J = 0; J < 2; ++J) {
+        union { bf16x8 v; unsigned u[4]; } pf;
+        pf.u[0] = pack2(sc[2 * J][0], sc[2 * J][1]);
+        pf.u[1] = pack2(sc[2 * J][2], sc[2 * J][3]);
+        pf.u[2] = pack2(sc[2 * J + 1][0], sc[2 * J + 1][1]);
+        pf.u[3] = pack2(sc[2 * J + 1][2], sc[2 * J + 1][3]);
+#pragma unroll
+        for (int n = 0; n < NDT; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[n][J], pf.v, o[n], 0, 0, 0);
+    }
+    if (qidx < L) {
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        const int tok = s0 + qidx;
+        // dims h HD + 16 n + 4 lg + r -> piece (step (h HD + 16 n) / 32, tile tok / 16), lane (2 (n & 1) + lg / 2, tok % 16), half lg & 1
+        bf16_t *op = a.Ofrag + (((size_t)(h * (HD / 32)) * a.frag_mt + (tok >> 4)) * 64 + (lg >> 1) * 16 + (tok & 15)) * 8 + 4 * (lg & 1);
+#pragma unroll
+        for (int n = 0; n < NDT; ++n) {
+            uint2 pk;
+            pk.x = pack2(o[n][0] * inv, o[n][1] * inv);
+            pk.y = pack2(o[n][2] * inv, o[n][3] * inv);
+            *reinterpret_cast<uint2 *>(op + ((size_t)(n >> 1) * a.frag_mt * 64 + (n & 1) * 32) * 8) = pk;
+        }
+    }
+}
+
 }  // namespace mienc

@@ -1887,11 +1887,14 @@ int mi_index_save(mi_index *h, const char *fname, const char *ondisk_data) {
     });
 }
 
-int mi_index_load(const char *fname, int device, mi_index **out) {
+int mi_index_load(const char *fname, int device, mi_index **out) { return mi_index_load_at(fname, 0, device, out); }
+
+int mi_index_load_at(const char *fname, int64_t offset, int device, mi_index **out) {
     mi_index *h = nullptr;
     int rc = guard([&] {
-        MI_REQUIRE(fname && out, "null argument");
+        MI_REQUIRE(fname && out && offset >= 0, "null argument");
         FileR r(fname);
+        if (offset) r.seek((uint64_t)offset);
         const std::string name(fname);
         const std::string cc = r.cc();
         if (cc == "IvPQ" || cc == "IvQR" || cc == "IwQR") throw Error(name + ": " + cc + " (legacy / refined IVFPQ) is not supported, only IwPQ");

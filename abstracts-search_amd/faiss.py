@@ -68,6 +68,7 @@ class _Lib:
                 "mi_index_reserve": [v, c_int64],
                 "mi_index_save": [v, c_char_p, c_char_p],
                 "mi_index_load": [c_char_p, c_int, POINTER(v)],
+                "mi_index_load_at": [c_char_p, c_int64, c_int, POINTER(v)],
                 "mi_index_get_params": [v, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                         POINTER(c_int), POINTER(c_int), POINTER(c_int)],
                 "mi_index_set_nprobe": [v, c_int],
@@ -951,6 +952,53 @@ def downcast_index(index):
 _MAGIC = "mi355x-ivfpq-v1"
 
 
+class IndexPreTransform:
+    """faiss.IndexPreTransform over LinearTransforms (OPQMatrix, RandomRotationMatrix, LinearTransform): x -> A x + b
+    applied (one small GEMM per transform, torch on the index's device) in front of train / add / search of the wrapped
+    index -- what `index_factory(d, "OPQ64,IVF65536,PQ64")` builds.  read_index returns one for an "IxPT" file."""
+
+    def __init__(self, chain, index):
+        self.chain = [(np.ascontiguousarray(A, np.float32), None if b is None else np.ascontiguousarray(b, np.float32)) for A, b in chain]
+        self.index = index
+        self.d = int(self.chain[0][0].shape[1]) if self.chain else index.d
+        self.metric_type = index.metric_type
+        self._dev = None
+
+    ntotal = property(lambda self: self.index.ntotal)
+    is_trained = property(lambda self: self.index.is_trained)
+    nprobe = property(lambda self: self.index.nprobe, lambda self, v: setattr(self.index, "nprobe", v))
+
+    def apply(self, x):
+        """VectorTransform::apply of the whole chain (numpy in -> numpy out, CUDA tensor in -> CUDA tensor out)."""
+        import torch
+        was_np = not _is_torch(x)
+        t = torch.as_tensor(np.ascontiguousarray(x, np.float32)) if was_np else x.float()
+        t = t.to(torch.device("cuda", self.index.device))
+        if self._dev is None:
+            self._dev = [(torch.from_numpy(A).to(t.device), None if b is None else torch.from_numpy(b).to(t.device)) for A, b in self.chain]
+        prev = torch.backends.cuda.matmul.allow_tf32
+        torch.backends.cuda.matmul.allow_tf32 = False
+        try:
+            for A, b in self._dev:
+                t = t @ A.T if b is None else torch.addmm(b, t, A.T)
+        finally:
+            torch.backends.cuda.matmul.allow_tf32 = prev
+        t = t.contiguous()
+        return t.cpu().numpy() if was_np else t
+
+    def train(self, x):
+        self.index.train(self.apply(x))
+
+    def add(self, x):
+        self.index.add(self.apply(x))
+
+    def search(self, x, k, **kw):
+        return self.index.search(self.apply(x), k, **kw)
+
+    def reset(self):
+        self.index.reset()
+
+
 def _lists_of(index):
     sizes = index.list_sizes()
     codes, ids = index.export_lists()
@@ -992,14 +1040,16 @@ def read_index(fname: str, device: int = 0):
     with open(fname, "rb") as f:
         head = f.read(4)
     if head != b"PK\x03\x04":
+        chain, offset = faiss_io.parse_pretransform(fname) if head == b"IxPT" else (None, 0)
         h = c_void_p()
-        rc = _Lib.get().mi_index_load(str(fname).encode(), int(device), ctypes.byref(h))
+        rc = _Lib.get().mi_index_load_at(str(fname).encode(), int(offset), int(device), ctypes.byref(h))
         if rc:
             msg = _Lib.get().mi_last_error().decode()
             if "no HIP device" in msg:
                 raise RuntimeError("mi_ivfpq: " + msg)
             raise faiss_io.FaissFormatError(msg)
-        return IndexIVFPQ._from_handle(h, device)
+        index = IndexIVFPQ._from_handle(h, device)
+        return index if chain is None else IndexPreTransform(chain, index)
     z = np.load(fname, allow_pickle=False)
     if str(z["magic"]) != _MAGIC:
         raise ValueError(f"{fname}: not a {_MAGIC} file")

@@ -112,6 +112,37 @@ def _write_header(f, d: int, ntotal: int, trained: bool, metric: int) -> None:
 # ----------------------------------------------------------------------
 # reading
 # ----------------------------------------------------------------------
+def parse_pretransform(fname: str):
+    """[PRIOR: faiss index_write.cpp as remembered; no faiss-written file has been read on any box of this pool]
+    An IndexPreTransform file: fourcc "IxPT", the index header, int32 chain length, then per VectorTransform a fourcc
+    ("LTra": LinearTransform / OPQMatrix, "rrot": RandomRotationMatrix), uint8 have_bias, vector<float> A [d_out x d_in],
+    vector<float> b, int32 d_in, int32 d_out, uint8 is_trained; then the sub-index.  Returns (chain, offset) with
+    chain = [(A [d_out, d_in] float32, b [d_out] float32 or None), ...] and the byte offset of the sub-index, or
+    (None, 0) when the file does not start with IxPT.  Other transforms (PCA with eigenvalues, ITQ, norm) are rejected."""
+    with open(fname, "rb") as fh:
+        r = _Reader(fh, fname)
+        if r.fourcc() != "IxPT":
+            return None, 0
+        _read_header(r)
+        nt = r.one("i")
+        if not 0 <= nt <= 8:
+            raise FaissFormatError(f"{fname}: implausible pre-transform chain length {nt}")
+        chain = []
+        for _ in range(nt):
+            cc = r.fourcc()
+            if cc not in ("LTra", "rrot"):
+                raise FaissFormatError(f"{fname}: vector transform {cc!r} is not supported (LinearTransform / OPQMatrix / RandomRotationMatrix only)")
+            have_bias = bool(r.one("B"))
+            A = r.vector(np.float32)
+            b = r.vector(np.float32)
+            d_in, d_out = r.one("i"), r.one("i")
+            r.one("B")
+            if A.size != d_in * d_out or (have_bias and b.size != d_out):
+                raise FaissFormatError(f"{fname}: transform {cc} is {d_out} x {d_in} but holds {A.size} + {b.size} floats")
+            chain.append((A.reshape(d_out, d_in).copy(), b.copy() if have_bias else None))
+        return chain, fh.tell()
+
+
 def parse(fname: str) -> dict:
     """Parse an IndexIVFPQ file into plain arrays (no GPU needed):
     d nlist M nbits metric by_residual nprobe is_trained ntotal,

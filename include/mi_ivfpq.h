@@ -113,6 +113,10 @@ int mi_index_reserve(mi_index *h, int64_t n);
  * The lists stream between HBM and the file in bounded slabs. */
 int mi_index_save(mi_index *h, const char *fname, const char *ondisk_data);
 int mi_index_load(const char *fname, int device, mi_index **out);
+/* The same with the IwPQ record starting `offset` bytes into the file: the sub-index of a faiss IndexPreTransform file
+ * ("IxPT": header, the VectorTransform chain, then the index -- sidecar-search's `index train` may wrap the IVF-PQ index
+ * in an OPQ rotation; faiss.py parses the chain and applies it to the vectors before add() / search()). */
+int mi_index_load_at(const char *fname, int64_t offset, int device, mi_index **out);
 /* Parameters of a handle (e.g. one returned by mi_index_load); any output may be NULL.
  * nprobe is faiss's index.nprobe attribute as stored in index files -- mi_index_search()
  * takes nprobe per call. */

@@ -136,3 +136,45 @@ def test_rejects_what_it_does_not_understand(tmp_path):
     f.write_bytes(bad_total)
     with pytest.raises(fio.FaissFormatError, match="header says 99"):
         fio.parse(str(f))
+
+
+def test_pretransform_chain_is_parsed(tmp_path):
+    """[PRIOR layout] an "IxPT" file -- header, chain of LinearTransforms (what OPQ is written as), then the IwPQ record:
+    parse_pretransform returns the matrices and the sub-index's offset, and what follows at that offset parses as the
+    index written alone.  (reference Makefile:12-13: whatever `sidecar-search index train` wrapped the index in.)"""
+    import struct
+    from abstracts_search_amd import faiss_io as fio
+    rng = np.random.default_rng(5)
+    d, d_in = 16, 24
+    A = rng.standard_normal((d, d_in)).astype(np.float32)
+    b = rng.standard_normal(d).astype(np.float32)
+    sub = str(tmp_path / "sub.faiss")
+    cent = rng.standard_normal((4, d)).astype(np.float32)
+    cb = rng.standard_normal((4, 256, 4)).astype(np.float32)
+    sizes = np.array([2, 0, 1, 0])
+    codes = rng.integers(0, 256, (3, 4)).astype(np.uint8)
+    ids = np.array([5, 6, 7], np.int64)
+    fio.dump(sub, d=d, nlist=4, M=4, nbits=8, metric=0, by_residual=True, nprobe=2, is_trained=True, centroids=cent, codebook=cb,
+             sizes=sizes, codes=codes, ids=ids)
+    f = str(tmp_path / "opq.faiss")
+    with open(f, "wb") as fh:
+        fh.write(b"IxPT")
+        fh.write(struct.pack("<iqqqBi", d_in, 3, 1 << 20, 1 << 20, 1, 0))
+        fh.write(struct.pack("<i", 2))
+        for M_, b_ in ((A, b), (np.eye(d, dtype=np.float32), None)):
+            fh.write(b"LTra" if b_ is not None else b"rrot")
+            fh.write(struct.pack("<B", b_ is not None))
+            fh.write(struct.pack("<Q", M_.size)); fh.write(M_.tobytes())
+            bb = b_ if b_ is not None else np.zeros(0, np.float32)
+            fh.write(struct.pack("<Q", bb.size)); fh.write(bb.tobytes())
+            fh.write(struct.pack("<iiB", M_.shape[1], M_.shape[0], 1))
+        fh.write(open(sub, "rb").read())
+    chain, off = fio.parse_pretransform(f)
+    assert len(chain) == 2 and np.array_equal(chain[0][0], A) and np.array_equal(chain[0][1], b) and chain[1][1] is None
+    assert open(f, "rb").read()[off:] == open(sub, "rb").read()
+    assert fio.parse_pretransform(sub) == (None, 0)
+    with open(f, "r+b") as fh:                                  # a transform this build does not implement: a named error
+        fh.seek(4 + 33 + 4)
+        fh.write(b"PcAm")
+    with pytest.raises(fio.FaissFormatError, match="PcAm"):
+        fio.parse_pretransform(f)

@@ -658,6 +658,35 @@ def test_write_read_roundtrip(faiss, tmp_path, kind):
     assert np.array_equal(I, I2) and np.array_equal(bits(D), bits(D2))
 
 
+def test_read_index_of_a_pretransform_file(faiss, tmp_path):
+    """[PRIOR layout] read_index of an "IxPT" file (an OPQ-style rotation in front of the IVF-PQ index, what
+    index_factory(d, "OPQ..,IVF..,PQ..") writes): the rotation is applied before the search, the IwPQ record is loaded from
+    its offset -- results equal the bare index searched with the rotated queries.  (reference Makefile:12-13.)"""
+    import struct
+    import torch
+    d, M, nlist = 64, 8, 16
+    cent, cb, x, q = random_problem(31, d, M, nlist, 3000, 12)
+    rng = np.random.default_rng(2)
+    R = np.linalg.qr(rng.standard_normal((d, d)))[0].astype(np.float32)
+    idx = make_index(faiss, cent, cb)
+    idx.add(x @ R.T)
+    idx.nprobe = 5
+    sub, f = str(tmp_path / "sub.faiss"), str(tmp_path / "opq.faiss")
+    faiss.write_index(idx, sub)
+    with open(f, "wb") as fh:
+        fh.write(b"IxPT" + struct.pack("<iqqqBi", d, idx.ntotal, 1 << 20, 1 << 20, 1, 0) + struct.pack("<i", 1))
+        fh.write(b"LTra" + struct.pack("<B", 0) + struct.pack("<Q", R.size) + R.tobytes() + struct.pack("<Q", 0) + struct.pack("<iiB", d, d, 1))
+        fh.write(open(sub, "rb").read())
+    pt = faiss.read_index(f)
+    assert isinstance(pt, faiss.IndexPreTransform) and pt.ntotal == idx.ntotal and pt.d == d
+    pt.nprobe = 5
+    D, I = pt.search(q, 10)
+    De, Ie = idx.search(pt.apply(q), 10)
+    assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De))
+    Dn, In = idx.search((torch.from_numpy(q).cuda() @ torch.from_numpy(R).cuda().T).cpu().numpy(), 10)
+    assert (I == In).mean() > 0.99                              # (the same rotation by another GEMM: rounding ties at most)
+
+
 def test_sparse_lists_through_the_c_abi_match_the_documented_layout(faiss, tmp_path):
     """A non-empty index with at most half of its lists filled takes faiss's 'sprs' size encoding:
     a vector of 2 * non_empty words ({list, size} pairs flattened).  The C ABI writer
