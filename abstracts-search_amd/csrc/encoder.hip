@@ -502,7 +502,7 @@ struct mi_encoder {
     };
     struct WS {
         std::mutex mu;
-        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_up, ws_out, ws_stage, ws_part;
+        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_up, ws_out, ws_stage, ws_part, few_ctr;
         Pinned pin[3];
         int pin_next = 0;
         size_t vt_zeroed = 0, att_zeroed = 0;
@@ -766,7 +766,8 @@ void few_set_attributes() {
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_gemm_kernel<FEW_QKV, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_gemm_kernel<FEW_GU, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_o_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_d_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_d_kernel<MT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_d_kernel<MT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 }
 
 // the weight pieces of every layer, built once per handle (and again after a load_tensor); caller holds h->mu
@@ -818,6 +819,17 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         d0.nslices = (d0.nk + d0.ks_per_slice - 1) / d0.ks_per_slice;
     }
     float *part = static_cast<float *>(ws.ws_part.reserve((size_t)d0.nslices * T_pad * H * 4));
+    // MI_FEW_D_FUSE=1: the down projection's reduction inside its own launch (write-through planes, one arrival counter per
+    // unit group, the last slice to arrive finishes the group's columns) instead of the few_row_kernel pass.  Measured and
+    // OFF by default: 13.2 us against 7.7 + 4.8 for the two launches (one query 1.265 vs 1.211 ms) -- the 8-byte
+    // write-through stores and the 80 KB the last arriver reads back past its L1 cost more than a kernel boundary, as the
+    // guide's splitk-seam row prices it.  Kept as the parity-tested alternative (tests run both).
+    const bool fuse_env = std::getenv("MI_FEW_D_FUSE") != nullptr;   // (read per call: tests toggle it)
+    const bool fuse_d = fuse_env && ugroups <= FEW_SSQ_LD * 3 && d0.nslices * d0.ks_per_slice >= d0.nk;
+    if (ws.few_ctr.cap < (size_t)ugroups * 4) {
+        MI_HIP(hipMemsetAsync(ws.few_ctr.reserve((size_t)ugroups * 4 + 1024), 0, (size_t)ugroups * 4 + 1024, st));
+    }
+    unsigned *ctr = ws.few_ctr.get<unsigned>();
     // MI_FEW_SYNC=1 (debugging): wait after every launch and name the stage on stderr
     static const bool dbg_sync = std::getenv("MI_FEW_SYNC") != nullptr;
     // MI_FEW_TS=1 (profiling): s_memtime stamps of every workgroup of the first layer's two fragment GEMMs, mean / max per phase
@@ -858,6 +870,7 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         Range layer_range("mi_encoder:layer");
         FewArgs q{};
         q.T = T; q.H = H; q.nk = H / 32; q.nunits = (h->qk_cols + h->v_cols) / 16; q.W = w.few_qkv.get<bf16_t>(); q.afrag = xfrag;
+        if (fuse_d && l > 0) { q.ssq = ssq; q.nparts = ugroups; }    // (the previous layer's down projection left bf16(x g) and partial sums of squares)
         q.eps = c.rms_eps; q.bias = w.bqkv.get<float>(); q.qk = qk; q.vt = vt;
         q.ldqk = h->qk_cols; q.ldvt = ldvt; q.qk_cols = h->qk_cols; q.hd = c.head_dim; q.rope_blocks = h->qk_cols / 16;
         q.pos = b.pos; q.cos_t = h->rope_cos.get<float>(); q.sin_t = h->rope_sin.get<float>();
@@ -893,7 +906,15 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         chk("gu");
         FewArgs d = d0;
         d.T = T; d.H = H; d.W = w.few_d.get<bf16_t>(); d.afrag = hfrag; d.part = part; d.T_pad = T_pad;
-        hipLaunchKernelGGL((few_d_kernel<MT>), dim3((unsigned)(ugroups * d.nslices)), dim3(256), (size_t)d.ks_per_slice * MT * 1024, st, d);
+        if (fuse_d) {
+            // the last slice of a unit group to arrive finishes the group's columns: no reduction launch
+            d.x = x; d.ctr = ctr; d.ssq_out = ssq; d.xfrag = xfrag;
+            d.norm_w = l + 1 < c.n_layers ? h->layers[l + 1].ln1.get<float>() : nullptr;
+            hipLaunchKernelGGL((few_d_kernel<MT, true>), dim3((unsigned)(ugroups * d.nslices)), dim3(256), (size_t)d.ks_per_slice * MT * 1024 + 16, st, d);
+            chk("d+reduce");
+            continue;
+        }
+        hipLaunchKernelGGL((few_d_kernel<MT, false>), dim3((unsigned)(ugroups * d.nslices)), dim3(256), (size_t)d.ks_per_slice * MT * 1024, st, d);
         chk("d");
         FewArgs r{};
         r.T = T; r.H = H; r.x = x; r.part = part; r.T_pad = T_pad; r.nslices = d.nslices; r.eps = c.rms_eps; r.xfrag = xfrag;

@@ -70,6 +70,7 @@ struct FewArgs {
     const float *cos_t, *sin_t;    // [max_seq][hd / 2]
     bf16_t *hfrag;                 // GU epilogue: h as fragments (K step of the down projection, token tile)
     float *part;                   // D: [nslices][T_pad][H] partial planes; reduce: the same, read
+    unsigned *ctr;                 // D (fused reduction): one arrival counter per unit group, zero between launches
     int T_pad;
     // embed
     const int32_t *ids;
@@ -231,9 +232,9 @@ __global__ void __launch_bounds__(64 * FEW_NW) few_gemm_kernel(FewArgs a) {
             pre_b = *reinterpret_cast<const f32x4 *>(a.bias + a.qk_cols + 16 * (eunit - a.rope_blocks) + 4 * lg);
         }
     }
-    constexpr int SQ = MODE == FEW_GU ? 32 : 1;                 // partials per wave requested at once (192 = H / 8 at H = 1536)
+    constexpr int SQ = MODE == FEW_GU ? 32 : 4;                 // partials per wave requested at once (GU: 192 = H / 8 from the O projection; QKV: 24 unit groups of the down projection)
     float sq[SQ];
-    if (MODE == FEW_GU && a.nparts > 0) {                       // wave w adds the partials w, w + 6, ... of token `lane`
+    if (a.nparts > 0) {                                         // wave w adds the partials w, w + 6, ... of token `lane`
 #pragma unroll
         for (int i = 0; i < SQ; ++i) sq[i] = a.ssq[min(w + FEW_NW * i, a.nparts - 1) * FEW_SSQ_LD + lane];
     }
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(64 * FEW_NW) few_gemm_kernel(FewArgs a) {
     bf16x8 ring[U][WN];
     few_ring_start<WN, U, 512>(wp, blk_stride, nsteps, ring);
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE == FEW_GU && a.nparts > 0) {
+    if (a.nparts > 0) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < SQ; ++i) s += w + FEW_NW * i < a.nparts ? sq[i] : 0.f;
@@ -427,19 +428,19 @@ __global__ void __launch_bounds__(64 * FEW_OW) few_o_kernel(FewArgs a) {
 // grid: (ceil(nunits / 4) unit groups) x nslices, 4 waves; wave w streams unit 4 ug + w over the slice, whose activation
 // fragments are staged in LDS once.   dynamic LDS: ks_per_slice x MT KiB
 // ---------------------------------------------------------------------------------------------------------------
-template <int MT>
+template <int MT, bool FUSE>
 __global__ void __launch_bounds__(256) few_d_kernel(FewArgs a) {
     constexpr int U = 14;
-    extern __shared__ __attribute__((aligned(16))) uint4 few_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint4 few_lds[];   // ks_per_slice x MT KiB of fragments | 16 B: the arrival ticket
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int nk = a.nk, T = a.T;
+    const int nk = a.nk, T = a.T, H = a.H;
     const int sl = (int)blockIdx.x % a.nslices, ug = (int)blockIdx.x / a.nslices;
-    const int k0 = sl * a.ks_per_slice, k1 = min(nk, k0 + a.ks_per_slice), nsteps = k1 - k0;
-    if (nsteps <= 0) return;
+    const int k0 = sl * a.ks_per_slice, k1 = min(nk, k0 + a.ks_per_slice), nsteps = max(k1 - k0, 1);   // (the host never leaves a slice empty)
     const int unit = ug * 4 + w;
     const bool live = unit < a.nunits;
+    unsigned &s_ticket = *reinterpret_cast<unsigned *>(few_lds + (size_t)a.ks_per_slice * MT * 64);   // (all LDS in the dynamic region: Guideline 17)
     const bf16_t *wp = a.W + ((size_t)min(unit, a.nunits - 1) * nk + k0) * 512 + lane * 8;
     const bf16_t *asrc = a.afrag + (size_t)k0 * MT * 512;
     i32x4_t av[7 * MT];                                          // the default slice (28 K steps) in one batch
@@ -450,18 +451,86 @@ __global__ void __launch_bounds__(256) few_d_kernel(FewArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     few_stage_store<4, 7 * MT>(av, asrc, few_lds, nsteps * MT, w, lane);
     __syncthreads();
-    if (!live) return;
     f32x4 acc[1][MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[0][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    few_stream<1, MT, U, 512>(wp, 0, nsteps, few_lds + lane, ring, acc);
-    float *plane = a.part + (size_t)sl * a.T_pad * a.H;
+    if (live) few_stream<1, MT, U, 512>(wp, 0, nsteps, few_lds + lane, ring, acc);
+    float *plane = a.part + (size_t)sl * a.T_pad * H;
+    if (live) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = 16 * mt + li;
-        if (m < T)
-            *reinterpret_cast<float4 *>(plane + (size_t)m * a.H + unit * 16 + lg * 4) =
-                make_float4(acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]);
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = 16 * mt + li;
+            if (m < T) {
+                float *pp = plane + (size_t)m * H + unit * 16 + lg * 4;
+                if constexpr (FUSE) {
+                    // write-through (sc1): the last arriver of this unit group reads the planes back past its L1, no fence on
+                    // either side (cdna_hip_programming.md Guideline 16, form R1; the index library's scan merges its slices so)
+                    typedef unsigned long long u64;
+                    __hip_atomic_store(reinterpret_cast<u64 *>(pp), ((u64)__float_as_uint(acc[0][mt][1]) << 32) | __float_as_uint(acc[0][mt][0]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(reinterpret_cast<u64 *>(pp + 2), ((u64)__float_as_uint(acc[0][mt][3]) << 32) | __float_as_uint(acc[0][mt][2]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    *reinterpret_cast<float4 *>(pp) = make_float4(acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]);
+                }
+            }
+        }
+    }
+    if constexpr (!FUSE) return;
+    // ---- the unit group's LAST slice to arrive completes the group's 64 columns of the stream: planes added in ascending
+    // slice order (whoever arrives last: the sum does not depend on it), residual add, and what the next QKV projection
+    // needs -- bf16(x g) fragments and this group's part of the rows' sums of squares (1 / rms rides on its accumulators)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its stores
+    __syncthreads();
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.ctr + ug, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != (unsigned)(a.nslices - 1)) return;
+    if (tid == 0) __hip_atomic_store(a.ctr + ug, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    const int c4 = tid & 15, col = ug * 64 + c4 * 4;            // 16 threads per row: 4 columns each
+    const bool colok = col < H;
+    const size_t plane_sz = (size_t)a.T_pad * H;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = (tid >> 4) + 16 * i;
+        const bool own = m < T && colok;
+        const size_t o = (size_t)min(m, T - 1) * H + min(col, H - 4);
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < a.nslices; s0 += 5) {             // five planes' loads in flight, added in ascending order
+            unsigned long long q[5][2];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const unsigned long long *pp = reinterpret_cast<const unsigned long long *>(a.part + (size_t)min(s0 + u, a.nslices - 1) * plane_sz + o);
+                q[u][0] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q[u][1] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+                if (s0 + u < a.nslices) {
+                    s4[0] += __uint_as_float((unsigned)q[u][0]); s4[1] += __uint_as_float((unsigned)(q[u][0] >> 32));
+                    s4[2] += __uint_as_float((unsigned)q[u][1]); s4[3] += __uint_as_float((unsigned)(q[u][1] >> 32));
+                }
+        }
+        f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float ss = 0.f;
+        if (own) {
+            xv = *reinterpret_cast<const f32x4 *>(a.x + o);
+            xv[0] += s4[0]; xv[1] += s4[1]; xv[2] += s4[2]; xv[3] += s4[3];
+            *reinterpret_cast<f32x4 *>(a.x + o) = xv;
+            ss = xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2] + xv[3] * xv[3];
+        }
+        ss = row16_sum(ss);                                      // the row's 16 threads are one DPP row
+        if (a.norm_w) {
+            if (c4 == 0 && m < 16 * MT) a.ssq_out[ug * FEW_SSQ_LD + m] = ss;   // (padding tokens: 0)
+            if (colok && m < 16 * MT) {
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(a.norm_w + col);
+                uint2 ov;
+                ov.x = pack2(xv[0] * g[0], xv[1] * g[1]);
+                ov.y = pack2(xv[2] * g[2], xv[3] * g[3]);
+                // columns col .. col + 3 of token m -> piece (K step col / 32, tile m / 16), lane ((col % 32) / 8, m % 16), half (col / 4) & 1
+                bf16_t *dst = a.xfrag + ((size_t)((col >> 5) * MT + (m >> 4)) * 64 + (((col & 31) >> 3) * 16 + (m & 15))) * 8 + 4 * ((col >> 2) & 1);
+                *reinterpret_cast<uint2 *>(dst) = ov;
+            }
+        }
     }
 }
 

@@ -530,7 +530,7 @@ def cfg4_workload(args, ctx):
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic, traffic_src = None, None
     try:                                                               # separate --pmc passes of this same command
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_cfg4_scan_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_cfg4_scan_pmc.json")))
         if (N, nlist, batch, nprobe, k, nsh) == tuple(pmc["config"]):
             traffic, traffic_src = int(pmc["corrected_bytes_per_launch"]), pmc["source"]
     except Exception:

@@ -302,13 +302,15 @@ def test_query_batches_at_stella_widths_vs_oracle(st, nq, layers):
 
 
 @pytest.mark.parametrize("lens", [[1], [3], [16], [17], [32], [33], [48], [5, 9, 20], [1] * 7, [16, 16, 16], [2, 46]])
-def test_few_token_path_at_stella_widths_vs_oracle(st, lens):
+def test_few_token_path_at_stella_widths_vs_oracle(st, lens, monkeypatch):
     """The query-time path (csrc/encoder_few.h: RMSNorm in the GEMM prologue, RoPE / SwiGLU / residual atomics in the
     epilogues, weights as 1-KiB pieces) for every token-tile count it serves (1..48 tokens = 1, 2 or 3 tiles of 16, the
     tile edges, several sequences in one pass) at stella's widths, 3 layers deep: last hidden state per token and the
     embedding against the fp32 oracle.  (reference README.md:28: one prompted query per call.)"""
     import torch
     from oracle import encoder_oracle as E
+    if len(lens) % 2 == 0:                                       # half the layouts through the in-launch reduction of the down projection
+        monkeypatch.setenv("MI_FEW_D_FUSE", "1")
     cfg = dict(st.STELLA_EN_1_5B_V5)
     cfg["vocab_size"], cfg["n_layers"] = 4096, 3
     W = _rand_weights_gpu(cfg, 77)
