@@ -906,7 +906,7 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         chk("gu");
         FewArgs d = d0;
         d.T = T; d.H = H; d.W = w.few_d.get<bf16_t>(); d.afrag = hfrag; d.part = part; d.T_pad = T_pad;
-        if (fuse_d) {
+        if (fuse_d && l + 1 < c.n_layers) {                  // (the last layer keeps the row kernel: the pooling tail wants the final norm)
             // the last slice of a unit group to arrive finishes the group's columns: no reduction launch
             d.x = x; d.ctr = ctr; d.ssq_out = ssq; d.xfrag = xfrag;
             d.norm_w = l + 1 < c.n_layers ? h->layers[l + 1].ln1.get<float>() : nullptr;
@@ -918,14 +918,15 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         chk("d");
         FewArgs r{};
         r.T = T; r.H = H; r.x = x; r.part = part; r.T_pad = T_pad; r.nslices = d.nslices; r.eps = c.rms_eps; r.xfrag = xfrag;
-        r.norm_w = l + 1 < c.n_layers ? h->layers[l + 1].ln1.get<float>() : nullptr;
+        r.norm_w = l + 1 < c.n_layers ? h->layers[l + 1].ln1.get<float>() : h->norm_w.get<float>();   // (last layer: the final norm, for the pooling tail)
         hipLaunchKernelGGL((few_row_kernel<false, MT>), dim3((unsigned)T), dim3(256), 0, st, r);
         chk("reduce");
     }
 }
 
 // the decoder stack: leaves the residual stream (before the final norm) in ws_x
-void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st) {
+// returns the token tiles (1..3) of a pass that took the query-time path -- its final-norm fragments are in ws_xn --, else 0
+int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st) {
     const mi_encoder_cfg &c = h->cfg;
     for (auto &kv : h->loaded) MI_REQUIRE(kv.second, std::string("encoder parameter not loaded: ") + kv.first);
     const int H = c.hidden, I = c.intermediate, T = b.T_pad, hd = c.head_dim;
@@ -976,7 +977,7 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         if (mt == 1) few_stack<1>(h, ws, b, x, qk, vt, ldvt, st);
         else if (mt == 2) few_stack<2>(h, ws, b, x, qk, vt, ldvt, st);
         else few_stack<3>(h, ws, b, x, qk, vt, ldvt, st);
-        return;
+        return mt;
     }
     // few tokens (a query, or a handful): the GEMMs stream the weights once and are bound by how
     // they read them -- use the fragment-major copies (a second copy of the layer weights, built
@@ -1048,6 +1049,7 @@ void run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st
         }
         normed = (timed_gemm(h, EPI_RESID, d, st) & GEMM_NORMED) != 0;
     }
+    return 0;
 }
 
 }  // namespace
@@ -1216,10 +1218,25 @@ void encode_impl(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu,
         const bool od_dev = is_device_ptr(out);
         MI_REQUIRE(!out_rows || od_dev, "encode: out_rows needs a device output");
         Batch b = prepare_batch(h, ws, nseq, ids, cu, out_rows, st);
-        run_stack(h, ws, b, st);
+        const int few_mt = run_stack(h, ws, b, st);
         Range pool_range("mi_encoder:pool+dense+normalise");
         const mi_encoder_cfg &c = h->cfg;
         const int od = c.dense_out ? c.dense_out : c.hidden;
+        static const bool few_pool_off = std::getenv("MI_NO_FEW_POOL") != nullptr;
+        if (few_mt && c.dense_out && c.hidden <= 2048 && od_dev && !few_pool_off) {
+            // the query-time tail: pooling from the final-norm fragments + Dense, then normalise + place the row (two launches)
+            float *raw = ws.ws_out.as<float>((size_t)nseq * od);
+            FewPoolArgs p{};
+            p.xfrag = ws.ws_xn.get<bf16_t>(); p.MT = few_mt; p.H = c.hidden; p.out_dim = od;
+            p.parts = std::max(1, std::min(od / 16, 256 / std::max(1, nseq)));
+            p.seq_start = b.seq_start; p.seq_len = b.seq_len; p.dense_w = h->dense_w.get<bf16_t>(); p.dense_b = h->dense_b.get<float>();
+            p.raw = raw;
+            hipLaunchKernelGGL(few_pool_kernel, dim3((unsigned)nseq, (unsigned)p.parts), dim3(256), 0, st, p);
+            MI_HIP(hipGetLastError());
+            hipLaunchKernelGGL(few_finish_kernel, dim3((unsigned)nseq), dim3(256), 0, st, raw, od, normalize, out_rows ? b.out_rows : nullptr, out);
+            MI_HIP(hipGetLastError());
+            return;
+        }
         float *o = (od_dev && !out_rows) ? out : ws.ws_out.as<float>((size_t)nseq * od);
         auto finish = [&] {
             if (out_rows) {

@@ -711,4 +711,97 @@ __global__ void __launch_bounds__(64) few_attn_kernel(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The tail of a query-time pass: mean pooling of the final-norm fragments, Dense, and the row's L2 normalisation.
+// few_pool_kernel, grid (nseq, parts): every workgroup pools its sequence (the bf16 normalised hidden states arrive as
+// fragments from the last few_row_kernel: T x H x 2 bytes instead of two passes over the f32 stream; four accumulators by
+// token mod 4 and a bf16-rounded mean, the rounding points of pool_kernel / meanpool_kernel) and multiplies its share of
+// the Dense rows; few_finish_kernel normalises the row and writes it where the caller wants it.   H <= 2048.
+// ---------------------------------------------------------------------------------------------------------------
+struct FewPoolArgs {
+    const bf16_t *xfrag;           // [H / 32][MT] KiB: bf16(x / rms * g_final)
+    int MT, H, out_dim, parts;
+    const int32_t *seq_start, *seq_len;
+    const bf16_t *dense_w;         // [out_dim][H]
+    const float *dense_b;          // [out_dim] or null
+    float *raw;                    // [nseq][out_dim]
+};
+
+__global__ void __launch_bounds__(256) few_pool_kernel(FewPoolArgs a) {
+    __shared__ float pooled[2048];
+    const int seq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s0 = a.seq_start[seq], L = a.seq_len[seq], H = a.H;
+    if (tid < H / 8) {                                           // thread = 8 columns 8 tid ..: piece tid / 4, lane group tid & 3
+        float acc[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[u][q] = 0.f;
+        const bf16_t *base = a.xfrag + ((size_t)(tid >> 2) * a.MT * 64 + (tid & 3) * 16) * 8;
+        for (int t0 = 0; t0 < L; t0 += 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = s0 + min(t0 + u, L - 1);
+                v[u] = *reinterpret_cast<const uint4 *>(base + ((size_t)(t >> 4) * 64 + (t & 15)) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t0 + u < L) {
+                    const unsigned x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[u][2 * q] += __uint_as_float(x[q] << 16);
+                        acc[u][2 * q + 1] += __uint_as_float(x[q] & 0xffff0000u);
+                    }
+                }
+        }
+        const float invL = 1.0f / (float)max(L, 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pooled[tid * 8 + q] = bf2f(f2bf(((acc[0][q] + acc[1][q]) + (acc[2][q] + acc[3][q])) * invL));
+    }
+    __syncthreads();
+    const int per = (a.out_dim + a.parts - 1) / a.parts;
+    const int j0 = blockIdx.y * per, j1 = min(a.out_dim, j0 + per);
+    for (int j = j0 + w * 4; j < j1; j += 16) {                 // four Dense rows per wave step: four weight streams in flight
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane * 8; c < H; c += 512) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(a.dense_w + (size_t)min(j + r, j1 - 1) * H + c);
+                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[r] += pooled[c + 2 * q] * __uint_as_float(u[q] << 16);
+                    acc[r] += pooled[c + 2 * q + 1] * __uint_as_float(u[q] & 0xffff0000u);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = wave_sum(acc[r]);
+            if (lane == 0 && j + r < j1) a.raw[(size_t)seq * a.out_dim + j + r] = t + (a.dense_b ? a.dense_b[j + r] : 0.f);
+        }
+    }
+}
+
+// out[rows[seq]][:] = raw[seq][:] (/ its L2 norm)
+__global__ void __launch_bounds__(256) few_finish_kernel(const float *__restrict__ raw, int n, int normalize,
+                                                         const int32_t *__restrict__ rows, float *__restrict__ out) {
+    __shared__ float red[4];
+    const float *r = raw + (size_t)blockIdx.x * n;
+    float *d = out + (size_t)(rows ? rows[blockIdx.x] : (int)blockIdx.x) * n;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float scale = 1.f;
+    if (normalize) {
+        float ss = 0.f;
+        for (int c = tid; c < n; c += 256) ss += r[c] * r[c];
+        ss = wave_sum(ss);
+        if (lane == 0) red[w] = ss;
+        __syncthreads();
+        scale = 1.0f / fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);   // torch.nn.functional.normalize eps
+    }
+    for (int c = tid; c < n; c += 256) d[c] = r[c] * scale;
+}
+
 }  // namespace mienc

@@ -219,6 +219,7 @@ def main():
                     help="abstracts per encode step (default 128); 0 = the library's own batching: as many abstracts as fit "
                          "32 768 padded tokens per forward pass (~135; +1 % tokens/s: every GEMM fills whole rounds of the CUs)")
     ap.add_argument("--encode-steps", type=int, default=24, help="cfg4 line: encode steps (x encode-batch abstracts)")
+    ap.add_argument("--encode-streams", type=int, default=1, help="encode steps issued round-robin on this many HIP streams")
     ap.add_argument("--multi-gpu-mode", choices=["shards", "replicas"], default="shards",
                     help="N>1: shards = vector-sharded index + one all-gather of top-k (default, the north star's "
                          "layout); replicas = query-parallel, no collective")
@@ -1184,9 +1185,17 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True, pack=None):
     ntok = [sum(len(t) for t in b) for b in batches]
     nabs = [len(b) for b in batches]
 
+    # batches are independent: like the search loops, steps may be issued round-robin on S streams (the library keeps a
+    # workspace set per stream) -- the partial last round of one batch's GEMM tiles then shares the chip with the other's
+    ES = max(1, args.encode_streams)
+    estreams = [torch.cuda.Stream(device=dev) for _ in range(ES)] if ES > 1 else None
+
     def step(i):
         b = batches[i % NBATCH]
-        return model.encode_tokens(b, batch_size=len(b), normalize_embeddings=True, as_tensor=True)
+        if estreams is None:
+            return model.encode_tokens(b, batch_size=len(b), normalize_embeddings=True, as_tensor=True)
+        with torch.cuda.stream(estreams[i % ES]):
+            return model.encode_tokens(b, batch_size=len(b), normalize_embeddings=True, as_tensor=True)
 
     dt, blocks, _ = clock.measure(step, steps, max(warmup, 1))
     toks = sum(ntok[(warmup + i) % NBATCH] for i in range(steps))
