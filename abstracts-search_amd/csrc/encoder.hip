@@ -813,7 +813,8 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
     d0.nk = I / 32; d0.nunits = H / 16;
     const int ugroups = (d0.nunits + 3) / 4;
     {
-        const int ns = std::max(1, std::min(d0.nk, (248 + ugroups / 2) / ugroups));
+        static const int d_wgs = std::getenv("MI_FEW_D_WGS") ? std::atoi(std::getenv("MI_FEW_D_WGS")) : 248;   // workgroups the down projection aims at
+        const int ns = std::max(1, std::min(d0.nk, (d_wgs + ugroups / 2) / ugroups));
         d0.ks_per_slice = (d0.nk + ns - 1) / ns;
         while ((size_t)d0.ks_per_slice * MT * 1024 > 128 * 1024) d0.ks_per_slice = (d0.ks_per_slice + 1) / 2;
         d0.nslices = (d0.nk + d0.ks_per_slice - 1) / d0.ks_per_slice;

@@ -191,7 +191,10 @@ __device__ __forceinline__ void few_stage_store(i32x4_t (&av)[AB], const bf16_t 
 template <int MODE, int MT>
 __global__ void __launch_bounds__(64 * FEW_NW) few_gemm_kernel(FewArgs a) {
     constexpr int WN = MODE == FEW_GU ? 2 : 1;
-    constexpr int U = MODE == FEW_GU ? (MT == 3 ? 12 : 16) : 8;   // K steps in flight per wave: ALL of a 2-unit workgroup's (the memory pipe of the CU must never idle: 47 GB/s is all it has)
+#ifndef FEW_U_GU
+#define FEW_U_GU 16
+#endif
+    constexpr int U = MODE == FEW_GU ? (MT == 3 ? 12 : FEW_U_GU) : 8;   // K steps in flight per wave: ALL of a 2-unit workgroup's (the memory pipe of the CU must never idle: 47 GB/s is all it has)
     extern __shared__ __attribute__((aligned(16))) uint4 few_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -430,7 +433,10 @@ __global__ void __launch_bounds__(64 * FEW_OW) few_o_kernel(FewArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 template <int MT, bool FUSE>
 __global__ void __launch_bounds__(256) few_d_kernel(FewArgs a) {
-    constexpr int U = 14;
+#ifndef FEW_U_D
+#define FEW_U_D 14
+#endif
+    constexpr int U = FEW_U_D;
     extern __shared__ __attribute__((aligned(16))) uint4 few_lds[];   // ks_per_slice x MT KiB of fragments | 16 B: the arrival ticket
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

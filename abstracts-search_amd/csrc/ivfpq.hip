@@ -1945,12 +1945,27 @@ int mi_index_load_at(const char *fname, int64_t offset, int device, mi_index **o
                     if (n != nlist) throw Error(name + ": " + std::to_string(n) + " list sizes for " + std::to_string(nlist) + " lists");
                     r.raw(sizes.data(), (size_t)n * 8);
                 } else if (kind == "sprs") {
-                    if (n % 2 || n / 2 > nlist) throw Error(name + ": sparse list sizes are " + std::to_string(n) + " words (pairs expected)");
-                    for (uint64_t i = 0; i < n / 2; ++i) {
-                        const uint64_t l = r.one<uint64_t>(), k = r.one<uint64_t>();
-                        if (l >= nlist) throw Error(name + ": sparse list number out of range");
-                        sizes[(size_t)l] = k;
+                    // faiss: the count is that of the flattened words (2 per non-empty list).  Files written by this library
+                    // before round 3's fix carry the number of PAIRS there: told apart by which reading adds up to ntotal
+                    const off_t at = ftello(r.f);
+                    auto read_pairs = [&](uint64_t npairs) -> bool {
+                        std::fill(sizes.begin(), sizes.end(), 0);
+                        uint64_t sum = 0;
+                        for (uint64_t i = 0; i < npairs; ++i) {
+                            const uint64_t l = r.one<uint64_t>(), k = r.one<uint64_t>();
+                            if (l >= nlist) return false;
+                            sizes[(size_t)l] = k;
+                            sum += k;
+                        }
+                        return sum == (uint64_t)ih.ntotal;
+                    };
+                    bool ok = n % 2 == 0 && n / 2 <= nlist && read_pairs(n / 2);
+                    if (!ok && n <= nlist) {                             // the legacy count
+                        r.seek((uint64_t)at);
+                        ok = read_pairs(n);
                     }
+                    if (!ok) throw Error(name + ": sparse list sizes (" + std::to_string(n) + " words) do not add up to ntotal " +
+                                         std::to_string(ih.ntotal) + " under faiss's layout nor under this library's pre-round-3 one: re-save the index");
                 } else throw Error(name + ": list size encoding '" + kind + "'");
             } else {
                 ondisk = true;
@@ -2364,15 +2379,19 @@ int mi_flat_get_rows(mi_flat *h, int64_t n, const int64_t *ids, void *out) {
             hi = hid.data();
         }
         for (int64_t i = 0; i < n; ++i) MI_REQUIRE(hi[i] >= 0 && hi[i] < h->ntotal, "mi_flat_get_rows: id out of range");
-        // the test / parity hook of the stores (no kernel: n row copies grouped into runs of consecutive ids)
-        const char *base = h->base.get<char>();
-        char *dst = static_cast<char *>(out);
-        for (int64_t i = 0; i < n;) {
-            int64_t j = i + 1;
-            while (j < n && hi[j] == hi[j - 1] + 1) ++j;
-            MI_HIP(hipMemcpy(dst + (size_t)i * row, base + (size_t)hi[i] * row, (size_t)(j - i) * row, hipMemcpyDefault));
-            i = j;
+        // a gather kernel into a device buffer, then one copy (a sample of a 212 GB store is a few hundred thousand rows)
+        DevBuf dids, dout;
+        const int64_t *d_ids = ids;
+        if (!is_device_ptr(ids)) {
+            MI_HIP(hipMemcpy(dids.reserve((size_t)n * 8), hi, (size_t)n * 8, hipMemcpyHostToDevice));
+            d_ids = dids.get<int64_t>();
         }
+        const bool od = is_device_ptr(out);
+        unsigned char *dst = od ? static_cast<unsigned char *>(out) : static_cast<unsigned char *>(dout.reserve((size_t)n * row));
+        hipLaunchKernelGGL(gather_rows_bytes_kernel, dim3((unsigned)n), dim3(256), 0, nullptr, h->base.get<unsigned char>(), row, d_ids, dst);
+        MI_HIP(hipGetLastError());
+        if (!od) MI_HIP(hipMemcpy(out, dst, (size_t)n * row, hipMemcpyDeviceToHost));
+        else MI_HIP(hipStreamSynchronize(nullptr));
     });
 }
 

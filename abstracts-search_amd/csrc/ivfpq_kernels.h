@@ -2697,6 +2697,20 @@ __global__ void __launch_bounds__(256)
     if (i < n) atomicAdd(&cnt[list_no[i]], 1);
 }
 
+// out[i][:] = base[ids[i]][:], rows of `row_bytes` bytes (mi_flat_get_rows: the stored bytes of a sample of a store).
+// One workgroup per row; 16-byte pieces when the row size allows, bytes otherwise.
+__global__ void __launch_bounds__(256) gather_rows_bytes_kernel(const unsigned char *__restrict__ base, size_t row_bytes,
+                                                                const int64_t *__restrict__ ids, unsigned char *__restrict__ out) {
+    const unsigned char *src = base + (size_t)ids[blockIdx.x] * row_bytes;
+    unsigned char *dst = out + (size_t)blockIdx.x * row_bytes;
+    if ((row_bytes & 15) == 0) {
+        for (size_t o = (size_t)threadIdx.x * 16; o < row_bytes; o += 256 * 16)
+            *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(src + o);
+    } else {
+        for (size_t o = threadIdx.x; o < row_bytes; o += 256) dst[o] = src[o];
+    }
+}
+
 __global__ void __launch_bounds__(256) iota_ids_kernel(int64_t *__restrict__ ids, int64_t n, int64_t start) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) ids[i] = start + i;

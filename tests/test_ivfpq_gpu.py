@@ -721,7 +721,13 @@ def test_sparse_lists_through_the_c_abi_match_the_documented_layout(faiss, tmp_p
         assert idx2.ntotal == len(lists)
         D2, I2 = idx2.search(q, 10)
         assert np.array_equal(I, I2) and np.array_equal(bits(D), bits(D2))
-    # an odd word count cannot be a list of pairs
+    # a file this library wrote before round 3's fix (the count was the number of PAIRS): recognised by which reading of the
+    # count adds up to ntotal, and loaded
+    open(f, "wb").write(raw.replace(b"sprs" + np.uint64(6).tobytes(), b"sprs" + np.uint64(3).tobytes()))
+    idx3 = faiss.read_index(f)
+    D3, I3 = idx3.search(q, 10)
+    assert idx3.ntotal == len(lists) and np.array_equal(I, I3) and np.array_equal(bits(D), bits(D3))
+    # a count that fits neither reading: a named error
     bad = raw.replace(b"sprs" + np.uint64(6).tobytes(), b"sprs" + np.uint64(5).tobytes())
     open(f, "wb").write(bad)
     with pytest.raises(Exception):
