@@ -178,6 +178,31 @@ def test_model_directory_and_text_encode(st, tmp_path):
         model.encode(docs[0], prompt_name="nope")
 
 
+def test_model_named_by_its_hub_id_loads_from_the_cache(st, tmp_path, monkeypatch):
+    """SentenceTransformer("NovaSearch/stella_en_1.5B_v5") the way the reference names its model (README.md:28
+    MODEL_NAME=..., README.md:60 SIDECARSEARCH_MODEL=...): the id resolves through the Hugging Face cache layout
+    (models--org--name/snapshots/<rev>, refs/main) with the hub offline, and encodes exactly like the directory itself."""
+    from oracle import encoder_oracle as E
+    from helpers_modeldir import write_model_dir
+    cfg = E.TINY
+    W = E.synth_weights(cfg, 12)
+    rev = "89ab" * 10
+    repo = tmp_path / "hub" / "models--NovaSearch--stella_en_1.5B_v5"
+    snap = repo / "snapshots" / rev
+    write_model_dir(snap, cfg, W, max_seq_length=32)
+    (repo / "refs").mkdir()
+    (repo / "refs" / "main").write_text(rev)
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    by_id = st.SentenceTransformer("NovaSearch/stella_en_1.5B_v5", trust_remote_code=True, cache_folder=str(tmp_path / "hub"))
+    by_dir = st.SentenceTransformer(str(snap), trust_remote_code=True)
+    docs = ["w1 w2 w3 w4", "w9 w8"]
+    a = by_id.encode(docs, prompt_name="s2p_query", normalize_embeddings=True)
+    b = by_dir.encode(docs, prompt_name="s2p_query", normalize_embeddings=True)
+    assert a.shape == (2, cfg.dense_out) and np.array_equal(a, b)
+    with pytest.raises(FileNotFoundError, match="Hugging Face cache"):
+        st.SentenceTransformer("NovaSearch/not_there", cache_folder=str(tmp_path / "hub"))
+
+
 def _rand_weights_gpu(cfg, seed):
     """random-init bf16 weights of a given architecture, generated on the GPU"""
     import torch
