@@ -29,13 +29,22 @@ std::atomic<int64_t> g_tail_split_launches{0};
 std::atomic<int64_t> g_splitk_launches{0};
 std::atomic<int64_t> g_reduce_norm_launches{0};
 std::atomic<int64_t> g_n192_launches{0};
+std::atomic<int64_t> g_fused_norm_launches{0};   // residual slab GEMMs whose epilogue carried the next RMSNorm (GEMM_RAWNORM)
+std::atomic<int64_t> g_fused_rope_launches{0};   // QKV slab GEMMs whose epilogue rotated Q and K
 std::atomic<int64_t> g_few_passes{0};     // forward passes that took the query-time path (encoder_few.h)
 
 struct LayerW {
     DevBuf wqkv, bqkv, wo, wgu, wd, ln1, ln2;
     DevBuf wqkv_t, wo_t, wgu_t, wd_t;   // fragment-major copies for the general path's few-token tiles (MI_NO_FEW=1; built lazily)
     DevBuf few_qkv, few_o, few_gu, few_d;   // 1-KiB pieces of the query-time path (encoder_few.h; built lazily)
+    DevBuf wqkv_r, bqkv_r;                  // Q / K rows interleaved by rotary pair: the many-token path's QKV epilogue rotates in place (built lazily)
 };
+
+// what a GEMM launch did besides the GEMM (launch_gemm's return value)
+enum { GEMM_NORMED = 1,      // a split-K reduction pass also wrote the RMSNorm of the updated stream (GemmArgs::norm_w / norm_y)
+       GEMM_ROPED = 2,       // the QKV epilogue (or its reduction pass) rotated Q and K
+       GEMM_RAWNORM = 4 };   // the residual epilogue wrote bf16(X * norm_w) and the rows' partial sums of squares
+                             // (GemmArgs::ssq_out; the number of slots per row in bits 8..15)
 
 template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
 void launch_ring(int epi, GemmArgs g, hipStream_t st) {
@@ -99,7 +108,7 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
 
 // 256x256 tiles, slab ring + hand-ordered K loop (gemm_bf16_slab_kernel; WN_ = 4: 8 waves, 2: 4 waves): whole-K workgroups, the same wave-quantisation tail split
 template <int WN_>
-bool launch_slab(int epi, GemmArgs g, hipStream_t st) {
+int launch_slab(int epi, GemmArgs g, hipStream_t st) {
     g.tiles_m = (g.M + 255) / 256;
     g.tiles_n = (g.N + 255) / 256;
     const int per = (g.tiles_m * g.tiles_n + 7) / 8;
@@ -136,7 +145,11 @@ bool launch_slab(int epi, GemmArgs g, hipStream_t st) {
                 if (gain > best_gain) { best_gain = gain; best = sp; }
             }
             if (std::getenv("MI_TAIL_SPLIT_FORCE") && sp_max >= 2) best = sp_max;   // tests: the split whatever the model says
+            // the split tail meets in f32 atomics: no workgroup sees the finished rows, so the fused RMSNorm (ssq_out) and the
+            // split exclude each other -- the fusion saves ~30 us a launch, the split has to buy more than that
+            if (best >= 2 && g.ssq_out && best_gain < 40.0 && !std::getenv("MI_TAIL_SPLIT_FORCE")) best = 1;
             if (best >= 2) {
+                g.ssq_out = nullptr;
                 g.tail_first = main_b;
                 g.tail_split = best;
                 nblocks = (unsigned)(main_b + rem * best);
@@ -165,6 +178,10 @@ bool launch_slab(int epi, GemmArgs g, hipStream_t st) {
         }
     }
     dim3 grid(nblocks), block(128 * WN_);
+    constexpr int CW = 16 * (16 / WN_);                   // columns per wave = per slot of sums of squares
+    const int nslots = (g.N + CW - 1) / CW;
+    if (split_all > 1 || nslots > SSQ_LD) g.ssq_out = nullptr;
+    const int rawnorm = epi == EPI_RESID && g.ssq_out ? (GEMM_RAWNORM | nslots << 8) : 0;
     bool normed = false;                                  // the reduction pass also wrote the RMSNorm the caller asked for
     auto finish_split = [&] {
         if (split_all == 1) return;
@@ -197,7 +214,8 @@ bool launch_slab(int epi, GemmArgs g, hipStream_t st) {
             default: throw Error("bad epilogue");
         }
         MI_HIP(hipGetLastError());
-        return false;
+        MI_REQUIRE(!g.row_scale && !g.ssq_out && !g.rope_cs, "persistent slab GEMM: no fused RMSNorm / rotary epilogues");
+        return 0;
     }
     switch (epi) {
         case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_STORE, WN_>), grid, block, 0, st, g); break;
@@ -208,12 +226,14 @@ bool launch_slab(int epi, GemmArgs g, hipStream_t st) {
     }
     MI_HIP(hipGetLastError());
     finish_split();
-    return normed;
+    if (rawnorm) ++g_fused_norm_launches;
+    if (epi == EPI_QKV && g.rope_cs) ++g_fused_rope_launches;
+    return (normed ? GEMM_NORMED : 0) | rawnorm | (epi == EPI_QKV && g.rope_cs ? GEMM_ROPED : 0);
 }
 
 // 256 x 192 tiles of the slab kernel (residual epilogue): N = 1536 is 8 tile columns instead of 6 -- at 5 400 .. 8 192
 // tokens that is one full round of <= 256 workgroups where 256-column tiles leave a quarter of the CUs idle
-void launch_slab_n192(GemmArgs g, hipStream_t st) {
+int launch_slab_n192(GemmArgs g, hipStream_t st) {
     g.tiles_m = (g.M + 255) / 256;
     g.tiles_n = (g.N + 191) / 192;
     const int per = (g.tiles_m * g.tiles_n + 7) / 8;
@@ -223,9 +243,14 @@ void launch_slab_n192(GemmArgs g, hipStream_t st) {
     g.part = nullptr;
     g.stagger = 0;
     g.order = g.tiles_n <= 16 ? 1 : 0;
+    const int nslots = (g.N + 95) / 96;
+    if (nslots > SSQ_LD) g.ssq_out = nullptr;
+    const int rawnorm = g.ssq_out ? (GEMM_RAWNORM | nslots << 8) : 0;
     hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, 2, false, 6>), dim3(8u * per), dim3(256), 0, st, g);
     MI_HIP(hipGetLastError());
     ++g_n192_launches;
+    if (rawnorm) ++g_fused_norm_launches;
+    return rawnorm;
 }
 
 // whether 192-column tiles beat 256-column tiles for this residual GEMM: rounds of workgroups on 256 CUs, a 192-column
@@ -320,7 +345,15 @@ bool mid_split_pays(const GemmArgs &g) {
     return g.M > 64 && g.K >= min_k && S >= 2 && ntiles * S >= min_wg && (size_t)S * g.M * g.N * 4 <= g.part_bytes;
 }
 
-enum { GEMM_NORMED = 1, GEMM_ROPED = 2 };
+
+// whether launch_gemm sends this GEMM to the 256 x 256 slab kernel with whole-K tiles (the many-token path): the shapes whose
+// epilogues carry the fused RMSNorm / rotary embedding
+bool slab_whole_k(int epi, const GemmArgs &g) {
+    const long tiles_big = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+    if (tiles_big < 100 || !(epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) return false;
+    // (read per call: the tests switch the knobs inside one process)
+    return !(std::getenv("MI_GEMM_TILE") || std::getenv("MI_GEMM_RING") || std::getenv("MI_GEMM_PERSIST") || std::getenv("MI_NO_BULK_FUSE"));
+}
 
 // A few hundred tokens through the K = 1536 projections (QKV, O): 128 x 128 tiles are too few to fill the chip (80 / 60 at
 // 576 tokens) and a CU's memory pipe bounds what one workgroup can pull (~590 KB per 128 x 64 x 1536 tile: 17-19 us a launch,
@@ -384,6 +417,12 @@ int launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         std::string cfg = force ? std::string(force) : "";
         if (cfg.empty()) cfg = g.M <= 64 ? "tiny" : tiles_big >= 100 ? "big" : tiles_mid >= 150 ? "mid" : "small";
         g.ksplit = 1;
+        // the fused RMSNorm / rotary epilogues live in the whole-K slab kernel only: a consumer that asks for them anywhere
+        // else is a caller's error (its A operand is not normalised); a producer's request is just dropped
+        MI_REQUIRE((!g.row_scale && !g.rope_cs) || (slab_whole_k(epi, g) && (epi == EPI_QKV || epi == EPI_SWIGLU)),
+                   "encoder GEMM: fused RMSNorm / rotary epilogue requested on a shape the slab kernel does not take");
+        if (!(epi == EPI_RESID && slab_whole_k(epi, g) && g.norm_w && g.norm_y && g.N % 64 == 0 && g.N <= 64 * SSQ_LD && g.ldc == g.N && !g.bias))
+            g.ssq_out = nullptr;
         const bool split_k = !force && epi == EPI_RESID && g.part && g.N % 8 == 0 && mid_split_pays(g) && !std::getenv("MI_NO_SPLITK");
         if (!force && cfg == "small" && g.M > 64 && g.K < 4096 && g.part) {
             const int fl = launch_mid_part(epi, g, st);
@@ -412,14 +451,14 @@ int launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             // workspace (launch_slab) -- 576 x 1536 x 8960: 18 tiles x 14 slices = 252 workgroups of 20 K steps + one reduction
             // pass, where 128x128 tiles with K split three ways by f32 atomics took 76 us; at 1558 / 2097 tokens the forward
             // pass went 7.91 -> 6.46 / 9.21 -> 7.82 ms against the 128x128 ring tiles
-            return launch_slab<2>(epi, g, st) ? GEMM_NORMED : 0;
+            return launch_slab<2>(epi, g, st);
         } else if (cfg == "big" && !force && epi == EPI_RESID && n192_pays(g) && !std::getenv("MI_NO_N192")) {
-            launch_slab_n192(g, st);
+            return launch_slab_n192(g, st);
         } else if (cfg == "big" && !std::getenv("MI_GEMM_RING") && (epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {   // the slab kernel stores 8 bf16 columns per lane
             // measured (tools/gemm_bench.py, 32768 tokens): 8 waves 1051 / 1060 TF on QKV / O, 4 waves 1106 / 1303 on
             // gate-up / down (ring kernel: 968 / 952 / 1006 / 1166)
-            if (epi == EPI_SWIGLU || g.K >= 4096) launch_slab<2>(epi, g, st);
-            else launch_slab<4>(epi, g, st);
+            if (epi == EPI_SWIGLU || g.K >= 4096) return launch_slab<2>(epi, g, st);
+            return launch_slab<4>(epi, g, st);
         } else if (cfg == "big" || cfg == "big32") {
             launch_ring<8, 4, 2, 4, 4>(epi, g, st);
         } else if (cfg == "mid") {
@@ -482,7 +521,7 @@ struct mi_encoder {
     mi_encoder_cfg cfg{};
     int device = 0;
     int qk_cols = 0, v_cols = 0, q_cols = 0;
-    DevBuf embed, norm_w, dense_w, dense_b, rope_cos, rope_sin;
+    DevBuf embed, norm_w, dense_w, dense_b, rope_cos, rope_sin, rope_cs;   // rope_cs: [pos][pair] (cos, sin) for the fused QKV epilogue
     std::vector<LayerW> layers;
     std::map<std::string, bool> loaded;
     // activations and staging buffers, one set per stream an encode is issued on: calls on different streams overlap on
@@ -502,7 +541,7 @@ struct mi_encoder {
     };
     struct WS {
         std::mutex mu;
-        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_up, ws_out, ws_stage, ws_part, few_ctr;
+        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_up, ws_out, ws_stage, ws_part, ws_ssq, few_ctr;
         Pinned pin[3];
         int pin_next = 0;
         size_t vt_zeroed = 0, att_zeroed = 0;
@@ -512,6 +551,7 @@ struct mi_encoder {
     DevBuf ws_stage;         // load_tensor staging (exclusive calls)
     bool tiled_ok = false;   // fragment-major weight copies are current
     bool few_ok = false;     // the query-time path's weight pieces are current
+    bool roped_ok = false;   // the rotary-pair-interleaved QKV copies are current
     // profiling: the GEMM launches of the most recent encode (arguments as launched), replayed back to back between two
     // HIP events by mi_encoder_profile_read -- like the index library's scan replay; per-launch event pairs measured
     // 3-4 % short of rocprofv3's per-kernel durations in the same run
@@ -1004,15 +1044,52 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
         h->tiled_ok = true;
     }
     if (few) tiled_lk.unlock();
+    // many tokens: the RMSNorms ride in the epilogues of the slab GEMMs either side of them and the rotary embedding in the
+    // QKV epilogue (GemmArgs::ssq_out / ssq_in / rope_cs) wherever both GEMMs take the whole-K slab kernel
+    GemmArgs probe{};
+    probe.M = T; probe.N = h->qk_cols + h->v_cols; probe.K = H;
+    const bool qkv_slab = slab_whole_k(EPI_QKV, probe) && T % 8 == 0 && ldvt % 8 == 0;
+    // (H < 4096: launch_gemm gives the QKV projection the 8-wave slab kernel, whose waves own 64 columns = 32 rotary pairs)
+    const bool rope_fused = qkv_slab && H < 4096 && h->qk_cols % 256 == 0 && h->v_cols % 256 == 0 && !std::getenv("MI_NO_ROPE_FUSE");
+    const bool norm1_fused = qkv_slab && !std::getenv("MI_NO_NORM_FUSE");
+    probe.N = 2 * I; probe.ldc = I;
+    const bool norm2_fused = slab_whole_k(EPI_SWIGLU, probe) && !std::getenv("MI_NO_NORM_FUSE");
+    float *ssq = (norm1_fused || norm2_fused) ? ws.ws_ssq.as<float>((size_t)T * (SSQ_LD + 1)) : nullptr;
+    float *inv_rms = ssq ? ssq + (size_t)T * SSQ_LD : nullptr;
+    auto row_rms = [&](int nslots) -> const float * {       // the slots a residual epilogue left -> 1/rms per row
+        hipLaunchKernelGGL(row_rms_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, ssq, nslots, T, H, c.rms_eps, inv_rms);
+        MI_HIP(hipGetLastError());
+        if (h->prof) {                                       // replayed with the GEMMs (mi_encoder_profile_read)
+            GemmArgs r{};
+            r.ssq_out = ssq; r.N = nslots; r.M = T; r.K = H; r.norm_eps = c.rms_eps; r.row_scale = inv_rms;
+            std::lock_guard<std::mutex> hl(h->mu);
+            h->prof_launches.push_back({-1, r});
+        }
+        return inv_rms;
+    };
+    if (rope_fused) {
+        std::lock_guard<std::mutex> hl(h->mu);             // the interleaved copies are built once; other streams wait for them
+        if (!h->roped_ok) {
+            const int N = h->qk_cols + h->v_cols;
+            for (auto &w : h->layers) {
+                const int64_t n = (int64_t)N * (H / 8);
+                hipLaunchKernelGGL(interleave_qk_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.wqkv.get<bf16_t>(),
+                                   w.bqkv.get<float>(), h->qk_cols, N, H, hd, w.wqkv_r.as<bf16_t>((size_t)N * H), w.bqkv_r.as<float>((size_t)N));
+                MI_HIP(hipGetLastError());
+            }
+            MI_HIP(hipStreamSynchronize(st));
+            h->roped_ok = true;
+        }
+    }
     Range stack_range("mi_encoder:stack");
     hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, st, b.ids,
                        h->embed.get<bf16_t>(), H, T, x);
     MI_HIP(hipGetLastError());
-    bool normed = false;
+    int normed = 0;                                  // what the previous residual GEMM left of this layer's first RMSNorm
     for (int l = 0; l < c.n_layers; ++l) {
         LayerW &w = h->layers[l];
         Range layer_range("mi_encoder:layer");
-        if (!normed)                                 // (else the previous layer's split-K reduction pass wrote it)
+        if (!(normed & (GEMM_NORMED | GEMM_RAWNORM)))  // (else the previous layer's down projection wrote it)
             hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln1.get<float>(), H, T,
                                c.rms_eps, xn);
         GemmArgs g{};
@@ -1021,6 +1098,8 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
         if (few) g.Wt = w.wqkv_t.get<bf16_t>();
         g.part = part; g.part_bytes = part_bytes;    // (a few hundred tokens: K split + one pass that also rotates Q and K)
         g.rope_pos = b.pos; g.rope_cos = h->rope_cos.get<float>(); g.rope_sin = h->rope_sin.get<float>(); g.rope_hd = hd;
+        if (normed & GEMM_RAWNORM) g.row_scale = row_rms(normed >> 8);
+        if (rope_fused) { g.W = w.wqkv_r.get<bf16_t>(); g.bias = w.bqkv_r.get<float>(); g.rope_cs = h->rope_cs.get<float2>(); }
         if (!(timed_gemm(h, EPI_QKV, g, st) & GEMM_ROPED)) {
             const int nh_qk = c.n_heads + c.n_kv_heads;
             const int64_t n = (int64_t)T * nh_qk * (hd / 16);
@@ -1033,22 +1112,26 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
         o.A = att; o.lda = h->q_cols; o.W = w.wo.get<bf16_t>(); o.ldw = h->q_cols; o.M = T; o.N = H; o.K = h->q_cols;
         o.X = x; o.ldc = H; o.part = part; o.part_bytes = part_bytes;
         if (few) o.Wt = w.wo_t.get<bf16_t>();
-        o.norm_w = w.ln2.get<float>(); o.norm_y = xn; o.norm_eps = c.rms_eps;   // (rides in a split-K reduction pass when there is one)
-        if (!(timed_gemm(h, EPI_RESID, o, st) & GEMM_NORMED))
+        o.norm_w = w.ln2.get<float>(); o.norm_y = xn; o.norm_eps = c.rms_eps;   // (rides in a split-K reduction pass when there is one,
+        if (norm2_fused) o.ssq_out = ssq;                                        //  or in the slab epilogue: unscaled row + sums of squares)
+        const int on = timed_gemm(h, EPI_RESID, o, st);
+        if (!(on & (GEMM_NORMED | GEMM_RAWNORM)))
             hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln2.get<float>(), H, T,
                                c.rms_eps, xn);
         GemmArgs u{};
         u.A = xn; u.lda = H; u.W = w.wgu.get<bf16_t>(); u.ldw = H; u.M = T; u.N = 2 * I; u.K = H; u.C = hb; u.ldc = I;
         if (few) u.Wt = w.wgu_t.get<bf16_t>();
+        if (on & GEMM_RAWNORM) u.row_scale = row_rms(on >> 8);
         timed_gemm(h, EPI_SWIGLU, u, st);
         GemmArgs d{};
         d.A = hb; d.lda = I; d.W = w.wd.get<bf16_t>(); d.ldw = I; d.M = T; d.N = H; d.K = I; d.X = x; d.ldc = H;
         d.part = part; d.part_bytes = part_bytes;
         if (few) d.Wt = w.wd_t.get<bf16_t>();
-        if (l + 1 < c.n_layers) {                    // the next layer's first RMSNorm can ride in a split-K reduction pass
+        if (l + 1 < c.n_layers) {                    // the next layer's first RMSNorm can ride in this GEMM the same way
             d.norm_w = h->layers[l + 1].ln1.get<float>(); d.norm_y = xn; d.norm_eps = c.rms_eps;
+            if (norm1_fused) d.ssq_out = ssq;
         }
-        normed = (timed_gemm(h, EPI_RESID, d, st) & GEMM_NORMED) != 0;
+        normed = timed_gemm(h, EPI_RESID, d, st);
     }
     return 0;
 }
@@ -1114,6 +1197,9 @@ int mi_encoder_create(const mi_encoder_cfg *cfg, int device, mi_encoder **out) {
             }
         MI_HIP(hipMemcpy(h->rope_cos.reserve(cs.size() * 4), cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
         MI_HIP(hipMemcpy(h->rope_sin.reserve(sn.size() * 4), sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+        std::vector<float> both(cs.size() * 2);
+        for (size_t i = 0; i < cs.size(); ++i) { both[2 * i] = cs[i]; both[2 * i + 1] = sn[i]; }
+        MI_HIP(hipMemcpy(h->rope_cs.reserve(both.size() * 4), both.data(), both.size() * 4, hipMemcpyHostToDevice));
         register_params(h.get());
         *out = h.release();
     });
@@ -1134,6 +1220,7 @@ int mi_encoder_load_tensor(mi_encoder *h, const char *name_c, const void *data, 
         MI_REQUIRE(dtype >= 0 && dtype <= 2, "bad dtype");
         h->tiled_ok = false;   // any new weight invalidates the fragment-major copies
         h->few_ok = false;
+        h->roped_ok = false;
         std::string name(name_c);
         if (name.rfind("model.", 0) == 0) name = name.substr(6);
         auto it = h->loaded.find(name);
@@ -1361,10 +1448,19 @@ int mi_encoder_profile_read(mi_encoder *h, double *gemm_ms, double *gemm_flops) 
         hipEvent_t e0, e1;
         MI_HIP(hipEventCreate(&e0));
         MI_HIP(hipEventCreate(&e1));
-        for (auto &l : launches) launch_gemm(l.epi, l.g, st);
+        // (epi -1: the row_rms_kernel between a fused-RMSNorm residual GEMM and its consumer -- part of that fusion's cost, and
+        // what keeps the replayed stream's values finite: without it the consumers would scale by a stale 1/rms, the stream
+        // would overflow within a pass, and GEMMs on NaN operands draw less power and clock higher than real ones)
+        auto replay = [&](const mi_encoder::Launch &l) {
+            if (l.epi >= 0) { launch_gemm(l.epi, l.g, st); return; }
+            hipLaunchKernelGGL(row_rms_kernel, dim3((unsigned)((l.g.M + 255) / 256)), dim3(256), 0, st, l.g.ssq_out, l.g.N, l.g.M, l.g.K,
+                               l.g.norm_eps, const_cast<float *>(l.g.row_scale));
+            MI_HIP(hipGetLastError());
+        };
+        for (auto &l : launches) replay(l);
         MI_HIP(hipEventRecord(e0, st));
         for (int r = 0; r < reps; ++r)
-            for (auto &l : launches) launch_gemm(l.epi, l.g, st);
+            for (auto &l : launches) replay(l);
         MI_HIP(hipEventRecord(e1, st));
         MI_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -1386,6 +1482,8 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
         else if (std::string(name) == "splitk_launches") *value = g_splitk_launches.load();
         else if (std::string(name) == "reduce_norm_launches") *value = g_reduce_norm_launches.load();
         else if (std::string(name) == "n192_launches") *value = g_n192_launches.load();
+        else if (std::string(name) == "fused_norm_launches") *value = g_fused_norm_launches.load();
+        else if (std::string(name) == "fused_rope_launches") *value = g_fused_rope_launches.load();
         else if (std::string(name) == "few_passes") *value = g_few_passes.load();
         else throw Error(std::string("unknown debug counter: ") + name);
     });

@@ -255,7 +255,22 @@ struct GemmArgs {
     const int32_t *rope_pos;
     const float *rope_cos, *rope_sin;
     int rope_hd;
+    // 256 x 256 slab kernel, many-token path: the RMSNorm between a residual GEMM and the GEMM that reads the stream is split
+    // over the two epilogues, and the rotary embedding rides in the QKV epilogue (no rmsnorm_kernel / rope_kernel launches):
+    //   EPI_RESID, ssq_out set: besides X, the epilogue writes norm_y = bf16(X * norm_w) (NOT yet scaled by 1/rms) and, per
+    //     row, the sum of squares of its 16*WNT columns into ssq_out[slot][M], slot = (first column) / (16*WNT) < SSQ_LD;
+    //     row_rms_kernel turns the slots into 1/rms per row (summing them inside the consumer cost its every tile a second
+    //     memory round trip before the first K step: +47 us on the gate/up GEMM of 28 k tokens);
+    //   EPI_QKV / EPI_SWIGLU, row_scale set: A is that unscaled row; the accumulator rows are multiplied by row_scale[row]
+    //     (= rsqrt(mean(X^2) + eps)) before bias / SwiGLU -- a scale per row commutes with the GEMM;
+    //   EPI_QKV, rope_cs set: W's Q and K rows are interleaved inside each head (row 2f + h = rotary pair f, half h) so that a
+    //     lane's 4 consecutive columns hold two whole pairs; rope_cs[pos][f] = (cos, sin).  Q and K leave in the interleaved
+    //     order -- the attention scores are dot products over the head, indifferent to a permutation applied to both.
+    float *ssq_out;
+    const float *row_scale;
+    const float2 *rope_cs;
 };
+constexpr int SSQ_LD = 24;   // partial sums of squares per row (1536 / 64)
 
 // W [N][ldw] (N % 16 == 0, K % 32 == 0) -> fragment-major Wt: one 64-thread workgroup per
 // (16-row block, K step); lane i carries what the ring kernel's DMA lane i would fetch:
@@ -267,6 +282,38 @@ __global__ void __launch_bounds__(64) tile_weights_kernel(const bf16_t *__restri
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (row < N) v = *reinterpret_cast<const uint4 *>(W + (size_t)row * ldw + ks * 32 + slot * 8);
     *reinterpret_cast<uint4 *>(Wt + (size_t)piece * 512 + i * 8) = v;
+}
+
+// inv[row] = rsqrt(sum_s ssq[s][row] / dim + eps), s ascending: the second half of the RMSNorm a residual slab epilogue began
+// (GemmArgs::ssq_out -> row_scale).  One thread per row; a slot's loads are consecutive rows.
+__global__ void __launch_bounds__(256) row_rms_kernel(const float *__restrict__ ssq, int nslots, int M, int dim, float eps, float *__restrict__ inv) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= M) return;
+    float v[SSQ_LD];
+#pragma unroll
+    for (int q = 0; q < SSQ_LD; ++q) v[q] = ssq[(size_t)min(q, nslots - 1) * M + r];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < SSQ_LD; ++q)
+        if (q < nslots) s += v[q];
+    inv[r] = rsqrtf(s / (float)dim + eps);
+}
+
+// Wr / br = W / bias with the Q and K rows interleaved inside each head: row 2 f + h of a head <- row h * hd/2 + f (rotary
+// pair f, half h); the V rows (>= qk_rows) copied.  One 16-byte chunk per thread.  (GemmArgs::rope_cs)
+__global__ void __launch_bounds__(256) interleave_qk_rows_kernel(const bf16_t *__restrict__ W, const float *__restrict__ bias, int qk_rows,
+                                                                 int nrows, int K, int hd, bf16_t *__restrict__ Wr, float *__restrict__ br) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = K / 8;
+    if (gi >= (int64_t)nrows * cpr) return;
+    const int n = (int)(gi / cpr), ch = (int)(gi - (int64_t)n * cpr);
+    int src = n;
+    if (n < qk_rows) {
+        const int head = n / hd, p = n - head * hd;
+        src = head * hd + (p & 1) * (hd / 2) + (p >> 1);
+    }
+    *reinterpret_cast<uint4 *>(Wr + (size_t)n * K + ch * 8) = *reinterpret_cast<const uint4 *>(W + (size_t)src * K + ch * 8);
+    if (ch == 0) br[n] = bias[src];
 }
 
 // 4x4 transpose across the 4 lanes of a quad (DPP quad_perm, no LDS): before,
@@ -1049,6 +1096,22 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     }
     set_sources(tm, tn, kt0);
     request_first(nk);
+    // fused RMSNorm (consumer side) / rotary positions: lane l keeps the scale (position) of rows l and 64 + l of the wave's
+    // 128 rows; the epilogue fetches its rows' values with ds_bpermute.  Requested right behind the first slabs, so the
+    // latency is the pipeline fill's.
+    [[maybe_unused]] float inv_lo = 1.f, inv_hi = 1.f;
+    [[maybe_unused]] int pos_lo = 0, pos_hi = 0;
+    if constexpr ((EPI == EPI_QKV || EPI == EPI_SWIGLU) && !PERSIST) {
+        const int r0 = min(tm * BM + wm * 128 + lane, g.M - 1), r1 = min(tm * BM + wm * 128 + 64 + lane, g.M - 1);
+        if (g.row_scale) { inv_lo = g.row_scale[r0]; inv_hi = g.row_scale[r1]; }
+        if constexpr (EPI == EPI_QKV) {
+            if (g.rope_cs) { pos_lo = g.rope_pos[r0]; pos_hi = g.rope_pos[r1]; }
+        }
+    }
+    auto row_f = [&](int i, int r16) -> float {      // the scale of row 16 i + r16 of the wave's rows
+        return __int_as_float(__builtin_amdgcn_ds_bpermute(((i & 3) * 16 + r16) * 4, __float_as_int(i < 4 ? inv_lo : inv_hi)));
+    };
+    auto row_i = [&](int i, int r16) -> int { return __builtin_amdgcn_ds_bpermute(((i & 3) * 16 + r16) * 4, i < 4 ? pos_lo : pos_hi); };
     for (;;) {   // one pass per work unit
 #pragma unroll
     for (int i = 0; i < WMT; ++i)
@@ -1161,6 +1224,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 if (trow + r < g.M && col < ncols) *reinterpret_cast<uint4 *>(g.C + (size_t)(trow + r) * g.ldc + col) = o;
             }
         } else if constexpr (PERM == 2) {   // 8 consecutive SwiGLU outputs per lane from tiles (gate, up, gate, up)
+            const float sc = PERSIST ? 1.f : row_f(i, li);   // (fused RMSNorm: 1/rms of the lane's row; 1 without)
 #pragma unroll
             for (int q = 0; q < WNT / 4; ++q) {
                 const int col0 = (n0 + wn * WNT * 16) / 2 + 32 * q + 8 * lg;
@@ -1168,9 +1232,9 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     float h[8];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float ga = acc[i][4 * q][c], gb = acc[i][4 * q + 2][c];
-                        h[c] = ga * __builtin_amdgcn_rcpf(1.0f + __expf(-ga)) * acc[i][4 * q + 1][c];
-                        h[4 + c] = gb * __builtin_amdgcn_rcpf(1.0f + __expf(-gb)) * acc[i][4 * q + 3][c];
+                        const float ga = acc[i][4 * q][c] * sc, gb = acc[i][4 * q + 2][c] * sc;
+                        h[c] = ga * __builtin_amdgcn_rcpf(1.0f + __expf(-ga)) * (acc[i][4 * q + 1][c] * sc);
+                        h[4 + c] = gb * __builtin_amdgcn_rcpf(1.0f + __expf(-gb)) * (acc[i][4 * q + 3][c] * sc);
                     }
                     uint4 o;
                     o.x = pack2(h[0], h[1]); o.y = pack2(h[2], h[3]); o.z = pack2(h[4], h[5]); o.w = pack2(h[6], h[7]);
@@ -1246,6 +1310,11 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 } else {
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (g.bias && col < g.N) bv = *reinterpret_cast<const float4 *>(g.bias + col);
+                // fused RMSNorm, producer side (GemmArgs::ssq_out): the unscaled normalised row and the columns' sum of squares
+                const bool fuse = EPI == EPI_RESID && g.ssq_out != nullptr;
+                float4 nw = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (fuse && col < g.N) nw = *reinterpret_cast<const float4 *>(g.norm_w + col);
+                float *sred = reinterpret_cast<float *>(smem) + 10240 + w * 512;   // [16 / RPI][64] behind the staging blocks
                 // (requesting X two or four 16-row blocks ahead, so that the eight blocks of a wave are not eight dependent round
                 // trips, measured no better: the in-kernel stamps put this epilogue at ~45 000 cycles of a ~110 000-cycle
                 // O-projection tile because all 256 tiles of a round move 128 MiB at once -- HBM-bound, not latency-bound)
@@ -1259,11 +1328,31 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 for (int it = 0; it < 16 / RPI; ++it) {
                     const int r = it * RPI + lane / LPR;
                     const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + r * ROWF + c4 * 4);
+                    float ss = 0.f;
                     if (lane_on && trow + r < g.M && col < g.N) {
                         float4 x = xs[it];
                         x.x += v[0] + bv.x; x.y += v[1] + bv.y; x.z += v[2] + bv.z; x.w += v[3] + bv.w;
                         *reinterpret_cast<float4 *>(g.X + (size_t)(trow + r) * g.ldc + col) = x;
+                        if (fuse) {
+                            uint2 o;
+                            o.x = pack2(x.x * nw.x, x.y * nw.y);
+                            o.y = pack2(x.z * nw.z, x.w * nw.w);
+                            *reinterpret_cast<uint2 *>(g.norm_y + (size_t)(trow + r) * g.ldc + col) = o;
+                            ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+                        }
                     }
+                    if (fuse) sred[it * 64 + lane] = ss;
+                }
+                if (fuse && lane < 16) {
+                    // row `lane` of the block: its LPR lanes' sums, in lane order (a fixed order: bit-reproducible)
+                    const float4 *sp = reinterpret_cast<const float4 *>(sred + (lane / RPI) * 64 + (lane % RPI) * LPR);
+                    float t = 0.f;
+#pragma unroll
+                    for (int q = 0; q < LPR / 4; ++q) {
+                        const float4 a = sp[q];
+                        t += a.x; t += a.y; t += a.z; t += a.w;
+                    }
+                    if (trow + lane < g.M) g.ssq_out[(size_t)((n0 + wn * CW) / CW) * g.M + trow + lane] = t;   // slot-major: one 64-byte segment
                 }
                 }
             } else {
@@ -1285,14 +1374,40 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     asm volatile("s_barrier" ::: "memory");
                 }
                 const int srow = 4 * lg + (li & 3), scol0 = 4 * (li >> 2);
+                const float sc = row_f(i, srow);             // fused RMSNorm: 1/rms of the lane's row (1 without)
+                float4 cs[WNT];
+                if (g.rope_cs) {
+                    // (cos, sin) of the wave's 16 rows x CW/2 rotary pairs (columns 2f, 2f+1 = pair f): 256 contiguous bytes per
+                    // row, fetched as whole lines (4 rows per instruction) into a wave-private LDS block and read back per
+                    // lane -- straight from the table a lane's float4 is 16 rows x 64 B per instruction, twice the lines, and
+                    // the CU's memory pipe charges per (instruction, line): the first version cost what rope_kernel takes
+                    char *csb = reinterpret_cast<char *>(smem) + 24576 + w * 5120;   // [16 rows][320 B] behind the staging blocks
+                    const int fb = ((n0 + wn * CW) & (g.rope_hd - 1)) >> 1;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int rr = 4 * k + (lane >> 4);
+                        const int pp = row_i(i, rr);         // rotary position of row rr
+                        const float4 v = *reinterpret_cast<const float4 *>(g.rope_cs + (size_t)pp * (g.rope_hd >> 1) + fb + 2 * (lane & 15));
+                        *reinterpret_cast<float4 *>(csb + rr * 320 + (lane & 15) * 16) = v;
+                    }
+#pragma unroll
+                    for (int j = 0; j < WNT; ++j) cs[j] = *reinterpret_cast<const float4 *>(csb + srow * 320 + 64 * j + 16 * (li >> 2));
+                }
 #pragma unroll
                 for (int j = 0; j < WNT; ++j) {
                     const f32x4 v = quad_transpose(acc[i][j], lane);
                     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (g.bias) b = *reinterpret_cast<const float4 *>(g.bias + n0 + wn * CW + j * 16 + scol0);
+                    float x0 = v[0] * sc + b.x, x1 = v[1] * sc + b.y, x2 = v[2] * sc + b.z, x3 = v[3] * sc + b.w;
+                    if (g.rope_cs) {
+                        const float4 c = cs[j];
+                        const float y0 = x0 * c.x - x1 * c.y, y1 = x1 * c.x + x0 * c.y;
+                        const float y2 = x2 * c.z - x3 * c.w, y3 = x3 * c.z + x2 * c.w;
+                        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+                    }
                     uint2 o;
-                    o.x = pack2(v[0] + b.x, v[1] + b.y);
-                    o.y = pack2(v[2] + b.z, v[3] + b.w);
+                    o.x = pack2(x0, x1);
+                    o.y = pack2(x2, x3);
                     *reinterpret_cast<uint2 *>(stg + srow * ROWH + j * 16 + scol0) = o;
                 }
                 const int c8 = lane % LPR, col = n0 + wn * CW + c8 * 8;
@@ -1310,18 +1425,24 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     asm volatile("s_barrier" ::: "memory");
                 }
                 bf16_t *stg = smem + w * (WNT * 16) * VROW;
+                const float s0 = row_f(i, 4 * lg), s1 = row_f(i, 4 * lg + 1), s2 = row_f(i, 4 * lg + 2), s3 = row_f(i, 4 * lg + 3);
 #pragma unroll
                 for (int j = 0; j < WNT; ++j) {
                     const float bv = g.bias ? g.bias[n0 + (wn * WNT + j) * 16 + li] : 0.f;
                     const f32x4 v = acc[i][j];
                     uint2 o;
-                    o.x = pack2(v[0] + bv, v[1] + bv);
-                    o.y = pack2(v[2] + bv, v[3] + bv);
+                    o.x = pack2(v[0] * s0 + bv, v[1] * s1 + bv);
+                    o.y = pack2(v[2] * s2 + bv, v[3] * s3 + bv);
                     *reinterpret_cast<uint2 *>(stg + (j * 16 + li) * VROW + i * 16 + 4 * lg) = o;
                 }
             } else {
+                const float s0 = row_f(i, 4 * lg), s1 = row_f(i, 4 * lg + 1), s2 = row_f(i, 4 * lg + 2), s3 = row_f(i, 4 * lg + 3);
 #pragma unroll
-                for (int j = 0; j < WNT; ++j) store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
+                for (int j = 0; j < WNT; ++j) {
+                    f32x4 v = acc[i][j];
+                    v[0] *= s0; v[1] *= s1; v[2] *= s2; v[3] *= s3;
+                    store_tile<EPI>(ge, v, v, trow, n0 + (wn * WNT + j) * 16, lane);
+                }
             }
         } else {
 #pragma unroll

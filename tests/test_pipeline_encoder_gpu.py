@@ -271,7 +271,12 @@ def test_bulk_encode_path_at_stella_widths_vs_oracle(st):
     assert 25000 < ntok < 32768
     model = st.SentenceTransformer(config=cfg, weights=W)
     model.token_budget = None                                 # one pass of 128 abstracts, as `bench.py --encode-batch 128` issues it
+    fused = st.debug_counter("fused_norm_launches"), st.debug_counter("fused_rope_launches")
     e = model.encode_tokens(toks, batch_size=128, normalize_embeddings=True)
+    # no rmsnorm_kernel / rope_kernel between the GEMMs of this pass: every RMSNorm but the first layer's first (and the final
+    # one) is split over the slab epilogues either side of it, the rotary embedding is in the QKV epilogue
+    assert st.debug_counter("fused_norm_launches") - fused[0] == 2 * cfg["n_layers"] - 1
+    assert st.debug_counter("fused_rope_launches") - fused[1] == cfg["n_layers"]
     order = sorted(range(128), key=lambda i: -len(toks[i]))   # the pass's own order (longest first)
     hs = model.last_hidden_state([toks[i] for i in order])
     Wc = {k: v.float().cpu() for k, v in W.items()}
@@ -290,6 +295,37 @@ def test_bulk_encode_path_at_stella_widths_vs_oracle(st):
     more = toks + [rng.integers(0, cfg["vocab_size"], 300).tolist() for _ in range(9)]
     e2 = model.encode_tokens(more, batch_size=32, normalize_embeddings=True)
     assert np.abs(e2[:128] - e).max() < 2e-3 and ((e2[:128] * ref).sum(1)).min() > 1 - 1e-3
+
+
+def test_fused_epilogues_agree_with_the_standalone_kernels(st, monkeypatch):
+    """The many-token pass with the RMSNorms and the rotary embedding inside the slab GEMM epilogues (default) against the same
+    pass through rmsnorm_kernel / rope_kernel (MI_NO_BULK_FUSE=1), each half of the fusion alone too: same embeddings to bf16
+    rounding.  Also a width whose residual GEMMs take the 256 x 192 tiles (16 slots of sums of squares per row)."""
+    cfg = dict(st.STELLA_EN_1_5B_V5)
+    cfg["vocab_size"], cfg["n_layers"] = 2048, 2
+    W = _rand_weights_gpu(cfg, 29)
+    rng = np.random.default_rng(29)
+    for ntok_target in (28000, 6400):                         # 110 row tiles: 256-column residual tiles; 25: 256 x 192 (n192_pays)
+        lens = np.clip(np.exp(rng.normal(np.log(220), 0.45, 400)), 8, 512).astype(int)
+        lens = lens[: int(np.searchsorted(np.cumsum(lens), ntok_target))]
+        toks = [rng.integers(0, cfg["vocab_size"], int(L)).tolist() for L in lens]
+        outs = {}
+        for name, env in (("fused", {}), ("plain", {"MI_NO_BULK_FUSE": "1"}), ("norm_only", {"MI_NO_ROPE_FUSE": "1"}),
+                          ("rope_only", {"MI_NO_NORM_FUSE": "1"})):
+            for k in ("MI_NO_BULK_FUSE", "MI_NO_ROPE_FUSE", "MI_NO_NORM_FUSE"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            model = st.SentenceTransformer(config=cfg, weights=W)
+            model.token_budget = None
+            c0 = st.debug_counter("fused_norm_launches"), st.debug_counter("fused_rope_launches"), st.debug_counter("n192_launches")
+            outs[name] = model.encode_tokens(toks, batch_size=len(toks), normalize_embeddings=True)
+            took = (st.debug_counter("fused_norm_launches") - c0[0], st.debug_counter("fused_rope_launches") - c0[1])
+            assert took == {"fused": (3, 2), "plain": (0, 0), "norm_only": (3, 0), "rope_only": (0, 2)}[name], (name, took)
+            assert (st.debug_counter("n192_launches") - c0[2] > 0) == (ntok_target == 6400)
+        for name in ("plain", "norm_only", "rope_only"):
+            cos = (outs["fused"] * outs[name]).sum(1)
+            assert cos.min() > 1 - 2e-4 and np.abs(outs["fused"] - outs[name]).max() < 4e-3, (ntok_target, name, cos.min())
 
 
 @pytest.mark.parametrize("nq,layers", [(1, 28), (5, 28), (16, 28), (64, 4), (132, 3), (200, 2), (256, 3)])
