@@ -20,6 +20,7 @@ the call only enqueues work on the current stream -- the path bench.py times).
 """
 from __future__ import annotations
 
+import os
 import ctypes
 import re
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p

@@ -691,9 +691,13 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
         r = float(t.item())
     log(f"  refine point chosen on the held-out batch: nprobe={nprobe} k_factor_rf={kf} (recall {r_sel:.4f} there); reported batch: {r:.4f}")
     kb = k * kf
-    # batches are independent: like the main line, the unsharded loop issues them round-robin on 2 streams (the library
-    # keeps a workspace set per stream) -- the HBM-bound re-rank of one batch overlaps the MFMA-bound coarse stage of the next
-    S2 = max(1, int(os.environ.get("BENCH_REFINE_STREAMS", "0")) or (2 if args.streams is None else args.streams))
+    # batches are independent: the unsharded loop issues them round-robin on 4 streams (the library keeps a workspace set per
+    # stream) -- the HBM-bound re-rank and scan of some batches beside the MFMA- and latency-bound coarse stage and set
+    # selection of others.  Measured on the 207 M index: 1 stream 2.08 ms per batch, 2: 1.85, 3: 1.79, 4: 1.74
+    # (profiles/r04_refine_streams.txt); the two stages of consecutive batches on two streams linked by events (a stage
+    # pipeline) measured 2.05 -- no overlap at all on this runtime, although spin kernels linked the same way do overlap
+    # (tools/micro/stream_event_overlap.py).
+    S2 = max(1, int(os.environ.get("BENCH_REFINE_STREAMS", "0")) or (4 if args.streams is None else args.streams))
     if sharded is not None:
         S2 = max(1, int(os.environ.get("BENCH_SHARD_STREAMS", "0")) or S2)
     rstreams = [torch.cuda.Stream(device=dev) for _ in range(S2)] if S2 > 1 else [torch.cuda.current_stream(dev)]
