@@ -1,7 +1,9 @@
-"""gpurun_out/r03_prof/{encode_gemm_FETCH_SIZE,encode_gemm_WRITE_SIZE}.txt + encode_kernel_stats.csv + the two bench lines
--> profiles/r03_cfg3_encoder_gemm_pmc.json (what bench.py reads for encode.roofline.traffic and the kernel-trace cross-check)."""
+"""<dir>/{encode_gemm_FETCH_SIZE,encode_gemm_WRITE_SIZE}.txt + encode_kernel_stats.csv + the two bench lines (tools/prof_r04.sh)
+-> profiles/r04_cfg3_encoder_gemm_pmc.json (what bench.py reads for encode.roofline.traffic and the kernel-trace cross-check).
+usage: python tools/pmc_encode_json.py [dir = gpurun_out/r04_prof] [out.json = profiles/r04_cfg3_encoder_gemm_pmc.json]"""
 import csv, json, re, sys
-out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r03_prof"
+out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r04_prof"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04_cfg3_encoder_gemm_pmc.json"
 def parse(fn):
     d, k = {}, None
     for l in open(fn):
@@ -28,15 +30,16 @@ for k, v in F.items():
     tot += f + w
 e, p = json.load(open(out + "/encode_under_stats.json")), json.load(open(out + "/encode_plain.json"))
 gemm_us = sum(k["avg_duration_us_kernel_trace"] for k in kern.values()) * 28
-doc = {"command": "bench.py --workload encode --steps 4 --warmup 1 --no-cpu-baseline (cfg3 shape, batch 128) under rocprofv3: one --kernel-trace --stats run, then separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (--kernel-trace only, --kernel-include-regex 'gemm_bf16_(ring|slab)'); tools/prof_r03.sh",
+doc = {"command": "bench.py --workload encode --steps 4 --warmup 1 --no-cpu-baseline (cfg3 shape, batch 128) under rocprofv3: one --kernel-trace --stats run, then separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (--kernel-trace only, --kernel-include-regex 'gemm_bf16_(ring|slab)'); tools/prof_r04.sh",
        "batch": 128, "tokens_step0": 27958, "flops_per_step": e["roofline"]["flops_per_step"],
        "correction": "gfx950: FETCH_SIZE counts a wide coalesced read at half its bytes (MI355X_MICROARCH.md, section HBM) -> read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE taken as is; both are the L2's memory-side requests: Infinity-Cache hits are counted, not excluded",
        "kernels": kern, "hbm_bytes_per_step": int(tot * 28),
-       "algorithmic_bytes_per_step": "~63 GB (operands once + outputs of the 112 launches): the L2-miss traffic is ~2.9 x that -- gate/up alone re-fetches its operands ~19 x (8 x 4 tile patches per XCD share A strips only in L2 lockstep)",
-       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction (profiles/r03_cfg3_encoder_gemm_pmc.json)",
+       "algorithmic_bytes_per_step": "~68 GB (operands once + outputs of the 112 launches, incl. the unscaled normalised rows the residual epilogues now write): the L2-miss traffic is a multiple of that -- gate/up alone re-fetches its operands ~19 x (8 x 4 tile patches per XCD share A strips only in L2 lockstep); Infinity-Cache hits are inside the count",
+       "ratio_to_algorithmic": round(tot * 28 / 68e9, 2),
+       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction (" + dst + ")",
        "same_run_timing": {"step_ms_plain": p["ms_per_step"], "step_ms_under_kernel_trace": e["ms_per_step"],
                            "gemm_ms_per_step_replay_between_one_event_pair": e["roofline"]["gemm_ms_per_step"],
                            "gemm_ms_per_step_kernel_trace_sum": round(gemm_us / 1e3, 2),
                            "note": "a kernel's traced duration includes its drain tail and end-of-kernel cache write-back, during which the next launch already runs: the sum reads 3-4 % above what the launches occupy back to back (round 2's per-launch event pairs read the same as the replay)"}}
-json.dump(doc, open("profiles/r03_cfg3_encoder_gemm_pmc.json", "w"), indent=1)
+json.dump(doc, open(dst, "w"), indent=1)
 print(json.dumps(doc["same_run_timing"], indent=1), doc["hbm_bytes_per_step"] / 1e9)

@@ -2,7 +2,7 @@
 # usage: tools/prof_r04.sh   (GPU box, from the repo root) -- round-4 rocprofv3 evidence:
 #   cfg4 (207 M, incl. the recall-0.95 point): --kernel-trace --stats; FETCH_SIZE / WRITE_SIZE passes of scan / re-rank / selection
 #   the query-time encoder (one 31-token query): --kernel-trace --stats; FETCH_SIZE pass of its six kernels
-#   encode (cfg3): --kernel-trace --stats
+#   encode (cfg3): --kernel-trace --stats; FETCH_SIZE / WRITE_SIZE passes of its GEMM kernels (tools/pmc_encode_json.py makes the json bench.py reads)
 # Counters always in their own passes with --kernel-trace only.  Summaries -> gpurun_out/r04_prof/
 out=$GRAFT_REPO_ROOT/gpurun_out/r04_prof
 mkdir -p $out
@@ -23,6 +23,11 @@ python $GRAFT_REPO_ROOT/tools/pmc_summarize.py $(find /tmp/p_b1_fetch -name "*co
 E="python $GRAFT_REPO_ROOT/bench.py --workload encode --steps 4 --warmup 1 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_enc_stats -o r -- $E > $out/encode_under_stats.json 2> $out/encode_stats.err
 cp $(find /tmp/p_enc_stats -name "*kernel_stats.csv" | head -1) $out/encode_kernel_stats.csv
+timeout 600 $E > $out/encode_plain.json 2> $out/encode_plain.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "gemm_bf16_(ring|slab)" --output-format csv -d /tmp/p_enc_$c -o r -- $E > /dev/null 2> $out/encode_$c.err
+  python $GRAFT_REPO_ROOT/tools/pmc_summarize.py $(find /tmp/p_enc_$c -name "*counter_collection.csv" | head -1) gemm_bf16_ > $out/encode_gemm_$c.txt
+done
 cd $GRAFT_REPO_ROOT
 head -12 $out/cfg4_kernel_stats.csv | cut -c1-170
 cat $out/cfg4_FETCH_SIZE.txt $out/cfg4_WRITE_SIZE.txt $out/b1_FETCH_SIZE.txt
