@@ -29,6 +29,7 @@ std::atomic<int64_t> g_tail_split_launches{0};
 std::atomic<int64_t> g_splitk_launches{0};
 std::atomic<int64_t> g_reduce_norm_launches{0};
 std::atomic<int64_t> g_n192_launches{0};
+std::atomic<int64_t> g_m192_launches{0};      // slab GEMMs on 192-row tiles
 std::atomic<int64_t> g_fused_norm_launches{0};   // residual slab GEMMs whose epilogue carried the next RMSNorm (GEMM_RAWNORM)
 std::atomic<int64_t> g_fused_rope_launches{0};   // QKV slab GEMMs whose epilogue rotated Q and K
 std::atomic<int64_t> g_few_passes{0};     // forward passes that took the query-time path (encoder_few.h)
@@ -107,9 +108,10 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
 }
 
 // 256x256 tiles, slab ring + hand-ordered K loop (gemm_bf16_slab_kernel; WN_ = 4: 8 waves, 2: 4 waves): whole-K workgroups, the same wave-quantisation tail split
-template <int WN_>
+template <int WN_, int WMT_ = 8>
 int launch_slab(int epi, GemmArgs g, hipStream_t st) {
-    g.tiles_m = (g.M + 255) / 256;
+    constexpr int BM = 32 * WMT_;
+    g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + 255) / 256;
     const int per = (g.tiles_m * g.tiles_n + 7) / 8;
     g.ksplit = 1;
@@ -204,7 +206,7 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
     // is the ISSUE of the epilogue's stores, not the relaunch or the pipeline fill.  MI_GEMM_PERSIST=1 keeps the experiment.
     static const int persist_env = std::getenv("MI_GEMM_PERSIST") ? std::atoi(std::getenv("MI_GEMM_PERSIST")) : 0;   // 1: every epilogue, 2: SwiGLU only
     const bool persist_on = persist_env == 1 || (persist_env == 2 && epi == EPI_SWIGLU);
-    if (persist_on && nblocks > 256) {
+    if (persist_on && nblocks > 256 && WMT_ == 8) {
         dim3 pgrid(256);
         switch (epi) {
             case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_STORE, WN_, true>), pgrid, block, 0, st, g); break;
@@ -217,12 +219,21 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
         MI_REQUIRE(!g.row_scale && !g.ssq_out && !g.rope_cs, "persistent slab GEMM: no fused RMSNorm / rotary epilogues");
         return 0;
     }
+    if constexpr (WMT_ == 6) {                            // 192-row tiles: the two epilogues the few-hundred-token passes send here
+        ++g_m192_launches;
+        switch (epi) {
+            case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, WN_, false, 16 / WN_, 6>), grid, block, 0, st, g); break;
+            case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_SWIGLU, WN_, false, 16 / WN_, 6>), grid, block, 0, st, g); break;
+            default: throw Error("192-row slab tiles: epilogue not instantiated");
+        }
+    } else {
     switch (epi) {
         case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_STORE, WN_>), grid, block, 0, st, g); break;
         case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, WN_>), grid, block, 0, st, g); break;
         case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_QKV, WN_>), grid, block, 0, st, g); break;
         case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_SWIGLU, WN_>), grid, block, 0, st, g); break;
         default: throw Error("bad epilogue");
+    }
     }
     MI_HIP(hipGetLastError());
     finish_split();
@@ -332,6 +343,14 @@ void launch_ring32(int epi, GemmArgs g, hipStream_t st) {
         default: throw Error("32x32 GEMM: epilogue not implemented");
     }
     MI_HIP(hipGetLastError());
+}
+
+// whether 192-row tiles beat 256-row tiles for this GEMM: at least a tenth fewer padded rows and no more rounds of workgroups
+// (513 .. 576 tokens: three row tiles either way, 576 rows instead of 768)
+bool m192_pays(const GemmArgs &g) {
+    const bool off = std::getenv("MI_NO_M192") != nullptr;   // (read per call: the tests switch it inside one process)
+    const long t192 = (g.M + 191) / 192, t256 = (g.M + 255) / 256, tn = (g.N + 255) / 256;
+    return !off && t192 * 192 * 10 <= t256 * 256 * 9 && (t192 * tn + 255) / 256 <= (t256 * tn + 255) / 256;
 }
 
 // whether splitting every 256x256 tile of a residual GEMM along K (launch_slab's workspace path) fills the chip
@@ -451,12 +470,13 @@ int launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             // workspace (launch_slab) -- 576 x 1536 x 8960: 18 tiles x 14 slices = 252 workgroups of 20 K steps + one reduction
             // pass, where 128x128 tiles with K split three ways by f32 atomics took 76 us; at 1558 / 2097 tokens the forward
             // pass went 7.91 -> 6.46 / 9.21 -> 7.82 ms against the 128x128 ring tiles
-            return launch_slab<2>(epi, g, st);
+            return m192_pays(g) ? launch_slab<2, 6>(epi, g, st) : launch_slab<2>(epi, g, st);
         } else if (cfg == "big" && !force && epi == EPI_RESID && n192_pays(g) && !std::getenv("MI_NO_N192")) {
             return launch_slab_n192(g, st);
         } else if (cfg == "big" && !std::getenv("MI_GEMM_RING") && (epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {   // the slab kernel stores 8 bf16 columns per lane
             // measured (tools/gemm_bench.py, 32768 tokens): 8 waves 1051 / 1060 TF on QKV / O, 4 waves 1106 / 1303 on
             // gate-up / down (ring kernel: 968 / 952 / 1006 / 1166)
+            if ((epi == EPI_SWIGLU || (epi == EPI_RESID && g.K >= 4096)) && !force && m192_pays(g)) return launch_slab<2, 6>(epi, g, st);
             if (epi == EPI_SWIGLU || g.K >= 4096) return launch_slab<2>(epi, g, st);
             return launch_slab<4>(epi, g, st);
         } else if (cfg == "big" || cfg == "big32") {
@@ -1482,6 +1502,7 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
         else if (std::string(name) == "splitk_launches") *value = g_splitk_launches.load();
         else if (std::string(name) == "reduce_norm_launches") *value = g_reduce_norm_launches.load();
         else if (std::string(name) == "n192_launches") *value = g_n192_launches.load();
+        else if (std::string(name) == "m192_launches") *value = g_m192_launches.load();
         else if (std::string(name) == "fused_norm_launches") *value = g_fused_norm_launches.load();
         else if (std::string(name) == "fused_rope_launches") *value = g_fused_rope_launches.load();
         else if (std::string(name) == "few_passes") *value = g_few_passes.load();

@@ -916,10 +916,15 @@ __host__ __device__ constexpr int slab_w_tile_off(int j) {
 // (residual epilogue only) for the token counts at which N = 1536 yields 130-190 tiles of 256 columns on 256 CUs and
 // exactly <= 256 tiles of 192 -- the W slabs keep their 32 KiB slots and all 32 pieces (rows 192..255 are never read), so
 // nothing of the DMA / wait schedule changes; a step is 48 MFMAs and 14 fragment reads.
-template <int EPI, int WN_, bool PERSIST = false, int WNT_ = 16 / WN_>
+// WMT_ = 6: 192-row tiles for the token counts at which 256-row tiles multiply mostly padding (513 .. 576 tokens are three
+// row tiles either way: a quarter fewer MFMAs per step).  The A slabs keep their 256 rows of LDS and all 32 pieces (rows
+// 192 .. 255 belong to the next tile and are never read), so, as with WNT_ = 6, nothing of the DMA / wait schedule changes.
+template <int EPI, int WN_, bool PERSIST = false, int WNT_ = 16 / WN_, int WMT_ = 8>
 __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g) {
-    constexpr int BM = 256, WMT = 8, WNT = WNT_, BN = WN_ * WNT * 16, NW = 2 * WN_;
+    constexpr int WMT = WMT_, BM = 32 * WMT, WNT = WNT_, BN = WN_ * WNT * 16, NW = 2 * WN_;
+    static_assert(WMT_ == 8 || WMT_ == 6, "row tiles of 256 or 192");
     static_assert(BN <= 256 && (WNT_ == 16 / WN_ || EPI == EPI_RESID), "narrower tiles: residual epilogue only");
+    static_assert(WMT_ == 8 || !PERSIST, "192-row tiles: one unit per workgroup");
     constexpr int PPW = 32 / NW;                             // DMA pieces (1 KiB: 8 rows x 128 B) per wave per slab
     constexpr int NS = 5, DQ = 4;                            // slabs in the ring, request distance in slabs
     constexpr unsigned SLAB_B = 256 * 128;                   // 32 KiB
@@ -1015,7 +1020,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
 #endif
 
     // fragment (16 rows x 32 k) of K half kk: lane (li, lg) reads row li, global slot 4 kk + lg -> LDS slot ^ (row & 7)
-    const unsigned rdA = lds0 + (unsigned)(wm * 128 + li) * 128u + (unsigned)((lg ^ (li & 7)) * 16);          // kk = 1: ^ 64
+    const unsigned rdA = lds0 + (unsigned)(wm * (WMT * 16) + li) * 128u + (unsigned)((lg ^ (li & 7)) * 16);   // kk = 1: ^ 64
     const int bsub = li >> 2, bc = li & 3;
     const int brow = PERM == 1 ? 8 * bsub + bc : PERM == 2 ? 32 * (bsub >> 1) + 8 * (bsub & 1) + bc : li;   // W row of tile position li
     const int bkey = (brow & 3) | (((brow >> 3) & 1) << 2);
@@ -1102,7 +1107,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     [[maybe_unused]] float inv_lo = 1.f, inv_hi = 1.f;
     [[maybe_unused]] int pos_lo = 0, pos_hi = 0;
     if constexpr ((EPI == EPI_QKV || EPI == EPI_SWIGLU) && !PERSIST) {
-        const int r0 = min(tm * BM + wm * 128 + lane, g.M - 1), r1 = min(tm * BM + wm * 128 + 64 + lane, g.M - 1);
+        const int r0 = min(tm * BM + wm * (WMT * 16) + lane, g.M - 1), r1 = min(tm * BM + wm * (WMT * 16) + 64 + lane, g.M - 1);
         if (g.row_scale) { inv_lo = g.row_scale[r0]; inv_hi = g.row_scale[r1]; }
         if constexpr (EPI == EPI_QKV) {
             if (g.rope_cs) { pos_lo = g.rope_pos[r0]; pos_hi = g.rope_pos[r1]; }

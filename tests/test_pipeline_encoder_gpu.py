@@ -362,6 +362,34 @@ def test_query_batches_at_stella_widths_vs_oracle(st, nq, layers):
     assert cos.min() > 1 - 1e-3, (nq, cos.min())
 
 
+def test_192_row_tiles_vs_oracle(st, monkeypatch):
+    """Token counts at which 256-row GEMM tiles would multiply mostly padding (bench.py's 16-query batch: ~570 tokens = three
+    row tiles either way, 576 rows instead of 768): the gate/up and down projections take the slab kernel's 192-row variant.
+    Same embeddings as the 256-row tiles (MI_NO_M192=1) to rounding, and within 1e-3 cosine of the fp32 oracle."""
+    import torch
+    from oracle import encoder_oracle as E
+    cfg = dict(st.STELLA_EN_1_5B_V5)
+    cfg["vocab_size"], cfg["n_layers"] = 4096, 3
+    W = _rand_weights_gpu(cfg, 57)
+    rng = np.random.default_rng(57)
+    for lens in ([31] * 18, [48] * 6 + [17] * 3):            # 558 tokens -> 576 rows; 339 -> 352 rows: two tiles of 192 against two of 256
+        toks = [rng.integers(0, cfg["vocab_size"], int(L)).tolist() for L in lens]
+        outs = {}
+        for name in ("m192", "m256"):
+            monkeypatch.delenv("MI_NO_M192", raising=False)
+            if name == "m256":
+                monkeypatch.setenv("MI_NO_M192", "1")
+            model = st.SentenceTransformer(config=cfg, weights=W)
+            c0 = st.debug_counter("m192_launches")
+            outs[name] = model.encode_tokens(toks, batch_size=len(toks), normalize_embeddings=True)
+            assert st.debug_counter("m192_launches") - c0 == (2 * cfg["n_layers"] if name == "m192" else 0), (name, len(lens))
+        Wc = {k: v.float().cpu() for k, v in W.items()}
+        with torch.no_grad():
+            ref = E.encode(E.EncoderConfig(**cfg), Wc, np.concatenate(toks), np.concatenate([[0], np.cumsum(lens)]), True).numpy()
+        assert ((outs["m192"] * ref).sum(1)).min() > 1 - 1e-3
+        assert ((outs["m192"] * outs["m256"]).sum(1)).min() > 1 - 2e-4 and np.abs(outs["m192"] - outs["m256"]).max() < 4e-3
+
+
 @pytest.mark.parametrize("lens", [[1], [3], [16], [17], [32], [33], [48], [5, 9, 20], [1] * 7, [16, 16, 16], [2, 46]])
 def test_few_token_path_at_stella_widths_vs_oracle(st, lens, monkeypatch):
     """The query-time path (csrc/encoder_few.h: RMSNorm in the GEMM prologue, RoPE / SwiGLU / residual atomics in the
