@@ -2365,6 +2365,34 @@ int mi_flat_reconstruct_n(mi_flat *h, int64_t i0, int64_t n, float *out) {
     });
 }
 
+int mi_flat_release_workspaces(mi_flat *h) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        DeviceGuard dg(h->device);
+        std::lock_guard<std::mutex> hl(h->mu);
+        MI_HIP(hipDeviceSynchronize());                  // nothing in flight reads the buffers any more
+        for (auto &kv : h->ws_sets) {
+            std::unique_lock<std::mutex> lk(kv.second->mu, std::try_to_lock);
+            MI_REQUIRE(lk.owns_lock(), "release_workspaces: a call is running on this handle");
+        }
+        h->ws_sets.clear();
+    });
+}
+
+int mi_index_release_workspaces(mi_index *h) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        DeviceGuard dg(h->device);
+        std::lock_guard<std::mutex> hl(h->mu);
+        MI_HIP(hipDeviceSynchronize());
+        for (auto &kv : h->ws_sets) {
+            std::unique_lock<std::mutex> lk(kv.second->mu, std::try_to_lock);
+            MI_REQUIRE(lk.owns_lock(), "release_workspaces: a call is running on this handle");
+        }
+        h->ws_sets.clear();
+    });
+}
+
 int mi_flat_get_rows(mi_flat *h, int64_t n, const int64_t *ids, void *out) {
     return guard([&] {
         MI_REQUIRE(h && (n == 0 || (ids && out)), "null argument");

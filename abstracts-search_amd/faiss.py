@@ -99,6 +99,8 @@ class _Lib:
                 "mi_flat_ntotal": [v, POINTER(c_int64)],
                 "mi_flat_reconstruct_n": [v, c_int64, c_int64, v],
                 "mi_flat_get_rows": [v, c_int64, v, v],
+                "mi_flat_release_workspaces": [v],
+                "mi_index_release_workspaces": [v],
                 "mi_flat_reset": [v],
                 "mi_flat_search": [v, c_int64, v, c_int, v, v, v],
                 "mi_flat_rerank": [v, c_int64, v, c_int, v, c_int, v, v, v],
@@ -218,6 +220,10 @@ class IndexFlatIP:
         out = np.empty((ni, self.d), np.float32)
         _check(_Lib.get().mi_flat_reconstruct_n(self._h, int(i0), int(ni), _ptr(out)))
         return out
+
+    def release_workspaces(self) -> None:
+        """Give the per-stream scratch buffers back to the allocator (they return on the next call)."""
+        _check(_Lib.get().mi_flat_release_workspaces(self._h))
 
     def get_rows(self, ids) -> np.ndarray:
         """The stored bytes of the rows `ids`, uint8 [len(ids), row_bytes]: d float32 (IndexFlat), d IEEE halves
@@ -587,6 +593,11 @@ class IndexIVFPQ:
         _check(_Lib.get().mi_index_list_sizes(self._h, _ptr(out)))
         return out
 
+    def release_workspaces(self) -> None:
+        """Give the per-stream scratch buffers (a set per stream that ever searched) back to the allocator; they return
+        on the next call.  Not while another thread is inside a call on this index."""
+        _check(_Lib.get().mi_index_release_workspaces(self._h))
+
     def export_lists(self, list_lo: int = 0, list_hi: int | None = None):
         """(codes [rows, M] uint8, ids [rows] int64) of the lists [list_lo, list_hi)
         concatenated in list order, each list in insertion order (host arrays)."""
@@ -822,6 +833,11 @@ class IndexRefine:
             return self.refine_index.rerank(x, cand, k)
         _, cand = self.base_index.search(x, k_base, params=bp)
         return self.refine_index.rerank(x, cand, k)
+
+    def release_workspaces(self) -> None:
+        for ix in (self.base_index, self.refine_index):
+            if hasattr(ix, "release_workspaces"):
+                ix.release_workspaces()
 
     def search_into(self, x, k: int, D, I, cand_D, cand_I, stream: int | None = None):
         """search() into caller-owned CUDA tensors (cand_I: [nq, k_base] scratch; cand_D is only written when the base

@@ -785,6 +785,10 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
                   "note": "the candidate SETS themselves are the PQ scan's, whose parity is the main line's parity_vs_oracle "
                           "(tests/test_ivfpq_gpu.py::test_refine_sq8_at_the_timed_shape_matches_oracle checks both at this shape)"}
     base.nprobe = index.nprobe = args_nprobe
+    # the scratch sets of the streams used so far (2 of the main line + S2 here: ~2-3 GB each) go back to the allocator: the
+    # cfg5 leg's CPU baseline exports the lists through a 15 GB device staging buffer
+    torch.cuda.synchronize()
+    ref.release_workspaces()
     gb = flat_r.ntotal * D_MODEL * relem / 1e9
     if refine_own:
         scope = (f"the whole job: every rank re-ranks k*k_factor candidates of its own shard against the shard's {store} "

@@ -257,6 +257,13 @@ int mi_flat_reconstruct_n(mi_flat *h, int64_t i0, int64_t n, float *out);
  * the parity hook that hands a sample of a store too large to export (212 GB at cfg4) to the oracle
  * (bench.py at_recall_095.parity_vs_oracle; reference call site Makefile:32 `tune` -> the operating point). */
 int mi_flat_get_rows(mi_flat *h, int64_t n, const int64_t *ids, void *out);
+/* Frees the per-stream scratch buffers (a set per stream that has ever searched: ~2-3 GB each at batch 1024 over
+ * 65 536 lists) after the device has drained; the next call on a stream allocates its set again.  Not to be called
+ * while another thread is inside a call on the same handle.  (faiss keeps no such state: its search allocates per
+ * call; a caller that searched on many streams and now needs the HBM -- bench.py before it exports the lists --
+ * gives it back here.) */
+int mi_flat_release_workspaces(mi_flat *h);
+int mi_index_release_workspaces(mi_index *h);
 int mi_flat_ntotal(mi_flat *h, int64_t *out);
 int mi_flat_reset(mi_flat *h);
 int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int64_t *I,

@@ -1147,6 +1147,40 @@ def test_refine_sq8_matches_oracle(faiss, oracle, d, M):
         other.train(x[:10])
 
 
+def test_release_workspaces_gives_the_scratch_back(faiss):
+    """mi_index_release_workspaces / mi_flat_release_workspaces: searches on several streams leave a scratch set per stream
+    behind; releasing them returns the memory and the next search (which allocates again) gives the same bits."""
+    import torch
+    d, M, nlist, n, k = 128, 16, 64, 30000, 10
+    cent, cb, x, q = random_problem(93, d, M, nlist, n, 512)
+    idx = faiss.index_factory(d, f"IVF{nlist},PQ{M},Refine(SQ8)", faiss.METRIC_INNER_PRODUCT)
+    idx.base_index.set_centroids(cent)
+    idx.base_index.set_codebook(cb)
+    idx.refine_index.train(x)
+    idx.add(x)
+    faiss.ParameterSpace().set_index_parameters(idx, "nprobe=16,k_factor_rf=64")
+    qd = torch.from_numpy(q).cuda()
+    D0, I0 = idx.search(qd, k)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = []
+    for s_ in streams:
+        D, I = torch.empty_like(D0), torch.empty_like(I0)
+        cI = torch.empty((512, 640), dtype=torch.int64, device="cuda")
+        idx.search_into(qd, k, D, I, None, cI, int(s_.cuda_stream))
+        outs.append((D, I))
+    torch.cuda.synchronize()
+    for D, I in outs:
+        assert torch.equal(I, I0) and torch.equal(D.view(torch.int32), D0.view(torch.int32))
+    free0 = torch.cuda.mem_get_info()[0]
+    idx.release_workspaces()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 > free0 + 5 * 512 * 640 * 4                   # at least the five re-rank score buffers came back
+    D1, I1 = idx.search(qd, k)
+    assert torch.equal(I1, I0) and torch.equal(D1.view(torch.int32), D0.view(torch.int32))
+    idx.base_index.release_workspaces()
+    idx.release_workspaces()                                   # nothing left: a no-op
+
+
 def test_refine_sq8_at_the_timed_shape_matches_oracle(faiss, oracle):
     """The shape bench.py's at_recall_095 point times on the 207 M index -- d 1024, k 10, k_factor 512: 5120 candidates
     per query through the unordered-candidates scan, select_pairs_kernel<32,true> and the streaming SQ8 re-rank -- for a
