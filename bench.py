@@ -639,6 +639,8 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     base = index if refine_own else sub
     args_nprobe = index.nprobe                                         # restored below
     ref = faiss.IndexRefine(base, flat_r)
+    torch.cuda.synchronize()
+    ref.release_workspaces()                                           # the main line's scratch sets: this loop brings its own
     qt = getattr(flat_r, "qtype", None)
     relem = 1 if qt == faiss.ScalarQuantizer.QT_8bit else 2 if qt == faiss.ScalarQuantizer.QT_fp16 else 4
     store = {1: "8-bit (SQ8, per-dimension ranges)", 2: "IEEE-half (SQfp16)", 4: "raw f32"}[relem]
