@@ -2365,6 +2365,10 @@ int mi_flat_reconstruct_n(mi_flat *h, int64_t i0, int64_t n, float *out) {
     });
 }
 
+#ifdef MI_SELP_TS
+int mi_debug_selp_stamps(unsigned long long *out) { return guard([&] { MI_HIP(hipDeviceSynchronize()); MI_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(selp_ts), sizeof(unsigned long long) * 8 * 4096)); }); }
+#endif
+
 int mi_flat_release_workspaces(mi_flat *h) {
     return guard([&] {
         MI_REQUIRE(h, "null argument");

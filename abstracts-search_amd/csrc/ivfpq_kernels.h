@@ -954,6 +954,12 @@ __global__ void __launch_bounds__(256)
 // order of its candidates): the same K entries, written in no particular order and without their scores -- the exact
 // K-th key by a descent over the survivors in LDS instead of the 91-stage bitonic sort of 8192 slots (1.24 ms of the
 // 4.6 ms whole-index refine step).  Ties at the cut that do not all fit keep the sorted route (ids decide).
+#ifdef MI_SELP_TS   // profiling build only (tools/micro/selp_stamps.py): s_memtime at the phase boundaries of every workgroup
+__device__ unsigned long long selp_ts[8 * 4096];
+#define SELP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) selp_ts[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SELP_STAMP(i) do {} while (0)
+#endif
 template <int VPT_, bool SET_ = false>
 __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
     select_pairs_kernel(const float *__restrict__ S, const int64_t *__restrict__ IDS, int64_t ld,
@@ -971,6 +977,7 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = uniform_i(tid >> 6);
     const int64_t row = blockIdx.x;
+    SELP_STAMP(0);
     const int n = p_prefix[row * (nprobe + 1) + nprobe] * 64;
     const float *r = S + row * ld;
     const int64_t *ids = IDS + row * ld;
@@ -998,6 +1005,7 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
         c_eq = 0;
     }
     int ph = 0;
+    SELP_STAMP(1);
     auto block_sum = [&](int wave_total) -> int {   // one barrier; alternating slots
         if (lane == 0) wcnt[ph][w] = wave_total;
         __syncthreads();
@@ -1052,7 +1060,9 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
             __syncthreads();
         }
     };
+    SELP_STAMP(2);
     compact([&](unsigned kx, int) { return kx >= T0; });
+    SELP_STAMP(3);
     int Sn = c_cnt;
     if (Sn > CAP) {   // workgroup-uniform
         // exact route: counts over the whole row, streamed (rare: masses of tied scores)
@@ -1114,11 +1124,16 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
         int64_t U = INT64_MAX;      // ties at T with id < U are kept, of those with id == U the first take_u
         int take_u = 0;
         const bool all = Sn <= K;
-        if (!all) {
-            // the survivors' keys in registers (CAP / 256 per thread): the descent is ballots + popcounts, no LDS traffic
-            unsigned mine[VPT_];
+        // the survivors' keys in registers (CAP / 256 per thread): the descent is ballots + popcounts, no LDS traffic
+        unsigned mine[VPT_];
 #pragma unroll
-            for (int j = 0; j < VPT_; ++j) mine[j] = (j * 256 + tid) < Sn ? sk[j * 256 + tid] : 0u;
+        for (int j = 0; j < VPT_; ++j) mine[j] = (j * 256 + tid) < Sn ? sk[j * 256 + tid] : 0u;
+        // ... and their ids, every load of a thread in flight at once and under the descent below (fetched inside the output
+        // loop each of its up to 32 rounds waited for its own scattered load: ~45 us of a ~170 us workgroup)
+        int64_t idv[VPT_];
+#pragma unroll
+        for (int j = 0; j < VPT_; ++j) idv[j] = mine[j] != 0u ? ids[sid[j * 256 + tid]] : (int64_t)0;
+        if (!all) {
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned t = T | (1u << bit);
                 int c = 0;
@@ -1154,18 +1169,19 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
                 take_u = take_eq - count_ties([&](int64_t id) { return id < U; });
             }
         }
+        SELP_STAMP(4);
         if (tid == 0) {
             c_cnt = 0;
             c_eq = 0;
         }
         __syncthreads();
-        for (int base = 0; base < Sn; base += 256) {
-            const int e = base + tid;
-            bool keep = e < Sn && sk[e] != 0u;
-            int64_t id = 0;
-            if (keep) id = ids[sid[e]];
+#pragma unroll
+        for (int j = 0; j < VPT_; ++j) {
+            if (j * 256 >= Sn) continue;                   // workgroup-uniform (no break: the loop must unroll, idv[] lives in registers)
+            bool keep = mine[j] != 0u;
+            const int64_t id = idv[j];
             if (keep && !all) {
-                const unsigned kx = sk[e];
+                const unsigned kx = mine[j];
                 keep = kx > T || (kx == T && (take_eq == ceq || id < U || (id == U && atomicAdd(&c_eq, 1) < take_u)));
             }
             const unsigned long long m = __ballot(keep);
@@ -1176,6 +1192,8 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
         }
         __syncthreads();
         for (int e = c_cnt + tid; e < K; e += 256) I[row * ldo + e] = (int64_t)-1;
+        SELP_STAMP(5);
+        if (tid == 0 && blockIdx.x < 4096) selp_ts[blockIdx.x * 8 + 6] = (unsigned long long)Sn;
         return;
     } else {
     int P = 64;
