@@ -1193,7 +1193,9 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
         __syncthreads();
         for (int e = c_cnt + tid; e < K; e += 256) I[row * ldo + e] = (int64_t)-1;
         SELP_STAMP(5);
+#ifdef MI_SELP_TS
         if (tid == 0 && blockIdx.x < 4096) selp_ts[blockIdx.x * 8 + 6] = (unsigned long long)Sn;
+#endif
         return;
     } else {
     int P = 64;
