@@ -982,23 +982,54 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
     const float *r = S + row * ld;
     const int64_t *ids = IDS + row * ld;
     constexpr int VPT = VPT_, TILE = 256 * VPT;
-    const bool one_tile = n <= TILE;
-    unsigned key[VPT];
-    auto load_tile = [&](int base) {
+    // Which column a thread's j-th value of a tile is, is free (the survivors carry their column): four CONSECUTIVE columns per
+    // lane, one 16-byte load -- 25.6 k scores per query as 32 four-byte loads per thread and round ran at 0.75 TB/s chip-wide
+    // (profiles/r04_select_pairs_stamps.txt: the first pass was 43 % of the kernel).
+    auto col_of = [&](int base, int j) { return base + (((j >> 2) << 8) + tid) * 4 + (j & 3); };
+    const bool wide = ((reinterpret_cast<uintptr_t>(r) | (uintptr_t)(ld * 4)) & 15) == 0;   // (workgroup-uniform) rows 16-byte aligned
+    auto load_tile = [&](int base, unsigned (&key)[VPT]) {
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            const int c = base + j * 256 + tid;
-            const float v = r[min(c, max(n - 1, 0))];
-            key[j] = (c < n && v == v) ? f2o(v) : 0u;
+        for (int j4 = 0; j4 < VPT / 4; ++j4) {
+            const int c0 = col_of(base, 4 * j4);
+            float v[4];
+            if (wide) {
+                const float4 t = *reinterpret_cast<const float4 *>(r + (c0 < n ? c0 : 0));   // n is a multiple of 64: all four or none
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = r[min(c0 + q, max(n - 1, 0))];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) key[4 * j4 + q] = (c0 + q < n && v[q] == v[q]) ? f2o(v[q]) : 0u;
         }
     };
+    // up to RT tiles of keys stay in registers between the two passes (32 k scores at VPT 32: the refine stage's rows): the
+    // compaction pass then reads nothing
+    constexpr int RT = 4;
+    const bool resident = n <= RT * TILE;
+    unsigned kk[RT][VPT];
     unsigned gm[VPT];
 #pragma unroll
     for (int j = 0; j < VPT; ++j) gm[j] = 0u;
-    for (int base = 0; base < n; base += TILE) {
-        load_tile(base);
+    if (resident) {
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) gm[j] = max(gm[j], key[j]);
+        for (int t = 0; t < RT; ++t) {
+            if (t * TILE < n) load_tile(t * TILE, kk[t]);
+            else {
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) kk[t][j] = 0u;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) gm[j] = max(gm[j], kk[t][j]);
+    } else {
+        for (int base = 0; base < n; base += TILE) {
+            load_tile(base, kk[0]);
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) gm[j] = max(gm[j], kk[0][j]);
+        }
     }
     if (tid == 0) {
         c_cnt = 0;
@@ -1025,13 +1056,12 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
     }
     // survivors of `keep(key, column)` into sk / sid
     auto compact = [&](auto keep) {
-        for (int base = 0; base < n; base += TILE) {
-            if (!one_tile) load_tile(base);
+        auto tile = [&](int base, const unsigned (&key)[VPT]) {
             unsigned long long m[VPT];
             int tot = 0;
 #pragma unroll
             for (int j = 0; j < VPT; ++j) {
-                m[j] = __ballot(key[j] != 0u && keep(key[j], base + j * 256 + tid));
+                m[j] = __ballot(key[j] != 0u && keep(key[j], col_of(base, j)));
                 tot += __popcll(m[j]);
             }
             if (tot) {
@@ -1044,11 +1074,21 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
                         const int pos = o + lane_prefix_count(m[j]);
                         if (((m[j] >> lane) & 1ull) && pos < CAP) {
                             sk[pos] = key[j];
-                            sid[pos] = (SlotT)(base + j * 256 + tid);   // the column; its id is fetched below (set mode: on output)
+                            sid[pos] = (SlotT)col_of(base, j);   // the column; its id is fetched below (set mode: on output)
                         }
                         o += __popcll(m[j]);
                     }
                 }
+            }
+        };
+        if (resident) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+                if (t * TILE < n) tile(t * TILE, kk[t]);
+        } else {
+            for (int base = 0; base < n; base += TILE) {
+                load_tile(base, kk[0]);
+                tile(base, kk[0]);
             }
         }
         __syncthreads();
