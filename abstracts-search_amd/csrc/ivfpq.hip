@@ -2311,9 +2311,18 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
         if (h->elem == 4) launch_rerank_scores<float>(qs, (int)nq, h->base.get<float>(), h->ntotal, h->da, ci, kc, scores, kc, st);
         else if (h->elem == 1) launch_rerank_sq8(qs, (int)nq, h->base.get<uint8_t>(), h->ntotal, h->d, h->sq_trained.get<float>(), ci, kc, scores, kc, w.qaug, st);
         else launch_rerank_scores<f16_t>(qs, (int)nq, h->base.get<f16_t>(), h->ntotal, h->d, ci, kc, scores, kc, st);
-        // the candidate list as kc/k "parts" of k entries: the k-way merge ranks them under
-        // (score desc, id asc) and skips the negative ids
-        launch_merge(scores, ci, kc / k, k, kc, nq, k, Dc, Ic, k, 0, nullptr, nullptr, st, -1, IdMap{}, &w.bigmerge);
+        // the k best under (score desc, id asc), negative ids skipped: a few results of a long list in one pass over the rows
+        // (topk_rows_kernel); otherwise the candidate list as kc/k "parts" of k entries through the k-way merge
+        const bool no_rows = std::getenv("MI_NO_TOPK_ROWS") != nullptr;   // (read per call: the tests run both routes)
+        if (k <= 32 && kc >= 256 && kc <= 8192 && !no_rows) {
+            const int vpt = (kc + 255) / 256;
+            if (vpt <= 8) hipLaunchKernelGGL((topk_rows_kernel<8>), dim3((unsigned)nq), dim3(256), 0, st, scores, ci, kc, k, Dc, Ic, (int64_t)k);
+            else if (vpt <= 20) hipLaunchKernelGGL((topk_rows_kernel<20>), dim3((unsigned)nq), dim3(256), 0, st, scores, ci, kc, k, Dc, Ic, (int64_t)k);
+            else hipLaunchKernelGGL((topk_rows_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, scores, ci, kc, k, Dc, Ic, (int64_t)k);
+            MI_HIP(hipGetLastError());
+        } else {
+            launch_merge(scores, ci, kc / k, k, kc, nq, k, Dc, Ic, k, 0, nullptr, nullptr, st, -1, IdMap{}, &w.bigmerge);
+        }
         if (l2) {
             hipLaunchKernelGGL(l2_flat_finish_kernel, dim3((unsigned)(((size_t)nq * k + 255) / 256)), dim3(256), 0, st, Dc, Ic,
                                w.qn.get<float>(), nq, k);

@@ -2542,6 +2542,66 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// The k best (score desc, id asc) of each row of kc (score, id) candidates, negative ids and NaN scores skipped: the last step of
+// a re-rank, k <= 32 of up to 8192 exact scores per query.  One 256-thread workgroup per row, the candidates in registers
+// (kc / 256 per thread), k rounds of a block-wide arg-max on 96-bit (score key, id) keys -- where the general route
+// (gather_parts_kernel + the sorting select_pairs_kernel) spent 36 + 33 us at 1024 x 5120, this is one pass over the rows.
+template <int VPT_>
+__global__ void __launch_bounds__(256) topk_rows_kernel(const float *__restrict__ S, const int64_t *__restrict__ IDS, int kc, int k,
+                                                        float *__restrict__ D, int64_t *__restrict__ I, int64_t ldo) {
+    __shared__ unsigned wk[2][4];
+    __shared__ long long wi[2][4];
+    __shared__ int wp[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t row = blockIdx.x;
+    unsigned key[VPT_];
+    long long id[VPT_];
+#pragma unroll
+    for (int j = 0; j < VPT_; ++j) {
+        const int c = j * 256 + tid;
+        const int cc = min(c, kc - 1);
+        const float v = S[row * kc + cc];
+        const long long t = IDS[row * kc + cc];
+        id[j] = t;
+        key[j] = (c < kc && t >= 0 && v == v) ? f2o(v) : 0u;
+    }
+    for (int r = 0; r < k; ++r) {
+        // this round's best under (key desc, id asc, position asc): the position only separates a caller's duplicate ids
+        unsigned bk = 0u;
+        long long bi = 0x7fffffffffffffffll;
+        int bp = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < VPT_; ++j) {
+            const bool better = key[j] > bk || (key[j] == bk && key[j] != 0u && id[j] < bi);   // (positions ascend with j)
+            if (better) { bk = key[j]; bi = id[j]; bp = j * 256 + tid; }
+        }
+        auto take = [&](unsigned ok, long long oi, int op) {
+            if (ok > bk || (ok == bk && (oi < bi || (oi == bi && op < bp)))) { bk = ok; bi = oi; bp = op; }
+        };
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned ok = (unsigned)__shfl_xor((int)bk, off);
+            const long long oi = ((long long)__shfl_xor((int)(bi >> 32), off) << 32) | (unsigned)__shfl_xor((int)bi, off);
+            const int op = __shfl_xor(bp, off);
+            take(ok, oi, op);
+        }
+        if (lane == 0) { wk[r & 1][w] = bk; wi[r & 1][w] = bi; wp[r & 1][w] = bp; }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 4; ++x) take(wk[r & 1][x], wi[r & 1][x], wp[r & 1][x]);
+        if (tid == 0) {
+            D[row * ldo + r] = bk ? o2f(bk) : -FLT_MAX;
+            I[row * ldo + r] = bk ? (int64_t)bi : (int64_t)-1;
+        }
+        if (bk == 0u) continue;                              // (workgroup-uniform) nothing left: the remaining rounds write the padding
+        if ((bp & 255) == tid) {
+#pragma unroll
+            for (int j = 0; j < VPT_; ++j)
+                if (j == (bp >> 8)) key[j] = 0u;             // the winner leaves
+        }
+    }
+}
+
 __host__ __device__ inline size_t merge_wave_bytes(int nparts, int k) {
     size_t n = (size_t)nparts * k;
     return ((n * 12 + 7) & ~(size_t)7) + (size_t)k * 16;   // e_id[n] e_s[n] | o_id[k] o_s[k](+pad)

@@ -1147,6 +1147,37 @@ def test_refine_sq8_matches_oracle(faiss, oracle, d, M):
         other.train(x[:10])
 
 
+@pytest.mark.parametrize("kc,k", [(1000, 10), (5120, 10), (8192, 32), (300, 1), (2560, 20)])
+def test_rerank_topk_of_long_candidate_lists(faiss, oracle, kc, k, monkeypatch):
+    """IndexFlat.rerank with candidate lists of 256..8192 entries and k <= 32 (the last step of the recall >= 0.95 point:
+    10 of 5120): topk_rows_kernel against the oracle's re-rank and against the general merge route (MI_NO_TOPK_ROWS=1) --
+    empty slots (-1), a caller's duplicate ids (both copies are returned, like the oracle), fewer valid candidates than k."""
+    import torch
+    d, n, nq = 64, 6000, 23
+    rng = np.random.default_rng(kc + k)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[100:140] = x[100]                                        # equal scores: ids decide
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    cand = rng.integers(0, n, (nq, kc)).astype(np.int64)       # (with replacement: duplicates)
+    cand[rng.random((nq, kc)) < 0.1] = -1
+    cand[0, :40] = np.arange(100, 140)
+    cand[1] = -1
+    cand[1, 5] = 77                                            # one valid candidate: the rest of the row is padding
+    cand[2] = -1
+    idx = faiss.IndexFlatIP(d)
+    idx.add(x)
+    De, Ie = oracle.rerank(q, x, cand, k)
+    outs = {}
+    for name in ("rows", "merge"):
+        monkeypatch.delenv("MI_NO_TOPK_ROWS", raising=False)
+        if name == "merge":
+            monkeypatch.setenv("MI_NO_TOPK_ROWS", "1")
+        D, I = idx.rerank(torch.from_numpy(q).cuda(), torch.from_numpy(cand).cuda(), k)
+        outs[name] = (D.cpu().numpy(), I.cpu().numpy())
+        assert np.array_equal(outs[name][1], Ie) and np.array_equal(bits(outs[name][0]), bits(De)), name
+    assert (outs["rows"][1][2] == -1).all() and outs["rows"][1][1, 0] == 77 and (outs["rows"][1][1, 1:] == -1).all()
+
+
 def test_release_workspaces_gives_the_scratch_back(faiss):
     """mi_index_release_workspaces / mi_flat_release_workspaces: searches on several streams leave a scratch set per stream
     behind; releasing them returns the memory and the next search (which allocates again) gives the same bits."""
