@@ -393,17 +393,21 @@ void launch_scan(int M, const ScanArgs &a, hipStream_t st) {
 
 // the K best pairs of every row (K <= 4096: 48 KiB of LDS per workgroup; K <= 8192: 96 KiB)
 // as_set: ids only (D may be null), in no particular order -- what the first stage of a refine search needs
+// IDS null: the ids of the survivors come from the lists through the probe tables (p_goff [rows][nprobe], list_ids = the scan
+// image's id array) -- the all-scores scan then stores scores only
 void launch_select_pairs(const float *S, const int64_t *IDS, int64_t ld, const int32_t *p_prefix, int nprobe, int K, int64_t rows,
-                         float *D, int64_t *I, int64_t ldo, hipStream_t st, bool as_set = false) {
+                         float *D, int64_t *I, int64_t ldo, hipStream_t st, bool as_set = false, const int32_t *p_goff = nullptr,
+                         const int64_t *list_ids = nullptr) {
     MI_REQUIRE(K <= SELP_CAP, "select_pairs: K too large (max 8192)");
     MI_REQUIRE(as_set || D, "select_pairs: scores requested without a buffer");
+    MI_REQUIRE(IDS || (p_goff && list_ids), "select_pairs: neither an id row nor the probe tables");
     const dim3 grid((unsigned)rows), block(256);
     if (as_set) {
-        if (K <= SELB_CAP) hipLaunchKernelGGL((select_pairs_kernel<16, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
-        else hipLaunchKernelGGL((select_pairs_kernel<32, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
+        if (K <= SELB_CAP) hipLaunchKernelGGL((select_pairs_kernel<16, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
+        else hipLaunchKernelGGL((select_pairs_kernel<32, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
     } else {
-        if (K <= SELB_CAP) hipLaunchKernelGGL((select_pairs_kernel<16, false>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
-        else hipLaunchKernelGGL((select_pairs_kernel<32, false>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo);
+        if (K <= SELB_CAP) hipLaunchKernelGGL((select_pairs_kernel<16, false>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
+        else hipLaunchKernelGGL((select_pairs_kernel<32, false>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
     }
     MI_HIP(hipGetLastError());
 }
@@ -1283,7 +1287,10 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         }
         const int64_t qc = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (R * 12)));
         float *all_s = w.all_s.as<float>((size_t)(qc * R));
-        int64_t *all_id = w.all_id.as<int64_t>((size_t)(qc * R));
+        // scores only (inner product): the selection fetches the survivors' ids from the lists; MI_ALLSCORES_IDS=1 (and METRIC_L2,
+        // whose scan variant was left as it is) keeps the row of ids beside the scores
+        const bool ids_row = l2 || std::getenv("MI_ALLSCORES_IDS") != nullptr;
+        int64_t *all_id = ids_row ? w.all_id.as<int64_t>((size_t)(qc * R)) : nullptr;
         for (int64_t c0 = 0; c0 < nq; c0 += qc) {
             const int64_t m = std::min(qc, nq - c0);
             ScanArgs a{};
@@ -1303,7 +1310,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
             a.all_s = all_s; a.all_id = all_id; a.all_ld = R;
             launch_scan(M, a, st);
             launch_select_pairs(all_s, all_id, R, a.p_prefix, nprobe, k, m, Ddev ? Ddev + (size_t)c0 * k : nullptr, Idev + (size_t)c0 * k,
-                                (int64_t)k, st, cand_set && !l2);
+                                (int64_t)k, st, cand_set && !l2, a.p_goff, a.ids);
             MI_HIP(hipGetLastError());
         }
         l2_finish();

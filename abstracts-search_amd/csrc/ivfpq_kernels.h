@@ -964,7 +964,8 @@ template <int VPT_, bool SET_ = false>
 __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
     select_pairs_kernel(const float *__restrict__ S, const int64_t *__restrict__ IDS, int64_t ld,
                         const int32_t *__restrict__ p_prefix, int nprobe, int K, float *__restrict__ D,
-                        int64_t *__restrict__ I, int64_t ldo) {
+                        int64_t *__restrict__ I, int64_t ldo, const int32_t *__restrict__ p_goff = nullptr,
+                        const int64_t *__restrict__ list_ids = nullptr) {
     constexpr int CAP = 256 * VPT_;
     // the survivors: key + id (sorted mode: the sort moves both), or key + 32-bit column in the set mode, whose ids are
     // fetched when they are written out -- 64 instead of 96 KiB of LDS at 8192 slots: two workgroups per CU, and this
@@ -980,7 +981,38 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
     SELP_STAMP(0);
     const int n = p_prefix[row * (nprobe + 1) + nprobe] * 64;
     const float *r = S + row * ld;
-    const int64_t *ids = IDS + row * ld;
+    // the id of column c: the row of ids the scan stored beside the scores, or -- IDS null: the all-scores scan of an
+    // inner-product search stores scores only -- read from the lists themselves through the probe tables: column c is lane
+    // c % 64 of the query's group c / 64, i.e. group (c / 64 - prefix[p]) of probe p's list, whose groups start at p_goff[p]
+    // (the scan's own addressing).  Only the survivors' ids are ever read: 5 120 of 25.6 k at the recall-0.95 point, where
+    // storing every id cost the scan 16 of its 84 bytes per code.
+    // (the two probe tables of the row in LDS when they fit: the search is then registers and LDS, the id itself one load)
+    constexpr int TAB = 256;
+    __shared__ int s_pre[TAB + 1], s_goff[TAB];
+    const int32_t *pre_g = p_prefix + row * (nprobe + 1);
+    const bool tab_lds = !IDS && nprobe <= TAB;
+    if (tab_lds) {
+        for (int p = tid; p <= nprobe; p += 256) s_pre[p] = pre_g[p];
+        for (int p = tid; p < nprobe; p += 256) s_goff[p] = p_goff[row * nprobe + p];
+        __syncthreads();
+    }
+    auto id_at = [&](int c) -> int64_t {
+        if (IDS) return IDS[row * ld + c];
+        const int t = c >> 6;
+        int lo = 0, hi = nprobe;                              // last p with prefix[p] <= t
+        if (tab_lds) {
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pre[mid] <= t) lo = mid; else hi = mid;
+            }
+            return list_ids[(size_t)(s_goff[lo] + (t - s_pre[lo])) * 64 + (c & 63)];
+        }
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre_g[mid] <= t) lo = mid; else hi = mid;
+        }
+        return list_ids[(size_t)(p_goff[row * nprobe + lo] + (t - pre_g[lo])) * 64 + (c & 63)];
+    };
     constexpr int VPT = VPT_, TILE = 256 * VPT;
     // Which column a thread's j-th value of a tile is, is free (the survivors carry their column): four CONSECUTIVE columns per
     // lane, one 16-byte load -- 25.6 k scores per query as 32 four-byte loads per thread and round ran at 0.75 TB/s chip-wide
@@ -1096,7 +1128,7 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
         // every load sat in front of its own LDS store: a DRAM latency per survivor column)
         if constexpr (!SET_) {
             const int got = min(c_cnt, CAP);
-            for (int e = tid; e < got; e += 256) sid[e] = ids[sid[e]];
+            for (int e = tid; e < got; e += 256) sid[e] = id_at((int)sid[e]);
             __syncthreads();
         }
     };
@@ -1140,15 +1172,15 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
             int64_t U = 0;
             for (int bit = 62; bit >= 0; --bit) {
                 const int64_t t = U | ((int64_t)1 << bit);
-                const int c = count_row([&](unsigned kx, int col) { return kx == T && ids[col] < t; });
+                const int c = count_row([&](unsigned kx, int col) { return kx == T && id_at(col) < t; });
                 if (c < need) U = t;
             }
-            const int below = count_row([&](unsigned kx, int col) { return kx == T && ids[col] < U; });
+            const int below = count_row([&](unsigned kx, int col) { return kx == T && id_at(col) < U; });
             const int take_eq = need - below;   // entries with id == U to keep (duplicated ids)
             compact([&](unsigned kx, int col) {
                 if (kx > T) return true;
                 if (kx != T) return false;
-                const int64_t id = ids[col];
+                const int64_t id = id_at(col);
                 if (id < U) return true;
                 if (id > U) return false;
                 return atomicAdd(&c_eq, 1) < take_eq;
@@ -1172,7 +1204,7 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
         // loop each of its up to 32 rounds waited for its own scattered load: ~45 us of a ~170 us workgroup)
         int64_t idv[VPT_];
 #pragma unroll
-        for (int j = 0; j < VPT_; ++j) idv[j] = mine[j] != 0u ? ids[sid[j * 256 + tid]] : (int64_t)0;
+        for (int j = 0; j < VPT_; ++j) idv[j] = mine[j] != 0u ? id_at((int)sid[j * 256 + tid]) : (int64_t)0;
         if (!all) {
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned t = T | (1u << bit);
@@ -1197,7 +1229,7 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
                     int c = 0;
                     for (int base = 0; base < Sn; base += 256) {
                         const int e = base + tid;
-                        c += __popcll(__ballot(e < Sn && sk[e] == T && pred(ids[sid[min(e, Sn - 1)]])));
+                        c += __popcll(__ballot(e < Sn && sk[e] == T && pred(id_at((int)sid[min(e, Sn - 1)]))));
                     }
                     return block_sum(c);
                 };
@@ -2142,7 +2174,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         const uint4 *gp = reinterpret_cast<const uint4 *>(a.codes + (size_t)gg * (NCH * 1024)) + lane;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) g.c[ch] = gp[ch * 64];
-        g.id = a.ids[(size_t)gg * 64 + lane];
+        if (!ALL || a.all_id) g.id = a.ids[(size_t)gg * 64 + lane];
         if constexpr (L2) g.t = a.tnorm[(size_t)gg * 64 + lane];
     };
     // Two groups per wave are requested before the LUT barrier (most of a cfg2-sized
@@ -2175,7 +2207,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         if constexpr (ALL) {
             const size_t o = (size_t)q * a.all_ld + (size_t)t * 64 + lane;   // t: this group's index in the query
             a.all_s[o] = lane < g.nvalid ? s : __builtin_nanf("");
-            a.all_id[o] = g.id;
+            if (a.all_id) a.all_id[o] = g.id;                 // (null: the selection reads the survivors' ids from the lists)
             return;
         }
         if (n_proc == 0) stamp(13);

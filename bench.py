@@ -667,7 +667,8 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
         curve.append([nprobe, kf, round(r, 4)])
         return r
 
-    for nprobe in (8, 16, 32, 64, 128, 256):
+    nprobes = [int(v) for v in os.environ.get("BENCH_REFINE_NPROBES", "8,16,32,64,128,256").split(",")]
+    for nprobe in nprobes:
         if nprobe > base.nlist:
             break
         prev = None
