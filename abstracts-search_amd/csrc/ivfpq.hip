@@ -1300,6 +1300,13 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
             a.p_prefix = pt.p_prefix + (size_t)c0 * (nprobe + 1);
             a.codes = h->d_codes.get<uint8_t>(); a.ids = h->d_ids.get<int64_t>();
             a.nq = (int)m; a.nprobe = nprobe; a.nslice = choose_nslice(h, m, nprobe); a.k = 64;
+            if (!std::getenv("MI_NSLICE")) {
+                // the all-scores scan has no cross-slice merge to keep short: slices of ~64 groups even out the rounds of
+                // workgroups better than the k-limited count above (1024 queries x 395 groups: 1 / 2 / 3 / 6 / 8 / 12 slices
+                // 449 / 401 / 389 / 366 / 384 / 393 us -- tools/micro/nslice_sweep.sh)
+                const double per_query = (h->nlist > 0 ? (double)h->ngroups / h->nlist : 0.0) * nprobe;
+                a.nslice = std::max(a.nslice, (int)std::min(6.0, per_query / 64.0));
+            }
             a.by_residual = l2 ? 1 : h->by_residual;
             a.nw = 8;
             {
