@@ -1102,10 +1102,15 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
         }
     }
     Range stack_range("mi_encoder:stack");
-    hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, st, b.ids,
-                       h->embed.get<bf16_t>(), H, T, x);
-    MI_HIP(hipGetLastError());
     int normed = 0;                                  // what the previous residual GEMM left of this layer's first RMSNorm
+    if (H <= 2048 && H % 4 == 0 && !std::getenv("MI_NO_EMBED_NORM")) {   // the first layer's RMSNorm rides in the embedding gather
+        hipLaunchKernelGGL(embed_norm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, b.ids, h->embed.get<bf16_t>(), H, T, x,
+                           h->layers[0].ln1.get<float>(), c.rms_eps, xn);
+        normed = GEMM_NORMED;
+    } else {
+        hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, st, b.ids, h->embed.get<bf16_t>(), H, T, x);
+    }
+    MI_HIP(hipGetLastError());
     for (int l = 0; l < c.n_layers; ++l) {
         LayerW &w = h->layers[l];
         Range layer_range("mi_encoder:layer");

@@ -83,6 +83,49 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------------
+// The same with the first layer's RMSNorm in the same pass (the wave holds the whole row): x as above and
+// y[t][:] = bf16( x[t][:] * rsqrt(mean(x^2) + eps) * w[:] ) -- exactly what rmsnorm_kernel would then compute from x (the
+// f32 values are the table's bf16 values widened, the sums run in the same order), without reading the stream back.
+// H <= 2048 (8 chunks of 256 columns per lane in registers); the launcher falls back to the two kernels otherwise.
+// ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    embed_norm_kernel(const int32_t *__restrict__ ids, const bf16_t *__restrict__ table, int H, int T, float *__restrict__ x,
+                      const float *__restrict__ w, float eps, bf16_t *__restrict__ y) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;
+    const bf16_t *src = table + (size_t)ids[t] * H;
+    float *dst = x + (size_t)t * H;
+    bf16_t *yd = y + (size_t)t * H;
+    constexpr int MAXC = 8;
+    float4 v[MAXC], g[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = min(lane * 4 + 256 * i, H - 4);         // clamped: unconditional loads (rmsnorm_kernel's column map)
+        const uint2 raw = *reinterpret_cast<const uint2 *>(src + c);
+        v[i].x = __uint_as_float(raw.x << 16); v[i].y = __uint_as_float(raw.x & 0xffff0000u);
+        v[i].z = __uint_as_float(raw.y << 16); v[i].w = __uint_as_float(raw.y & 0xffff0000u);
+        g[i] = *reinterpret_cast<const float4 *>(w + c);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+        if (lane * 4 + 256 * i < H) ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    ss = wave_sum(ss);
+    const float inv = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) {
+            *reinterpret_cast<float4 *>(dst + c) = v[i];
+            uint2 o;
+            o.x = pack2(v[i].x * inv * g[i].x, v[i].y * inv * g[i].y);
+            o.y = pack2(v[i].z * inv * g[i].z, v[i].w * inv * g[i].w);
+            *reinterpret_cast<uint2 *>(yd + c) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------
 // y[t][:] = bf16( x[t][:] * rsqrt(mean(x^2) + eps) * w[:] ), one wave per token
 // ---------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

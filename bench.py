@@ -1104,7 +1104,7 @@ def cfg2_workload(args, ctx):
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_cfg2_scan_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_cfg2_scan_pmc.json")))
         if (N, nlist, batch, nprobe, k, world) == (1_000_000, 4096, 64, 16, 10, 1) and not os.environ.get("MI_NSLICE"):
             traffic = int(pmc["corrected_bytes_per_launch"])
     except Exception:
@@ -1112,7 +1112,9 @@ def cfg2_workload(args, ctx):
     roofline = {"kernel": "scan_kernel<64,8,false>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, gfx950 x2 read correction "
-                                  "(profiles/r01_cfg2_scan_pmc.json, round-1 kernel)" if traffic else None,
+                                  "(profiles/r04_cfg2_scan_pmc.json, round-4 kernel)" if traffic else None,
+                "note": "a 14-15 us launch: a latency chain (tables + LUT staging, three rounds of gathers, rank / publish / merge), not a "
+                        "bandwidth number -- DESIGN.md section 5",
                 "bytes_per_launch": int(scan_bytes), "avg_launch_ms": round(scan_ms, 5)}
     if rank != 0:
         return None
