@@ -395,6 +395,11 @@ void launch_scan(int M, const ScanArgs &a, hipStream_t st) {
 // as_set: ids only (D may be null), in no particular order -- what the first stage of a refine search needs
 // IDS null: the ids of the survivors come from the lists through the probe tables (p_goff [rows][nprobe], list_ids = the scan
 // image's id array) -- the all-scores scan then stores scores only
+// threads per row of the 8192-slot set selection (MI_SELP_NT = 256 | 512: A/B knob)
+static int selp_nt() {
+    static const int nt = std::getenv("MI_SELP_NT") ? std::atoi(std::getenv("MI_SELP_NT")) : 512;
+    return nt;
+}
 void launch_select_pairs(const float *S, const int64_t *IDS, int64_t ld, const int32_t *p_prefix, int nprobe, int K, int64_t rows,
                          float *D, int64_t *I, int64_t ldo, hipStream_t st, bool as_set = false, const int32_t *p_goff = nullptr,
                          const int64_t *list_ids = nullptr) {
@@ -404,6 +409,7 @@ void launch_select_pairs(const float *S, const int64_t *IDS, int64_t ld, const i
     const dim3 grid((unsigned)rows), block(256);
     if (as_set) {
         if (K <= SELB_CAP) hipLaunchKernelGGL((select_pairs_kernel<16, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
+        else if (selp_nt() == 512) hipLaunchKernelGGL((select_pairs_kernel<16, true, 512>), grid, dim3(512), 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
         else hipLaunchKernelGGL((select_pairs_kernel<32, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
     } else {
         if (K <= SELB_CAP) hipLaunchKernelGGL((select_pairs_kernel<16, false>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);

@@ -960,20 +960,24 @@ __device__ unsigned long long selp_ts[8 * 4096];
 #else
 #define SELP_STAMP(i) do {} while (0)
 #endif
-template <int VPT_, bool SET_ = false>
-__global__ void __launch_bounds__(256, SET_ ? 2 : 1)
+// NT_ threads per workgroup (CAP = NT_ VPT_ slots): <32, ., 256> and <16, ., 512> hold the same 8192 slots -- twice the waves
+// per row halve every per-thread chain (ballots per descent step, loads per pass, output rounds)
+template <int VPT_, bool SET_ = false, int NT_ = 256>
+__global__ void __launch_bounds__(NT_, SET_ ? (NT_ == 256 ? 2 : 4) : 1)
     select_pairs_kernel(const float *__restrict__ S, const int64_t *__restrict__ IDS, int64_t ld,
                         const int32_t *__restrict__ p_prefix, int nprobe, int K, float *__restrict__ D,
                         int64_t *__restrict__ I, int64_t ldo, const int32_t *__restrict__ p_goff = nullptr,
                         const int64_t *__restrict__ list_ids = nullptr) {
-    constexpr int CAP = 256 * VPT_;
+    constexpr int CAP = NT_ * VPT_;
+    constexpr int NW = NT_ / 64;
     // the survivors: key + id (sorted mode: the sort moves both), or key + 32-bit column in the set mode, whose ids are
     // fetched when they are written out -- 64 instead of 96 KiB of LDS at 8192 slots: two workgroups per CU, and this
     // kernel spends two thirds of its wave cycles waiting (memory round trips, 70 block-wide barriers)
     using SlotT = std::conditional_t<SET_, int32_t, int64_t>;
     __shared__ unsigned sk[CAP];
     __shared__ SlotT sid[CAP];
-    __shared__ int wcnt[2][4];
+    __shared__ int wcnt[2][NW];
+    __shared__ unsigned wmm[2][2][NW];
     __shared__ int c_cnt, c_eq;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = uniform_i(tid >> 6);
@@ -992,8 +996,8 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
     const int32_t *pre_g = p_prefix + row * (nprobe + 1);
     const bool tab_lds = !IDS && nprobe <= TAB;
     if (tab_lds) {
-        for (int p = tid; p <= nprobe; p += 256) s_pre[p] = pre_g[p];
-        for (int p = tid; p < nprobe; p += 256) s_goff[p] = p_goff[row * nprobe + p];
+        for (int p = tid; p <= nprobe; p += NT_) s_pre[p] = pre_g[p];
+        for (int p = tid; p < nprobe; p += NT_) s_goff[p] = p_goff[row * nprobe + p];
         __syncthreads();
     }
     auto id_at = [&](int c) -> int64_t {
@@ -1013,11 +1017,11 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
         }
         return list_ids[(size_t)(p_goff[row * nprobe + lo] + (t - pre_g[lo])) * 64 + (c & 63)];
     };
-    constexpr int VPT = VPT_, TILE = 256 * VPT;
+    constexpr int VPT = VPT_, TILE = NT_ * VPT;
     // Which column a thread's j-th value of a tile is, is free (the survivors carry their column): four CONSECUTIVE columns per
     // lane, one 16-byte load -- 25.6 k scores per query as 32 four-byte loads per thread and round ran at 0.75 TB/s chip-wide
     // (profiles/r04_select_pairs_stamps.txt: the first pass was 43 % of the kernel).
-    auto col_of = [&](int base, int j) { return base + (((j >> 2) << 8) + tid) * 4 + (j & 3); };
+    auto col_of = [&](int base, int j) { return base + ((j >> 2) * NT_ + tid) * 4 + (j & 3); };
     const bool wide = ((reinterpret_cast<uintptr_t>(r) | (uintptr_t)(ld * 4)) & 15) == 0;   // (workgroup-uniform) rows 16-byte aligned
     auto load_tile = [&](int base, unsigned (&key)[VPT]) {
 #pragma unroll
@@ -1043,15 +1047,38 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
     unsigned gm[VPT];
 #pragma unroll
     for (int j = 0; j < VPT; ++j) gm[j] = 0u;
-    if (resident) {
+    if (resident && wide) {
+        // every load of the thread first (columns past n: the row's first line, key 0), then the keys: written as load +
+        // convert per tile, each 16-byte load was followed by `s_waitcnt vmcnt(0)` and the NaN test's branches -- one memory
+        // latency per load, 32 in a row (the first pass was 36 % of the kernel: profiles/r04_select_pairs_stamps.txt)
+        float4 raw[RT][VPT / 4];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            if (t * TILE < n) load_tile(t * TILE, kk[t]);
-            else {
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int j = 0; j < VPT; ++j) kk[t][j] = 0u;
+            for (int j4 = 0; j4 < VPT / 4; ++j4) {
+                const int c0 = col_of(t * TILE, 4 * j4);
+                raw[t][j4] = *reinterpret_cast<const float4 *>(r + (c0 < n ? c0 : 0));
             }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int j4 = 0; j4 < VPT / 4; ++j4) {
+                const bool in = col_of(t * TILE, 4 * j4) < n;       // n is a multiple of 64: all four or none
+                const float v[4] = {raw[t][j4].x, raw[t][j4].y, raw[t][j4].z, raw[t][j4].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned kx = f2o(v[q]);
+                    kk[t][4 * j4 + q] = (in && v[q] == v[q]) ? kx : 0u;
+                }
+            }
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) gm[j] = max(gm[j], kk[t][j]);
+    } else if (resident) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) load_tile(t * TILE, kk[t]);
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -1072,23 +1099,92 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
     auto block_sum = [&](int wave_total) -> int {   // one barrier; alternating slots
         if (lane == 0) wcnt[ph][w] = wave_total;
         __syncthreads();
-        const int c = wcnt[ph][0] + wcnt[ph][1] + wcnt[ph][2] + wcnt[ph][3];
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) c += wcnt[ph][i];
         ph ^= 1;
         return c;
     };
-    unsigned T0 = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const unsigned t = T0 | (1u << bit);
+    // The K-th largest of the block's keys v (0 = no key; 0 when fewer than K keys): a bitwise descent on the count of keys >= t,
+    // started below the common prefix of the largest and the smallest key -- the scores of one query share their sign, exponent
+    // and often a few mantissa bits: a third of the 32 block-wide steps (with the count of keys, the prefix bits are decided:
+    // count >= K sets every one bit of the prefix, a zero bit of it can never be set).  An exact count ends it early.
+    auto kth_largest = [&](const unsigned (&v)[VPT_]) -> unsigned {
+        unsigned mx = 0u, mn = ~0u;
         int c = 0;
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) c += __popcll(__ballot(gm[j] >= t));
-        c = block_sum(c);
-        if (c >= K) T0 = t;
-        if (c == K) break;
-    }
+        for (int j = 0; j < VPT_; ++j) {
+            mx = max(mx, v[j]);
+            mn = min(mn, v[j] != 0u ? v[j] : ~0u);
+            c += __popcll(__ballot(v[j] != 0u));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+            mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+        }
+        if (lane == 0) {
+            wcnt[ph][w] = c;
+            wmm[ph][0][w] = mx;
+            wmm[ph][1][w] = mn;
+        }
+        __syncthreads();
+        c = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            c += wcnt[ph][i];
+            mx = max(mx, wmm[ph][0][i]);
+            mn = min(mn, wmm[ph][1][i]);
+        }
+        ph ^= 1;
+        if (c < K) return 0u;
+        const unsigned diff = mx ^ mn;
+        int bit = diff ? 31 - __clz((int)diff) : -1;
+        unsigned T = diff ? (mx & ~((2u << bit) - 1u)) : mx;
+        if (c == K) return T;
+        // (two bits a step -- three thresholds, one barrier -- measured slower: 19.4 -> 26.8 us.  A step is bound by the CU's
+        // scalar unit, two scalar instructions per ballot whatever the number of waves that share the keys.)
+        for (; bit >= 0; --bit) {
+            const unsigned t = T | (1u << bit);
+            int cc = 0;
+#pragma unroll
+            for (int j = 0; j < VPT_; ++j) cc += __popcll(__ballot(v[j] >= t));
+            cc = block_sum(cc);
+            if (cc >= K) T = t;
+            if (cc == K) break;
+        }
+        return T;
+    };
+    const unsigned T0 = kth_largest(gm);
     // survivors of `keep(key, column)` into sk / sid
-    auto compact = [&](auto keep) {
+    // (pure: `keep` has no side effects -- the ballots are then taken twice, once for the wave's total and once for the
+    // positions, instead of VPT 64-bit masks held across the slot reservation: 64 SGPRs at VPT 32, which the compiler spilt)
+    auto compact = [&](auto keep, auto pure) {
         auto tile = [&](int base, const unsigned (&key)[VPT]) {
+            if constexpr (decltype(pure)::value) {
+                int tot = 0;
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) tot += __popcll(__ballot(key[j] != 0u && keep(key[j], col_of(base, j))));
+                if (tot) {
+                    int o = 0;
+                    if (lane == 0) o = atomicAdd(&c_cnt, tot);
+                    o = uniform_i(o);
+#pragma unroll
+                    for (int j = 0; j < VPT; ++j) {
+                        const bool kp = key[j] != 0u && keep(key[j], col_of(base, j));
+                        const unsigned long long m = __ballot(kp);
+                        if (m) {
+                            const int pos = o + lane_prefix_count(m);
+                            if (kp && pos < CAP) {
+                                sk[pos] = key[j];
+                                sid[pos] = (SlotT)col_of(base, j);
+                            }
+                            o += __popcll(m);
+                        }
+                    }
+                }
+                return;
+            }
             unsigned long long m[VPT];
             int tot = 0;
 #pragma unroll
@@ -1128,19 +1224,19 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
         // every load sat in front of its own LDS store: a DRAM latency per survivor column)
         if constexpr (!SET_) {
             const int got = min(c_cnt, CAP);
-            for (int e = tid; e < got; e += 256) sid[e] = id_at((int)sid[e]);
+            for (int e = tid; e < got; e += NT_) sid[e] = id_at((int)sid[e]);
             __syncthreads();
         }
     };
     SELP_STAMP(2);
-    compact([&](unsigned kx, int) { return kx >= T0; });
+    compact([&](unsigned kx, int) { return kx >= T0; }, std::true_type{});
     SELP_STAMP(3);
     int Sn = c_cnt;
     if (Sn > CAP) {   // workgroup-uniform
         // exact route: counts over the whole row, streamed (rare: masses of tied scores)
         auto count_row = [&](auto pred) -> int {
             int c = 0;
-            for (int base = 0; base < n; base += 256) {
+            for (int base = 0; base < n; base += NT_) {
                 const int col = base + tid;
                 bool p = false;
                 if (col < n) {
@@ -1164,7 +1260,7 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
         if (tid == 0) c_cnt = 0;
         __syncthreads();
         if (cgt + ceq <= CAP) {
-            compact([&](unsigned kx, int) { return kx >= T; });
+            compact([&](unsigned kx, int) { return kx >= T; }, std::true_type{});
         } else {
             // the (K - cgt)-th smallest id among the entries tied at T: the largest U with
             // fewer than that many tied ids below it
@@ -1184,7 +1280,7 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
                 if (id < U) return true;
                 if (id > U) return false;
                 return atomicAdd(&c_eq, 1) < take_eq;
-            });
+            }, std::false_type{});
         }
         Sn = c_cnt;   // <= CAP now
     }
@@ -1199,22 +1295,44 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
         // the survivors' keys in registers (CAP / 256 per thread): the descent is ballots + popcounts, no LDS traffic
         unsigned mine[VPT_];
 #pragma unroll
-        for (int j = 0; j < VPT_; ++j) mine[j] = (j * 256 + tid) < Sn ? sk[j * 256 + tid] : 0u;
+        for (int j = 0; j < VPT_; ++j) mine[j] = (j * NT_ + tid) < Sn ? sk[j * NT_ + tid] : 0u;
         // ... and their ids, every load of a thread in flight at once and under the descent below (fetched inside the output
         // loop each of its up to 32 rounds waited for its own scattered load: ~45 us of a ~170 us workgroup)
         int64_t idv[VPT_];
+        if (tab_lds) {
+            // the probe-table search of every slot first (a fixed number of branch-free steps, the slots interleaved), then all
+            // the id loads together: through id_at() each slot's search loop and load sat behind the previous slot's
+            int lo[VPT_], hi[VPT_], tg[VPT_], cl[VPT_];
 #pragma unroll
-        for (int j = 0; j < VPT_; ++j) idv[j] = mine[j] != 0u ? id_at((int)sid[j * 256 + tid]) : (int64_t)0;
-        if (!all) {
-            for (int bit = 31; bit >= 0; --bit) {
-                const unsigned t = T | (1u << bit);
-                int c = 0;
-#pragma unroll
-                for (int j = 0; j < VPT_; ++j) c += __popcll(__ballot(mine[j] >= t));
-                c = block_sum(c);
-                if (c >= K) T = t;
-                if (c == K) break;
+            for (int j = 0; j < VPT_; ++j) {
+                const int c = mine[j] != 0u ? (int)sid[j * NT_ + tid] : 0;
+                tg[j] = c >> 6;
+                cl[j] = c & 63;
+                lo[j] = 0;
+                hi[j] = nprobe;
             }
+            int nsteps = 0;
+            while ((1 << nsteps) < nprobe) ++nsteps;
+            for (int st = 0; st < nsteps; ++st) {
+#pragma unroll
+                for (int j = 0; j < VPT_; ++j) {
+                    const int mid = (lo[j] + hi[j]) >> 1;            // hi - lo <= 1: mid = lo, nothing moves
+                    const bool le = s_pre[mid] <= tg[j];
+                    lo[j] = le ? mid : lo[j];
+                    hi[j] = le ? hi[j] : mid;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VPT_; ++j) {
+                const size_t at = (size_t)(s_goff[lo[j]] + (tg[j] - s_pre[lo[j]])) * 64 + cl[j];
+                idv[j] = mine[j] != 0u ? list_ids[at] : (int64_t)0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VPT_; ++j) idv[j] = mine[j] != 0u ? id_at((int)sid[j * NT_ + tid]) : (int64_t)0;
+        }
+        if (!all) {
+            T = kth_largest(mine);
             int cg = 0, ce = 0;
 #pragma unroll
             for (int j = 0; j < VPT_; ++j) {
@@ -1227,7 +1345,7 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
             if (take_eq != ceq) {   // workgroup-uniform, rare: the cut falls inside a run of equal scores -- ids decide
                 auto count_ties = [&](auto pred) -> int {
                     int c = 0;
-                    for (int base = 0; base < Sn; base += 256) {
+                    for (int base = 0; base < Sn; base += NT_) {
                         const int e = base + tid;
                         c += __popcll(__ballot(e < Sn && sk[e] == T && pred(id_at((int)sid[min(e, Sn - 1)]))));
                     }
@@ -1249,7 +1367,7 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < VPT_; ++j) {
-            if (j * 256 >= Sn) continue;                   // workgroup-uniform (no break: the loop must unroll, idv[] lives in registers)
+            if (j * NT_ >= Sn) continue;                   // workgroup-uniform (no break: the loop must unroll, idv[] lives in registers)
             bool keep = mine[j] != 0u;
             const int64_t id = idv[j];
             if (keep && !all) {
@@ -1263,7 +1381,7 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
             if (keep) I[row * ldo + o + lane_prefix_count(m)] = id;
         }
         __syncthreads();
-        for (int e = c_cnt + tid; e < K; e += 256) I[row * ldo + e] = (int64_t)-1;
+        for (int e = c_cnt + tid; e < K; e += NT_) I[row * ldo + e] = (int64_t)-1;
         SELP_STAMP(5);
 #ifdef MI_SELP_TS
         if (tid == 0 && blockIdx.x < 4096) selp_ts[blockIdx.x * 8 + 6] = (unsigned long long)Sn;
@@ -1272,14 +1390,14 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
     } else {
     int P = 64;
     while (P < Sn) P <<= 1;
-    for (int e = Sn + tid; e < P; e += 256) {
+    for (int e = Sn + tid; e < P; e += NT_) {
         sk[e] = 0u;   // after every survivor
         sid[e] = INT64_MAX;
     }
     __syncthreads();
     for (int k2 = 2; k2 <= P; k2 <<= 1)
         for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < (P >> 1); i += 256) {
+            for (int i = tid; i < (P >> 1); i += NT_) {
                 const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                 const int hi = lo | j;
                 const unsigned ka = sk[lo], kb = sk[hi];
@@ -1295,7 +1413,7 @@ __global__ void __launch_bounds__(256, SET_ ? 2 : 1)
             }
             __syncthreads();
         }
-    for (int e = tid; e < K; e += 256) {
+    for (int e = tid; e < K; e += NT_) {
         const bool filled = e < Sn && sk[e] != 0u;
         if (D) D[row * ldo + e] = filled ? o2f(sk[e]) : -FLT_MAX;
         I[row * ldo + e] = filled ? (int64_t)sid[e] : (int64_t)-1;

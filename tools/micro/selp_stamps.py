@@ -26,5 +26,5 @@ names = ["pass 1 (group maxima)", "descent over the maxima", "compaction pass", 
 print("survivors per query: mean %.0f max %.0f" % (a[:, 6].mean(), a[:, 6].max()))
 for i, nm in enumerate(names):
     dlt = a[:, i + 1] - a[:, i]
-    print(f"  {nm:38s} mean {dlt.mean() / 100:8.2f} us   max {dlt.max() / 100:8.2f} us")
-print(f"  whole workgroup                        mean {(a[:, 5] - a[:, 0]).mean() / 100:8.2f} us; first start -> last end {(a[:, 5].max() - a[:, 0].min()) / 100:.1f} us")
+    print(f"  {nm:38s} mean {dlt.mean() / 1000:8.2f} us   max {dlt.max() / 1000:8.2f} us")
+print(f"  whole workgroup                        mean {(a[:, 5] - a[:, 0]).mean() / 1000:8.2f} us; first start -> last end {(a[:, 5].max() - a[:, 0].min()) / 1000:.1f} us   (one s_memtime tick ~ 1 ns on this part)")
