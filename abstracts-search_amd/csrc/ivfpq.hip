@@ -408,7 +408,9 @@ void launch_select_pairs(const float *S, const int64_t *IDS, int64_t ld, const i
     MI_REQUIRE(IDS || (p_goff && list_ids), "select_pairs: neither an id row nor the probe tables");
     const dim3 grid((unsigned)rows), block(256);
     if (as_set) {
-        if (K <= SELB_CAP) hipLaunchKernelGGL((select_pairs_kernel<16, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
+        // (rows longer than the 4096-slot kernel keeps resident -- 4 tiles of 4096 -- go to the 8192-slot one whatever K: it holds
+        //  32 k scores in registers; streamed, a 25.6 k row took 591 us where the resident pass takes ~210)
+        if (K <= SELB_CAP && (ld <= 16384 || selp_nt() != 512)) hipLaunchKernelGGL((select_pairs_kernel<16, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
         else if (selp_nt() == 512) hipLaunchKernelGGL((select_pairs_kernel<16, true, 512>), grid, dim3(512), 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
         else hipLaunchKernelGGL((select_pairs_kernel<32, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
     } else {
