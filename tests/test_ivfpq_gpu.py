@@ -1214,7 +1214,7 @@ def test_release_workspaces_gives_the_scratch_back(faiss):
 
 def test_refine_sq8_at_the_timed_shape_matches_oracle(faiss, oracle):
     """The shape bench.py's at_recall_095 point times on the 207 M index -- d 1024, k 10, k_factor 512: 5120 candidates
-    per query through the unordered-candidates scan, select_pairs_kernel<32,true> and the streaming SQ8 re-rank -- for a
+    per query through the unordered-candidates scan, select_pairs_kernel<16,true,512> and the streaming SQ8 re-rank -- for a
     batch of 256 queries against the oracle: candidate SETS equal, re-ranked ids and score bits equal (duplicated rows:
     ties at every rank).  (reference Makefile:32 `tune` -> the (nprobe, k_factor) operating point.)"""
     import torch
