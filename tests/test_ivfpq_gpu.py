@@ -1099,6 +1099,29 @@ def test_search_candidates_is_the_topk_set(faiss, oracle):
     assert np.array_equal(Ih, Ie) and np.array_equal(bits(Dh), bits(De))
 
 
+def test_search_candidates_rows_longer_than_the_resident_tiles(faiss, oracle):
+    """The set selection keeps up to 4 tiles of 8192 scores of a row in registers; a longer row (here ~45 k scores: every
+    list of a 45 000-vector index probed) is streamed twice instead.  Same contract as above, at kc = 3000 (the 4096-slot
+    kernel hands long rows to the 8192-slot one), 5120 and 8192, with a run of identical vectors across the cut."""
+    import torch
+    cent, cb, x, q = random_problem(57, 32, 4, 24, 45000, 9)
+    x[30000:33000] = x[7]
+    q[0] = x[7]
+    idx = make_index(faiss, cent, cb)
+    idx.add(x)
+    ln, codes = oracle.encode(x, cent, cb)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(len(x)), 24)
+    qd = torch.from_numpy(q).cuda()
+    for kc in (3000, 5120, 8192):
+        I = torch.empty((len(q), kc), dtype=torch.int64, device="cuda")
+        idx.search_candidates_into(qd, kc, I, 24)
+        _, Ie = oracle.search(q, cent, cb, off, lc, li, 24, kc)
+        got = I.cpu().numpy()
+        for r in range(len(q)):
+            a, b = np.sort(got[r]), np.sort(Ie[r])
+            assert np.array_equal(a, b), (kc, r, int((a != b).sum()))
+
+
 @pytest.mark.parametrize("d,M", [(128, 16), (192, 48), (1024, 64)])
 def test_refine_sq8_matches_oracle(faiss, oracle, d, M):
     """factory "IVF..,PQ..,Refine(SQ8)" (faiss IndexScalarQuantizer QT_8bit: per-dimension ranges trained as min /
