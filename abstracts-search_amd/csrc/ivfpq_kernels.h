@@ -1024,17 +1024,32 @@ __global__ void __launch_bounds__(NT_, SET_ ? (NT_ == 256 ? 2 : 4) : 1)
     auto col_of = [&](int base, int j) { return base + ((j >> 2) * NT_ + tid) * 4 + (j & 3); };
     const bool wide = ((reinterpret_cast<uintptr_t>(r) | (uintptr_t)(ld * 4)) & 15) == 0;   // (workgroup-uniform) rows 16-byte aligned
     auto load_tile = [&](int base, unsigned (&key)[VPT]) {
+        if (wide) {   // (workgroup-uniform) the tile's loads first, then the keys: per load, hipcc waits for each before the next
+            float4 raw[VPT / 4];
+#pragma unroll
+            for (int j4 = 0; j4 < VPT / 4; ++j4) {
+                const int c0 = col_of(base, 4 * j4);
+                raw[j4] = *reinterpret_cast<const float4 *>(r + (c0 < n ? c0 : 0));   // n is a multiple of 64: all four or none
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j4 = 0; j4 < VPT / 4; ++j4) {
+                const bool in = col_of(base, 4 * j4) < n;
+                const float v[4] = {raw[j4].x, raw[j4].y, raw[j4].z, raw[j4].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned kx = f2o(v[q]);
+                    key[4 * j4 + q] = (in && v[q] == v[q]) ? kx : 0u;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j4 = 0; j4 < VPT / 4; ++j4) {
             const int c0 = col_of(base, 4 * j4);
             float v[4];
-            if (wide) {
-                const float4 t = *reinterpret_cast<const float4 *>(r + (c0 < n ? c0 : 0));   // n is a multiple of 64: all four or none
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = r[min(c0 + q, max(n - 1, 0))];
-            }
+            for (int q = 0; q < 4; ++q) v[q] = r[min(c0 + q, max(n - 1, 0))];
 #pragma unroll
             for (int q = 0; q < 4; ++q) key[4 * j4 + q] = (c0 + q < n && v[q] == v[q]) ? f2o(v[q]) : 0u;
         }

@@ -13,11 +13,17 @@ x0 = cent[torch.randint(0, nlist, (1 << 18,), generator=g, device=dev)] + 0.3 * 
 idx.train(x0)
 for c in range(n >> 18):
     idx.add(cent[torch.randint(0, nlist, (1 << 18,), generator=g, device=dev)] + 0.3 * torch.randn((1 << 18, d), generator=g, device=dev))
-idx.nprobe = 8
+idx.nprobe = int(os.environ.get('SELP_NPROBE', 8))
 q = x0[:batch].contiguous() + 0.05
 cI = torch.empty((batch, kb), dtype=torch.int64, device=dev)
 for _ in range(3): idx.search_candidates_into(q, kb, cI)
 torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+ev[0].record()
+for _ in range(10): idx.search_candidates_into(q, kb, cI)
+ev[1].record(); torch.cuda.synchronize()
+print(f"nprobe {idx.nprobe}: {ev[0].elapsed_time(ev[1]) / 10:.3f} ms per candidate search of {batch} queries (coarse + LUT + all-scores scan + set selection)")
+if 'ts' not in os.environ.get('MI_IVFPQ_LIB', ''): sys.exit(0)
 lib = faiss._Lib.get()
 out = (ctypes.c_ulonglong * (8 * 4096))()
 assert lib.mi_debug_selp_stamps(out) == 0
