@@ -87,16 +87,46 @@ STELLA_EN_1_5B_V5 = dict(vocab_size=151646, hidden=1536, n_layers=28, n_heads=12
                          dense_bias=True, max_seq_len=512)
 
 
-def _cfg_from_hf(hf: dict) -> dict:
+def _causal_from_hf(hf: dict, is_embedding_model: bool = False, override=None) -> bool:
+    """Which attention mask a checkpoint's config.json asks for -- never guessed.
+
+    * an explicit `causal=` (constructor) or MI_ENCODER_CAUSAL=0|1 (for pipelines that cannot pass keywords:
+      `sidecar-search build`, reference Makefile:65) wins;
+    * `is_causal` in config.json (the key of the gte-Qwen2 / stella remote code) is taken as written;
+    * no key and no remote code (`auto_map` absent): a plain Qwen2 checkpoint, which transformers runs causally --
+      also under sentence-transformers (modules.json), whose Transformer module calls the same Qwen2Model;
+    * no key but `auto_map` names remote modelling code: the mask is decided inside a modeling_*.py this package
+      does not execute.  Running such a model with the wrong mask gives plausible, wrong embeddings and no error,
+      so this raises and asks."""
+    if override is None:
+        env = os.environ.get("MI_ENCODER_CAUSAL", "").strip()
+        if env != "":
+            override = env not in ("0", "false", "False")
+    if override is not None:
+        return bool(override)
+    if "is_causal" in hf:
+        return bool(hf["is_causal"])
+    auto_map = hf.get("auto_map") or {}
+    if auto_map:
+        raise ValueError(
+            "config.json has no `is_causal` key and its `auto_map` points at remote modelling code "
+            f"({sorted(set(str(v).split('.')[0] for v in auto_map.values()))}): whether attention is causal or "
+            "bidirectional is decided inside that code, which is not executed here.  Pass "
+            "SentenceTransformer(..., causal=False) for a bidirectional encoder (stella / gte-Qwen2 style) or "
+            "causal=True, or set MI_ENCODER_CAUSAL=0|1" +
+            (" (this directory is a sentence-transformers embedding model: modules.json present)"
+             if is_embedding_model else ""))
+    return True
+
+
+def _cfg_from_hf(hf: dict, is_embedding_model: bool = False, causal=None) -> dict:
     hidden = int(hf["hidden_size"])
     nh = int(hf["num_attention_heads"])
     return dict(vocab_size=int(hf["vocab_size"]), hidden=hidden, n_layers=int(hf["num_hidden_layers"]),
                 n_heads=nh, n_kv_heads=int(hf.get("num_key_value_heads", nh)),
                 head_dim=int(hf.get("head_dim") or hidden // nh), intermediate=int(hf["intermediate_size"]),
                 rms_eps=float(hf.get("rms_norm_eps", 1e-6)), rope_theta=float(hf.get("rope_theta", 1e6)),
-                # `is_causal` is the key of the gte-Qwen2 / stella remote code (false there: bidirectional attention); a plain
-                # Qwen2 config.json has no such key and IS causal
-                causal=bool(hf.get("is_causal", True)), dense_out=0, dense_bias=True,
+                causal=_causal_from_hf(hf, is_embedding_model, causal), dense_out=0, dense_bias=True,
                 max_seq_len=int(hf.get("max_position_embeddings", 512)))
 
 
@@ -157,8 +187,12 @@ class SentenceTransformer:
     def __init__(self, model_name_or_path: str | None = None, device=None, prompts: dict | None = None,
                  default_prompt_name: str | None = None, trust_remote_code: bool = False,
                  config: dict | None = None, weights: dict | None = None, tokenizer=None,
-                 max_seq_length: int | None = None, **_ignored):
+                 max_seq_length: int | None = None, causal: bool | None = None, **_ignored):
         self.trust_remote_code = trust_remote_code
+        mk = _ignored.get("model_kwargs") or {}
+        if causal is None and "is_causal" in mk:                 # sentence-transformers' way of reaching the HF config
+            causal = bool(mk["is_causal"])
+        self._causal_override = causal
         self.prompts = dict(prompts or {})
         self.default_prompt_name = default_prompt_name
         self.tokenizer = tokenizer
@@ -178,6 +212,8 @@ class SentenceTransformer:
             cfg = cfg.to_dict()
         if max_seq_length is not None:
             cfg["max_seq_len"] = int(max_seq_length)
+        if causal is not None:
+            cfg["causal"] = bool(causal)
         self.config = cfg
         c = _Cfg(**{k: (int(v) if isinstance(v, bool) else v) for k, v in cfg.items() if k in dict(_Cfg._fields_)})
         self._h = c_void_p()
@@ -226,7 +262,7 @@ class SentenceTransformer:
         from safetensors import safe_open
         with open(os.path.join(path, "config.json")) as f:
             hf = json.load(f)
-        cfg = cfg or _cfg_from_hf(hf)
+        cfg = cfg or _cfg_from_hf(hf, os.path.exists(os.path.join(path, "modules.json")), self._causal_override)
         weights = dict(weights or {})
         files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
         for fn in files:
@@ -374,7 +410,10 @@ class SentenceTransformer:
         for sel in self._passes(order, token_lists, batch_size):
             cu = np.zeros(len(sel) + 1, np.int32)
             np.cumsum([len(token_lists[i]) for i in sel], out=cu[1:])
-            ids = np.fromiter(itertools.chain.from_iterable(token_lists[i] for i in sel), np.int32, count=int(cu[-1]))
+            if isinstance(token_lists[sel[0]], np.ndarray):           # id arrays (what `tokenizers` can hand over)
+                ids = np.concatenate([token_lists[i] for i in sel]).astype(np.int32, copy=False)
+            else:
+                ids = np.fromiter(itertools.chain.from_iterable(token_lists[i] for i in sel), np.int32, count=int(cu[-1]))
             rows = np.asarray(sel, np.int32)
             _check(lib.mi_encoder_encode_rows(self._h, len(sel), c_void_p(ids.ctypes.data), c_void_p(cu.ctypes.data),
                                               int(normalize_embeddings), c_void_p(out.data_ptr()), c_void_p(rows.ctypes.data),

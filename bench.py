@@ -218,6 +218,10 @@ def main():
     ap.add_argument("--encode-batch", type=int, default=128,
                     help="abstracts per encode step (default 128); 0 = the library's own batching: as many abstracts as fit "
                          "32 768 padded tokens per forward pass (~135; +1 % tokens/s: every GEMM fills whole rounds of the CUs)")
+    ap.add_argument("--full", action="store_true",
+                    help="--workload encode: also push ALL of configs[2]'s 100 000 synthetic abstracts through one "
+                         "encode_tokens() call (length sort, token-budget passes, embeddings back on the host) and report the wall rate")
+    ap.add_argument("--full-abstracts", type=int, default=100000, help="--full: how many abstracts (configs[2] says 100k)")
     ap.add_argument("--encode-steps", type=int, default=24, help="cfg4 line: encode steps (x encode-batch abstracts)")
     ap.add_argument("--encode-streams", type=int, default=1, help="encode steps issued round-robin on this many HIP streams")
     ap.add_argument("--multi-gpu-mode", choices=["shards", "replicas"], default="shards",
@@ -1245,6 +1249,7 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True, pack=None):
                                        "epilogues buy shows here -- they lengthen the GEMM launches (frac above falls ~3 %) and shorten the step (~1 %)"},
                 "timing": "the GEMM launches of one profiled step replayed back to back on the launch stream between two HIP events "
                           "(one warm pass, three timed; mi_encoder_profile_read), after the timed blocks"}
+    full_run = encode_full_run(args, ctx, model, cfg) if getattr(args, "full", False) else None
     cpu = parity = None
     if do_cpu:
         cpu, parity = encode_cpu_baseline(model, cfg, host_w, batches, ctx)
@@ -1263,7 +1268,47 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True, pack=None):
                              % (n_abs, steps),
                    "tokens_per_sec": round(toks * world / dt, 0), "parallelism": "replicas" if world > 1 else "1 GPU",
                    "timed_blocks": len(blocks)},
+        "full_run": full_run,
         "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "reference_oracles": reference_oracles()}
+
+
+def encode_full_run(args, ctx, model, cfg):
+    """configs[2] as a RUN, not a sample: every one of the 100 000 synthetic abstracts goes through the call
+    `sidecar-search build` makes (reference Makefile:65: SentenceTransformer.encode over the whole input) -- here
+    encode_tokens(), i.e. encode() behind the tokenizer (token ids are synthetic: there is no text to tokenise) -- with
+    the library's own glue inside the timed region: sort by length, cut into forward passes by `token_budget`, pack
+    ids on the host, stage them through pinned memory, scatter the embeddings to their input rows, copy the
+    [n, 1024] float32 result back to the host.  Wall clock, one call, nothing rotated or replayed."""
+    np, torch, rank = ctx["np"], ctx["torch"], ctx["rank"]
+    n = int(args.full_abstracts)
+    rng = np.random.default_rng(1007 + rank)
+    lens = np.clip(np.exp(rng.normal(np.log(220), 0.45, n)), 8, 512).astype(int)
+    flat = rng.integers(0, cfg["vocab_size"], int(lens.sum()), dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    toks = [flat[off[i]:off[i + 1]] for i in range(n)]                # what a tokenizer hands over: one id array per text
+    budget0 = model.token_budget
+    model.token_budget = 32768
+    order = sorted(range(n), key=lambda i: -len(toks[i]))
+    passes = model._passes(order, toks, None)
+    model.encode_tokens(toks[:256], normalize_embeddings=True)         # warm (workspaces at the pass size are allocated lazily)
+    model.encode_tokens([toks[i] for i in passes[0]], normalize_embeddings=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    emb = model.encode_tokens(toks, normalize_embeddings=True)         # -> numpy on the host
+    wall = time.perf_counter() - t0
+    model.token_budget = budget0
+    norms = np.linalg.norm(emb, axis=1)
+    assert emb.shape == (n, 1024) and np.isfinite(emb).all() and abs(norms - 1).max() < 1e-3
+    # the glue must not change a result: rows of a mid-run pass recomputed alone
+    probe = passes[len(passes) // 2][:64]
+    again = model.encode_tokens([toks[i] for i in probe], normalize_embeddings=True)
+    cos = float((again * emb[probe]).sum(1).min())
+    return {"abstracts": n, "tokens": int(lens.sum()), "forward_passes": len(passes),
+            "abstracts_per_pass": [min(len(p) for p in passes), max(len(p) for p in passes)],
+            "wall_s": round(wall, 2), "abstracts_per_s": round(n / wall, 1), "tokens_per_s": round(float(lens.sum()) / wall, 0),
+            "min_cosine_vs_same_rows_encoded_alone": round(cos, 7),
+            "what": "ONE encode_tokens() call over all abstracts, wall clock: length sort + token-budget passes + host packing + "
+                    "pinned staging + row scatter + the [n, 1024] f32 copy to the host (tokenisation excluded: ids are synthetic)"}
 
 
 def encode_cpu_baseline(model, cfg, host_w, batches, ctx):

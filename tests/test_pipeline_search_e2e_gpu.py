@@ -4,6 +4,8 @@ cfg4  IVF65536,PQ64 over >= 2 M clustered 1024-d vectors, batch-1024 queries: th
       (two-stage coarse quantiser -> LUT -> sliced scan -> top-k) against the oracle, bit for
       bit; the same index dealt into 2 / 8 vector shards whose per-shard top-k go through the
       exchange step's packed buffer + merge == the unsharded result.
+cfg1  BASELINE configs[0] on the HIP path: ONE prompted query -> SentenceTransformer.encode -> IndexFlatIP(1024)
+      over 10 000 seeded unit vectors, against encoder-oracle -> oracle.flat_ip.
 cfg5  end to end: SentenceTransformer.encode(texts, prompt_name="s2p_query") -> index.search at
       batches 1 / 16 / 256 against encoder-oracle -> ivfpq-oracle.
 
@@ -145,6 +147,61 @@ def test_write_read_index_through_the_c_abi(faiss, cfg4, tmp_path):
     D0, I0 = idx.search(q[:256].contiguous(), 10)
     D1, I1 = back.search(q[:256].contiguous(), 10)
     assert torch.equal(I0, I1) and torch.equal(D0, D1)
+
+
+# ----------------------------------------------------------------------
+# cfg1: one encoded query -> IndexFlatIP over 10 k x 1024 (BASELINE.json configs[0], the reference's plumbing case)
+# ----------------------------------------------------------------------
+def test_cfg1_one_query_flat_ip_10k_chain(faiss, oracle, tmp_path):
+    import dataclasses
+    import torch
+    import abstracts_search_amd.sentence_transformers as st
+    from oracle import encoder_oracle as E
+    from helpers_modeldir import write_model_dir
+    cfg = dataclasses.replace(E.TINY, dense_out=1024, max_seq_len=64)           # the reference's embedding width
+    W = E.synth_weights(cfg, 31)
+    mdir = tmp_path / "model"
+    write_model_dir(mdir, cfg, W, max_seq_length=64, prompts={"s2p_query": "query : "})
+    model = st.SentenceTransformer(str(mdir), trust_remote_code=True)
+    d, n, k = 1024, 10000, 10
+    assert model.get_sentence_embedding_dimension() == d
+    rng = np.random.default_rng(1234)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    idx = faiss.IndexFlatIP(d)
+    idx.add(base)
+    assert idx.ntotal == n
+    query = " ".join(f"w{int(t)}" for t in rng.integers(0, cfg.vocab_size - 3, 17))
+    qe = model.encode(query, prompt_name="s2p_query", normalize_embeddings=True)    # ONE string, as app.py calls it
+    assert qe.shape == (d,) and qe.dtype == np.float32
+    D, I = idx.search(qe[None, :], k)
+    # (1) the search on the embedding the HIP encoder produced: ids and score bits equal the oracle's IndexFlatIP
+    De, Ie = oracle.flat_ip(qe[None, :], base, k)
+    assert np.array_equal(I, Ie) and np.array_equal(bits(D), bits(De))
+    # (2) the embedding against the fp32 oracle on the same token ids: the north star's tolerance
+    toks = model.tokenize(["query : " + query])
+    cu = np.array([0, len(toks[0])])
+    with torch.no_grad():
+        qr = E.encode(cfg, W, np.asarray(toks[0]), cu, True).numpy()
+    cos = float((qe * qr[0]).sum())
+    assert cos > 1 - 1e-3, cos
+    # (3) the whole chain on the oracle side: every rank whose gap to its neighbours exceeds the score error bound
+    # |<qe - qr, x>| <= |qe - qr| (unit rows) must hold the same id
+    kk = 256
+    Dr, Ir = oracle.flat_ip(qr, base, kk)
+    eps = float(np.linalg.norm(qe - qr[0])) * 1.01 + 1e-6
+    gaps = Dr[0, :-1] - Dr[0, 1:]
+    same = [r for r in range(k) if gaps[r] > 2 * eps and (r == 0 or gaps[r - 1] > 2 * eps)]
+    assert all(I[0, r] == Ir[0, r] for r in same), (I, Ir)
+    # ... and as sets: everything the oracle chain scores above its k-th by more than the bound is in the HIP top-k, and
+    # nothing in the HIP top-k scores below the oracle chain's k-th by more than the bound
+    kth = Dr[0, k - 1]
+    assert Dr[0, kk - 1] < kth - 2 * eps, "widen kk"
+    must = set(Ir[0, Dr[0] > kth + 2 * eps].tolist())
+    may = set(Ir[0, Dr[0] >= kth - 2 * eps].tolist())
+    got = set(I[0].tolist())
+    assert must <= got <= may, (must - got, got - may)
+    print(f"cfg1 chain: cosine {cos:.6f}; {len(same)} of {k} ranks separated by more than the bound, all agree")
 
 
 # ----------------------------------------------------------------------

@@ -68,7 +68,34 @@ def test_passes_respect_batch_size_and_token_budget(st):
     assert [len(x) for x in m._passes(order, toks, None)] == [8]         # (default 32)
 
 
-def test_plain_qwen2_config_is_causal_and_stella_style_is_not(st):
+# config.json of a stella / gte-Qwen2 style checkpoint as published: Qwen2 fields + an `auto_map` to the repository's own
+# modeling_qwen.py (hence TRUST_REMOTE_CODE in reference README.md:28,60).  Whether the real file also carries
+# `is_causal` cannot be checked offline (SURVEY Appendix B.1 [PRIOR]) -- both spellings are covered.
+STELLA_STYLE = dict(architectures=["Qwen2Model"], model_type="qwen2", hidden_size=1536, num_attention_heads=12,
+                    num_key_value_heads=2, num_hidden_layers=28, intermediate_size=8960, vocab_size=151646,
+                    rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=131072,
+                    auto_map={"AutoModel": "modeling_qwen.Qwen2Model",
+                              "AutoModelForCausalLM": "modeling_qwen.Qwen2ForCausalLM"})
+
+
+def test_attention_mask_is_never_guessed(st, monkeypatch):
+    monkeypatch.delenv("MI_ENCODER_CAUSAL", raising=False)
     base = dict(hidden_size=64, num_attention_heads=4, vocab_size=10, num_hidden_layers=1, intermediate_size=128)
-    assert st._cfg_from_hf(base)["causal"] is True
+    assert st._cfg_from_hf(base)["causal"] is True                         # plain Qwen2: transformers runs it causally
+    assert st._cfg_from_hf(base, is_embedding_model=True)["causal"] is True   # ... under sentence-transformers too
     assert st._cfg_from_hf(dict(base, is_causal=False))["causal"] is False
+    assert st._cfg_from_hf(dict(STELLA_STYLE, is_causal=False))["causal"] is False
+    assert st._cfg_from_hf(dict(STELLA_STYLE, is_causal=True))["causal"] is True
+    # remote modelling code and no key: the mask lives in code that is not run here -> an error that says what to pass
+    with pytest.raises(ValueError, match="causal=False.*MI_ENCODER_CAUSAL"):
+        st._cfg_from_hf(STELLA_STYLE, is_embedding_model=True)
+    assert st._cfg_from_hf(STELLA_STYLE, causal=False)["causal"] is False    # constructor override
+    monkeypatch.setenv("MI_ENCODER_CAUSAL", "0")                             # pipeline override (no keyword to pass)
+    assert st._cfg_from_hf(STELLA_STYLE)["causal"] is False
+    monkeypatch.setenv("MI_ENCODER_CAUSAL", "1")
+    assert st._cfg_from_hf(STELLA_STYLE)["causal"] is True
+    assert st._cfg_from_hf(dict(STELLA_STYLE, is_causal=False), causal=True)["causal"] is True   # explicit beats the file
+    monkeypatch.delenv("MI_ENCODER_CAUSAL")
+    full = st._cfg_from_hf(dict(STELLA_STYLE, is_causal=False))
+    want = {k: v for k, v in st.STELLA_EN_1_5B_V5.items() if k not in ("dense_out", "max_seq_len")}
+    assert {k: full[k] for k in want} == want                              # the [PRIOR] shape table == the parsed file
