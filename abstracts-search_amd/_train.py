@@ -119,7 +119,9 @@ def _assign_list(x, c, device, metric):
 
 
 def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbose: bool = False, centroids=None,
-                metric: int = 0):
+                metric: int = 0, pq_cp=None):
+    """cp: the coarse quantiser's ClusteringParameters (index.cp); pq_cp: the product quantiser's (index.pq.cp; None: cp)."""
+    pq_cp = pq_cp or cp
     import torch
     d = x.shape[1]
     dsub = d // M
@@ -132,12 +134,12 @@ def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbo
             print(f"train: coarse k-means on {xs.shape[0]} points, k={nlist}")
         cent = kmeans_l2(xs, nlist, cp.niter, cp.seed, device, verbose)
     # PQ codebooks on (residual) sub-vectors
-    xp = _to_device_sample(x, cp.max_points_per_centroid * 256, cp.seed + 1, device)
+    xp = _to_device_sample(x, pq_cp.max_points_per_centroid * 256, pq_cp.seed + 1, device)
     if by_residual:
         a = _assign_list(xp, cent, device, metric).long()
         xp = (xp - cent[a]).contiguous()
     n = xp.shape[0]
-    g = torch.Generator(device="cpu").manual_seed(cp.seed + 2)
+    g = torch.Generator(device="cpu").manual_seed(pq_cp.seed + 2)
     init = torch.randperm(n, generator=g)[:256]
     if init.numel() < 256:
         init = torch.cat([init, torch.randint(0, n, (256 - init.numel(),), generator=g)])
@@ -146,7 +148,7 @@ def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbo
     stream = lambda: c_void_p(torch.cuda.current_stream().cuda_stream)
     offs = (torch.arange(M, device=xp.device, dtype=torch.int32) * 256).unsqueeze(0)
     rows = xp.view(n * M, dsub)                      # row i*M + m = sub-vector m of point i
-    for it in range(cp.niter):
+    for it in range(pq_cp.niter):
         _check(_lib().mi_pq_encode(device, n, c_void_p(xp.data_ptr()), d, M, c_void_p(cb.data_ptr()),
                                    c_void_p(codes.data_ptr()), stream()))
         a = (codes.to(torch.int32) + offs).reshape(-1).contiguous()          # cluster = m * 256 + code

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "encoder_kernels.h"
 #include "encoder_few.h"
+#include "encoder_mid.h"
 
 using namespace mi;
 using namespace mienc;
@@ -32,6 +33,7 @@ std::atomic<int64_t> g_n192_launches{0};
 std::atomic<int64_t> g_m192_launches{0};      // slab GEMMs on 192-row tiles
 std::atomic<int64_t> g_fused_norm_launches{0};   // residual slab GEMMs whose epilogue carried the next RMSNorm (GEMM_RAWNORM)
 std::atomic<int64_t> g_fused_rope_launches{0};   // QKV slab GEMMs whose epilogue rotated Q and K
+std::atomic<int64_t> g_mid_launches{0};   // QKV / O projections on the one-launch whole-K tiles of encoder_mid.h
 std::atomic<int64_t> g_few_passes{0};     // forward passes that took the query-time path (encoder_few.h)
 
 struct LayerW {
@@ -177,6 +179,11 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
             g.tail_first = 0;
             g.tail_split = S;
             nblocks = (unsigned)(ntiles * S);
+            static const bool slice_major = !(std::getenv("MI_SPLITK_ORDER") && std::atoi(std::getenv("MI_SPLITK_ORDER")) == 0);
+            if (slice_major) {                            // slices of K to XCDs (gemm_bf16_slab_kernel::decode, order 2)
+                g.order = 2;
+                nblocks = 8u * (unsigned)((ntiles * S + 7) / 8);
+            }
         }
     }
     dim3 grid(nblocks), block(128 * WN_);
@@ -417,6 +424,80 @@ int launch_mid_part(int epi, GemmArgs g, hipStream_t st) {
     return 0x100;                                                        // launched, nothing extra folded in
 }
 
+// ---- encoder_mid.h: the K = hidden projections of ~100 .. ~4000 tokens, one launch each --------------------------------
+struct MidTile { int bm, bn, ns; };
+// whether launch_gemm sends this GEMM to mid_gemm_kernel.  QKV: the caller must hand over the rotary-interleaved weights and
+// the (cos, sin) table (GemmArgs::rope_cs) -- `assume_rope`: the caller is asking in order to decide whether to build them.
+bool mid_takes(int epi, const GemmArgs &g, bool assume_rope = false) {
+    const bool off = std::getenv("MI_NO_MID_GEMM") != nullptr;   // (read per call: the tests switch it inside one process)
+    if (off || g.M <= 64 || g.K % 64 != 0 || g.K >= 4096 || g.N % 64 != 0 || g.lda % 8 != 0 || g.ldw % 8 != 0) return false;
+    if (slab_whole_k(epi, g)) return false;                             // enough tokens for whole rounds of 256 x 256 tiles
+    if (epi == EPI_QKV)
+        return (assume_rope || (g.rope_cs && g.rope_pos)) && g.qk_cols % 64 == 0 && g.rope_hd % 4 == 0 && g.qk_cols % std::max(g.rope_hd, 1) == 0 &&
+               g.ldc % 4 == 0 && g.M % 4 == 0;
+    return epi == EPI_RESID && g.ldc == g.N;
+}
+
+MidTile mid_pick_tile(const GemmArgs &g, int qk_cols) {
+    // what a workgroup costs is what it ingests through its CU's memory pipe, (BM + BN) x K x 2 bytes at ~75 GB/s; the launch
+    // lasts as long as the busiest CU: ceil(workgroups / 256) of them.  Ties: the larger tile (fewer bytes chip-wide).
+    // ring depth: what bounds a workgroup is its bytes IN FLIGHT (an LDS-DMA piece lands ~1.1-1.5 us after its issue: three
+    // slabs of a 96 x 64 tile were 60 KB = ~45 GB/s, 14 us for the QKV projection of 576 tokens) -- one workgroup per CU with
+    // most of the CU's LDS as its ring
+    static const MidTile cand[] = {{128, 128, 4}, {128, 64, 6}, {96, 64, 7}, {64, 64, 8}};
+    static const char *env = std::getenv("MI_MID_TILE");                // tools: "128x128" | "128x64" | "96x64" | "64x64"
+    MidTile best = cand[3];
+    double best_cost = 1e30;
+    for (const MidTile &c : cand) {
+        if (qk_cols % c.bn != 0 || g.N % c.bn != 0) continue;
+        if (env && std::string(env) != std::to_string(c.bm) + "x" + std::to_string(c.bn)) continue;
+        const long n = (long)((g.M + c.bm - 1) / c.bm) * (g.N / c.bn);
+        const double cost = (double)((n + 255) / 256) * ((double)(c.bm + c.bn) * g.K * 2.0 / 75e3 + 1.0);
+        if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+
+template <int EPI, int WMT, int WNT, int NS>
+void launch_mid_t(GemmArgs g, hipStream_t st) {
+    constexpr int BM = 32 * WMT, BN = 32 * WNT;
+    constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
+    static std::once_flag once[16];                                     // per device
+    int dev = 0;
+    MI_HIP(hipGetDevice(&dev));
+    std::call_once(once[dev & 15], [] {
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_gemm_kernel<EPI, WMT, WNT, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    });
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const int per = (g.tiles_m * g.tiles_n + 7) / 8;
+    hipLaunchKernelGGL((mid_gemm_kernel<EPI, WMT, WNT, NS>), dim3((unsigned)(8 * per)), dim3(256), lds, st, g);
+    MI_HIP(hipGetLastError());
+}
+
+int launch_mid(int epi, GemmArgs g, hipStream_t st) {
+    const MidTile t = mid_pick_tile(g, epi == EPI_QKV ? g.qk_cols : g.N);
+    int flags = 0;
+    if (epi == EPI_QKV) {
+        flags = GEMM_ROPED;
+        ++g_fused_rope_launches;
+    } else {
+        const int nslots = g.N / t.bn;
+        if (!(g.ssq_out && g.norm_w && g.norm_y && nslots <= SSQ_LD)) g.ssq_out = nullptr;
+        if (g.ssq_out) { flags = GEMM_RAWNORM | nslots << 8; ++g_fused_norm_launches; }
+    }
+    g.part = nullptr;
+#define MI_MID_CASE(BM_, BN_, NS_)                                                                              \
+    if (t.bm == BM_ && t.bn == BN_) {                                                                           \
+        if (epi == EPI_QKV) launch_mid_t<MID_QKV, BM_ / 32, BN_ / 32, NS_>(g, st);                              \
+        else launch_mid_t<MID_O, BM_ / 32, BN_ / 32, NS_>(g, st);                                               \
+    }
+    MI_MID_CASE(128, 128, 4) MI_MID_CASE(128, 64, 6) MI_MID_CASE(96, 64, 7) MI_MID_CASE(64, 64, 8)
+#undef MI_MID_CASE
+    ++g_mid_launches;
+    return flags;
+}
+
 // returns the GEMM_* flags: GEMM_NORMED when the launch also wrote the RMSNorm of the updated stream the caller asked for
 // (GemmArgs::norm_w / norm_y), GEMM_ROPED when the QKV epilogue already rotated Q and K
 int launch_gemm(int epi, GemmArgs g, hipStream_t st) {
@@ -436,6 +517,7 @@ int launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         std::string cfg = force ? std::string(force) : "";
         if (cfg.empty()) cfg = g.M <= 64 ? "tiny" : tiles_big >= 100 ? "big" : tiles_mid >= 150 ? "mid" : "small";
         g.ksplit = 1;
+        if (!force && mid_takes(epi, g)) return launch_mid(epi, g, st);
         // the fused RMSNorm / rotary epilogues live in the whole-K slab kernel only: a consumer that asks for them anywhere
         // else is a caller's error (its A operand is not normalised); a producer's request is just dropped
         MI_REQUIRE((!g.row_scale && !g.rope_cs) || (slab_whole_k(epi, g) && (epi == EPI_QKV || epi == EPI_SWIGLU)),
@@ -1070,7 +1152,9 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
     probe.M = T; probe.N = h->qk_cols + h->v_cols; probe.K = H;
     const bool qkv_slab = slab_whole_k(EPI_QKV, probe) && T % 8 == 0 && ldvt % 8 == 0;
     // (H < 4096: launch_gemm gives the QKV projection the 8-wave slab kernel, whose waves own 64 columns = 32 rotary pairs)
-    const bool rope_fused = qkv_slab && H < 4096 && h->qk_cols % 256 == 0 && h->v_cols % 256 == 0 && !std::getenv("MI_NO_ROPE_FUSE");
+    probe.qk_cols = h->qk_cols; probe.rope_hd = hd; probe.lda = probe.ldw = H; probe.ldc = h->qk_cols;
+    const bool qkv_mid = mid_takes(EPI_QKV, probe, true);   // a few hundred .. few thousand tokens: encoder_mid.h, RoPE in its epilogue
+    const bool rope_fused = (qkv_slab && H < 4096 && h->qk_cols % 256 == 0 && h->v_cols % 256 == 0 && !std::getenv("MI_NO_ROPE_FUSE")) || qkv_mid;
     const bool norm1_fused = qkv_slab && !std::getenv("MI_NO_NORM_FUSE");
     probe.N = 2 * I; probe.ldc = I;
     const bool norm2_fused = slab_whole_k(EPI_SWIGLU, probe) && !std::getenv("MI_NO_NORM_FUSE");
@@ -1511,6 +1595,7 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
         else if (std::string(name) == "fused_norm_launches") *value = g_fused_norm_launches.load();
         else if (std::string(name) == "fused_rope_launches") *value = g_fused_rope_launches.load();
         else if (std::string(name) == "few_passes") *value = g_few_passes.load();
+        else if (std::string(name) == "mid_launches") *value = g_mid_launches.load();
         else throw Error(std::string("unknown debug counter: ") + name);
     });
 }

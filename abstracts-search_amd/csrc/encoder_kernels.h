@@ -278,7 +278,7 @@ struct GemmArgs {
     // tail_first) is split tail_split ways along K so that it occupies the whole chip
     // for 1/tail_split of a tile time instead of a few CUs for a full one
     int tail_first, tail_split;
-    int order;         // tile order of the 256x256 slab kernel: 0 = per-XCD grouped eighths, 1 = chip patches (tile_coords)
+    int order;         // tile order of the 256x256 slab kernel: 0 = per-XCD grouped eighths, 1 = chip patches (tile_coords), 2 = every tile K-split, slice-major eighths per XCD
     size_t part_bytes; // capacity of `part`
     float *part;       // EPI_RESID slab kernel with tail_first == 0 (EVERY tile split tail_split ways along K: too few tiles to fill
                        // the chip): slice ks writes its partial tile to part[ks][M][N] (plain whole-line stores, no atomics) and
@@ -995,6 +995,24 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
         int ks = 0, vb = unit;
         ksplit_ = 1;
         if constexpr (EPI == EPI_RESID) {
+            if (g.order == 2) {
+                // EVERY tile split tail_split ways (a few hundred tokens): the (slice, tile) pairs in slice-major order, XCD x
+                // (= unit % 8: where the hardware puts the workgroup) takes the x-th eighth of them -- the workgroups of an
+                // XCD then share one or two K slices of A and W in their L2 instead of touching all of them (PMC at 576
+                // tokens: the down projection fetched 124 MB past L2 for 38 MB of operands)
+                const int ntiles = g.tiles_m * g.tiles_n, P = ntiles * g.tail_split;
+                const int x = unit & 7, p = (int)(((long)x * P) >> 3) + (unit >> 3);
+                if (p >= (int)(((long)(x + 1) * P) >> 3)) return false;
+                ks = p / ntiles;
+                const int t = p - ks * ntiles;
+                tn_ = t / g.tiles_m;
+                tm_ = t - tn_ * g.tiles_m;
+                ksplit_ = g.tail_split;
+                ks_cur = ks;
+                kt0_ = (nt_all * ks) / ksplit_;
+                nk_ = 2 * ((nt_all * (ks + 1)) / ksplit_ - kt0_);
+                return true;
+            }
             if (g.tail_split > 1 && unit >= g.tail_first) {
                 const int j = unit - g.tail_first;
                 ksplit_ = g.tail_split;

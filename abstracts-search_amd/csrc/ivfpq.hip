@@ -1924,7 +1924,25 @@ int mi_index_load_at(const char *fname, int64_t offset, int device, mi_index **o
         const IndexHeader ih = read_index_header(r);
         const uint64_t nlist = r.one<uint64_t>(), nprobe = r.one<uint64_t>();
         MI_REQUIRE(nlist > 0 && nlist < ((uint64_t)1 << 31), "implausible nlist");
-        const std::string qcc = r.cc();
+        std::string qcc = r.cc();
+        if (qcc == "IHNf") {
+            // [PRIOR layout: faiss write_index(IndexHNSW) = fourcc, index header, write_HNSW, storage index]  "IVF65536_HNSW32,..."
+            // puts an IndexHNSWFlat in front of the lists.  Its flat storage IS the centroid table: it is taken over and searched
+            // exactly (the probes of an exact search are what the HNSW graph approximates -- a superset in recall terms, not the
+            // same list set faiss would visit); the graph itself is skipped.
+            (void)read_index_header(r);
+            const size_t elem[5] = {8, 4, 4, 8, 4};   // assign_probas f64, cum_nneighbor_per_level i32, levels i32, offsets u64, neighbors i32
+            for (int v = 0; v < 5; ++v) {
+                const uint64_t n = r.one<uint64_t>();
+                MI_REQUIRE(n < ((uint64_t)1 << 40), "implausible HNSW vector length");
+                r.seek((uint64_t)ftello(r.f) + n * elem[v]);
+            }
+            for (int v = 0; v < 5; ++v) (void)r.one<int32_t>();   // entry_point, max_level, efConstruction, efSearch, upper_beam (deprecated)
+            qcc = r.cc();
+            if (qcc != "IxFI" && qcc != "IxF2" && qcc != "IxFl") throw Error(name + ": HNSW coarse quantiser over '" + qcc + "' storage: only flat storage (IndexHNSWFlat) is read");
+        } else if (qcc == "IHNp" || qcc == "IHNs" || qcc == "IHN2" || qcc == "IHNc") {
+            throw Error(name + ": coarse quantiser '" + qcc + "' (HNSW over compressed storage) holds no exact centroid table and is not supported; IHNf (IndexHNSWFlat) is");
+        }
         if (qcc != "IxFI" && qcc != "IxF2" && qcc != "IxFl") throw Error(name + ": coarse quantiser '" + qcc + "' is not an IndexFlat");
         const IndexHeader qh = read_index_header(r);
         const uint64_t ncf = r.one<uint64_t>();
@@ -2523,6 +2541,26 @@ int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int6
 }
 
 // ---- building blocks for train() --------------------------------------
+
+// out[n][nc] = x . c^T (+ bias[nc]): the exact f32 GEMM of the coarse quantiser (ascending-k fmaf chain per element) as a
+// plain operator -- the VectorTransform in front of an IndexPreTransform (OPQ / random rotation: x -> A x + b)
+int mi_ip_gemm(int device, int64_t n, const float *x, int64_t nc, const float *c, int d, const float *bias, float *out,
+               void *stream) {
+    return guard([&] {
+        MI_REQUIRE(x && c && out, "null argument");
+        MI_REQUIRE(n > 0 && nc > 0 && d > 0 && d % 4 == 0, "mi_ip_gemm: empty input or d not a multiple of 4");
+        DeviceGuard dg(device);
+        hipStream_t st = as_stream(stream);
+        MI_REQUIRE(is_device_ptr(x) && is_device_ptr(c) && is_device_ptr(out) && (!bias || is_device_ptr(bias)),
+                   "mi_ip_gemm: x, c, bias and out must be device pointers");
+        launch_gemm(x, n, c, nc, d, out, nc, st);
+        if (bias) {
+            const int64_t total = n * nc;
+            hipLaunchKernelGGL(add_row_bias_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536)), dim3(256), 0, st, out, total, (int)nc, bias);
+            MI_HIP(hipGetLastError());
+        }
+    });
+}
 
 int mi_ip_assign(int device, int64_t n, const float *x, int64_t nc, const float *c, int d,
                  int32_t *assign, float *score, void *stream) {

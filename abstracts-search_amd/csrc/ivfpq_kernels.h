@@ -3465,4 +3465,9 @@ __global__ void __launch_bounds__(256)
     if (i < n * d) out[i] = x[(i / d) * da + (i % d)];
 }
 
+// out[i][j] += bias[j] (the b of a LinearTransform x -> A x + b behind mi_ip_gemm)
+__global__ void __launch_bounds__(256) add_row_bias_kernel(float *__restrict__ out, int64_t total, int nc, const float *__restrict__ bias) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] += bias[i % nc];
+}
+
 }  // namespace mi

@@ -105,6 +105,7 @@ class _Lib:
                 "mi_flat_search": [v, c_int64, v, c_int, v, v, v],
                 "mi_flat_rerank": [v, c_int64, v, c_int, v, c_int, v, v, v],
                 "mi_ip_assign": [c_int, c_int64, v, c_int64, v, c_int, v, v, v],
+                "mi_ip_gemm": [c_int, c_int64, v, c_int64, v, c_int, v, v, v],
                 "mi_pq_encode": [c_int, c_int64, v, c_int, c_int, v, v, v],
                 "mi_cluster_means": [c_int, c_int64, v, c_int, v, c_int, v, v, v],
                 "mi_neg_half_sqnorm": [c_int, c_int64, v, c_int, v, v],
@@ -375,25 +376,49 @@ class IndexScalarQuantizer(IndexFlatIP):
 # IndexIVFPQ
 # ----------------------------------------------------------------------
 
+class ClusteringParameters:
+    """faiss.ClusteringParameters: the fields faiss's Clustering reads.  What train() here honours: `niter`,
+    `max_points_per_centroid` (the training set is subsampled to that many points per centroid, like faiss), `seed`,
+    `verbose`.  `nredo` > 1, `spherical`, `int_centroids`, `frozen_centroids`, `update_index` raise at train() instead of
+    being ignored; `min_points_per_centroid` only warns in faiss and is unused here.
+
+    train() here is NOT faiss's Clustering: it is a bit-reproducible Lloyd's k-means (oracle/train_oracle.py is its
+    restatement) -- initial centroids from a seeded permutation (faiss: its own RandomGenerator permutation), empty clusters
+    re-seeded from random points (faiss: split the largest cluster with a +-1/1024 perturbation), members summed in
+    ascending row order.  An index TRAINED here is therefore a different (equally valid) index from the one faiss trains
+    on the same data; a faiss-trained index is reproduced through set_centroids / set_codebook or read_index."""
+
+    def __init__(self, niter: int = 25):
+        self.niter = niter
+        self.nredo = 1
+        self.max_points_per_centroid = 256
+        self.min_points_per_centroid = 39
+        self.seed = 1234
+        self.verbose = False
+        self.spherical = False
+        self.int_centroids = False
+        self.update_index = False
+        self.frozen_centroids = False
+
+    def check_supported(self, what: str):
+        bad = [k for k, v in (("nredo", self.nredo != 1), ("spherical", self.spherical), ("int_centroids", self.int_centroids),
+                              ("update_index", self.update_index), ("frozen_centroids", self.frozen_centroids)) if v]
+        if bad:
+            raise NotImplementedError(f"{what}: ClusteringParameters.{', '.join(bad)} not implemented (would be silently ignored)")
+        if self.niter < 0 or self.max_points_per_centroid < 1:
+            raise ValueError(f"{what}: niter >= 0 and max_points_per_centroid >= 1 required")
+
+
 class _PQ:
-    """index.pq: ProductQuantizer parameters (read-only view)."""
+    """index.pq: ProductQuantizer parameters (read-only view) + its own ClusteringParameters `cp` (faiss: pq.cp, 25
+    iterations by default -- the coarse quantiser's `index.cp` defaults to 10, as faiss's Level1Quantizer sets it)."""
 
     def __init__(self, d, M, nbits):
         self.d, self.M, self.nbits = d, M, nbits
         self.ksub = 1 << nbits
         self.dsub = d // M
         self.code_size = M
-
-
-class ClusteringParameters:
-    """faiss.ClusteringParameters subset used by train()."""
-
-    def __init__(self):
-        self.niter = 25
-        self.max_points_per_centroid = 256
-        self.min_points_per_centroid = 39
-        self.seed = 1234
-        self.verbose = False
+        self.cp = ClusteringParameters(25)
 
 
 class IndexIVFPQ:
@@ -429,7 +454,7 @@ class IndexIVFPQ:
         self.by_residual = bool(by_residual)
         self.nprobe = 1
         self.pq = _PQ(self.d, int(M), int(nbits))
-        self.cp = ClusteringParameters()
+        self.cp = ClusteringParameters(10)
         self.verbose = False
         self._h = c_void_p()
         _check(_Lib.get().mi_index_create(self.d, self.nlist, int(M), int(nbits), self.metric_type,
@@ -460,7 +485,7 @@ class IndexIVFPQ:
         self.d, self.nlist, self.device = d, nlist, int(device)
         self.metric_type, self.by_residual, self.nprobe = metric, bool(by_res), max(1, nprobe)
         self.pq = _PQ(d, M, nbits)
-        self.cp = ClusteringParameters()
+        self.cp = ClusteringParameters(10)
         self.verbose = False
         self._h = h
         self._coarse_set = self.is_trained
@@ -528,8 +553,11 @@ class IndexIVFPQ:
         if self._coarse_set and not self.is_trained:
             import torch
             given = torch.from_numpy(self.get_centroids()).to(torch.device("cuda", self.device))
+        self.cp.check_supported("IndexIVFPQ.train (index.cp)")
+        self.pq.cp.check_supported("IndexIVFPQ.train (index.pq.cp)")
         cent, cb = _train.train_ivfpq(x, self.nlist, self.pq.M, self.by_residual, self.cp,
-                                      self.device, self.verbose, centroids=given, metric=self.metric_type)
+                                      self.device, self.verbose or self.cp.verbose, centroids=given, metric=self.metric_type,
+                                      pq_cp=self.pq.cp)
         self.set_centroids(cent)
         self.set_codebook(cb)
 
@@ -971,8 +999,10 @@ _MAGIC = "mi355x-ivfpq-v1"
 
 class IndexPreTransform:
     """faiss.IndexPreTransform over LinearTransforms (OPQMatrix, RandomRotationMatrix, LinearTransform): x -> A x + b
-    applied (one small GEMM per transform, torch on the index's device) in front of train / add / search of the wrapped
-    index -- what `index_factory(d, "OPQ64,IVF65536,PQ64")` builds.  read_index returns one for an "IxPT" file."""
+    applied (one exact-f32 GEMM per transform on the library's own kernel) in front of train / add / search of the wrapped
+    index.  read_index returns one for an "IxPT" file and write_index writes one back; the matrices come from the file or
+    from the caller -- OPQ TRAINING (faiss OPQMatrix.train) is not implemented, so `index_factory` does not accept "OPQ..."
+    strings and train() needs a chain that is already trained."""
 
     def __init__(self, chain, index):
         self.chain = [(np.ascontiguousarray(A, np.float32), None if b is None else np.ascontiguousarray(b, np.float32)) for A, b in chain]
@@ -986,21 +1016,29 @@ class IndexPreTransform:
     nprobe = property(lambda self: self.index.nprobe, lambda self, v: setattr(self.index, "nprobe", v))
 
     def apply(self, x):
-        """VectorTransform::apply of the whole chain (numpy in -> numpy out, CUDA tensor in -> CUDA tensor out)."""
+        """VectorTransform::apply of the whole chain (numpy in -> numpy out, CUDA tensor in -> CUDA tensor out): every
+        transform is one exact-f32 GEMM on the library's own kernel (mi_ip_gemm: an ascending-k fmaf chain per output, + b)."""
         import torch
         was_np = not _is_torch(x)
+        dev = torch.device("cuda", self.index.device)
         t = torch.as_tensor(np.ascontiguousarray(x, np.float32)) if was_np else x.float()
-        t = t.to(torch.device("cuda", self.index.device))
+        if t.dim() != 2 or t.shape[1] != self.d:
+            raise ValueError(f"IndexPreTransform: expected [n, {self.d}] vectors, got {tuple(t.shape)}")
+        t = t.to(dev).contiguous()
         if self._dev is None:
-            self._dev = [(torch.from_numpy(A).to(t.device), None if b is None else torch.from_numpy(b).to(t.device)) for A, b in self.chain]
-        prev = torch.backends.cuda.matmul.allow_tf32
-        torch.backends.cuda.matmul.allow_tf32 = False
-        try:
-            for A, b in self._dev:
-                t = t @ A.T if b is None else torch.addmm(b, t, A.T)
-        finally:
-            torch.backends.cuda.matmul.allow_tf32 = prev
-        t = t.contiguous()
+            self._dev = [(torch.from_numpy(A).to(dev).contiguous(), None if b is None else torch.from_numpy(b).to(dev).contiguous())
+                         for A, b in self.chain]
+        stream = _current_stream()
+        for A, b in self._dev:
+            if t.shape[0] == 0:
+                t = torch.empty((0, A.shape[0]), dtype=torch.float32, device=dev)
+                continue
+            if A.shape[1] % 4:
+                raise NotImplementedError("IndexPreTransform: transform input width must be a multiple of 4")
+            out = torch.empty((t.shape[0], A.shape[0]), dtype=torch.float32, device=dev)
+            _check(_Lib.get().mi_ip_gemm(self.index.device, t.shape[0], c_void_p(t.data_ptr()), A.shape[0], c_void_p(A.data_ptr()),
+                                         A.shape[1], c_void_p(b.data_ptr() if b is not None else 0), c_void_p(out.data_ptr()), stream))
+            t = out
         return t.cpu().numpy() if was_np else t
 
     def train(self, x):
@@ -1031,6 +1069,16 @@ def write_index(index, fname: str, ondisk_data: str | None = None) -> None:
     own numpy container instead."""
     if isinstance(index, IndexFlatIP):
         raise NotImplementedError("write_index: IndexFlatIP is not serialised")
+    if isinstance(index, IndexPreTransform):
+        if str(fname).endswith(".npz"):
+            raise NotImplementedError("write_index: IndexPreTransform goes to faiss's binary format only (IxPT)")
+        tmp = str(fname) + ".sub.tmp"
+        write_index(index.index, tmp, ondisk_data)
+        try:
+            faiss_io.dump_pretransform(fname, index.chain, index.d, index.ntotal, index.is_trained, index.metric_type, tmp)
+        finally:
+            os.remove(tmp)
+        return
     if isinstance(index, IndexRefine):
         raise NotImplementedError("write_index: IndexRefine / IndexRefineFlat (faiss's IxRF) is not serialised -- write "
                                   "index.base_index; the refine stage re-reads the raw vectors at load time")

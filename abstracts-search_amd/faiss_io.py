@@ -1,5 +1,5 @@
 """faiss's binary index format for the one index family of the hot path:
-``IndexIVFPQ`` over an ``IndexFlat`` coarse quantiser, with in-file
+``IndexIVFPQ`` over an ``IndexFlat`` (or ``IndexHNSWFlat``: read as its flat storage) coarse quantiser, with in-file
 (``ArrayInvertedLists``) or on-disk (``OnDiskInvertedLists``) lists.
 
 This is the artefact the reference pipeline publishes and consumes --
@@ -137,10 +137,46 @@ def parse_pretransform(fname: str):
             b = r.vector(np.float32)
             d_in, d_out = r.one("i"), r.one("i")
             r.one("B")
-            if A.size != d_in * d_out or (have_bias and b.size != d_out):
+            # faiss's writer only guarantees A.size() >= d_in * d_out and b.size() >= d_out: longer vectors are legal
+            if d_in <= 0 or d_out <= 0 or A.size < d_in * d_out or (have_bias and b.size < d_out):
                 raise FaissFormatError(f"{fname}: transform {cc} is {d_out} x {d_in} but holds {A.size} + {b.size} floats")
-            chain.append((A.reshape(d_out, d_in).copy(), b.copy() if have_bias else None))
+            chain.append((A[:d_in * d_out].reshape(d_out, d_in).copy(), b[:d_out].copy() if have_bias else None))
         return chain, fh.tell()
+
+
+def dump_pretransform(fname: str, chain, d: int, ntotal: int, trained: bool, metric: int, sub_index_file: str) -> None:
+    """Write an IndexPreTransform file ([PRIOR] layout, the inverse of parse_pretransform): "IxPT", the index header (d = the
+    chain's input width), the chain as "LTra" records, then the bytes of `sub_index_file` (the wrapped index, already
+    written)."""
+    with open(fname, "wb") as f:
+        f.write(b"IxPT")
+        _write_header(f, d, ntotal, trained, metric)
+        _w(f, "i", len(chain))
+        for A, b in chain:
+            A = np.ascontiguousarray(A, np.float32)
+            f.write(b"LTra")
+            _w(f, "B", int(b is not None))
+            _wvec(f, A.reshape(-1))
+            _wvec(f, np.zeros(0, np.float32) if b is None else np.ascontiguousarray(b, np.float32))
+            _w(f, "iiB", A.shape[1], A.shape[0], 1)
+        with open(sub_index_file, "rb") as sf:
+            while True:
+                blk = sf.read(1 << 24)
+                if not blk:
+                    break
+                f.write(blk)
+
+
+def _skip_hnsw(r: "_Reader") -> None:
+    """[PRIOR: faiss write_HNSW] the graph of an IndexHNSW record: five vectors (assign_probas f64, cum_nneighbor_per_level
+    i32, levels i32, offsets u64, neighbors i32) and five ints (entry_point, max_level, efConstruction, efSearch, the
+    deprecated upper_beam)."""
+    for dt in (np.float64, np.int32, np.int32, np.uint64, np.int32):
+        n = r.one("Q")
+        if n > (1 << 40):
+            raise FaissFormatError(f"{r.name}: implausible HNSW vector length {n}")
+        r.f.seek(n * np.dtype(dt).itemsize, os.SEEK_CUR)
+    r.raw(20)
 
 
 def parse(fname: str) -> dict:
@@ -158,6 +194,16 @@ def parse(fname: str) -> dict:
         d, ntotal, trained, metric = _read_header(r)
         nlist, nprobe = r.one("Q"), r.one("Q")
         qh = r.fourcc()
+        hnsw_quantizer = qh == "IHNf"
+        if hnsw_quantizer:
+            # "IVF65536_HNSW32,...": an IndexHNSWFlat in front of the lists.  Its flat storage is the centroid table; it is
+            # searched EXACTLY here (what the graph approximates), the graph is skipped
+            _read_header(r)
+            _skip_hnsw(r)
+            qh = r.fourcc()
+        elif qh in ("IHNp", "IHNs", "IHN2", "IHNc"):
+            raise FaissFormatError(f"{fname}: coarse quantiser {qh!r} (HNSW over compressed storage) holds no exact centroid "
+                                   "table and is not supported; IHNf (IndexHNSWFlat) is")
         if qh not in ("IxFI", "IxF2", "IxFl"):
             raise FaissFormatError(f"{fname}: coarse quantiser {qh!r} is not an IndexFlat")
         qd, qn, _qt, _qm = _read_header(r)
@@ -182,8 +228,13 @@ def parse(fname: str) -> dict:
     if int(sizes.sum()) != ntotal:
         raise FaissFormatError(f"{fname}: lists hold {int(sizes.sum())} vectors, header says {ntotal}")
     return dict(d=d, nlist=nlist, M=M, nbits=nbits, metric=metric, by_residual=by_residual, nprobe=nprobe,
-                is_trained=trained, ntotal=ntotal, centroids=cent.reshape(qn, d),
+                is_trained=trained, ntotal=ntotal, centroids=cent.reshape(qn, d), hnsw_quantizer=hnsw_quantizer,
                 codebook=cb.reshape(M, ksub, dsub) if cb.size else cb, sizes=sizes, codes=codes, ids=ids)
+
+
+def parse_is_flat(fname: str) -> bool:
+    """whether the file's coarse quantiser is a plain IndexFlat (False: an IndexHNSWFlat read as its flat storage)"""
+    return not parse(fname)["hnsw_quantizer"]
 
 
 def _read_invlists(r: _Reader, fname: str, nlist: int, code_size: int):

@@ -104,6 +104,25 @@ class Clock:
         return statistics.median(times), times, statistics.median(issue)
 
 
+def committed_traffic(name, match):
+    """HBM-side bytes of a kernel from the committed counter passes (profiles/<name>: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    their own runs, tools/prof_r05.sh) -- only when `match(doc)` says the file is of this configuration AND the kernel's source
+    text is the one the pass profiled (tools/kernel_stamp.py): a stale file yields (None, why), never an old number.
+    -> (doc or None, source / reason text)"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_stamp
+        doc = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception as e:
+        return None, f"no counter file profiles/{name} ({type(e).__name__})"
+    if not match(doc):
+        return None, f"profiles/{name} is of another configuration"
+    ok, why = kernel_stamp.fresh(doc)
+    if not ok:
+        return None, f"profiles/{name} dropped: {why}"
+    return doc, doc.get("source", f"profiles/{name}")
+
+
 def hbm_gb(torch):
     free, total = torch.cuda.mem_get_info()
     return (total - free) / 1e9, total / 1e9
@@ -327,7 +346,7 @@ def cfg4_workload(args, ctx):
 
     # ---- train on rank 0 (first 4 M rows: 64 points per centroid), broadcast the tables
     index = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT, device=local_rank)
-    index.cp.niter = train_iters
+    index.cp.niter = index.pq.cp.niter = train_iters
     cent = torch.empty((nlist, d), dtype=torch.float32, device=dev)
     cb = torch.empty((M, 256, d // M), dtype=torch.float32, device=dev)
     sq_train_rows = None
@@ -533,13 +552,8 @@ def cfg4_workload(args, ctx):
     torch.cuda.synchronize()
     scan_ms, scan_bytes = prof["scan_ms_avg"], prof["scan_bytes"]
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    traffic, traffic_src = None, None
-    try:                                                               # separate --pmc passes of this same command
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_cfg4_scan_pmc.json")))
-        if (N, nlist, batch, nprobe, k, nsh) == tuple(pmc["config"]):
-            traffic, traffic_src = int(pmc["corrected_bytes_per_launch"]), pmc["source"]
-    except Exception:
-        pass
+    pmc, traffic_src = committed_traffic("r05_cfg4_scan_pmc.json", lambda d: (N, nlist, batch, nprobe, k, nsh) == tuple(d["config"]))
+    traffic = int(pmc["corrected_bytes_per_launch"]) if pmc else None
     roofline = {"kernel": "scan_kernel<64,8,false>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_launch": int(scan_bytes), "avg_launch_ms": round(scan_ms, 5),
@@ -975,7 +989,7 @@ def cfg5_workload(args, ctx):
     nsh = world
     t0 = time.time()
     index = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT, device=local_rank)
-    index.cp.niter = 4 if args.train_iters is None else args.train_iters
+    index.cp.niter = index.pq.cp.niter = 4 if args.train_iters is None else args.train_iters
     cent = torch.empty((nlist, d), dtype=torch.float32, device=dev)
     cb = torch.empty((M, 256, d // M), dtype=torch.float32, device=dev)
     if rank == 0:
@@ -1035,7 +1049,7 @@ def cfg2_workload(args, ctx):
     t0 = time.time()
     x = synth.corpus_cuda(N, d, device=local_rank)
     index = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT, device=local_rank)
-    index.cp.niter = 10 if args.train_iters is None else args.train_iters
+    index.cp.niter = index.pq.cp.niter = 10 if args.train_iters is None else args.train_iters
     force_sharded = bool(os.environ.get("BENCH_FORCE_SHARDED"))
     use_shards = (world > 1 and args.multi_gpu_mode == "shards") or force_sharded
     if world > 1 or force_sharded:
@@ -1106,17 +1120,12 @@ def cfg2_workload(args, ctx):
     torch.cuda.synchronize()
     scan_ms, scan_bytes = prof["scan_ms_avg"], prof["scan_bytes"]
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_cfg2_scan_pmc.json")))
-        if (N, nlist, batch, nprobe, k, world) == (1_000_000, 4096, 64, 16, 10, 1) and not os.environ.get("MI_NSLICE"):
-            traffic = int(pmc["corrected_bytes_per_launch"])
-    except Exception:
-        traffic = None
+    pmc, traffic_src2 = committed_traffic("r04_cfg2_scan_pmc.json", lambda d: (N, nlist, batch, nprobe, k, world) == (1_000_000, 4096, 64, 16, 10, 1)
+                                          and not os.environ.get("MI_NSLICE"))
+    traffic = int(pmc["corrected_bytes_per_launch"]) if pmc else None
     roofline = {"kernel": "scan_kernel<64,8,false>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, gfx950 x2 read correction "
-                                  "(profiles/r04_cfg2_scan_pmc.json, round-4 kernel)" if traffic else None,
+                "traffic_source": traffic_src2,
                 "note": "a 14-15 us launch: a latency chain (tables + LUT staging, three rounds of gathers, rank / publish / merge), not a "
                         "bandwidth number -- DESIGN.md section 5",
                 "bytes_per_launch": int(scan_bytes), "avg_launch_ms": round(scan_ms, 5)}
@@ -1225,20 +1234,18 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True, pack=None):
     pr = model.profile_read()
     model.profile(False)
     tf = pr["gemm_flops"] / (pr["gemm_ms"] * 1e-3) / 1e12
-    traffic, traffic_src, xcheck = None, None, None
-    try:                                                               # separate --pmc passes of `bench.py --workload encode`
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_cfg3_encoder_gemm_pmc.json")))
-        if pmc.get("batch") == bs and pmc.get("tokens_step0") == ntok[0]:
-            traffic, traffic_src = int(pmc["hbm_bytes_per_step"]), pmc["source"]
-            kt = pmc["same_run_timing"]["gemm_ms_per_step_kernel_trace_sum"]
-            xcheck = {"gemm_ms_per_step": kt, "achieved": round(pr["gemm_flops"] / (kt * 1e-3) / 1e12, 1),
-                      "frac": round(pr["gemm_flops"] / (kt * 1e-3) / 1e12 / 2500.0, 4),
-                      "what": "the same FLOPs over the SUM of rocprofv3's per-kernel durations of the four GEMM kernels in the committed "
-                              "kernel-trace run of this workload (profiles/r04_cfg3_encoder_kernel_stats_v2.csv): a kernel's traced duration "
-                              "includes its drain tail and end-of-kernel cache write-back, during which the next launch already runs -- the "
-                              "sum reads 3-4 % above what the launches occupy back to back, and bounds `frac` from below"}
-    except Exception:
-        pass
+    # separate --pmc passes of `bench.py --workload encode` (tools/prof_r05.sh), dropped when the slab kernel changed since
+    pmc, traffic_src = committed_traffic("r05_cfg3_encoder_gemm_pmc.json", lambda d: d.get("batch") == bs and d.get("tokens_step0") == ntok[0])
+    traffic, xcheck = None, None
+    if pmc:
+        traffic = int(pmc["hbm_bytes_per_step"])
+        kt = pmc["same_run_timing"]["gemm_ms_per_step_kernel_trace_sum"]
+        xcheck = {"gemm_ms_per_step": kt, "achieved": round(pr["gemm_flops"] / (kt * 1e-3) / 1e12, 1),
+                  "frac": round(pr["gemm_flops"] / (kt * 1e-3) / 1e12 / 2500.0, 4),
+                  "what": "the same FLOPs over the SUM of rocprofv3's per-kernel durations of the four GEMM kernels in the committed "
+                          "kernel-trace run of this workload (" + str(pmc.get("kernel_stats_file", "profiles/")) + "): a kernel's traced duration "
+                          "includes its drain tail and end-of-kernel cache write-back, during which the next launch already runs -- the "
+                          "sum reads 3-4 % above what the launches occupy back to back, and bounds `frac` from below"}
     roofline = {"kernel": "gemm_bf16_slab_kernel (QKV / O / gate-up+SwiGLU / down, 112 launches per step; their epilogues carry the RMSNorms "
                           "and the rotary embedding: no rmsnorm_kernel / rope_kernel in the pass)",
                 "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",

@@ -280,6 +280,13 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
 
 /* ---- building blocks used by train() in the Python mirror ---------- */
 
+/* out[n][nc] = x . c^T (+ bias[nc] when not NULL), exact f32 (every element an ascending-k fmaf chain: the coarse
+ * quantiser's GEMM as a plain operator).  Replaces faiss VectorTransform::apply / LinearTransform::apply_noalloc (sgemm)
+ * in front of an IndexPreTransform ("OPQ64,IVF...": the factory string reference Makefile:39 leaves to sidecar-search's
+ * default).  Device pointers; d % 4 == 0. */
+int mi_ip_gemm(int device, int64_t n, const float *x, int64_t nc, const float *c, int d,
+               const float *bias, float *out, void *stream);
+
 /* arg max_j <x_i, c_j> (ties: smallest j) -> assign int32 [n], score float32 [n]
  * (host or device outputs; score may be NULL).  Clustering assignment step. */
 int mi_ip_assign(int device, int64_t n, const float *x, int64_t nc, const float *c, int d,

@@ -48,3 +48,24 @@ def test_search_parameter_objects():
     assert p.nprobe == 32 and p.max_codes == 0 and p.sel is None
     r = faiss.IndexRefineSearchParameters(k_factor=4, base_index_params=p)
     assert r.k_factor == 4.0 and r.base_index_params is p
+
+
+def test_clustering_parameters_mirror_faiss_defaults():
+    """faiss: ClusteringParameters.niter = 25, max_points_per_centroid = 256, seed = 1234; Level1Quantizer (index.cp) sets
+    niter = 10; the product quantizer trains with its own pq.cp (25).  Fields train() would silently ignore raise."""
+    import abstracts_search_amd.faiss as faiss
+    cp = faiss.ClusteringParameters()
+    assert (cp.niter, cp.nredo, cp.max_points_per_centroid, cp.min_points_per_centroid, cp.seed) == (25, 1, 256, 39, 1234)
+    assert not (cp.spherical or cp.int_centroids or cp.update_index or cp.frozen_centroids or cp.verbose)
+    cp.check_supported("x")
+    for field in ("spherical", "int_centroids", "update_index", "frozen_centroids"):
+        c2 = faiss.ClusteringParameters()
+        setattr(c2, field, True)
+        with pytest.raises(NotImplementedError, match=field):
+            c2.check_supported("train")
+    c2 = faiss.ClusteringParameters()
+    c2.nredo = 3
+    with pytest.raises(NotImplementedError, match="nredo"):
+        c2.check_supported("train")
+    pq = faiss._PQ(64, 8, 8)
+    assert pq.cp.niter == 25 and pq.cp is not faiss._PQ(64, 8, 8).cp

@@ -178,3 +178,71 @@ def test_pretransform_chain_is_parsed(tmp_path):
         fh.write(b"PcAm")
     with pytest.raises(fio.FaissFormatError, match="PcAm"):
         fio.parse_pretransform(f)
+
+
+def hnsw_record(rng, nlist, levels=3):
+    """[PRIOR: faiss write_HNSW] a plausible graph for nlist points: the five vectors and five ints, contents arbitrary --
+    the reader skips them"""
+    probas = np.array([0.9, 0.09, 0.01][:levels], np.float64)
+    cum = np.array([0, 64, 96, 128][:levels + 1], np.int32)
+    lev = rng.integers(1, levels + 1, nlist).astype(np.int32)
+    offsets = np.concatenate([[0], np.cumsum(cum[lev])]).astype(np.uint64)
+    neigh = rng.integers(-1, nlist, int(offsets[-1])).astype(np.int32)
+    b = b""
+    for v in (probas, cum, lev, offsets, neigh):
+        b += struct.pack("<Q", v.size) + v.tobytes()
+    return b + struct.pack("<iiiii", 3, levels - 1, 40, 16, 1)
+
+
+def with_hnsw_quantizer(t, raw: bytes) -> bytes:
+    """the IwPQ bytes of hand_assembled(t) with the IndexFlatIP quantiser wrapped in an IndexHNSWFlat record (IHNf: header,
+    graph, then the flat storage index): what "IVF<n>_HNSW32,PQ<M>" writes"""
+    flat_at = raw.index(b"IxFI")
+    flat_len = 4 + 33 + 8 + t["centroids"].size * 4
+    rng = np.random.default_rng(3)
+    return (raw[:flat_at] + b"IHNf" + header(t["d"], t["nlist"], True, 0) + hnsw_record(rng, t["nlist"]) +
+            raw[flat_at:flat_at + flat_len] + raw[flat_at + flat_len:])
+
+
+def test_hnsw_coarse_quantiser_is_read_as_its_flat_storage(tmp_path):
+    """[PRIOR layout] reference Makefile:39 passes no factory string to `index train`: if sidecar-search's default is
+    "IVF65536_HNSW32,...", index.faiss holds an IndexHNSWFlat in front of the lists.  The reader takes its flat storage as
+    the centroid table (searched exactly: a superset of what the graph would probe) and skips the graph."""
+    t = tiny()
+    f = tmp_path / "hnsw.faiss"
+    f.write_bytes(with_hnsw_quantizer(t, hand_assembled(t, "full")))
+    z = fio.parse(str(f))
+    same(z, t)
+    assert z["hnsw_quantizer"] is True and fio.parse_is_flat(str(f)) is False
+    g = tmp_path / "flat.faiss"
+    g.write_bytes(hand_assembled(t, "full"))
+    assert fio.parse(str(g))["hnsw_quantizer"] is False
+    bad = with_hnsw_quantizer(t, hand_assembled(t, "full")).replace(b"IHNf", b"IHNp")
+    f.write_bytes(bad)
+    with pytest.raises(fio.FaissFormatError, match="IHNp.*compressed storage"):
+        fio.parse(str(f))
+
+
+def test_linear_transform_longer_than_its_shape_is_accepted(tmp_path):
+    """faiss's writer only asserts A.size() >= d_in * d_out and b.size() >= d_out: the surplus is ignored, not an error"""
+    rng = np.random.default_rng(9)
+    d_in, d_out = 12, 8
+    A = rng.standard_normal(d_in * d_out + 5).astype(np.float32)
+    b = rng.standard_normal(d_out + 3).astype(np.float32)
+    f = tmp_path / "pt.faiss"
+    with open(f, "wb") as fh:
+        fh.write(b"IxPT" + header(d_in, 0, True, 0) + struct.pack("<i", 1))
+        fh.write(b"LTra" + struct.pack("<B", 1) + struct.pack("<Q", A.size) + A.tobytes() + struct.pack("<Q", b.size) + b.tobytes())
+        fh.write(struct.pack("<iiB", d_in, d_out, 1))
+        fh.write(b"IwPQ")
+    chain, off = fio.parse_pretransform(str(f))
+    assert np.array_equal(chain[0][0], A[:d_in * d_out].reshape(d_out, d_in)) and np.array_equal(chain[0][1], b[:d_out])
+    assert f.read_bytes()[off:] == b"IwPQ"
+    # and the writer is the reader's inverse
+    sub = tmp_path / "sub.bin"
+    sub.write_bytes(b"IwPQ-and-the-rest")
+    g = tmp_path / "out.faiss"
+    fio.dump_pretransform(str(g), chain, d_in, 7, True, 0, str(sub))
+    chain2, off2 = fio.parse_pretransform(str(g))
+    assert np.array_equal(chain2[0][0], chain[0][0]) and np.array_equal(chain2[0][1], chain[0][1])
+    assert g.read_bytes()[off2:] == b"IwPQ-and-the-rest"

@@ -687,6 +687,115 @@ def test_read_index_of_a_pretransform_file(faiss, tmp_path):
     assert (I == In).mean() > 0.99                              # (the same rotation by another GEMM: rounding ties at most)
 
 
+def test_pretransform_apply_is_the_exact_gemm_and_the_file_round_trips(faiss, oracle, tmp_path):
+    """IndexPreTransform.apply runs on the library's own exact-f32 GEMM (mi_ip_gemm; no BLAS call in the product package):
+    every output element is the ascending-k fmaf chain the oracle's IndexFlatIP computes, + b; write_index(IndexPreTransform)
+    -> read_index gives the same chain and the same search results.  (reference Makefile:12-13, 39: whatever factory string
+    sidecar-search's `index train` defaults to -- an "OPQ..," prefix is an IndexPreTransform.)"""
+    d_in, d, M, nlist = 96, 64, 8, 16
+    cent, cb, x, q = random_problem(41, d, M, nlist, 2500, 40)
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((d, d_in)).astype(np.float32) / np.sqrt(d_in)
+    b = rng.standard_normal(d).astype(np.float32)
+    R = np.linalg.qr(rng.standard_normal((d, d)))[0].astype(np.float32)
+    idx = make_index(faiss, cent, cb)
+    pt = faiss.IndexPreTransform([(A, b), (R, None)], idx)
+    xin = rng.standard_normal((x.shape[0], d_in)).astype(np.float32)
+    qin = xin[:40] + 0.01 * rng.standard_normal((40, d_in)).astype(np.float32)
+    # (1) the chain, element by element, against the oracle's dot product (flat_ip scores of the rows of A, all d of them)
+    y = pt.apply(qin)
+    D1, I1 = oracle.flat_ip(qin, A, d)
+    step1 = np.empty((40, d), np.float32)
+    np.put_along_axis(step1, I1, D1, axis=1)
+    step1 = step1 + b[None, :]                                   # one f32 add per element, as add_row_bias_kernel does
+    D2, I2 = oracle.flat_ip(step1, R, d)
+    want = np.empty((40, d), np.float32)
+    np.put_along_axis(want, I2, D2, axis=1)
+    assert np.array_equal(bits(y), bits(want))
+    import torch
+    yt = pt.apply(torch.from_numpy(qin).cuda())                  # CUDA tensor in -> CUDA tensor out, same bits
+    assert yt.is_cuda and np.array_equal(bits(yt.cpu().numpy()), bits(want))
+    assert pt.apply(np.zeros((0, d_in), np.float32)).shape == (0, d)
+    with pytest.raises(ValueError):
+        pt.apply(np.zeros((3, d), np.float32))
+    # (2) add / search through the chain, then the file
+    pt.add(xin)
+    pt.nprobe = 6
+    D, I = pt.search(qin, 10)
+    f = str(tmp_path / "opq.faiss")
+    faiss.write_index(pt, f)
+    assert open(f, "rb").read(4) == b"IxPT"
+    back = faiss.read_index(f)
+    assert isinstance(back, faiss.IndexPreTransform) and back.d == d_in and back.ntotal == pt.ntotal and len(back.chain) == 2
+    assert np.array_equal(back.chain[0][0], A) and np.array_equal(back.chain[0][1], b) and back.chain[1][1] is None
+    back.nprobe = 6
+    Db, Ib = back.search(qin, 10)
+    assert np.array_equal(I, Ib) and np.array_equal(bits(D), bits(Db))
+
+
+def test_read_index_with_an_hnsw_coarse_quantiser(faiss, tmp_path):
+    """[PRIOR layout] "IVF<n>_HNSW32,PQ<M>": index.faiss holds an IndexHNSWFlat (IHNf) in front of the lists.  mi_index_load
+    takes its flat storage as the centroid table and skips the graph: the loaded index equals the flat-quantiser one."""
+    import struct
+    d, M, nlist = 64, 8, 32
+    cent, cb, x, q = random_problem(53, d, M, nlist, 4000, 16)
+    idx = make_index(faiss, cent, cb)
+    idx.add(x)
+    idx.nprobe = 7
+    D, I = idx.search(q, 10)
+    flat = str(tmp_path / "flat.faiss")
+    faiss.write_index(idx, flat)
+    raw = open(flat, "rb").read()
+    at = raw.index(b"IxFI")
+    flen = 4 + 33 + 8 + nlist * d * 4
+    rng = np.random.default_rng(1)
+    lev = rng.integers(1, 4, nlist).astype(np.int32)
+    cum = np.array([0, 64, 96, 128], np.int32)
+    offsets = np.concatenate([[0], np.cumsum(cum[lev])]).astype(np.uint64)
+    neigh = rng.integers(-1, nlist, int(offsets[-1])).astype(np.int32)
+    graph = b""
+    for v in (np.array([0.9, 0.09, 0.01]), cum, lev, offsets, neigh):
+        graph += struct.pack("<Q", v.size) + v.tobytes()
+    graph += struct.pack("<iiiii", 3, 2, 40, 16, 1)
+    hdr = struct.pack("<iqqqBi", d, nlist, 1 << 20, 1 << 20, 1, 0)
+    f = str(tmp_path / "hnsw.faiss")
+    with open(f, "wb") as fh:
+        fh.write(raw[:at] + b"IHNf" + hdr + graph + raw[at:at + flen] + raw[at + flen:])
+    back = faiss.read_index(f)
+    assert back.ntotal == idx.ntotal and back.nprobe == 7 and back.is_trained
+    assert np.array_equal(back.get_centroids(), cent)
+    D2, I2 = back.search(q, 10)
+    assert np.array_equal(I, I2) and np.array_equal(bits(D), bits(D2))
+    with open(f, "wb") as fh:                                    # HNSW over compressed storage: no exact centroid table
+        fh.write(raw[:at] + b"IHNs" + hdr + graph + raw[at:])
+    with pytest.raises(Exception, match="IHNs"):
+        faiss.read_index(f)
+
+
+def test_crosscheck_tool_runs_end_to_end_against_itself():
+    """tools/crosscheck_faiss.py (first contact with the real faiss as one command) with this package standing in for the
+    real library: both directions of the file format, every rank identical; without --self on a box that has no faiss it
+    says so and exits 3."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "crosscheck_faiss.py")
+    out = subprocess.run([sys.executable, tool, "--self", "--n", "30000", "--nlist", "64", "--d", "64", "--M", "8", "--nq", "100"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = json.loads(out.stdout)
+    assert len(rep["cases"]) == 2 and all(c["id_match_rate"] == 1.0 and c["real"] == 0 and c["max_score_ulps"] == 0 for c in rep["cases"])
+    try:
+        import faiss as real                                    # noqa: F401
+        has_real = not getattr(real, "__file__", "").startswith(root)
+    except Exception:
+        has_real = False
+    if not has_real:
+        out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 3 and json.loads(out.stdout)["faiss"] == "absent"
+
+
 def test_sparse_lists_through_the_c_abi_match_the_documented_layout(faiss, tmp_path):
     """A non-empty index with at most half of its lists filled takes faiss's 'sprs' size encoding:
     a vector of 2 * non_empty words ({list, size} pairs flattened).  The C ABI writer
@@ -741,7 +850,7 @@ def test_train_builds_a_usable_index(faiss):
     x = synth.corpus_rows(0, 20000, d=64, ncentres=64, cos=0.8)
     q = synth.queries_from(x, 50, cos=0.8)
     idx = faiss.index_factory(64, "IVF32,PQ16", faiss.METRIC_INNER_PRODUCT)
-    idx.cp.niter = 8
+    idx.cp.niter = idx.pq.cp.niter = 8
     idx.train(x)
     assert idx.is_trained
     idx.add(x)
@@ -763,7 +872,7 @@ def test_cfg2_full_size_properties(faiss, oracle):
     n, d, nlist, M = 1_000_000, 1024, 4096, 64
     x = synth.corpus_cuda(n, d)
     idx = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT)
-    idx.cp.niter = 4
+    idx.cp.niter = idx.pq.cp.niter = 4
     idx.train(x)
     idx.add(x)
     assert idx.ntotal == n

@@ -88,7 +88,7 @@ def test_ivfpq_l2_factory_train_write_read(faiss, oracle, tmp_path):
     x = (c[rng.integers(0, 30, n)] + 0.4 * rng.standard_normal((n, d))).astype(np.float32)
     idx = faiss.index_factory(d, f"IVF{nlist},PQ{M}")
     assert idx.metric_type == faiss.METRIC_L2
-    idx.cp.niter = 4
+    idx.cp.niter = idx.pq.cp.niter = 4
     idx.train(x)
     ce, cbe = T.train_ivfpq_l2(x, nlist, M, True, niter=4, max_points_per_centroid=idx.cp.max_points_per_centroid, seed=idx.cp.seed)
     assert np.array_equal(bits(idx.get_centroids()), bits(ce)) and np.array_equal(bits(idx.get_codebook()), bits(cbe))

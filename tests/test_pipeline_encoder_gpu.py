@@ -345,13 +345,16 @@ def test_query_batches_at_stella_widths_vs_oracle(st, nq, layers):
     toks = [rng.integers(0, cfg["vocab_size"], int(L)).tolist() for L in lens]
     model = st.SentenceTransformer(config=cfg, weights=W)
     before, before_n, before_w = st.debug_counter("splitk_launches"), st.debug_counter("reduce_norm_launches"), st.debug_counter("n192_launches")
+    before_m = st.debug_counter("mid_launches")
     e = model.encode_tokens(toks, batch_size=nq, normalize_embeddings=True)
     # ~100 to ~5000 tokens: the down projection of every layer runs K-split through the workspace (16 / 64 / 132 queries:
-    # 18 x 14, 54 x 4 and 102 x 2 workgroups), and its reduction pass writes the next layer's first RMSNorm
-    # ~100 to ~1500 tokens: the QKV and O projections are K-split too (128 x 128 tiles, planes, one reduction pass that also
-    # rotates Q / K resp. writes the post-attention RMSNorm: no rope_kernel, no rmsnorm_kernel in the layer)
-    assert st.debug_counter("splitk_launches") - before == {5: 3 * layers, 16: 3 * layers, 64: layers, 132: layers}.get(nq, 0)
-    assert st.debug_counter("reduce_norm_launches") - before_n == {5: 2 * layers - 1, 16: 2 * layers - 1, 64: layers - 1, 132: layers - 1}.get(nq, 0)
+    # 18 x 10, 54 x 4 and 102 x 2 workgroups), and its reduction pass writes the next layer's first RMSNorm
+    # ~100 to ~3000 / ~4000 tokens: the QKV and O projections are ONE launch each (encoder_mid.h: whole-K 64 x 64 .. 128 x 128
+    # tiles, bias + RoPE resp. residual + RMSNorm partials in the epilogue: no planes, no reduction pass, no rope_kernel)
+    # (132 queries and more: the pooled Dense GEMM -- M = queries > 64, K = 1536 -- is such a projection too)
+    assert st.debug_counter("mid_launches") - before_m == {5: 2 * layers, 16: 2 * layers, 64: 2 * layers}.get(nq, 1 if nq > 64 else 0)
+    assert st.debug_counter("splitk_launches") - before == {5: layers, 16: layers, 64: layers, 132: layers}.get(nq, 0)
+    assert st.debug_counter("reduce_norm_launches") - before_n == {5: layers - 1, 16: layers - 1, 64: layers - 1, 132: layers - 1}.get(nq, 0)
     # ~5 400 to 8 192 tokens: O and down projection on 256 x 192 tiles (8 tile columns: one full round of workgroups);
     # 4 100 to 5 400: the O projection alone (the down projection is K-split there)
     assert st.debug_counter("n192_launches") - before_w == {200: 2 * layers, 132: layers}.get(nq, 0)
@@ -388,6 +391,38 @@ def test_192_row_tiles_vs_oracle(st, monkeypatch):
             ref = E.encode(E.EncoderConfig(**cfg), Wc, np.concatenate(toks), np.concatenate([[0], np.cumsum(lens)]), True).numpy()
         assert ((outs["m192"] * ref).sum(1)).min() > 1 - 1e-3
         assert ((outs["m192"] * outs["m256"]).sum(1)).min() > 1 - 2e-4 and np.abs(outs["m192"] - outs["m256"]).max() < 4e-3
+
+
+@pytest.mark.parametrize("lens", [[40] * 3, [31] * 18, [48] * 6 + [17] * 3, [33] * 40, [16, 48] * 40, [512, 300, 77, 8]])
+def test_one_launch_projections_vs_the_k_split_path_and_oracle(st, lens, monkeypatch):
+    """encoder_mid.h (QKV and O projections of ~100 .. ~4000 tokens as one launch each: whole-K tiles, RoPE / residual +
+    RMSNorm partials in the epilogue) against round 4's K-split planes + reduction passes (MI_NO_MID_GEMM=1) and against the
+    fp32 oracle, over token counts that pick every tile shape (64 x 64 .. 128 x 128), ragged last row tiles, the fused and
+    the standalone post-attention RMSNorm (<= 256 tokens: gate/up is not on the slab kernel), and long sequences."""
+    import torch
+    from oracle import encoder_oracle as E
+    cfg = dict(st.STELLA_EN_1_5B_V5)
+    cfg["vocab_size"], cfg["n_layers"] = 4096, 2
+    W = _rand_weights_gpu(cfg, 91)
+    rng = np.random.default_rng(len(lens))
+    toks = [rng.integers(0, cfg["vocab_size"], int(L)).tolist() for L in lens]
+    outs = {}
+    for name in ("mid", "ksplit"):
+        monkeypatch.delenv("MI_NO_MID_GEMM", raising=False)
+        if name == "ksplit":
+            monkeypatch.setenv("MI_NO_MID_GEMM", "1")
+        model = st.SentenceTransformer(config=cfg, weights=W)
+        c0 = st.debug_counter("mid_launches")
+        outs[name] = model.encode_tokens(toks, batch_size=len(toks), normalize_embeddings=True)
+        assert st.debug_counter("mid_launches") - c0 == (2 * cfg["n_layers"] if name == "mid" else 0), name
+    Wc = {k: v.float().cpu() for k, v in W.items()}
+    with torch.no_grad():
+        ref = E.encode(E.EncoderConfig(**cfg), Wc, np.concatenate(toks), np.concatenate([[0], np.cumsum(lens)]), True).numpy()
+    assert ((outs["mid"] * ref).sum(1)).min() > 1 - 1e-3
+    assert ((outs["mid"] * outs["ksplit"]).sum(1)).min() > 1 - 2e-4 and np.abs(outs["mid"] - outs["ksplit"]).max() < 4e-3
+    monkeypatch.delenv("MI_NO_MID_GEMM", raising=False)
+    again = st.SentenceTransformer(config=cfg, weights=W).encode_tokens(toks, batch_size=len(toks), normalize_embeddings=True)
+    assert np.array_equal(again, outs["mid"])                  # no atomics: run-to-run identical
 
 
 @pytest.mark.parametrize("lens", [[1], [3], [16], [17], [32], [33], [48], [5, 9, 20], [1] * 7, [16, 16, 16], [2, 46]])

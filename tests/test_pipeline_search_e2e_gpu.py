@@ -36,7 +36,7 @@ def cfg4(faiss):
     n, d, nlist, M = 2 * 1024 * 1024, 1024, 65536, 64
     x = synth.corpus_cuda(n, d)
     idx = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT)
-    idx.cp.niter = 2
+    idx.cp.niter = idx.pq.cp.niter = 2
     idx.train(x)
     idx.add(x)
     q = synth.queries_cuda(x, 1024, seed=77)
@@ -228,7 +228,7 @@ def test_cfg5_encode_then_search_vs_oracle_chain(faiss, oracle, tmp_path):
     emb = model.encode(docs, batch_size=256, normalize_embeddings=True)          # documents are encoded bare
     nlist, M, k, nprobe = 64, 8, 10, 8
     idx = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT)
-    idx.cp.niter = 8
+    idx.cp.niter = idx.pq.cp.niter = 8
     idx.train(emb)
     idx.add(emb)
     idx.nprobe = nprobe

@@ -26,7 +26,7 @@ def test_train_is_bit_equal_to_the_oracle(oracle, n, d, nlist, M, by_residual):
     from oracle import train_oracle as T
     x = _data(n + d, n, d, 40)
     idx = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT, by_residual)
-    idx.cp.niter = 5
+    idx.cp.niter = idx.pq.cp.niter = 5
     idx.train(x)
     cent, cb = idx.get_centroids(), idx.get_codebook()
     ce, cbe = T.train_ivfpq(x, nlist, M, by_residual, niter=5, max_points_per_centroid=idx.cp.max_points_per_centroid,
@@ -35,7 +35,7 @@ def test_train_is_bit_equal_to_the_oracle(oracle, n, d, nlist, M, by_residual):
     assert np.array_equal(bits(cb), bits(cbe))
     # run to run
     idx2 = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT, by_residual)
-    idx2.cp.niter = 5
+    idx2.cp.niter = idx2.pq.cp.niter = 5
     idx2.train(x)
     assert np.array_equal(bits(idx2.get_centroids()), bits(cent)) and np.array_equal(bits(idx2.get_codebook()), bits(cb))
     # a training run is k-means: the quantisation error of the trained tables beats the initial draw

@@ -27,7 +27,7 @@ for l in range(cfg["n_layers"]):
 # index: cfg2 by default; E2E_N=25875000 E2E_NLIST=65536 is one shard of the 207 M configuration
 N, NLIST = int(os.environ.get("E2E_N", 1_000_000)), int(os.environ.get("E2E_NLIST", 4096))
 idx = faiss.IndexIVFPQ(1024, NLIST, 64, 8, faiss.METRIC_INNER_PRODUCT)
-idx.cp.niter = 6 if NLIST <= 4096 else 4
+idx.cp.niter = idx.pq.cp.niter = 6 if NLIST <= 4096 else 4
 x = synth.corpus_cuda(min(N, max(1_000_000, 64 * NLIST)), 1024)
 idx.train(x)
 if N <= x.shape[0]:

@@ -9,6 +9,7 @@ ntok = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 nseq = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 cfg = dict(st.STELLA_EN_1_5B_V5)
+cfg["n_layers"] = int(os.environ.get("ENC_LAYERS", cfg["n_layers"]))   # ENC_LAYERS=2: both layers' weights (187 MB) stay in the 256 MB Infinity Cache
 model = st.SentenceTransformer(config=cfg)
 g = torch.Generator(device="cuda").manual_seed(7)
 def rnd(shape, scale): return (torch.randn(shape, generator=g, device="cuda") * scale).bfloat16()

@@ -4,7 +4,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import abstracts_search_amd.sentence_transformers as st
-cfg = dict(st.STELLA_EN_1_5B_V5); cfg["vocab_size"] = 8192
+cfg = dict(st.STELLA_EN_1_5B_V5)
+cfg["n_layers"] = int(os.environ.get("ENC_LAYERS", cfg["n_layers"]))   # ENC_LAYERS=2: both layers' weights (187 MB) stay in the 256 MB Infinity Cache; cfg["vocab_size"] = 8192
 g = torch.Generator(device="cuda").manual_seed(7)
 rnd = lambda shape, scale: (torch.randn(shape, generator=g, device="cuda") * scale).bfloat16()
 H, I = cfg["hidden"], cfg["intermediate"]; qc, kc = cfg["n_heads"] * cfg["head_dim"], cfg["n_kv_heads"] * cfg["head_dim"]

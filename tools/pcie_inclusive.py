@@ -6,7 +6,7 @@ import abstracts_search_amd.faiss as faiss
 import abstracts_search_amd.synth as synth
 N, d, nlist = 8 << 20, 1024, 65536
 idx = faiss.IndexIVFPQ(d, nlist, 64, 8, faiss.METRIC_INNER_PRODUCT)
-idx.cp.niter = 2
+idx.cp.niter = idx.pq.cp.niter = 2
 x = synth.corpus_cuda(4 << 20, d)
 idx.train(x)
 for c0 in range(0, N, 1 << 20):

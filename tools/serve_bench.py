@@ -26,7 +26,7 @@ for l in range(cfg["n_layers"]):
         p + "mlp.up_proj.weight": rnd((I, H), H ** -0.5), p + "mlp.down_proj.weight": rnd((H, I), I ** -0.5)})
 N, NLIST = int(os.environ.get("SERVE_N", 8 * 1048576)), int(os.environ.get("SERVE_NLIST", 4096))
 idx = faiss.IndexIVFPQ(1024, NLIST, 64, 8, faiss.METRIC_INNER_PRODUCT)
-idx.cp.niter = 4
+idx.cp.niter = idx.pq.cp.niter = 4
 idx.train(synth.corpus_cuda(1048576, 1024))
 for c0 in range(0, N, 1048576):
     idx.add(synth.corpus_cuda(1048576, 1024, row0=c0))

@@ -17,7 +17,7 @@ out = sys.argv[5] if len(sys.argv) > 5 else "gpurun_out/params.json"
 nlist, k = 4096, 10
 x = synth.corpus_cuda(n, 1024)
 idx = faiss.index_factory(1024, f"IVF{nlist},PQ64,RFlat", faiss.METRIC_INNER_PRODUCT)
-idx.base_index.cp.niter = 10
+idx.base_index.cp.niter = idx.base_index.pq.cp.niter = 10
 idx.train(x)
 idx.add(x)
 q = synth.queries_cuda(x, nq, seed=4321)
