@@ -20,7 +20,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 LIBS = {
     "ivfpq": ("libmi_ivfpq.so", ["ivfpq.hip"], ["ivfpq_kernels.h", "encoder_kernels.h", "common.h"]),   # ivfpq.hip includes the ring GEMM
-    "encoder": ("libmi_encoder.so", ["encoder.hip"], ["encoder_kernels.h", "common.h"]),
+    "encoder": ("libmi_encoder.so", ["encoder.hip"], ["encoder_kernels.h", "encoder_few.h", "encoder_mid.h", "common.h"]),
 }
 
 _loaded: dict[str, ctypes.CDLL] = {}

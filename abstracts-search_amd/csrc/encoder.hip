@@ -25,6 +25,47 @@ namespace {
 
 hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Environment knobs.  Read ONCE -- at the first call into the library, or again by mi_encoder_reload_env() (tests and tools:
+// not beside a running encode) -- into this struct: no encode call path calls getenv (not safe against a concurrent setenv).
+// Every knob is exercised by a test or a committed tool; what each overrides is a measured dispatch rule.
+struct Knobs {
+    std::string gemm_tile;   // MI_GEMM_TILE=big|slab8|slab4|mid|mid64|small|tiny|128: one tile configuration for every GEMM
+    bool gemm_ring;          // MI_GEMM_RING=1: round 1's 256 x 256 ring kernel instead of the slab kernel
+    bool tail_split_force;   // MI_TAIL_SPLIT_FORCE=1: split a short last round along K whatever the cost model says
+    bool no_bulk_fuse, no_rope_fuse, no_norm_fuse;   // MI_NO_BULK_FUSE / MI_NO_ROPE_FUSE / MI_NO_NORM_FUSE: standalone rmsnorm / rope kernels
+    bool no_mid_gemm;        // MI_NO_MID_GEMM=1: round 4's K-split planes for the QKV / O projections of a few hundred tokens
+    std::string mid_tile;    // MI_MID_TILE=128x128|128x64|96x64|64x64: one tile shape for encoder_mid.h
+    bool no_m192;            // MI_NO_M192=1: 256-row slab tiles where 192-row ones would pay
+    int splitk;              // MI_SPLITK=S: K slices of the all-tiles split (-1: by shape)
+    int pool_gemm;           // MI_POOL_GEMM=0: the per-sequence pooling kernel for every batch size
+    bool no_few;             // MI_NO_FEW=1: a handful of tokens through the general path (fragment-major tiles)
+    bool few_d_fuse, few_sync, few_ts;   // MI_FEW_D_FUSE (in-launch reduction of the down projection), MI_FEW_SYNC, MI_FEW_TS
+    int enc_ts;              // MI_ENC_TS=1: in-kernel stamps of the first four slab GEMMs of > 4096 tokens; =n (n > 1): of > n tokens
+    bool gemm_ts;            // MI_GEMM_TS=1: the same for mi_enc_gemm_bf16
+    void load() {
+        auto num = [](const char *n, int dflt) { const char *e = std::getenv(n); return e && *e ? std::atoi(e) : dflt; };
+        auto set = [](const char *n) { return std::getenv(n) != nullptr; };
+        auto str = [](const char *n) { const char *e = std::getenv(n); return std::string(e ? e : ""); };
+        gemm_tile = str("MI_GEMM_TILE");
+        gemm_ring = set("MI_GEMM_RING");
+        tail_split_force = set("MI_TAIL_SPLIT_FORCE");
+        no_bulk_fuse = set("MI_NO_BULK_FUSE"); no_rope_fuse = set("MI_NO_ROPE_FUSE"); no_norm_fuse = set("MI_NO_NORM_FUSE");
+        no_mid_gemm = set("MI_NO_MID_GEMM");
+        mid_tile = str("MI_MID_TILE");
+        no_m192 = set("MI_NO_M192");
+        splitk = num("MI_SPLITK", -1);
+        pool_gemm = num("MI_POOL_GEMM", -1);
+        no_few = set("MI_NO_FEW");
+        few_d_fuse = set("MI_FEW_D_FUSE"); few_sync = set("MI_FEW_SYNC"); few_ts = set("MI_FEW_TS");
+        enc_ts = num("MI_ENC_TS", 0); gemm_ts = set("MI_GEMM_TS");
+    }
+};
+Knobs &knobs_mut() {
+    static Knobs k = [] { Knobs x{}; x.load(); return x; }();
+    return k;
+}
+inline const Knobs &knobs() { return knobs_mut(); }
+
 // launches that took the K-split tail (f32 atomics into the residual stream): tests assert the path ran
 std::atomic<int64_t> g_tail_split_launches{0};
 std::atomic<int64_t> g_splitk_launches{0};
@@ -44,7 +85,8 @@ struct LayerW {
 };
 
 // what a GEMM launch did besides the GEMM (launch_gemm's return value)
-enum { GEMM_NORMED = 1,      // a split-K reduction pass also wrote the RMSNorm of the updated stream (GemmArgs::norm_w / norm_y)
+enum { GEMM_RMS_DONE = 8,    // ... and already turned them into 1/rms per row (GemmArgs::rms_out): no row_rms_kernel launch
+       GEMM_NORMED = 1,      // a split-K reduction pass also wrote the RMSNorm of the updated stream (GemmArgs::norm_w / norm_y)
        GEMM_ROPED = 2,       // the QKV epilogue (or its reduction pass) rotated Q and K
        GEMM_RAWNORM = 4 };   // the residual epilogue wrote bf16(X * norm_w) and the rows' partial sums of squares
                              // (GemmArgs::ssq_out; the number of slots per row in bits 8..15)
@@ -61,7 +103,7 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
     unsigned nblocks = 8u * per * g.ksplit;
     g.tail_first = 0;
     g.tail_split = 1;
-    if (epi == EPI_RESID && !g.bias && g.ksplit == 1 && BM * BN >= 256 * 256 && !std::getenv("MI_NO_TAIL_SPLIT")) {
+    if (epi == EPI_RESID && !g.bias && g.ksplit == 1 && BM * BN >= 256 * 256) {
         // wave quantisation: 780 tiles on 256 CUs are 3 full rounds + 12 tiles that would
         // hold the kernel for a 4th tile time; split those along K (f32 atomics into the
         // residual stream, as the small-batch split-K path does)
@@ -79,26 +121,8 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
         }
     }
     dim3 grid(nblocks), block(64 * WAVES_M * WAVES_N);
-    // big tiles, whole-K workgroups, more tiles than CUs: one persistent workgroup per CU walks its
-    // tiles and requests the next tile's first K tiles before the epilogue of the current one
-    // Off by default: the extra loop level pushes the 256x256 kernel over its 256 VGPRs (44 B of
-    // scratch per lane) and it measured 5 % slower (976 vs 1 030 TF on gate/up); MI_GEMM_PERSIST=1 keeps
-    // the experiment.  What it would hide is the ~11 us per tile of output write + pipeline fill.
-    static const bool persist_on = std::getenv("MI_GEMM_PERSIST") && std::atoi(std::getenv("MI_GEMM_PERSIST")) != 0;
-    if constexpr (BM * BN >= 256 * 256) {
-        if (persist_on && g.ksplit == 1 && g.tail_split == 1 && 8 * per > 256) {
-            dim3 pgrid(256);
-            switch (epi) {
-                case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_STORE, WMT, WNT, WAVES_M, WAVES_N, ST, true>), pgrid, block, 0, st, g); break;
-                case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_RESID, WMT, WNT, WAVES_M, WAVES_N, ST, true>), pgrid, block, 0, st, g); break;
-                case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_QKV, WMT, WNT, WAVES_M, WAVES_N, ST, true>), pgrid, block, 0, st, g); break;
-                case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_SWIGLU, WMT, WNT, WAVES_M, WAVES_N, ST, true>), pgrid, block, 0, st, g); break;
-                default: throw Error("bad epilogue");
-            }
-            MI_HIP(hipGetLastError());
-            return;
-        }
-    }
+    // (a persistent variant -- one workgroup per CU walking its tiles, the next tile's first slabs requested before the
+    //  epilogue -- measured 5 % slower here and no faster on the slab kernel: DESIGN_HISTORY.md)
     switch (epi) {
         case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_STORE, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
         case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI_RESID, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
@@ -122,17 +146,10 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
     g.tail_split = 1;
     float *part = g.part;
     g.part = nullptr;                                     // set again below if every tile is split
-    static const int order_env = std::getenv("MI_TILE_ORDER") ? std::atoi(std::getenv("MI_TILE_ORDER")) : -1;
     // measured at 29 312 tokens (tools/gemm_bench.py, profiles/r03_gemm_tile_order.txt): chip patches +3 / +5 / +5 % on the
     // QKV / O / down shapes (N <= 2048), -1.5 % on gate-up (N = 17 920: 70 tile columns) -- so by the width of the GEMM
-    g.order = order_env >= 0 ? order_env : (g.tiles_n <= 16 ? 1 : 0);
-    // staggered start (gemm_bf16_slab_kernel): for the epilogues that move the most bytes per tile, when the launch runs several rounds
-    static const int stagger_env = std::getenv("MI_GEMM_STAGGER") ? std::atoi(std::getenv("MI_GEMM_STAGGER")) : -1;
-    static const int stagger_qkv = std::getenv("MI_GEMM_STAGGER_QKV") ? std::atoi(std::getenv("MI_GEMM_STAGGER_QKV")) : -1;
-    g.stagger = 0;
-    if (nblocks > 256u && epi == EPI_RESID) g.stagger = stagger_env >= 0 ? stagger_env : 0;
-    if (nblocks > 256u && epi == EPI_QKV) g.stagger = stagger_qkv >= 0 ? stagger_qkv : 0;
-    if (epi == EPI_RESID && !g.bias && !std::getenv("MI_NO_TAIL_SPLIT")) {
+    g.order = g.tiles_n <= 16 ? 1 : 0;
+    if (epi == EPI_RESID && !g.bias) {
         const int ncu = 256, nb = 8 * per;
         const int main_b = nb / ncu * ncu, rem = nb - main_b;
         const int nk = g.K / 32;
@@ -148,10 +165,10 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
                 const double gain = tile_us * (1.0 - 1.0 / sp) - 0.57 * rem * sp - 6.0;
                 if (gain > best_gain) { best_gain = gain; best = sp; }
             }
-            if (std::getenv("MI_TAIL_SPLIT_FORCE") && sp_max >= 2) best = sp_max;   // tests: the split whatever the model says
+            if (knobs().tail_split_force && sp_max >= 2) best = sp_max;   // tests: the split whatever the model says
             // the split tail meets in f32 atomics: no workgroup sees the finished rows, so the fused RMSNorm (ssq_out) and the
             // split exclude each other -- the fusion saves ~30 us a launch, the split has to buy more than that
-            if (best >= 2 && g.ssq_out && best_gain < 40.0 && !std::getenv("MI_TAIL_SPLIT_FORCE")) best = 1;
+            if (best >= 2 && g.ssq_out && best_gain < 40.0 && !knobs().tail_split_force) best = 1;
             if (best >= 2) {
                 g.ssq_out = nullptr;
                 g.tail_first = main_b;
@@ -170,8 +187,7 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
         // (>= 4 K tiles (8 steps) per slice; at most 10 slices: every slice writes an M x N f32 plane that the reduction pass
         // reads back -- 14 slices of 576 x 1536 are 49 MB each way; 16 queries 3.85 -> 3.71 ms with 10: profiles/r04 notes)
         int S = std::min({10, 256 / std::max(1, ntiles), nt64 / 4});
-        static const int s_env = std::getenv("MI_SPLITK") ? std::atoi(std::getenv("MI_SPLITK")) : -1;
-        if (s_env >= 0) S = std::min(s_env, nt64);
+        if (knobs().splitk >= 0) S = std::min(knobs().splitk, nt64);
         if (S >= 2 && (size_t)S * g.M * g.N * 4 <= g.part_bytes) {
             split_all = S;
             ++g_splitk_launches;
@@ -179,11 +195,8 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
             g.tail_first = 0;
             g.tail_split = S;
             nblocks = (unsigned)(ntiles * S);
-            static const bool slice_major = !(std::getenv("MI_SPLITK_ORDER") && std::atoi(std::getenv("MI_SPLITK_ORDER")) == 0);
-            if (slice_major) {                            // slices of K to XCDs (gemm_bf16_slab_kernel::decode, order 2)
-                g.order = 2;
-                nblocks = 8u * (unsigned)((ntiles * S + 7) / 8);
-            }
+            g.order = 2;                                  // slices of K to XCDs (gemm_bf16_slab_kernel::decode): the down projection's
+            nblocks = 8u * (unsigned)((ntiles * S + 7) / 8);   // fetch 124 -> ~40 MB at 576 tokens
         }
     }
     dim3 grid(nblocks), block(128 * WN_);
@@ -194,8 +207,7 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
     bool normed = false;                                  // the reduction pass also wrote the RMSNorm the caller asked for
     auto finish_split = [&] {
         if (split_all == 1) return;
-        static const bool no_fuse = std::getenv("MI_NO_REDUCE_NORM") != nullptr;
-        if (g.norm_w && g.norm_y && g.ldc == g.N && g.N <= 2048 && !no_fuse) {
+        if (g.norm_w && g.norm_y && g.ldc == g.N && g.N <= 2048) {
             hipLaunchKernelGGL(splitk_reduce_norm_kernel, dim3((unsigned)g.M), dim3(256), 0, st, g.X, g.part, split_all, g.M, g.N, g.bias,
                                g.norm_w, g.norm_eps, g.norm_y);
             normed = true;
@@ -207,25 +219,6 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
         }
         MI_HIP(hipGetLastError());
     };
-    // more work units than CUs: one persistent workgroup per CU could walk its units and request the next unit's first
-    // slabs before the epilogue of the current one.
-    // Off by default: it measured no faster (1 136 vs 1 169 TF on the QKV shape) -- what a tile pays outside its K loop
-    // is the ISSUE of the epilogue's stores, not the relaunch or the pipeline fill.  MI_GEMM_PERSIST=1 keeps the experiment.
-    static const int persist_env = std::getenv("MI_GEMM_PERSIST") ? std::atoi(std::getenv("MI_GEMM_PERSIST")) : 0;   // 1: every epilogue, 2: SwiGLU only
-    const bool persist_on = persist_env == 1 || (persist_env == 2 && epi == EPI_SWIGLU);
-    if (persist_on && nblocks > 256 && WMT_ == 8) {
-        dim3 pgrid(256);
-        switch (epi) {
-            case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_STORE, WN_, true>), pgrid, block, 0, st, g); break;
-            case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, WN_, true>), pgrid, block, 0, st, g); break;
-            case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_QKV, WN_, true>), pgrid, block, 0, st, g); break;
-            case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_SWIGLU, WN_, true>), pgrid, block, 0, st, g); break;
-            default: throw Error("bad epilogue");
-        }
-        MI_HIP(hipGetLastError());
-        MI_REQUIRE(!g.row_scale && !g.ssq_out && !g.rope_cs, "persistent slab GEMM: no fused RMSNorm / rotary epilogues");
-        return 0;
-    }
     if constexpr (WMT_ == 6) {                            // 192-row tiles: the two epilogues the few-hundred-token passes send here
         ++g_m192_launches;
         switch (epi) {
@@ -259,7 +252,6 @@ int launch_slab_n192(GemmArgs g, hipStream_t st) {
     g.tail_first = 0;
     g.tail_split = 1;
     g.part = nullptr;
-    g.stagger = 0;
     g.order = g.tiles_n <= 16 ? 1 : 0;
     const int nslots = (g.N + 95) / 96;
     if (nslots > SSQ_LD) g.ssq_out = nullptr;
@@ -277,7 +269,7 @@ bool n192_pays(const GemmArgs &g) {
     const long tm = (g.M + 255) / 256;
     const long t256 = tm * ((g.N + 255) / 256);
     const long r256 = (t256 + 255) / 256, r192 = (tm * ((g.N + 191) / 192) + 255) / 256;
-    static const double rel = std::getenv("MI_N192_COST") ? std::atof(std::getenv("MI_N192_COST")) : 0.8;
+    constexpr double rel = 0.8;
     // a short last round of 256-column tiles is split along K by launch_slab (nearly free): measured at 11 290 tokens
     // (270 tiles) the 256-column tiles win by 28 us per layer, at 13 205 (312 tiles) the 192-column ones by 66
     if (r256 >= 2 && t256 % 256 != 0 && t256 % 256 <= 48) return false;
@@ -325,37 +317,19 @@ void launch_skinny_e(GemmArgs g, int wpb, hipStream_t st) {
     MI_HIP(hipGetLastError());
 }
 void launch_skinny(int epi, GemmArgs g, hipStream_t st) {
-    static const int wpb_env = std::getenv("MI_SKINNY_WPB") ? atoi(std::getenv("MI_SKINNY_WPB")) : 0;
     switch (epi) {
-        case EPI_STORE: launch_skinny_e<EPI_STORE, 1>(g, wpb_env ? wpb_env : 2, st); break;
-        case EPI_RESID: launch_skinny_e<EPI_RESID, 1>(g, wpb_env ? wpb_env : 2, st); break;
-        case EPI_QKV: launch_skinny_e<EPI_QKV, 1>(g, wpb_env ? wpb_env : 2, st); break;
-        case EPI_SWIGLU: launch_skinny_e<EPI_SWIGLU, 2>(g, wpb_env ? wpb_env : 4, st); break;
+        case EPI_STORE: launch_skinny_e<EPI_STORE, 1>(g, 2, st); break;
+        case EPI_RESID: launch_skinny_e<EPI_RESID, 1>(g, 2, st); break;
+        case EPI_QKV: launch_skinny_e<EPI_QKV, 1>(g, 2, st); break;
+        case EPI_SWIGLU: launch_skinny_e<EPI_SWIGLU, 2>(g, 4, st); break;
         default: throw Error("bad epilogue");
     }
-}
-
-template <int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
-void launch_ring32(int epi, GemmArgs g, hipStream_t st) {
-    constexpr int BM = 32 * WMT * WAVES_M, BN = 32 * WNT * WAVES_N;
-    g.tiles_m = (g.M + BM - 1) / BM;
-    g.tiles_n = (g.N + BN - 1) / BN;
-    g.ksplit = 1;
-    const int per = (g.tiles_m * g.tiles_n + 7) / 8;
-    dim3 grid(8 * per), block(64 * WAVES_M * WAVES_N);
-    switch (epi) {
-        case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_ring32_kernel<EPI_STORE, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
-        case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_ring32_kernel<EPI_RESID, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
-        case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_ring32_kernel<EPI_QKV, WMT, WNT, WAVES_M, WAVES_N, ST>), grid, block, 0, st, g); break;
-        default: throw Error("32x32 GEMM: epilogue not implemented");
-    }
-    MI_HIP(hipGetLastError());
 }
 
 // whether 192-row tiles beat 256-row tiles for this GEMM: at least a tenth fewer padded rows and no more rounds of workgroups
 // (513 .. 576 tokens: three row tiles either way, 576 rows instead of 768)
 bool m192_pays(const GemmArgs &g) {
-    const bool off = std::getenv("MI_NO_M192") != nullptr;   // (read per call: the tests switch it inside one process)
+    const bool off = knobs().no_m192;
     const long t192 = (g.M + 191) / 192, t256 = (g.M + 255) / 256, tn = (g.N + 255) / 256;
     return !off && t192 * 192 * 10 <= t256 * 256 * 9 && (t192 * tn + 255) / 256 <= (t256 * tn + 255) / 256;
 }
@@ -364,21 +338,23 @@ bool m192_pays(const GemmArgs &g) {
 bool mid_split_pays(const GemmArgs &g) {
     const int ntiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), nt64 = g.K / 64;
     const int S = std::min({16, 256 / std::max(1, ntiles), nt64 / 4});
-    static const int min_wg = std::getenv("MI_MID_MIN_WG") ? std::atoi(std::getenv("MI_MID_MIN_WG")) : 96;
+    constexpr int min_wg = 96;
     // long K only (the down projection): at K = 1536 a slice is 4 K tiles and the tile's fixed cost plus the reduction pass
     // (17.2 + 7.5 us at 576 tokens) lose to the 128-row ring tiles (20 us) -- profiles/r03_encode_nq16_kernel_stats_v1.csv
-    static const int min_k = std::getenv("MI_MID_MIN_K") ? std::atoi(std::getenv("MI_MID_MIN_K")) : 4096;
+    constexpr int min_k = 4096;
     return g.M > 64 && g.K >= min_k && S >= 2 && ntiles * S >= min_wg && (size_t)S * g.M * g.N * 4 <= g.part_bytes;
 }
 
 
 // whether launch_gemm sends this GEMM to the 256 x 256 slab kernel with whole-K tiles (the many-token path): the shapes whose
 // epilogues carry the fused RMSNorm / rotary embedding
-bool slab_whole_k(int epi, const GemmArgs &g) {
+bool slab_shape(int epi, const GemmArgs &g) {               // by the shape alone: the token count at which the 256 x 256 tiles take over
     const long tiles_big = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-    if (tiles_big < 100 || !(epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) return false;
-    // (read per call: the tests switch the knobs inside one process)
-    return !(std::getenv("MI_GEMM_TILE") || std::getenv("MI_GEMM_RING") || std::getenv("MI_GEMM_PERSIST") || std::getenv("MI_NO_BULK_FUSE"));
+    return tiles_big >= 100 && (epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0);
+}
+bool slab_whole_k(int epi, const GemmArgs &g) {
+    if (!slab_shape(epi, g)) return false;
+    return knobs().gemm_tile.empty() && !knobs().gemm_ring && !knobs().no_bulk_fuse;
 }
 
 // A few hundred tokens through the K = 1536 projections (QKV, O): 128 x 128 tiles are too few to fill the chip (80 / 60 at
@@ -388,8 +364,7 @@ bool slab_whole_k(int epi, const GemmArgs &g) {
 // residual add + the next RMSNorm (O: rmsnorm_kernel disappears).  Returns the GEMM_* flags of what the pass did; 0 with
 // nothing launched when the shape does not fit.
 int launch_mid_part(int epi, GemmArgs g, hipStream_t st) {
-    static const bool off = std::getenv("MI_NO_MID_PART") != nullptr;
-    if (off || !g.part || (epi != EPI_QKV && epi != EPI_RESID) || g.N % 8 != 0 || g.N > 4096) return 0;
+    if (!g.part || (epi != EPI_QKV && epi != EPI_RESID) || g.N % 8 != 0 || g.N > 4096) return 0;
     if (epi == EPI_QKV && !(g.rope_pos && g.rope_cos && g.rope_sin && g.rope_hd % 8 == 0 && g.qk_cols % g.rope_hd == 0)) return 0;
     if (epi == EPI_RESID && (g.ldc != g.N)) return 0;
     constexpr int BM = 128, BN = 128;
@@ -429,9 +404,9 @@ struct MidTile { int bm, bn, ns; };
 // whether launch_gemm sends this GEMM to mid_gemm_kernel.  QKV: the caller must hand over the rotary-interleaved weights and
 // the (cos, sin) table (GemmArgs::rope_cs) -- `assume_rope`: the caller is asking in order to decide whether to build them.
 bool mid_takes(int epi, const GemmArgs &g, bool assume_rope = false) {
-    const bool off = std::getenv("MI_NO_MID_GEMM") != nullptr;   // (read per call: the tests switch it inside one process)
+    const bool off = knobs().no_mid_gemm || !knobs().gemm_tile.empty();   // (a forced tile configuration is for every GEMM)
     if (off || g.M <= 64 || g.K % 64 != 0 || g.K >= 4096 || g.N % 64 != 0 || g.lda % 8 != 0 || g.ldw % 8 != 0) return false;
-    if (slab_whole_k(epi, g)) return false;                             // enough tokens for whole rounds of 256 x 256 tiles
+    if (slab_shape(epi, g)) return false;                               // enough tokens for whole rounds of 256 x 256 tiles (whatever the knobs say)
     if (epi == EPI_QKV)
         return (assume_rope || (g.rope_cs && g.rope_pos)) && g.qk_cols % 64 == 0 && g.rope_hd % 4 == 0 && g.qk_cols % std::max(g.rope_hd, 1) == 0 &&
                g.ldc % 4 == 0 && g.M % 4 == 0;
@@ -445,12 +420,12 @@ MidTile mid_pick_tile(const GemmArgs &g, int qk_cols) {
     // slabs of a 96 x 64 tile were 60 KB = ~45 GB/s, 14 us for the QKV projection of 576 tokens) -- one workgroup per CU with
     // most of the CU's LDS as its ring
     static const MidTile cand[] = {{128, 128, 4}, {128, 64, 6}, {96, 64, 7}, {64, 64, 8}};
-    static const char *env = std::getenv("MI_MID_TILE");                // tools: "128x128" | "128x64" | "96x64" | "64x64"
+    const std::string &env = knobs().mid_tile;                          // tools: "128x128" | "128x64" | "96x64" | "64x64"
     MidTile best = cand[3];
     double best_cost = 1e30;
     for (const MidTile &c : cand) {
         if (qk_cols % c.bn != 0 || g.N % c.bn != 0) continue;
-        if (env && std::string(env) != std::to_string(c.bm) + "x" + std::to_string(c.bn)) continue;
+        if (!env.empty() && env != std::to_string(c.bm) + "x" + std::to_string(c.bn)) continue;
         const long n = (long)((g.M + c.bm - 1) / c.bm) * (g.N / c.bn);
         const double cost = (double)((n + 255) / 256) * ((double)(c.bm + c.bn) * g.K * 2.0 / 75e3 + 1.0);
         if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
@@ -484,7 +459,8 @@ int launch_mid(int epi, GemmArgs g, hipStream_t st) {
     } else {
         const int nslots = g.N / t.bn;
         if (!(g.ssq_out && g.norm_w && g.norm_y && nslots <= SSQ_LD)) g.ssq_out = nullptr;
-        if (g.ssq_out) { flags = GEMM_RAWNORM | nslots << 8; ++g_fused_norm_launches; }
+        if (!(g.ssq_out && g.arrive)) g.rms_out = nullptr;
+        if (g.ssq_out) { flags = GEMM_RAWNORM | (g.rms_out ? GEMM_RMS_DONE : 0) | nslots << 8; ++g_fused_norm_launches; }
     }
     g.part = nullptr;
 #define MI_MID_CASE(BM_, BN_, NS_)                                                                              \
@@ -504,8 +480,8 @@ int launch_gemm(int epi, GemmArgs g, hipStream_t st) {
     MI_REQUIRE(g.K % 64 == 0, "encoder GEMM: K must be a multiple of 64");
     MI_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "encoder GEMM: leading dimensions must be multiples of 8");
     MI_REQUIRE(g.N % 4 == 0 && g.ldc % 4 == 0, "encoder GEMM: N and ldc must be multiples of 4");
-    const char *force = std::getenv("MI_GEMM_TILE");  // tuning knob: big | mid | small | tiny | 128 (legacy kernel)
-    const bool legacy = force && std::string(force) == "128";
+    const bool force = !knobs().gemm_tile.empty();    // tuning knob: big | mid | small | tiny | 128 (legacy kernel)
+    const bool legacy = knobs().gemm_tile == "128";
     if (!legacy) {
         // tile by how many workgroups the problem yields (256 CUs to fill):
         //   big   256x256 (8 waves)  needs >= ~100 tiles to pay off
@@ -514,31 +490,28 @@ int launch_gemm(int epi, GemmArgs g, hipStream_t st) {
         //   tiny  32x64 + split-K on the residual GEMMs: a handful of tokens (one query)
         const long tiles_big = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
         const long tiles_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-        std::string cfg = force ? std::string(force) : "";
+        std::string cfg = knobs().gemm_tile;
         if (cfg.empty()) cfg = g.M <= 64 ? "tiny" : tiles_big >= 100 ? "big" : tiles_mid >= 150 ? "mid" : "small";
         g.ksplit = 1;
-        if (!force && mid_takes(epi, g)) return launch_mid(epi, g, st);
+        if (mid_takes(epi, g)) return launch_mid(epi, g, st);
         // the fused RMSNorm / rotary epilogues live in the whole-K slab kernel only: a consumer that asks for them anywhere
         // else is a caller's error (its A operand is not normalised); a producer's request is just dropped
         MI_REQUIRE((!g.row_scale && !g.rope_cs) || (slab_whole_k(epi, g) && (epi == EPI_QKV || epi == EPI_SWIGLU)),
                    "encoder GEMM: fused RMSNorm / rotary epilogue requested on a shape the slab kernel does not take");
         if (!(epi == EPI_RESID && slab_whole_k(epi, g) && g.norm_w && g.norm_y && g.N % 64 == 0 && g.N <= 64 * SSQ_LD && g.ldc == g.N && !g.bias))
             g.ssq_out = nullptr;
-        const bool split_k = !force && epi == EPI_RESID && g.part && g.N % 8 == 0 && mid_split_pays(g) && !std::getenv("MI_NO_SPLITK");
+        const bool split_k = !force && epi == EPI_RESID && g.part && g.N % 8 == 0 && mid_split_pays(g);
         if (!force && cfg == "small" && g.M > 64 && g.K < 4096 && g.part) {
             const int fl = launch_mid_part(epi, g, st);
             if (fl) return fl & 0xff;
         }
         if (!split_k) g.part = nullptr;
-        if (cfg != "tiny" || std::getenv("MI_NO_TILED_W")) g.Wt = nullptr;   // only the few-token path streams fragment-major weights
+        if (cfg != "tiny") g.Wt = nullptr;   // only the few-token path streams fragment-major weights
         const bool skinny_ok = g.Wt && g.M <= 32 && g.N % 16 == 0 && (g.K <= SKINNY_KS_MAX || (epi == EPI_RESID && !g.bias));
         // measured per launch for one query: gate/up 14.5 vs 17.3 us (ring tiles), but QKV 10.7 vs 8.1
-        // and the residual GEMMs 13.0 vs 10.2 -- so only the SwiGLU GEMM takes it (MI_SKINNY=all/none)
-        static const std::string skinny_env = std::getenv("MI_SKINNY") ? std::getenv("MI_SKINNY") : "";
-        if (skinny_ok && cfg == "tiny" && skinny_env != "none" && (epi == EPI_SWIGLU || skinny_env == "all")) {
+        // and the residual GEMMs 13.0 vs 10.2 -- so only the SwiGLU GEMM takes it
+        if (skinny_ok && cfg == "tiny" && epi == EPI_SWIGLU) {
             launch_skinny(epi, g, st);
-        } else if (cfg == "big32" && epi != EPI_SWIGLU) {
-            launch_ring32<4, 2, 2, 4, 4>(epi, g, st);   // 256x256 on the 32x32x16 MFMA shape (experimental)
         } else if ((cfg == "slab8" || cfg == "slab4") && !(epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {
             launch_ring<8, 4, 2, 4, 4>(epi, g, st);          // the slab kernel stores 8 bf16 columns per lane
         } else if (cfg == "slab8") {
@@ -553,19 +526,19 @@ int launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             // pass, where 128x128 tiles with K split three ways by f32 atomics took 76 us; at 1558 / 2097 tokens the forward
             // pass went 7.91 -> 6.46 / 9.21 -> 7.82 ms against the 128x128 ring tiles
             return m192_pays(g) ? launch_slab<2, 6>(epi, g, st) : launch_slab<2>(epi, g, st);
-        } else if (cfg == "big" && !force && epi == EPI_RESID && n192_pays(g) && !std::getenv("MI_NO_N192")) {
+        } else if (cfg == "big" && !force && epi == EPI_RESID && n192_pays(g)) {
             return launch_slab_n192(g, st);
-        } else if (cfg == "big" && !std::getenv("MI_GEMM_RING") && (epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {   // the slab kernel stores 8 bf16 columns per lane
+        } else if (cfg == "big" && !knobs().gemm_ring && (epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {   // the slab kernel stores 8 bf16 columns per lane
             // measured (tools/gemm_bench.py, 32768 tokens): 8 waves 1051 / 1060 TF on QKV / O, 4 waves 1106 / 1303 on
             // gate-up / down (ring kernel: 968 / 952 / 1006 / 1166)
             if ((epi == EPI_SWIGLU || (epi == EPI_RESID && g.K >= 4096)) && !force && m192_pays(g)) return launch_slab<2, 6>(epi, g, st);
             if (epi == EPI_SWIGLU || g.K >= 4096) return launch_slab<2>(epi, g, st);
             return launch_slab<4>(epi, g, st);
-        } else if (cfg == "big" || cfg == "big32") {
+        } else if (cfg == "big") {
             launch_ring<8, 4, 2, 4, 4>(epi, g, st);
         } else if (cfg == "mid") {
             launch_ring<4, 4, 2, 2, 4>(epi, g, st);
-        } else if (cfg == "mid64" || (cfg == "small" && !force && epi != EPI_SWIGLU && g.M > 256 && g.K < 4096 && !std::getenv("MI_NO_MID64"))) {
+        } else if (cfg == "mid64" || (cfg == "small" && !force && epi != EPI_SWIGLU && g.M > 256 && g.K < 4096)) {
             // a few hundred to ~1500 tokens through the QKV / O projections: 128x64 tiles, 4 waves of 64x32 -- 3 DMA pieces per
             // wave per K step where the 128x32 / 2-wave tiles issue 5 (they are DMA-issue-bound): QKV 16.0 -> 13.5 us at 576
             // tokens, 35.8 -> 24.6 at 1152; O 21.8 -> 14.8 at 1152 (profiles/r03_gemm_mid_bench_v2.txt)
@@ -643,7 +616,7 @@ struct mi_encoder {
     };
     struct WS {
         std::mutex mu;
-        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_up, ws_out, ws_stage, ws_part, ws_ssq, few_ctr;
+        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_up, ws_out, ws_stage, ws_part, ws_ssq, ws_arrive, few_ctr;
         Pinned pin[3];
         int pin_next = 0;
         size_t vt_zeroed = 0, att_zeroed = 0;
@@ -818,7 +791,7 @@ Batch prepare_batch(mi_encoder *h, mi_encoder::WS &ws, int nseq, const int32_t *
 // profile launch (MI_GEMM_TS=1): in-kernel s_memtime stamps of every workgroup's phases (256x256 tiles), mean / max to stderr
 void stamped_launch(int epi, GemmArgs g, hipStream_t stream) {
     const int M = g.M, N = g.N, K = g.K;
-    const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nb = 8 * ((tiles + 7) / 8) * 2;   // (tail-split launches have more workgroups than tiles)
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nb = std::max(1024, 8 * ((tiles + 7) / 8) * 2);   // (tail-split / all-tiles-split launches have more workgroups than tiles)
     DevBuf tsb;
     unsigned long long *dts = tsb.as<unsigned long long>((size_t)nb * 8);
     MI_HIP(hipMemsetAsync(dts, 0, (size_t)nb * 64, stream));
@@ -854,9 +827,9 @@ void stamped_launch(int epi, GemmArgs g, hipStream_t stream) {
 }
 
 int timed_gemm(mi_encoder *h, int epi, const GemmArgs &g, hipStream_t st) {
-    static const bool enc_ts = std::getenv("MI_ENC_TS") != nullptr;      // stamps of the first layer's four GEMMs, in place
+    const int enc_ts = knobs().enc_ts;                                   // stamps of the first layer's four GEMMs, in place
     static std::atomic<int> ts_left{4};
-    if (enc_ts && g.M > 4096 && ts_left.fetch_sub(1) > 0) stamped_launch(epi, g, st);
+    if (enc_ts > 0 && g.M > (enc_ts == 1 ? 4096 : enc_ts) && ts_left.fetch_sub(1) > 0) stamped_launch(epi, g, st);
     const int normed = launch_gemm(epi, g, st);
     if (!h->prof) return normed;
     std::lock_guard<std::mutex> hl(h->mu);
@@ -875,12 +848,11 @@ void launch_attention(mi_encoder *h, const Batch &b, const bf16_t *qk, const bf1
     a.seq_start = b.seq_start; a.seq_len = b.seq_len; a.ldqk = h->qk_cols; a.ldvt = ldvt;
     a.n_heads = c.n_heads; a.n_kv = c.n_kv_heads; a.causal = c.causal;
     a.scale = 1.0f / std::sqrt((float)hd);
-    // two query heads of one K/V head per workgroup when the GQA group allows it (MI_ATTN_HPW=1: one head per workgroup)
-    static const bool hpw1 = std::getenv("MI_ATTN_HPW") && std::atoi(std::getenv("MI_ATTN_HPW")) == 1;
-    const bool pair = !hpw1 && c.n_heads % 2 == 0 && (c.n_heads / c.n_kv_heads) % 2 == 0;
+    // two query heads of one K/V head per workgroup when the GQA group allows it
+    const bool pair = c.n_heads % 2 == 0 && (c.n_heads / c.n_kv_heads) % 2 == 0;
     a.nwork = b.nwork;
     // persistent workgroups: two per CU (64 KiB of LDS each at head dim 128 x 2 heads), or one per item when there are fewer
-    static const int wgs_cu = std::getenv("MI_ATTN_WGS_PER_CU") ? std::max(1, std::atoi(std::getenv("MI_ATTN_WGS_PER_CU"))) : 2;
+    constexpr int wgs_cu = 2;
     const int hpw = pair ? 2 : 1;
     const unsigned nwg = (unsigned)std::min<long>((long)b.nwork * (c.n_heads / hpw), 256L * wgs_cu);
     if (hd == 128 && pair) hipLaunchKernelGGL((attn_kernel<128, 2>), dim3(nwg), dim3(512), 0, st, a);
@@ -894,7 +866,7 @@ void launch_attention(mi_encoder *h, const Batch &b, const bf16_t *qk, const bf1
 // The query-time path (encoder_few.h): T <= 48 tokens, six launches per layer, no atomics.
 // ---------------------------------------------------------------------------------------------------------------
 bool few_eligible(const mi_encoder *h, const Batch &b) {
-    static const bool off = std::getenv("MI_NO_FEW") != nullptr;
+    const bool off = knobs().no_few;
     const mi_encoder_cfg &c = h->cfg;
     const int mt = (b.T_real + 15) / 16;
     return !off && b.T_real <= FEW_MAX_T && c.hidden % 32 == 0 && c.hidden <= 4096 && c.intermediate % 32 == 0 && h->q_cols % 32 == 0 &&
@@ -955,7 +927,7 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
     d0.nk = I / 32; d0.nunits = H / 16;
     const int ugroups = (d0.nunits + 3) / 4;
     {
-        static const int d_wgs = std::getenv("MI_FEW_D_WGS") ? std::atoi(std::getenv("MI_FEW_D_WGS")) : 248;   // workgroups the down projection aims at
+        constexpr int d_wgs = 248;                           // workgroups the down projection aims at
         const int ns = std::max(1, std::min(d0.nk, (d_wgs + ugroups / 2) / ugroups));
         d0.ks_per_slice = (d0.nk + ns - 1) / ns;
         while ((size_t)d0.ks_per_slice * MT * 1024 > 128 * 1024) d0.ks_per_slice = (d0.ks_per_slice + 1) / 2;
@@ -967,16 +939,16 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
     // OFF by default: 13.2 us against 7.7 + 4.8 for the two launches (one query 1.265 vs 1.211 ms) -- the 8-byte
     // write-through stores and the 80 KB the last arriver reads back past its L1 cost more than a kernel boundary, as the
     // guide's splitk-seam row prices it.  Kept as the parity-tested alternative (tests run both).
-    const bool fuse_env = std::getenv("MI_FEW_D_FUSE") != nullptr;   // (read per call: tests toggle it)
+    const bool fuse_env = knobs().few_d_fuse;
     const bool fuse_d = fuse_env && ugroups <= FEW_SSQ_LD * 3 && d0.nslices * d0.ks_per_slice >= d0.nk;
     if (ws.few_ctr.cap < (size_t)ugroups * 4) {
         MI_HIP(hipMemsetAsync(ws.few_ctr.reserve((size_t)ugroups * 4 + 1024), 0, (size_t)ugroups * 4 + 1024, st));
     }
     unsigned *ctr = ws.few_ctr.get<unsigned>();
     // MI_FEW_SYNC=1 (debugging): wait after every launch and name the stage on stderr
-    static const bool dbg_sync = std::getenv("MI_FEW_SYNC") != nullptr;
+    const bool dbg_sync = knobs().few_sync;
     // MI_FEW_TS=1 (profiling): s_memtime stamps of every workgroup of the first layer's two fragment GEMMs, mean / max per phase
-    static const bool dbg_ts = std::getenv("MI_FEW_TS") != nullptr;
+    const bool dbg_ts = knobs().few_ts;
     DevBuf tsb;
     auto stamps = [&](const char *name, int nwg) {
         std::vector<unsigned long long> hts((size_t)nwg * 8);
@@ -1021,8 +993,7 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         hipLaunchKernelGGL((few_gemm_kernel<FEW_QKV, MT>), dim3((unsigned)gemm_grid(q.nunits)), dim3(64 * FEW_NW), gemm_smem(q.nk, 1), st, q);
         if (q.ts) stamps("qkv", gemm_grid(q.nunits));
         chk("qkv");
-        static const bool old_attn = std::getenv("MI_FEW_ATTN_OLD") != nullptr;
-        if (old_attn || b.Lmax > FEW_MAX_T || (c.head_dim != 64 && c.head_dim != 128)) {
+        if (b.Lmax > FEW_MAX_T || (c.head_dim != 64 && c.head_dim != 128)) {
             launch_attention(h, b, qk, vt, nullptr, ldvt, st, afrag, MT);
         } else {
             AttnArgs aa{};
@@ -1154,12 +1125,20 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
     // (H < 4096: launch_gemm gives the QKV projection the 8-wave slab kernel, whose waves own 64 columns = 32 rotary pairs)
     probe.qk_cols = h->qk_cols; probe.rope_hd = hd; probe.lda = probe.ldw = H; probe.ldc = h->qk_cols;
     const bool qkv_mid = mid_takes(EPI_QKV, probe, true);   // a few hundred .. few thousand tokens: encoder_mid.h, RoPE in its epilogue
-    const bool rope_fused = (qkv_slab && H < 4096 && h->qk_cols % 256 == 0 && h->v_cols % 256 == 0 && !std::getenv("MI_NO_ROPE_FUSE")) || qkv_mid;
-    const bool norm1_fused = qkv_slab && !std::getenv("MI_NO_NORM_FUSE");
+    const bool rope_fused = (qkv_slab && H < 4096 && h->qk_cols % 256 == 0 && h->v_cols % 256 == 0 && !knobs().no_rope_fuse) || qkv_mid;
+    const bool norm1_fused = qkv_slab && !knobs().no_norm_fuse;
     probe.N = 2 * I; probe.ldc = I;
-    const bool norm2_fused = slab_whole_k(EPI_SWIGLU, probe) && !std::getenv("MI_NO_NORM_FUSE");
+    const bool norm2_fused = slab_whole_k(EPI_SWIGLU, probe) && !knobs().no_norm_fuse;
     float *ssq = (norm1_fused || norm2_fused) ? ws.ws_ssq.as<float>((size_t)T * (SSQ_LD + 1)) : nullptr;
     float *inv_rms = ssq ? ssq + (size_t)T * SSQ_LD : nullptr;
+    // encoder_mid.h's O projection finishes the RMSNorm itself: one arrival counter per row block (zeroed once: the kernel
+    // leaves them at zero)
+    unsigned *arrive = nullptr;
+    if (norm2_fused) {
+        constexpr size_t NCTR = 4096;
+        if (ws.ws_arrive.cap < NCTR * 4) MI_HIP(hipMemsetAsync(ws.ws_arrive.reserve(NCTR * 4), 0, NCTR * 4, st));
+        arrive = ws.ws_arrive.get<unsigned>();
+    }
     auto row_rms = [&](int nslots) -> const float * {       // the slots a residual epilogue left -> 1/rms per row
         hipLaunchKernelGGL(row_rms_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, ssq, nslots, T, H, c.rms_eps, inv_rms);
         MI_HIP(hipGetLastError());
@@ -1187,7 +1166,7 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
     }
     Range stack_range("mi_encoder:stack");
     int normed = 0;                                  // what the previous residual GEMM left of this layer's first RMSNorm
-    if (H <= 2048 && H % 4 == 0 && !std::getenv("MI_NO_EMBED_NORM")) {   // the first layer's RMSNorm rides in the embedding gather
+    if (H <= 2048 && H % 4 == 0) {   // the first layer's RMSNorm rides in the embedding gather
         hipLaunchKernelGGL(embed_norm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, b.ids, h->embed.get<bf16_t>(), H, T, x,
                            h->layers[0].ln1.get<float>(), c.rms_eps, xn);
         normed = GEMM_NORMED;
@@ -1222,7 +1201,7 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
         o.X = x; o.ldc = H; o.part = part; o.part_bytes = part_bytes;
         if (few) o.Wt = w.wo_t.get<bf16_t>();
         o.norm_w = w.ln2.get<float>(); o.norm_y = xn; o.norm_eps = c.rms_eps;   // (rides in a split-K reduction pass when there is one,
-        if (norm2_fused) o.ssq_out = ssq;                                        //  or in the slab epilogue: unscaled row + sums of squares)
+        if (norm2_fused) { o.ssq_out = ssq; o.rms_out = inv_rms; o.arrive = arrive; }   //  or in the slab / mid epilogue: unscaled row + sums of squares)
         const int on = timed_gemm(h, EPI_RESID, o, st);
         if (!(on & (GEMM_NORMED | GEMM_RAWNORM)))
             hipLaunchKernelGGL(rmsnorm_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, w.ln2.get<float>(), H, T,
@@ -1230,7 +1209,7 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
         GemmArgs u{};
         u.A = xn; u.lda = H; u.W = w.wgu.get<bf16_t>(); u.ldw = H; u.M = T; u.N = 2 * I; u.K = H; u.C = hb; u.ldc = I;
         if (few) u.Wt = w.wgu_t.get<bf16_t>();
-        if (on & GEMM_RAWNORM) u.row_scale = row_rms(on >> 8);
+        if (on & GEMM_RAWNORM) u.row_scale = (on & GEMM_RMS_DONE) ? inv_rms : row_rms(on >> 8);
         timed_gemm(h, EPI_SWIGLU, u, st);
         GemmArgs d{};
         d.A = hb; d.lda = I; d.W = w.wd.get<bf16_t>(); d.ldw = I; d.M = T; d.N = H; d.K = I; d.X = x; d.ldc = H;
@@ -1419,8 +1398,7 @@ void encode_impl(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu,
         Range pool_range("mi_encoder:pool+dense+normalise");
         const mi_encoder_cfg &c = h->cfg;
         const int od = c.dense_out ? c.dense_out : c.hidden;
-        static const bool few_pool_off = std::getenv("MI_NO_FEW_POOL") != nullptr;
-        if (few_mt && c.dense_out && c.hidden <= 2048 && od_dev && !few_pool_off) {
+        if (few_mt && c.dense_out && c.hidden <= 2048 && od_dev) {
             // the query-time tail: pooling from the final-norm fragments + Dense, then normalise + place the row (two launches)
             float *raw = ws.ws_out.as<float>((size_t)nseq * od);
             FewPoolArgs p{};
@@ -1456,7 +1434,7 @@ void encode_impl(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu,
         // output (= A W^T + bias) -- and the row normalisation.  (A workgroup per sequence doing all of that is a
         // chain of dependent row reads plus a private pass over the 3 MB Dense matrix: 0.70 ms per 128-abstract batch.)
         // MI_POOL_GEMM=0: the per-sequence kernel for every batch size.
-        const bool pool_gemm_off = std::getenv("MI_POOL_GEMM") && std::atoi(std::getenv("MI_POOL_GEMM")) == 0;
+        const bool pool_gemm_off = knobs().pool_gemm == 0;
         if (c.dense_out && nseq >= 64 && !pool_gemm_off && c.hidden % 64 == 0 && od % 4 == 0) {
             const int H = c.hidden, T = b.T_pad;
             bf16_t *xn = ws.ws_xn.as<bf16_t>((size_t)T * H);
@@ -1479,7 +1457,7 @@ void encode_impl(mi_encoder *h, int nseq, const int32_t *ids, const int32_t *cu,
             return;
         }
         // few sequences: split the Dense rows of each over several workgroups (256 CUs to fill)
-        static const int rows_per_part = std::getenv("MI_POOL_ROWS") ? std::max(16, std::atoi(std::getenv("MI_POOL_ROWS"))) : 16;
+        constexpr int rows_per_part = 16;
         p.parts = c.dense_out ? std::max(1, std::min(od / rows_per_part, 256 / std::max(1, nseq))) : 1;
         hipLaunchKernelGGL(pool_kernel, dim3(nseq, p.parts), dim3(256), smem, st, p);
         MI_HIP(hipGetLastError());
@@ -1600,6 +1578,10 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
     });
 }
 
+int mi_encoder_reload_env(void) {
+    return guard([&] { knobs_mut().load(); });
+}
+
 int mi_enc_gemm_bf16(int device, int M, int N, int K, const void *A, const void *W, void *C, void *stream) {
     return guard([&] {
         MI_REQUIRE(A && W && C, "null argument");
@@ -1608,7 +1590,7 @@ int mi_enc_gemm_bf16(int device, int M, int N, int K, const void *A, const void 
         GemmArgs g{};
         g.A = static_cast<const bf16_t *>(A); g.lda = K; g.W = static_cast<const bf16_t *>(W); g.ldw = K;
         g.M = M; g.N = N; g.K = K; g.C = static_cast<bf16_t *>(C); g.ldc = N;
-        if (std::getenv("MI_GEMM_TS")) {
+        if (knobs().gemm_ts) {
             stamped_launch(EPI_STORE, g, as_stream(stream));
             return;
         }

@@ -292,7 +292,6 @@ struct GemmArgs {
     const float *norm_w;
     bf16_t *norm_y;
     float norm_eps;
-    int stagger;       // slab kernel: the first round's workgroups start up to stagger x 1024 cycles apart (0 = together)
     // host side only (EPI_QKV): what the reduction pass of a K-split QKV projection needs to finish the epilogue
     // (splitk_reduce_qkv_kernel: RoPE in the same pass) -- null pos: the caller runs rope_kernel itself
     const int32_t *rope_pos;
@@ -310,6 +309,8 @@ struct GemmArgs {
     //     lane's 4 consecutive columns hold two whole pairs; rope_cs[pos][f] = (cos, sin).  Q and K leave in the interleaved
     //     order -- the attention scores are dot products over the head, indifferent to a permutation applied to both.
     float *ssq_out;
+    float *rms_out;        // encoder_mid.h, residual epilogue with ssq_out: the last tile of a row block to arrive writes 1/rms of
+    unsigned *arrive;      // the block's rows here (arrive[row block] counts the tiles; zero before and after a launch)
     const float *row_scale;
     const float2 *rope_cs;
 };
@@ -752,21 +753,6 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
                 }
             }
     };
-    // Issue order of a steady-state step (MI_GEMM_SCHED builds only, experiment): the MFMAs
-    // first, the fragment reads of the next tile spread between them -- both waves of a SIMD
-    // leave the barrier together, and a block of 12 ds_read_b128 in front of the MFMAs
-    // would leave the matrix pipe idle while both issue it.
-    auto interleave = [&] {
-#ifdef MI_GEMM_SCHED
-        constexpr int NR = WMT + WNT, NM = WMT * WNT, PER = NM / NR;
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * NR, 0);
-#endif
-    };
     // tile `next` must have landed in every wave's view before it is read: own DMA
     // pieces by counted vmcnt (up to D-2 later tiles stay in flight), the other
     // waves' pieces by the barrier; lgkmcnt(0) first so that no ds_read of the stage
@@ -802,13 +788,11 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
         read_frags(t + 1, a1, b1);
         issue(t + D);
         mma(a0, b0);
-        interleave();
         wait_vm_lgkm0<(D - 2) * PPW>();
         __builtin_amdgcn_s_barrier();
         read_frags(t + 2, a0, b0);
         issue(t + D + 1);
         mma(a1, b1);
-        interleave();
     }
     for (; t < nk; t += 2) {  // tail: same schedule with guards
         if (t + 1 < nk) {
@@ -925,22 +909,6 @@ __device__ __forceinline__ void dma16_off(const void *gptr, unsigned lds_off) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n" ::"s"(lds_off), "v"(gptr) : "memory");
 }
 
-// The same piece addressed through a buffer resource: one 32-bit VGPR offset per lane + a scalar offset (the K position),
-// the base and the extent in four SGPRs.  Rows past the end of the matrix read zeros (range-checked on the VGPR offset).
-typedef int __attribute__((ext_vector_type(4))) i32x4;
-__device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
-    const unsigned long long a = (unsigned long long)base;
-    i32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));   // stride 0: a raw buffer
-    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-    r[3] = 0x00020000;
-    return r;
-}
-__device__ __forceinline__ void dma16_buf(const i32x4 &srd, unsigned voff, unsigned soff, unsigned lds_off) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n" ::"s"(lds_off), "v"(voff), "s"(srd), "s"(soff) : "memory");
-}
-
 // Which W row feeds position p of a wave's MFMA tile j is free -- it only decides which output column a lane ends
 // up holding.  PERM 0: tile j = W rows 16 j + p (a lane holds 4 consecutive columns of tile j).  bf16 outputs
 // choose rows so that a lane's values of two tiles are 8 CONSECUTIVE output columns: one 16-byte store, 64-byte
@@ -1035,31 +1003,6 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     const int prow = lane >> 3, scol = ((lane & 7) ^ prow) * 8;
     const int scolW[2] = {((lane & 7) ^ (prow & 3)) * 8, ((lane & 7) ^ ((prow & 3) | 4)) * 8};   // even / odd piece (bit 3 of the row)
     const unsigned dma_dst = lds0 + (unsigned)w * PPW * 1024u;       // + slot * SLAB_B + p * 1024
-#ifdef MI_DMA_BUFFER
-    // buffer-addressed pieces (the launcher guarantees M * lda and N * ldw < 2^31 elements): byte offset of this lane's
-    // 16 bytes of piece p inside A / W at K column 0; the K position is the scalar offset
-    const i32x4 srdA = make_srd(g.A, (unsigned)((size_t)g.M * g.lda * 2)), srdW = make_srd(g.W, (unsigned)((size_t)g.N * g.ldw * 2));
-    unsigned voA[PPW], voW[PPW];
-    unsigned so0 = 0;                                        // byte offset of the unit's first K column
-    auto set_sources = [&](int tm_, int tn_, int kt0_) {
-#pragma unroll
-        for (int p = 0; p < PPW; ++p) {
-            const int r = (w * PPW + p) * 8 + prow;
-            voA[p] = ((unsigned)(tm_ * BM + r) * (unsigned)g.lda + (unsigned)scol) * 2u;
-            voW[p] = ((unsigned)(tn_ * BN + r) * (unsigned)g.ldw + (unsigned)scolW[p & 1]) * 2u;
-        }
-        so0 = (unsigned)kt0_ * 128u;
-    };
-    auto request_first = [&](int nk_) {                      // slabs 0 .. DQ-1 into ring slots 0 .. DQ-1
-#pragma unroll
-        for (int q = 0; q < DQ; ++q)
-            if (q < nk_) {
-#pragma unroll
-                for (int p = 0; p < PPW; ++p)
-                    dma16_buf((q & 1) ? srdW : srdA, (q & 1) ? voW[p] : voA[p], so0 + (unsigned)(q >> 1) * 128u, dma_dst + q * SLAB_B + p * 1024u);
-            }
-    };
-#else
     const bf16_t *srcA[PPW], *srcW[PPW];
     auto set_sources = [&](int tm_, int tn_, int kt0_) {
 #pragma unroll
@@ -1078,7 +1021,6 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     dma16_off(((q & 1) ? srcW[p] : srcA[p]) + (size_t)(q >> 1) * 64, dma_dst + q * SLAB_B + p * 1024u);
             }
     };
-#endif
 
     // fragment (16 rows x 32 k) of K half kk: lane (li, lg) reads row li, global slot 4 kk + lg -> LDS slot ^ (row & 7)
     const unsigned rdA = lds0 + (unsigned)(wm * (WMT * 16) + li) * 128u + (unsigned)((lg ^ (li & 7)) * 16);   // kk = 1: ^ 64
@@ -1106,17 +1048,9 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
         // slab u + DQ: DQ even -> an A slab in even steps, a W slab in odd steps; tile (u + DQ) >> 1
         const unsigned sd = wrap(c + par + DQ);
         const bool dma_on = decltype(STEADY)::value || u + DQ < nk;
-#ifdef MI_DMA_BUFFER
-        const unsigned soff = so0 + (unsigned)((u + DQ) >> 1) * 128u;
-#else
         const size_t koff = (size_t)((u + DQ) >> 1) * 64;
-#endif
         static_for<NMF>([&](auto M_) {
-#ifdef MI_MFMA_JOUTER   // experiment: hold the W fragment (the MFMA's first source under SWAP) across WMT consecutive MFMAs instead of the A fragment
-            constexpr int m = decltype(M_)::value, i = m % WMT, j = m / WMT;
-#else
             constexpr int m = decltype(M_)::value, i = m / WNT, j = m % WNT;
-#endif
             mfma(acc[i][j], ac[i], bc[j]);
             if constexpr (m % RSTEP == RSTEP - 1 && m / RSTEP < NRD) {
                 constexpr int r = m / RSTEP;                          // first the W fragments, then the A fragments
@@ -1125,11 +1059,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
             }
             if constexpr (m % DSTEP == DSTEP - 1) {
                 constexpr int p = m / DSTEP;
-#ifdef MI_DMA_BUFFER
-                if (dma_on) dma16_buf(par == 0 ? srdA : srdW, par == 0 ? voA[p] : voW[p], soff, dma_dst + sd * SLAB_B + p * 1024u);
-#else
                 if (dma_on) dma16_off((par == 0 ? srcA[p] : srcW[p]) + koff, dma_dst + sd * SLAB_B + p * 1024u);
-#endif
             }
         });
     };
@@ -1152,14 +1082,6 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                                            ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);   // HW_REG_XCC_ID
     }
     if (!decode(unit, tm, tn, ksplit, kt0, nk)) return;
-    if (g.stagger > 0 && blockIdx.x < 256u) {
-        // De-synchronise the CUs: the workgroups of a round otherwise leave their K loops together and their epilogues hit
-        // the memory system as one burst (a residual epilogue reads and writes 512 KiB per tile: 128 MiB at once, ~45 000
-        // cycles where a lone tile takes ~10 000).  The first round's workgroups start 0 .. stagger x 1024 cycles apart, in
-        // dispatch order; later workgroups inherit the phase of the CU they land on.
-        const int q = (int)(blockIdx.x * (unsigned)g.stagger) >> 8;
-        for (int i = 0; i < q; ++i) __builtin_amdgcn_s_sleep(16);
-    }
     set_sources(tm, tn, kt0);
     request_first(nk);
     // fused RMSNorm (consumer side) / rotary positions: lane l keeps the scale (position) of rows l and 64 + l of the wave's
@@ -1801,141 +1723,6 @@ __global__ void __launch_bounds__(256) gemm_bf16_skinny_kernel(GemmArgs g, int k
             }
         }
     }
-}
-
-// ---------------------------------------------------------------------
-// Same ring pipeline on v_mfma_f32_32x32x16_bf16 (half the MFMA issue slots per
-// FLOP; microbenchmark ceiling 2.38 vs 2.08 PFLOP/s for the 16x16 shape).
-// Fragment maps: A lane l -> row l&31, k = 8*(l>>5)..+7 (+16 per k-step);
-// C lane l -> col l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16).
-// Experimental: EPI_STORE / EPI_RESID / EPI_QKV only (MI_GEMM_TILE=big32).
-// ---------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-template <int EPI, int WMT, int WNT, int WAVES_M, int WAVES_N, int ST>
-__global__ void __launch_bounds__(64 * WAVES_M *WAVES_N) gemm_bf16_ring32_kernel(GemmArgs g) {
-    constexpr int BM = 32 * WMT * WAVES_M, BN = 32 * WNT * WAVES_N, BK = 32;
-    constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int PA = BM / 16, PB = BN / 16;
-    static_assert((PA + PB) % NW == 0, "DMA pieces must divide evenly over the waves");
-    constexpr int PPW = (PA + PB) / NW;
-    constexpr int D = ST - 1;
-    static_assert(EPI != EPI_SWIGLU, "SwiGLU epilogue not implemented for the 32x32 shape");
-    __shared__ __attribute__((aligned(16))) bf16_t smem[ST * (BM + BN) * BK];
-
-    int tm, tn;
-    if (!tile_coords(g.tiles_m, g.tiles_n, tm, tn)) return;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w % WAVES_M, wn = w / WAVES_M;
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    const int srow = lane >> 2;
-    const int scol = ((lane & 3) ^ ((0 - (lane >> 4)) & 3)) * 8;
-    const bf16_t *src[PPW];
-    int dst[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int q = w * PPW + i;
-        if (q < PA) {
-            src[i] = g.A + (size_t)min(m0 + q * 16 + srow, g.M - 1) * g.lda + scol;
-            dst[i] = q * 16 * BK;
-        } else {
-            src[i] = g.W + (size_t)min(n0 + (q - PA) * 16 + srow, g.N - 1) * g.ldw + scol;
-            dst[i] = BM * BK + (q - PA) * 16 * BK;
-        }
-    }
-    auto issue = [&](int tile) {
-        bf16_t *base = smem + (tile & (ST - 1)) * (BM + BN) * BK;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) dma16(src[i] + tile * BK, base + dst[i]);
-    };
-
-    f32x16 acc[WMT][WNT];
-#pragma unroll
-    for (int i = 0; i < WMT; ++i)
-#pragma unroll
-        for (int j = 0; j < WNT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = g.K / BK;
-    // row = 32*tile + l31 -> (row >> 2) & 3 == (l31 >> 2) & 3; k slot = 2*kk + lh
-    const int fsw = (0 - (l31 >> 2)) & 3;
-    const int a_off = (wm * WMT * 32 + l31) * BK, b_off = BM * BK + (wn * WNT * 32 + l31) * BK;
-    bf16x8 a0[WMT][2], b0[WNT][2], a1[WMT][2], b1[WNT][2];
-    auto read_frags = [&](int tile, bf16x8(&a)[WMT][2], bf16x8(&b)[WNT][2]) {
-        const bf16_t *base = smem + (tile & (ST - 1)) * (BM + BN) * BK;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int slot = ((2 * kk + lh) ^ fsw) * 8;
-#pragma unroll
-            for (int j = 0; j < WNT; ++j) b[j][kk] = *reinterpret_cast<const bf16x8 *>(base + b_off + j * 32 * BK + slot);
-#pragma unroll
-            for (int i = 0; i < WMT; ++i) a[i][kk] = *reinterpret_cast<const bf16x8 *>(base + a_off + i * 32 * BK + slot);
-        }
-    };
-    auto mma = [&](const bf16x8(&a)[WMT][2], const bf16x8(&b)[WNT][2]) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < WMT; ++i)
-#pragma unroll
-                for (int j = 0; j < WNT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
-    };
-    auto arrive = [&](int next) {
-        wait_tiles<PPW, D - 2>(min(D - 2, nk - 1 - next), true);
-        __builtin_amdgcn_s_barrier();
-    };
-#pragma unroll
-    for (int s_ = 0; s_ < D; ++s_)
-        if (s_ < nk) issue(s_);
-    wait_tiles<PPW, D - 1>(min(D - 1, nk - 1), false);
-    __builtin_amdgcn_s_barrier();
-    read_frags(0, a0, b0);
-    int t = 0;
-    for (; t + D + 1 < nk; t += 2) {
-        wait_vm_lgkm0<(D - 2) * PPW>();
-        __builtin_amdgcn_s_barrier();
-        read_frags(t + 1, a1, b1);
-        issue(t + D);
-        mma(a0, b0);
-        wait_vm_lgkm0<(D - 2) * PPW>();
-        __builtin_amdgcn_s_barrier();
-        read_frags(t + 2, a0, b0);
-        issue(t + D + 1);
-        mma(a1, b1);
-    }
-    for (; t < nk; t += 2) {
-        if (t + 1 < nk) {
-            arrive(t + 1);
-            read_frags(t + 1, a1, b1);
-        }
-        if (t + D < nk) issue(t + D);
-        mma(a0, b0);
-        if (t + 1 < nk) {
-            if (t + 2 < nk) {
-                arrive(t + 2);
-                read_frags(t + 2, a0, b0);
-            }
-            if (t + D + 1 < nk) issue(t + D + 1);
-            mma(a1, b1);
-        }
-    }
-    // epilogue: each group of 4 accumulator registers is 4 consecutive rows of one column
-#pragma unroll
-    for (int i = 0; i < WMT; ++i)
-#pragma unroll
-        for (int j = 0; j < WNT; ++j)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                f32x4 v = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
-                const int row0 = m0 + (wm * WMT + i) * 32 + 8 * g4 + 4 * lh;
-                const int col = n0 + (wn * WNT + j) * 32 + l31;
-                store_rows4<EPI>(g, v, v, row0, col, lane);
-            }
 }
 
 // ---------------------------------------------------------------------

@@ -17,8 +17,9 @@
 //                              consecutive columns are two whole pairs) -> + bias -> RoPE -> Q|K rows; V tiles are
 //                              accumulated untransposed (a lane = 4 consecutive tokens of one channel) -> V^T
 //   mid_gemm_kernel<MID_O>     attention output x W_o -> x += ...; optionally bf16(x g2) and the tile's part of the rows'
-//                              sums of squares (slot = tile column: row_rms_kernel finishes the RMSNorm, the gate/up slab
-//                              GEMM applies it to its accumulators)
+//                              sums of squares (slot = tile column); the last tile of a row block to arrive turns the block's
+//                              slots into 1/rms (GemmArgs::rms_out / arrive: no row_rms_kernel launch) and the gate/up slab
+//                              GEMM applies it to its accumulators
 //
 // LDS: slab s of the ring = BM rows of A then BN rows of W, 128 B per row, the 16-byte slot index XORed with (row & 7) on
 // the SOURCE side (the DMA itself is lane-linear): the 16 rows a ds_read_b128 lane group touches fall on 16 distinct
@@ -227,7 +228,36 @@ __global__ void __launch_bounds__(256, (NS * (WMT + WNT) * 4096 <= 80 * 1024 ? 2
         }
         if (fuse) {
             __syncthreads();
-            if (tid < BM && m0 + tid < g.M) g.ssq_out[(size_t)tn * g.M + m0 + tid] = sred[tid] + sred[BM + tid];
+            const bool mine = tid < BM && m0 + tid < g.M;
+            if (!g.rms_out) {
+                if (mine) g.ssq_out[(size_t)tn * g.M + m0 + tid] = sred[tid] + sred[BM + tid];
+                return;
+            }
+            // The RMSNorm finished here, by the LAST tile of the row block to arrive (no row_rms_kernel launch between this
+            // projection and gate/up): the slots leave as write-through stores (device scope: past the XCD's L2) that are
+            // acknowledged before the tile counts itself in on the row block's counter; the last arriver reads the block's slots
+            // past its own L2 and adds them in slot order -- the order row_rms_kernel adds them in -- and puts the counter back
+            // to zero for the next launch.  No release / acquire fence: a device-scope release is a write-back of the XCD's
+            // whole L2 (buffer_wbl2: it made this launch 13.4 -> 22.6 us), and the only data that has to cross are these slots.
+            if (mine) __hip_atomic_store(g.ssq_out + (size_t)tn * g.M + m0 + tid, sred[tid] + sred[BM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __shared__ unsigned s_last;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) s_last = __hip_atomic_fetch_add(g.arrive + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)g.tiles_n - 1u;
+            __syncthreads();
+            if (!s_last) return;
+            if (mine) {
+                float v[SSQ_LD];                             // every load in flight before the first add (one round trip, not 24)
+#pragma unroll
+                for (int q = 0; q < SSQ_LD; ++q)
+                    v[q] = __hip_atomic_load(g.ssq_out + (size_t)min(q, g.tiles_n - 1) * g.M + m0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float ssum = 0.f;
+#pragma unroll
+                for (int q = 0; q < SSQ_LD; ++q)
+                    if (q < g.tiles_n) ssum += v[q];
+                g.rms_out[m0 + tid] = rsqrtf(ssum / (float)g.N + g.norm_eps);
+            }
+            if (tid == 0) __hip_atomic_store(g.arrive + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

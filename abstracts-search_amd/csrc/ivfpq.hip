@@ -34,6 +34,44 @@ namespace {
 hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ------------------------------------------------------------------
+// Environment knobs.  Read ONCE -- at the first call into the library, or again by mi_ivfpq_reload_env() (tests and tools:
+// not to be called beside a running search) -- into this struct: nothing on a search / add call path calls getenv, which is
+// not safe against a concurrent setenv.  Every knob here is exercised by a test or a committed tool; the dispatch rules
+// they override are the measured defaults.
+// ------------------------------------------------------------------
+struct Knobs {
+    int two_stage;        // MI_TWO_STAGE=0|1: force the two-stage coarse quantiser off / on (-1: by shape)
+    bool refine_gmax;     // MI_REFINE_GMAX=0: its second stage reads the score rows instead of the GEMM's group maxima
+    bool refine_stats;    // MI_REFINE_STATS=1: print candidates per row of the second stage (synchronises)
+    int select_big_from;  // MI_SELECT_BIG_FROM: smallest K the sort-based selection takes (65)
+    int nslice;           // MI_NSLICE: scan slices per query (0: by shape)
+    int scan_nw;          // MI_SCAN_NW=8|16: waves per scan workgroup (0: by shape)
+    bool no_allscores;    // MI_NO_ALLSCORES=1: k > 64 by one extraction pass per 64 results
+    bool no_fused_merge;  // MI_NO_FUSED_MERGE=1: cross-slice merge as its own launch
+    bool no_topk_rows;    // MI_NO_TOPK_ROWS=1: the re-rank's final top-k through the general merge
+    bool scan_ts;         // MI_SCAN_TS=1: mi_index_profile_scan prints in-kernel phase stamps
+    void load() {
+        auto num = [](const char *n, int dflt) { const char *e = std::getenv(n); return e && *e ? std::atoi(e) : dflt; };
+        auto set = [](const char *n) { return std::getenv(n) != nullptr; };
+        two_stage = num("MI_TWO_STAGE", -1);
+        refine_gmax = num("MI_REFINE_GMAX", 1) != 0;
+        refine_stats = set("MI_REFINE_STATS");
+        select_big_from = num("MI_SELECT_BIG_FROM", 65);
+        nslice = num("MI_NSLICE", 0);
+        scan_nw = num("MI_SCAN_NW", 0);
+        no_allscores = set("MI_NO_ALLSCORES");
+        no_fused_merge = set("MI_NO_FUSED_MERGE");
+        no_topk_rows = set("MI_NO_TOPK_ROWS");
+        scan_ts = set("MI_SCAN_TS");
+    }
+};
+Knobs &knobs_mut() {
+    static Knobs k = [] { Knobs x{}; x.load(); return x; }();
+    return k;
+}
+inline const Knobs &knobs() { return knobs_mut(); }
+
+// ------------------------------------------------------------------
 // kernel launch helpers
 // ------------------------------------------------------------------
 
@@ -67,22 +105,15 @@ void launch_gemm_gather(const float *A, int nq, const TB *B, int64_t nb, int d, 
 }
 
 // exact scores of kc candidate rows per query: the streaming kernel when the rows are whole
-// 128-byte pieces, else the gather mode of the score GEMM (MI_RERANK=gemm forces the latter)
+// 128-byte pieces, else the gather mode of the score GEMM
 template <typename TB>
 void launch_rerank_scores(const float *q, int nq, const TB *base, int64_t nb, int d, const int64_t *idx, int kc,
                           float *S, int64_t ldS, hipStream_t st) {
-    const char *e = std::getenv("MI_RERANK");
-    const bool force_gemm = e && std::string(e) == "gemm";
     const int tiles = (kc + 63) / 64;
-    if (!force_gemm && ((size_t)d * sizeof(TB)) % 128 == 0 && (int64_t)nq * tiles < ((int64_t)1 << 31)) {
-        int nst = 3;   // 24.5 KiB of LDS per wave: 6 waves per CU, 2 x 8 KiB each in flight (tools/gather_bench.py: 3 > 4 > 6 > 8 stages)
-        if (e && std::atoi(e) > 0) nst = std::atoi(e);
+    if (((size_t)d * sizeof(TB)) % 128 == 0 && (int64_t)nq * tiles < ((int64_t)1 << 31)) {
+        // a ring of 3 stages: 24.5 KiB of LDS per wave, 6 waves per CU, 2 x 8 KiB each in flight (3 > 4 > 6 > 8 stages measured)
         const unsigned grid = (unsigned)((int64_t)nq * tiles);
-        if (nst == 6) hipLaunchKernelGGL((rerank_rows_kernel<TB, 6>), dim3(grid), dim3(64), 0, st, q, base, nb, d, idx, kc, S, ldS, tiles);
-        else if (nst == 4) hipLaunchKernelGGL((rerank_rows_kernel<TB, 4>), dim3(grid), dim3(64), 0, st, q, base, nb, d, idx, kc, S, ldS, tiles);
-        else if (nst == 2) hipLaunchKernelGGL((rerank_rows_kernel<TB, 2>), dim3(grid), dim3(64), 0, st, q, base, nb, d, idx, kc, S, ldS, tiles);
-        else if (nst == 8) hipLaunchKernelGGL((rerank_rows_kernel<TB, 8>), dim3(grid), dim3(64), 0, st, q, base, nb, d, idx, kc, S, ldS, tiles);
-        else hipLaunchKernelGGL((rerank_rows_kernel<TB, 3>), dim3(grid), dim3(64), 0, st, q, base, nb, d, idx, kc, S, ldS, tiles);
+        hipLaunchKernelGGL((rerank_rows_kernel<TB, 3>), dim3(grid), dim3(64), 0, st, q, base, nb, d, idx, kc, S, ldS, tiles);
         MI_HIP(hipGetLastError());
         return;
     }
@@ -99,15 +130,9 @@ void launch_rerank_sq8(const float *q, int nq, const uint8_t *base, int64_t nb, 
     hipLaunchKernelGGL(sq8_query_table_kernel, dim3((unsigned)nq), dim3(64), (size_t)d * 8, st, q, (int64_t)nq, d, trained, wq, Aq);
     MI_HIP(hipGetLastError());
     const int tiles = (kc + 63) / 64;
-    const char *e = std::getenv("MI_RERANK");
-    if (d % 128 == 0 && (int64_t)nq * tiles < ((int64_t)1 << 31) && !(e && std::string(e) == "simple")) {
-        int nst = 3;
-        if (e && std::atoi(e) > 0) nst = std::atoi(e);
+    if (d % 128 == 0 && (int64_t)nq * tiles < ((int64_t)1 << 31)) {
         const unsigned grid = (unsigned)((int64_t)nq * tiles);
-        if (nst == 2) hipLaunchKernelGGL((rerank_sq8_kernel<2>), dim3(grid), dim3(64), 0, st, wq, Aq, base, nb, d, idx, kc, S, ldS, tiles);
-        else if (nst == 4) hipLaunchKernelGGL((rerank_sq8_kernel<4>), dim3(grid), dim3(64), 0, st, wq, Aq, base, nb, d, idx, kc, S, ldS, tiles);
-        else if (nst == 6) hipLaunchKernelGGL((rerank_sq8_kernel<6>), dim3(grid), dim3(64), 0, st, wq, Aq, base, nb, d, idx, kc, S, ldS, tiles);
-        else hipLaunchKernelGGL((rerank_sq8_kernel<3>), dim3(grid), dim3(64), 0, st, wq, Aq, base, nb, d, idx, kc, S, ldS, tiles);
+        hipLaunchKernelGGL((rerank_sq8_kernel<3>), dim3(grid), dim3(64), 0, st, wq, Aq, base, nb, d, idx, kc, S, ldS, tiles);
         MI_HIP(hipGetLastError());
         return;
     }
@@ -136,8 +161,7 @@ void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int3
     MI_REQUIRE(K >= 1, "select: K < 1");
     // 64 < K <= 4096: threshold + bitonic sort (K = 256 of 4096: 16 us; the rank-counting path of
     // select_kernel 55 us, its insertion path 764 us at K = 1024).  MI_SELECT_BIG_FROM moves the border.
-    const char *e = std::getenv("MI_SELECT_BIG_FROM");
-    const int big_from = e ? std::atoi(e) : 65;
+    const int big_from = knobs().select_big_from;
     if (K >= big_from && K <= SELB_CAP) {
         hipLaunchKernelGGL(select_big_kernel, dim3((unsigned)rows), dim3(256), 0, st, S, ldS, n, K, oi32,
                            oi64, os, pt, idx_off);
@@ -193,26 +217,15 @@ void launch_slab_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int
 // gmax (optional, [na][nb / 64]): filled with the 64-column group maxima when the slab kernel runs; returns whether it was
 bool launch_gemm_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int K, float *S, int64_t ldS,
                      hipStream_t st, float *gmax = nullptr) {
-    MI_REQUIRE(K % 64 == 0 && ldS % 4 == 0, "f16 gemm: K % 64 and ldS % 4");
-    // the encoder's ring-pipelined kernel, f16 instantiation (MI_F16_GEMM=simple: the two-stage
-    // 128 x 128 kernel of ivfpq_kernels.h, for A/B runs)
-    const char *e = std::getenv("MI_F16_GEMM");
-    if (!(e && std::string(e) == "simple") && ldS < ((int64_t)1 << 31)) {
-        const int64_t tiles_big = ((na + 255) / 256) * ((nb + 255) / 256);
-        if (tiles_big >= 512 && !(e && std::string(e) == "ring")) {                               // 256 x 256, 8 waves
-            const bool with_gmax = gmax && nb % 64 == 0;
-            launch_slab_f16(A, na, B, nb, K, S, ldS, st, with_gmax ? gmax : nullptr, (int)(nb / 64));
-            return with_gmax;
-        }
-        if (tiles_big >= 512) launch_ring_f16<8, 4, 2, 4, 4>(A, na, B, nb, K, S, ldS, st);   // MI_F16_GEMM=ring: the older kernel (A/B runs)
-        else launch_ring_f16<4, 4, 2, 2, 4>(A, na, B, nb, K, S, ldS, st);                    // 128 x 128, 4 waves
-        return false;
+    MI_REQUIRE(K % 64 == 0 && ldS % 4 == 0 && ldS < ((int64_t)1 << 31), "f16 gemm: K % 64, ldS % 4, ldS < 2^31");
+    // the encoder's GEMM kernels, f16 instantiation: 256 x 256 slab tiles from 512 tiles up, 128 x 128 ring tiles below
+    const int64_t tiles_big = ((na + 255) / 256) * ((nb + 255) / 256);
+    if (tiles_big >= 512) {
+        const bool with_gmax = gmax && nb % 64 == 0;
+        launch_slab_f16(A, na, B, nb, K, S, ldS, st, with_gmax ? gmax : nullptr, (int)(nb / 64));
+        return with_gmax;
     }
-    const int tiles_m = (int)((na + 127) / 128), tiles_n = (int)((nb + 127) / 128);
-    const int per = (tiles_m * tiles_n + 7) / 8;
-    hipLaunchKernelGGL(ip_gemm_f16_kernel, dim3((unsigned)(per * 8)), dim3(256), 0, st, A, (int)na, B, (int)nb, K, S,
-                       ldS, tiles_m, tiles_n);
-    MI_HIP(hipGetLastError());
+    launch_ring_f16<4, 4, 2, 2, 4>(A, na, B, nb, K, S, ldS, st);
     return false;
 }
 
@@ -243,7 +256,7 @@ void prepare_cent16(const float *c, int64_t nc, int d, DevBuf &c16, DevBuf &stat
 // than it saves.  MI_TWO_STAGE=0 / 1 forces it off / on (tests).
 bool two_stage_wanted(int64_t nq, int64_t nc, int d, int K) {
     bool on = nq >= 256 && nc >= 8192 && nq * nc >= ((int64_t)1 << 24) && (K <= 128 || nq * nc >= ((int64_t)1 << 26));   // (1024 x 65536, K 256: 2.68 -> 2.16 ms)
-    if (const char *e = std::getenv("MI_TWO_STAGE")) on = std::atoi(e) != 0;
+    if (knobs().two_stage >= 0) on = knobs().two_stage != 0;
     return on && d % 128 == 0 && d <= 4096 && nc % 4 == 0 && K <= 1024 && nc < ((int64_t)1 << 31);
 }
 
@@ -254,7 +267,7 @@ void launch_two_stage(const float *q, int64_t nq, const float *c32, const f16_t 
                       int32_t *out_i32, float *out_s, ProbeTables pt, hipStream_t st, int idx_off = 0) {
     f16_t *q16 = static_cast<f16_t *>(q16buf.reserve((size_t)nq * d * 2));
     // behind the per-row scales: the 64-column group maxima of the approximate scores (MI_REFINE_GMAX=0: without)
-    const bool want_gmax = nc % 64 == 0 && nc / 64 <= 1024 && !(std::getenv("MI_REFINE_GMAX") && std::atoi(std::getenv("MI_REFINE_GMAX")) == 0);
+    const bool want_gmax = nc % 64 == 0 && nc / 64 <= 1024 && knobs().refine_gmax;
     const size_t qs_bytes = (((size_t)nq * 4 + 255) / 256) * 256;
     float *qscale = static_cast<float *>(qscalebuf.reserve(qs_bytes + (want_gmax ? (size_t)nq * (nc / 64) * 4 : 0)));
     float *gmax = want_gmax ? reinterpret_cast<float *>(reinterpret_cast<char *>(qscale) + qs_bytes) : nullptr;
@@ -269,8 +282,7 @@ void launch_two_stage(const float *q, int64_t nq, const float *c32, const f16_t 
     ra.eps_rel = (0x1p-10f + (float)d * (0x1p-22f + 0x1p-24f) + 0x1p-26f * std::sqrt((float)d)) * 1.01f;
     ra.qscale = qscale; ra.cscale = cscale; ra.cmax = cmax;
     ra.out_i32 = out_i32; ra.out_s = out_s; ra.pt = pt; ra.idx_off = idx_off;
-    if (const char *e = std::getenv("MI_REFINE_DEBUG")) ra.debug = std::atoi(e);
-    const bool want_stats = std::getenv("MI_REFINE_STATS") != nullptr;
+    const bool want_stats = knobs().refine_stats;
     if (want_stats) {
         ra.stats = static_cast<unsigned *>(statbuf.reserve(8));
         MI_HIP(hipMemsetAsync(ra.stats, 0, 8, st));
@@ -395,11 +407,6 @@ void launch_scan(int M, const ScanArgs &a, hipStream_t st) {
 // as_set: ids only (D may be null), in no particular order -- what the first stage of a refine search needs
 // IDS null: the ids of the survivors come from the lists through the probe tables (p_goff [rows][nprobe], list_ids = the scan
 // image's id array) -- the all-scores scan then stores scores only
-// threads per row of the 8192-slot set selection (MI_SELP_NT = 256 | 512: A/B knob)
-static int selp_nt() {
-    static const int nt = std::getenv("MI_SELP_NT") ? std::atoi(std::getenv("MI_SELP_NT")) : 512;
-    return nt;
-}
 void launch_select_pairs(const float *S, const int64_t *IDS, int64_t ld, const int32_t *p_prefix, int nprobe, int K, int64_t rows,
                          float *D, int64_t *I, int64_t ldo, hipStream_t st, bool as_set = false, const int32_t *p_goff = nullptr,
                          const int64_t *list_ids = nullptr) {
@@ -410,9 +417,8 @@ void launch_select_pairs(const float *S, const int64_t *IDS, int64_t ld, const i
     if (as_set) {
         // (rows longer than the 4096-slot kernel keeps resident -- 4 tiles of 4096 -- go to the 8192-slot one whatever K: it holds
         //  32 k scores in registers; streamed, a 25.6 k row took 591 us where the resident pass takes ~210)
-        if (K <= SELB_CAP && (ld <= 16384 || selp_nt() != 512)) hipLaunchKernelGGL((select_pairs_kernel<16, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
-        else if (selp_nt() == 512) hipLaunchKernelGGL((select_pairs_kernel<16, true, 512>), grid, dim3(512), 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
-        else hipLaunchKernelGGL((select_pairs_kernel<32, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
+        if (K <= SELB_CAP && ld <= 16384) hipLaunchKernelGGL((select_pairs_kernel<16, true>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
+        else hipLaunchKernelGGL((select_pairs_kernel<16, true, 512>), grid, dim3(512), 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
     } else {
         if (K <= SELB_CAP) hipLaunchKernelGGL((select_pairs_kernel<16, false>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
         else hipLaunchKernelGGL((select_pairs_kernel<32, false>), grid, block, 0, st, S, IDS, ld, p_prefix, nprobe, K, D, I, ldo, p_goff, list_ids);
@@ -433,7 +439,7 @@ void launch_merge(const float *ps, const int64_t *pid, int nparts, int64_t strid
     const size_t per_wave = merge_wave_bytes(nparts, k);
     // the counting tiers rank every candidate against every other one -- (nparts k)^2 / 64 steps per lane: a re-rank of 5 120
     // candidates took 0.77 ms of a 4.6 ms step there -- so long candidate lists go to the selection tier (linear in nparts k)
-    static const int64_t big_from = std::getenv("MI_MERGE_SELECT_FROM") ? std::atoll(std::getenv("MI_MERGE_SELECT_FROM")) : 2048;
+    constexpr int64_t big_from = 2048;
     // (only for callers that bring a kept scratch buffer: without one the tier would hipMalloc + synchronise + hipFree on every
     // call -- a single query's cross-slice merge must stay enqueue-only)
     const bool by_selection = scratch && !bs && !bid && (int64_t)nparts * k >= big_from && k <= SELB_CAP;
@@ -498,14 +504,6 @@ struct SearchWS {
     bool have_last_scan = false;
     int64_t last_nq = 0;
     int last_nprobe = 0;
-    // optional side stream for the LUT kernel (MI_SIDE_STREAM=1; measured slower)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    ~SearchWS() {
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side) (void)hipStreamDestroy(side);
-    }
 };
 
 struct mi_index {
@@ -540,7 +538,7 @@ struct mi_index {
     // search workspaces: one set per stream the index is searched on, so that
     // batches issued on different streams overlap on the GPU (a serving loop
     // round-robins 2-4 streams; each kernel of one batch leaves most CUs idle)
-    std::vector<std::pair<void *, std::unique_ptr<SearchWS>>> ws_sets;
+    std::vector<std::pair<void *, std::shared_ptr<SearchWS>>> ws_sets;   // shared: a leased set outlives release_workspaces
     // Concurrent readers (mi_ivfpq.h "Threading"): `mu` guards the list of workspace sets and every piece of state a
     // search builds lazily (the scan image after an add, the f16 centroid image, the all-scores row capacity); the
     // arithmetic of a search only reads the index.
@@ -568,7 +566,7 @@ struct mi_flat {
         std::mutex mu;
         DevBuf q, cand, scores, D, I, qaug, qn, bigmerge, rerank;
     };
-    std::vector<std::pair<void *, std::unique_ptr<WS>>> ws_sets;
+    std::vector<std::pair<void *, std::shared_ptr<WS>>> ws_sets;
     std::mutex mu;            // guards ws_sets
 };
 
@@ -577,12 +575,12 @@ namespace {
 constexpr size_t MAX_STREAMS = 64;   // distinct streams one handle keeps workspaces for
 
 // caller holds h->mu
-SearchWS &ws_for(mi_index *h, void *stream) {
+std::shared_ptr<SearchWS> ws_for(mi_index *h, void *stream) {
     for (auto &kv : h->ws_sets)
-        if (kv.first == stream) return *kv.second;
+        if (kv.first == stream) return kv.second;
     MI_REQUIRE(h->ws_sets.size() < MAX_STREAMS, "too many distinct streams on one index handle (max 64)");
-    h->ws_sets.emplace_back(stream, std::make_unique<SearchWS>());
-    return *h->ws_sets.back().second;
+    h->ws_sets.emplace_back(stream, std::make_shared<SearchWS>());
+    return h->ws_sets.back().second;
 }
 
 void sync_lists(mi_index *h);
@@ -590,37 +588,43 @@ void sync_lists(mi_index *h);
 // The workspace set of `stream`, leased to the calling thread until the lease dies.  Threads on distinct streams run
 // concurrently; threads that share a stream take turns enqueuing (the GPU serialises their work anyway).  `sync`: also
 // bring the scan image up to date (the first search after an add builds it, once, under the handle lock).
+// The lease owns a reference: mi_index_release_workspaces between the look-up and the lock drops the handle's reference only,
+// the set lives until the call that leased it returns.
 struct WsLease {
+    std::shared_ptr<SearchWS> keep;
     SearchWS &w;
     std::unique_lock<std::mutex> lk;
 };
 WsLease lease_ws(mi_index *h, void *stream, bool sync) {
-    SearchWS *w;
+    std::shared_ptr<SearchWS> w;
     {
         std::lock_guard<std::mutex> hl(h->mu);
-        w = &ws_for(h, stream);
+        w = ws_for(h, stream);
         if (sync) sync_lists(h);
     }
-    return WsLease{*w, std::unique_lock<std::mutex>(w->mu)};
+    SearchWS &r = *w;
+    return WsLease{std::move(w), r, std::unique_lock<std::mutex>(r.mu)};
 }
 
 struct FlatLease {
+    std::shared_ptr<mi_flat::WS> keep;
     mi_flat::WS &w;
     std::unique_lock<std::mutex> lk;
 };
 FlatLease lease_ws(mi_flat *h, void *stream) {
-    mi_flat::WS *w = nullptr;
+    std::shared_ptr<mi_flat::WS> w;
     {
         std::lock_guard<std::mutex> hl(h->mu);
         for (auto &kv : h->ws_sets)
-            if (kv.first == stream) w = kv.second.get();
+            if (kv.first == stream) w = kv.second;
         if (!w) {
             MI_REQUIRE(h->ws_sets.size() < MAX_STREAMS, "too many distinct streams on one flat index handle (max 64)");
-            h->ws_sets.emplace_back(stream, std::make_unique<mi_flat::WS>());
-            w = h->ws_sets.back().second.get();
+            h->ws_sets.emplace_back(stream, std::make_shared<mi_flat::WS>());
+            w = h->ws_sets.back().second;
         }
     }
-    return FlatLease{*w, std::unique_lock<std::mutex>(w->mu)};
+    mi_flat::WS &r = *w;
+    return FlatLease{std::move(w), r, std::unique_lock<std::mutex>(r.mu)};
 }
 
 void require_trained(mi_index *h) {
@@ -1085,7 +1089,7 @@ int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_a
         MI_HIP(hipEventElapsedTime(&ms, e0, e1));
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-        if (std::getenv("MI_SCAN_TS")) {
+        if (knobs().scan_ts) {
             // one more replay with in-kernel s_memtime stamps: mean/max time of each phase
             // boundary relative to the earliest workgroup start, printed to stderr
             const size_t nb = scan_grid(w.last_scan.nq, w.last_scan.nslice);
@@ -1147,7 +1151,7 @@ static int choose_nslice(const mi_index *h, int64_t nq, int nprobe, int k = 10) 
     // at most 64 / k slices so that the cross-slice merge stays on its one-wave path.
     const int64_t by_tail = std::min<int64_t>((int64_t)(per_query / 128.0), std::max(1, std::min(8, 64 / std::max(1, std::min(k, 64)))));
     s = std::max(s, by_tail);
-    if (const char *e = std::getenv("MI_NSLICE")) s = std::atoi(e);  // tuning knob
+    if (knobs().nslice > 0) s = knobs().nslice;          // tuning knob
     return (int)std::max<int64_t>(1, std::min<int64_t>(s, 32));
 }
 
@@ -1188,18 +1192,6 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         MI_HIP(hipGetLastError());
         qc = qa; cc = h->cent_aug.get<float>(); dc = h->da;
     }
-    const bool fork = std::getenv("MI_SIDE_STREAM") != nullptr;  // measured slower in eager mode: opt-in
-    if (fork) {
-        if (!w.side) {
-            MI_HIP(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
-            MI_HIP(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
-            MI_HIP(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
-        }
-        MI_HIP(hipEventRecord(w.ev_fork, st));
-        MI_HIP(hipStreamWaitEvent(w.side, w.ev_fork, 0));
-        launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, w.side);
-        MI_HIP(hipEventRecord(w.ev_join, w.side));
-    }
     // Large batches: f16 MFMA scores + exact re-scoring of the few centroids within a proven
     // error margin of the cut (bit-identical result, see select_refine_kernel) instead of the
     // exact f32 GEMM over all of them.
@@ -1214,15 +1206,13 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         }
         launch_two_stage(qc, nq, cc, static_cast<const f16_t *>(h->cent16.p), h->nlist, dc,
                          nprobe, h->cmax, h->cscale, scores, w.q16, w.qscale, w.rstats, cidx, cdis, pt, st);
-        if (fork) MI_HIP(hipStreamWaitEvent(st, w.ev_join, 0));
-        else launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
+        launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
     } else {
-    const bool lut_in_gemm = !fork && (h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && !std::getenv("MI_NO_LUT_FUSION");
+    const bool lut_in_gemm = h->dsub == 4 || h->dsub == 8 || h->dsub == 16;
     launch_gemm(qc, nq, cc, h->nlist, dc, scores, h->nlist, st,
                 lut_in_gemm ? make_lut_args(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut) : LutArgs{});
     launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st, pt);
-    if (fork) MI_HIP(hipStreamWaitEvent(st, w.ev_join, 0));
-    else if (!lut_in_gemm) launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
+    if (!lut_in_gemm) launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
     }
     }
     const float *cscan = cdis;   // the per-(query, probe) term the scan adds
@@ -1268,8 +1258,8 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         const double groups_per_slice = (h->nlist > 0 ? (double)h->ngroups / h->nlist : 0.0) * nprobe / nslice;
         if (scan_grid((int)nq, nslice) <= 256 && groups_per_slice >= 128.0) scan_nw = 16;
     }
-    if (const char *e = std::getenv("MI_SCAN_NW")) scan_nw = std::atoi(e) == 16 ? 16 : 8;
-    if (npass > 1 && !std::getenv("MI_NO_ALLSCORES")) {
+    if (knobs().scan_nw) scan_nw = knobs().scan_nw == 16 ? 16 : 8;
+    if (npass > 1 && !knobs().no_allscores) {
         // k > 64: one pass over the codes that stores every (score, id) of the probed lists,
         // then the k best of each row (select_pairs_kernel) -- instead of one scan per 64
         // results.  Row capacity = the groups of the nprobe longest lists; queries go in
@@ -1295,9 +1285,9 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         }
         const int64_t qc = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (R * 12)));
         float *all_s = w.all_s.as<float>((size_t)(qc * R));
-        // scores only (inner product): the selection fetches the survivors' ids from the lists; MI_ALLSCORES_IDS=1 (and METRIC_L2,
-        // whose scan variant was left as it is) keeps the row of ids beside the scores
-        const bool ids_row = l2 || std::getenv("MI_ALLSCORES_IDS") != nullptr;
+        // scores only (inner product): the selection fetches the survivors' ids from the lists; METRIC_L2 (whose scan variant
+        // was left as it is) keeps the row of ids beside the scores
+        const bool ids_row = l2;
         int64_t *all_id = ids_row ? w.all_id.as<int64_t>((size_t)(qc * R)) : nullptr;
         for (int64_t c0 = 0; c0 < nq; c0 += qc) {
             const int64_t m = std::min(qc, nq - c0);
@@ -1308,7 +1298,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
             a.p_prefix = pt.p_prefix + (size_t)c0 * (nprobe + 1);
             a.codes = h->d_codes.get<uint8_t>(); a.ids = h->d_ids.get<int64_t>();
             a.nq = (int)m; a.nprobe = nprobe; a.nslice = choose_nslice(h, m, nprobe); a.k = 64;
-            if (!std::getenv("MI_NSLICE")) {
+            if (knobs().nslice <= 0) {
                 // the all-scores scan has no cross-slice merge to keep short: slices of ~64 groups even out the rounds of
                 // workgroups better than the k-limited count above (1024 queries x 395 groups: 1 / 2 / 3 / 6 / 8 / 12 slices
                 // 449 / 401 / 389 / 366 / 384 / 393 us -- tools/micro/nslice_sweep.sh)
@@ -1321,7 +1311,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
                 const double groups_per_slice = (h->nlist > 0 ? (double)h->ngroups / h->nlist : 0.0) * nprobe / a.nslice;
                 if (scan_grid((int)m, a.nslice) <= 256 && groups_per_slice >= 128.0) a.nw = 16;
             }
-            if (const char *e = std::getenv("MI_SCAN_NW")) a.nw = std::atoi(e) == 16 ? 16 : 8;
+            if (knobs().scan_nw) a.nw = knobs().scan_nw == 16 ? 16 : 8;
             a.all_s = all_s; a.all_id = all_id; a.all_ld = R;
             launch_scan(M, a, st);
             launch_select_pairs(all_s, all_id, R, a.p_prefix, nprobe, k, m, Ddev ? Ddev + (size_t)c0 * k : nullptr, Idev + (size_t)c0 * k,
@@ -1344,11 +1334,10 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         a.nw = scan_nw;
         a.debug = 0;
         a.ts = nullptr;
-        if (const char *e = std::getenv("MI_SCAN_DEBUG")) a.debug = std::atoi(e);
         // the last slice of each query merges the partial lists in-kernel when
         // they fit in the LUT's LDS region; otherwise a separate merge kernel
         const bool fuse = scan_fused_merge_bytes(nslice, kp) <= scan_lut_bytes(M, scan_nw) &&
-                          !std::getenv("MI_NO_FUSED_MERGE");
+                          !knobs().no_fused_merge;
         a.counters = nullptr; a.D = Ddev; a.I = Idev; a.ldo = k; a.out_off = pass * 64;
         a.next_bound_s = npass > 1 ? bs : nullptr; a.next_bound_id = npass > 1 ? bid : nullptr;
         if (fuse) {
@@ -1427,7 +1416,7 @@ int mi_index_search_candidates(mi_index *h, int64_t nq, const float *q, int kc, 
         for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
             const int64_t m = std::min(chunk, nq - c0);
             // kc <= 64 (selected inside the scan) and METRIC_L2 (scores are finished in place) keep the sorted path
-            const bool set = kc > 64 && h->metric == MI_METRIC_INNER_PRODUCT && !std::getenv("MI_NO_ALLSCORES");
+            const bool set = kc > 64 && h->metric == MI_METRIC_INNER_PRODUCT && !knobs().no_allscores;
             float *Dc = set ? nullptr : w.D.as<float>((size_t)m * kc);
             search_chunk(h, w, m, q + (size_t)c0 * h->d, kc, nprobe, Dc, I + (size_t)c0 * kc, st, nullptr, nullptr, nullptr, false,
                          nullptr, nullptr, set);
@@ -1534,9 +1523,13 @@ DevBuf *merge_scratch(int device, void *stream) {
     static thread_local std::vector<Slot> slots;
     for (auto &sl : slots)
         if (sl.device == device && sl.stream == stream) return sl.buf.get();
-    if (slots.size() >= 64) {
+    if (slots.size() >= 64) {                            // recycle the oldest: nothing on ITS device may still read it
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(slots.front().device);
         (void)hipDeviceSynchronize();
-        slots.erase(slots.begin());
+        slots.erase(slots.begin());                      // (frees on the slot's device)
+        (void)hipSetDevice(cur);
     }
     slots.push_back(Slot{device, stream, std::make_unique<DevBuf>()});
     return slots.back().buf.get();
@@ -2353,7 +2346,7 @@ int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t
         else launch_rerank_scores<f16_t>(qs, (int)nq, h->base.get<f16_t>(), h->ntotal, h->d, ci, kc, scores, kc, st);
         // the k best under (score desc, id asc), negative ids skipped: a few results of a long list in one pass over the rows
         // (topk_rows_kernel); otherwise the candidate list as kc/k "parts" of k entries through the k-way merge
-        const bool no_rows = std::getenv("MI_NO_TOPK_ROWS") != nullptr;   // (read per call: the tests run both routes)
+        const bool no_rows = knobs().no_topk_rows;
         if (k <= 32 && kc >= 256 && kc <= 8192 && !no_rows) {
             const int vpt = (kc + 255) / 256;
             if (vpt <= 8) hipLaunchKernelGGL((topk_rows_kernel<8>), dim3((unsigned)nq), dim3(256), 0, st, scores, ci, kc, k, Dc, Ic, (int64_t)k);
@@ -2451,6 +2444,10 @@ int mi_flat_get_rows(mi_flat *h, int64_t n, const int64_t *ids, void *out) {
         MI_REQUIRE(h && (n == 0 || (ids && out)), "null argument");
         if (n == 0) return;
         DeviceGuard dg(h->device);
+        // not a search-type call: it reads the store on the null stream, so it takes the handle lock and waits for whatever an
+        // add() on another stream still has in flight
+        std::lock_guard<std::mutex> hl(h->mu);
+        MI_HIP(hipDeviceSynchronize());
         const size_t row = (size_t)h->da * h->elem;                     // bytes per stored row
         std::vector<int64_t> hid;
         const int64_t *hi = ids;
@@ -2469,7 +2466,8 @@ int mi_flat_get_rows(mi_flat *h, int64_t n, const int64_t *ids, void *out) {
         }
         const bool od = is_device_ptr(out);
         unsigned char *dst = od ? static_cast<unsigned char *>(out) : static_cast<unsigned char *>(dout.reserve((size_t)n * row));
-        hipLaunchKernelGGL(gather_rows_bytes_kernel, dim3((unsigned)n), dim3(256), 0, nullptr, h->base.get<unsigned char>(), row, d_ids, dst);
+        const bool wide = row % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0;   // 16-byte copies only for an aligned destination
+        hipLaunchKernelGGL(gather_rows_bytes_kernel, dim3((unsigned)n), dim3(256), 0, nullptr, h->base.get<unsigned char>(), row, d_ids, dst, wide ? 1 : 0);
         MI_HIP(hipGetLastError());
         if (!od) MI_HIP(hipMemcpy(out, dst, (size_t)n * row, hipMemcpyDeviceToHost));
         else MI_HIP(hipStreamSynchronize(nullptr));
@@ -2544,6 +2542,10 @@ int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int6
 
 // out[n][nc] = x . c^T (+ bias[nc]): the exact f32 GEMM of the coarse quantiser (ascending-k fmaf chain per element) as a
 // plain operator -- the VectorTransform in front of an IndexPreTransform (OPQ / random rotation: x -> A x + b)
+int mi_ivfpq_reload_env(void) {
+    return guard([&] { knobs_mut().load(); });
+}
+
 int mi_ip_gemm(int device, int64_t n, const float *x, int64_t nc, const float *c, int d, const float *bias, float *out,
                void *stream) {
     return guard([&] {

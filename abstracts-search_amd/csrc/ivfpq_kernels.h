@@ -1518,110 +1518,6 @@ __global__ void __launch_bounds__(256) max_row_norm_kernel(const float *__restri
     }
 }
 
-__device__ __forceinline__ float ivf_dpp_quad_xor1(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float ivf_dpp_quad_xor2(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
-}
-// 4x4 transpose across a lane quad: before, lane b of the quad holds C[4 lg + r][4a + b] in
-// v[r]; after, C[4 lg + b][4a + c] in v[c] (four consecutive columns: one 16-byte store)
-__device__ __forceinline__ f32x4 ivf_quad_transpose(f32x4 v, int lane) {
-    const bool odd = lane & 1, hi = lane & 2;
-    float r0 = ivf_dpp_quad_xor1(odd ? v[0] : v[1]);
-    float r1 = ivf_dpp_quad_xor1(odd ? v[2] : v[3]);
-    if (odd) { v[0] = r0; v[2] = r1; } else { v[1] = r0; v[3] = r1; }
-    r0 = ivf_dpp_quad_xor2(hi ? v[0] : v[2]);
-    r1 = ivf_dpp_quad_xor2(hi ? v[1] : v[3]);
-    if (hi) { v[0] = r0; v[1] = r1; } else { v[2] = r0; v[3] = r1; }
-    return v;
-}
-
-// S[na][nb] ~= A[na][K] . B[nb][K]^T, f16 operands, f32 accumulate (v_mfma_f32_16x16x32_f16).
-// 128 x 128 x 64 tiles, 4 waves of 64 x 64, two LDS stages filled by LDS-DMA (128-byte rows,
-// 16-byte slots XOR-swizzled by row & 7).  Tile order: every XCD walks a contiguous eighth
-// of a sequence in which 8 M tiles share one B strip (its L2 holds the strip and all of A).
-// K % 64 == 0, ldS % 4 == 0; rows are clamped, stores guarded.
-__global__ void __launch_bounds__(256)
-    ip_gemm_f16_kernel(const f16_t *__restrict__ A, int na, const f16_t *__restrict__ B, int nb, int K,
-                       float *__restrict__ S, int64_t ldS, int tiles_m, int tiles_n) {
-    constexpr int BM = 128, BN = 128, BK = 64, GM = 8;
-    __shared__ __attribute__((aligned(16))) f16_t smem[2 * (BM + BN) * BK];   // 64 KiB
-    f16_t *As = smem, *Bs = smem + 2 * BM * BK;
-    int tm, tn;
-    {
-        const int ntiles = tiles_m * tiles_n, bid = (int)blockIdx.x, per = (ntiles + 7) / 8;
-        const int t = (bid & 7) * per + (bid >> 3);
-        if (t >= ntiles || (bid >> 3) >= per) return;
-        const int group = t / (GM * tiles_n), within = t - group * (GM * tiles_n);
-        const int gm = min(GM, tiles_m - group * GM);
-        tn = within / gm;
-        tm = group * GM + (within - tn * gm);
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = uniform_i(tid >> 6);
-    const int wm = w & 1, wn = w >> 1;
-    const int li = lane & 15, lg = lane >> 4;
-    const int srow = lane >> 3, scol = ((lane & 7) ^ srow) * 8;
-    auto stage = [&](int buf, int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r0 = (w * 4 + i) * 8;
-            const int ra = min(m0 + r0 + srow, na - 1), rb = min(n0 + r0 + srow, nb - 1);
-            dma16_lds(A + (size_t)ra * K + k0 + scol, As + buf * BM * BK + r0 * BK);
-            dma16_lds(B + (size_t)rb * K + k0 + scol, Bs + buf * BN * BK + r0 * BK);
-        }
-    };
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nk = K / BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
-        const f16_t *ab = As + (kt & 1) * BM * BK + (wm * 64 + li) * BK;
-        const f16_t *bb = Bs + (kt & 1) * BN * BK + (wn * 64 + li) * BK;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int slot = ((kk * 4 + lg) ^ (li & 7)) * 8;
-            f16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f16x8 *>(ab + i * 16 * BK + slot);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f16x8 *>(bb + j * 16 * BK + slot);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // lane: rows (lane >> 4) * 4 + r of column lane & 15 -> after the quad transpose,
-            // row (lane >> 4) * 4 + (lane & 3), columns (lane & 12) .. + 3
-            const f32x4 v = ivf_quad_transpose(acc[i][j], lane);
-            const int row = m0 + wm * 64 + i * 16 + lg * 4 + (lane & 3);
-            const int col = n0 + wn * 64 + j * 16 + (li & ~3);
-            if (row < na) {
-                float *o = S + (size_t)row * ldS + col;
-                if (col + 3 < nb) *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    for (int c = 0; c < 4; ++c)
-                        if (col + c < nb) o[c] = v[c];
-            }
-        }
-}
-
 // Stage 2: one 256-thread workgroup per query row of approximate scores Sa [rows][ldS].
 //   cut = (K-th largest of 4096 group maxima of the approximate row) - 2 eps;
 //   candidates = columns with approximate score >= cut;
@@ -1644,7 +1540,6 @@ struct RefineArgs {
     float *out_s;         // [rows][K]
     ProbeTables pt;
     unsigned *stats;      // null, or [2]: total candidates, rows that fell back
-    int debug;            // timing experiments: 1 = no exact chain
     int idx_off;          // added to every index written (a slice of a larger centroid table: mi_index_coarse_slice)
     const float *gmax;    // null, or [rows][ngroups]: maxima of the approximate row over 64-column groups, written by the
     int ngroups;          // f16 GEMM's epilogue (+inf marks a group with a non-finite score): the row itself is then read
@@ -1911,7 +1806,7 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
         const int e = e0 + (tid >> 6) + 4 * (tid & 63);
         if (e >= Sn) continue;
         const unsigned col = (unsigned)skey[e];
-        const float s = (exact_row || (a.debug & 1)) ? __uint_as_float((unsigned)(skey[e] >> 32)) : exact((int)col);
+        const float s = exact_row ? __uint_as_float((unsigned)(skey[e] >> 32)) : exact((int)col);
         skey[e] = s == s ? ((unsigned long long)f2o(s) << 32) | (unsigned)~col : 0ull;   // NaN never survives
     }
     int P = 64;
@@ -2985,10 +2880,10 @@ __global__ void __launch_bounds__(256)
 // out[i][:] = base[ids[i]][:], rows of `row_bytes` bytes (mi_flat_get_rows: the stored bytes of a sample of a store).
 // One workgroup per row; 16-byte pieces when the row size allows, bytes otherwise.
 __global__ void __launch_bounds__(256) gather_rows_bytes_kernel(const unsigned char *__restrict__ base, size_t row_bytes,
-                                                                const int64_t *__restrict__ ids, unsigned char *__restrict__ out) {
+                                                                const int64_t *__restrict__ ids, unsigned char *__restrict__ out, int wide) {
     const unsigned char *src = base + (size_t)ids[blockIdx.x] * row_bytes;
     unsigned char *dst = out + (size_t)blockIdx.x * row_bytes;
-    if ((row_bytes & 15) == 0) {
+    if (wide) {                                          // row_bytes % 16 == 0 and an aligned destination (host-checked)
         for (size_t o = (size_t)threadIdx.x * 16; o < row_bytes; o += 256 * 16)
             *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(src + o);
     } else {

@@ -106,6 +106,7 @@ class _Lib:
                 "mi_flat_rerank": [v, c_int64, v, c_int, v, c_int, v, v, v],
                 "mi_ip_assign": [c_int, c_int64, v, c_int64, v, c_int, v, v, v],
                 "mi_ip_gemm": [c_int, c_int64, v, c_int64, v, c_int, v, v, v],
+                "mi_ivfpq_reload_env": [],
                 "mi_pq_encode": [c_int, c_int64, v, c_int, c_int, v, v, v],
                 "mi_cluster_means": [c_int, c_int64, v, c_int, v, c_int, v, v, v],
                 "mi_neg_half_sqnorm": [c_int, c_int64, v, c_int, v, v],
@@ -153,6 +154,12 @@ def _ptr(x):
     if _is_torch(x):
         return c_void_p(x.data_ptr())
     return c_void_p(x.ctypes.data)
+
+
+def reload_env() -> None:
+    """re-read the library's MI_* knobs from the environment (tests / tools; the library reads them once otherwise).  Not a
+    faiss call."""
+    _check(_Lib.get().mi_ivfpq_reload_env())
 
 
 def get_num_gpus() -> int:

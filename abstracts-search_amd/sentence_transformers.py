@@ -61,6 +61,7 @@ class _Lib:
                 "mi_encoder_profile_read": [v, POINTER(c_double), POINTER(c_double)],
                 "mi_enc_gemm_bf16": [c_int, c_int, c_int, c_int, v, v, v, v],
                 "mi_enc_debug_counter": [c_char_p, POINTER(c_int64)],
+                "mi_encoder_reload_env": [],
             }
             for name, args in sigs.items():
                 fn = getattr(lib, name)
@@ -441,6 +442,11 @@ class SentenceTransformer:
         ms, fl = c_double(0), c_double(0)
         _check(_Lib.get().mi_encoder_profile_read(self._h, ctypes.byref(ms), ctypes.byref(fl)))
         return {"gemm_ms": ms.value, "gemm_flops": fl.value}
+
+
+def reload_env() -> None:
+    """re-read the library's MI_* knobs from the environment (tests / tools; the library reads them once otherwise)"""
+    _check(_Lib.get().mi_encoder_reload_env())
 
 
 def debug_counter(name: str) -> int:

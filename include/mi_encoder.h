@@ -100,6 +100,11 @@ int mi_encoder_profile_read(mi_encoder *h, double *gemm_ms, double *gemm_flops);
  * GEMMs run on 256 x 192 tiles. */
 int mi_enc_debug_counter(const char *name, int64_t *value);
 
+/* The library reads its MI_* environment knobs (README.md lists them; each overrides a measured dispatch rule) ONCE, at the
+ * first call that needs one, into a process-wide struct: no encode call path calls getenv.  This re-reads them -- for tests
+ * and tools that switch a knob inside one process; not to be called while another thread is inside the library. */
+int mi_encoder_reload_env(void);
+
 /* Building block exposed for numerics tests: C[M][N] = A[M][K] . W[N][K]^T in
  * bf16 with f32 accumulation (device pointers; C bf16 row-major). */
 int mi_enc_gemm_bf16(int device, int M, int N, int K, const void *A, const void *W, void *C,

@@ -278,6 +278,14 @@ int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int6
 int mi_flat_rerank(mi_flat *h, int64_t nq, const float *q, int kc, const int64_t *cand_I, int k,
                    float *D, int64_t *I, void *stream);
 
+/* ---- tuning knobs ------------------------------------------------------ */
+
+/* The library reads its MI_* environment knobs (README.md lists them; each overrides a measured dispatch rule) ONCE, at the
+ * first call that needs one, into a process-wide struct: no search / add call path calls getenv.  This re-reads them --
+ * for tests and tools that switch a knob inside one process; not to be called while another thread is inside the library.
+ * No faiss counterpart. */
+int mi_ivfpq_reload_env(void);
+
 /* ---- building blocks used by train() in the Python mirror ---------- */
 
 /* out[n][nc] = x . c^T (+ bias[nc] when not NULL), exact f32 (every element an ascending-k fmaf chain: the coarse

@@ -45,3 +45,42 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def _reload_native_env():
+    """the HIP libraries read their MI_* knobs once; tests that switch one call the libraries' reload hooks (only libraries
+    this process has loaded already: a CPU test never builds or loads one through here)"""
+    mods = sys.modules
+    st = mods.get("abstracts_search_amd.sentence_transformers")
+    fa = mods.get("abstracts_search_amd.faiss")
+    if st is not None and getattr(st._Lib, "_lib", None) is not None:
+        st.reload_env()
+    if fa is not None and getattr(fa._Lib, "_lib", None) is not None:
+        fa.reload_env()
+
+
+class _KnobPatch:
+    """pytest's monkeypatch, with setenv / delenv of an MI_* name followed by the libraries' reload_env()"""
+
+    def __init__(self, mp):
+        self._mp = mp
+
+    def setenv(self, name, value, prepend=None):
+        self._mp.setenv(name, value, prepend)
+        if name.startswith("MI_"):
+            _reload_native_env()
+
+    def delenv(self, name, raising=True):
+        self._mp.delenv(name, raising)
+        if name.startswith("MI_"):
+            _reload_native_env()
+
+    def __getattr__(self, attr):
+        return getattr(self._mp, attr)
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    yield _KnobPatch(monkeypatch)
+    monkeypatch.undo()
+    _reload_native_env()

@@ -695,7 +695,7 @@ def test_pretransform_apply_is_the_exact_gemm_and_the_file_round_trips(faiss, or
     d_in, d, M, nlist = 96, 64, 8, 16
     cent, cb, x, q = random_problem(41, d, M, nlist, 2500, 40)
     rng = np.random.default_rng(4)
-    A = rng.standard_normal((d, d_in)).astype(np.float32) / np.sqrt(d_in)
+    A = rng.standard_normal((d, d_in)).astype(np.float32) / np.float32(np.sqrt(d_in))   # (a float64 scalar would promote the matrix)
     b = rng.standard_normal(d).astype(np.float32)
     R = np.linalg.qr(rng.standard_normal((d, d)))[0].astype(np.float32)
     idx = make_index(faiss, cent, cb)
