@@ -35,6 +35,7 @@ struct Knobs {
     bool no_bulk_fuse, no_rope_fuse, no_norm_fuse;   // MI_NO_BULK_FUSE / MI_NO_ROPE_FUSE / MI_NO_NORM_FUSE: standalone rmsnorm / rope kernels
     bool no_mid_gemm;        // MI_NO_MID_GEMM=1: round 4's K-split planes for the QKV / O projections of a few hundred tokens
     std::string mid_tile;    // MI_MID_TILE=128x128|128x64|96x64|64x64: one tile shape for encoder_mid.h
+    bool no_short_attn;      // MI_NO_SHORT_ATTN=1: the persistent flash-attention kernel for batches of short sequences too
     bool no_m192;            // MI_NO_M192=1: 256-row slab tiles where 192-row ones would pay
     int splitk;              // MI_SPLITK=S: K slices of the all-tiles split (-1: by shape)
     int pool_gemm;           // MI_POOL_GEMM=0: the per-sequence pooling kernel for every batch size
@@ -53,6 +54,7 @@ struct Knobs {
         no_mid_gemm = set("MI_NO_MID_GEMM");
         mid_tile = str("MI_MID_TILE");
         no_m192 = set("MI_NO_M192");
+        no_short_attn = set("MI_NO_SHORT_ATTN");
         splitk = num("MI_SPLITK", -1);
         pool_gemm = num("MI_POOL_GEMM", -1);
         no_few = set("MI_NO_FEW");
@@ -74,6 +76,7 @@ std::atomic<int64_t> g_n192_launches{0};
 std::atomic<int64_t> g_m192_launches{0};      // slab GEMMs on 192-row tiles
 std::atomic<int64_t> g_fused_norm_launches{0};   // residual slab GEMMs whose epilogue carried the next RMSNorm (GEMM_RAWNORM)
 std::atomic<int64_t> g_fused_rope_launches{0};   // QKV slab GEMMs whose epilogue rotated Q and K
+std::atomic<int64_t> g_short_attn_launches{0};   // attention launches of the general path that took few_attn_kernel (every sequence <= 48 tokens)
 std::atomic<int64_t> g_mid_launches{0};   // QKV / O projections on the one-launch whole-K tiles of encoder_mid.h
 std::atomic<int64_t> g_few_passes{0};     // forward passes that took the query-time path (encoder_few.h)
 
@@ -848,6 +851,16 @@ void launch_attention(mi_encoder *h, const Batch &b, const bf16_t *qk, const bf1
     a.seq_start = b.seq_start; a.seq_len = b.seq_len; a.ldqk = h->qk_cols; a.ldvt = ldvt;
     a.n_heads = c.n_heads; a.n_kv = c.n_kv_heads; a.causal = c.causal;
     a.scale = 1.0f / std::sqrt((float)hd);
+    // every sequence short enough for one pass over its keys (a batch of queries): one wave per (head, 16-query tile), no LDS,
+    // no online softmax -- few_attn_kernel (encoder_few.h)
+    if (b.Lmax <= FEW_MAX_T && (hd == 64 || hd == 128) && !knobs().no_short_attn && b.nwork > 0 && b.nwork <= 24) {   // (16 queries: 6.3 vs 7.9 us; 64: 13.0 vs 11.0 -- a wave per tile is one latency chain each)
+        const dim3 ga((unsigned)c.n_heads, (unsigned)(b.nwork * 3));
+        if (hd == 128) hipLaunchKernelGGL((few_attn_kernel<128>), ga, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((few_attn_kernel<64>), ga, dim3(64), 0, st, a);
+        MI_HIP(hipGetLastError());
+        ++g_short_attn_launches;
+        return;
+    }
     // two query heads of one K/V head per workgroup when the GQA group allows it
     const bool pair = c.n_heads % 2 == 0 && (c.n_heads / c.n_kv_heads) % 2 == 0;
     a.nwork = b.nwork;
@@ -1574,6 +1587,7 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
         else if (std::string(name) == "fused_rope_launches") *value = g_fused_rope_launches.load();
         else if (std::string(name) == "few_passes") *value = g_few_passes.load();
         else if (std::string(name) == "mid_launches") *value = g_mid_launches.load();
+        else if (std::string(name) == "short_attn_launches") *value = g_short_attn_launches.load();
         else throw Error(std::string("unknown debug counter: ") + name);
     });
 }

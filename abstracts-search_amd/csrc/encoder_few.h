@@ -621,7 +621,8 @@ __global__ void __launch_bounds__(256) few_row_kernel(FewArgs a) {
 // one wave per (head, 16-query tile of a sequence).  Computed transposed like attn_kernel (encoder_kernels.h): S^T = K Q^T
 // with MFMA row position p of key tile j standing for key 32 (j / 2) + 8 (p / 4) + 4 (j % 2) + p % 4, so that the lane's
 // probabilities of tiles 2 J, 2 J + 1 are the B fragment of the P V product as they stand; O^T = V^T P^T leaves four
-// consecutive dims of one query per lane, written as fragments of the O projection's operand.  Q, K rows and V^T rows come
+// consecutive dims of one query per lane, written as fragments of the O projection's operand (the query-time path) or as
+// rows of O (a batch of short sequences on the general path: 16 queries 7.8 -> ~5 us a layer against the persistent kernel).  Q, K rows and V^T rows come
 // straight from global memory (all 36 loads of a lane requested at once: the kernel is one latency chain).  The key axis
 // starts at the sequence's first token rounded down to 8 (V^T rows are fetched in 16-byte pieces); the < 8 foreign keys in
 // front and the keys past the end are masked.
@@ -705,14 +706,17 @@ __global__ void __launch_bounds__(64) few_attn_kernel(AttnArgs a) {
     if (qidx < L) {
         const float inv = sum > 0.f ? 1.0f / sum : 0.f;
         const int tok = s0 + qidx;
-        // dims h HD + 16 n + 4 lg + r -> piece (step (h HD + 16 n) / 32, tile tok / 16), lane (2 (n & 1) + lg / 2, tok % 16), half lg & 1
-        bf16_t *op = a.Ofrag + (((size_t)(h * (HD / 32)) * a.frag_mt + (tok >> 4)) * 64 + (lg >> 1) * 16 + (tok & 15)) * 8 + 4 * (lg & 1);
+        // dims h HD + 16 n + 4 lg + r -> piece (step (h HD + 16 n) / 32, tile tok / 16), lane (2 (n & 1) + lg / 2, tok % 16), half lg & 1;
+        // or (Ofrag null: a batch of short sequences on the general path) row tok of O, 4 consecutive dims per lane and tile
+        bf16_t *op = a.Ofrag ? a.Ofrag + (((size_t)(h * (HD / 32)) * a.frag_mt + (tok >> 4)) * 64 + (lg >> 1) * 16 + (tok & 15)) * 8 + 4 * (lg & 1)
+                             : a.O + (size_t)tok * (a.n_heads * HD) + h * HD + 4 * lg;
 #pragma unroll
         for (int n = 0; n < NDT; ++n) {
             uint2 pk;
             pk.x = pack2(o[n][0] * inv, o[n][1] * inv);
             pk.y = pack2(o[n][2] * inv, o[n][3] * inv);
-            *reinterpret_cast<uint2 *>(op + ((size_t)(n >> 1) * a.frag_mt * 64 + (n & 1) * 32) * 8) = pk;
+            const size_t off = a.Ofrag ? ((size_t)(n >> 1) * a.frag_mt * 64 + (n & 1) * 32) * 8 : (size_t)n * 16;
+            *reinterpret_cast<uint2 *>(op + off) = pk;
         }
     }
 }

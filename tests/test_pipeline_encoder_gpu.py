@@ -427,7 +427,7 @@ def test_one_launch_projections_vs_the_k_split_path_and_oracle(st, lens, monkeyp
 
 
 @pytest.mark.parametrize("env", [{"MI_MID_TILE": "128x128"}, {"MI_MID_TILE": "128x64"}, {"MI_MID_TILE": "96x64"}, {"MI_MID_TILE": "64x64"},
-                                 {"MI_SPLITK": "4"}, {"MI_SPLITK": "14"}, {"MI_NO_FEW": "1"}])
+                                 {"MI_SPLITK": "4"}, {"MI_SPLITK": "14"}, {"MI_NO_FEW": "1"}, {"MI_NO_SHORT_ATTN": "1"}])
 def test_dispatch_knobs_keep_the_embeddings(st, env, monkeypatch):
     """The tool knobs that force a tile shape of encoder_mid.h (every instantiation at one token count), the K-slice count of
     the down projection's all-tiles split, and the general path for a handful of tokens (MI_NO_FEW): same embeddings as the
@@ -442,12 +442,15 @@ def test_dispatch_knobs_keep_the_embeddings(st, env, monkeypatch):
     lens = [7, 22] if "MI_NO_FEW" in env else [37] * 9 + [48] * 5
     toks = [rng.integers(0, cfg["vocab_size"], int(L)).tolist() for L in lens]
     base = st.SentenceTransformer(config=cfg, weights=W).encode_tokens(toks, batch_size=len(toks), normalize_embeddings=True)
-    few0 = st.debug_counter("few_passes")
+    few0, sa0 = st.debug_counter("few_passes"), st.debug_counter("short_attn_launches")
+    assert sa0 > 0 or "MI_NO_FEW" in env                       # (every sequence <= 48 tokens: one wave per head and query tile)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     out = st.SentenceTransformer(config=cfg, weights=W).encode_tokens(toks, batch_size=len(toks), normalize_embeddings=True)
     if "MI_NO_FEW" in env:
         assert st.debug_counter("few_passes") == few0          # the query-time path stayed out
+    if "MI_NO_SHORT_ATTN" in env:
+        assert st.debug_counter("short_attn_launches") == sa0  # the persistent flash-attention kernel took them
     Wc = {k: v.float().cpu() for k, v in W.items()}
     with torch.no_grad():
         ref = E.encode(E.EncoderConfig(**cfg), Wc, np.concatenate(toks), np.concatenate([[0], np.cumsum(lens)]), True).numpy()
