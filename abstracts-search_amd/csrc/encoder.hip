@@ -36,6 +36,8 @@ struct Knobs {
     bool no_mid_gemm;        // MI_NO_MID_GEMM=1: round 4's K-split planes for the QKV / O projections of a few hundred tokens
     std::string mid_tile;    // MI_MID_TILE=128x128|128x64|96x64|64x64: one tile shape for encoder_mid.h
     bool no_short_attn;      // MI_NO_SHORT_ATTN=1: the persistent flash-attention kernel for batches of short sequences too
+    int krot;                // MI_KROT=n: K tiles between the starts of consecutive row tiles (default 3; -1: K / row tiles)
+    bool no_krot;            // MI_NO_KROT=1: one-round GEMMs walk K from 0 in every row tile (GemmArgs::krot off)
     bool no_m192;            // MI_NO_M192=1: 256-row slab tiles where 192-row ones would pay
     int splitk;              // MI_SPLITK=S: K slices of the all-tiles split (-1: by shape)
     int pool_gemm;           // MI_POOL_GEMM=0: the per-sequence pooling kernel for every batch size
@@ -54,6 +56,8 @@ struct Knobs {
         no_mid_gemm = set("MI_NO_MID_GEMM");
         mid_tile = str("MI_MID_TILE");
         no_m192 = set("MI_NO_M192");
+        no_krot = set("MI_NO_KROT");
+        krot = num("MI_KROT", 3);      // 563 tokens, forward pass: off 3.192 ms, 1 / 2 / 3 / 4 K tiles 3.171 / 3.158 / 3.142 / 3.147, K / row tiles 3.157
         no_short_attn = set("MI_NO_SHORT_ATTN");
         splitk = num("MI_SPLITK", -1);
         pool_gemm = num("MI_POOL_GEMM", -1);
@@ -202,6 +206,8 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
             nblocks = 8u * (unsigned)((ntiles * S + 7) / 8);   // fetch 124 -> ~40 MB at 576 tokens
         }
     }
+    // one round of workgroups: the row tiles of a column strip run side by side -- each walks K from its own offset (GemmArgs::krot)
+    g.krot = (!knobs().no_krot && nblocks <= 256 && g.tiles_m > 1 && g.tail_split == (split_all > 1 ? split_all : 1)) ? knobs().krot : 0;
     dim3 grid(nblocks), block(128 * WN_);
     constexpr int CW = 16 * (16 / WN_);                   // columns per wave = per slot of sums of squares
     const int nslots = (g.N + CW - 1) / CW;
@@ -449,6 +455,7 @@ void launch_mid_t(GemmArgs g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     const int per = (g.tiles_m * g.tiles_n + 7) / 8;
+    g.krot = (!knobs().no_krot && 8 * per <= 512 && g.tiles_m > 1) ? knobs().krot : 0;
     hipLaunchKernelGGL((mid_gemm_kernel<EPI, WMT, WNT, NS>), dim3((unsigned)(8 * per)), dim3(256), lds, st, g);
     MI_HIP(hipGetLastError());
 }

@@ -309,6 +309,12 @@ struct GemmArgs {
     //     lane's 4 consecutive columns hold two whole pairs; rope_cs[pos][f] = (cos, sin).  Q and K leave in the interleaved
     //     order -- the attention scores are dot products over the head, indifferent to a permutation applied to both.
     float *ssq_out;
+    int krot;              // one-round launches (slab kernel, encoder_mid.h): row tile tm walks its K tiles from tm x krot round the end
+                           // instead of from 0 (-1: from tm x tiles / tiles_m).  The row tiles of a column strip run side by side on one
+                           // XCD and otherwise ask for the same W line at the same moment, each waiting out the miss; a few K tiles apart,
+                           // one takes the miss and the others find the line in L2.  Worth 1.6 % of a 563-token forward pass -- a CU's
+                           // stream is capped elsewhere: ~32 KB of lines in flight whatever the ring holds (tools/micro/w_stream.hip:
+                           // 36 GB/s per CU from HBM, 57 from the Infinity Cache, 64 or 128 KiB requested ahead alike)
     float *rms_out;        // encoder_mid.h, residual epilogue with ssq_out: the last tile of a row block to arrive writes 1/rms of
     unsigned *arrive;      // the block's rows here (arrive[row block] counts the tiles; zero before and after a launch)
     const float *row_scale;
@@ -936,7 +942,9 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     static_assert(WMT_ == 8 || WMT_ == 6, "row tiles of 256 or 192");
     static_assert(BN <= 256 && (WNT_ == 16 / WN_ || EPI == EPI_RESID), "narrower tiles: residual epilogue only");
     static_assert(WMT_ == 8 || !PERSIST, "192-row tiles: one unit per workgroup");
-    constexpr int PPW = 32 / NW;                             // DMA pieces (1 KiB: 8 rows x 128 B) per wave per slab
+    constexpr int PPW = 32 / NW;                             // DMA pieces (1 KiB: 8 rows x 128 B) per wave per W slab
+    constexpr int PA = (BM / 8) / NW;                        // ... per A slab: a 192-row tile requests its 24 pieces, not the 32 of the slot
+    static_assert(PA * NW * 8 == BM && PA <= PPW, "A pieces");
     constexpr int NS = 5, DQ = 4;                            // slabs in the ring, request distance in slabs
     constexpr unsigned SLAB_B = 256 * 128;                   // 32 KiB
     constexpr int NMF = WMT * WNT, NRD = WMT + WNT;          // MFMAs / fragment reads per wave per step
@@ -1003,22 +1011,33 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     const int prow = lane >> 3, scol = ((lane & 7) ^ prow) * 8;
     const int scolW[2] = {((lane & 7) ^ (prow & 3)) * 8, ((lane & 7) ^ ((prow & 3) | 4)) * 8};   // even / odd piece (bit 3 of the row)
     const unsigned dma_dst = lds0 + (unsigned)w * PPW * 1024u;       // + slot * SLAB_B + p * 1024
-    const bf16_t *srcA[PPW], *srcW[PPW];
+    const unsigned dma_dstA = lds0 + (unsigned)w * PA * 1024u;
+    const bf16_t *srcA[PA], *srcW[PPW];
     auto set_sources = [&](int tm_, int tn_, int kt0_) {
 #pragma unroll
         for (int p = 0; p < PPW; ++p) {
             const int r = (w * PPW + p) * 8 + prow;
-            srcA[p] = g.A + (size_t)min(tm_ * BM + r, g.M - 1) * g.lda + scol + (size_t)kt0_ * 64;
             srcW[p] = g.W + (size_t)min(tn_ * BN + r, g.N - 1) * g.ldw + scolW[p & 1] + (size_t)kt0_ * 64;   // PPW is even: piece parity = p & 1
         }
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int r = (w * PA + p) * 8 + prow;
+            srcA[p] = g.A + (size_t)min(tm_ * BM + r, g.M - 1) * g.lda + scol + (size_t)kt0_ * 64;
+        }
     };
+    int krot = 0, kn = 1;                                    // GemmArgs::krot: the unit's K tiles are walked from krot round the end
+    auto kmap = [&](int t) -> size_t { const int r = t + krot; return (size_t)(r >= kn ? r - kn : r) * 64; };
     auto request_first = [&](int nk_) {                      // slabs 0 .. DQ-1 into ring slots 0 .. DQ-1
 #pragma unroll
         for (int q = 0; q < DQ; ++q)
             if (q < nk_) {
+                if (q & 1) {
 #pragma unroll
-                for (int p = 0; p < PPW; ++p)
-                    dma16_off(((q & 1) ? srcW[p] : srcA[p]) + (size_t)(q >> 1) * 64, dma_dst + q * SLAB_B + p * 1024u);
+                    for (int p = 0; p < PPW; ++p) dma16_off(srcW[p] + kmap(q >> 1), dma_dst + q * SLAB_B + p * 1024u);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < PA; ++p) dma16_off(srcA[p] + kmap(q >> 1), dma_dstA + q * SLAB_B + p * 1024u);
+                }
             }
     };
 
@@ -1048,7 +1067,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
         // slab u + DQ: DQ even -> an A slab in even steps, a W slab in odd steps; tile (u + DQ) >> 1
         const unsigned sd = wrap(c + par + DQ);
         const bool dma_on = decltype(STEADY)::value || u + DQ < nk;
-        const size_t koff = (size_t)((u + DQ) >> 1) * 64;
+        const size_t koff = kmap((u + DQ) >> 1);
         static_for<NMF>([&](auto M_) {
             constexpr int m = decltype(M_)::value, i = m / WNT, j = m % WNT;
             mfma(acc[i][j], ac[i], bc[j]);
@@ -1059,7 +1078,13 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
             }
             if constexpr (m % DSTEP == DSTEP - 1) {
                 constexpr int p = m / DSTEP;
-                if (dma_on) dma16_off((par == 0 ? srcA[p] : srcW[p]) + koff, dma_dst + sd * SLAB_B + p * 1024u);
+                if constexpr (par == 0) {
+                    if constexpr (p < PA) {
+                        if (dma_on) dma16_off(srcA[p] + koff, dma_dstA + sd * SLAB_B + p * 1024u);
+                    }
+                } else {
+                    if (dma_on) dma16_off(srcW[p] + koff, dma_dst + sd * SLAB_B + p * 1024u);
+                }
             }
         });
     };
@@ -1083,6 +1108,8 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     }
     if (!decode(unit, tm, tn, ksplit, kt0, nk)) return;
     set_sources(tm, tn, kt0);
+    kn = max(nk >> 1, 1);
+    krot = g.krot < 0 ? (int)(((long)tm * kn) / g.tiles_m) : (tm * g.krot) % kn;
     request_first(nk);
     // fused RMSNorm (consumer side) / rotary positions: lane l keeps the scale (position) of rows l and 64 + l of the wave's
     // 128 rows; the epilogue fetches its rows' values with ds_bpermute.  Requested right behind the first slabs, so the
@@ -1108,7 +1135,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
 
     // slabs 0 and 1 landed (after a previous unit's epilogue its stores count as well: more conservative, never less --
     // loads return in order among themselves); fragments of step 0 read
-    wait_tiles<PPW, DQ - 2>(max(0, min(DQ - 2, nk - 2)), false);
+    wait_tiles<PA, DQ - 2>(max(0, min(DQ - 2, nk - 2)), false);   // (PA <= PPW pieces per slab: never fewer landed than needed)
     asm volatile("s_barrier" ::: "memory");
     stamp(1);
     static_for<WNT>([&](auto R) { lds_read16<slab_w_tile_off<PERM>(decltype(R)::value)>(b0[decltype(R)::value], rdB + SLAB_B); });
@@ -1117,19 +1144,20 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     unsigned c = 0;                                          // ring slot of the current tile's A slab
     int u = 0;
     for (; u + DQ + 1 < nk; u += 2) {                        // steady state, branch-free
-        wait_vm_lgkm0<(DQ - 2) * PPW>();                     // even step: reads the second half of slabs that landed a step ago
+        static_assert(DQ == 4, "the two slabs in flight at an even step are one A and one W slab");
+        wait_vm_lgkm0<PA + PPW>();                           // even step: reads the second half of slabs that landed a step ago
         asm volatile("s_barrier" ::: "memory");
         step(a0, b0, a1, b1, P0{}, T_{}, u, c);
-        wait_vm_lgkm0<(DQ - 3) * PPW>();
+        wait_vm_lgkm0<PA>();                                 // odd step: only the A slab requested a step ago may be in flight
         asm volatile("s_barrier" ::: "memory");
         step(a1, b1, a0, b0, P1{}, T_{}, u + 1, c);
         c = wrap(c + 2);
     }
     for (; u < nk; u += 2) {                                 // the last steps: fewer slabs in flight, no new requests
-        wait_tiles<PPW, DQ - 3>(max(0, min(DQ - 3, nk - 3 - u)), true);
+        wait_tiles<PA, DQ - 3>(max(0, min(DQ - 3, nk - 3 - u)), true);
         asm volatile("s_barrier" ::: "memory");
         step(a0, b0, a1, b1, P0{}, F_{}, u, c);
-        wait_tiles<PPW, DQ - 3>(max(0, min(DQ - 3, nk - 4 - u)), true);
+        wait_tiles<PA, DQ - 3>(max(0, min(DQ - 3, nk - 4 - u)), true);
         asm volatile("s_barrier" ::: "memory");
         step(a1, b1, a0, b0, P1{}, F_{}, u + 1, c);
         c = wrap(c + 2);

@@ -67,9 +67,12 @@ __global__ void __launch_bounds__(256, (NS * (WMT + WNT) * 4096 <= 80 * 1024 ? 2
         }
     }
     const int nslab = g.K / 64;
+    const int krot = g.krot < 0 ? (int)(((long)tm * nslab) / g.tiles_m) : (tm * g.krot) % nslab;   // GemmArgs::krot: the row tiles of a column strip start at different K
     auto issue = [&](int s, unsigned slot) {
+        const int r = s + krot;
+        const size_t ko = (size_t)(r >= nslab ? r - nslab : r) * 64;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) dma16_off(src[i] + (size_t)s * 64, lds0 + slot * STAGE_B + dst[i]);
+        for (int i = 0; i < PPW; ++i) dma16_off(src[i] + ko, lds0 + slot * STAGE_B + dst[i]);
     };
 #pragma unroll
     for (int s = 0; s < D; ++s)

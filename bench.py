@@ -668,6 +668,8 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     # near-identical cluster mates needs) and, only when a longer list stops helping, the number of probes (list coverage).  On
     # the 207 M configuration nprobe 8 already holds the neighbours (16 / 32 / 64 probes change no digit at a given k_factor).
     kfs = [f for f in (64, 72, 80, 100, 128, 160, 200, 256, 320, 400, 512, 640, 800) if k * f <= 8192]
+    if os.environ.get("BENCH_REFINE_KFS"):                            # counter passes: the timed shape only (tools/prof_r05.sh)
+        kfs = [int(v) for v in os.environ["BENCH_REFINE_KFS"].split(",")]
     best, curve, i_kf, done = None, [], 0, False
 
     def recall_on(qs, rows):
@@ -766,9 +768,13 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
         ncand = int((cI[0] >= 0).sum().item())
         rr_bytes = ncand * D_MODEL * relem                               # every candidate's stored row, read once
         ach = rr_bytes / (ms_rr * 1e-3) / 1e9
+        # the re-rank kernel's HBM-side bytes at THIS shape (counter passes with the sweep pinned: tools/prof_r05.sh cfg4)
+        pmc, rr_traffic_src = committed_traffic("r05_cfg4_refine_pmc.json", lambda d_: relem == 1 and world == 1 and
+                                                 tuple(d_["config"]) == (int(base.ntotal), int(base.nlist), batch, nprobe, kf, k))
         roofline = {"kernel": {1: "rerank_sq8_kernel", 2: "rerank_f16_kernel", 4: "rerank_f32_kernel"}[relem] + " (streaming re-rank of k*k_factor candidates per query)",
                     "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                    "traffic": None, "bytes_per_launch": int(rr_bytes), "avg_launch_ms": round(ms_rr, 5),
+                    "traffic": int(pmc["corrected_bytes_per_launch"]) if pmc else None, "traffic_source": rr_traffic_src,
+                    "bytes_per_launch": int(rr_bytes), "avg_launch_ms": round(ms_rr, 5),
                     "algorithmic_bytes": "candidates x d x %d B (the stored row of every candidate, read once)" % relem,
                     "step_split_ms": {"candidates (coarse + LUT + all-scores scan + set selection)": round(ms_cand, 4),
                                       "re-rank (query table + streaming kernel + top-k)": round(ms_rr, 4),
@@ -932,9 +938,11 @@ def cfg5_curve(args, ctx, model, cfg, host_w, index, sharded, nprobe, k, steps, 
             roof = {"bound": "mfma", "achieved": round(flops / enc / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                     "frac": round(flops / enc / 2.5e15, 4), "flops_per_launch": flops,
                     "algorithmic_flops": "2 x parameters x tokens + 4 x layers x q_cols x sum(len^2) (attention)"}
+        qp, q_src = committed_traffic("r05_encode_query_pmc.json", lambda d_: any(r_.get("tokens") == ntok for r_ in d_["regimes"].values()))
+        q_traffic = [r_["bytes_per_pass"] for r_ in qp["regimes"].values() if r_.get("tokens") == ntok][0] if qp else None
         roof.update({"kernel": "the encoder forward pass (%s)" % ("csrc/encoder_few.h: six weight-streaming launches per layer" if ntok <= 48 else
                                                                     "general path: MFMA GEMM tiles by token count"),
-                     "traffic": None, "avg_launch_ms": round(enc * 1e3, 4), "what": "encode alone, back-to-back calls"})
+                     "traffic": q_traffic, "traffic_source": q_src, "avg_launch_ms": round(enc * 1e3, 4), "what": "encode alone, back-to-back calls"})
         curve.append({"batch": batch, "latency_ms_p50": round(lat[len(lat) // 2] * 1e3, 3),
                       "latency_ms_p95": round(lat[min(len(lat) - 1, int(0.95 * len(lat)))] * 1e3, 3),
                       "queries_per_s": round(steps * batch / dt, 1), "encode_alone_ms": round(enc * 1e3, 3),

@@ -427,7 +427,7 @@ def test_one_launch_projections_vs_the_k_split_path_and_oracle(st, lens, monkeyp
 
 
 @pytest.mark.parametrize("env", [{"MI_MID_TILE": "128x128"}, {"MI_MID_TILE": "128x64"}, {"MI_MID_TILE": "96x64"}, {"MI_MID_TILE": "64x64"},
-                                 {"MI_SPLITK": "4"}, {"MI_SPLITK": "14"}, {"MI_NO_FEW": "1"}, {"MI_NO_SHORT_ATTN": "1"}])
+                                 {"MI_SPLITK": "4"}, {"MI_SPLITK": "14"}, {"MI_NO_FEW": "1"}, {"MI_NO_SHORT_ATTN": "1"}, {"MI_NO_KROT": "1"}, {"MI_KROT": "-1"}])
 def test_dispatch_knobs_keep_the_embeddings(st, env, monkeypatch):
     """The tool knobs that force a tile shape of encoder_mid.h (every instantiation at one token count), the K-slice count of
     the down projection's all-tiles split, and the general path for a handful of tokens (MI_NO_FEW): same embeddings as the
