@@ -22,7 +22,14 @@ for l in range(cfg["n_layers"]):
         p + "mlp.up_proj.weight": rnd((I, H), H ** -0.5), p + "mlp.down_proj.weight": rnd((H, I), I ** -0.5)})
 nq, reps = int(os.environ.get("ENC_NQ", 16)), int(os.environ.get("ENC_REPS", 30))
 rng = np.random.default_rng(1)
-toks = [rng.integers(0, cfg["vocab_size"], int(rng.integers(16, 49))).tolist() for _ in range(nq)]
+toks = None
+if nq in (1, 16, 256):                                   # bench.py's cfg5 batches, drawn in its order (1, 16, 256): 31 / 570 / 8 097 tokens
+    for b in (1, 16, 256):
+        toks = [rng.integers(0, cfg["vocab_size"], int(rng.integers(16, 49))).tolist() for _ in range(b)]
+        if b == nq:
+            break
+else:
+    toks = [rng.integers(0, cfg["vocab_size"], int(rng.integers(16, 49))).tolist() for _ in range(nq)]
 for _ in range(3): model.encode_tokens(toks, batch_size=nq, normalize_embeddings=True, as_tensor=True)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(reps): model.encode_tokens(toks, batch_size=nq, normalize_embeddings=True, as_tensor=True)
