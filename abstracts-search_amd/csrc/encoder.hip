@@ -38,6 +38,7 @@ struct Knobs {
     bool no_short_attn;      // MI_NO_SHORT_ATTN=1: the persistent flash-attention kernel for batches of short sequences too
     int krot;                // MI_KROT=n: K tiles between the starts of consecutive row tiles (default 3; -1: K / row tiles)
     bool no_krot;            // MI_NO_KROT=1: one-round GEMMs walk K from 0 in every row tile (GemmArgs::krot off)
+    int down_bn;             // MI_DOWN_BN=128|192|256: columns of the down projection's K-split tiles (0: by the cost model)
     bool no_m192;            // MI_NO_M192=1: 256-row slab tiles where 192-row ones would pay
     int splitk;              // MI_SPLITK=S: K slices of the all-tiles split (-1: by shape)
     int pool_gemm;           // MI_POOL_GEMM=0: the per-sequence pooling kernel for every batch size
@@ -56,6 +57,7 @@ struct Knobs {
         no_mid_gemm = set("MI_NO_MID_GEMM");
         mid_tile = str("MI_MID_TILE");
         no_m192 = set("MI_NO_M192");
+        down_bn = num("MI_DOWN_BN", 0);
         no_krot = set("MI_NO_KROT");
         krot = num("MI_KROT", 3);      // 563 tokens, forward pass: off 3.192 ms, 1 / 2 / 3 / 4 K tiles 3.171 / 3.158 / 3.142 / 3.147, K / row tiles 3.157
         no_short_attn = set("MI_NO_SHORT_ATTN");
@@ -141,11 +143,11 @@ void launch_ring(int epi, GemmArgs g, hipStream_t st) {
 }
 
 // 256x256 tiles, slab ring + hand-ordered K loop (gemm_bf16_slab_kernel; WN_ = 4: 8 waves, 2: 4 waves): whole-K workgroups, the same wave-quantisation tail split
-template <int WN_, int WMT_ = 8>
+template <int WN_, int WMT_ = 8, int WNT_ = 16 / WN_>
 int launch_slab(int epi, GemmArgs g, hipStream_t st) {
-    constexpr int BM = 32 * WMT_;
+    constexpr int BM = 32 * WMT_, BN = WN_ * WNT_ * 16;
     g.tiles_m = (g.M + BM - 1) / BM;
-    g.tiles_n = (g.N + 255) / 256;
+    g.tiles_n = (g.N + BN - 1) / BN;
     const int per = (g.tiles_m * g.tiles_n + 7) / 8;
     g.ksplit = 1;
     unsigned nblocks = 8u * per;
@@ -209,7 +211,7 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
     // one round of workgroups: the row tiles of a column strip run side by side -- each walks K from its own offset (GemmArgs::krot)
     g.krot = (!knobs().no_krot && nblocks <= 256 && g.tiles_m > 1 && g.tail_split == (split_all > 1 ? split_all : 1)) ? knobs().krot : 0;
     dim3 grid(nblocks), block(128 * WN_);
-    constexpr int CW = 16 * (16 / WN_);                   // columns per wave = per slot of sums of squares
+    constexpr int CW = 16 * WNT_;                         // columns per wave = per slot of sums of squares
     const int nslots = (g.N + CW - 1) / CW;
     if (split_all > 1 || nslots > SSQ_LD) g.ssq_out = nullptr;
     const int rawnorm = epi == EPI_RESID && g.ssq_out ? (GEMM_RAWNORM | nslots << 8) : 0;
@@ -228,7 +230,11 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
         }
         MI_HIP(hipGetLastError());
     };
-    if constexpr (WMT_ == 6) {                            // 192-row tiles: the two epilogues the few-hundred-token passes send here
+    if constexpr (WNT_ != 16 / WN_) {                     // narrow tiles: the K-split down projection of a few hundred tokens
+        MI_REQUIRE(epi == EPI_RESID && (split_all > 1 || WMT_ == 8), "narrow slab tiles: residual epilogue, K split or 256-row tiles");
+        if (WMT_ == 6) ++g_m192_launches;
+        hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, WN_, false, WNT_, WMT_>), grid, block, 0, st, g);
+    } else if constexpr (WMT_ == 6) {                     // 192-row tiles: the two epilogues the few-hundred-token passes send here
         ++g_m192_launches;
         switch (epi) {
             case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, WN_, false, 16 / WN_, 6>), grid, block, 0, st, g); break;
@@ -535,7 +541,26 @@ int launch_gemm(int epi, GemmArgs g, hipStream_t st) {
             // workspace (launch_slab) -- 576 x 1536 x 8960: 18 tiles x 14 slices = 252 workgroups of 20 K steps + one reduction
             // pass, where 128x128 tiles with K split three ways by f32 atomics took 76 us; at 1558 / 2097 tokens the forward
             // pass went 7.91 -> 6.46 / 9.21 -> 7.82 ms against the 128x128 ring tiles
-            return m192_pays(g) ? launch_slab<2, 6>(epi, g, st) : launch_slab<2>(epi, g, st);
+            // Columns of the K-split tiles.  What a slice costs is its operand stream, (BM + BN) x K / S x 2 bytes at the ~50 GB/s
+            // a CU pulls, and its share of the S planes leaving and coming back (S x M x N x 4 bytes at ~3.2 and ~3.6
+            // TB/s chip-wide): narrower tiles are more tiles, hence fewer, longer slices -- fewer planes.  563 tokens, forward
+            // pass: 256 columns x 10 slices 3.246 ms, 128 x 7 3.09, 128 x 6 / 5 3.11 / 3.17, 64 x 3 3.33 (the model: 36.7 / 30.9 /
+            // 31.5 / 33.2 / 36.8 us a launch + pass).  MI_DOWN_BN forces one width.
+            const bool m192 = m192_pays(g);
+            const int bm = m192 ? 192 : 256, tm_ = (g.M + bm - 1) / bm, nt64 = g.K / 64;
+            int bn = 256;
+            double best = 1e30;
+            for (int c : {256, 192, 128}) {
+                if (knobs().down_bn && knobs().down_bn != c) continue;
+                const int ntiles = tm_ * ((g.N + c - 1) / c), per = (ntiles + 7) / 8;
+                const int S = std::min({10, 256 / std::max(1, ntiles), nt64 / 4});
+                if (8 * per >= 200 || S < 2 || (size_t)S * g.M * g.N * 4 > g.part_bytes) continue;
+                const double cost = (double)(bm + c) * ((double)g.K / S) * 2.0 / 50e3 + (double)S * g.M * g.N * 4.0 * 0.59e-6;
+                if (cost < best) { best = cost; bn = c; }
+            }
+            if (bn == 128) return m192 ? launch_slab<2, 6, 4>(epi, g, st) : launch_slab<2, 8, 4>(epi, g, st);
+            if (bn == 192) return m192 ? launch_slab<2, 6, 6>(epi, g, st) : launch_slab<2, 8, 6>(epi, g, st);
+            return m192 ? launch_slab<2, 6>(epi, g, st) : launch_slab<2>(epi, g, st);
         } else if (cfg == "big" && !force && epi == EPI_RESID && n192_pays(g)) {
             return launch_slab_n192(g, st);
         } else if (cfg == "big" && !knobs().gemm_ring && (epi == EPI_SWIGLU ? g.ldc % 8 == 0 : g.N % 8 == 0)) {   // the slab kernel stores 8 bf16 columns per lane

@@ -929,31 +929,32 @@ __host__ __device__ constexpr int slab_w_tile_off(int j) {
     return (PERM == 1 ? 32 * (j / 2) + 4 * (j % 2) : PERM == 2 ? 64 * (j / 4) + 16 * (j % 2) + 4 * ((j / 2) % 2) : 16 * j) * 128;
 }
 
-// WNT_ (16-column MFMA tiles per wave along N): 16 / WN_ gives the 256-column tile; WN_ = 2, WNT_ = 6 is a 256 x 192 tile
-// (residual epilogue only) for the token counts at which N = 1536 yields 130-190 tiles of 256 columns on 256 CUs and
-// exactly <= 256 tiles of 192 -- the W slabs keep their 32 KiB slots and all 32 pieces (rows 192..255 are never read), so
-// nothing of the DMA / wait schedule changes; a step is 48 MFMAs and 14 fragment reads.
-// WMT_ = 6: 192-row tiles for the token counts at which 256-row tiles multiply mostly padding (513 .. 576 tokens are three
-// row tiles either way: a quarter fewer MFMAs per step).  The A slabs keep their 256 rows of LDS and all 32 pieces (rows
-// 192 .. 255 belong to the next tile and are never read), so, as with WNT_ = 6, nothing of the DMA / wait schedule changes.
+// WNT_ (16-column MFMA tiles per wave along N): 16 / WN_ gives the 256-column tile; narrower tiles (residual epilogue only):
+// WN_ = 2, WNT_ = 6 is a 256 x 192 tile for the token counts at which N = 1536 yields 130-190 tiles of 256 columns on 256 CUs and
+// exactly <= 256 tiles of 192; WNT_ = 4 / 2 are 128- / 64-column tiles for the K-split down projection of a few hundred tokens
+// (fewer, longer K slices: fewer f32 planes to write and add -- and a workgroup's W strip, the operand that misses L2, is the
+// narrow side).  WMT_ = 6: 192-row tiles for the token counts at which 256-row tiles multiply mostly padding (513 .. 576 tokens
+// are three row tiles either way: a quarter fewer MFMAs per step).  The slabs keep their 32 KiB ring slots whatever the tile; a
+// slab REQUESTS the tile's rows only (PA / PPW pieces per wave), and the waits count those.
 template <int EPI, int WN_, bool PERSIST = false, int WNT_ = 16 / WN_, int WMT_ = 8>
 __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g) {
     constexpr int WMT = WMT_, BM = 32 * WMT, WNT = WNT_, BN = WN_ * WNT * 16, NW = 2 * WN_;
     static_assert(WMT_ == 8 || WMT_ == 6, "row tiles of 256 or 192");
     static_assert(BN <= 256 && (WNT_ == 16 / WN_ || EPI == EPI_RESID), "narrower tiles: residual epilogue only");
     static_assert(WMT_ == 8 || !PERSIST, "192-row tiles: one unit per workgroup");
-    constexpr int PPW = 32 / NW;                             // DMA pieces (1 KiB: 8 rows x 128 B) per wave per W slab
-    constexpr int PA = (BM / 8) / NW;                        // ... per A slab: a 192-row tile requests its 24 pieces, not the 32 of the slot
-    static_assert(PA * NW * 8 == BM && PA <= PPW, "A pieces");
+    constexpr int PPW = (BN / 8) / NW;                       // DMA pieces (1 KiB: 8 rows x 128 B) per wave per W slab: the tile's rows, not the 32 KiB slot's
+    constexpr int PA = (BM / 8) / NW;                        // ... per A slab (a 192-row tile requests 24 pieces)
+    constexpr int PMAX = PA > PPW ? PA : PPW, PMIN = PA < PPW ? PA : PPW;
+    static_assert(PA * NW * 8 == BM && PPW * NW * 8 == BN, "pieces");
     constexpr int NS = 5, DQ = 4;                            // slabs in the ring, request distance in slabs
     constexpr unsigned SLAB_B = 256 * 128;                   // 32 KiB
     constexpr int NMF = WMT * WNT, NRD = WMT + WNT;          // MFMAs / fragment reads per wave per step
     constexpr int RSTEP = (NMF * 3 / 4) / NRD;               // one read every RSTEP MFMAs, all inside the first 3/4 of the step (placement
                                                              // of reads and DMA pieces inside the step measured +-2 %: noise)
-    constexpr int DSTEP = NMF / PPW;                         // one DMA piece every DSTEP MFMAs
+    constexpr int DSTEP = NMF / PMAX;                        // one DMA piece every DSTEP MFMAs
     constexpr bool SWAP = EPI != EPI_QKV;
     constexpr int PERM = EPI == EPI_STORE ? 1 : EPI == EPI_SWIGLU ? 2 : 0;
-    static_assert(RSTEP >= 1 && NW * PPW == 32 && PPW % 2 == 0, "schedule");
+    static_assert(RSTEP >= 1 && DSTEP >= 1 && PPW % 2 == 0, "schedule");
     __shared__ __attribute__((aligned(16))) bf16_t smem[NS * SLAB_B / 2];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1083,7 +1084,9 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                         if (dma_on) dma16_off(srcA[p] + koff, dma_dstA + sd * SLAB_B + p * 1024u);
                     }
                 } else {
-                    if (dma_on) dma16_off(srcW[p] + koff, dma_dst + sd * SLAB_B + p * 1024u);
+                    if constexpr (p < PPW) {
+                        if (dma_on) dma16_off(srcW[p] + koff, dma_dst + sd * SLAB_B + p * 1024u);
+                    }
                 }
             }
         });
@@ -1135,7 +1138,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
 
     // slabs 0 and 1 landed (after a previous unit's epilogue its stores count as well: more conservative, never less --
     // loads return in order among themselves); fragments of step 0 read
-    wait_tiles<PA, DQ - 2>(max(0, min(DQ - 2, nk - 2)), false);   // (PA <= PPW pieces per slab: never fewer landed than needed)
+    wait_tiles<PMIN, DQ - 2>(max(0, min(DQ - 2, nk - 2)), false);   // (the smaller of the two slab sizes: never fewer landed than needed)
     asm volatile("s_barrier" ::: "memory");
     stamp(1);
     static_for<WNT>([&](auto R) { lds_read16<slab_w_tile_off<PERM>(decltype(R)::value)>(b0[decltype(R)::value], rdB + SLAB_B); });
@@ -1154,10 +1157,10 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
         c = wrap(c + 2);
     }
     for (; u < nk; u += 2) {                                 // the last steps: fewer slabs in flight, no new requests
-        wait_tiles<PA, DQ - 3>(max(0, min(DQ - 3, nk - 3 - u)), true);
+        wait_tiles<PMIN, DQ - 3>(max(0, min(DQ - 3, nk - 3 - u)), true);
         asm volatile("s_barrier" ::: "memory");
         step(a0, b0, a1, b1, P0{}, F_{}, u, c);
-        wait_tiles<PA, DQ - 3>(max(0, min(DQ - 3, nk - 4 - u)), true);
+        wait_tiles<PMIN, DQ - 3>(max(0, min(DQ - 3, nk - 4 - u)), true);
         asm volatile("s_barrier" ::: "memory");
         step(a1, b1, a0, b0, P1{}, F_{}, u + 1, c);
         c = wrap(c + 2);
