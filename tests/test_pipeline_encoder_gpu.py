@@ -458,6 +458,31 @@ def test_dispatch_knobs_keep_the_embeddings(st, env, monkeypatch):
     assert ((out * base).sum(1)).min() > 1 - 2e-4 and np.abs(out - base).max() < 4e-3
 
 
+@pytest.mark.parametrize("ntok", [70, 130, 193, 257, 385, 449, 577, 700, 830, 1000, 1290, 1700])
+def test_k_split_tile_widths_and_k_offsets_over_token_counts(st, ntok, monkeypatch):
+    """The down projection of ~70 .. 1 700 tokens: the launcher picks the K-split tile width (256 / 192 / 128 columns) and slice
+    count by its cost model, slabs request the tile's rows only, and the row tiles of one-round GEMMs walk K from offsets 3 K tiles
+    apart -- against the same pass on 256-column tiles without the offsets (MI_DOWN_BN=256, MI_NO_KROT=1: round 4's launches) to
+    bf16 rounding, over token counts either side of every row-tile and dispatch border.  Run-to-run identical (no atomics)."""
+    cfg = dict(st.STELLA_EN_1_5B_V5)
+    cfg["vocab_size"], cfg["n_layers"] = 4096, 2
+    W = _rand_weights_gpu(cfg, 23)
+    rng = np.random.default_rng(ntok)
+    lens, left = [], ntok
+    while left > 0:
+        L = int(min(left, rng.integers(9, 49)))
+        lens.append(L)
+        left -= L
+    toks = [rng.integers(0, cfg["vocab_size"], L).tolist() for L in lens]
+    new = st.SentenceTransformer(config=cfg, weights=W).encode_tokens(toks, batch_size=len(toks), normalize_embeddings=True)
+    again = st.SentenceTransformer(config=cfg, weights=W).encode_tokens(toks, batch_size=len(toks), normalize_embeddings=True)
+    assert np.array_equal(new, again)
+    monkeypatch.setenv("MI_DOWN_BN", "256")
+    monkeypatch.setenv("MI_NO_KROT", "1")
+    old = st.SentenceTransformer(config=cfg, weights=W).encode_tokens(toks, batch_size=len(toks), normalize_embeddings=True)
+    assert ((new * old).sum(1)).min() > 1 - 2e-4 and np.abs(new - old).max() < 4e-3, (ntok, ((new * old).sum(1)).min())
+
+
 @pytest.mark.parametrize("lens", [[1], [3], [16], [17], [32], [33], [48], [5, 9, 20], [1] * 7, [16, 16, 16], [2, 46]])
 def test_few_token_path_at_stella_widths_vs_oracle(st, lens, monkeypatch):
     """The query-time path (csrc/encoder_few.h: RMSNorm in the GEMM prologue, RoPE / SwiGLU / residual atomics in the
