@@ -98,7 +98,7 @@ doc = {"correction": CORR, "regimes": {}, "source": "rocprofv3 --pmc FETCH_SIZE 
        "how": "tools/prof_r05.sh b1 / mid: every kernel of the pass summed (per-kernel mean x launches per forward pass = dispatches / passes)"}
 stamps = []
 for tag, frag, hdr, kerns in (("b1", "few_", "encoder_few.h", ["few_gemm_kernel", "few_o_kernel", "few_d_kernel", "few_row_kernel"]),
-                              ("mid", "mienc", "encoder_mid.h", ["mid_gemm_kernel"])):
+                              ("mid", "mienc", "encoder_mid.h", ["mid_gemm_kernel"]), ("mid256", "mienc", "encoder_kernels.h", ["gemm_bf16_slab_kernel"])):
     F, W, st = parse(src + f"/{tag}_FETCH_SIZE.txt"), parse(src + f"/{tag}_WRITE_SIZE.txt"), stats(src + f"/{tag}_kernel_stats.csv")
     if not F:
         continue
@@ -108,7 +108,7 @@ for tag, frag, hdr, kerns in (("b1", "few_", "encoder_few.h", ["few_gemm_kernel"
     ntok = int(m.group(1)) if m else None
     layer_k = [k for k in F if frag in k and not any(x in k for x in ("import_rows", "interleave", "few_tile", "tile_weights"))]
     # launches per pass: a per-layer kernel is dispatched 28 x passes times; passes = dispatches of the first per-layer GEMM / 28
-    gem = [k for k in layer_k if ("few_gemm_kernel<0" in k or "mid_gemm_kernel<0" in k)]
+    gem = [k for k in layer_k if ("few_gemm_kernel<0" in k or "mid_gemm_kernel<0" in k or "gemm_bf16_slab_kernel<3" in k)]
     passes = F[gem[0]]["FETCH_SIZE"][0] / 28.0 if gem else None
     tot_f = tot_w = 0.0
     per = {}

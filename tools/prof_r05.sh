@@ -4,7 +4,8 @@
 #         scan / re-rank / selection with the refine point's (nprobe, k_factor) sweep pinned to the timed shape (BENCH_REFINE_NPROBES /
 #         BENCH_REFINE_KFS), so that a kernel's mean is over launches of ONE shape
 #   b1    the query-time encoder (one 31-token query): stats + FETCH_SIZE of its kernels
-#   mid   the few-hundred-token encoder (16 queries, 563 tokens): stats + FETCH_SIZE + WRITE_SIZE of every kernel of the pass
+#   mid   the few-hundred-token encoder (bench.py's 16 queries, 570 tokens): stats + FETCH_SIZE + WRITE_SIZE of every kernel of the pass
+#   mid256  the same for bench.py's 256 queries (8 097 tokens)
 #   enc   encode (cfg3): stats, a plain run, FETCH_SIZE / WRITE_SIZE of its GEMM kernels
 # Counters always in their own passes with --kernel-trace only.  tools/pmc_json_r05.py turns the summaries into the stamped
 # profiles/r05_*_pmc.json files bench.py reads for `roofline.traffic`.
@@ -43,6 +44,13 @@ mid)
   export ENC_REPS=5
   for c in FETCH_SIZE WRITE_SIZE; do pmc mid $c "mienc" $Q; done
   unset ENC_NQ ENC_REPS ;;
+mid256)
+  export ENC_NQ=256 ENC_REPS=10
+  Q="python $R/tools/encode_mid_prof.py"
+  stats mid256 $Q; timeout 300 $Q > $out/mid256_plain.out 2>/dev/null
+  export ENC_REPS=3
+  for c in FETCH_SIZE WRITE_SIZE; do pmc mid256 $c "mienc" $Q; done
+  unset ENC_NQ ENC_REPS ;;
 enc)
   E="python $R/bench.py --workload encode --steps 4 --warmup 1 --no-cpu-baseline"
   stats encode $E; cp $out/encode_under_stats.out $out/encode_under_stats.json
@@ -50,5 +58,5 @@ enc)
   for c in FETCH_SIZE WRITE_SIZE; do pmc encode_gemm $c "gemm_bf16_(ring|slab)" $E; done ;;
 esac; done
 cd $R
-for f in cfg4 b1 mid encode; do [ -f $out/${f}_kernel_stats.csv ] && { echo "== $f"; head -9 $out/${f}_kernel_stats.csv | cut -c1-160; }; done
+for f in cfg4 b1 mid mid256 encode; do [ -f $out/${f}_kernel_stats.csv ] && { echo "== $f"; head -9 $out/${f}_kernel_stats.csv | cut -c1-160; }; done
 grep -h "ms per\|per encode" $out/*_plain.out $out/*_under_stats.out 2>/dev/null
