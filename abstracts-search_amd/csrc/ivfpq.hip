@@ -48,6 +48,7 @@ struct Knobs {
     int scan_nw;          // MI_SCAN_NW=8|16: waves per scan workgroup (0: by shape)
     bool no_allscores;    // MI_NO_ALLSCORES=1: k > 64 by one extraction pass per 64 results
     bool no_fused_merge;  // MI_NO_FUSED_MERGE=1: cross-slice merge as its own launch
+    bool no_sliced_select;   // MI_NO_SLICED_SELECT=1: one workgroup per row for a few long rows too
     bool no_topk_rows;    // MI_NO_TOPK_ROWS=1: the re-rank's final top-k through the general merge
     bool scan_ts;         // MI_SCAN_TS=1: mi_index_profile_scan prints in-kernel phase stamps
     void load() {
@@ -62,6 +63,7 @@ struct Knobs {
         no_allscores = set("MI_NO_ALLSCORES");
         no_fused_merge = set("MI_NO_FUSED_MERGE");
         no_topk_rows = set("MI_NO_TOPK_ROWS");
+        no_sliced_select = set("MI_NO_SLICED_SELECT");
         scan_ts = set("MI_SCAN_TS");
     }
 };
@@ -157,8 +159,25 @@ void launch_gemm(const float *A, int64_t na, const float *B, int64_t nb, int d, 
 }
 
 void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int32_t *oi32,
-                   int64_t *oi64, float *os, hipStream_t st, ProbeTables pt = ProbeTables{}, int idx_off = 0) {
+                   int64_t *oi64, float *os, hipStream_t st, ProbeTables pt = ProbeTables{}, int idx_off = 0, DevBuf *scratch = nullptr) {
     MI_REQUIRE(K >= 1, "select: K < 1");
+    // A few long rows (one query against 65 536 centroids): one workgroup per row is a chain of n / 4096 tiles (37 us at 65 536);
+    // sliced, every 4096-column slice is a workgroup whose row stays in registers, and a second launch picks the K best of the
+    // slices' results (SelSlices; same total order: the result is bit-identical) -- 37 -> ~14 us for one query.
+    constexpr int SL = 4096;
+    if (scratch && !knobs().no_sliced_select && rows <= 64 && K <= 64 && K < knobs().select_big_from && ldS == n && n % SL == 0 && n / SL >= 4 &&
+        n / SL <= 64 && !oi64 && oi32) {
+        const int nsl = n / SL;
+        const size_t cnt = (size_t)rows * nsl * K;
+        float *ss = scratch->as<float>(cnt * 2);
+        int32_t *si = reinterpret_cast<int32_t *>(ss + cnt);
+        hipLaunchKernelGGL(select_kernel, dim3((unsigned)(rows * nsl)), dim3(256), 0, st, S, (int64_t)SL, SL, K, si, (int64_t *)nullptr, ss,
+                           ProbeTables{}, idx_off, SelSlices{nsl, nullptr});
+        hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(256), 0, st, ss, (int64_t)nsl * K, nsl * K, K, oi32, (int64_t *)nullptr, os, pt,
+                           0, SelSlices{0, si});
+        MI_HIP(hipGetLastError());
+        return;
+    }
     // 64 < K <= 4096: threshold + bitonic sort (K = 256 of 4096: 16 us; the rank-counting path of
     // select_kernel 55 us, its insertion path 764 us at K = 1024).  MI_SELECT_BIG_FROM moves the border.
     const int big_from = knobs().select_big_from;
@@ -169,7 +188,7 @@ void launch_select(const float *S, int64_t ldS, int64_t rows, int n, int K, int3
         return;
     }
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(256), 0, st, S, ldS, n, K, oi32,
-                       oi64, os, pt, idx_off);
+                       oi64, os, pt, idx_off, SelSlices{0, nullptr});
     MI_HIP(hipGetLastError());
 }
 
@@ -497,6 +516,7 @@ const void *to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t 
 // per-stream search workspaces (see mi_index::ws_sets)
 struct SearchWS {
     std::mutex mu;   // held by the one call that is enqueuing work through this set (two host threads on one stream take turns)
+    DevBuf selsc;   // the sliced selection's per-slice results (launch_select)
     DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters, all_s, all_id, q16, qscale, rstats, qaug, qn, cscan;
     size_t counters_zeroed = 0;  // bytes of `counters` known to be zero
     // most recent scan launch on this stream (mi_index_profile_scan replays it)
@@ -1211,7 +1231,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     const bool lut_in_gemm = h->dsub == 4 || h->dsub == 8 || h->dsub == 16;
     launch_gemm(qc, nq, cc, h->nlist, dc, scores, h->nlist, st,
                 lut_in_gemm ? make_lut_args(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut) : LutArgs{});
-    launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st, pt);
+    launch_select(scores, h->nlist, nq, h->nlist, nprobe, cidx, nullptr, cdis, st, pt, 0, &w.selsc);
     if (!lut_in_gemm) launch_lut(qdev, (int)nq, h->d, M, h->codebook.get<float>(), lut, st);
     }
     }

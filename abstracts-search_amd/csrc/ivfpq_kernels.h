@@ -541,6 +541,16 @@ __global__ void __launch_bounds__(256)
     emit_probe_tables(pt, blockIdx.x, K, idx + (size_t)blockIdx.x * K, wtot);
 }
 
+// Sliced selection (launch_select, few long rows): one workgroup walking a 65 536-column row is a chain of 16 tiles (37 us); 16
+// workgroups take a 4 096-column slice each (one tile: the row stays in registers) and a second pass picks the K best of the
+// 16 K results.  Pass 1: mod = slices per row (the slice's first column is added to the indices).  Pass 2: remap = the slices'
+// indices [rows][mod K]; equal scores keep their order: inside a slice they come index-ascending, and slices ascend.
+struct SelSlices {
+    int mod;
+    const int32_t *remap;
+};
+
+
 // Last-resort selection for any K and n: per-wave sorted lists with serial insertion, 64
 // results per pass over the row (pass p keeps the best 64 among the entries strictly after
 // the last entry of pass p-1).  Whole 256-thread workgroup; c_s / c_i: 256 LDS slots,
@@ -549,7 +559,7 @@ __global__ void __launch_bounds__(256)
 __device__ __noinline__ void select_by_insertion(const float *__restrict__ r, int n, int K, int64_t row,
                                                  int32_t *__restrict__ out_i32, int64_t *__restrict__ out_i64,
                                                  float *__restrict__ out_s, int idx_off, float *c_s, int *c_i,
-                                                 float *o_s, int *o_i) {
+                                                 float *o_s, int *o_i, const int32_t *__restrict__ remap = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = uniform_i(tid >> 6);
     float *m_s = c_s;
@@ -603,8 +613,9 @@ __device__ __noinline__ void select_by_insertion(const float *__restrict__ r, in
             int oi = o_i[tid];
             float os = o_s[tid];
             size_t o = (size_t)row * K + p0 + tid;
-            if (out_i32) out_i32[o] = oi == INT_MAX ? -1 : oi + idx_off;
-            if (out_i64) out_i64[o] = oi == INT_MAX ? (int64_t)-1 : (int64_t)oi + idx_off;
+            const int sel = oi == INT_MAX ? -1 : remap ? remap[oi] : oi + idx_off;
+            if (out_i32) out_i32[o] = sel;
+            if (out_i64) out_i64[o] = (int64_t)sel;
             if (out_s) out_s[o] = oi == INT_MAX ? -FLT_MAX : os;
         }
         has_bound = true;
@@ -618,7 +629,7 @@ constexpr int SEL_CAP = 1024;  // survivor slots of the fast path
 
 __global__ void __launch_bounds__(256)
     select_kernel(const float *__restrict__ S, int64_t ldS, int n, int K, int32_t *__restrict__ out_i32,
-                  int64_t *__restrict__ out_i64, float *__restrict__ out_s, ProbeTables pt, int idx_off) {
+                  int64_t *__restrict__ out_i64, float *__restrict__ out_s, ProbeTables pt, int idx_off, SelSlices sl) {
     __shared__ float c_s[SEL_CAP];   // survivors (fast path) / wave lists (fallback: first 256)
     __shared__ int c_i[SEL_CAP];
     __shared__ int c_rank[SEL_CAP];
@@ -631,6 +642,10 @@ __global__ void __launch_bounds__(256)
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t row = blockIdx.x;
     const float *r = S + row * ldS;
+    // sliced selection of a few long rows (SelSlices): pass 1 -- this "row" is slice row % mod of a longer one, its columns start
+    // at (row % mod) * n; pass 2 -- the row holds the slices' results, column c stands for the index remap[c]
+    if (sl.mod > 1) idx_off += (int)(row % sl.mod) * n;
+    const int32_t *remap = sl.remap ? sl.remap + row * ldS : nullptr;
 
     // ---- fast path (K <= 256): the K-th largest of the 256 per-thread maxima
     // is a lower bound of the K-th largest element, so everything below it is
@@ -771,7 +786,7 @@ __global__ void __launch_bounds__(256)
                 const int oi = o_i[tid];
                 const float os = o_s[tid];
                 const size_t o = (size_t)row * K + tid;
-                const int sel = oi == INT_MAX ? -1 : oi + idx_off;
+                const int sel = oi == INT_MAX ? -1 : remap ? remap[oi] : oi + idx_off;
                 if (out_i32) out_i32[o] = sel;
                 if (out_i64) out_i64[o] = (int64_t)sel;
                 if (out_s) out_s[o] = oi == INT_MAX ? -FLT_MAX : os;
@@ -788,7 +803,7 @@ __global__ void __launch_bounds__(256)
 
     // ---- K > 256 reaches this kernel only through select_big_kernel's overflow; a
     // pathological row with > SEL_CAP tied survivors falls through to here as well.
-    if (!done) select_by_insertion(r, n, K, row, out_i32, out_i64, out_s, idx_off, c_s, c_i, o_s, o_i);
+    if (!done) select_by_insertion(r, n, K, row, out_i32, out_i64, out_s, idx_off, c_s, c_i, o_s, o_i, remap);
     if (pt.list_goff && !tables_done) emit_probe_tables(pt, row, K, out_i32 + (size_t)row * K, wtot);
 }
 

@@ -48,6 +48,30 @@ def random_problem(seed, d, M, nlist, n, nq, scale=0.3):
     return cent, cb, x, q
 
 
+@pytest.mark.parametrize("nq,nprobe", [(1, 64), (5, 17), (16, 1), (64, 33)])
+def test_sliced_coarse_selection_of_a_few_long_rows(faiss, oracle, monkeypatch, nq, nprobe):
+    """A few queries against many centroids (16 384 = 4 slices of 4 096): the coarse selection runs as one workgroup per slice + a
+    second pass over the slices' results (launch_select, SelSlices) -- same probes, same coarse scores (bits) and the same search
+    results as one workgroup per row (MI_NO_SLICED_SELECT=1) and as the oracle, with centroids DUPLICATED across slices so that
+    equal scores meet at the cut (ties by the smaller list number)."""
+    d, M, nlist, n = 64, 8, 16384, 40000
+    cent, cb, x, q = random_problem(61, d, M, nlist, n, nq)
+    cent[4096:4096 + 300] = cent[:300]                           # the same centroid in two slices ...
+    cent[12288 + 7] = cent[5000]                                 # ... and in two others
+    idx = make_index(faiss, cent, cb)
+    idx.add(x)
+    idx.nprobe = nprobe
+    cI, cD, _ = idx.coarse_and_lut(q, nprobe, want_lut=False)
+    D, I = idx.search(q, 10)
+    monkeypatch.setenv("MI_NO_SLICED_SELECT", "1")
+    cI0, cD0, _ = idx.coarse_and_lut(q, nprobe, want_lut=False)
+    D0, I0 = idx.search(q, 10)
+    assert np.array_equal(cI, cI0) and np.array_equal(bits(cD), bits(cD0))
+    assert np.array_equal(I, I0) and np.array_equal(bits(D), bits(D0))
+    eD, eI = oracle.flat_ip(q, cent, nprobe)                     # the coarse quantiser IS a flat inner-product search over the centroids
+    assert np.array_equal(cI, eI.astype(np.int32)) and np.array_equal(bits(cD), bits(eD))
+
+
 def test_golden_fixture(faiss, gold):
     cent, cb, x, q, ids = gold["centroids"], gold["codebook"], gold["x"], gold["q"], gold["ids"]
     k = int(gold["k"])
