@@ -44,6 +44,8 @@ struct Knobs {
     int pool_gemm;           // MI_POOL_GEMM=0: the per-sequence pooling kernel for every batch size
     bool no_few;             // MI_NO_FEW=1: a handful of tokens through the general path (fragment-major tiles)
     bool few_d_fuse, few_sync, few_ts;   // MI_FEW_D_FUSE (in-launch reduction of the down projection), MI_FEW_SYNC, MI_FEW_TS
+    bool no_few_gu8;         // MI_NO_FEW_GU8=1: the query-time gate/up projection on 16-feature unit pairs (few_gemm_kernel<FEW_GU>) instead of 8-feature units
+    bool no_few_ao;          // MI_NO_FEW_AO=1: one sequence of <= 32 tokens keeps few_attn_kernel + few_o_kernel (no attention inside the O projection)
     int enc_ts;              // MI_ENC_TS=1: in-kernel stamps of the first four slab GEMMs of > 4096 tokens; =n (n > 1): of > n tokens
     bool gemm_ts;            // MI_GEMM_TS=1: the same for mi_enc_gemm_bf16
     void load() {
@@ -65,6 +67,7 @@ struct Knobs {
         pool_gemm = num("MI_POOL_GEMM", -1);
         no_few = set("MI_NO_FEW");
         few_d_fuse = set("MI_FEW_D_FUSE"); few_sync = set("MI_FEW_SYNC"); few_ts = set("MI_FEW_TS");
+        no_few_ao = set("MI_NO_FEW_AO"); no_few_gu8 = set("MI_NO_FEW_GU8");
         enc_ts = num("MI_ENC_TS", 0); gemm_ts = set("MI_GEMM_TS");
     }
 };
@@ -85,11 +88,14 @@ std::atomic<int64_t> g_fused_rope_launches{0};   // QKV slab GEMMs whose epilogu
 std::atomic<int64_t> g_short_attn_launches{0};   // attention launches of the general path that took few_attn_kernel (every sequence <= 48 tokens)
 std::atomic<int64_t> g_mid_launches{0};   // QKV / O projections on the one-launch whole-K tiles of encoder_mid.h
 std::atomic<int64_t> g_few_passes{0};     // forward passes that took the query-time path (encoder_few.h)
+std::atomic<int64_t> g_few_gu8_passes{0}; // ... with the gate/up projection on 8-feature units (few_gu8_kernel)
+std::atomic<int64_t> g_few_ao_passes{0};  // ... of them, with the attention inside the O projection (few_ao_kernel)
 
 struct LayerW {
     DevBuf wqkv, bqkv, wo, wgu, wd, ln1, ln2;
     DevBuf wqkv_t, wo_t, wgu_t, wd_t;   // fragment-major copies for the general path's few-token tiles (MI_NO_FEW=1; built lazily)
     DevBuf few_qkv, few_o, few_gu, few_d;   // 1-KiB pieces of the query-time path (encoder_few.h; built lazily)
+    DevBuf few_op;                          // the O projection's half pieces in few_ao_kernel's K order
     DevBuf wqkv_r, bqkv_r;                  // Q / K rows interleaved by rotary pair: the many-token path's QKV epilogue rotates in place (built lazily)
 };
 
@@ -661,6 +667,7 @@ struct mi_encoder {
     DevBuf ws_stage;         // load_tensor staging (exclusive calls)
     bool tiled_ok = false;   // fragment-major weight copies are current
     bool few_ok = false;     // the query-time path's weight pieces are current
+    bool few_gu8 = false;    // ... and the gate/up pieces are few_gu8_kernel's (8 gate + 8 up rows per piece)
     bool roped_ok = false;   // the rotary-pair-interleaved QKV copies are current
     // profiling: the GEMM launches of the most recent encode (arguments as launched), replayed back to back between two
     // HIP events by mi_encoder_profile_read -- like the index library's scan replay; per-launch event pairs measured
@@ -924,6 +931,7 @@ void few_set_attributes() {
     const int lim = 160 * 1024;
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_gemm_kernel<FEW_QKV, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_gemm_kernel<FEW_GU, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_gu8_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_o_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_d_kernel<MT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&few_d_kernel<MT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -942,10 +950,25 @@ void few_build_weights(mi_encoder *h, hipStream_t st) {
                                rope_blocks, c.head_dim, d);
         MI_HIP(hipGetLastError());
     };
+    // 8-feature gate/up units: every wave keeps its K range of the fragments in registers (FEW_GKP steps), a workgroup <= FEW_GNU units
+    h->few_gu8 = !knobs().no_few_gu8 && I % 32 == 0 && (H / 32 + FEW_GW - 1) / FEW_GW <= FEW_GKP &&
+                 (I / 8 + std::min(I / 8, 256) - 1) / std::min(I / 8, 256) <= FEW_GNU;
     for (auto &w : h->layers) {
         tile(w.wqkv, h->qk_cols + h->v_cols, H, h->qk_cols / 16, w.few_qkv, false);
         tile(w.wo, H, h->q_cols, 0, w.few_o, true);
-        tile(w.wgu, 2 * I, H, 0, w.few_gu, false);
+        {
+            bf16_t *d = w.few_op.as<bf16_t>((size_t)H * h->q_cols);
+            hipLaunchKernelGGL((few_tile_kernel<8, true>), dim3((unsigned)((H / 8) * (h->q_cols / 32))), dim3(64), 0, st, w.wo.get<bf16_t>(), H,
+                               h->q_cols, h->q_cols, 0, c.head_dim, d);
+            MI_HIP(hipGetLastError());
+        }
+        if (h->few_gu8) {
+            hipLaunchKernelGGL((few_tile_kernel<16, false, true>), dim3((unsigned)((2 * I / 16) * (H / 32))), dim3(64), 0, st, w.wgu.get<bf16_t>(), 2 * I, H,
+                               H, 0, c.head_dim, w.few_gu.as<bf16_t>((size_t)2 * I * H));
+            MI_HIP(hipGetLastError());
+        } else {
+            tile(w.wgu, 2 * I, H, 0, w.few_gu, false);
+        }
         tile(w.wd, H, I, 0, w.few_d, false);
     }
     few_set_attributes<1>();
@@ -1020,6 +1043,13 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         }
     };
 
+    // one sequence of <= 32 tokens (the prompted query): the attention runs inside the O projection's workgroups (few_ao_kernel),
+    // its operands arrive from the QKV epilogue as pieces (they fit the row buffers: T_pad >= 16 MT)
+    const size_t ao_lds = ((size_t)c.n_kv_heads * (2 * (c.head_dim / 32) + c.head_dim / 16) + (size_t)FEW_AW * MT) * 1024;
+    const bool fuse_ao = MT <= 2 && b.nseq == 1 && !knobs().no_few_ao && (c.head_dim == 64 || c.head_dim == 128) &&
+                         h->q_cols == c.n_heads * c.head_dim && h->v_cols == c.n_kv_heads * c.head_dim &&
+                         h->qk_cols == (c.n_heads + c.n_kv_heads) * c.head_dim && c.n_heads % std::max(c.n_kv_heads, 1) == 0 &&
+                         T_pad >= 16 * MT && ldvt >= 16 * MT && ao_lds <= 64 * 1024;
     FewArgs e{};
     e.T = T; e.H = H; e.x = x; e.norm_w = h->layers[0].ln1.get<float>(); e.eps = c.rms_eps; e.xfrag = xfrag; e.ids = b.ids;
     e.table = h->embed.get<bf16_t>();
@@ -1030,6 +1060,7 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         Range layer_range("mi_encoder:layer");
         FewArgs q{};
         q.T = T; q.H = H; q.nk = H / 32; q.nunits = (h->qk_cols + h->v_cols) / 16; q.W = w.few_qkv.get<bf16_t>(); q.afrag = xfrag;
+        q.attn_pieces = fuse_ao ? 1 : 0; q.n_heads = c.n_heads; q.n_kv = c.n_kv_heads;
         if (fuse_d && l > 0) { q.ssq = ssq; q.nparts = ugroups; }    // (the previous layer's down projection left bf16(x g) and partial sums of squares)
         q.eps = c.rms_eps; q.bias = w.bqkv.get<float>(); q.qk = qk; q.vt = vt;
         q.ldqk = h->qk_cols; q.ldvt = ldvt; q.qk_cols = h->qk_cols; q.hd = c.head_dim; q.rope_blocks = h->qk_cols / 16;
@@ -1038,7 +1069,19 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         hipLaunchKernelGGL((few_gemm_kernel<FEW_QKV, MT>), dim3((unsigned)gemm_grid(q.nunits)), dim3(64 * FEW_NW), gemm_smem(q.nk, 1), st, q);
         if (q.ts) stamps("qkv", gemm_grid(q.nunits));
         chk("qkv");
-        if (b.Lmax > FEW_MAX_T || (c.head_dim != 64 && c.head_dim != 128)) {
+        if (l == 0 && fuse_ao) g_few_ao_passes.fetch_add(1);
+        if (fuse_ao) {
+            if constexpr (MT <= 2) {
+                FewArgs o{};
+                o.T = T; o.H = H; o.nk = h->q_cols / 32; o.nunits = H / 8; o.W = w.few_op.get<bf16_t>(); o.x = x;
+                o.norm_w = w.ln2.get<float>(); o.ssq_out = ssq; o.xfrag = xfrag;
+                o.qk = qk; o.vt = vt; o.ldqk = h->qk_cols; o.ldvt = ldvt; o.n_heads = c.n_heads; o.n_kv = c.n_kv_heads; o.causal = c.causal;
+                o.scale = 1.0f / std::sqrt((float)c.head_dim);
+                if (c.head_dim == 128) hipLaunchKernelGGL((few_ao_kernel<128, MT>), dim3((unsigned)o.nunits), dim3(64 * FEW_AW), ao_lds, st, o);
+                else hipLaunchKernelGGL((few_ao_kernel<64, MT>), dim3((unsigned)o.nunits), dim3(64 * FEW_AW), ao_lds, st, o);
+                chk("attention + o");
+            }
+        } else if (b.Lmax > FEW_MAX_T || (c.head_dim != 64 && c.head_dim != 128)) {
             launch_attention(h, b, qk, vt, nullptr, ldvt, st, afrag, MT);
         } else {
             AttnArgs aa{};
@@ -1050,18 +1093,27 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
             if (c.head_dim == 128) hipLaunchKernelGGL((few_attn_kernel<128>), ga, dim3(64), 0, st, aa);
             else hipLaunchKernelGGL((few_attn_kernel<64>), ga, dim3(64), 0, st, aa);
         }
+        if (!fuse_ao) {
         chk("attention");
         FewArgs o{};
         o.T = T; o.H = H; o.nk = h->q_cols / 32; o.nunits = H / 8; o.W = w.few_o.get<bf16_t>(); o.afrag = afrag; o.x = x;
         o.norm_w = w.ln2.get<float>(); o.ssq_out = ssq; o.xfrag = xfrag;
         hipLaunchKernelGGL((few_o_kernel<MT>), dim3((unsigned)o.nunits), dim3(64 * FEW_OW), (size_t)std::max(o.nk, FEW_OW) * MT * 1024, st, o);
         chk("o");
+        }
         FewArgs u{};
         u.T = T; u.H = H; u.nk = H / 32; u.nunits = I / 16; u.W = w.few_gu.get<bf16_t>(); u.afrag = xfrag; u.eps = c.rms_eps;
         u.ssq = ssq; u.nparts = H / 8; u.hfrag = hfrag;
+        if (h->few_gu8) {
+            u.nunits = I / 8;
+            if (l == 0) g_few_gu8_passes.fetch_add(1);
+            hipLaunchKernelGGL((few_gu8_kernel<MT>), dim3((unsigned)std::min(u.nunits, 256)), dim3(64 * FEW_GW),
+                               (size_t)FEW_GW * FEW_GNU * MT * 1024 + (size_t)FEW_GW * 64 * 4, st, u);
+        } else {
         if (dbg_ts && l == 0) u.ts = tsb.as<unsigned long long>((size_t)gemm_grid(u.nunits) * 8);
         hipLaunchKernelGGL((few_gemm_kernel<FEW_GU, MT>), dim3((unsigned)gemm_grid(u.nunits)), dim3(64 * FEW_NW), gemm_smem(u.nk, 2), st, u);
         if (u.ts) stamps("gate/up", gemm_grid(u.nunits));
+        }
         chk("gu");
         FewArgs d = d0;
         d.T = T; d.H = H; d.W = w.few_d.get<bf16_t>(); d.afrag = hfrag; d.part = part; d.T_pad = T_pad;
@@ -1618,6 +1670,8 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
         else if (std::string(name) == "fused_norm_launches") *value = g_fused_norm_launches.load();
         else if (std::string(name) == "fused_rope_launches") *value = g_fused_rope_launches.load();
         else if (std::string(name) == "few_passes") *value = g_few_passes.load();
+        else if (std::string(name) == "few_ao_passes") *value = g_few_ao_passes.load();
+        else if (std::string(name) == "few_gu8_passes") *value = g_few_gu8_passes.load();
         else if (std::string(name) == "mid_launches") *value = g_mid_launches.load();
         else if (std::string(name) == "short_attn_launches") *value = g_short_attn_launches.load();
         else throw Error(std::string("unknown debug counter: ") + name);

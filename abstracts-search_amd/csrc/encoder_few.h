@@ -76,6 +76,18 @@ struct FewArgs {
     const int32_t *ids;
     const bf16_t *table;
     unsigned long long *ts;        // MI_FEW_TS (profiling): [workgroup][8] s_memtime stamps of wave 0
+    // few_ao_kernel (attention inside the O projection): qk / vt above are read
+    int n_heads, n_kv, causal;
+    float scale;
+    // attn_pieces (QKV epilogue -> few_ao_kernel, one sequence of <= 32 tokens): qk / vt hold the MFMA operands of the attention
+    // as 1-KiB pieces instead of rows --
+    //   Q   qk + ((head (hd/32) + kd) MT + mt) KiB: lane (token % 16, lg) = dims 32 kd + 8 lg .. + 8 of token 16 mt + ..
+    //   K   behind the n_heads (hd/32) MT pieces of Q, ((kvh 2 + j) (hd/32) + kd) KiB: lane (p, lg), tile position p of key
+    //       tile j = key 8 (p / 4) + 4 j + p % 4 (few_attn_kernel's key order)
+    //   V^T vt + (kvh (hd/16) + n) KiB: lane (dim % 16, lg) = keys 8 lg .. + 8 of dim 16 n + ..
+    // so that every load of the attention is one contiguous KiB (a row-wise operand load touches 16 lines of which it uses half:
+    // 4 800 line requests per workgroup, 7 us of a CU's memory pipe, against ~1 100)
+    int attn_pieces;
 };
 
 __device__ __forceinline__ void few_stamp(const FewArgs &a, int slot) {
@@ -85,19 +97,32 @@ __device__ __forceinline__ void few_stamp(const FewArgs &a, int slot) {
 // W [N][ldw] row-major bf16 -> pieces of RB rows (16, or 8 for the O projection: lane l then carries row l & 7, so a
 // half piece is 512 B).  rope_blocks > 0 (RB = 16): the first rope_blocks blocks are Q / K head rows, permuted inside each
 // head so that block b of a head holds the features {8 b .. 8 b + 7} and {hd/2 + 8 b .. hd/2 + 8 b + 7}.
-template <int RB>
+// KPERM (RB = 8, few_ao_kernel's copy of the O projection): inside every K step lane group lg carries the columns
+// {4 lg .. 4 lg + 3} u {16 + 4 lg .. 16 + 4 lg + 3} -- the order in which the attention's output tiles leave a lane's registers.
+// GU8 (RB = 16, few_gu8_kernel's copy of the gate/up matrix, whose rows come as 16 gate rows / 16 up rows per 16 features):
+// piece rb = the gate rows (positions 0..7) and the up rows (8..15) of the 8 features 8 rb ..
+template <int RB, bool KPERM = false, bool GU8 = false>
 __global__ void __launch_bounds__(64) few_tile_kernel(const bf16_t *__restrict__ W, int N, int K, int ldw, int rope_blocks,
                                                       int hd, bf16_t *__restrict__ out) {
     const int nk = K / 32, piece = blockIdx.x, rb = piece / nk, ks = piece - rb * nk, l = threadIdx.x;
     const int i = l & 15, lg = l >> 4;
     if (RB == 8 && i >= 8) return;
     int row = rb * RB + i;
+    if constexpr (GU8) row = 32 * (rb >> 1) + 8 * (rb & 1) + (i < 8 ? i : i + 8);
     if (RB == 16 && rb < rope_blocks) {
         const int bph = hd / 16, head = rb / bph, b = rb - head * bph;
         row = head * hd + (i < 8 ? 8 * b + i : hd / 2 + 8 * b + (i - 8));
     }
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (row < N) v = *reinterpret_cast<const uint4 *>(W + (size_t)row * ldw + ks * 32 + lg * 8);
+    if (row < N) {
+        if constexpr (KPERM) {
+            const uint2 lo = *reinterpret_cast<const uint2 *>(W + (size_t)row * ldw + ks * 32 + lg * 4);
+            const uint2 hi = *reinterpret_cast<const uint2 *>(W + (size_t)row * ldw + ks * 32 + 16 + lg * 4);
+            v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+            v = *reinterpret_cast<const uint4 *>(W + (size_t)row * ldw + ks * 32 + lg * 8);
+        }
+    }
     *reinterpret_cast<uint4 *>(out + (size_t)piece * (RB * 32) + (lg * RB + i) * 8) = v;
 }
 
@@ -336,7 +361,16 @@ __global__ void __launch_bounds__(64 * FEW_NW) few_gemm_kernel(FewArgs a) {
                     uint2 o;
                     o.x = pack2(o4[0], o4[1]);
                     o.y = pack2(o4[2], o4[3]);
-                    *reinterpret_cast<uint2 *>(a.qk + (size_t)m * a.ldqk + head * a.hd + fih) = o;
+                    bf16_t *dst = a.qk + (size_t)m * a.ldqk + head * a.hd + fih;
+                    if (a.attn_pieces) {                           // features fih .. fih + 3 of the head: K step fih / 32, lane group (fih / 8) % 4, half (fih / 4) % 2
+                        const int nkd = a.hd / 32, kd = fih >> 5, sub = (((fih >> 3) & 3) * 16) * 8 + (fih & 4);
+                        if (head < a.n_heads)
+                            dst = a.qk + ((size_t)((head * nkd + kd) * MT + mt) * 64 + li) * 8 + sub;
+                        else                                       // key m: tile (m / 4) % 2, position 4 (m / 8) + m % 4
+                            dst = a.qk + ((size_t)a.n_heads * nkd * MT + (size_t)(((head - a.n_heads) * 2 + ((m >> 2) & 1)) * nkd + kd)) * 512 +
+                                  (4 * (m >> 3) + (m & 3)) * 8 + sub;
+                    }
+                    *reinterpret_cast<uint2 *>(dst) = o;
                 }
             } else {
                 const int vf = 16 * (eunit - a.rope_blocks) + 4 * lg;   // V feature (r added below)
@@ -344,13 +378,134 @@ __global__ void __launch_bounds__(64 * FEW_NW) few_gemm_kernel(FewArgs a) {
                 if (it != w) bv = *reinterpret_cast<const f32x4 *>(a.bias + a.qk_cols + vf);
                 const float bb[4] = {bv[0], bv[1], bv[2], bv[3]};
                 if (m < T) {
+                    if (a.attn_pieces) {                           // dim vf + r of key m: piece (kv head, (dim % hd) / 16), lane (dim % 16, m / 8), element m % 8
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a.vt[(size_t)(vf + r) * a.ldvt + m] = f2bf(v[0][r] + bb[r]);
+                        for (int r = 0; r < 4; ++r) {
+                            const int dim = vf + r, kvh = dim / a.hd, wi = dim - kvh * a.hd;
+                            a.vt[((size_t)(kvh * (a.hd / 16) + (wi >> 4)) * 64 + ((m >> 3) * 16 + (wi & 15))) * 8 + (m & 7)] = f2bf(v[0][r] + bb[r]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a.vt[(size_t)(vf + r) * a.ldvt + m] = f2bf(v[0][r] + bb[r]);
+                    }
                 }
             }
         }
     }
     few_stamp(a, 7);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gate/up projection + SwiGLU on 8-FEATURE units (H <= 1536): a unit = one 16-row piece stream, positions 0..7 the gate rows
+// and 8..15 the up rows of 8 features (few_tile_kernel<16, false, true>), so that the I / 8 = 1120 units deal out as 4 or 5 per
+// workgroup where the 560 16-feature pairs of few_gemm_kernel<FEW_GU> deal out as 2 or 3 -- its launch lasts as long as the
+// 3-unit workgroups (a third more stream than the mean: 13.4 us against 11.6 by the in-kernel stamps).  Wave w = K range w of
+// EVERY unit of the workgroup: its B fragments (8 K steps x MT tiles) stay in registers for the whole launch -- no staging
+// through LDS, no barrier in front of the stream -- and the ring holds the next unit's pieces of the same range.  The six
+// ranges' partial tiles meet in LDS in ascending order; 1 / rms on the sums; the up value of a gate value sits in lane ^ 32.
+// dynamic LDS: FEW_GW x FEW_GNU x MT KiB (partial tiles) | ssw[FEW_GW][64] f32
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FEW_GW = 6, FEW_GKP = 8, FEW_GNU = 6;     // waves = K ranges, K steps of a range at most, units of a workgroup at most
+template <int MT>
+__global__ void __launch_bounds__(64 * FEW_GW) few_gu8_kernel(FewArgs a) {
+    constexpr int KP = FEW_GKP;
+    extern __shared__ __attribute__((aligned(16))) uint4 few_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int nk = a.nk, H = a.H;
+    f32x4 *part = reinterpret_cast<f32x4 *>(few_lds);
+    float *ssw = reinterpret_cast<float *>(few_lds + (size_t)FEW_GW * FEW_GNU * MT * 64);
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int u0 = (int)((long)b * a.nunits / G), u1 = (int)((long)(b + 1) * a.nunits / G);
+    const int nu = u1 - u0;                                      // <= FEW_GNU (the host sizes G so)
+    if (nu <= 0) return;
+    const int kper = (nk + FEW_GW - 1) / FEW_GW;                 // <= KP
+    const int k0 = min(nk, w * kper), k1 = min(nk, k0 + kper), nsteps = k1 - k0;
+    // ---- requests, in the order they are needed: the rows' partial sums of squares, the fragments of this K range, unit 0's pieces
+    constexpr int SQ = 32;
+    float sq[SQ];
+    if (a.nparts > 0) {
+#pragma unroll
+        for (int i = 0; i < SQ; ++i) sq[i] = a.ssq[min(w + FEW_GW * i, a.nparts - 1) * FEW_SSQ_LD + lane];
+    }
+    bf16x8 bf[KP][MT];
+#pragma unroll
+    for (int s = 0; s < KP; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            bf[s][mt] = *reinterpret_cast<const bf16x8 *>(a.afrag + ((size_t)(min(k0 + s, nk - 1) * MT + mt) * 64 + lane) * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16_t *wbase = a.W + (size_t)lane * 8;
+    auto piece = [&](int unit, int s) { return wbase + ((size_t)unit * nk + min(k0 + s, nk - 1)) * 512; };
+    bf16x8 ring[KP];
+#pragma unroll
+    for (int s = 0; s < KP; ++s) few_wload(ring[s], piece(u0, s));
+    if (a.nparts > 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < SQ; ++i) t += w + FEW_GW * i < a.nparts ? sq[i] : 0.f;
+        for (int p = w + FEW_GW * SQ; p < a.nparts; p += FEW_GW) t += a.ssq[p * FEW_SSQ_LD + lane];
+        ssw[w * 64 + lane] = t;
+    }
+#pragma unroll
+    for (int s = 0; s < KP; ++s)
+        if (s >= nsteps) {                                       // (past the range: the step multiplies zeros)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) bf[s][mt] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    // ---- the stream: unit by unit over this wave's K range
+    for (int u = 0; u < nu; ++u) {
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int un = u0 + min(u + 1, nu - 1);
+#pragma unroll
+        for (int s = 0; s < KP; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[s], bf[s][mt], acc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            few_wload(ring[s], piece(un, s));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) part[((w * FEW_GNU + u) * MT + mt) * 64 + lane] = acc[mt];
+    }
+    __syncthreads();
+    // ---- epilogue: item = (unit of the workgroup, token tile)
+    for (int it = w; it < nu * MT; it += FEW_GW) {
+        const int u = it / MT, mt = it - u * MT;
+        const int m = 16 * mt + li;
+        float inv = 1.f;
+        if (a.nparts > 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < FEW_GW; ++ww) tot += ssw[ww * 64 + m];
+            inv = rsqrtf(tot / (float)H + a.eps);
+        }
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < FEW_GW; ++c) {                        // ascending K ranges: a fixed order
+            const f32x4 p = part[((c * FEW_GNU + u) * MT + mt) * 64 + lane];
+            v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+        }
+        float hq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float g = v[r] * inv;
+            const float up = __shfl_xor(g, 32);                   // lanes lg < 2: gate rows 4 lg + r; their up rows sit in lg + 2
+            hq[r] = g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)) * up;
+        }
+        if (lg < 2) {
+            uint2 o;
+            o.x = pack2(hq[0], hq[1]);
+            o.y = pack2(hq[2], hq[3]);
+            // feature 8 unit + 4 lg + r of token m -> piece (K step unit / 4, tile mt), lane (unit & 3, li), half lg
+            const int unit = u0 + u;
+            bf16_t *dst = a.hfrag + ((size_t)((unit >> 2) * MT + mt) * 64 + ((unit & 3) * 16 + li)) * 8 + 4 * lg;
+            *reinterpret_cast<uint2 *>(dst) = o;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -717,6 +872,166 @@ __global__ void __launch_bounds__(64) few_attn_kernel(AttnArgs a) {
             pk.y = pack2(o[n][2] * inv, o[n][3] * inv);
             const size_t off = a.Ofrag ? ((size_t)(n >> 1) * a.frag_mt * 64 + (n & 1) * 32) * 8 : (size_t)n * 16;
             *reinterpret_cast<uint2 *>(op + off) = pk;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention INSIDE the O projection, for ONE sequence of <= 32 tokens (the prompted query of README.md:28): the launch that
+// few_attn_kernel was (4.6 us of a 43 us layer for ~6 MFLOP) and the round trip of its output through memory disappear.
+// Workgroup = 8 output features over all of K like few_o_kernel; wave w = head w (FEW_AW waves; more heads: w, w + FEW_AW, ..):
+// it computes its head's attention for every query tile exactly as few_attn_kernel does (S^T = K Q^T, one pass over <= 32
+// keys, O^T = V^T P^T) -- redundantly in every workgroup: Q | K | V^T are 4 KB per token, less than the fragments few_o_kernel
+// stages -- and its lane's output registers (four dims of tiles 2 J, 2 J + 1 of one query) ARE the B operand of the O
+// projection's K step (head, J) once the weight pieces carry their K columns in that order (few_tile_kernel<8, true>).
+// The heads' partial tiles meet in LDS in ascending order; the epilogue is few_o_kernel's.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FEW_AW = 12;
+template <int HD, int MT>
+__global__ void __launch_bounds__(64 * FEW_AW) few_ao_kernel(FewArgs a) {
+    constexpr int NKD = HD / 32, NDT = HD / 16, NJ = 2;            // K steps of a head, output tiles, key tiles (32 keys)
+    static_assert(MT <= 2, "one pass over 32 keys");
+    extern __shared__ __attribute__((aligned(16))) uint4 few_lds[];   // n_kv (2 NKD + NDT) KiB: the K and V^T pieces | FEW_AW MT KiB: the heads' partial tiles
+    const int PK = a.n_kv * NJ * NKD, PKV = PK + a.n_kv * NDT;
+    f32x4 *part = reinterpret_cast<f32x4 *>(few_lds + (size_t)PKV * 64);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int nk = a.nk, T = a.T, H = a.H;
+    const int hu = (int)blockIdx.x;
+    // the lanes that will finish a tile (wave mt, lg < 2) request their 4 columns of the stream and the gains first
+    const int em = 16 * w + li, ef = 8 * hu + 4 * (lg & 1);
+    const bool eown = w < MT && lg < 2 && em < T;
+    float *px = a.x + (size_t)min(em, T - 1) * H + ef;
+    f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f}, gv = xv;
+    if (eown) xv = *reinterpret_cast<const f32x4 *>(px);
+    if (w < MT) gv = *reinterpret_cast<const f32x4 *>(a.norm_w + ef);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float scale2 = a.scale * 1.4426950408889634f;
+    // ---- the K and V^T pieces of every KV head -> LDS, once per workgroup (a head group shares them); the first head's Q and
+    // weight pieces requested behind them
+    {
+        const bf16_t *kbase = a.qk + (size_t)a.n_heads * NKD * MT * 512;
+        constexpr int KVB = 3;                                      // pieces per wave requested at once (32 pieces over 12 waves)
+        i32x4_t kv[KVB];
+#pragma unroll
+        for (int i = 0; i < KVB; ++i) {
+            const int p = min(w + FEW_AW * i, PKV - 1);
+            kv[i] = *reinterpret_cast<const i32x4_t *>((p < PK ? kbase + (size_t)p * 512 : a.vt + (size_t)(p - PK) * 512) + lane * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < KVB; ++i) reinterpret_cast<i32x4_t *>(few_lds)[min(w + FEW_AW * i, PKV - 1) * 64 + lane] = kv[i];
+        for (int p = w + FEW_AW * KVB; p < PKV; p += FEW_AW)
+            reinterpret_cast<i32x4_t *>(few_lds)[p * 64 + lane] =
+                *reinterpret_cast<const i32x4_t *>((p < PK ? kbase + (size_t)p * 512 : a.vt + (size_t)(p - PK) * 512) + lane * 8);
+    }
+    bf16x8 qf[MT][NKD], wf[NKD];
+    auto head_loads = [&](int h) {                                 // the head's Q pieces and its K steps of the weight stream
+        h = min(h, a.n_heads - 1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int kd = 0; kd < NKD; ++kd)
+                qf[mt][kd] = *reinterpret_cast<const bf16x8 *>(a.qk + ((size_t)((h * NKD + kd) * MT + mt) * 64 + lane) * 8);
+        const bf16_t *wp = a.W + ((size_t)hu * nk + h * NKD) * 256 + (lg * 8 + (li & 7)) * 8;
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd) few_wload(wf[kd], wp + kd * 256);
+    };
+    head_loads(w);
+    __syncthreads();
+    for (int h = w; h < a.n_heads; h += FEW_AW) {
+        const int kvh = h / (a.n_heads / a.n_kv);
+        bf16x8 kf[NJ][NKD], vf[NDT];
+        if (h != w) head_loads(h);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int kd = 0; kd < NKD; ++kd) kf[j][kd] = as_bf16x8(few_lds[((kvh * NJ + j) * NKD + kd) * 64 + lane]);
+#pragma unroll
+        for (int n = 0; n < NDT; ++n) vf[n] = as_bf16x8(few_lds[(PK + kvh * NDT + n) * 64 + lane]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int qidx = 16 * mt + li;
+            // ---- S^T = K Q^T; softmax over the keys of query li: the lane holds keys 8 lg + 4 j + r
+            f32x4 sc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                sc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kd = 0; kd < NKD; ++kd) sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j][kd], qf[mt][kd], sc[j], 0, 0, 0);
+            }
+            float mx = -__builtin_huge_valf();
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kidx = 8 * lg + 4 * j + r;
+                    if (kidx >= T || (a.causal && kidx > qidx)) sc[j][r] = -__builtin_huge_valf();
+                    mx = fmaxf(mx, sc[j][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float msub = mx == -__builtin_huge_valf() ? 0.f : mx * scale2;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j][r], scale2, -msub));
+                    sum += p;
+                    sc[j][r] = p;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+            union { bf16x8 v; unsigned u[4]; } pf;
+            pf.u[0] = pack2(sc[0][0], sc[0][1]);
+            pf.u[1] = pack2(sc[0][2], sc[0][3]);
+            pf.u[2] = pack2(sc[1][0], sc[1][1]);
+            pf.u[3] = pack2(sc[1][2], sc[1][3]);
+            // ---- O^T = V^T P^T, two output tiles at a time: they are one K step of the O projection
+#pragma unroll
+            for (int kd = 0; kd < NKD; ++kd) {
+                f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+                o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[2 * kd], pf.v, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[2 * kd + 1], pf.v, o1, 0, 0, 0);
+                union { bf16x8 v; unsigned u[4]; } of;
+                of.u[0] = pack2(o0[0] * inv, o0[1] * inv);
+                of.u[1] = pack2(o0[2] * inv, o0[3] * inv);
+                of.u[2] = pack2(o1[0] * inv, o1[1] * inv);
+                of.u[3] = pack2(o1[2] * inv, o1[3] * inv);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kd], of.v, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) part[(w * MT + mt) * 64 + lane] = acc[mt];
+    __syncthreads();
+    // tile mt is finished by wave mt; lanes lg < 2 hold the 8 real features (4 lg + r), token li
+    if (w < MT) {
+        const int mt = w, m = 16 * mt + li;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < FEW_AW; ++c) {
+            const f32x4 p = part[(c * MT + mt) * 64 + lane];
+            v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+        }
+        float ss = 0.f;                                         // (lanes lg >= 2 repeat lg - 2; they store nothing)
+        if (eown) {
+            xv[0] += v[0]; xv[1] += v[1]; xv[2] += v[2]; xv[3] += v[3];
+            *reinterpret_cast<f32x4 *>(px) = xv;
+            ss = xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2] + xv[3] * xv[3];
+        }
+        ss += __shfl_xor(ss, 16);                               // the two halves of the 8 features
+        if (lg == 0) a.ssq_out[hu * FEW_SSQ_LD + m] = ss;       // (padding tokens: 0)
+        if (lg < 2) {                                           // fragments: every token of the tile (padding tokens: zeros)
+            uint2 o;
+            o.x = pack2(xv[0] * gv[0], xv[1] * gv[1]);
+            o.y = pack2(xv[2] * gv[2], xv[3] * gv[3]);
+            bf16_t *dst = a.xfrag + ((size_t)((hu >> 2) * MT + mt) * 64 + ((hu & 3) * 16 + li)) * 8 + 4 * lg;
+            *reinterpret_cast<uint2 *>(dst) = o;
         }
     }
 }

@@ -499,10 +499,13 @@ def test_few_token_path_at_stella_widths_vs_oracle(st, lens, monkeypatch):
     rng = np.random.default_rng(sum(lens) * 31 + len(lens))
     toks = [rng.integers(0, cfg["vocab_size"], int(L)).tolist() for L in lens]
     model = st.SentenceTransformer(config=cfg, weights=W)
-    before = st.debug_counter("few_passes")
+    before, ao0, gu0 = st.debug_counter("few_passes"), st.debug_counter("few_ao_passes"), st.debug_counter("few_gu8_passes")
     hs = model.last_hidden_state(toks)
     e = model.encode_tokens(toks, batch_size=len(lens), normalize_embeddings=True)
     assert st.debug_counter("few_passes") - before == 2
+    # one sequence of <= 32 tokens: the attention ran inside the O projection's workgroups (few_ao_kernel)
+    assert st.debug_counter("few_ao_passes") - ao0 == (2 if len(lens) == 1 and lens[0] <= 32 else 0)
+    assert st.debug_counter("few_gu8_passes") - gu0 == 2         # gate/up on 8-feature units (few_gu8_kernel) at these widths
     Wc = {k: v.float().cpu() for k, v in W.items()}
     ids, cu = np.concatenate(toks), np.concatenate([[0], np.cumsum(lens)])
     with torch.no_grad():
@@ -513,6 +516,49 @@ def test_few_token_path_at_stella_widths_vs_oracle(st, lens, monkeypatch):
     assert cos.min() > 1 - 1e-3, (cos.min(), int(cos.argmin()))
     rel = np.linalg.norm(hs - ref_h, axis=1) / np.linalg.norm(ref_h, axis=1)
     assert rel.max() < 3e-2, rel.max()
+    assert ((e * ref_e).sum(1)).min() > 1 - 1e-3
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("ntok", [1, 7, 16, 17, 25, 31, 32])
+def test_attention_inside_the_o_projection_vs_the_two_launches(st, ntok, causal, monkeypatch):
+    """One prompted query (reference README.md:28) of <= 32 tokens: few_ao_kernel -- the attention computed by the O
+    projection's own workgroups from Q / K / V^T pieces the QKV epilogue writes, its output registers the B operand of the
+    projection -- against few_attn_kernel + few_o_kernel (MI_NO_FEW_AO=1: rows of Q | K, V^T rows, fragments through memory)
+    and against the fp32 oracle, bidirectional and causal, at stella's widths, at the token-tile and key-tile edges.  The second
+    model also takes the gate/up projection on 16-feature unit pairs (MI_NO_FEW_GU8=1: few_gemm_kernel<FEW_GU>) where the
+    first runs few_gu8_kernel."""
+    import torch
+    from oracle import encoder_oracle as E
+    cfg = dict(st.STELLA_EN_1_5B_V5)
+    cfg["vocab_size"], cfg["n_layers"], cfg["causal"] = 4096, 3, causal
+    W = _rand_weights_gpu(cfg, 91)
+    rng = np.random.default_rng(ntok * 7 + causal)
+    toks = [rng.integers(0, cfg["vocab_size"], ntok).tolist()]
+    ao0, gu0 = st.debug_counter("few_ao_passes"), st.debug_counter("few_gu8_passes")
+    model = st.SentenceTransformer(config=cfg, weights=W)
+    hs = model.last_hidden_state(toks)
+    e = model.encode_tokens(toks, batch_size=1, normalize_embeddings=True)
+    e2 = model.encode_tokens(toks, batch_size=1, normalize_embeddings=True)
+    assert st.debug_counter("few_ao_passes") - ao0 == 3
+    assert np.array_equal(e, e2)                                  # no atomics: run to run identical
+    assert st.debug_counter("few_gu8_passes") - gu0 == 3
+    monkeypatch.setenv("MI_NO_FEW_AO", "1")
+    monkeypatch.setenv("MI_NO_FEW_GU8", "1")
+    model2 = st.SentenceTransformer(config=cfg, weights=W)
+    hs2 = model2.last_hidden_state(toks)
+    e_two = model2.encode_tokens(toks, batch_size=1, normalize_embeddings=True)
+    assert st.debug_counter("few_ao_passes") - ao0 == 3           # the two launches took these
+    assert st.debug_counter("few_gu8_passes") - gu0 == 3
+    cos2 = (hs * hs2).sum(1) / (np.linalg.norm(hs, axis=1) * np.linalg.norm(hs2, axis=1))
+    assert cos2.min() > 1 - 2e-4 and ((e * e_two).sum(1)).min() > 1 - 2e-4, (cos2.min(), (e * e_two).sum(1))
+    Wc = {k: v.float().cpu() for k, v in W.items()}
+    ids, cu = np.asarray(toks[0]), np.asarray([0, ntok])
+    with torch.no_grad():
+        ref_h = E.stack_forward(E.EncoderConfig(**cfg), Wc, ids, cu).numpy()
+        ref_e = E.encode(E.EncoderConfig(**cfg), Wc, ids, cu, True).numpy()
+    cos = (hs * ref_h).sum(1) / (np.linalg.norm(hs, axis=1) * np.linalg.norm(ref_h, axis=1))
+    assert cos.min() > 1 - 1e-3, (cos.min(), int(cos.argmin()))
     assert ((e * ref_e).sum(1)).min() > 1 - 1e-3
 
 
