@@ -45,6 +45,7 @@ struct Knobs {
     bool no_few;             // MI_NO_FEW=1: a handful of tokens through the general path (fragment-major tiles)
     bool few_d_fuse, few_sync, few_ts;   // MI_FEW_D_FUSE (in-launch reduction of the down projection), MI_FEW_SYNC, MI_FEW_TS
     bool no_few_gu8;         // MI_NO_FEW_GU8=1: the query-time gate/up projection on 16-feature unit pairs (few_gemm_kernel<FEW_GU>) instead of 8-feature units
+    bool no_few_qkv8;        // MI_NO_FEW_QKV8=1: the query-time QKV projection stages its fragments through LDS (few_gemm_kernel<FEW_QKV>)
     bool no_few_ao;          // MI_NO_FEW_AO=1: one sequence of <= 32 tokens keeps few_attn_kernel + few_o_kernel (no attention inside the O projection)
     int enc_ts;              // MI_ENC_TS=1: in-kernel stamps of the first four slab GEMMs of > 4096 tokens; =n (n > 1): of > n tokens
     bool gemm_ts;            // MI_GEMM_TS=1: the same for mi_enc_gemm_bf16
@@ -67,7 +68,7 @@ struct Knobs {
         pool_gemm = num("MI_POOL_GEMM", -1);
         no_few = set("MI_NO_FEW");
         few_d_fuse = set("MI_FEW_D_FUSE"); few_sync = set("MI_FEW_SYNC"); few_ts = set("MI_FEW_TS");
-        no_few_ao = set("MI_NO_FEW_AO"); no_few_gu8 = set("MI_NO_FEW_GU8");
+        no_few_ao = set("MI_NO_FEW_AO"); no_few_gu8 = set("MI_NO_FEW_GU8"); no_few_qkv8 = set("MI_NO_FEW_QKV8");
         enc_ts = num("MI_ENC_TS", 0); gemm_ts = set("MI_GEMM_TS");
     }
 };
@@ -88,6 +89,7 @@ std::atomic<int64_t> g_fused_rope_launches{0};   // QKV slab GEMMs whose epilogu
 std::atomic<int64_t> g_short_attn_launches{0};   // attention launches of the general path that took few_attn_kernel (every sequence <= 48 tokens)
 std::atomic<int64_t> g_mid_launches{0};   // QKV / O projections on the one-launch whole-K tiles of encoder_mid.h
 std::atomic<int64_t> g_few_passes{0};     // forward passes that took the query-time path (encoder_few.h)
+std::atomic<int64_t> g_few_qkv8_passes{0}; // ... with the QKV projection's fragments in registers (few_qkv8_kernel)
 std::atomic<int64_t> g_few_gu8_passes{0}; // ... with the gate/up projection on 8-feature units (few_gu8_kernel)
 std::atomic<int64_t> g_few_ao_passes{0};  // ... of them, with the attention inside the O projection (few_ao_kernel)
 
@@ -1066,6 +1068,12 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         q.ldqk = h->qk_cols; q.ldvt = ldvt; q.qk_cols = h->qk_cols; q.hd = c.head_dim; q.rope_blocks = h->qk_cols / 16;
         q.pos = b.pos; q.cos_t = h->rope_cos.get<float>(); q.sin_t = h->rope_sin.get<float>();
         if (dbg_ts && l == 0) q.ts = tsb.as<unsigned long long>((size_t)gemm_grid(q.nunits) * 8);
+        // fragments in registers (one unit per workgroup, a wave's K range <= FEW_GKP steps): few_qkv8_kernel
+        const bool qkv8 = !knobs().no_few_qkv8 && (q.nk + FEW_GW - 1) / FEW_GW <= FEW_GKP && q.nunits <= 256 && !(dbg_ts && l == 0);
+        if (qkv8) {
+            if (l == 0) g_few_qkv8_passes.fetch_add(1);
+            hipLaunchKernelGGL((few_qkv8_kernel<MT>), dim3((unsigned)q.nunits), dim3(64 * FEW_GW), 0, st, q);
+        } else
         hipLaunchKernelGGL((few_gemm_kernel<FEW_QKV, MT>), dim3((unsigned)gemm_grid(q.nunits)), dim3(64 * FEW_NW), gemm_smem(q.nk, 1), st, q);
         if (q.ts) stamps("qkv", gemm_grid(q.nunits));
         chk("qkv");
@@ -1107,8 +1115,13 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         if (h->few_gu8) {
             u.nunits = I / 8;
             if (l == 0) g_few_gu8_passes.fetch_add(1);
+            if (dbg_ts && l == 0) {
+                u.ts = tsb.as<unsigned long long>((size_t)256 * 8);
+                MI_HIP(hipMemsetAsync(u.ts, 0, (size_t)256 * 64, st));
+            }
             hipLaunchKernelGGL((few_gu8_kernel<MT>), dim3((unsigned)std::min(u.nunits, 256)), dim3(64 * FEW_GW),
                                (size_t)FEW_GW * FEW_GNU * MT * 1024 + (size_t)FEW_GW * 64 * 4, st, u);
+            if (u.ts) stamps("gate/up (8-feature units; phases: 1 requests issued, 2 first unit streamed, 4 stream done, 5 barrier, 7 end)", std::min(u.nunits, 256));
         } else {
         if (dbg_ts && l == 0) u.ts = tsb.as<unsigned long long>((size_t)gemm_grid(u.nunits) * 8);
         hipLaunchKernelGGL((few_gemm_kernel<FEW_GU, MT>), dim3((unsigned)gemm_grid(u.nunits)), dim3(64 * FEW_NW), gemm_smem(u.nk, 2), st, u);
@@ -1672,6 +1685,7 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
         else if (std::string(name) == "few_passes") *value = g_few_passes.load();
         else if (std::string(name) == "few_ao_passes") *value = g_few_ao_passes.load();
         else if (std::string(name) == "few_gu8_passes") *value = g_few_gu8_passes.load();
+        else if (std::string(name) == "few_qkv8_passes") *value = g_few_qkv8_passes.load();
         else if (std::string(name) == "mid_launches") *value = g_mid_launches.load();
         else if (std::string(name) == "short_attn_launches") *value = g_short_attn_launches.load();
         else throw Error(std::string("unknown debug counter: ") + name);

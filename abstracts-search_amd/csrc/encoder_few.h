@@ -422,6 +422,7 @@ __global__ void __launch_bounds__(64 * FEW_GW) few_gu8_kernel(FewArgs a) {
     if (nu <= 0) return;
     const int kper = (nk + FEW_GW - 1) / FEW_GW;                 // <= KP
     const int k0 = min(nk, w * kper), k1 = min(nk, k0 + kper), nsteps = k1 - k0;
+    few_stamp(a, 0);
     // ---- requests, in the order they are needed: the rows' partial sums of squares, the fragments of this K range, unit 0's pieces
     constexpr int SQ = 32;
     float sq[SQ];
@@ -454,8 +455,10 @@ __global__ void __launch_bounds__(64 * FEW_GW) few_gu8_kernel(FewArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) bf[s][mt] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
         }
+    few_stamp(a, 1);
     // ---- the stream: unit by unit over this wave's K range
     for (int u = 0; u < nu; ++u) {
+        if (u == 1) few_stamp(a, 2);
         f32x4 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -471,7 +474,9 @@ __global__ void __launch_bounds__(64 * FEW_GW) few_gu8_kernel(FewArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) part[((w * FEW_GNU + u) * MT + mt) * 64 + lane] = acc[mt];
     }
+    few_stamp(a, 4);
     __syncthreads();
+    few_stamp(a, 5);
     // ---- epilogue: item = (unit of the workgroup, token tile)
     for (int it = w; it < nu * MT; it += FEW_GW) {
         const int u = it / MT, mt = it - u * MT;
@@ -504,6 +509,136 @@ __global__ void __launch_bounds__(64 * FEW_GW) few_gu8_kernel(FewArgs a) {
             const int unit = u0 + u;
             bf16_t *dst = a.hfrag + ((size_t)((unit >> 2) * MT + mt) * 64 + ((unit & 3) * 16 + li)) * 8 + 4 * lg;
             *reinterpret_cast<uint2 *>(dst) = o;
+        }
+    }
+    few_stamp(a, 7);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// QKV projection with the fragments in registers (H <= 1536): workgroup = one 16-row unit, wave w = K range w, like
+// few_gemm_kernel<FEW_QKV> -- but a wave loads the fragments of ITS range (8 K steps x MT tiles) straight into its B operands
+// instead of the workgroup staging all of them through LDS first: the first MFMA waits for one wave's 24 KB, not for the
+// workgroup's 144 KB and a barrier (few_gemm_kernel's stamps: barrier at 5.5 k cycles of a 9.5 k-cycle workgroup).  The six
+// partial tiles meet in LDS in ascending order; epilogue = few_gemm_kernel<FEW_QKV>'s (1 / rms, bias, RoPE, Q | K rows or
+// pieces, V^T).   grid: nunits;  static LDS: FEW_GW x MT KiB | ssw[FEW_GW][64]
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ void __launch_bounds__(64 * FEW_GW) few_qkv8_kernel(FewArgs a) {
+    constexpr int KP = FEW_GKP;
+    __shared__ f32x4 part[FEW_GW * MT * 64];
+    __shared__ float ssw[FEW_GW * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int nk = a.nk, H = a.H, T = a.T;
+    const int unit = (int)blockIdx.x;
+    const int kper = (nk + FEW_GW - 1) / FEW_GW;                 // <= KP
+    const int k0 = min(nk, w * kper), k1 = min(nk, k0 + kper), nsteps = k1 - k0;
+    // the epilogue operands of the tile this wave will finish (wave mt: bias, position -> rotary table rows) ride in front
+    f32x4 pre_b = (f32x4){0.f, 0.f, 0.f, 0.f}, pre_c = pre_b, pre_s = pre_b;
+    if (w < MT) {
+        if (unit < a.rope_blocks) {
+            const int bph = a.hd / 16, head = unit / bph, bb = unit - head * bph, half = a.hd / 2;
+            const int jf = 8 * bb + 4 * (lg & 1);
+            const int ps = a.pos[min(16 * w + li, T - 1)];
+            pre_b = *reinterpret_cast<const f32x4 *>(a.bias + head * a.hd + (lg < 2 ? 0 : half) + jf);
+            pre_c = *reinterpret_cast<const f32x4 *>(a.cos_t + (size_t)ps * half + jf);
+            pre_s = *reinterpret_cast<const f32x4 *>(a.sin_t + (size_t)ps * half + jf);
+        } else {
+            pre_b = *reinterpret_cast<const f32x4 *>(a.bias + a.qk_cols + 16 * (unit - a.rope_blocks) + 4 * lg);
+        }
+    }
+    constexpr int SQ = 4;
+    float sq[SQ];
+    if (a.nparts > 0) {
+#pragma unroll
+        for (int i = 0; i < SQ; ++i) sq[i] = a.ssq[min(w + FEW_GW * i, a.nparts - 1) * FEW_SSQ_LD + lane];
+    }
+    bf16x8 bf[KP][MT], ring[KP];
+#pragma unroll
+    for (int s = 0; s < KP; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            bf[s][mt] = *reinterpret_cast<const bf16x8 *>(a.afrag + ((size_t)(min(k0 + s, nk - 1) * MT + mt) * 64 + lane) * 8);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < KP; ++s) few_wload(ring[s], a.W + ((size_t)unit * nk + min(k0 + s, nk - 1)) * 512 + lane * 8);
+    if (a.nparts > 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < SQ; ++i) t += w + FEW_GW * i < a.nparts ? sq[i] : 0.f;
+        for (int p = w + FEW_GW * SQ; p < a.nparts; p += FEW_GW) t += a.ssq[p * FEW_SSQ_LD + lane];
+        ssw[w * 64 + lane] = t;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KP; ++s)
+        if (s < nsteps) {                                        // (uniform)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[s], bf[s][mt], acc[mt], 0, 0, 0);
+        }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) part[(w * MT + mt) * 64 + lane] = acc[mt];
+    __syncthreads();
+    if (w >= MT) return;
+    // ---- epilogue: wave mt finishes tile mt
+    const int mt = w, m = 16 * mt + li;
+    float inv = 1.f;
+    if (a.nparts > 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < FEW_GW; ++ww) tot += ssw[ww * 64 + m];
+        inv = rsqrtf(tot / (float)H + a.eps);
+    }
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < FEW_GW; ++c) {                            // ascending K ranges: a fixed order
+        const f32x4 p = part[(c * MT + mt) * 64 + lane];
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= inv;
+    if (unit < a.rope_blocks) {
+        const int bph = a.hd / 16, head = unit / bph, bb = unit - head * bph, half = a.hd / 2;
+        const int jf = 8 * bb + 4 * (lg & 1);                     // index inside the half
+        const int fih = (lg < 2 ? 0 : half) + jf;                 // feature inside the head (r added below)
+        float q[4] = {v[0] + pre_b[0], v[1] + pre_b[1], v[2] + pre_b[2], v[3] + pre_b[3]};
+        float pp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pp[r] = __shfl_xor(q[r], 32);
+        float o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = lg < 2 ? q[r] * pre_c[r] - pp[r] * pre_s[r] : q[r] * pre_c[r] + pp[r] * pre_s[r];
+        if (m < T) {
+            uint2 o;
+            o.x = pack2(o4[0], o4[1]);
+            o.y = pack2(o4[2], o4[3]);
+            bf16_t *dst = a.qk + (size_t)m * a.ldqk + head * a.hd + fih;
+            if (a.attn_pieces) {                                  // (few_gemm_kernel<FEW_QKV>'s piece addresses)
+                const int nkd = a.hd / 32, kd = fih >> 5, sub = (((fih >> 3) & 3) * 16) * 8 + (fih & 4);
+                if (head < a.n_heads)
+                    dst = a.qk + ((size_t)((head * nkd + kd) * MT + mt) * 64 + li) * 8 + sub;
+                else
+                    dst = a.qk + ((size_t)a.n_heads * nkd * MT + (size_t)(((head - a.n_heads) * 2 + ((m >> 2) & 1)) * nkd + kd)) * 512 +
+                          (4 * (m >> 3) + (m & 3)) * 8 + sub;
+            }
+            *reinterpret_cast<uint2 *>(dst) = o;
+        }
+    } else {
+        const int vf = 16 * (unit - a.rope_blocks) + 4 * lg;      // V feature (r added below)
+        if (m < T) {
+            if (a.attn_pieces) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dim = vf + r, kvh = dim / a.hd, wi = dim - kvh * a.hd;
+                    a.vt[((size_t)(kvh * (a.hd / 16) + (wi >> 4)) * 64 + ((m >> 3) * 16 + (wi & 15))) * 8 + (m & 7)] = f2bf(v[r] + pre_b[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.vt[(size_t)(vf + r) * a.ldvt + m] = f2bf(v[r] + pre_b[r]);
+            }
         }
     }
 }
@@ -884,7 +1019,9 @@ __global__ void __launch_bounds__(64) few_attn_kernel(AttnArgs a) {
 // keys, O^T = V^T P^T) -- redundantly in every workgroup: Q | K | V^T are 4 KB per token, less than the fragments few_o_kernel
 // stages -- and its lane's output registers (four dims of tiles 2 J, 2 J + 1 of one query) ARE the B operand of the O
 // projection's K step (head, J) once the weight pieces carry their K columns in that order (few_tile_kernel<8, true>).
-// The heads' partial tiles meet in LDS in ascending order; the epilogue is few_o_kernel's.
+// The heads' partial tiles meet in LDS in ascending order; the epilogue is few_o_kernel's.  (33 .. 48 tokens keep the two launches:
+// 64 keys and three query tiles are ~180 operand registers -- on 12 waves the build spilled (one query 1.26 -> 1.69 ms), on 6 waves
+// of two heads each it measured 1.31 against 1.26.)
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int FEW_AW = 12;
 template <int HD, int MT>

@@ -527,7 +527,8 @@ def test_attention_inside_the_o_projection_vs_the_two_launches(st, ntok, causal,
     projection -- against few_attn_kernel + few_o_kernel (MI_NO_FEW_AO=1: rows of Q | K, V^T rows, fragments through memory)
     and against the fp32 oracle, bidirectional and causal, at stella's widths, at the token-tile and key-tile edges.  The second
     model also takes the gate/up projection on 16-feature unit pairs (MI_NO_FEW_GU8=1: few_gemm_kernel<FEW_GU>) where the
-    first runs few_gu8_kernel."""
+    first runs few_gu8_kernel, and the QKV projection with its fragments staged through LDS (MI_NO_FEW_QKV8=1) where the first
+    keeps them in registers (few_qkv8_kernel)."""
     import torch
     from oracle import encoder_oracle as E
     cfg = dict(st.STELLA_EN_1_5B_V5)
@@ -545,11 +546,13 @@ def test_attention_inside_the_o_projection_vs_the_two_launches(st, ntok, causal,
     assert st.debug_counter("few_gu8_passes") - gu0 == 3
     monkeypatch.setenv("MI_NO_FEW_AO", "1")
     monkeypatch.setenv("MI_NO_FEW_GU8", "1")
+    monkeypatch.setenv("MI_NO_FEW_QKV8", "1")
+    q0 = st.debug_counter("few_qkv8_passes")
     model2 = st.SentenceTransformer(config=cfg, weights=W)
     hs2 = model2.last_hidden_state(toks)
     e_two = model2.encode_tokens(toks, batch_size=1, normalize_embeddings=True)
     assert st.debug_counter("few_ao_passes") - ao0 == 3           # the two launches took these
-    assert st.debug_counter("few_gu8_passes") - gu0 == 3
+    assert st.debug_counter("few_gu8_passes") - gu0 == 3 and st.debug_counter("few_qkv8_passes") == q0
     cos2 = (hs * hs2).sum(1) / (np.linalg.norm(hs, axis=1) * np.linalg.norm(hs2, axis=1))
     assert cos2.min() > 1 - 2e-4 and ((e * e_two).sum(1)).min() > 1 - 2e-4, (cos2.min(), (e * e_two).sum(1))
     Wc = {k: v.float().cpu() for k, v in W.items()}
