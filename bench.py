@@ -940,7 +940,8 @@ def cfg5_curve(args, ctx, model, cfg, host_w, index, sharded, nprobe, k, steps, 
                     "algorithmic_flops": "2 x parameters x tokens + 4 x layers x q_cols x sum(len^2) (attention)"}
         qp, q_src = committed_traffic("r05_encode_query_pmc.json", lambda d_: any(r_.get("tokens") == ntok for r_ in d_["regimes"].values()))
         q_traffic = [r_["bytes_per_pass"] for r_ in qp["regimes"].values() if r_.get("tokens") == ntok][0] if qp else None
-        roof.update({"kernel": "the encoder forward pass (%s)" % ("csrc/encoder_few.h: six weight-streaming launches per layer" if ntok <= 48 else
+        roof.update({"kernel": "the encoder forward pass (%s)" % ("csrc/encoder_few.h: five weight-streaming launches per layer, the attention inside the O projection's" if ntok <= 32 else
+                                                                    "csrc/encoder_few.h: six weight-streaming launches per layer" if ntok <= 48 else
                                                                     "general path: MFMA GEMM tiles by token count"),
                      "traffic": q_traffic, "traffic_source": q_src, "avg_launch_ms": round(enc * 1e3, 4), "what": "encode alone, back-to-back calls"})
         curve.append({"batch": batch, "latency_ms_p50": round(lat[len(lat) // 2] * 1e3, 3),

@@ -5,13 +5,16 @@
   profiles/r05_encode_query_pmc.json       whole forward passes of the query-time regimes: one query (31 tokens), 16 queries (563 tokens)
 Every file carries `kernel_source` (tools/kernel_stamp.py): bench.py drops a number whose kernel text changed since the pass.
 FETCH_SIZE: x2 on gfx950 (a wide coalesced read is counted at half its bytes: MI355X_MICROARCH.md, section HBM), KiB units;
-WRITE_SIZE as is.   usage: python tools/pmc_json_r05.py [dir = gpurun_out/r05_prof]"""
+WRITE_SIZE as is.   usage: [PMC_VER=v2] python tools/pmc_json_r05.py [dir = gpurun_out/r05_prof]
+Only the parts found under `dir` are rewritten: the query-time file keeps the regimes (and their stamps) a run did not profile again;
+PMC_VER names the copies of the summaries it cites (profiles/r05_<part>_kernel_stats_<ver>.csv ...)."""
 import csv, json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import kernel_stamp
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r05_prof")
 prof = os.path.join(ROOT, "profiles")
+VER = os.environ.get("PMC_VER", "v1")
 CORR = "gfx950: FETCH_SIZE counts a wide coalesced read at half its bytes (MI355X_MICROARCH.md, section HBM) -> read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 taken as is; both are the L2's memory-side requests (Infinity-Cache hits are inside the count)"
 
 
@@ -41,7 +44,7 @@ def keep(stem):   # copy the summaries the json files cite
     for suf in ("_kernel_stats.csv", "_FETCH_SIZE.txt", "_WRITE_SIZE.txt"):
         f = os.path.join(src, stem + suf)
         if os.path.exists(f):
-            dst = os.path.join(prof, "r05_" + stem + suf.replace("_kernel_stats", "_kernel_stats_v1").replace("_SIZE.txt", "_SIZE_v1.txt"))
+            dst = os.path.join(prof, "r05_" + stem + suf.replace("_kernel_stats", "_kernel_stats_" + VER).replace("_SIZE.txt", "_SIZE_" + VER + ".txt"))
             open(dst, "w").write(open(f).read())
 
 
@@ -97,8 +100,18 @@ if os.path.exists(src + "/encode_gemm_FETCH_SIZE.txt"):
 doc = {"correction": CORR, "regimes": {}, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction (profiles/r05_encode_query_pmc.json)",
        "how": "tools/prof_r05.sh b1 / mid: every kernel of the pass summed (per-kernel mean x launches per forward pass = dispatches / passes)"}
 stamps = []
-for tag, frag, hdr, kerns in (("b1", "few_", "encoder_few.h", ["few_gemm_kernel", "few_o_kernel", "few_d_kernel", "few_row_kernel"]),
-                              ("mid", "mienc", "encoder_mid.h", ["mid_gemm_kernel"]), ("mid256", "mienc", "encoder_kernels.h", ["gemm_bf16_slab_kernel"])):
+try:                                                              # regimes an earlier run profiled stay (with their stamps) unless this run has them again
+    old = json.load(open(prof + "/r05_encode_query_pmc.json"))
+except Exception:
+    old = {"regimes": {}, "kernel_source": []}
+REG = (("b1", "few_", "encoder_few.h", ["few_qkv8_kernel", "few_ao_kernel", "few_gu8_kernel", "few_d_kernel", "few_row_kernel"]),
+       ("mid", "mienc", "encoder_mid.h", ["mid_gemm_kernel"]), ("mid256", "mienc", "encoder_kernels.h", ["gemm_bf16_slab_kernel"]))
+again = [tag for tag, *_ in REG if os.path.exists(src + f"/{tag}_FETCH_SIZE.txt")]
+for tag, r in old.get("regimes", {}).items():
+    if tag not in again:
+        doc["regimes"][tag] = r
+        stamps += r.get("kernel_source") or [s_ for s_ in old.get("kernel_source", []) if (tag == "b1") == s_["kernel"].startswith("few_")]
+for tag, frag, hdr, kerns in REG:
     F, W, st = parse(src + f"/{tag}_FETCH_SIZE.txt"), parse(src + f"/{tag}_WRITE_SIZE.txt"), stats(src + f"/{tag}_kernel_stats.csv")
     if not F:
         continue
@@ -108,7 +121,7 @@ for tag, frag, hdr, kerns in (("b1", "few_", "encoder_few.h", ["few_gemm_kernel"
     ntok = int(m.group(1)) if m else None
     layer_k = [k for k in F if frag in k and not any(x in k for x in ("import_rows", "interleave", "few_tile", "tile_weights"))]
     # launches per pass: a per-layer kernel is dispatched 28 x passes times; passes = dispatches of the first per-layer GEMM / 28
-    gem = [k for k in layer_k if ("few_gemm_kernel<0" in k or "mid_gemm_kernel<0" in k or "gemm_bf16_slab_kernel<3" in k)]
+    gem = [k for k in layer_k if ("few_qkv8_kernel" in k or "few_gemm_kernel<0" in k or "mid_gemm_kernel<0" in k or "gemm_bf16_slab_kernel<3" in k)]
     passes = F[gem[0]]["FETCH_SIZE"][0] / 28.0 if gem else None
     tot_f = tot_w = 0.0
     per = {}
@@ -120,11 +133,14 @@ for tag, frag, hdr, kerns in (("b1", "few_", "encoder_few.h", ["few_gemm_kernel"
         tot_f += f; tot_w += w
         per[k] = {"launches_per_pass": round(per_pass, 2), "fetch_bytes_per_pass": int(f), "write_bytes_per_pass": int(w), "avg_us": avg_us(st, k[:40])}
     doc["regimes"][tag] = {"tokens": ntok, "passes_profiled": passes, "fetch_bytes_per_pass": int(tot_f), "write_bytes_per_pass": int(tot_w) if W else None,
-                           "bytes_per_pass": int(tot_f + tot_w), "kernels": per, "kernel_stats_file": f"profiles/r05_{tag}_kernel_stats_v1.csv"}
-    stamps += [kernel_stamp.stamp(hdr, k) for k in kerns]
+                           "bytes_per_pass": int(tot_f + tot_w), "kernels": per, "kernel_stats_file": f"profiles/r05_{tag}_kernel_stats_{VER}.csv"}
+    mine = [kernel_stamp.stamp(hdr, k) for k in kerns]
     if tag == "mid":
-        stamps.append(kernel_stamp.stamp("encoder_kernels.h", "gemm_bf16_slab_kernel"))
+        mine.append(kernel_stamp.stamp("encoder_kernels.h", "gemm_bf16_slab_kernel"))
+    doc["regimes"][tag]["kernel_source"] = mine
+    stamps += mine
 if doc["regimes"]:
-    doc["kernel_source"] = stamps
+    seen = set()
+    doc["kernel_source"] = [s_ for s_ in stamps if not ((s_["header"], s_["kernel"]) in seen or seen.add((s_["header"], s_["kernel"])))]
     json.dump(doc, open(prof + "/r05_encode_query_pmc.json", "w"), indent=1); made.append("r05_encode_query_pmc.json")
 print("wrote", made)
