@@ -1,15 +1,19 @@
 // encoder_few.h -- the query-time encoder: a forward pass over a handful of tokens (one prompted query, T <= 48) is a
 // pass over the 93.6 MB of bf16 weights of every layer and nothing else, so every kernel here is a WEIGHT STREAM with the
 // arithmetic hanging off it (reference call site: README.md:28, the query-time app; arithmetic restated in
-// oracle/encoder_oracle.py).  Six launches per layer instead of the general path's ten, no atomics (bit-reproducible):
+// oracle/encoder_oracle.py).  Five launches per layer for one sequence of <= 32 tokens (six otherwise) instead of the general
+// path's ten, no atomics (bit-reproducible):
 //
 //   few_row_kernel<EMBED>          token ids -> f32 stream + the first RMSNorm as bf16 fragments
-//   few_gemm_kernel<FEW_QKV>       QKV projection of the normalised fragments -> +bias -> RoPE -> Q|K rows, V^T
-//   attn_kernel                    (encoder_kernels.h) with its output written as fragments
-//   few_o_kernel                   O projection + residual add, 8 output features per workgroup over ALL of K:
-//                                  writes the stream, bf16(x g) fragments for the next RMSNorm and the per-token
-//                                  partial sums of squares of its 8 columns
-//   few_gemm_kernel<FEW_GU>        gate/up projection of those fragments, 1/rms applied to the accumulators -> SwiGLU -> h fragments
+//   few_qkv8_kernel                QKV projection (H <= 1536: a wave keeps the fragments of its K range in registers;
+//                                  else few_gemm_kernel<FEW_QKV>, fragments staged through LDS) -> +bias -> RoPE -> Q|K rows, V^T
+//                                  -- or, in front of few_ao_kernel, the same values as the attention's MFMA-operand pieces
+//   few_ao_kernel                  one sequence of <= 32 tokens: attention INSIDE the O projection's workgroups + residual add
+//   few_attn_kernel + few_o_kernel otherwise: attention with its output written as fragments; O projection + residual add,
+//                                  8 output features per workgroup over ALL of K: writes the stream, bf16(x g) fragments for
+//                                  the next RMSNorm and the per-token partial sums of squares of its 8 columns
+//   few_gu8_kernel                 gate/up projection on 8-feature units (H <= 1536; else few_gemm_kernel<FEW_GU> on 16-feature
+//                                  pairs), 1/rms applied to the accumulators -> SwiGLU -> h fragments
 //   few_d_kernel                   down projection, K split over workgroups -> partial planes (plain stores)
 //   few_row_kernel<REDUCE>         stream += planes (fixed order), next layer's first RMSNorm as fragments
 //
