@@ -45,7 +45,7 @@ struct Knobs {
     bool no_few;             // MI_NO_FEW=1: a handful of tokens through the general path (fragment-major tiles)
     bool few_d_fuse, few_sync, few_ts;   // MI_FEW_D_FUSE (in-launch reduction of the down projection), MI_FEW_SYNC, MI_FEW_TS
     bool no_few_gu8;         // MI_NO_FEW_GU8=1: the query-time gate/up projection on 16-feature unit pairs (few_gemm_kernel<FEW_GU>) instead of 8-feature units
-    bool no_few_qkv8;        // MI_NO_FEW_QKV8=1: the query-time QKV projection stages its fragments through LDS (few_gemm_kernel<FEW_QKV>)
+    bool no_few_qkv8;        // MI_NO_FEW_QKV8=1: the query-time QKV / O projections stage their fragments through LDS (few_gemm_kernel<FEW_QKV>, few_o_kernel)
     bool no_few_ao;          // MI_NO_FEW_AO=1: one sequence of <= 32 tokens keeps few_attn_kernel + few_o_kernel (no attention inside the O projection)
     int enc_ts;              // MI_ENC_TS=1: in-kernel stamps of the first four slab GEMMs of > 4096 tokens; =n (n > 1): of > n tokens
     bool gemm_ts;            // MI_GEMM_TS=1: the same for mi_enc_gemm_bf16
@@ -1106,6 +1106,9 @@ void few_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, float *x, bf16
         FewArgs o{};
         o.T = T; o.H = H; o.nk = h->q_cols / 32; o.nunits = H / 8; o.W = w.few_o.get<bf16_t>(); o.afrag = afrag; o.x = x;
         o.norm_w = w.ln2.get<float>(); o.ssq_out = ssq; o.xfrag = xfrag;
+        if (!knobs().no_few_qkv8 && (o.nk + FEW_OW - 1) / FEW_OW <= 6)   // fragments in registers (MI_NO_FEW_QKV8 turns both projections back)
+            hipLaunchKernelGGL((few_o8_kernel<MT>), dim3((unsigned)o.nunits), dim3(64 * FEW_OW), 0, st, o);
+        else
         hipLaunchKernelGGL((few_o_kernel<MT>), dim3((unsigned)o.nunits), dim3(64 * FEW_OW), (size_t)std::max(o.nk, FEW_OW) * MT * 1024, st, o);
         chk("o");
         }

@@ -720,6 +720,78 @@ __global__ void __launch_bounds__(64 * FEW_OW) few_o_kernel(FewArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// few_o_kernel with the fragments in registers (q_cols <= 1536): the 8 waves' K ranges are disjoint, so a wave loads the
+// attention fragments of ITS range (6 K steps x MT tiles) straight into its B operands -- no staging of all of them through
+// LDS, no barrier in front of the stream (few_qkv8_kernel's reasoning).  Same sums in the same order as few_o_kernel.
+// static LDS: 8 x MT KiB
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ void __launch_bounds__(64 * FEW_OW) few_o8_kernel(FewArgs a) {
+    constexpr int KP = 6;
+    __shared__ f32x4 part[FEW_OW * MT * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int nk = a.nk, T = a.T, H = a.H;
+    const int hu = (int)blockIdx.x;
+    const int kper = (nk + FEW_OW - 1) / FEW_OW;                 // <= KP (the host checks)
+    const int k0 = min(nk, w * kper), k1 = min(nk, k0 + kper), nsteps = k1 - k0;
+    // the lanes that will finish a tile (wave mt, lg < 2) request their 4 columns of the stream and the gains first
+    const int em = 16 * w + li, ef = 8 * hu + 4 * (lg & 1);
+    const bool eown = w < MT && lg < 2 && em < T;
+    float *px = a.x + (size_t)min(em, T - 1) * H + ef;
+    f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f}, gv = xv;
+    if (eown) xv = *reinterpret_cast<const f32x4 *>(px);
+    if (w < MT) gv = *reinterpret_cast<const f32x4 *>(a.norm_w + ef);
+    bf16x8 bf[KP][MT], ring[KP];
+#pragma unroll
+    for (int s = 0; s < KP; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            bf[s][mt] = *reinterpret_cast<const bf16x8 *>(a.afrag + ((size_t)(min(k0 + s, nk - 1) * MT + mt) * 64 + lane) * 8);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < KP; ++s) few_wload(ring[s], a.W + ((size_t)hu * nk + min(k0 + s, nk - 1)) * 256 + (lg * 8 + (li & 7)) * 8);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KP; ++s)
+        if (s < nsteps) {                                        // (uniform)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[s], bf[s][mt], acc[mt], 0, 0, 0);
+        }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) part[(w * MT + mt) * 64 + lane] = acc[mt];
+    __syncthreads();
+    // tile mt is finished by wave mt; lanes lg < 2 hold the 8 real features (4 lg + r), token li
+    if (w < MT) {
+        const int mt = w, m = 16 * mt + li;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < FEW_OW; ++c) {
+            const f32x4 p = part[(c * MT + mt) * 64 + lane];
+            v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+        }
+        float ss = 0.f;                                         // (lanes lg >= 2 repeat lg - 2; they store nothing)
+        if (eown) {
+            xv[0] += v[0]; xv[1] += v[1]; xv[2] += v[2]; xv[3] += v[3];
+            *reinterpret_cast<f32x4 *>(px) = xv;
+            ss = xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2] + xv[3] * xv[3];
+        }
+        ss += __shfl_xor(ss, 16);                               // the two halves of the 8 features
+        if (lg == 0) a.ssq_out[hu * FEW_SSQ_LD + m] = ss;       // (padding tokens: 0)
+        if (lg < 2) {                                           // fragments: every token of the tile (padding tokens: zeros)
+            uint2 o;
+            o.x = pack2(xv[0] * gv[0], xv[1] * gv[1]);
+            o.y = pack2(xv[2] * gv[2], xv[3] * gv[3]);
+            bf16_t *dst = a.xfrag + ((size_t)((hu >> 2) * MT + mt) * 64 + ((hu & 3) * 16 + li)) * 8 + 4 * lg;
+            *reinterpret_cast<uint2 *>(dst) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Down projection: h (T x I) is too long to give every workgroup all of K, so K is split over workgroups and slice s
 // writes its partial tile into plane s (plain 16-byte stores; few_row_kernel adds the planes in order).
 // grid: (ceil(nunits / 4) unit groups) x nslices, 4 waves; wave w streams unit 4 ug + w over the slice, whose activation
