@@ -43,6 +43,7 @@ struct Knobs {
     int two_stage;        // MI_TWO_STAGE=0|1: force the two-stage coarse quantiser off / on (-1: by shape)
     bool refine_gmax;     // MI_REFINE_GMAX=0: its second stage reads the score rows instead of the GEMM's group maxima
     bool refine_stats;    // MI_REFINE_STATS=1: print candidates per row of the second stage (synchronises)
+    bool refine_ts;       // MI_REFINE_TS=1: print the mean in-kernel phase stamps of the second stage (synchronises; tools/micro/coarse_stage.py)
     int select_big_from;  // MI_SELECT_BIG_FROM: smallest K the sort-based selection takes (65)
     int nslice;           // MI_NSLICE: scan slices per query (0: by shape)
     int scan_nw;          // MI_SCAN_NW=8|16: waves per scan workgroup (0: by shape)
@@ -57,6 +58,7 @@ struct Knobs {
         two_stage = num("MI_TWO_STAGE", -1);
         refine_gmax = num("MI_REFINE_GMAX", 1) != 0;
         refine_stats = set("MI_REFINE_STATS");
+        refine_ts = set("MI_REFINE_TS");
         select_big_from = num("MI_SELECT_BIG_FROM", 65);
         nslice = num("MI_NSLICE", 0);
         scan_nw = num("MI_SCAN_NW", 0);
@@ -306,8 +308,28 @@ void launch_two_stage(const float *q, int64_t nq, const float *c32, const f16_t 
         ra.stats = static_cast<unsigned *>(statbuf.reserve(8));
         MI_HIP(hipMemsetAsync(ra.stats, 0, 8, st));
     }
-    hipLaunchKernelGGL(select_refine_kernel, dim3((unsigned)nq), dim3(256), 0, st, ra);
+    DevBuf tsbuf;
+    if (knobs().refine_ts) {
+        ra.ts = static_cast<unsigned long long *>(tsbuf.reserve((size_t)nq * 64));
+        MI_HIP(hipMemsetAsync(ra.ts, 0, (size_t)nq * 64, st));
+    }
+    if (d <= 1024) hipLaunchKernelGGL(select_refine_kernel<1024>, dim3((unsigned)nq), dim3(256), 0, st, ra);
+    else hipLaunchKernelGGL(select_refine_kernel<4096>, dim3((unsigned)nq), dim3(256), 0, st, ra);
     MI_HIP(hipGetLastError());
+    if (ra.ts) {
+        std::vector<unsigned long long> ts((size_t)nq * 8);
+        MI_HIP(hipMemcpyAsync(ts.data(), ra.ts, ts.size() * 8, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
+        double sum[8] = {0}, first = 1e300, last = 0;
+        for (int64_t r = 0; r < nq; ++r) {
+            for (int i = 1; i < 8; ++i) sum[i] += (double)(ts[r * 8 + i] - ts[r * 8 + i - 1]);
+            first = std::min(first, (double)ts[r * 8]);
+            last = std::max(last, (double)ts[r * 8 + 7]);
+        }
+        std::fprintf(stderr, "select_refine stamps (s_memtime ticks, mean of %lld workgroups; K %d): load+norm+maxima %.0f | descent %.0f | "
+                     "groups+candidates %.0f | chains %.0f | sort %.0f | output %.0f | tables %.0f | kernel span %.0f\n",
+                     (long long)nq, K, sum[1] / nq, sum[2] / nq, sum[3] / nq, sum[4] / nq, sum[5] / nq, sum[6] / nq, sum[7] / nq, last - first);
+    }
     if (want_stats) {
         unsigned hs[2] = {0, 0};
         MI_HIP(hipMemcpyAsync(hs, ra.stats, 8, hipMemcpyDeviceToHost, st));

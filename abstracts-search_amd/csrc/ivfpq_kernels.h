@@ -1474,6 +1474,12 @@ __global__ void __launch_bounds__(NT_, SET_ ? (NT_ == 256 ? 2 : 4) : 1)
 // The host adds 1 % for the second-order terms; |q| and max|c| are rounded up by 0.1 %.
 // =====================================================================
 
+// value of lane (CTRL & 3) of the lane's quad in every lane of the quad (CTRL = quad_perm [j, j, j, j] = j * 0x55)
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 // Power of two that brings a largest magnitude m into [2^13, 2^14): far from f16's overflow
 // (65504), and an element then only leaves f16's normal range if it is below 2^-27 m.
 __device__ __forceinline__ float f16_pow2_scale(float m) {
@@ -1559,11 +1565,15 @@ struct RefineArgs {
     const float *gmax;    // null, or [rows][ngroups]: maxima of the approximate row over 64-column groups, written by the
     int ngroups;          // f16 GEMM's epilogue (+inf marks a group with a non-finite score): the row itself is then read
                           // only where a group can hold a candidate (268 MB of scores at 1024 x 65536 otherwise)
+    unsigned long long *ts;   // null, or [rows][8] s_memtime stamps of the workgroup's phases (MI_REFINE_TS=1, tools only)
 };
 
-__global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
+// DCAP: the longest query row the instantiation holds in LDS (d <= DCAP).  <1024>: 39 KiB of LDS, FOUR workgroups per CU --
+// 1024 rows are one round of workgroups on 256 CUs where the 51 KiB of <4096> made them a round of 768 and one of 256.
+template <int DCAP>
+__global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kernel(RefineArgs a) {   // (HIP: min waves per SIMD = workgroups per CU here)
     __shared__ unsigned long long skey[SELB_CAP];
-    __shared__ __attribute__((aligned(16))) float qs[4096];   // the query row (d <= 4096), read as float4
+    __shared__ __attribute__((aligned(16))) float qs[DCAP];   // the query row (d <= DCAP), read as float4
     __shared__ int wcnt[2][4];
     __shared__ float wred[4];
     __shared__ int wtot[4];
@@ -1576,6 +1586,10 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
     const int n = a.n, d = a.d, K = a.K;
     float *r = a.Sa + row * a.ldS;
     const float *qg = a.q + row * d;
+    auto stamp = [&](int i) {   // no-op unless a profiling run asked for stamps
+        if (a.ts && tid == 0) a.ts[(size_t)row * 8 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     // query row -> LDS, its norm
     float nrm = 0.f;
     for (int k = tid; k < d; k += 256) {
@@ -1628,6 +1642,50 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
         }
         return acc;
     };
+    // The same chain with the row LOADED by the four lanes of a quad: lane j of the quad requests the 16-byte pieces
+    // 4 i + j of the row, so a quad reads 64 contiguous bytes per instruction (a lane on its own row: 16 B of a line per
+    // instruction, eight instructions per line -- the one-lane chain was bound by its ~0.5 us load round trips, 128 B
+    // in flight per row and set) and four times the bytes are in flight per row; every lane of the quad then runs the
+    // whole chain on the pieces broadcast inside the quad (DPP quad_perm), k ascending: the same value in all four.
+    auto exact_quad = [&](int col) -> float {
+        const int j = lane & 3;
+        const float4 *cp = reinterpret_cast<const float4 *>(a.cent + (size_t)col * d) + j;
+        const int nset = d >> 7;   // 128 floats per set (d % 128 == 0)
+        float4 A[8], B[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) A[i] = cp[4 * i];
+        float acc = 0.f;
+        auto run = [&](const float4 (&S)[8], int set) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 qv = *reinterpret_cast<const float4 *>(qs + 128 * set + 16 * i + 4 * jj);
+                    // acc = fma(c of quad lane jj, q, acc), four times: v_fmac_f32 with a DPP source (hipcc keeps a
+                    // v_mov_b32_dpp in front of every v_fma_f32: twice the VALU time of the chain).  The compiler does not see
+                    // a DPP read in the asm: s_nop 1 covers a VALU write of the first piece right in front (2 wait states).
+                    switch (jj) {
+                    case 0: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %5 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %2, %6 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %3, %7 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %4, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(S[i].x), "v"(S[i].y), "v"(S[i].z), "v"(S[i].w), "v"(qv.x), "v"(qv.y), "v"(qv.z), "v"(qv.w)); break;
+                    case 1: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %5 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %2, %6 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %3, %7 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %4, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(S[i].x), "v"(S[i].y), "v"(S[i].z), "v"(S[i].w), "v"(qv.x), "v"(qv.y), "v"(qv.z), "v"(qv.w)); break;
+                    case 2: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %5 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %2, %6 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %3, %7 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %4, %8 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(S[i].x), "v"(S[i].y), "v"(S[i].z), "v"(S[i].w), "v"(qv.x), "v"(qv.y), "v"(qv.z), "v"(qv.w)); break;
+                    default: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %2, %6 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %3, %7 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %4, %8 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(S[i].x), "v"(S[i].y), "v"(S[i].z), "v"(S[i].w), "v"(qv.x), "v"(qv.y), "v"(qv.z), "v"(qv.w)); break;
+                    }
+                }
+            }
+        };
+        for (int set = 0; set < nset; set += 2) {
+            const int nb = min(set + 1, nset - 1);   // (an odd number of sets: a harmless re-read, not used)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) B[i] = cp[32 * nb + 4 * i];
+            run(A, set);
+            if (set + 1 >= nset) break;
+            const int nx = min(set + 2, nset - 1);   // last round: a harmless re-read
+#pragma unroll
+            for (int i = 0; i < 8; ++i) A[i] = cp[32 * nx + 4 * i];
+            run(B, set + 1);
+        }
+        return acc;
+    };
     constexpr int VPT = 16, TILE = 256 * VPT;
     int ph = 0;
     auto block_sum = [&](int wave_total) -> int {
@@ -1673,6 +1731,7 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
             }
         }
         if (!exact_row && block_sum(__popcll(__ballot(nonfinite != 0))) > 0) bad = true;
+        stamp(1);
         unsigned T0 = 0;
         if (K <= 256) {
             // barrier-free, as in select_kernel: 1024 maxima (4 per thread) in LDS, every wave
@@ -1718,6 +1777,7 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
                 if (c == K) break;
             }
         }
+        stamp(2);
         // cut in the score domain; T0 == 0: fewer than K finite entries, keep all
         const float cut = T0 ? o2f(T0) - (exact_row ? 0.f : margin) : -__builtin_inff();
         if (ext) {
@@ -1727,13 +1787,32 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
                 for (int g = 0; g < 4; ++g)
                     if (gq[g] != 0u && o2f(gq[g]) >= cut) glist[atomicAdd(&g_cnt, 1)] = (unsigned short)(g * 256 + tid);
                 __syncthreads();
+                // 16 bytes of a group per lane (4 scores; 16 groups a pass), four passes' loads issued together: a wave per group
+                // and pass was a dependent round trip per ~100 surviving groups / 4 waves
                 const int ng = g_cnt;
-                for (int i = w; i < ng; i += 4) {
-                    const int c = (int)glist[i] * 64 + lane;
-                    const float v = r[c] * inv;
-                    if (v >= cut) {
-                        const int pos = atomicAdd(&c_cnt, 1);
-                        if (pos < SELB_CAP) skey[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)c;
+                constexpr int lpg = 16, epl = 4, gpp = 256 / lpg;
+                const int gsl = tid / lpg, part = tid % lpg;
+                for (int i0 = 0; i0 < ng; i0 += 4 * gpp) {
+                    float4 raw[4];
+                    int c0[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int gi = i0 + u * gpp + gsl;
+                        c0[u] = gi < ng ? (int)glist[gi] * 64 + part * epl : -1;
+                        if (gi < ng) raw[u] = *reinterpret_cast<const float4 *>(r + c0[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (c0[u] < 0) continue;
+                        const float wd[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+#pragma unroll
+                        for (int e = 0; e < epl; ++e) {
+                            const float v = wd[e] * inv;
+                            if (v >= cut) {
+                                const int pos = atomicAdd(&c_cnt, 1);
+                                if (pos < SELB_CAP) skey[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(c0[u] + e);
+                            }
+                        }
                     }
                 }
             }
@@ -1791,6 +1870,7 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
             }
         }
         __syncthreads();
+        stamp(3);
         Sn = c_cnt;
         if ((bad && !exact_row) || Sn > SELB_CAP) {
             if (exact_row) break;   // still too many after the exact pass: masses of exact ties
@@ -1816,14 +1896,25 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
     if (a.stats && tid == 0) atomicAdd(a.stats, (unsigned)Sn);
     // exact score of every candidate, then the sort key
     __syncthreads();
-    // candidate e goes to thread (e % 4) * 64 + e / 4: the chains spread over the four SIMDs
-    for (int e0 = 0; e0 < Sn; e0 += 256) {
-        const int e = e0 + (tid >> 6) + 4 * (tid & 63);
-        if (e >= Sn) continue;
-        const unsigned col = (unsigned)skey[e];
-        const float s = exact_row ? __uint_as_float((unsigned)(skey[e] >> 32)) : exact((int)col);
-        skey[e] = s == s ? ((unsigned long long)f2o(s) << 32) | (unsigned)~col : 0ull;   // NaN never survives
+    // candidate e goes to the quad e / 4 % 16 of wave e % 4: the chains spread over the four SIMDs, 64 candidates a round
+    if (exact_row) {   // (scores already exact)
+        for (int e0 = 0; e0 < Sn; e0 += 256) {
+            const int e = e0 + (tid >> 6) + 4 * (tid & 63);
+            if (e >= Sn) continue;
+            const unsigned col = (unsigned)skey[e];
+            const float s = exact_row ? __uint_as_float((unsigned)(skey[e] >> 32)) : exact((int)col);
+            skey[e] = s == s ? ((unsigned long long)f2o(s) << 32) | (unsigned)~col : 0ull;   // NaN never survives
+        }
+    } else {
+        for (int e0 = 0; e0 < Sn; e0 += 64) {
+            const int e = e0 + w + 4 * (lane >> 2);
+            if (e0 + w + 4 * (lane >> 2) >= Sn) continue;
+            const unsigned col = (unsigned)skey[e];
+            const float s = exact_quad((int)col);
+            if ((lane & 3) == 0) skey[e] = s == s ? ((unsigned long long)f2o(s) << 32) | (unsigned)~col : 0ull;
+        }
     }
+    stamp(4);
     int P = 64;
     while (P < Sn) P <<= 1;
     for (int e = Sn + tid; e < P; e += 256) skey[e] = 0ull;
@@ -1842,6 +1933,7 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
             }
             __syncthreads();
         }
+    stamp(5);
     constexpr int RPT = SELB_CAP / 256;
     unsigned long long res[RPT];
 #pragma unroll
@@ -1864,7 +1956,9 @@ __global__ void __launch_bounds__(256) select_refine_kernel(RefineArgs a) {
         }
     }
     __syncthreads();
+    stamp(6);
     if (a.pt.list_goff) emit_probe_tables(a.pt, row, K, sel, wtot);
+    stamp(7);
 }
 
 template <int DSUB>

@@ -372,6 +372,26 @@ def test_two_stage_coarse_is_bit_identical(faiss, oracle, monkeypatch):
             assert np.array_equal(cI0, cI1) and np.array_equal(bits(cD0), bits(cD1)), (gm, nprobe)
             assert (cI1[9] == -1).all()
     monkeypatch.delenv("MI_REFINE_GMAX")
+    # the adversarial norms again at the size where the group maxima steer the second stage (batched 16-byte reads of the
+    # surviving groups, quad-loaded exact chains): large and tiny norms mixed in one batch, far below f16's range,
+    # components that span 12 orders of magnitude, near-ties around the cut (clustered centroids: hundreds of
+    # candidates within the margin -- several rounds of chains)
+    scale = np.where(np.arange(1024) % 3 == 0, 100.0, np.where(np.arange(1024) % 3 == 1, 1e-3, 1.0)).astype(np.float32)
+    wide = np.exp(rng.uniform(-14, 14, (1, d))).astype(np.float32)
+    base32 = rng.standard_normal((512, d)).astype(np.float32)
+    clustered = (base32[rng.integers(0, 512, 32768)] + 0.02 * rng.standard_normal((32768, d))).astype(np.float32)
+    qcl = (clustered[rng.integers(0, 32768, 1024)] + 0.1 * rng.standard_normal((1024, d))).astype(np.float32)
+    for cc, qq in (((cent32 * 30).astype(np.float32), (q32 * scale[:, None]).astype(np.float32)),
+                   ((cent32 * 1e-9).astype(np.float32), (q32 * 1e-12).astype(np.float32)),
+                   ((cent32 * wide).astype(np.float32), (q32 / wide).astype(np.float32)),
+                   (clustered, qcl)):
+        idx = make_index(faiss, cc, cb)
+        for nprobe in (5, 64):
+            monkeypatch.setenv("MI_TWO_STAGE", "1")
+            cI1, cD1, _ = idx.coarse_and_lut(qq, nprobe, want_lut=False)
+            monkeypatch.setenv("MI_TWO_STAGE", "0")
+            cI0, cD0, _ = idx.coarse_and_lut(qq, nprobe, want_lut=False)
+            assert np.array_equal(cI0, cI1) and np.array_equal(bits(cD0), bits(cD1)), nprobe
 
 
 def test_lut_matches_oracle(faiss, oracle):
