@@ -222,6 +222,13 @@ void launch_ring_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int
 void launch_slab_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int K, float *S, int64_t ldS, hipStream_t st,
                      float *gmax = nullptr, int ld_gmax = 0) {
     mienc::GemmArgs g{};
+    // MI_REFINE_TS=1 (tools/micro/coarse_stage.py): the tiles' in-kernel phase stamps, mean over the workgroups
+    DevBuf tsb;
+    const unsigned nwg = 8u * (unsigned)((((na + 255) / 256) * ((nb + 255) / 256) + 7) / 8);
+    if (knobs().refine_ts) {
+        g.ts = tsb.as<unsigned long long>((size_t)nwg * 8);
+        MI_HIP(hipMemsetAsync(g.ts, 0, (size_t)nwg * 64, st));
+    }
     g.A = reinterpret_cast<const mienc::bf16_t *>(A);
     g.W = reinterpret_cast<const mienc::bf16_t *>(B);
     g.lda = K; g.ldw = K; g.M = (int)na; g.N = (int)nb; g.K = K;
@@ -233,6 +240,17 @@ void launch_slab_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int
     const int per = (g.tiles_m * g.tiles_n + 7) / 8;
     hipLaunchKernelGGL((mienc::gemm_bf16_slab_kernel<mienc::EPI_F32H, 4>), dim3(8u * per), dim3(512), 0, st, g);
     MI_HIP(hipGetLastError());
+    if (g.ts) {
+        std::vector<unsigned long long> h((size_t)nwg * 8);
+        MI_HIP(hipStreamSynchronize(st));
+        MI_HIP(hipMemcpy(h.data(), g.ts, h.size() * 8, hipMemcpyDeviceToHost));
+        double sum[5] = {0}; size_t cnt = 0;
+        for (unsigned b = 0; b < nwg; ++b)
+            if (h[(size_t)b * 8 + 4]) { for (int i = 1; i <= 4; ++i) sum[i] += (double)h[(size_t)b * 8 + i] - 1; ++cnt; }
+        if (cnt) std::fprintf(stderr, "f16 slab GEMM stamps (s_memtime ticks since the workgroup's start, mean of %zu tiles; %lld x %lld x %d): first slabs landed %.0f | "
+                              "K loop done %.0f | epilogue issued %.0f | stores acknowledged %.0f\n", cnt, (long long)na, (long long)nb, K,
+                              sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt);
+    }
 }
 
 // gmax (optional, [na][nb / 64]): filled with the 64-column group maxima when the slab kernel runs; returns whether it was
@@ -320,15 +338,12 @@ void launch_two_stage(const float *q, int64_t nq, const float *c32, const f16_t 
         std::vector<unsigned long long> ts((size_t)nq * 8);
         MI_HIP(hipMemcpyAsync(ts.data(), ra.ts, ts.size() * 8, hipMemcpyDeviceToHost, st));
         MI_HIP(hipStreamSynchronize(st));
-        double sum[8] = {0}, first = 1e300, last = 0;
-        for (int64_t r = 0; r < nq; ++r) {
+        double sum[8] = {0};
+        for (int64_t r = 0; r < nq; ++r)
             for (int i = 1; i < 8; ++i) sum[i] += (double)(ts[r * 8 + i] - ts[r * 8 + i - 1]);
-            first = std::min(first, (double)ts[r * 8]);
-            last = std::max(last, (double)ts[r * 8 + 7]);
-        }
         std::fprintf(stderr, "select_refine stamps (s_memtime ticks, mean of %lld workgroups; K %d): load+norm+maxima %.0f | descent %.0f | "
-                     "groups+candidates %.0f | chains %.0f | sort %.0f | output %.0f | tables %.0f | kernel span %.0f\n",
-                     (long long)nq, K, sum[1] / nq, sum[2] / nq, sum[3] / nq, sum[4] / nq, sum[5] / nq, sum[6] / nq, sum[7] / nq, last - first);
+                     "group list %.0f | candidates %.0f | chains %.0f | sort %.0f | output+tables %.0f\n",
+                     (long long)nq, K, sum[1] / nq, sum[2] / nq, sum[3] / nq, sum[4] / nq, sum[5] / nq, sum[6] / nq, sum[7] / nq);
     }
     if (want_stats) {
         unsigned hs[2] = {0, 0};

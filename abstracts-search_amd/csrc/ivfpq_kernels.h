@@ -1579,6 +1579,7 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
     __shared__ int wtot[4];
     __shared__ int c_cnt;
     __shared__ int g_cnt;
+    __shared__ unsigned t0_sh;
     __shared__ unsigned short glist[1024];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = uniform_i(tid >> 6);
@@ -1590,6 +1591,13 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
         if (a.ts && tid == 0) a.ts[(size_t)row * 8 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
+    // the row's group maxima (first attempt of the loop below) requested in front of the query row: one round trip, not two
+    const bool ext0 = a.gmax != nullptr && K <= 256 && a.ngroups <= 1024 && a.ngroups >= 4 * K && n == a.ngroups * 64;
+    float graw[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ext0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) graw[g] = a.gmax[row * a.ngroups + min(g * 256 + tid, a.ngroups - 1)];
+    }
     // query row -> LDS, its norm
     float nrm = 0.f;
     for (int k = tid; k < d; k += 256) {
@@ -1702,13 +1710,13 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
         unsigned gm[VPT];
         int nonfinite = 0;
         // group maxima from the GEMM epilogue: enough groups that the K-th largest of them is a useful cut
-        const bool ext = a.gmax != nullptr && !exact_row && K <= 256 && a.ngroups <= 1024 && a.ngroups >= 4 * K && n == a.ngroups * 64;
+        const bool ext = ext0 && !exact_row;
         unsigned gq[4] = {0u, 0u, 0u, 0u};
         if (ext) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int gi = g * 256 + tid;
-                const float v = a.gmax[row * a.ngroups + min(gi, a.ngroups - 1)] * inv;
+                const float v = graw[g] * inv;
                 const bool fin = fabsf(v) <= 3.0e38f;
                 nonfinite |= (gi < a.ngroups && !fin);
                 gq[g] = (gi < a.ngroups && fin) ? f2o(v) : 0u;
@@ -1755,17 +1763,42 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
                     if (c >= K) T0 = t;
                     if (c == K) break;
                 }
-            } else {
-                for (int bit = 31; bit >= 0; --bit) {
-                    const unsigned t = T0 | (1u << bit);
-                    int c = 0;
+            } else if (w == 0) {
+                // ONE wave descends (16 ballots a step: with every wave of the CU's four workgroups at it the steps queued at
+                // the CU's scalar unit -- 28-38 k cycles of the workgroup), from below the common prefix of the largest and the
+                // smallest maximum (a query's scores share sign, exponent and a few mantissa bits: a third of the steps;
+                // with at least K maxima set, every one bit of the prefix is decided, a zero bit of it can never be set)
+                unsigned mx = 0u, mn = ~0u;
+                int cn = 0;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) c += __popcll(__ballot(kk[i] >= t));
-                    if (c >= K) T0 = t;
-                    if (c == K) break;
+                for (int i = 0; i < 16; ++i) {
+                    mx = max(mx, kk[i]);
+                    mn = min(mn, kk[i] != 0u ? kk[i] : ~0u);
+                    cn += __popcll(__ballot(kk[i] != 0u));
                 }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+                    mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+                }
+                if (cn >= K) {
+                    const unsigned diff = mx ^ mn;
+                    int bit = diff ? 31 - __clz((int)diff) : -1;
+                    T0 = diff ? (mx & ~((2u << bit) - 1u)) : mx;
+                    if (cn > K)
+                        for (; bit >= 0; --bit) {
+                            const unsigned t = T0 | (1u << bit);
+                            int c = 0;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) c += __popcll(__ballot(kk[i] >= t));
+                            if (c >= K) T0 = t;
+                            if (c == K) break;
+                        }
+                }
+                if (lane == 0) t0_sh = T0;
             }
             __syncthreads();   // skey is reused for the candidates
+            if (K > 16) T0 = t0_sh;
         } else {
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned t = T0 | (1u << bit);
@@ -1787,6 +1820,7 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
                 for (int g = 0; g < 4; ++g)
                     if (gq[g] != 0u && o2f(gq[g]) >= cut) glist[atomicAdd(&g_cnt, 1)] = (unsigned short)(g * 256 + tid);
                 __syncthreads();
+                stamp(3);
                 // 16 bytes of a group per lane (4 scores; 16 groups a pass), four passes' loads issued together: a wave per group
                 // and pass was a dependent round trip per ~100 surviving groups / 4 waves
                 const int ng = g_cnt;
@@ -1870,7 +1904,7 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
             }
         }
         __syncthreads();
-        stamp(3);
+        stamp(4);
         Sn = c_cnt;
         if ((bad && !exact_row) || Sn > SELB_CAP) {
             if (exact_row) break;   // still too many after the exact pass: masses of exact ties
@@ -1914,7 +1948,7 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
             if ((lane & 3) == 0) skey[e] = s == s ? ((unsigned long long)f2o(s) << 32) | (unsigned)~col : 0ull;
         }
     }
-    stamp(4);
+    stamp(5);
     int P = 64;
     while (P < Sn) P <<= 1;
     for (int e = Sn + tid; e < P; e += 256) skey[e] = 0ull;
@@ -1933,7 +1967,7 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
             }
             __syncthreads();
         }
-    stamp(5);
+    stamp(6);
     constexpr int RPT = SELB_CAP / 256;
     unsigned long long res[RPT];
 #pragma unroll
@@ -1956,7 +1990,6 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
         }
     }
     __syncthreads();
-    stamp(6);
     if (a.pt.list_goff) emit_probe_tables(a.pt, row, K, sel, wtot);
     stamp(7);
 }
