@@ -394,6 +394,33 @@ def test_two_stage_coarse_is_bit_identical(faiss, oracle, monkeypatch):
             assert np.array_equal(cI0, cI1) and np.array_equal(bits(cD0), bits(cD1)), nprobe
 
 
+def test_two_stage_coarse_long_rows(faiss, oracle, monkeypatch):
+    """Rows longer than 1024 floats take the second stage's `<4096>` instantiation (three workgroups per CU); three, twelve and
+    sixteen 128-float sets in the quad-loaded exact chains (an odd count ends on a half round); with and without the group maxima (32 768 centroids x 1024
+    queries is the slab GEMM, 8192 x 512 the ring GEMM).  Same lists and score bits as the one-stage quantiser and as the oracle's flat search."""
+    rng = np.random.default_rng(2718)
+    for d, M, nlist, nq in ((384, 48, 8192, 512), (1536, 96, 8192, 512), (2048, 64, 32768, 1024)):   # (the last: 512 slab tiles, group maxima)
+        cb = (0.3 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+        base = rng.standard_normal((256, d)).astype(np.float32)
+        cent = (base[rng.integers(0, 256, nlist)] + 0.05 * rng.standard_normal((nlist, d))).astype(np.float32)
+        q = (cent[rng.integers(0, nlist, nq)] + 0.2 * rng.standard_normal((nq, d))).astype(np.float32)
+        idx = make_index(faiss, cent, cb)
+        for gm in ("1", "0"):
+            monkeypatch.setenv("MI_REFINE_GMAX", gm)
+            for nprobe in (1, 24, 100):
+                monkeypatch.setenv("MI_TWO_STAGE", "1")
+                cI1, cD1, _ = idx.coarse_and_lut(q, nprobe, want_lut=False)
+                monkeypatch.setenv("MI_TWO_STAGE", "0")
+                cI0, cD0, _ = idx.coarse_and_lut(q, nprobe, want_lut=False)
+                assert np.array_equal(cI0, cI1) and np.array_equal(bits(cD0), bits(cD1)), (d, gm, nprobe)
+        monkeypatch.delenv("MI_REFINE_GMAX")
+        De, Ie = oracle.flat_ip(q[:32], cent, 24)
+        monkeypatch.setenv("MI_TWO_STAGE", "1")
+        cI1, cD1, _ = idx.coarse_and_lut(q[:32].repeat(16, axis=0), 24, want_lut=False)
+        assert np.array_equal(cI1[::16], Ie) and np.array_equal(bits(cD1[::16]), bits(De)), d
+    monkeypatch.delenv("MI_TWO_STAGE")
+
+
 def test_lut_matches_oracle(faiss, oracle):
     cent, cb, x, q = random_problem(3, 1024, 64, 8, 64, 9)
     idx = make_index(faiss, cent, cb)
