@@ -1663,24 +1663,39 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
 #pragma unroll
         for (int i = 0; i < 8; ++i) A[i] = cp[4 * i];
         float acc = 0.f;
+        // the query's values for two pieces (8 x 16 B) are read from LDS together, ahead of the 32 fmacs that use them: read where
+        // they are used, every ds_read_b128 was followed by s_waitcnt lgkmcnt(0) -- an LDS latency per four fmacs, ~40 k cycles a chain
+#define MI_FMAC4_QUAD(QP, CX, CY, CZ, CW, QV)                                                                                      \
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %5 quad_perm:" QP " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                       \
+        "v_fmac_f32_dpp %0, %2, %6 quad_perm:" QP " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                   \
+        "v_fmac_f32_dpp %0, %3, %7 quad_perm:" QP " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                   \
+        "v_fmac_f32_dpp %0, %4, %8 quad_perm:" QP " row_mask:0xf bank_mask:0xf bound_ctrl:1"                                        \
+        : "+v"(acc) : "v"(CX), "v"(CY), "v"(CZ), "v"(CW), "v"(QV.x), "v"(QV.y), "v"(QV.z), "v"(QV.w))
+        // acc = fma(c of quad lane jj, q, acc), four times a statement: v_fmac_f32 with a DPP source (hipcc keeps a v_mov_b32_dpp
+        // in front of every v_fma_f32: twice the VALU time of the chain).  The compiler does not see a DPP read in the asm:
+        // s_nop 1 covers a VALU write of the first piece right in front (2 wait states).
+        const float4 *q4 = reinterpret_cast<const float4 *>(qs);
         auto run = [&](const float4 (&S)[8], int set) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int h = 0; h < 4; ++h) {
+                float4 qv[8];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const float4 qv = *reinterpret_cast<const float4 *>(qs + 128 * set + 16 * i + 4 * jj);
-                    // acc = fma(c of quad lane jj, q, acc), four times: v_fmac_f32 with a DPP source (hipcc keeps a
-                    // v_mov_b32_dpp in front of every v_fma_f32: twice the VALU time of the chain).  The compiler does not see
-                    // a DPP read in the asm: s_nop 1 covers a VALU write of the first piece right in front (2 wait states).
-                    switch (jj) {
-                    case 0: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %5 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %2, %6 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %3, %7 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %4, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(S[i].x), "v"(S[i].y), "v"(S[i].z), "v"(S[i].w), "v"(qv.x), "v"(qv.y), "v"(qv.z), "v"(qv.w)); break;
-                    case 1: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %5 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %2, %6 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %3, %7 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %4, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(S[i].x), "v"(S[i].y), "v"(S[i].z), "v"(S[i].w), "v"(qv.x), "v"(qv.y), "v"(qv.z), "v"(qv.w)); break;
-                    case 2: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %5 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %2, %6 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %3, %7 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %4, %8 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(S[i].x), "v"(S[i].y), "v"(S[i].z), "v"(S[i].w), "v"(qv.x), "v"(qv.y), "v"(qv.z), "v"(qv.w)); break;
-                    default: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %2, %6 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %3, %7 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fmac_f32_dpp %0, %4, %8 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(S[i].x), "v"(S[i].y), "v"(S[i].z), "v"(S[i].w), "v"(qv.x), "v"(qv.y), "v"(qv.z), "v"(qv.w)); break;
+                for (int u = 0; u < 8; ++u) qv[u] = q4[32 * set + 8 * h + u];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = 2 * h + (u >> 2);
+                    switch (u & 3) {
+                    case 0: MI_FMAC4_QUAD("[0,0,0,0]", S[i].x, S[i].y, S[i].z, S[i].w, qv[u]); break;
+                    case 1: MI_FMAC4_QUAD("[1,1,1,1]", S[i].x, S[i].y, S[i].z, S[i].w, qv[u]); break;
+                    case 2: MI_FMAC4_QUAD("[2,2,2,2]", S[i].x, S[i].y, S[i].z, S[i].w, qv[u]); break;
+                    default: MI_FMAC4_QUAD("[3,3,3,3]", S[i].x, S[i].y, S[i].z, S[i].w, qv[u]); break;
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
+#undef MI_FMAC4_QUAD
         for (int set = 0; set < nset; set += 2) {
             const int nb = min(set + 1, nset - 1);   // (an odd number of sets: a harmless re-read, not used)
 #pragma unroll
@@ -1949,6 +1964,23 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
         }
     }
     stamp(5);
+    if (Sn <= 64) {
+        // a handful of candidates (the assignment step of add(): two or three; nprobe 8: a dozen): one wave ranks them -- every
+        // lane counts the keys above its own (broadcast reads; the keys carry their column: distinct but for NaN scores' zeros) -- where the
+        // bitonic network of 64 slots is 21 block-wide barriers (~9 k cycles of an 80 k-cycle workgroup)
+        __syncthreads();
+        if (w == 0) {
+            const unsigned long long mine = lane < Sn ? skey[lane] : 0ull;
+            int rk = 0;
+            for (int j = 0; j < Sn; ++j) {
+                const unsigned long long kj = skey[j];
+                rk += kj > mine || (kj == mine && j < lane);   // (equal keys: only the zeros of NaN scores -- slot order keeps the ranks distinct)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // every read of the wave in front of its writes
+            if (lane < Sn) skey[rk] = mine;
+        }
+        __syncthreads();
+    } else {
     int P = 64;
     while (P < Sn) P <<= 1;
     for (int e = Sn + tid; e < P; e += 256) skey[e] = 0ull;
@@ -1967,6 +1999,7 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
             }
             __syncthreads();
         }
+    }
     stamp(6);
     constexpr int RPT = SELB_CAP / 256;
     unsigned long long res[RPT];
