@@ -1836,22 +1836,22 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
                     if (gq[g] != 0u && o2f(gq[g]) >= cut) glist[atomicAdd(&g_cnt, 1)] = (unsigned short)(g * 256 + tid);
                 __syncthreads();
                 stamp(3);
-                // 16 bytes of a group per lane (4 scores; 16 groups a pass), four passes' loads issued together: a wave per group
+                // 16 bytes of a group per lane (4 scores; 16 groups a pass), eight passes' loads issued together: a wave per group
                 // and pass was a dependent round trip per ~100 surviving groups / 4 waves
                 const int ng = g_cnt;
-                constexpr int lpg = 16, epl = 4, gpp = 256 / lpg;
+                constexpr int lpg = 16, epl = 4, gpp = 256 / lpg, NPASS = 8;
                 const int gsl = tid / lpg, part = tid % lpg;
-                for (int i0 = 0; i0 < ng; i0 += 4 * gpp) {
-                    float4 raw[4];
-                    int c0[4];
+                for (int i0 = 0; i0 < ng; i0 += NPASS * gpp) {
+                    float4 raw[NPASS];
+                    int c0[NPASS];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < NPASS; ++u) {
                         const int gi = i0 + u * gpp + gsl;
                         c0[u] = gi < ng ? (int)glist[gi] * 64 + part * epl : -1;
                         if (gi < ng) raw[u] = *reinterpret_cast<const float4 *>(r + c0[u]);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < NPASS; ++u) {
                         if (c0[u] < 0) continue;
                         const float wd[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
 #pragma unroll
