@@ -1964,21 +1964,20 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
         }
     }
     stamp(5);
-    if (Sn <= 64) {
-        // a handful of candidates (the assignment step of add(): two or three; nprobe 8: a dozen): one wave ranks them -- every
-        // lane counts the keys above its own (broadcast reads; the keys carry their column: distinct but for NaN scores' zeros) -- where the
-        // bitonic network of 64 slots is 21 block-wide barriers (~9 k cycles of an 80 k-cycle workgroup)
+    if (Sn <= 256) {
+        // up to a key per thread (the assignment step of add(): two or three candidates; nprobe 8: a dozen; nprobe 64: ~95): every
+        // thread counts the keys above its own (broadcast reads; the keys carry their column: distinct but for NaN scores' zeros) and
+        // stores it at its rank -- where the bitonic network of 64 / 128 slots is 21 / 28 block-wide barriers (9-12 k cycles)
         __syncthreads();
-        if (w == 0) {
-            const unsigned long long mine = lane < Sn ? skey[lane] : 0ull;
-            int rk = 0;
+        const unsigned long long mine = tid < Sn ? skey[tid] : 0ull;
+        int rk = 0;
+        if (tid < Sn)
             for (int j = 0; j < Sn; ++j) {
                 const unsigned long long kj = skey[j];
-                rk += kj > mine || (kj == mine && j < lane);   // (equal keys: only the zeros of NaN scores -- slot order keeps the ranks distinct)
+                rk += kj > mine || (kj == mine && j < tid);   // (equal keys: only the zeros of NaN scores -- slot order keeps the ranks distinct)
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // every read of the wave in front of its writes
-            if (lane < Sn) skey[rk] = mine;
-        }
+        __syncthreads();   // every read in front of the writes
+        if (tid < Sn) skey[rk] = mine;
         __syncthreads();
     } else {
     int P = 64;
