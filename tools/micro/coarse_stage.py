@@ -43,7 +43,7 @@ def timeit(nprobe, n=200):
 
 for B, nprobe in SHAPES:
     qs = QALL[:8 * B].view(8, B, D)
-    env(MI_TWO_STAGE="0", MI_COARSE_HALF=None)
+    env(MI_TWO_STAGE="0")
     I0, D0 = idx.coarse_slice(qs[0], nprobe, 0, NLIST)
     env(MI_TWO_STAGE=None, MI_REFINE_STATS="1", MI_REFINE_TS="1")
     I1, D1 = idx.coarse_slice(qs[0], nprobe, 0, NLIST)

@@ -1,7 +1,7 @@
 """A / B of one MI_* knob of libmi_ivfpq.so on the search step, alternating in ONE process on one box (boxes of the pool differ by
 2-3 %: a change of a per cent only shows this way).  IVF65536,PQ64 over AB_N (default 40 M) synthetic vectors, batch 1024,
 nprobe AB_NPROBE (64), k 10; the results of both settings compared bit for bit first.
-    python tools/micro/knob_ab.py MI_NO_LUT_IN_REFINE"""
+    python tools/micro/knob_ab.py MI_NO_FUSED_MERGE"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
