@@ -1568,6 +1568,48 @@ struct RefineArgs {
     unsigned long long *ts;   // null, or [rows][8] s_memtime stamps of the workgroup's phases (MI_REFINE_TS=1, tools only)
 };
 
+// The exact fallback of select_refine_kernel (a row whose approximate scores are not finite, or with more candidates than slots:
+// degenerate data only): exact scores of the WHOLE row, one lane per column.  Not inlined -- inside the kernel its two register sets
+// of 8 x 16 B counted against the 128 VGPRs that four workgroups per CU allow, and the spills landed in the common path (eight
+// scratch reloads in the descent region).  qs: the query row (LDS, through a generic pointer: this path may be slow).
+__device__ __noinline__ void refine_exact_row(float *r, const float *cent, const float *qs, int n, int d) {
+    for (int col = (int)threadIdx.x; col < n; col += 256) {
+        // d % 128 == 0 (host).  The centroid row is streamed through two register sets of 8 x 16 B, named (not copied: a copy
+        // would make hipcc wait for the newest loads), so the loads of one set are in flight while the chain -- d dependent
+        // fmafs, k ascending -- runs on the other.
+            const float4 *cp = reinterpret_cast<const float4 *>(cent + (size_t)col * d);
+            const int n4 = d >> 2;
+            float4 A[8], B[8];
+    #pragma unroll
+            for (int i = 0; i < 8; ++i) A[i] = cp[i];
+            float acc = 0.f;
+            for (int k4 = 0; k4 < n4; k4 += 16) {
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) B[i] = cp[k4 + 8 + i];
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 qv = *reinterpret_cast<const float4 *>(qs + 4 * (k4 + i));
+                    acc = __builtin_fmaf(qv.x, A[i].x, acc);
+                    acc = __builtin_fmaf(qv.y, A[i].y, acc);
+                    acc = __builtin_fmaf(qv.z, A[i].z, acc);
+                    acc = __builtin_fmaf(qv.w, A[i].w, acc);
+                }
+                const int nx = min(k4 + 16, n4 - 8);   // last round: a harmless re-read
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) A[i] = cp[nx + i];
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 qv = *reinterpret_cast<const float4 *>(qs + 4 * (k4 + 8 + i));
+                    acc = __builtin_fmaf(qv.x, B[i].x, acc);
+                    acc = __builtin_fmaf(qv.y, B[i].y, acc);
+                    acc = __builtin_fmaf(qv.z, B[i].z, acc);
+                    acc = __builtin_fmaf(qv.w, B[i].w, acc);
+                }
+            }
+            r[col] = acc;
+    }
+}
+
 // DCAP: the longest query row the instantiation holds in LDS (d <= DCAP).  <1024>: 39 KiB of LDS, FOUR workgroups per CU --
 // 1024 rows are one round of workgroups on 256 CUs where the 51 KiB of <4096> made them a round of 768 and one of 256.
 template <int DCAP>
@@ -1614,42 +1656,6 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
     float margin = 2.f * a.eps_rel * qn * a.cmax;
     const float inv = 1.f / (a.qscale[row] * a.cscale);   // exact: powers of two
     bool bad = !(margin < 3.0e38f);   // NaN / inf query
-    auto exact = [&](int col) -> float {
-        // d % 128 == 0 (host).  The centroid row is streamed through two register sets of
-        // 8 x 16 B, named (not copied: a copy would make hipcc wait for the newest loads), so
-        // the loads of one set are in flight while the chain -- d dependent fmafs -- runs on
-        // the other.
-        const float4 *cp = reinterpret_cast<const float4 *>(a.cent + (size_t)col * d);
-        const int n4 = d >> 2;
-        float4 A[8], B[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) A[i] = cp[i];
-        float acc = 0.f;
-        for (int k4 = 0; k4 < n4; k4 += 16) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) B[i] = cp[k4 + 8 + i];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 qv = *reinterpret_cast<const float4 *>(qs + 4 * (k4 + i));
-                acc = __builtin_fmaf(qv.x, A[i].x, acc);
-                acc = __builtin_fmaf(qv.y, A[i].y, acc);
-                acc = __builtin_fmaf(qv.z, A[i].z, acc);
-                acc = __builtin_fmaf(qv.w, A[i].w, acc);
-            }
-            const int nx = min(k4 + 16, n4 - 8);   // last round: a harmless re-read
-#pragma unroll
-            for (int i = 0; i < 8; ++i) A[i] = cp[nx + i];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 qv = *reinterpret_cast<const float4 *>(qs + 4 * (k4 + 8 + i));
-                acc = __builtin_fmaf(qv.x, B[i].x, acc);
-                acc = __builtin_fmaf(qv.y, B[i].y, acc);
-                acc = __builtin_fmaf(qv.z, B[i].z, acc);
-                acc = __builtin_fmaf(qv.w, B[i].w, acc);
-            }
-        }
-        return acc;
-    };
     // The same chain with the row LOADED by the four lanes of a quad: lane j of the quad requests the 16-byte pieces
     // 4 i + j of the row, so a quad reads 64 contiguous bytes per instruction (a lane on its own row: 16 B of a line per
     // instruction, eight instructions per line -- the one-lane chain was bound by its ~0.5 us load round trips, 128 B
@@ -1924,7 +1930,7 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
         if ((bad && !exact_row) || Sn > SELB_CAP) {
             if (exact_row) break;   // still too many after the exact pass: masses of exact ties
             // exact scores for the whole row, in place
-            for (int c = tid; c < n; c += 256) r[c] = exact(c);
+            refine_exact_row(r, a.cent, qs, n, d);
             __threadfence_block();
             if (tid == 0) c_cnt = 0;
             if (a.stats && tid == 0) atomicAdd(a.stats + 1, 1u);
@@ -1951,7 +1957,7 @@ __global__ void __launch_bounds__(256, DCAP <= 1024 ? 4 : 3) select_refine_kerne
             const int e = e0 + (tid >> 6) + 4 * (tid & 63);
             if (e >= Sn) continue;
             const unsigned col = (unsigned)skey[e];
-            const float s = exact_row ? __uint_as_float((unsigned)(skey[e] >> 32)) : exact((int)col);
+            const float s = __uint_as_float((unsigned)(skey[e] >> 32));
             skey[e] = s == s ? ((unsigned long long)f2o(s) << 32) | (unsigned)~col : 0ull;   // NaN never survives
         }
     } else {
