@@ -76,6 +76,9 @@ Knobs &knobs_mut() {
     static Knobs k = [] { Knobs x{}; x.load(); return x; }();
     return k;
 }
+// bumped by mi_encoder_reload_env(): state a handle derived from the knobs (the query-time path's weight pieces: which
+// gate/up unit size they are laid out for) is rebuilt when the handle's generation is behind
+std::atomic<int> g_knob_gen{0};
 inline const Knobs &knobs() { return knobs_mut(); }
 
 // launches that took the K-split tail (f32 atomics into the residual stream): tests assert the path ran
@@ -669,6 +672,7 @@ struct mi_encoder {
     DevBuf ws_stage;         // load_tensor staging (exclusive calls)
     bool tiled_ok = false;   // fragment-major weight copies are current
     bool few_ok = false;     // the query-time path's weight pieces are current
+    int few_gen = -1;        // ... for this generation of the knobs (g_knob_gen)
     bool few_gu8 = false;    // ... and the gate/up pieces are few_gu8_kernel's (8 gate + 8 up rows per piece)
     bool roped_ok = false;   // the rotary-pair-interleaved QKV copies are current
     // profiling: the GEMM launches of the most recent encode (arguments as launched), replayed back to back between two
@@ -978,6 +982,7 @@ void few_build_weights(mi_encoder *h, hipStream_t st) {
     few_set_attributes<3>();
     MI_HIP(hipStreamSynchronize(st));
     h->few_ok = true;
+    h->few_gen = g_knob_gen.load();
 }
 
 // leaves the residual stream (before the final norm) in x
@@ -1196,7 +1201,7 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
     if (few_eligible(h, b)) {
         {
             std::lock_guard<std::mutex> hl(h->mu);         // the pieces are built once; other streams wait for them
-            if (!h->few_ok) few_build_weights(h, st);
+            if (!h->few_ok || h->few_gen != g_knob_gen.load()) few_build_weights(h, st);
         }
         Range stack_range("mi_encoder:stack(few)");
         g_few_passes.fetch_add(1);
@@ -1696,7 +1701,7 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
 }
 
 int mi_encoder_reload_env(void) {
-    return guard([&] { knobs_mut().load(); });
+    return guard([&] { knobs_mut().load(); ++g_knob_gen; });
 }
 
 int mi_enc_gemm_bf16(int device, int M, int N, int K, const void *A, const void *W, void *C, void *stream) {

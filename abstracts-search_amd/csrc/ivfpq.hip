@@ -2597,12 +2597,13 @@ int mi_flat_search(mi_flat *h, int64_t nq, const float *q, int k, float *D, int6
 
 // ---- building blocks for train() --------------------------------------
 
-// out[n][nc] = x . c^T (+ bias[nc]): the exact f32 GEMM of the coarse quantiser (ascending-k fmaf chain per element) as a
-// plain operator -- the VectorTransform in front of an IndexPreTransform (OPQ / random rotation: x -> A x + b)
+// re-read the MI_* knobs (tests and tools; not beside a running search)
 int mi_ivfpq_reload_env(void) {
     return guard([&] { knobs_mut().load(); });
 }
 
+// out[n][nc] = x . c^T (+ bias[nc]): the exact f32 GEMM of the coarse quantiser (ascending-k fmaf chain per element) as a
+// plain operator -- the VectorTransform in front of an IndexPreTransform (OPQ / random rotation: x -> A x + b)
 int mi_ip_gemm(int device, int64_t n, const float *x, int64_t nc, const float *c, int d, const float *bias, float *out,
                void *stream) {
     return guard([&] {

@@ -1035,7 +1035,7 @@ class IndexPreTransform:
         if self._dev is None:
             self._dev = [(torch.from_numpy(A).to(dev).contiguous(), None if b is None else torch.from_numpy(b).to(dev).contiguous())
                          for A, b in self.chain]
-        stream = _current_stream()
+        stream = c_void_p(torch.cuda.current_stream(dev).cuda_stream)   # the stream of index.device, not of torch's current device
         for A, b in self._dev:
             if t.shape[0] == 0:
                 t = torch.empty((0, A.shape[0]), dtype=torch.float32, device=dev)
@@ -1079,16 +1079,24 @@ def write_index(index, fname: str, ondisk_data: str | None = None) -> None:
     if isinstance(index, IndexPreTransform):
         if str(fname).endswith(".npz"):
             raise NotImplementedError("write_index: IndexPreTransform goes to faiss's binary format only (IxPT)")
+        # every transform goes out as `LTra` (a plain LinearTransform: what faiss applies for OPQ / a random rotation at
+        # search time -- the OPQm / rrot TYPE of a transform read from a file is not kept)
         tmp = str(fname) + ".sub.tmp"
-        write_index(index.index, tmp, ondisk_data)
         try:
+            write_index(index.index, tmp, ondisk_data)
             faiss_io.dump_pretransform(fname, index.chain, index.d, index.ntotal, index.is_trained, index.metric_type, tmp)
         finally:
-            os.remove(tmp)
+            if os.path.exists(tmp):
+                os.remove(tmp)
         return
     if isinstance(index, IndexRefine):
         raise NotImplementedError("write_index: IndexRefine / IndexRefineFlat (faiss's IxRF) is not serialised -- write "
                                   "index.base_index; the refine stage re-reads the raw vectors at load time")
+    if getattr(index, "hnsw_quantizer", False):
+        import warnings
+        warnings.warn("write_index: this index was read from a file with an IndexHNSWFlat (IHNf) coarse quantiser; it is "
+                      "written with a plain IndexFlat quantiser over the same centroids (the HNSW graph is not kept: "
+                      "faiss will search the coarse level exactly, as this package does)", stacklevel=2)
     if not str(fname).endswith(".npz"):
         # the C ABI streams the lists from HBM to the file slab by slab (mi_index_save)
         _check(_Lib.get().mi_index_set_nprobe(index._h, max(1, int(index.nprobe))))
@@ -1121,6 +1129,9 @@ def read_index(fname: str, device: int = 0):
                 raise RuntimeError("mi_ivfpq: " + msg)
             raise faiss_io.FaissFormatError(msg)
         index = IndexIVFPQ._from_handle(h, device)
+        # an IndexHNSWFlat quantiser was read as its flat storage (exact coarse search: a superset of the graph's probes);
+        # the index remembers it, and write_index says that what it writes is the IVF-Flat-quantiser form
+        index.hnsw_quantizer = not faiss_io.parse_is_flat(fname, int(offset))
         return index if chain is None else IndexPreTransform(chain, index)
     z = np.load(fname, allow_pickle=False)
     if str(z["magic"]) != _MAGIC:

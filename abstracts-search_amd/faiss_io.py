@@ -232,9 +232,22 @@ def parse(fname: str) -> dict:
                 codebook=cb.reshape(M, ksub, dsub) if cb.size else cb, sizes=sizes, codes=codes, ids=ids)
 
 
-def parse_is_flat(fname: str) -> bool:
+def quantizer_fourcc(fname: str, offset: int = 0) -> str:
+    """fourcc of the coarse quantiser of the IwPQ index that starts at byte `offset` of the file -- the headers only
+    (nothing proportional to the index is read)."""
+    with open(fname, "rb") as fh:
+        fh.seek(offset)
+        r = _Reader(fh, fname)
+        if r.fourcc() != "IwPQ":
+            raise FaissFormatError(f"{fname}: not an IndexIVFPQ (IwPQ) at byte {offset}")
+        _read_header(r)
+        r.one("Q"), r.one("Q")
+        return r.fourcc()
+
+
+def parse_is_flat(fname: str, offset: int = 0) -> bool:
     """whether the file's coarse quantiser is a plain IndexFlat (False: an IndexHNSWFlat read as its flat storage)"""
-    return not parse(fname)["hnsw_quantizer"]
+    return quantizer_fourcc(fname, offset) != "IHNf"
 
 
 def _read_invlists(r: _Reader, fname: str, nlist: int, code_size: int):

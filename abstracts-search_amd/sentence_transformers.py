@@ -88,30 +88,53 @@ STELLA_EN_1_5B_V5 = dict(vocab_size=151646, hidden=1536, n_layers=28, n_heads=12
                          dense_bias=True, max_seq_len=512)
 
 
-def _causal_from_hf(hf: dict, is_embedding_model: bool = False, override=None) -> bool:
-    """Which attention mask a checkpoint's config.json asks for -- never guessed.
+_ENV_TRUE = ("1", "true", "yes", "on")
+_ENV_FALSE = ("0", "false", "no", "off")
 
-    * an explicit `causal=` (constructor) or MI_ENCODER_CAUSAL=0|1 (for pipelines that cannot pass keywords:
-      `sidecar-search build`, reference Makefile:65) wins;
-    * `is_causal` in config.json (the key of the gte-Qwen2 / stella remote code) is taken as written;
+
+def _causal_from_hf(hf: dict, is_embedding_model: bool = False, override=None) -> bool:
+    """Which attention mask a checkpoint's config.json asks for -- never guessed silently.
+
+    * an explicit `causal=` (constructor) or MI_ENCODER_CAUSAL=0|1 (also true/false, yes/no, on/off; anything else
+      raises) -- for pipelines that cannot pass keywords: `sidecar-search build`, reference Makefile:65 -- wins;
+    * `is_causal` in config.json (the key of the gte-Qwen2 remote code) is taken as written;
     * no key and no remote code (`auto_map` absent): a plain Qwen2 checkpoint, which transformers runs causally --
       also under sentence-transformers (modules.json), whose Transformer module calls the same Qwen2Model;
-    * no key but `auto_map` names remote modelling code: the mask is decided inside a modeling_*.py this package
-      does not execute.  Running such a model with the wrong mask gives plausible, wrong embeddings and no error,
-      so this raises and asks."""
+    * no key, `auto_map` names `modeling_qwen.Qwen2Model` AND the directory is a sentence-transformers embedding
+      model (modules.json): the published signature of NovaSearch/stella_en_1.5B_v5 and the gte-Qwen2 family it
+      derives from, whose remote code runs bidirectional attention [PRIOR: SURVEY App. B.1; the file could not be
+      fetched here].  Taken as bidirectional WITH a warning, so that the reference's own command lines
+      (README.md:28, README.md:60) load without an extra knob;
+    * any other remote modelling code without the key: the mask is decided inside a modeling_*.py this package does
+      not execute.  Running such a model with the wrong mask gives plausible, wrong embeddings and no error, so this
+      raises and asks."""
     if override is None:
-        env = os.environ.get("MI_ENCODER_CAUSAL", "").strip()
+        env = os.environ.get("MI_ENCODER_CAUSAL", "").strip().lower()
         if env != "":
-            override = env not in ("0", "false", "False")
+            if env in _ENV_TRUE:
+                override = True
+            elif env in _ENV_FALSE:
+                override = False
+            else:
+                raise ValueError(f"MI_ENCODER_CAUSAL={env!r}: expected one of {_ENV_FALSE + _ENV_TRUE}")
     if override is not None:
         return bool(override)
     if "is_causal" in hf:
         return bool(hf["is_causal"])
     auto_map = hf.get("auto_map") or {}
     if auto_map:
+        targets = sorted(set(str(v) for v in auto_map.values()))
+        if is_embedding_model and str(auto_map.get("AutoModel", "")).split("--")[-1] == "modeling_qwen.Qwen2Model":
+            import warnings
+            warnings.warn(
+                "config.json has no `is_causal` key; its auto_map (modeling_qwen.Qwen2Model) and modules.json match the "
+                "stella_en_1.5B_v5 / gte-Qwen2 embedding models, whose remote code attends bidirectionally: running "
+                "BIDIRECTIONAL attention.  Pass causal=True/False or set MI_ENCODER_CAUSAL=1/0 to decide explicitly.",
+                stacklevel=3)
+            return False
         raise ValueError(
             "config.json has no `is_causal` key and its `auto_map` points at remote modelling code "
-            f"({sorted(set(str(v).split('.')[0] for v in auto_map.values()))}): whether attention is causal or "
+            f"({targets}): whether attention is causal or "
             "bidirectional is decided inside that code, which is not executed here.  Pass "
             "SentenceTransformer(..., causal=False) for a bidirectional encoder (stella / gte-Qwen2 style) or "
             "causal=True, or set MI_ENCODER_CAUSAL=0|1" +

@@ -837,6 +837,12 @@ def test_read_index_with_an_hnsw_coarse_quantiser(faiss, tmp_path):
     assert np.array_equal(back.get_centroids(), cent)
     D2, I2 = back.search(q, 10)
     assert np.array_equal(I, I2) and np.array_equal(bits(D), bits(D2))
+    # the loaded index remembers the graph it dropped; writing it back says that the file changes type (IHNf -> IxFI)
+    assert back.hnsw_quantizer is True and not getattr(faiss.read_index(flat), "hnsw_quantizer", True)
+    with pytest.warns(UserWarning, match="IndexHNSWFlat"):
+        faiss.write_index(back, str(tmp_path / "rewritten.faiss"))
+    again = faiss.read_index(str(tmp_path / "rewritten.faiss"))
+    assert again.hnsw_quantizer is False and np.array_equal(again.search(q, 10)[1], I)
     with open(f, "wb") as fh:                                    # HNSW over compressed storage: no exact centroid table
         fh.write(raw[:at] + b"IHNs" + hdr + graph + raw[at:])
     with pytest.raises(Exception, match="IHNs"):

@@ -86,9 +86,25 @@ def test_attention_mask_is_never_guessed(st, monkeypatch):
     assert st._cfg_from_hf(dict(base, is_causal=False))["causal"] is False
     assert st._cfg_from_hf(dict(STELLA_STYLE, is_causal=False))["causal"] is False
     assert st._cfg_from_hf(dict(STELLA_STYLE, is_causal=True))["causal"] is True
-    # remote modelling code and no key: the mask lives in code that is not run here -> an error that says what to pass
+    # remote modelling code and no key: the mask lives in code that is not run here.  The published stella / gte-Qwen2
+    # signature (auto_map -> modeling_qwen.Qwen2Model + modules.json) is taken as bidirectional, loudly; without
+    # modules.json, or with any other remote code, an error that says what to pass
+    with pytest.warns(UserWarning, match="BIDIRECTIONAL"):
+        assert st._cfg_from_hf(STELLA_STYLE, is_embedding_model=True)["causal"] is False
+    with pytest.warns(UserWarning, match="BIDIRECTIONAL"):                  # hub-qualified spelling of the same class
+        hub = dict(STELLA_STYLE, auto_map={"AutoModel": "NovaSearch/stella_en_1.5B_v5--modeling_qwen.Qwen2Model"})
+        assert st._cfg_from_hf(hub, is_embedding_model=True)["causal"] is False
     with pytest.raises(ValueError, match="causal=False.*MI_ENCODER_CAUSAL"):
-        st._cfg_from_hf(STELLA_STYLE, is_embedding_model=True)
+        st._cfg_from_hf(STELLA_STYLE)
+    with pytest.raises(ValueError, match="causal=False.*MI_ENCODER_CAUSAL"):
+        st._cfg_from_hf(dict(STELLA_STYLE, auto_map={"AutoModel": "modeling_other.OtherModel"}), is_embedding_model=True)
+    for spelling, want_causal in (("no", False), ("off", False), ("False", False), ("yes", True), ("ON", True), ("true", True)):
+        monkeypatch.setenv("MI_ENCODER_CAUSAL", spelling)
+        assert st._cfg_from_hf(STELLA_STYLE)["causal"] is want_causal
+    monkeypatch.setenv("MI_ENCODER_CAUSAL", "maybe")                         # an unknown value is an error, not True
+    with pytest.raises(ValueError, match="MI_ENCODER_CAUSAL"):
+        st._cfg_from_hf(STELLA_STYLE)
+    monkeypatch.delenv("MI_ENCODER_CAUSAL")
     assert st._cfg_from_hf(STELLA_STYLE, causal=False)["causal"] is False    # constructor override
     monkeypatch.setenv("MI_ENCODER_CAUSAL", "0")                             # pipeline override (no keyword to pass)
     assert st._cfg_from_hf(STELLA_STYLE)["causal"] is False
