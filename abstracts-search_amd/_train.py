@@ -74,11 +74,27 @@ def _neg_half_sqnorm(c, device):
     return out
 
 
-def kmeans_l2(x, k: int, niter: int, seed: int, device: int, verbose: bool = False):
-    """Lloyd k-means, L2, bit-reproducible (restated by oracle/train_oracle.py).
+def _renorm_rows(c, device):
+    """faiss fvec_renorm_L2 on the centroid table, in place (ClusteringParameters.spherical): row *= 1 / sqrt(|row|^2) where
+    |row|^2 > 0.  |row|^2 is the library's ascending-k fmaf chain (mi_neg_half_sqnorm x -2: exact); the k reciprocal roots
+    are taken on the host in double (1.0 / sqrtf(nr), as faiss writes it) so that the oracle's numpy gives the same bits;
+    the scaling is one f32 multiply per element."""
+    import torch
+    nr = (_neg_half_sqnorm(c, device) * -2.0).cpu().numpy()
+    inv = np.ones_like(nr)
+    pos = nr > 0
+    inv[pos] = (1.0 / np.sqrt(nr[pos]).astype(np.float64)).astype(np.float32)
+    c.mul_(torch.from_numpy(inv).to(c.device).unsqueeze(1))
+
+
+def kmeans_l2(x, k: int, niter: int, seed: int, device: int, verbose: bool = False, spherical: bool = False):
+    """Lloyd k-means, bit-reproducible (restated by oracle/train_oracle.py).
     arg min ||x-c||^2 = arg max (<x,c> - ||c||^2/2), evaluated by the inner-product kernel on
     vectors augmented with one column ([x, 1, 0...] . [c, -||c||^2/2, 0...]); the update step
-    sums a cluster's members in ascending row order (mi_cluster_means)."""
+    sums a cluster's members in ascending row order (mi_cluster_means).
+    spherical (faiss ClusteringParameters.spherical; what faiss's index_factory sets for METRIC_INNER_PRODUCT [PRIOR]):
+    the centroids are L2-normalised after the initial draw and after every update (faiss Clustering::post_process_centroids),
+    and points go to the centroid of largest inner product (faiss assigns with the index being trained: an IndexFlatIP)."""
     import torch
     n, d = x.shape
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -87,20 +103,27 @@ def kmeans_l2(x, k: int, niter: int, seed: int, device: int, verbose: bool = Fal
     if n <= k:  # degenerate: fewer points than centroids
         c = torch.cat([c, c[torch.randint(0, max(n, 1), (k - c.shape[0],), generator=g).to(x.device)]])
     c = c.contiguous()
+    if spherical:
+        _renorm_rows(c, device)
     # zero columns after the augmenting one add exact zeros to the end of every fmaf chain (the
     # scores do not change); padding to a multiple of 128 columns lets big problems take the
     # two-stage assignment (f16 MFMA scores + exact re-scoring, bit-identical arg max)
     pad = 127 if d % 128 == 0 and k >= 8192 else 3
-    xa = torch.cat([x, torch.ones(n, 1, device=x.device), torch.zeros(n, pad, device=x.device)], 1).contiguous()
+    xa = None if spherical else torch.cat([x, torch.ones(n, 1, device=x.device), torch.zeros(n, pad, device=x.device)], 1).contiguous()
     for it in range(niter):
-        ca = torch.cat([c, _neg_half_sqnorm(c, device).unsqueeze(1), torch.zeros(k, pad, device=x.device)], 1).contiguous()
-        a = _assign_ip(xa, ca, device)
+        if spherical:
+            a = _assign_ip(x, c, device)
+        else:
+            ca = torch.cat([c, _neg_half_sqnorm(c, device).unsqueeze(1), torch.zeros(k, pad, device=x.device)], 1).contiguous()
+            a = _assign_ip(xa, ca, device)
         cnt = _cluster_means(x, a, c, device)
         empty = cnt == 0
         ne = int(empty.sum())
         if ne:  # re-seed empty clusters from random points
             idx = torch.randint(0, n, (ne,), generator=g).to(x.device)
             c[empty] = x[idx]
+        if spherical:
+            _renorm_rows(c, device)
         if verbose:
             print(f"  kmeans iter {it}: {ne} empty clusters")
     return c.contiguous()
@@ -132,7 +155,7 @@ def train_ivfpq(x, nlist: int, M: int, by_residual: bool, cp, device: int, verbo
         xs = _to_device_sample(x, cp.max_points_per_centroid * nlist, cp.seed, device)
         if verbose:
             print(f"train: coarse k-means on {xs.shape[0]} points, k={nlist}")
-        cent = kmeans_l2(xs, nlist, cp.niter, cp.seed, device, verbose)
+        cent = kmeans_l2(xs, nlist, cp.niter, cp.seed, device, verbose, spherical=bool(getattr(cp, 'spherical', False)))
     # PQ codebooks on (residual) sub-vectors
     xp = _to_device_sample(x, pq_cp.max_points_per_centroid * 256, pq_cp.seed + 1, device)
     if by_residual:

@@ -386,8 +386,10 @@ class IndexScalarQuantizer(IndexFlatIP):
 class ClusteringParameters:
     """faiss.ClusteringParameters: the fields faiss's Clustering reads.  What train() here honours: `niter`,
     `max_points_per_centroid` (the training set is subsampled to that many points per centroid, like faiss), `seed`,
-    `verbose`.  `nredo` > 1, `spherical`, `int_centroids`, `frozen_centroids`, `update_index` raise at train() instead of
-    being ignored; `min_points_per_centroid` only warns in faiss and is unused here.
+    `verbose`, `spherical` (coarse k-means only: centroids L2-normalised after every update and points assigned by inner
+    product -- faiss Clustering::post_process_centroids [PRIOR]; `index_factory(..., METRIC_INNER_PRODUCT)` sets it, as
+    faiss's factory does [PRIOR]; the IndexIVFPQ constructor leaves it False, as faiss's does).  `nredo` > 1,
+    `int_centroids`, `frozen_centroids`, `update_index` raise at train() instead of being ignored; `min_points_per_centroid` only warns in faiss and is unused here.
 
     train() here is NOT faiss's Clustering: it is a bit-reproducible Lloyd's k-means (oracle/train_oracle.py is its
     restatement) -- initial centroids from a seeded permutation (faiss: its own RandomGenerator permutation), empty clusters
@@ -408,7 +410,7 @@ class ClusteringParameters:
         self.frozen_centroids = False
 
     def check_supported(self, what: str):
-        bad = [k for k, v in (("nredo", self.nredo != 1), ("spherical", self.spherical), ("int_centroids", self.int_centroids),
+        bad = [k for k, v in (("nredo", self.nredo != 1), ("int_centroids", self.int_centroids),
                               ("update_index", self.update_index), ("frozen_centroids", self.frozen_centroids)) if v]
         if bad:
             raise NotImplementedError(f"{what}: ClusteringParameters.{', '.join(bad)} not implemented (would be silently ignored)")
@@ -562,6 +564,9 @@ class IndexIVFPQ:
             given = torch.from_numpy(self.get_centroids()).to(torch.device("cuda", self.device))
         self.cp.check_supported("IndexIVFPQ.train (index.cp)")
         self.pq.cp.check_supported("IndexIVFPQ.train (index.pq.cp)")
+        if self.pq.cp.spherical:
+            raise NotImplementedError("IndexIVFPQ.train: index.pq.cp.spherical (unit-norm PQ codewords) is not implemented; "
+                                      "index.cp.spherical (the coarse quantiser) is")
         cent, cb = _train.train_ivfpq(x, self.nlist, self.pq.M, self.by_residual, self.cp,
                                       self.device, self.verbose or self.cp.verbose, centroids=given, metric=self.metric_type,
                                       pq_cp=self.pq.cp)
@@ -925,6 +930,8 @@ def index_factory(d: int, description: str, metric: int = METRIC_L2, device: int
                          "(supported: 'Flat', 'IVF<nlist>,PQ<M>[x8][,RFlat | ,Refine(SQfp16) | ,Refine(SQ8)]')")
     nlist, M, nbits = int(m.group(1)), int(m.group(2)), int(m.group(3) or 8)
     index = IndexIVFPQ(d, nlist, M, nbits, metric, device=device)
+    if metric == METRIC_INNER_PRODUCT:
+        index.cp.spherical = True                # [PRIOR] faiss index_factory: "if (metric == METRIC_INNER_PRODUCT) index_ivf->cp.spherical = true"
     if m.group(4) == ",Refine(SQfp16)":          # half-precision refine store: half the HBM and half the bytes per candidate
         return IndexRefine(index, IndexScalarQuantizer(d, ScalarQuantizer.QT_fp16, metric, device))
     if m.group(4) == ",Refine(SQ8)":             # 8-bit refine store with per-dimension ranges: a quarter of the f32 bytes

@@ -6,7 +6,8 @@ k-means per sub-quantiser on the residuals.
 TEST INFRASTRUCTURE ONLY (imported by tests/).  PARITY UNPINNED against faiss: faiss's
 Clustering object is absent here, and it differs in details this file does not claim
 (faiss splits the largest cluster to refill an empty one; here an empty cluster is re-seeded
-from a random training point).  What IS pinned, bit for bit, is the product against this
+from a random training point).  `spherical` restates faiss's ClusteringParameters.spherical (centroids
+renormalised after every update, assignment by inner product) from its published source [PRIOR].  What IS pinned, bit for bit, is the product against this
 file: same seeded draws, and every arithmetic step in a fixed order --
 
   assignment   arg max over j of  fmaf-chain(<x, c_j>) + 1 * (-0.5 * fmaf-chain(<c_j, c_j>))
@@ -38,30 +39,48 @@ def assign_l2(x: np.ndarray, c: np.ndarray, pad: int) -> np.ndarray:
     return O.flat_ip(xa, ca, 1)[1][:, 0].astype(np.int32)
 
 
-def kmeans_l2(x: np.ndarray, k: int, niter: int, seed: int) -> np.ndarray:
+def renorm_rows(c: np.ndarray) -> None:
+    """faiss fvec_renorm_L2 (utils/distances.cpp [PRIOR]: `nr = fvec_norm_L2sqr(xi); if (nr > 0) xi *= 1.0 / sqrtf(nr)`), in place:
+    |row|^2 by the ascending-k fmaf chain, the reciprocal root in double rounded to f32, one f32 multiply per element."""
+    nr = (O.neg_half_sqnorm(c) * np.float32(-2.0)).astype(np.float32)
+    inv = np.ones_like(nr)
+    pos = nr > 0
+    inv[pos] = (1.0 / np.sqrt(nr[pos]).astype(np.float64)).astype(np.float32)
+    c *= inv[:, None]
+
+
+def kmeans_l2(x: np.ndarray, k: int, niter: int, seed: int, spherical: bool = False) -> np.ndarray:
+    """spherical = faiss ClusteringParameters.spherical [PRIOR: Clustering::post_process_centroids renormalises the centroids
+    after every update; index_factory sets it for METRIC_INNER_PRODUCT]: unit-norm centroids, assignment by largest inner
+    product (faiss assigns with the quantiser being trained, an IndexFlatIP)."""
     n, d = x.shape
     g = torch.Generator(device="cpu").manual_seed(seed)
     perm = torch.randperm(n, generator=g)[:k].numpy()
     c = x[perm].copy()
     if n <= k:
         c = np.concatenate([c, c[torch.randint(0, max(n, 1), (k - c.shape[0],), generator=g).numpy()]])
+    c = np.ascontiguousarray(c)
+    if spherical:
+        renorm_rows(c)
     pad = 127 if d % 128 == 0 and k >= 8192 else 3
     for _ in range(niter):
-        a = assign_l2(x, c, pad)
+        a = O.flat_ip(x, c, 1)[1][:, 0].astype(np.int32) if spherical else assign_l2(x, c, pad)
         cnt = O.cluster_means(x, a, c)
         ne = int((cnt == 0).sum())
         if ne:
             idx = torch.randint(0, n, (ne,), generator=g).numpy()
             c[cnt == 0] = x[idx]
+        if spherical:
+            renorm_rows(c)
     return np.ascontiguousarray(c)
 
 
 def train_ivfpq(x: np.ndarray, nlist: int, M: int, by_residual: bool = True, niter: int = 25,
-                max_points_per_centroid: int = 256, seed: int = 1234):
+                max_points_per_centroid: int = 256, seed: int = 1234, spherical: bool = False):
     x = np.ascontiguousarray(x, np.float32)
     d = x.shape[1]
     dsub = d // M
-    cent = kmeans_l2(sample(x, max_points_per_centroid * nlist, seed), nlist, niter, seed)
+    cent = kmeans_l2(sample(x, max_points_per_centroid * nlist, seed), nlist, niter, seed, spherical)
     xp = sample(x, max_points_per_centroid * 256, seed + 1)
     if by_residual:
         xp = np.ascontiguousarray(xp - cent[O.flat_ip(xp, cent, 1)[1][:, 0]])

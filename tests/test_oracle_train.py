@@ -43,3 +43,26 @@ def test_train_ivfpq_shapes(oracle):
     cent, cb = T.train_ivfpq(x, 16, 4, True, niter=3)
     assert cent.shape == (16, 32) and cb.shape == (4, 256, 8)
     assert np.isfinite(cent).all() and np.isfinite(cb).all()
+
+
+def test_spherical_kmeans_restatement(oracle):
+    """ClusteringParameters.spherical: unit-norm centroids after every update, assignment by inner product; on unit-norm
+    data it is still k-means (the cosine objective rises with the iterations) and deterministic."""
+    from oracle import train_oracle as T
+    rng = np.random.default_rng(3)
+    c = rng.standard_normal((12, 16)).astype(np.float32)
+    x = (c[rng.integers(0, 12, 3000)] + 0.3 * rng.standard_normal((3000, 16))).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+
+    def objective(cent):
+        return (x.astype(np.float64) @ cent.astype(np.float64).T).max(1).sum()
+
+    c1, c8 = T.kmeans_l2(x, 12, 1, 5, spherical=True), T.kmeans_l2(x, 12, 8, 5, spherical=True)
+    assert objective(c8) > objective(c1)
+    assert np.allclose(np.linalg.norm(c8.astype(np.float64), axis=1), 1.0, atol=1e-6)
+    assert np.array_equal(c8, T.kmeans_l2(x, 12, 8, 5, spherical=True))
+    assert not np.array_equal(c8, T.kmeans_l2(x, 12, 8, 5))
+    z = np.zeros((2, 4), np.float32)
+    z[1] = [3, 0, 4, 0]
+    T.renorm_rows(z)                                                 # a zero row stays zero (faiss: nr > 0 only)
+    assert (z[0] == 0).all() and np.allclose(z[1], [0.6, 0, 0.8, 0])

@@ -43,6 +43,35 @@ def test_train_is_bit_equal_to_the_oracle(oracle, n, d, nlist, M, by_residual):
     assert len(np.unique(a)) > 0.5 * min(nlist, 40)
 
 
+@pytest.mark.parametrize("n,d,nlist,M", [(6000, 64, 32, 8), (20000, 128, 300, 16)])
+def test_spherical_train_is_bit_equal_to_the_oracle(oracle, n, d, nlist, M):
+    """ClusteringParameters.spherical (what faiss's index_factory sets for METRIC_INNER_PRODUCT [PRIOR]; reference Makefile:39
+    trains through the factory): unit-norm coarse centroids, inner-product assignment -- product == oracle bit for bit, and
+    index_factory turns it on while the constructor leaves it off."""
+    import abstracts_search_amd.faiss as faiss
+    from oracle import train_oracle as T
+    x = _data(n + d + 1, n, d, 40)
+    idx = faiss.index_factory(d, f"IVF{nlist},PQ{M}", faiss.METRIC_INNER_PRODUCT)
+    assert idx.cp.spherical is True and idx.pq.cp.spherical is False
+    assert faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT).cp.spherical is False
+    assert faiss.index_factory(d, f"IVF{nlist},PQ{M}").cp.spherical is False          # METRIC_L2: not spherical
+    idx.cp.niter = idx.pq.cp.niter = 5
+    idx.train(x)
+    cent, cb = idx.get_centroids(), idx.get_codebook()
+    ce, cbe = T.train_ivfpq(x, nlist, M, True, niter=5, max_points_per_centroid=idx.cp.max_points_per_centroid,
+                            seed=idx.cp.seed, spherical=True)
+    assert np.array_equal(bits(cent), bits(ce))
+    assert np.array_equal(bits(cb), bits(cbe))
+    assert np.allclose(np.linalg.norm(cent.astype(np.float64), axis=1), 1.0, atol=1e-6)
+    plain = faiss.IndexIVFPQ(d, nlist, M, 8, faiss.METRIC_INNER_PRODUCT)
+    plain.cp.niter = plain.pq.cp.niter = 5
+    plain.train(x)
+    assert not np.array_equal(bits(plain.get_centroids()), bits(cent))              # the flag changes the index
+    idx.pq.cp.spherical = True
+    with pytest.raises(NotImplementedError, match="pq.cp.spherical"):
+        idx.train(x)
+
+
 def test_cluster_means_kernel(oracle):
     """mi_cluster_means on skewed cluster sizes (one huge, many empty) == the plain loop"""
     import torch
