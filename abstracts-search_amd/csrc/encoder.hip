@@ -47,6 +47,10 @@ struct Knobs {
     bool no_few_gu8;         // MI_NO_FEW_GU8=1: the query-time gate/up projection on 16-feature unit pairs (few_gemm_kernel<FEW_GU>) instead of 8-feature units
     bool no_few_qkv8;        // MI_NO_FEW_QKV8=1: the query-time QKV / O projections stage their fragments through LDS (few_gemm_kernel<FEW_QKV>, few_o_kernel)
     bool no_few_ao;          // MI_NO_FEW_AO=1: one sequence of <= 32 tokens keeps few_attn_kernel + few_o_kernel (no attention inside the O projection)
+    int gemm_persist;        // MI_GEMM_PERSIST=mask: which many-token slab GEMMs run as one persistent workgroup per CU with a stream-K tail --
+                             // 1 plain store, 2 residual, 4 QKV, 8 SwiGLU.  Default 0 (one tile per workgroup): built, parity-tested
+                             // and measured in round 6, the persistent launches LOSE on every shape (profiles/r06_persist_gemm_ab.txt,
+                             // DESIGN 6.1) -- the GEMMs are bound by the 1 400 W cap, not by idle CUs
     int enc_ts;              // MI_ENC_TS=1: in-kernel stamps of the first four slab GEMMs of > 4096 tokens; =n (n > 1): of > n tokens
     bool gemm_ts;            // MI_GEMM_TS=1: the same for mi_enc_gemm_bf16
     void load() {
@@ -70,6 +74,7 @@ struct Knobs {
         few_d_fuse = set("MI_FEW_D_FUSE"); few_sync = set("MI_FEW_SYNC"); few_ts = set("MI_FEW_TS");
         no_few_ao = set("MI_NO_FEW_AO"); no_few_gu8 = set("MI_NO_FEW_GU8"); no_few_qkv8 = set("MI_NO_FEW_QKV8");
         enc_ts = num("MI_ENC_TS", 0); gemm_ts = set("MI_GEMM_TS");
+        gemm_persist = num("MI_GEMM_PERSIST", 0);
     }
 };
 Knobs &knobs_mut() {
@@ -87,6 +92,19 @@ std::atomic<int64_t> g_splitk_launches{0};
 std::atomic<int64_t> g_reduce_norm_launches{0};
 std::atomic<int64_t> g_n192_launches{0};
 std::atomic<int64_t> g_m192_launches{0};      // slab GEMMs on 192-row tiles
+// one word per device: polls of a stream-K head that gave up waiting for its tile's partials (GemmArgs::sk_err)
+unsigned *sk_err_word(int device) {
+    static std::mutex mu;
+    static unsigned *words[16] = {};                         // (never freed: process-lifetime, a few bytes per device)
+    std::lock_guard<std::mutex> lk(mu);
+    unsigned *&b = words[device & 15];
+    if (!b) {
+        MI_HIP(hipMalloc(reinterpret_cast<void **>(&b), 256));
+        MI_HIP(hipMemset(b, 0, 256));
+    }
+    return b;
+}
+std::atomic<int64_t> g_persist_launches{0};      // slab GEMMs launched as one persistent workgroup per CU (stream-K tail)
 std::atomic<int64_t> g_fused_norm_launches{0};   // residual slab GEMMs whose epilogue carried the next RMSNorm (GEMM_RAWNORM)
 std::atomic<int64_t> g_fused_rope_launches{0};   // QKV slab GEMMs whose epilogue rotated Q and K
 std::atomic<int64_t> g_short_attn_launches{0};   // attention launches of the general path that took few_attn_kernel (every sequence <= 48 tokens)
@@ -169,7 +187,10 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
     // measured at 29 312 tokens (tools/gemm_bench.py, profiles/r03_gemm_tile_order.txt): chip patches +3 / +5 / +5 % on the
     // QKV / O / down shapes (N <= 2048), -1.5 % on gate-up (N = 17 920: 70 tile columns) -- so by the width of the GEMM
     g.order = g.tiles_n <= 16 ? 1 : 0;
-    if (epi == EPI_RESID && !g.bias) {
+    // (a persistent launch deals the short last round out as K ranges itself: no K-split tail through atomics)
+    const int persist_bit = epi == EPI_STORE ? 1 : epi == EPI_RESID ? 2 : epi == EPI_QKV ? 4 : epi == EPI_SWIGLU ? 8 : 0;
+    const bool persist = (knobs().gemm_persist & persist_bit) && WMT_ == 8 && WNT_ == 16 / WN_ && g.tiles_m * g.tiles_n >= 2 * 256;
+    if (epi == EPI_RESID && !g.bias && !persist) {
         const int ncu = 256, nb = 8 * per;
         const int main_b = nb / ncu * ncu, rem = nb - main_b;
         const int nk = g.K / 32;
@@ -251,6 +272,19 @@ int launch_slab(int epi, GemmArgs g, hipStream_t st) {
             case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, WN_, false, 16 / WN_, 6>), grid, block, 0, st, g); break;
             case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_SWIGLU, WN_, false, 16 / WN_, 6>), grid, block, 0, st, g); break;
             default: throw Error("192-row slab tiles: epilogue not instantiated");
+        }
+    } else if (persist && g.tail_split == 1 && split_all == 1) {
+        // >= two rounds of tiles: ONE workgroup per CU walks them (the next tile's first slabs in flight under the epilogue) and
+        // the tiles that do not fill a last round are dealt out as K ranges (stream-K; GemmArgs::sk_part)
+        g.krot = 0;
+        ++g_persist_launches;
+        const dim3 pgrid(256);
+        switch (epi) {
+            case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_STORE, WN_, true>), pgrid, block, 0, st, g); break;
+            case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_RESID, WN_, true>), pgrid, block, 0, st, g); break;
+            case EPI_QKV: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_QKV, WN_, true>), pgrid, block, 0, st, g); break;
+            case EPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16_slab_kernel<EPI_SWIGLU, WN_, true>), pgrid, block, 0, st, g); break;
+            default: throw Error("bad epilogue");
         }
     } else {
     switch (epi) {
@@ -662,7 +696,7 @@ struct mi_encoder {
     };
     struct WS {
         std::mutex mu;
-        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_up, ws_out, ws_stage, ws_part, ws_ssq, ws_arrive, few_ctr;
+        DevBuf ws_x, ws_xn, ws_qk, ws_vt, ws_att, ws_h, ws_up, ws_out, ws_stage, ws_part, ws_ssq, ws_arrive, few_ctr, ws_skpart, ws_skctr;
         Pinned pin[3];
         int pin_next = 0;
         size_t vt_zeroed = 0, att_zeroed = 0;
@@ -844,6 +878,7 @@ void stamped_launch(int epi, GemmArgs g, hipStream_t stream) {
     unsigned long long *dts = tsb.as<unsigned long long>((size_t)nb * 8);
     MI_HIP(hipMemsetAsync(dts, 0, (size_t)nb * 64, stream));
     g.ts = dts;
+    g.ts_rows = nb;
     launch_gemm(epi, g, stream);
     std::vector<unsigned long long> h((size_t)nb * 8);
     MI_HIP(hipStreamSynchronize(stream));
@@ -1257,6 +1292,16 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
         if (ws.ws_arrive.cap < NCTR * 4) MI_HIP(hipMemsetAsync(ws.ws_arrive.reserve(NCTR * 4), 0, NCTR * 4, st));
         arrive = ws.ws_arrive.get<unsigned>();
     }
+    // persistent slab GEMMs (>= two rounds of 256 x 256 tiles): the stream-K workspace -- a partial tile per workgroup, arrival
+    // counters zeroed once (the kernel leaves them at zero)
+    float *sk_part = nullptr;
+    unsigned *sk_ctr = nullptr;
+    if (knobs().gemm_persist && T >= 1536) {               // (gate/up reaches two rounds of tiles first: ceil(T / 256) x 70 >= 512)
+        sk_part = static_cast<float *>(ws.ws_skpart.reserve((size_t)256 * 256 * 256 * 4));
+        if (ws.ws_skctr.cap < SK_CTR_WORDS * 4) MI_HIP(hipMemsetAsync(ws.ws_skctr.reserve(SK_CTR_WORDS * 4), 0, SK_CTR_WORDS * 4, st));
+        sk_ctr = ws.ws_skctr.get<unsigned>();
+    }
+    unsigned *sk_err = sk_part ? sk_err_word(h->device) : nullptr;
     auto row_rms = [&](int nslots) -> const float * {       // the slots a residual epilogue left -> 1/rms per row
         hipLaunchKernelGGL(row_rms_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, ssq, nslots, T, H, c.rms_eps, inv_rms);
         MI_HIP(hipGetLastError());
@@ -1304,6 +1349,7 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
         if (few) g.Wt = w.wqkv_t.get<bf16_t>();
         g.part = part; g.part_bytes = part_bytes;    // (a few hundred tokens: K split + one pass that also rotates Q and K)
         g.rope_pos = b.pos; g.rope_cos = h->rope_cos.get<float>(); g.rope_sin = h->rope_sin.get<float>(); g.rope_hd = hd;
+        g.sk_part = sk_part; g.sk_ctr = sk_ctr; g.sk_err = sk_err;
         if (normed & GEMM_RAWNORM) g.row_scale = row_rms(normed >> 8);
         if (rope_fused) { g.W = w.wqkv_r.get<bf16_t>(); g.bias = w.bqkv_r.get<float>(); g.rope_cs = h->rope_cs.get<float2>(); }
         if (!(timed_gemm(h, EPI_QKV, g, st) & GEMM_ROPED)) {
@@ -1317,6 +1363,7 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
         GemmArgs o{};
         o.A = att; o.lda = h->q_cols; o.W = w.wo.get<bf16_t>(); o.ldw = h->q_cols; o.M = T; o.N = H; o.K = h->q_cols;
         o.X = x; o.ldc = H; o.part = part; o.part_bytes = part_bytes;
+        o.sk_part = sk_part; o.sk_ctr = sk_ctr; o.sk_err = sk_err;
         if (few) o.Wt = w.wo_t.get<bf16_t>();
         o.norm_w = w.ln2.get<float>(); o.norm_y = xn; o.norm_eps = c.rms_eps;   // (rides in a split-K reduction pass when there is one,
         if (norm2_fused) { o.ssq_out = ssq; o.rms_out = inv_rms; o.arrive = arrive; }   //  or in the slab / mid epilogue: unscaled row + sums of squares)
@@ -1327,11 +1374,13 @@ int run_stack(mi_encoder *h, mi_encoder::WS &ws, const Batch &b, hipStream_t st)
         GemmArgs u{};
         u.A = xn; u.lda = H; u.W = w.wgu.get<bf16_t>(); u.ldw = H; u.M = T; u.N = 2 * I; u.K = H; u.C = hb; u.ldc = I;
         if (few) u.Wt = w.wgu_t.get<bf16_t>();
+        u.sk_part = sk_part; u.sk_ctr = sk_ctr; u.sk_err = sk_err;
         if (on & GEMM_RAWNORM) u.row_scale = (on & GEMM_RMS_DONE) ? inv_rms : row_rms(on >> 8);
         timed_gemm(h, EPI_SWIGLU, u, st);
         GemmArgs d{};
         d.A = hb; d.lda = I; d.W = w.wd.get<bf16_t>(); d.ldw = I; d.M = T; d.N = H; d.K = I; d.X = x; d.ldc = H;
         d.part = part; d.part_bytes = part_bytes;
+        d.sk_part = sk_part; d.sk_ctr = sk_ctr; d.sk_err = sk_err;
         if (few) d.Wt = w.wd_t.get<bf16_t>();
         if (l + 1 < c.n_layers) {                    // the next layer's first RMSNorm can ride in this GEMM the same way
             d.norm_w = h->layers[l + 1].ln1.get<float>(); d.norm_y = xn; d.norm_eps = c.rms_eps;
@@ -1687,6 +1736,15 @@ int mi_enc_debug_counter(const char *name, int64_t *value) {
         else if (std::string(name) == "splitk_launches") *value = g_splitk_launches.load();
         else if (std::string(name) == "reduce_norm_launches") *value = g_reduce_norm_launches.load();
         else if (std::string(name) == "n192_launches") *value = g_n192_launches.load();
+        else if (std::string(name) == "persist_launches") *value = g_persist_launches.load();
+        else if (std::string(name) == "sk_giveups") {          // (synchronises the device: tests only)
+            int dev = 0;
+            MI_HIP(hipGetDevice(&dev));
+            unsigned v = 0;
+            MI_HIP(hipDeviceSynchronize());
+            MI_HIP(hipMemcpy(&v, sk_err_word(dev), 4, hipMemcpyDeviceToHost));
+            *value = v;
+        }
         else if (std::string(name) == "m192_launches") *value = g_m192_launches.load();
         else if (std::string(name) == "fused_norm_launches") *value = g_fused_norm_launches.load();
         else if (std::string(name) == "fused_rope_launches") *value = g_fused_rope_launches.load();
@@ -1712,6 +1770,21 @@ int mi_enc_gemm_bf16(int device, int M, int N, int K, const void *A, const void 
         GemmArgs g{};
         g.A = static_cast<const bf16_t *>(A); g.lda = K; g.W = static_cast<const bf16_t *>(W); g.ldw = K;
         g.M = M; g.N = N; g.K = K; g.C = static_cast<bf16_t *>(C); g.ldc = N;
+        if (knobs().gemm_persist) {                          // the stream-K workspace of a persistent launch (tools: one call at a time per device)
+            static std::mutex mu;
+            static float *skp[16] = {};                          // (process-lifetime: 64 MiB + 8 KiB per device that calls this)
+            static unsigned *skc[16] = {};
+            std::lock_guard<std::mutex> lk(mu);
+            const int dv = device & 15;
+            if (!skp[dv]) {
+                MI_HIP(hipMalloc(reinterpret_cast<void **>(&skp[dv]), (size_t)256 * 256 * 256 * 4));
+                MI_HIP(hipMalloc(reinterpret_cast<void **>(&skc[dv]), SK_CTR_WORDS * 4));
+                MI_HIP(hipMemset(skc[dv], 0, SK_CTR_WORDS * 4));
+            }
+            g.sk_part = skp[dv];
+            g.sk_ctr = skc[dv];
+            g.sk_err = sk_err_word(device);
+        }
         if (knobs().gemm_ts) {
             stamped_launch(EPI_STORE, g, as_stream(stream));
             return;

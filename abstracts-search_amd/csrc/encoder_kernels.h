@@ -283,7 +283,8 @@ struct GemmArgs {
     float *part;       // EPI_RESID slab kernel with tail_first == 0 (EVERY tile split tail_split ways along K: too few tiles to fill
                        // the chip): slice ks writes its partial tile to part[ks][M][N] (plain whole-line stores, no atomics) and
                        // splitk_reduce_kernel adds the slices to X in ascending order -- bit-reproducible, unlike atomics
-    unsigned long long *ts;   // null, or [workgroups][8] s_memtime stamps of the first tile (MI_GEMM_TS=1 profile launch)
+    unsigned long long *ts;   // null, or [ts_rows][8] s_memtime stamps (MI_GEMM_TS=1 profile launch): row = workgroup; a persistent
+    int ts_rows;              // workgroup's i-th unit writes row blockIdx + i x gridDim
     float *gmax;       // EPI_F32H on the 8-wave slab kernel: null, or [M][ld_gmax] maxima of every 64-column group of a
     int ld_gmax;       // score row (+inf if the group holds a non-finite score) -- what select_refine_kernel's cut needs
     // host side only (EPI_RESID): the RMSNorm that reads the updated stream next -- y = bf16(X * rsqrt(mean(X^2) + eps) * w).
@@ -319,7 +320,16 @@ struct GemmArgs {
     unsigned *arrive;      // the block's rows here (arrive[row block] counts the tiles; zero before and after a launch)
     const float *row_scale;
     const float2 *rope_cs;
+    // PERSIST launches of the slab kernel (one workgroup per CU walks its tiles; see gemm_bf16_slab_kernel): the tiles that do not
+    // fill a last round of workgroups are dealt out as K ranges (stream-K).  A range that does not start at K = 0 leaves its
+    // partial accumulators in sk_part[blockIdx.x][BM x BN] (register-major, write-through) and counts itself in on
+    // sk_ctr[XCD x workgroups-per-XCD + tile]; the workgroup that holds the tile's head adds the partials in range order and runs
+    // the epilogue.  *sk_err counts polls that gave up (a bounded spin: never a hang; one word per device, read by tests through
+    // mi_enc_debug_counter("sk_giveups")); null sk_part: no stream-K, the remainder is a partly filled round.
+    float *sk_part;
+    unsigned *sk_ctr, *sk_err;
 };
+constexpr int SK_CTR_WORDS = 2048;   // GemmArgs::sk_ctr: 8 x 256 tile counters
 constexpr int SSQ_LD = 24;   // partial sums of squares per row (1536 / 64)
 
 // W [N][ldw] (N % 16 == 0, K % 32 == 0) -> fragment-major Wt: one 64-thread workgroup per
@@ -1009,12 +1019,22 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     // is lane-linear).  A slabs: key = row & 7.  W slabs: key = (row & 3) | (bit 3 of row) << 2 -- the 16 rows a
     // ds_read_b128 lane group touches are {0-3, 8-11, 16-19, 24-27} (+ multiples of 4) under the permuted tile
     // maps above and {0..15} under the plain one; this key keeps all of them on 16 distinct 16-byte LDS granules.
-    const int prow = lane >> 3, scol = ((lane & 7) ^ prow) * 8;
-    const int scolW[2] = {((lane & 7) ^ (prow & 3)) * 8, ((lane & 7) ^ ((prow & 3) | 4)) * 8};   // even / odd piece (bit 3 of the row)
+    // (PERSIST: what depends on the lane is derived again for every unit from an opaque copy of the lane number -- values that
+    // stay live across the epilogue are spilled there, and a reload that is first used inside the K loop brings the compiler's
+    // own s_waitcnt vmcnt(n) into the loop, which drains the hand-counted DMA pipeline: the first persistent build ran its K
+    // loop 22 % slower and its epilogue 5 x slower for exactly that)
+    auto opaque_lane = [&]() -> int {
+        int l_ = lane;
+        if constexpr (PERSIST) asm volatile("" : "+v"(l_));
+        return l_;
+    };
     const unsigned dma_dst = lds0 + (unsigned)w * PPW * 1024u;       // + slot * SLAB_B + p * 1024
     const unsigned dma_dstA = lds0 + (unsigned)w * PA * 1024u;
     const bf16_t *srcA[PA], *srcW[PPW];
     auto set_sources = [&](int tm_, int tn_, int kt0_) {
+        const int l_ = opaque_lane();
+        const int prow = l_ >> 3, scol = ((l_ & 7) ^ prow) * 8;
+        const int scolW[2] = {((l_ & 7) ^ (prow & 3)) * 8, ((l_ & 7) ^ ((prow & 3) | 4)) * 8};   // even / odd piece (bit 3 of the row)
 #pragma unroll
         for (int p = 0; p < PPW; ++p) {
             const int r = (w * PPW + p) * 8 + prow;
@@ -1028,26 +1048,37 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     };
     int krot = 0, kn = 1;                                    // GemmArgs::krot: the unit's K tiles are walked from krot round the end
     auto kmap = [&](int t) -> size_t { const int r = t + krot; return (size_t)(r >= kn ? r - kn : r) * 64; };
-    auto request_first = [&](int nk_) {                      // slabs 0 .. DQ-1 into ring slots 0 .. DQ-1
+    // PERSIST: a unit's slab q lives in ring slot (C0 + q) % NS with C0 = 3, so that slabs 0 and 1 of the NEXT unit -- requested
+    // before the current unit's epilogue -- land in [96 KiB, 160 KiB), clear of every epilogue's staging blocks (< 96 KiB; the
+    // V^T tiles of the QKV projection, whose staging takes most of the ring, request theirs after the epilogue)
+    constexpr unsigned C0 = PERSIST ? 3u : 0u;
+    auto request_slabs = [&](int nk_, int q0, int q1) {      // slabs q0 .. q1-1 (of the first DQ) into ring slots (C0 + q) % NS
 #pragma unroll
         for (int q = 0; q < DQ; ++q)
-            if (q < nk_) {
+            if (q >= q0 && q < q1 && q < nk_) {
+                const unsigned slot = (C0 + q) % NS;
                 if (q & 1) {
 #pragma unroll
-                    for (int p = 0; p < PPW; ++p) dma16_off(srcW[p] + kmap(q >> 1), dma_dst + q * SLAB_B + p * 1024u);
+                    for (int p = 0; p < PPW; ++p) dma16_off(srcW[p] + kmap(q >> 1), dma_dst + slot * SLAB_B + p * 1024u);
                 } else {
 #pragma unroll
-                    for (int p = 0; p < PA; ++p) dma16_off(srcA[p] + kmap(q >> 1), dma_dstA + q * SLAB_B + p * 1024u);
+                    for (int p = 0; p < PA; ++p) dma16_off(srcA[p] + kmap(q >> 1), dma_dstA + slot * SLAB_B + p * 1024u);
                 }
             }
     };
+    auto request_first = [&](int nk_) { request_slabs(nk_, 0, DQ); };
 
     // fragment (16 rows x 32 k) of K half kk: lane (li, lg) reads row li, global slot 4 kk + lg -> LDS slot ^ (row & 7)
-    const unsigned rdA = lds0 + (unsigned)(wm * (WMT * 16) + li) * 128u + (unsigned)((lg ^ (li & 7)) * 16);   // kk = 1: ^ 64
-    const int bsub = li >> 2, bc = li & 3;
-    const int brow = PERM == 1 ? 8 * bsub + bc : PERM == 2 ? 32 * (bsub >> 1) + 8 * (bsub & 1) + bc : li;   // W row of tile position li
-    const int bkey = (brow & 3) | (((brow >> 3) & 1) << 2);
-    const unsigned rdB = lds0 + (unsigned)(wn * WNT * 16 + brow) * 128u + (unsigned)((lg ^ bkey) * 16);
+    unsigned rdA = 0, rdB = 0;
+    auto set_read_addresses = [&] {
+        const int l_ = opaque_lane(), li_ = l_ & 15, lg_ = l_ >> 4;
+        rdA = lds0 + (unsigned)(wm * (WMT * 16) + li_) * 128u + (unsigned)((lg_ ^ (li_ & 7)) * 16);   // kk = 1: ^ 64
+        const int bsub = li_ >> 2, bc = li_ & 3;
+        const int brow = PERM == 1 ? 8 * bsub + bc : PERM == 2 ? 32 * (bsub >> 1) + 8 * (bsub & 1) + bc : li_;   // W row of tile position li
+        const int bkey = (brow & 3) | (((brow >> 3) & 1) << 2);
+        rdB = lds0 + (unsigned)(wn * WNT * 16 + brow) * 128u + (unsigned)((lg_ ^ bkey) * 16);
+    };
+    set_read_addresses();
     f32x4 acc[WMT][WNT];
     bf16x8 a0[WMT], b0[WNT], a1[WMT], b1[WNT];
     int nk = 0;                                              // K steps of the current unit
@@ -1100,32 +1131,107 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     int tm, tn, ksplit, kt0;
     // profile launches (MI_GEMM_TS=1): slot 0 = absolute start, 1..4 = ticks since the start at: first slabs landed, K loop
     // issued, epilogue issued, stores acknowledged; 5 = which CU (HW_ID | XCC_ID << 32)
-    const unsigned long long ts0 = g.ts ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long ts0 = g.ts ? __builtin_amdgcn_s_memtime() : 0ull;
+    int ts_row = (int)blockIdx.x;
     auto stamp = [&](int slot) {
-        if (g.ts && threadIdx.x == 0) g.ts[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime() - ts0 + 1;
+        if (g.ts && threadIdx.x == 0 && ts_row < g.ts_rows) g.ts[(size_t)ts_row * 8 + slot] = __builtin_amdgcn_s_memtime() - ts0 + 1;
     };
-    if (g.ts && threadIdx.x == 0) {
-        g.ts[(size_t)blockIdx.x * 8] = ts0;
-        g.ts[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_REG_HW_ID
+    auto stamp_row = [&] {
+        if (g.ts && threadIdx.x == 0 && ts_row < g.ts_rows) {
+            g.ts[(size_t)ts_row * 8] = ts0;
+            g.ts[(size_t)ts_row * 8 + 5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_REG_HW_ID
                                            ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);   // HW_REG_XCC_ID
-    }
-    if (!decode(unit, tm, tn, ksplit, kt0, nk)) return;
-    set_sources(tm, tn, kt0);
-    kn = max(nk >> 1, 1);
-    krot = g.krot < 0 ? (int)(((long)tm * kn) / g.tiles_m) : (tm * g.krot) % kn;
-    request_first(nk);
+        }
+    };
+    stamp_row();
+    // ---- PERSIST: this workgroup's schedule.  XCD x = blockIdx % 8 (where the hardware puts the block: locality only) owns the
+    // tiles tile_coords(vb = 8 s + x), s = 0 .. n_x - 1 -- the tiles the one-tile-per-workgroup launch runs there, in the same
+    // order.  Its G8 = gridDim / 8 workgroups take whole tiles round by round (s = l + i G8) while full rounds last; the R < G8
+    // tiles left over are ONE range of R x KT K tiles cut into P equal pieces (stream-K): workgroup l works [bnd(l), bnd(l+1)),
+    // which touches at most a tile's tail and the next tile's head.  A piece that does not start at K = 0 is a PARTIAL: its
+    // accumulators leave for GemmArgs::sk_part; the holder of a tile's head (K = 0) runs the tile's epilogue after adding the
+    // partials in piece order -- a fixed order: the result does not depend on timing.  Nobody waits for a later piece of their
+    // own: every workgroup runs its partial (if any) first, so a head's partials were published long before it asks.  Cuts
+    // closer than SK_MINK K tiles to a tile edge snap to the edge; pieces are >= SK_MINSEG K tiles.
+    constexpr int SK_MINK = 4, SK_MINSEG = 6;
+    [[maybe_unused]] int ps_x = 0, ps_l = 0, ps_G8 = 1, ps_nx = 0, ps_F = 0, ps_base = 0, ps_P = 0, ps_S = 0, ps_i = 0, ps_u = 0, ps_u1 = 0;
+    [[maybe_unused]] int sk_kind = 0, sk_nc = 0, sk_tile = 0;    // current unit: 0 whole tile / 1 partial / 2 head with sk_nc partials to add
+    auto sk_bnd = [&](int p) -> int {
+        int raw = (int)(((long)p * ps_S) / max(ps_P, 1));
+        const int o = raw % nt_all;
+        if (o < SK_MINK) raw -= o;
+        else if (o > nt_all - SK_MINK) raw += nt_all - o;
+        return raw;
+    };
+    auto pinit = [&] {
+        ps_x = (int)blockIdx.x & 7; ps_l = (int)blockIdx.x >> 3; ps_G8 = max((int)gridDim.x >> 3, 1);
+        const int ntiles = g.tiles_m * g.tiles_n;
+        if (g.order == 1) ps_nx = ntiles > ps_x ? (ntiles - ps_x + 7) >> 3 : 0;
+        else { const int per = (ntiles + 7) >> 3; ps_nx = max(0, min(per, ntiles - ps_x * per)); }
+        ps_F = ps_nx / ps_G8;
+        const int R = ps_nx - ps_F * ps_G8;
+        ps_base = ps_F * ps_G8;
+        const bool sk_on = g.sk_part && g.sk_ctr && R > 0 && R * 5 <= ps_G8 * 4 && nt_all >= 16;
+        if (!sk_on) { if (R > 0) ++ps_F; return; }          // the remainder as a partly filled round of whole tiles
+        ps_S = R * nt_all;
+        ps_P = min(ps_G8, ps_S / SK_MINSEG);
+        if (ps_l < ps_P) { ps_u = sk_bnd(ps_l); ps_u1 = sk_bnd(ps_l + 1); }
+    };
+    auto pnext = [&](int &tm_, int &tn_, int &kt0_, int &nk_, int &kind_, int &nc_, int &tile_) -> bool {
+        kind_ = 0; nc_ = 0; tile_ = 0;
+        if (ps_i < ps_F) {
+            const int sidx = ps_l + ps_i * ps_G8;
+            ++ps_i;
+            if (sidx < ps_nx && tile_coords(g.tiles_m, g.tiles_n, tm_, tn_, sidx * 8 + ps_x, g.order)) {
+                kt0_ = 0; nk_ = 2 * nt_all;
+                return true;
+            }
+            ps_i = ps_F;                                     // (a partly filled last round: nothing for this workgroup)
+        }
+        if (ps_u < ps_u1) {
+            const int t = ps_u / nt_all, o = ps_u - t * nt_all, e = min(ps_u1 - t * nt_all, nt_all);
+            if (!tile_coords(g.tiles_m, g.tiles_n, tm_, tn_, (ps_base + t) * 8 + ps_x, g.order)) { ps_u = ps_u1; return false; }
+            kt0_ = o; nk_ = 2 * (e - o);
+            tile_ = ps_x * ps_G8 + t;
+            if (o > 0) kind_ = 1;
+            else if (e < nt_all) {
+                kind_ = 2;
+                for (int q = ps_l + 1; q < ps_P && sk_bnd(q) < (t + 1) * nt_all; ++q) ++nc_;
+            }
+            ps_u = t * nt_all + e;
+            return true;
+        }
+        return false;
+    };
     // fused RMSNorm (consumer side) / rotary positions: lane l keeps the scale (position) of rows l and 64 + l of the wave's
     // 128 rows; the epilogue fetches its rows' values with ds_bpermute.  Requested right behind the first slabs, so the
     // latency is the pipeline fill's.
     [[maybe_unused]] float inv_lo = 1.f, inv_hi = 1.f;
     [[maybe_unused]] int pos_lo = 0, pos_hi = 0;
-    if constexpr ((EPI == EPI_QKV || EPI == EPI_SWIGLU) && !PERSIST) {
-        const int r0 = min(tm * BM + wm * (WMT * 16) + lane, g.M - 1), r1 = min(tm * BM + wm * (WMT * 16) + 64 + lane, g.M - 1);
-        if (g.row_scale) { inv_lo = g.row_scale[r0]; inv_hi = g.row_scale[r1]; }
-        if constexpr (EPI == EPI_QKV) {
-            if (g.rope_cs) { pos_lo = g.rope_pos[r0]; pos_hi = g.rope_pos[r1]; }
+    auto load_row_consts = [&](int tm_) {
+        if constexpr (EPI == EPI_QKV || EPI == EPI_SWIGLU) {
+            const int r0 = min(tm_ * BM + wm * (WMT * 16) + lane, g.M - 1), r1 = min(tm_ * BM + wm * (WMT * 16) + 64 + lane, g.M - 1);
+            if (g.row_scale) { inv_lo = g.row_scale[r0]; inv_hi = g.row_scale[r1]; }
+            if constexpr (EPI == EPI_QKV) {
+                if (g.rope_cs) { pos_lo = g.rope_pos[r0]; pos_hi = g.rope_pos[r1]; }
+            }
         }
+    };
+    if constexpr (PERSIST) {
+        pinit();
+        if (!pnext(tm, tn, kt0, nk, sk_kind, sk_nc, sk_tile)) return;
+        ksplit = 1;
+        set_sources(tm, tn, kt0);
+        kn = max(nk >> 1, 1);
+        krot = 0;
+    } else {
+        if (!decode(unit, tm, tn, ksplit, kt0, nk)) return;
+        set_sources(tm, tn, kt0);
+        kn = max(nk >> 1, 1);
+        krot = g.krot < 0 ? (int)(((long)tm * kn) / g.tiles_m) : (tm * g.krot) % kn;
     }
+    request_first(nk);
+    load_row_consts(tm);
     auto row_f = [&](int i, int r16) -> float {      // the scale of row 16 i + r16 of the wave's rows
         return __int_as_float(__builtin_amdgcn_ds_bpermute(((i & 3) * 16 + r16) * 4, __float_as_int(i < 4 ? inv_lo : inv_hi)));
     };
@@ -1141,10 +1247,10 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     wait_tiles<PMIN, DQ - 2>(max(0, min(DQ - 2, nk - 2)), false);   // (the smaller of the two slab sizes: never fewer landed than needed)
     asm volatile("s_barrier" ::: "memory");
     stamp(1);
-    static_for<WNT>([&](auto R) { lds_read16<slab_w_tile_off<PERM>(decltype(R)::value)>(b0[decltype(R)::value], rdB + SLAB_B); });
-    static_for<WMT>([&](auto R) { lds_read16<decltype(R)::value * 2048>(a0[decltype(R)::value], rdA); });
+    static_for<WNT>([&](auto R) { lds_read16<slab_w_tile_off<PERM>(decltype(R)::value)>(b0[decltype(R)::value], rdB + ((C0 + 1) % NS) * SLAB_B); });
+    static_for<WMT>([&](auto R) { lds_read16<decltype(R)::value * 2048>(a0[decltype(R)::value], rdA + C0 * SLAB_B); });
 
-    unsigned c = 0;                                          // ring slot of the current tile's A slab
+    unsigned c = C0;                                         // ring slot of the current tile's A slab
     int u = 0;
     for (; u + DQ + 1 < nk; u += 2) {                        // steady state, branch-free
         static_assert(DQ == 4, "the two slabs in flight at an even step are one A and one W slab");
@@ -1170,21 +1276,6 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     stamp(2);
 
-    // PERSIST: request the next unit's first slabs before this unit's epilogue -- the workgroup relaunch, the
-    // pipeline fill (the first slabs' trip from HBM / L2) and the drain of the epilogue's stores overlap
-    bool more = false;
-    int tm2 = 0, tn2 = 0, ksplit2 = 1, kt02 = 0, nk2 = 0;
-    if constexpr (PERSIST) {
-        unit += (int)gridDim.x;
-        more = decode(unit, tm2, tn2, ksplit2, kt02, nk2);
-        if (more) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last step's (unused) fragment reads: the ring is free
-            asm volatile("s_barrier" ::: "memory");              // ... in every wave
-            set_sources(tm2, tn2, kt02);
-            request_first(nk2);
-        }
-    }
-
     const int m0 = tm * BM, n0 = tn * BN;
     GemmArgs ge = g;
     ge.ksplit = ksplit;
@@ -1192,11 +1283,143 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     static_assert(NW * WNT * 16 * VROW * 2 <= NS * (int)SLAB_B, "the V^T staging blocks fit the ring");
     // QKV: a tile that lies wholly inside the V columns (and whole 8-token chunks: M % 8 == 0, ldvt % 8 == 0) leaves through LDS
     [[maybe_unused]] const bool vt_staged = EPI == EPI_QKV && n0 >= g.qk_cols && n0 + BN <= g.N && (g.M & 7) == 0 && (g.ldvt & 7) == 0;
+
+    // PERSIST: the next unit's slabs 0 and 1 are requested before this unit's epilogue, into the ring slots the staging blocks
+    // do not reach -- the pipeline fill (their trip from HBM / L2) runs under the epilogue, and the epilogue's stores drain under
+    // the next K loop's first steps.  (The source pointers are recomputed behind the epilogue: held across it they cost the
+    // epilogue 16-32 registers it does not have.)
+    bool more = false;
+    [[maybe_unused]] bool early = false;
+    int tm2 = 0, tn2 = 0, ksplit2 = 1, kt02 = 0, nk2 = 0;
+    [[maybe_unused]] int kind2 = 0, nc2 = 0, tile2 = 0;
+    if constexpr (PERSIST) {
+        more = pnext(tm2, tn2, kt02, nk2, kind2, nc2, tile2);
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last step's (unused) fragment reads: the ring is free
+            asm volatile("s_barrier" ::: "memory");              // ... in every wave
+            early = !vt_staged;
+            if (early) {
+                // (its own temporaries, not srcA / srcW: those are written once per unit, behind the epilogue)
+                const int l_ = opaque_lane();
+                const int prow = l_ >> 3, scol = ((l_ & 7) ^ prow) * 8;
+                const int scolW[2] = {((l_ & 7) ^ (prow & 3)) * 8, ((l_ & 7) ^ ((prow & 3) | 4)) * 8};
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    const int r = (w * PA + p) * 8 + prow;
+                    dma16_off(g.A + (size_t)min(tm2 * BM + r, g.M - 1) * g.lda + scol + (size_t)kt02 * 64, dma_dstA + C0 * SLAB_B + p * 1024u);
+                }
+                if (nk2 > 1) {
+#pragma unroll
+                    for (int p = 0; p < PPW; ++p) {
+                        const int r = (w * PPW + p) * 8 + prow;
+                        dma16_off(g.W + (size_t)min(tn2 * BN + r, g.N - 1) * g.ldw + scolW[p & 1] + (size_t)kt02 * 64,
+                                  dma_dst + ((C0 + 1) % NS) * SLAB_B + p * 1024u);
+                    }
+                }
+            }
+        }
+    }
+    // stream-K roles (PERSIST): a partial leaves its accumulators in the workspace and skips the epilogue; a head waits for its
+    // tile's partials (published long ago: every workgroup runs its partial first) and adds them in piece order.  Both sides
+    // touch the accumulators through 'a'-class asm operands only, like the K loop: with every AGPR taken, accumulators that
+    // the compiler sees in VALU code migrate to VGPRs and spill (the first version: 1.9 KiB of scratch per lane).
+    //   store: global_store_dwordx4 straight from the AGPR tuple, register-major (1 KiB per wave and instruction), write-through;
+    //   add:   D += T as four v_mfma_f32_16x16x4_f32 per 16 x 16 tile -- MFMA s multiplies the selector A_s[i][k] = (i == 4 s + k)
+    //          by B_s[k][j] = T[4 s + k][j], which in the register-major block is the dword at 256 s + 16 li + 4 lg of the tile's
+    //          KiB: the products are exact (1 x T, 0 x T), so D + T is rounded once, as a v_add_f32 would.
+    bool run_epilogue = true;
+    if constexpr (PERSIST) {
+        static_assert(NMF % 4 == 0, "four accumulator tiles per base address");
+        // (control flow kept to what the K loop already has -- a counted loop over asm that updates the accumulators in place, zero
+        // trips for a whole tile -- and ONE two-way branch, store or epilogue, behind which the accumulators are dead: a
+        // three-way switch with the accumulators live across its merge cost 250 spilled registers)
+        if (sk_nc > 0) {
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(g.sk_ctr + sk_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)sk_nc) {
+                    if (++spins > (1 << 22)) {                   // ~1 s: never a hang -- the tile is wrong and the give-up counter says so
+                        if (g.sk_err) __hip_atomic_fetch_add(g.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                __hip_atomic_store(g.sk_ctr + sk_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left at zero for the next launch
+            }
+            asm volatile("s_barrier" ::: "memory");
+        }
+        float sel[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sel[q] = li == 4 * q + lg ? 1.f : 0.f;
+        constexpr int NG = NMF / 4, DEPTH = NG < 4 ? NG : 4;  // groups of four tiles (16 dword loads each); groups in flight
+        for (int cidx = 0; cidx < sk_nc; ++cidx) {
+            // piece cidx of the tile belongs to workgroup l + 1 + cidx of this XCD = block blockIdx.x + 8 (1 + cidx)
+            const float *pp = g.sk_part + (size_t)(blockIdx.x + 8u * (1 + cidx)) * (BM * BN) + (size_t)w * NMF * 256 + li * 4 + lg;
+            float t[DEPTH][16];
+            auto issue = [&](int slot) {
+                asm volatile("" : "+v"(pp));
+                asm volatile(
+                    "global_load_dword %0, %16, off sc0 sc1\n\tglobal_load_dword %1, %16, off offset:256 sc0 sc1\n\t"
+                    "global_load_dword %2, %16, off offset:512 sc0 sc1\n\tglobal_load_dword %3, %16, off offset:768 sc0 sc1\n\t"
+                    "global_load_dword %4, %16, off offset:1024 sc0 sc1\n\tglobal_load_dword %5, %16, off offset:1280 sc0 sc1\n\t"
+                    "global_load_dword %6, %16, off offset:1536 sc0 sc1\n\tglobal_load_dword %7, %16, off offset:1792 sc0 sc1\n\t"
+                    "global_load_dword %8, %16, off offset:2048 sc0 sc1\n\tglobal_load_dword %9, %16, off offset:2304 sc0 sc1\n\t"
+                    "global_load_dword %10, %16, off offset:2560 sc0 sc1\n\tglobal_load_dword %11, %16, off offset:2816 sc0 sc1\n\t"
+                    "global_load_dword %12, %16, off offset:3072 sc0 sc1\n\tglobal_load_dword %13, %16, off offset:3328 sc0 sc1\n\t"
+                    "global_load_dword %14, %16, off offset:3584 sc0 sc1\n\tglobal_load_dword %15, %16, off offset:3840 sc0 sc1"
+                    : "=&v"(t[slot][0]), "=&v"(t[slot][1]), "=&v"(t[slot][2]), "=&v"(t[slot][3]), "=&v"(t[slot][4]), "=&v"(t[slot][5]),
+                      "=&v"(t[slot][6]), "=&v"(t[slot][7]), "=&v"(t[slot][8]), "=&v"(t[slot][9]), "=&v"(t[slot][10]), "=&v"(t[slot][11]),
+                      "=&v"(t[slot][12]), "=&v"(t[slot][13]), "=&v"(t[slot][14]), "=&v"(t[slot][15])
+                    : "v"(pp) : "memory");
+                pp += 1024;
+            };
+#pragma unroll
+            for (int gq = 0; gq < DEPTH; ++gq) issue(gq);
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+                const int left = NG - 1 - gq < DEPTH - 1 ? NG - 1 - gq : DEPTH - 1;   // groups requested behind this one
+                if (left == 3) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+                else if (left == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                else if (left == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int m = gq * 4 + q / 4;
+                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[m / WNT][m % WNT]) : "v"(sel[q & 3]), "v"(t[gq % DEPTH][q]));
+                }
+                if (gq + DEPTH < NG) issue(gq % DEPTH);      // (the MFMAs read their operands at issue: the returning loads cannot overtake them)
+            }
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // MFMA results -> v_accvgpr_read: the asm is opaque to the hazard recogniser
+        if (sk_kind == 1) {
+            // (as EXEC-masked straight-line code instead of this branch the stores were tried too: the compiler schedules the
+            // epilogue's own VALU work between the masked asm statements -- wrong embeddings -- and the spills stayed)
+            run_epilogue = false;
+            float *pp = g.sk_part + (size_t)blockIdx.x * (BM * BN) + ((size_t)w * NMF * 64 + lane) * 4;
+#pragma unroll
+            for (int m = 0; m < NMF; m += 4) {
+                asm volatile("" : "+v"(pp));                     // (opaque: one base per four stores, not 64 addresses computed up front)
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:1024 sc0 sc1\n\t"
+                             "global_store_dwordx4 %0, %3, off offset:2048 sc0 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:3072 sc0 sc1"
+                             ::"v"(pp), "a"(acc[m / WNT][m % WNT]), "a"(acc[(m + 1) / WNT][(m + 1) % WNT]), "a"(acc[(m + 2) / WNT][(m + 2) % WNT]),
+                               "a"(acc[(m + 3) / WNT][(m + 3) % WNT]) : "memory");
+                pp += 1024;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // acknowledged (device scope) ...
+            asm volatile("s_barrier" ::: "memory");              // ... by every wave, before the piece counts itself in
+            if (tid == 0) __hip_atomic_fetch_add(g.sk_ctr + sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (run_epilogue) {
+    // (PERSIST: the epilogue's lane-dependent values start from an opaque copy of the lane number -- shadowing the kernel's --
+    // so that nothing the epilogue derives from it is computed before the K loop, spilled across it and reloaded store by
+    // store behind an s_waitcnt vmcnt(0) each: that made a 7 k-cycle epilogue 33 k)
+    const int lane = opaque_lane();
+    const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         const int trow = m0 + (wm * WMT + i) * 16;
         const int row = trow + li;
-        if constexpr (PERM == 1 && !PERSIST) {
+        if constexpr (PERM == 1) {
             // plain bf16 store: the lane's 8 consecutive columns (one 16-byte value per tile pair) go through a wave-private LDS
             // block of 16 rows x OW columns and leave as whole rows -- 8 rows x 128 B (or 4 x 256 B) per store instruction
             // where the MFMA layout gives 16 rows x 64 B: the memory pipe charges per (instruction, line); +1.3 ... 2.5 % on
@@ -1243,7 +1466,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 if (trow + r < g.M && col < ncols) *reinterpret_cast<uint4 *>(g.C + (size_t)(trow + r) * g.ldc + col) = o;
             }
         } else if constexpr (PERM == 2) {   // 8 consecutive SwiGLU outputs per lane from tiles (gate, up, gate, up)
-            const float sc = PERSIST ? 1.f : row_f(i, li);   // (fused RMSNorm: 1/rms of the lane's row; 1 without)
+            const float sc = row_f(i, li);   // (fused RMSNorm: 1/rms of the lane's row; 1 without)
 #pragma unroll
             for (int q = 0; q < WNT / 4; ++q) {
                 const int col0 = (n0 + wn * WNT * 16) / 2 + 32 * q + 8 * lg;
@@ -1277,7 +1500,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     *reinterpret_cast<uint4 *>(g.C + (size_t)row * g.ldc + col0) = o;
                 }
             }
-        } else if constexpr ((EPI == EPI_RESID || EPI == EPI_F32H) && !PERSIST) {
+        } else if constexpr (EPI == EPI_RESID || EPI == EPI_F32H) {
             if (ksplit == 1 || (EPI == EPI_RESID && g.part)) {
                 // X += acc through a wave-private LDS staging block: straight from the MFMA layout an instruction
                 // touches 16 rows x 64 B, and the memory pipe charges ~3.5 cycles per (instruction, 128-byte line)
@@ -1381,7 +1604,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
         } else if constexpr (SWAP) {
 #pragma unroll
             for (int j = 0; j < WNT; ++j) store_tile_t<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
-        } else if constexpr (EPI == EPI_QKV && !PERSIST) {
+        } else if constexpr (EPI == EPI_QKV) {
             if (n0 + BN <= g.qk_cols) {
                 // Q / K columns (row-major bf16): the untransposed accumulator tile gives 32-byte row segments per store;
                 // staged like the residual epilogue, a wave's 16 x CW block leaves as whole 128-byte lines.  (The V
@@ -1468,7 +1691,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
             for (int j = 0; j < WNT; ++j) store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
         }
     }
-    if constexpr (EPI == EPI_QKV && !PERSIST) {
+    if constexpr (EPI == EPI_QKV) {
         if (vt_staged) {
             // straight from the accumulators a store is 16 channels x 32 bytes (the V tiles' epilogue measured ~50 000 cycles
             // against the Q / K tiles' ~12 000: in-kernel stamps, profiles/r03_encoder_gemm_stamps.txt); from the block, 4 channels x 256 bytes
@@ -1483,6 +1706,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
             }
         }
     }
+    }   // run_epilogue
     stamp(3);
     if (g.ts) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1490,6 +1714,22 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     }
     if (!more) break;
     tm = tm2; tn = tn2; ksplit = ksplit2; kt0 = kt02; nk = nk2;
+    if constexpr (PERSIST) {
+        sk_kind = kind2; sk_nc = nc2; sk_tile = tile2;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staging blocks are read: the rest of the ring is free ...
+        asm volatile("s_barrier" ::: "memory");                  // ... in every wave
+        asm volatile("" : "+s"(tm), "+s"(tn), "+s"(kt0));        // (opaque: the unit's source pointers are computed HERE, not before the epilogue)
+        set_sources(tm, tn, kt0);
+        set_read_addresses();
+        kn = max(nk >> 1, 1);
+        request_slabs(nk, early ? 2 : 0, DQ);
+        load_row_consts(tm);
+        if (g.ts) {                                              // the next unit's stamps: its own row
+            ts_row += (int)gridDim.x;
+            ts0 = __builtin_amdgcn_s_memtime();
+            stamp_row();
+        }
+    }
     }   // unit loop
 }
 

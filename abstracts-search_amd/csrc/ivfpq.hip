@@ -227,6 +227,7 @@ void launch_slab_f16(const f16_t *A, int64_t na, const f16_t *B, int64_t nb, int
     const unsigned nwg = 8u * (unsigned)((((na + 255) / 256) * ((nb + 255) / 256) + 7) / 8);
     if (knobs().refine_ts) {
         g.ts = tsb.as<unsigned long long>((size_t)nwg * 8);
+        g.ts_rows = nwg;
         MI_HIP(hipMemsetAsync(g.ts, 0, (size_t)nwg * 64, st));
     }
     g.A = reinterpret_cast<const mienc::bf16_t *>(A);
