@@ -583,6 +583,7 @@ struct mi_index {
     DevBuf cent_aug, log_t, d_tnorm, ws_xaug;
     int da = 0;
     int64_t log_cap = 0;
+    bool sealed = false;   // mi_index_seal: the log is freed (80 B per vector); rebuilt from the image by the next call that needs it
     std::vector<int32_t> h_len;
     bool len_ok = true;
     int64_t ntotal = 0;
@@ -697,8 +698,40 @@ void refresh_len(mi_index *h) {
     h->len_ok = true;
 }
 
+void refresh_len(mi_index *h);
+
+// A sealed index (mi_index_seal) holds its lists in the scan image only; whoever needs the log again -- add, export, save --
+// gets it back from the image, in list order (the slots inside a list, i.e. every list's insertion order, are the image's).
+void unseal(mi_index *h) {
+    if (!h->sealed) return;
+    h->sealed = false;
+    if (h->ntotal == 0) return;
+    refresh_len(h);
+    const int64_t n = h->ntotal;
+    h->log_cap = n;
+    uint8_t *lc = static_cast<uint8_t *>(h->log_codes.reserve((size_t)n * h->M));
+    int32_t *ll = static_cast<int32_t *>(h->log_list.reserve((size_t)n * 4));
+    int32_t *lp = static_cast<int32_t *>(h->log_pos.reserve((size_t)n * 4));
+    int64_t *li = static_cast<int64_t *>(h->log_ids.reserve((size_t)n * 8));
+    float *lt = h->metric == MI_METRIC_L2 ? static_cast<float *>(h->log_t.reserve((size_t)n * 4)) : nullptr;
+    std::vector<int64_t> start((size_t)h->nlist + 1, 0);
+    for (int l = 0; l < h->nlist; ++l) start[(size_t)l + 1] = start[(size_t)l] + h->h_len[(size_t)l];
+    MI_REQUIRE(start.back() == n, "unseal: list lengths do not add up to ntotal");
+    DevBuf dstart;
+    MI_HIP(hipMemcpyAsync(dstart.reserve(start.size() * 8), start.data(), start.size() * 8, hipMemcpyHostToDevice, nullptr));
+    const int64_t nslots = h->ngroups * 64;
+    if (nslots > 0) {
+        hipLaunchKernelGGL(image_to_log_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, nullptr, h->d_codes.get<uint8_t>(),
+                           h->d_ids.get<int64_t>(), lt ? h->d_tnorm.get<float>() : nullptr, nslots, h->d_goff.get<int32_t>(),
+                           h->d_len.get<int32_t>(), dstart.get<int64_t>(), h->nlist, h->M, h->nch(), lc, ll, lp, li, lt);
+        MI_HIP(hipGetLastError());
+    }
+    MI_HIP(hipStreamSynchronize(nullptr));
+}
+
 // room for `need` entries in the append log (grows by half, contents preserved)
 void ensure_log_cap(mi_index *h, int64_t need) {
+    unseal(h);
     if (need <= h->log_cap) return;
     const int64_t cap = std::max<int64_t>(need, std::max<int64_t>(h->log_cap + h->log_cap / 2, 4096));
     auto grow = [&](DevBuf &b, size_t elem) {
@@ -973,6 +1006,7 @@ int mi_index_reset(mi_index *h) {
         h->len_ok = true;
         h->ntotal = 0;
         h->dirty = true;
+        h->sealed = false;
     });
 }
 
@@ -1090,6 +1124,7 @@ int mi_index_export_lists(mi_index *h, int list_lo, int list_hi, uint8_t *codes,
         MI_REQUIRE(h, "null argument");
         MI_REQUIRE(0 <= list_lo && list_lo <= list_hi && list_hi <= h->nlist, "list range out of bounds");
         DeviceGuard dg(h->device);
+        unseal(h);
         refresh_len(h);
         std::vector<int64_t> start((size_t)(list_hi - list_lo) + 1, 0);
         for (int l = list_lo; l < list_hi; ++l) start[(size_t)(l - list_lo) + 1] = start[(size_t)(l - list_lo)] + h->h_len[(size_t)l];
@@ -1109,6 +1144,24 @@ int mi_index_export_lists(mi_index *h, int list_lo, int list_hi, uint8_t *codes,
         if (codes && !cdev) MI_HIP(hipMemcpyAsync(codes, oc, (size_t)rows * h->M, hipMemcpyDeviceToHost, nullptr));
         if (ids && !idev) MI_HIP(hipMemcpyAsync(ids, oi, (size_t)rows * 8, hipMemcpyDeviceToHost, nullptr));
         MI_HIP(hipStreamSynchronize(nullptr));
+    });
+}
+
+// The index is built and will be searched: free the append log (80 B per vector: 16.6 GB of the 207 M-vector index), keep the
+// scan image.  Nothing is lost -- a later add / add_codes / export / save rebuilds the log from the image first (one pass, list
+// order) -- and searches are unaffected.  An exclusive call, like add().
+int mi_index_seal(mi_index *h) {
+    return guard([&] {
+        MI_REQUIRE(h, "null argument");
+        DeviceGuard dg(h->device);
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            sync_lists(h);
+        }
+        if (h->sealed) return;
+        h->log_codes.release(); h->log_list.release(); h->log_pos.release(); h->log_ids.release(); h->log_t.release();
+        h->log_cap = 0;
+        h->sealed = true;
     });
 }
 

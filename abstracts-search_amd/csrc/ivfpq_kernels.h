@@ -3105,6 +3105,44 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// group-interleaved image -> log (mi_index_seal freed the log; an add / export / save needs it again): one thread per image
+// slot.  Entry e = start[l] + s for slot s of list l -- list order instead of insertion order, which no consumer of the log
+// depends on: the slot inside the list (log_pos) is what keeps a list's insertion order.
+__global__ void __launch_bounds__(256)
+    image_to_log_kernel(const uint8_t *__restrict__ img, const int64_t *__restrict__ img_ids, const float *__restrict__ img_t,
+                        int64_t nslots, const int32_t *__restrict__ goff, const int32_t *__restrict__ len,
+                        const int64_t *__restrict__ start, int nlist, int M, int NCH, uint8_t *__restrict__ log_codes,
+                        int32_t *__restrict__ log_list, int32_t *__restrict__ log_pos, int64_t *__restrict__ log_ids,
+                        float *__restrict__ log_t) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nslots) return;
+    const int64_t grp = t >> 6;
+    const int lane = (int)(t & 63);
+    int lo = 0, hi = nlist;                                  // the list whose groups [goff[l], goff[l + 1]) hold grp
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)(unsigned)goff[mid] <= grp) lo = mid; else hi = mid;
+    }
+    // (empty lists share their goff with the next list: take the last list that starts at or before grp and has groups)
+    const int l = lo;
+    const int64_t s = (grp - (int64_t)(unsigned)goff[l]) * 64 + lane;
+    if (s >= len[l]) return;
+    const int64_t e = start[l] + s;
+    log_list[e] = l;
+    log_pos[e] = (int32_t)s;
+    log_ids[e] = img_ids[t];
+    if (log_t) log_t[e] = img_t[t];
+    for (int ch = 0; ch < NCH; ++ch) {
+        const uint8_t *src = img + ((size_t)grp * NCH + ch) * 1024 + (size_t)lane * 16;
+        uint8_t *dst = log_codes + (size_t)e * M + ch * 16;
+        if ((M & 15) == 0) *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+        else {
+            const int nb = min(16, M - ch * 16);
+            for (int i = 0; i < nb; ++i) dst[i] = src[i];
+        }
+    }
+}
+
 // log -> the lists [list_lo, list_hi) concatenated, row-major codes, insertion order
 // (InvertedLists::get_codes / get_ids; write_index).  start[l - list_lo] = first output row
 // of list l.  One thread per (entry, 16-byte piece).

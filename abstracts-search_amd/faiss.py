@@ -59,6 +59,7 @@ class _Lib:
                 "mi_index_is_trained": [v, POINTER(c_int)],
                 "mi_index_ntotal": [v, POINTER(c_int64)],
                 "mi_index_reset": [v],
+                "mi_index_seal": [v],
                 "mi_index_add": [v, c_int64, v, v],
                 "mi_index_encode": [v, c_int64, v, v, v],
                 "mi_index_add_codes": [v, c_int64, v, v, v],
@@ -614,6 +615,12 @@ class IndexIVFPQ:
 
     def reset(self):
         _check(_Lib.get().mi_index_reset(self._h))
+
+    def seal(self):
+        """(not in faiss) The index is filled and will be searched: free the append log the lists were built from (80 B per
+        vector: 16.6 GB of the 207 M-vector index) and keep the scan image.  add / add_with_ids / export / write_index after a
+        seal() rebuild the log from the image first -- nothing changes but the HBM in use."""
+        _check(_Lib.get().mi_index_seal(self._h))
 
     def list_size(self, list_no: int) -> int:
         n = c_int64(0)

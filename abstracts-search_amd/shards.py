@@ -36,7 +36,7 @@ def _pad8(n: int) -> int:
 class ShardedIndex:
     def __init__(self, index, group=None, local_search=None, merge=None, shard_coarse=False,
                  local_coarse=None, local_search_pre=None, nlist=None, nprobe=None, id_map=None,
-                 id_affine=None):
+                 id_affine=None, emulate_world=None):
         import torch.distributed as dist
         assert dist.is_initialized(), "ShardedIndex needs an initialised process group"
         self.index = index
@@ -65,6 +65,16 @@ class ShardedIndex:
         assert id_map is None or id_affine is None, "id_map and id_affine are alternatives"
         self._id_map = id_map
         self._id_affine = tuple(int(v) for v in id_affine) if id_affine is not None else (1, 0, 0)
+        # emulate_world = E (a one-rank job only; bench.py --emulate-rank-of E): this process plays rank 0 of an E-rank job on
+        # the one GPU it has -- its shard of the rows, its 1 / E slice of the coarse quantiser, the real collective at world
+        # size 1, an E-block receive buffer and the E-way merge.  The blocks the E - 1 absent ranks would send are put behind
+        # the collective: the TRUE coarse lists of the other centroid slices (computed once per query batch, outside the
+        # stages, so that the merged probe lists -- hence the scan -- are the real job's), and copies of this shard's top-k
+        # for the result exchange.  What it prices: every fixed cost of a rank's step at that size.  What it cannot: xGMI.
+        self.emulate = int(emulate_world) if emulate_world else 0
+        assert not self.emulate or self.world == 1, "emulate_world: a one-rank job plays rank 0 of the emulated one"
+        self._emu_peer = {}
+        self.mworld = self.emulate or self.world                     # blocks in a receive buffer = ways of a merge
 
     # -- diagnostics ---------------------------------------------------------
     _probe = None
@@ -155,7 +165,7 @@ class ShardedIndex:
             idx.search_into(q, k, D, I)
 
     # -- the exchange step ---------------------------------------------------
-    def _exchange_merge(self, nq, k, device, fill, q_lo=0, nq_out=None, affine=(1, 0, 0)):
+    def _exchange_merge(self, nq, k, device, fill, q_lo=0, nq_out=None, affine=(1, 0, 0), peers=None):
         """fill(Dview, Iview) writes this rank's [nq, k] lists into the send buffer; one
         all-gather; merged (D, I) of the queries [q_lo, q_lo + nq_out)."""
         import torch
@@ -164,27 +174,35 @@ class ShardedIndex:
         dbytes = _pad8(nq * k * 4)
         blk = dbytes + nq * k * 8
         send = self._buf("send", blk, device)
-        recv = self._buf("recv", blk * self.world, device)
+        recv = self._buf("recv", blk * self.mworld, device)
         Dv = send[:nq * k * 4].view(torch.float32).view(nq, k)
         Iv = send[dbytes:].view(torch.int64).view(nq, k)
         mark = self._mark
         mark("begin")
         fill(Dv, Iv)
         mark("local")
-        dist.all_gather_into_tensor(recv, send, group=self.group)      # the path's one exchange step
+        if self.emulate:
+            dist.all_gather_into_tensor(recv[:blk], send, group=self.group)   # the real collective, at the world size there is
+            tail = recv[blk:].view(self.emulate - 1, blk)
+            if peers is not None:
+                tail.copy_(peers)                                      # the absent ranks' blocks (their true coarse lists)
+            else:
+                tail.copy_(send.unsqueeze(0).expand(self.emulate - 1, blk))   # ... or copies of this rank's (ids differ by the rank step)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)      # the path's one exchange step
         mark("exchange")
         if self._merge is None:
             from . import faiss
-            out = faiss.merge_topk_gathered(recv, self.world, nq, k, blk, affine, q_lo, nq_out)
+            out = faiss.merge_topk_gathered(recv, self.mworld, nq, k, blk, affine, q_lo, nq_out)
             mark("merge")
             return out
         # injected merge (CPU tests): the same views, ids translated with torch
-        parts = recv.view(self.world, blk)
-        Dg = torch.stack([parts[p, :nq * k * 4].view(torch.float32).view(nq, k) for p in range(self.world)])
-        Ig = torch.stack([parts[p, dbytes:].view(torch.int64).view(nq, k) for p in range(self.world)])
+        parts = recv.view(self.mworld, blk)
+        Dg = torch.stack([parts[p, :nq * k * 4].view(torch.float32).view(nq, k) for p in range(self.mworld)])
+        Ig = torch.stack([parts[p, dbytes:].view(torch.int64).view(nq, k) for p in range(self.mworld)])
         mul, add, step = affine
         if (mul, add, step) != (1, 0, 0):
-            off = (add + step * torch.arange(self.world, dtype=torch.int64, device=Ig.device)).view(-1, 1, 1)
+            off = (add + step * torch.arange(self.mworld, dtype=torch.int64, device=Ig.device)).view(-1, 1, 1)
             Ig = torch.where(Ig < 0, Ig, Ig * mul + off)
         out = self._merge(Dg[:, q_lo:q_lo + nq_out].contiguous(), Ig[:, q_lo:q_lo + nq_out].contiguous())
         mark("merge")
@@ -232,9 +250,24 @@ class ShardedIndex:
     def _search_sharded_coarse(self, qall, k):
         import torch
         nprobe = min(int(self._nprobe if self._nprobe is not None else self.index.nprobe), self._nlist)
-        per = (self._nlist + self.world - 1) // self.world
+        per = (self._nlist + self.mworld - 1) // self.mworld
         lo, hi = min(self.rank * per, self._nlist), min((self.rank + 1) * per, self._nlist)
         nq = qall.shape[0]
+        peers = None
+        if self.emulate:
+            # the other slices' lists for THIS query batch, once (outside the stages probe_split times)
+            key = (qall.data_ptr(), nq, nprobe)
+            peers = self._emu_peer.get(key)
+            if peers is None:
+                dbytes = _pad8(nq * nprobe * 4)
+                blk = dbytes + nq * nprobe * 8
+                peers = torch.empty((self.emulate - 1, blk), dtype=torch.uint8, device=qall.device)
+                for p in range(1, self.emulate):
+                    plo, phi = min(p * per, self._nlist), min((p + 1) * per, self._nlist)
+                    pI, pD = self._local_coarse(qall, nprobe, plo, phi)
+                    peers[p - 1, :nq * nprobe * 4].view(torch.float32).view(nq, nprobe).copy_(pD)
+                    peers[p - 1, dbytes:].view(torch.int64).view(nq, nprobe).copy_(pI)
+                self._emu_peer[key] = peers
         if hi > lo:
             cI, cD = self._local_coarse(qall, nprobe, lo, hi)
         else:
@@ -245,7 +278,7 @@ class ShardedIndex:
             Dv.copy_(cD)
             Iv.copy_(cI)                                            # int32 -> int64
 
-        mD, mI = self._exchange_merge(nq, nprobe, qall.device, fill)   # global top-nprobe lists
+        mD, mI = self._exchange_merge(nq, nprobe, qall.device, fill, peers=peers)   # global top-nprobe lists
         return self._local_search_pre(qall, k, mI.to(torch.int32), mD)
 
     def search_into(self, q_local, k, D, I):

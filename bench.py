@@ -241,6 +241,13 @@ def main():
                     help="--workload encode: also push ALL of configs[2]'s 100 000 synthetic abstracts through one "
                          "encode_tokens() call (length sort, token-budget passes, embeddings back on the host) and report the wall rate")
     ap.add_argument("--full-abstracts", type=int, default=100000, help="--full: how many abstracts (configs[2] says 100k)")
+    ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="E",
+                    help="cfg4 on ONE GPU as rank 0 of an E-GPU job: rows i = 0 (mod E) of the corpus, the 1/E slice of the coarse "
+                         "quantiser, both exchanges through the real collective at world size 1 with E-block receive buffers, the "
+                         "E-way merges; per-stage ms in `step_split`.  A rehearsal of a rank's fixed costs, never a scaling result")
+    ap.add_argument("--no-full", action="store_true",
+                    help="N = 1 runs configs[2] at its stated size by default (all 100 000 abstracts through one encode call, ~57 s: "
+                         "`full_run` beside the per-batch rate); this skips it")
     ap.add_argument("--encode-steps", type=int, default=24, help="cfg4 line: encode steps (x encode-batch abstracts)")
     ap.add_argument("--encode-streams", type=int, default=1, help="encode steps issued round-robin on this many HIP streams")
     ap.add_argument("--multi-gpu-mode", choices=["shards", "replicas"], default="shards",
@@ -260,6 +267,12 @@ def main():
         args.workload = "cfg2"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)                                        # does not return
+    if args.emulate_rank_of:
+        assert args.gpus == 1 and args.workload == "cfg4" and args.emulate_rank_of >= 2, "--emulate-rank-of E: one GPU, cfg4, E >= 2"
+        os.environ["BENCH_FORCE_SHARDED"] = "1"                       # a process group of one rank (RCCL)
+        args.no_refine_point = args.no_recall = args.no_encode = args.no_cfg5 = args.no_cpu_baseline = True
+        if args.shard_coarse is None:
+            args.shard_coarse = 1 if args.emulate_rank_of >= 4 else 0
     if args.shard_coarse is None:
         args.shard_coarse = 1 if (args.gpus >= 4 and args.workload == "cfg4") else 0
     # stdout carries exactly one JSON line: whatever native libraries print to fd 1 (RCCL's
@@ -341,6 +354,9 @@ def cfg4_workload(args, ctx):
     replicas = world > 1 and not use_shards
     nsh = world if use_shards else 1                                   # shards the corpus is dealt into
     my = rank if use_shards else 0
+    emu = int(getattr(args, "emulate_rank_of", 0) or 0)
+    if emu:
+        nsh, my = emu, 0                                               # this GPU holds what rank 0 of the E-rank job holds
     assert CH % max(nsh, 8) == 0
     t0 = time.time()
 
@@ -485,6 +501,7 @@ def cfg4_workload(args, ctx):
     index.search(q_gt[:8].contiguous(), k)                             # builds the scan image of the lists
     torch.cuda.synchronize()
     t_image = time.time() - t2
+    index.seal()                                                       # filled, searched from here on: the append log (80 B per vector) goes
     used, total = hbm_gb(torch)
     log(f"[rank {rank}] ntotal={index.ntotal} add {t_build:.1f}s ({index.ntotal / t_build / 1e6:.2f} M vec/s incl. "
         f"generation + ground truth), scan image {t_image:.2f}s, HBM in use {used:.1f} of {total:.0f} GB")
@@ -495,7 +512,7 @@ def cfg4_workload(args, ctx):
         from abstracts_search_amd.shards import NativeShardedIndex
         sharded = NativeShardedIndex(index, id_affine=(nsh, 0, 1))
     elif use_shards:
-        sharded = ShardedIndex(index, shard_coarse=bool(args.shard_coarse), id_affine=(nsh, 0, 1))
+        sharded = ShardedIndex(index, shard_coarse=bool(args.shard_coarse), id_affine=(nsh, 0, 1), emulate_world=emu or None)
     # batches are independent: 2 streams, also on the sharded path (the exchange of one batch and the coarse stage of
     # the next overlap the other's scan; ShardedIndex keeps a buffer set per stream, torch.distributed orders the
     # collectives by issue order on every rank).  BENCH_SHARD_STREAMS=1 issues the sharded steps on one stream.
@@ -534,6 +551,26 @@ def cfg4_workload(args, ctx):
     settle(step, args.settle_ms)
     dt, blocks, t_issue = clock.measure(step, steps, warmup)
     qps = steps * batch * (world if replicas else 1) / dt
+
+    # ---- the reference's own call shape, reported beside the metric and never as `value`: numpy queries in, numpy (D, I)
+    # out through IndexIVFPQ.search, as a faiss caller writes it (the timed loop above hands over device tensors and keeps
+    # the results in HBM).  The same K steps on ONE stream, every call synchronous: H2D of batch x 4 KiB from pageable host
+    # memory, the search, D2H of batch x k x 12 B.
+    host_io = None
+    if sharded is None and rank == 0:
+        q_np = [qb.cpu().numpy() for qb in my_q[:4]]
+        for b in range(2):
+            index.search(q_np[b % 4], k)
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
+        for b in range(steps):
+            Dh, Ih = index.search(q_np[b % 4], k)
+        dt_h = time.perf_counter() - t_h
+        assert isinstance(Dh, np.ndarray) and Ih.shape == (batch, k)
+        host_io = {"queries_per_s": round(steps * batch / dt_h, 1), "ms_per_step": round(dt_h / steps * 1e3, 5), "steps": steps,
+                   "what": "index.search(numpy [%d, 1024] f32, %d) -> numpy (D, I), back to back, one call in flight: the call the "
+                           "reference makes (faiss Index.search); PCIe both ways and the host's synchronisation inside every step -- "
+                           "a reported figure, never `value`" % (batch, k)}
 
     # recall of the timed configuration against the exact search
     recall = None
@@ -578,7 +615,7 @@ def cfg4_workload(args, ctx):
             dist.all_gather_object(gathered, mine_split)
         else:
             gathered = [mine_split]
-        coarse_pred = 0.23 / (world if args.shard_coarse else 1)       # ms: the measured N = 1 coarse stage (f16 slab GEMM + selection) at batch 1024
+        coarse_pred = 0.23 / ((emu or world) if args.shard_coarse else 1)       # ms: the measured N = 1 coarse stage (f16 slab GEMM + selection) at batch 1024
         split = {"per_rank": gathered,
                  "predicted_ms": {"scan": round(scan_bytes / (0.72 * 8e12) * 1e3, 4), "coarse": round(coarse_pred, 4), "all_gather": 0.05, "merge": 0.02,
                                   "model": "scan = this rank's scanned bytes / (0.72 x 8 TB/s: the fraction measured at N = 1); coarse = 0.23 ms at N = 1 "
@@ -614,12 +651,21 @@ def cfg4_workload(args, ctx):
                        "index_vectors_this_rank": index.ntotal, "index_vectors_per_rank": census["index_vectors_per_rank"],
                        "collective_backend": census["backend"], "rccl_ranks": census["ranks"],
                        "rccl_ranks_note": "ranks one all-reduce on the job's process group reached (backend nccl = RCCL; 1 = no collective, single GPU)",
-                       "hbm_in_use_gb": round(used, 1)},
+                       "hbm_in_use_gb": round(used, 1),
+                       "hbm_note": "after IndexIVFPQ.seal(): the append log the lists were built from is freed (an export / add rebuilds it from the scan image)"},
             "recall_at_10": None if recall is None else round(recall, 4),
             "recall_note": "against exact inner-product search over all %d rows, %d queries" % (N, batch),
-            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
+            "roofline": roofline, "host_io": host_io, "cpu_baseline": cpu, "parity_vs_oracle": parity,
             "at_recall_095": at095, "step_split": split, "reference_oracles": reference_oracles(),
         }
+        if emu:
+            out["rehearsal"] = True
+            out["emulation"] = {"rank_of": emu, "index_vectors": index.ntotal, "coarse_slice_centroids": (nlist + emu - 1) // emu,
+                                "what": "ONE GPU playing rank 0 of a %d-GPU job: its shard (rows i = 0 mod %d), its slice of the coarse quantiser, the "
+                                        "collective at world size 1 with %d-block receive buffers (the absent ranks' blocks are put behind it: their "
+                                        "true coarse lists, copies of this shard's top-k), the %d-way merges.  `value` is what ONE such rank sustains, "
+                                        "i.e. the job's rate if every rank kept up and xGMI cost nothing -- a rehearsal of a rank's fixed costs, "
+                                        "NOT a scaling measurement" % (emu, emu, emu, emu)}
     # ---- BASELINE.json configs[4] in the same line: encode + search at query batches 1 / 16 / 256 over THIS index (before it
     # is freed); the model is the one the encode half below times
     pack = None
@@ -641,7 +687,7 @@ def cfg4_workload(args, ctx):
         if out is not None and enc is not None:
             out["encode"] = {"abstracts_per_s": enc["value"], "tokens_per_s": enc["config"]["tokens_per_sec"],
                              "ms_per_step": enc["ms_per_step"], "steps": enc["steps"], "batch": enc["config"]["batch"],
-                             "sample": enc["config"]["sample"], "dtype": enc["dtype"], "data": enc["data"],
+                             "sample": enc["config"]["sample"], "full_run": enc["full_run"], "dtype": enc["dtype"], "data": enc["data"],
                              "roofline": enc["roofline"], "cpu_baseline": enc["cpu_baseline"],
                              "parity_vs_oracle": enc["parity_vs_oracle"]}
     return out
@@ -1265,7 +1311,9 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True, pack=None):
                                        "epilogues buy shows here -- they lengthen the GEMM launches (frac above falls ~3 %) and shorten the step (~1 %)"},
                 "timing": "the GEMM launches of one profiled step replayed back to back on the launch stream between two HIP events "
                           "(one warm pass, three timed; mi_encoder_profile_read), after the timed blocks"}
-    full_run = encode_full_run(args, ctx, model, cfg) if getattr(args, "full", False) else None
+    # configs[2] at its stated size: at N = 1 by default (the driver's line times the whole 100 000-abstract run, not a sample)
+    do_full = getattr(args, "full", False) or (world == 1 and not getattr(args, "no_full", False))
+    full_run = encode_full_run(args, ctx, model, cfg) if do_full else None
     cpu = parity = None
     if do_cpu:
         cpu, parity = encode_cpu_baseline(model, cfg, host_w, batches, ctx)

@@ -81,6 +81,12 @@ int mi_index_is_trained(mi_index *h, int *out);
 int mi_index_ntotal(mi_index *h, int64_t *out);
 int mi_index_reset(mi_index *h);
 
+/* No faiss counterpart (faiss keeps one copy of the lists): the index is built and will be searched -- free the append log
+ * (80 B per vector; the scan image, 72 B per padded vector, stays).  A later add / add_codes / export / save rebuilds the log
+ * from the image first; results of every call are unchanged.  Exclusive, like mi_index_add.  (reference Makefile:25
+ * `index fill` is followed by searches only.) */
+int mi_index_seal(mi_index *h);
+
 /* IndexIVFPQ.add (ids == NULL: sequential from ntotal) / add_with_ids.
  * x: float32 [n][d]. */
 int mi_index_add(mi_index *h, int64_t n, const float *x, const int64_t *ids);

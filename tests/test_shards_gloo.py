@@ -148,3 +148,54 @@ def test_sharded_equals_unsharded(world, mode):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), mode, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _emulate_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from abstracts_search_amd.shards import ShardedIndex
+    torch.manual_seed(0)
+    nlist, d, nq, nprobe, k, E = 64, 8, 5, 6, 4, 4
+    cent, q = torch.randn(nlist, d), torch.randn(nq, d)
+    seen = {}
+
+    def coarse(qq, npb, lo, hi):
+        D, I = (qq @ cent[lo:hi].T).topk(npb, dim=1)
+        return (I + lo).to(torch.int32), D
+
+    def pre(qq, kk, cI, cD):
+        seen["cI"] = cI.clone()
+        return cD[:, :kk].clone(), cI[:, :kk].to(torch.int64)
+
+    def merge(Dg, Ig):
+        W, n, kk = Dg.shape
+        Dc, Ic = Dg.permute(1, 0, 2).reshape(n, W * kk), Ig.permute(1, 0, 2).reshape(n, W * kk)
+        o = torch.argsort(-Dc, dim=1, stable=True)[:, :kk]
+        return Dc.gather(1, o), Ic.gather(1, o)
+
+    class Dummy:
+        metric_type = 0
+    sh = ShardedIndex(Dummy(), shard_coarse=True, local_coarse=coarse, local_search_pre=pre, nlist=nlist, nprobe=nprobe, merge=merge,
+                      id_affine=(E, 0, 1), emulate_world=E)
+    D, I = sh.search_replicated(q, k)
+    full = (q @ cent.T).topk(nprobe, dim=1)[1]
+    ok = torch.equal(torch.sort(seen["cI"].long(), dim=1)[0], torch.sort(full, dim=1)[0])       # the real job's probe lists
+    ok = ok and I.shape == (nq, k) and bool((I[:, 0] % E == 0).all()) and bool((I[:, 1] == I[:, 0] + 1).all())   # E copies, ids a rank step apart
+    split = sh.probe_split(q, k, reps=2)
+    ok = ok and {"coarse_slice_ms", "coarse_all_gather_ms", "coarse_merge_ms", "scan_preassigned_ms", "scan_all_gather_ms", "scan_merge_ms"} <= set(split)
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_emulated_rank_of_a_larger_job_sees_the_real_probe_lists():
+    """ShardedIndex(emulate_world=E) on a one-rank group (bench.py --emulate-rank-of E): rank 0's coarse slice merged with the
+    absent ranks' true lists gives the global top-nprobe -- the scan the real job's rank would run --, the result exchange
+    merges E blocks, and probe_split names every stage."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_emulate_worker, args=(0, 1, _free_port(), ret))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0 and ret.get(0) is True
