@@ -910,6 +910,17 @@ __global__ void __launch_bounds__(64 * WAVES_M *WAVES_N, (WAVES_M * WAVES_N == 4
 // different instruction sequences, where a failed coalesce would spill AGPRs to scratch.
 // Requires K % 64 == 0.
 // ---------------------------------------------------------------------
+// An accumulator tuple read through asm with 'a'-class inputs (the slab kernel's epilogues): the compiler then never sees the
+// accumulators in VALU code and cannot decide to move them into VGPRs -- and from there to scratch -- ahead of the epilogue.
+__device__ __forceinline__ f32x4 acc_read(const f32x4 &a) {
+    float x0, x1, x2, x3;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(a[0]));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(a[1]));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(x2) : "a"(a[2]));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(x3) : "a"(a[3]));
+    return (f32x4){x0, x1, x2, x3};
+}
+
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (N > 0) {
@@ -1415,6 +1426,11 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
     // store behind an s_waitcnt vmcnt(0) each: that made a 7 k-cycle epilogue 33 k)
     const int lane = opaque_lane();
     const int li = lane & 15, lg = lane >> 4;
+    // every accumulator read of the epilogues goes through acc_read (asm, 'a'-class inputs): read in plain C++ the residual
+    // epilogues carried 148-164 bytes of scratch per lane (reloads behind s_waitcnt vmcnt(0) between their stores), with it none
+    // of the slab kernel's instantiations spills and the 8-wave ones need 104-109 VGPRs instead of 128: +1.3 % on the bulk
+    // encode (1 848 -> 1 873 abstracts/s, alternating on one box: profiles/r06_persist_gemm_ab.txt)
+    auto AC = [&](int i_, int j_) -> f32x4 { return acc_read(acc[i_][j_]); };
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         const int trow = m0 + (wm * WMT + i) * 16;
@@ -1438,9 +1454,9 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     float h[8];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float ga = acc[i][4 * q][c], gb = acc[i][4 * q + 2][c];
-                        h[c] = ga * __builtin_amdgcn_rcpf(1.0f + __expf(-ga)) * acc[i][4 * q + 1][c];
-                        h[4 + c] = gb * __builtin_amdgcn_rcpf(1.0f + __expf(-gb)) * acc[i][4 * q + 3][c];
+                        const float ga = AC(i, 4 * q)[c], gb = AC(i, 4 * q + 2)[c];
+                        h[c] = ga * __builtin_amdgcn_rcpf(1.0f + __expf(-ga)) * AC(i, 4 * q + 1)[c];
+                        h[4 + c] = gb * __builtin_amdgcn_rcpf(1.0f + __expf(-gb)) * AC(i, 4 * q + 3)[c];
                     }
                     o.x = pack2(h[0], h[1]); o.y = pack2(h[2], h[3]); o.z = pack2(h[4], h[5]); o.w = pack2(h[6], h[7]);
                 } else {                    // plain store (+ bias) from tiles 2q, 2q+1
@@ -1450,7 +1466,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                         b0v = *reinterpret_cast<const float4 *>(g.bias + col0);
                         b1v = *reinterpret_cast<const float4 *>(g.bias + col0 + 4);
                     }
-                    const f32x4 v0 = acc[i][2 * q], v1 = acc[i][2 * q + 1];
+                    const f32x4 v0 = AC(i, 2 * q), v1 = AC(i, 2 * q + 1);
                     o.x = pack2(v0[0] + b0v.x, v0[1] + b0v.y); o.y = pack2(v0[2] + b0v.z, v0[3] + b0v.w);
                     o.z = pack2(v1[0] + b1v.x, v1[1] + b1v.y); o.w = pack2(v1[2] + b1v.z, v1[3] + b1v.w);
                 }
@@ -1474,9 +1490,9 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                     float h[8];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float ga = acc[i][4 * q][c] * sc, gb = acc[i][4 * q + 2][c] * sc;
-                        h[c] = ga * __builtin_amdgcn_rcpf(1.0f + __expf(-ga)) * (acc[i][4 * q + 1][c] * sc);
-                        h[4 + c] = gb * __builtin_amdgcn_rcpf(1.0f + __expf(-gb)) * (acc[i][4 * q + 3][c] * sc);
+                        const float ga = AC(i, 4 * q)[c] * sc, gb = AC(i, 4 * q + 2)[c] * sc;
+                        h[c] = ga * __builtin_amdgcn_rcpf(1.0f + __expf(-ga)) * (AC(i, 4 * q + 1)[c] * sc);
+                        h[4 + c] = gb * __builtin_amdgcn_rcpf(1.0f + __expf(-gb)) * (AC(i, 4 * q + 3)[c] * sc);
                     }
                     uint4 o;
                     o.x = pack2(h[0], h[1]); o.y = pack2(h[2], h[3]); o.z = pack2(h[4], h[5]); o.w = pack2(h[6], h[7]);
@@ -1493,7 +1509,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                         b0v = *reinterpret_cast<const float4 *>(g.bias + col0);
                         b1v = *reinterpret_cast<const float4 *>(g.bias + col0 + 4);
                     }
-                    const f32x4 v0 = acc[i][2 * J], v1 = acc[i][2 * J + 1];
+                    const f32x4 v0 = AC(i, 2 * J), v1 = AC(i, 2 * J + 1);
                     uint4 o;
                     o.x = pack2(v0[0] + b0v.x, v0[1] + b0v.y); o.y = pack2(v0[2] + b0v.z, v0[3] + b0v.w);
                     o.z = pack2(v1[0] + b1v.x, v1[1] + b1v.y); o.w = pack2(v1[2] + b1v.z, v1[3] + b1v.w);
@@ -1517,7 +1533,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 }
 #pragma unroll
                 for (int j = 0; j < WNT; ++j)
-                    *reinterpret_cast<f32x4 *>(stg + li * ROWF + j * 16 + 4 * lg) = acc[i][j];
+                    *reinterpret_cast<f32x4 *>(stg + li * ROWF + j * 16 + 4 * lg) = AC(i, j);
                 const int c4 = lane % LPR, col = n0 + wn * CW + c4 * 4;
                 if (EPI == EPI_RESID && ksplit > 1) {     // a K slice's partial tile -> its plane of the workspace (whole lines)
                     float *pp = g.part + (size_t)ks_cur * g.M * g.N;
@@ -1599,11 +1615,11 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < WNT; ++j) store_tile_t<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
+                for (int j = 0; j < WNT; ++j) store_tile_t<EPI>(ge, AC(i, j), AC(i, j), trow, n0 + (wn * WNT + j) * 16, lane);
             }
         } else if constexpr (SWAP) {
 #pragma unroll
-            for (int j = 0; j < WNT; ++j) store_tile_t<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
+            for (int j = 0; j < WNT; ++j) store_tile_t<EPI>(ge, AC(i, j), AC(i, j), trow, n0 + (wn * WNT + j) * 16, lane);
         } else if constexpr (EPI == EPI_QKV) {
             if (n0 + BN <= g.qk_cols) {
                 // Q / K columns (row-major bf16): the untransposed accumulator tile gives 32-byte row segments per store;
@@ -1637,7 +1653,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 }
 #pragma unroll
                 for (int j = 0; j < WNT; ++j) {
-                    const f32x4 v = quad_transpose(acc[i][j], lane);
+                    const f32x4 v = quad_transpose(AC(i, j), lane);
                     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (g.bias) b = *reinterpret_cast<const float4 *>(g.bias + n0 + wn * CW + j * 16 + scol0);
                     float x0 = v[0] * sc + b.x, x1 = v[1] * sc + b.y, x2 = v[2] * sc + b.z, x3 = v[3] * sc + b.w;
@@ -1671,7 +1687,7 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
 #pragma unroll
                 for (int j = 0; j < WNT; ++j) {
                     const float bv = g.bias ? g.bias[n0 + (wn * WNT + j) * 16 + li] : 0.f;
-                    const f32x4 v = acc[i][j];
+                    const f32x4 v = AC(i, j);
                     uint2 o;
                     o.x = pack2(v[0] * s0 + bv, v[1] * s1 + bv);
                     o.y = pack2(v[2] * s2 + bv, v[3] * s3 + bv);
@@ -1681,14 +1697,14 @@ __global__ void __launch_bounds__(128 * WN_, 1) gemm_bf16_slab_kernel(GemmArgs g
                 const float s0 = row_f(i, 4 * lg), s1 = row_f(i, 4 * lg + 1), s2 = row_f(i, 4 * lg + 2), s3 = row_f(i, 4 * lg + 3);
 #pragma unroll
                 for (int j = 0; j < WNT; ++j) {
-                    f32x4 v = acc[i][j];
+                    f32x4 v = AC(i, j);
                     v[0] *= s0; v[1] *= s1; v[2] *= s2; v[3] *= s3;
                     store_tile<EPI>(ge, v, v, trow, n0 + (wn * WNT + j) * 16, lane);
                 }
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < WNT; ++j) store_tile<EPI>(ge, acc[i][j], acc[i][j], trow, n0 + (wn * WNT + j) * 16, lane);
+            for (int j = 0; j < WNT; ++j) store_tile<EPI>(ge, AC(i, j), AC(i, j), trow, n0 + (wn * WNT + j) * 16, lane);
         }
     }
     if constexpr (EPI == EPI_QKV) {

@@ -106,7 +106,7 @@ class Clock:
 
 def committed_traffic(name, match):
     """HBM-side bytes of a kernel from the committed counter passes (profiles/<name>: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    their own runs, tools/prof_r05.sh) -- only when `match(doc)` says the file is of this configuration AND the kernel's source
+    their own runs, tools/prof_r06.sh) -- only when `match(doc)` says the file is of this configuration AND the kernel's source
     text is the one the pass profiled (tools/kernel_stamp.py): a stale file yields (None, why), never an old number.
     -> (doc or None, source / reason text)"""
     try:
@@ -589,7 +589,7 @@ def cfg4_workload(args, ctx):
     torch.cuda.synchronize()
     scan_ms, scan_bytes = prof["scan_ms_avg"], prof["scan_bytes"]
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    pmc, traffic_src = committed_traffic("r05_cfg4_scan_pmc.json", lambda d: (N, nlist, batch, nprobe, k, nsh) == tuple(d["config"]))
+    pmc, traffic_src = committed_traffic("r06_cfg4_scan_pmc.json", lambda d: (N, nlist, batch, nprobe, k, nsh) == tuple(d["config"]))
     traffic = int(pmc["corrected_bytes_per_launch"]) if pmc else None
     roofline = {"kernel": "scan_kernel<64,8,false>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -713,8 +713,10 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
     # Two knobs, explored in ascending cost: the length of the candidate list (k_factor_rf: what PQ64's ranking of the ~N/16384
     # near-identical cluster mates needs) and, only when a longer list stops helping, the number of probes (list coverage).  On
     # the 207 M configuration nprobe 8 already holds the neighbours (16 / 32 / 64 probes change no digit at a given k_factor).
-    kfs = [f for f in (64, 72, 80, 100, 128, 160, 200, 256, 320, 400, 512, 640, 800) if k * f <= 8192]
-    if os.environ.get("BENCH_REFINE_KFS"):                            # counter passes: the timed shape only (tools/prof_r05.sh)
+    # (steps of ~8 % from 320 up: the re-rank streams k_factor_rf KiB per query, so the grid's resolution there is the step's --
+    # round 5's 400 -> 512 jump chose 512 where 480 already holds the recall)
+    kfs = [f for f in (64, 72, 80, 100, 128, 160, 200, 256, 320, 352, 384, 416, 448, 480, 512, 560, 640, 720, 800) if k * f <= 8192]
+    if os.environ.get("BENCH_REFINE_KFS"):                            # counter passes: the timed shape only (tools/prof_r06.sh)
         kfs = [int(v) for v in os.environ["BENCH_REFINE_KFS"].split(",")]
     best, curve, i_kf, done = None, [], 0, False
 
@@ -814,8 +816,8 @@ def refine_point(args, ctx, faiss, ShardedIndex, index, sub, flat_r, refine_own,
         ncand = int((cI[0] >= 0).sum().item())
         rr_bytes = ncand * D_MODEL * relem                               # every candidate's stored row, read once
         ach = rr_bytes / (ms_rr * 1e-3) / 1e9
-        # the re-rank kernel's HBM-side bytes at THIS shape (counter passes with the sweep pinned: tools/prof_r05.sh cfg4)
-        pmc, rr_traffic_src = committed_traffic("r05_cfg4_refine_pmc.json", lambda d_: relem == 1 and world == 1 and
+        # the re-rank kernel's HBM-side bytes at THIS shape (counter passes with the sweep pinned: tools/prof_r06.sh cfg4)
+        pmc, rr_traffic_src = committed_traffic("r06_cfg4_refine_pmc.json", lambda d_: relem == 1 and world == 1 and
                                                  tuple(d_["config"]) == (int(base.ntotal), int(base.nlist), batch, nprobe, kf, k))
         roofline = {"kernel": {1: "rerank_sq8_kernel", 2: "rerank_f16_kernel", 4: "rerank_f32_kernel"}[relem] + " (streaming re-rank of k*k_factor candidates per query)",
                     "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
@@ -984,7 +986,7 @@ def cfg5_curve(args, ctx, model, cfg, host_w, index, sharded, nprobe, k, steps, 
             roof = {"bound": "mfma", "achieved": round(flops / enc / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                     "frac": round(flops / enc / 2.5e15, 4), "flops_per_launch": flops,
                     "algorithmic_flops": "2 x parameters x tokens + 4 x layers x q_cols x sum(len^2) (attention)"}
-        qp, q_src = committed_traffic("r05_encode_query_pmc.json", lambda d_: any(r_.get("tokens") == ntok for r_ in d_["regimes"].values()))
+        qp, q_src = committed_traffic("r06_encode_query_pmc.json", lambda d_: any(r_.get("tokens") == ntok for r_ in d_["regimes"].values()))
         q_traffic = [r_["bytes_per_pass"] for r_ in qp["regimes"].values() if r_.get("tokens") == ntok][0] if qp else None
         roof.update({"kernel": "the encoder forward pass (%s)" % ("csrc/encoder_few.h: five weight-streaming launches per layer, the attention inside the O projection's" if ntok <= 32 else
                                                                     "csrc/encoder_few.h: six weight-streaming launches per layer" if ntok <= 48 else
@@ -1289,8 +1291,8 @@ def encode_workload(args, ctx, steps, warmup, with_cpu=True, pack=None):
     pr = model.profile_read()
     model.profile(False)
     tf = pr["gemm_flops"] / (pr["gemm_ms"] * 1e-3) / 1e12
-    # separate --pmc passes of `bench.py --workload encode` (tools/prof_r05.sh), dropped when the slab kernel changed since
-    pmc, traffic_src = committed_traffic("r05_cfg3_encoder_gemm_pmc.json", lambda d: d.get("batch") == bs and d.get("tokens_step0") == ntok[0])
+    # separate --pmc passes of `bench.py --workload encode` (tools/prof_r06.sh), dropped when the slab kernel changed since
+    pmc, traffic_src = committed_traffic("r06_cfg3_encoder_gemm_pmc.json", lambda d: d.get("batch") == bs and d.get("tokens_step0") == ntok[0])
     traffic, xcheck = None, None
     if pmc:
         traffic = int(pmc["hbm_bytes_per_step"])

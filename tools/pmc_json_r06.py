@@ -1,18 +1,18 @@
-"""gpurun_out/r05_prof/ (tools/prof_r05.sh) -> the stamped counter files bench.py reads for `roofline.traffic`:
-  profiles/r05_cfg4_scan_pmc.json          scan_kernel<64, 8, false, false> at cfg4 (the headline's dominant kernel)
-  profiles/r05_cfg4_refine_pmc.json        rerank_sq8_kernel / scan_kernel<..., true, ...> / select_pairs_kernel at the recall-0.95 point's timed shape
-  profiles/r05_cfg3_encoder_gemm_pmc.json  the four slab GEMMs of the bulk encode (via tools/pmc_encode_json.py)
-  profiles/r05_encode_query_pmc.json       whole forward passes of the query-time regimes: one query (31 tokens), 16 queries (563 tokens)
+"""gpurun_out/r06_prof/ (tools/prof_r06.sh) -> the stamped counter files bench.py reads for `roofline.traffic`:
+  profiles/r06_cfg4_scan_pmc.json          scan_kernel<64, 8, false, false> at cfg4 (the headline's dominant kernel)
+  profiles/r06_cfg4_refine_pmc.json        rerank_sq8_kernel / scan_kernel<..., true, ...> / select_pairs_kernel at the recall-0.95 point's timed shape
+  profiles/r06_cfg3_encoder_gemm_pmc.json  the four slab GEMMs of the bulk encode (via tools/pmc_encode_json.py)
+  profiles/r06_encode_query_pmc.json       whole forward passes of the query-time regimes: one query (31 tokens), 16 queries (563 tokens)
 Every file carries `kernel_source` (tools/kernel_stamp.py): bench.py drops a number whose kernel text changed since the pass.
 FETCH_SIZE: x2 on gfx950 (a wide coalesced read is counted at half its bytes: MI355X_MICROARCH.md, section HBM), KiB units;
-WRITE_SIZE as is.   usage: [PMC_VER=v2] python tools/pmc_json_r05.py [dir = gpurun_out/r05_prof]
+WRITE_SIZE as is.   usage: [PMC_VER=v2] python tools/pmc_json_r06.py [dir = gpurun_out/r06_prof]
 Only the parts found under `dir` are rewritten: the query-time file keeps the regimes (and their stamps) a run did not profile again;
-PMC_VER names the copies of the summaries it cites (profiles/r05_<part>_kernel_stats_<ver>.csv ...)."""
+PMC_VER names the copies of the summaries it cites (profiles/r06_<part>_kernel_stats_<ver>.csv ...)."""
 import csv, json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import kernel_stamp
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r05_prof")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r06_prof")
 prof = os.path.join(ROOT, "profiles")
 VER = os.environ.get("PMC_VER", "v1")
 CORR = "gfx950: FETCH_SIZE counts a wide coalesced read at half its bytes (MI355X_MICROARCH.md, section HBM) -> read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 taken as is; both are the L2's memory-side requests (Infinity-Cache hits are inside the count)"
@@ -44,7 +44,7 @@ def keep(stem):   # copy the summaries the json files cite
     for suf in ("_kernel_stats.csv", "_FETCH_SIZE.txt", "_WRITE_SIZE.txt"):
         f = os.path.join(src, stem + suf)
         if os.path.exists(f):
-            dst = os.path.join(prof, "r05_" + stem + suf.replace("_kernel_stats", "_kernel_stats_" + VER).replace("_SIZE.txt", "_SIZE_" + VER + ".txt"))
+            dst = os.path.join(prof, "r06_" + stem + suf.replace("_kernel_stats", "_kernel_stats_" + VER).replace("_SIZE.txt", "_SIZE_" + VER + ".txt"))
             open(dst, "w").write(open(f).read())
 
 
@@ -65,13 +65,13 @@ if F and W:
                 "corrected_bytes_per_launch": int(F[k]["FETCH_SIZE"][1] * 2048 + W[kw]["WRITE_SIZE"][1] * 1024)}
     sc = one("scan_kernel<64, 8, false, false>")
     doc = dict(sc, config=[cfg["corpus"], cfg["nlist"], cfg["global_batch"], cfg["nprobe"], cfg["k"], 1],
-               config_text="cfg4: 207Mx1024 IVF65536,PQ64, batch 1024, nprobe 64, k 10, 1 GPU (round 5: the default line's search half, the refine point pinned to its timed shape)",
-               how="two separate rocprofv3 --pmc passes (tools/prof_r05.sh cfg4: FETCH_SIZE, then WRITE_SIZE; --kernel-trace only, --kernel-include-regex 'scan_kernel|rerank_sq8|select_pairs') of `bench.py --no-encode --no-cpu-baseline --streams 1 --no-recall --steps 10`; means over the dispatches of this kernel (profiles/r05_cfg4_FETCH_SIZE_v1.txt, _WRITE_SIZE_v1.txt)",
+               config_text="cfg4: 207Mx1024 IVF65536,PQ64, batch 1024, nprobe 64, k 10, 1 GPU (round 6: the default line's search half, the refine point pinned to its timed shape)",
+               how="two separate rocprofv3 --pmc passes (tools/prof_r06.sh cfg4: FETCH_SIZE, then WRITE_SIZE; --kernel-trace only, --kernel-include-regex 'scan_kernel|rerank_sq8|select_pairs') of `bench.py --no-encode --no-cpu-baseline --streams 1 --no-recall --steps 10`; means over the dispatches of this kernel (profiles/r06_cfg4_FETCH_SIZE_v1.txt, _WRITE_SIZE_v1.txt)",
                correction=CORR, algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=round(sc["corrected_bytes_per_launch"] / alg, 4),
-               source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction (profiles/r05_cfg4_scan_pmc.json)",
-               kernel_trace_same_command={"scan_avg_ms_batch1024": round((avg_us(st, "scan_kernel<64, 8, false, false>") or 0) / 1e3, 4), "file": "profiles/r05_cfg4_kernel_stats_v1.csv"},
+               source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction (profiles/r06_cfg4_scan_pmc.json)",
+               kernel_trace_same_command={"scan_avg_ms_batch1024": round((avg_us(st, "scan_kernel<64, 8, false, false>") or 0) / 1e3, 4), "file": "profiles/r06_cfg4_kernel_stats_v1.csv"},
                kernel_source=[kernel_stamp.stamp("ivfpq_kernels.h", "scan_kernel")])
-    json.dump(doc, open(prof + "/r05_cfg4_scan_pmc.json", "w"), indent=1); made.append("r05_cfg4_scan_pmc.json")
+    json.dump(doc, open(prof + "/r06_cfg4_scan_pmc.json", "w"), indent=1); made.append("r06_cfg4_scan_pmc.json")
     a95 = line.get("at_recall_095") or {}
     rr, sa, sp = one("rerank_sq8_kernel"), one("scan_kernel<64, 8, true, false>"), one("select_pairs_kernel")
     if rr and a95:
@@ -82,26 +82,26 @@ if F and W:
                "corrected_bytes_per_launch": rr["corrected_bytes_per_launch"], "algorithmic_bytes_per_launch": rl.get("bytes_per_launch"),
                "traffic_over_algorithmic": round(rr["corrected_bytes_per_launch"] / rl["bytes_per_launch"], 4) if rl.get("bytes_per_launch") else None,
                "avg_us_kernel_trace": {"rerank_sq8_kernel": avg_us(st, "rerank_sq8_kernel"), "scan_kernel<64, 8, true, false>": avg_us(st, "scan_kernel<64, 8, true, false>"),
-                                       "select_pairs_kernel": avg_us(st, "select_pairs_kernel"), "note": "profiles/r05_cfg4_kernel_stats_v1.csv: that run includes the (nprobe, k_factor) sweep's smaller launches"},
-               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction (profiles/r05_cfg4_refine_pmc.json)",
+                                       "select_pairs_kernel": avg_us(st, "select_pairs_kernel"), "note": "profiles/r06_cfg4_kernel_stats_v1.csv: that run includes the (nprobe, k_factor) sweep's smaller launches"},
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction (profiles/r06_cfg4_refine_pmc.json)",
                "kernel_source": [kernel_stamp.stamp("ivfpq_kernels.h", "rerank_sq8_kernel")]}
-        json.dump(doc, open(prof + "/r05_cfg4_refine_pmc.json", "w"), indent=1); made.append("r05_cfg4_refine_pmc.json")
+        json.dump(doc, open(prof + "/r06_cfg4_refine_pmc.json", "w"), indent=1); made.append("r06_cfg4_refine_pmc.json")
 # ---- bulk encode
 if os.path.exists(src + "/encode_gemm_FETCH_SIZE.txt"):
     keep("encode"); keep("encode_gemm")
-    dst = prof + "/r05_cfg3_encoder_gemm_pmc.json"
+    dst = prof + "/r06_cfg3_encoder_gemm_pmc.json"
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_encode_json.py"), src, dst])
     d = json.load(open(dst))
-    d["command"] = d["command"].replace("tools/prof_r04.sh", "tools/prof_r05.sh enc")
-    d["kernel_stats_file"] = "profiles/r05_encode_kernel_stats_v1.csv"
+    d["command"] = d["command"].replace("tools/prof_r04.sh", "tools/prof_r06.sh enc")
+    d["kernel_stats_file"] = "profiles/r06_encode_kernel_stats_v1.csv"
     d["kernel_source"] = [kernel_stamp.stamp("encoder_kernels.h", "gemm_bf16_slab_kernel")]
-    json.dump(d, open(dst, "w"), indent=1); made.append("r05_cfg3_encoder_gemm_pmc.json")
+    json.dump(d, open(dst, "w"), indent=1); made.append("r06_cfg3_encoder_gemm_pmc.json")
 # ---- the query-time regimes: bytes of a whole forward pass
-doc = {"correction": CORR, "regimes": {}, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction (profiles/r05_encode_query_pmc.json)",
-       "how": "tools/prof_r05.sh b1 / mid: every kernel of the pass summed (per-kernel mean x launches per forward pass = dispatches / passes)"}
+doc = {"correction": CORR, "regimes": {}, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction (profiles/r06_encode_query_pmc.json)",
+       "how": "tools/prof_r06.sh b1 / mid: every kernel of the pass summed (per-kernel mean x launches per forward pass = dispatches / passes)"}
 stamps = []
 try:                                                              # regimes an earlier run profiled stay (with their stamps) unless this run has them again
-    old = json.load(open(prof + "/r05_encode_query_pmc.json"))
+    old = json.load(open(prof + "/r06_encode_query_pmc.json"))
 except Exception:
     old = {"regimes": {}, "kernel_source": []}
 REG = (("b1", "few_", "encoder_few.h", ["few_qkv8_kernel", "few_ao_kernel", "few_gu8_kernel", "few_d_kernel", "few_row_kernel"]),
@@ -133,7 +133,7 @@ for tag, frag, hdr, kerns in REG:
         tot_f += f; tot_w += w
         per[k] = {"launches_per_pass": round(per_pass, 2), "fetch_bytes_per_pass": int(f), "write_bytes_per_pass": int(w), "avg_us": avg_us(st, k[:40])}
     doc["regimes"][tag] = {"tokens": ntok, "passes_profiled": passes, "fetch_bytes_per_pass": int(tot_f), "write_bytes_per_pass": int(tot_w) if W else None,
-                           "bytes_per_pass": int(tot_f + tot_w), "kernels": per, "kernel_stats_file": f"profiles/r05_{tag}_kernel_stats_{VER}.csv"}
+                           "bytes_per_pass": int(tot_f + tot_w), "kernels": per, "kernel_stats_file": f"profiles/r06_{tag}_kernel_stats_{VER}.csv"}
     mine = [kernel_stamp.stamp(hdr, k) for k in kerns]
     if tag == "mid":
         mine.append(kernel_stamp.stamp("encoder_kernels.h", "gemm_bf16_slab_kernel"))
@@ -142,5 +142,5 @@ for tag, frag, hdr, kerns in REG:
 if doc["regimes"]:
     seen = set()
     doc["kernel_source"] = [s_ for s_ in stamps if not ((s_["header"], s_["kernel"]) in seen or seen.add((s_["header"], s_["kernel"])))]
-    json.dump(doc, open(prof + "/r05_encode_query_pmc.json", "w"), indent=1); made.append("r05_encode_query_pmc.json")
+    json.dump(doc, open(prof + "/r06_encode_query_pmc.json", "w"), indent=1); made.append("r06_encode_query_pmc.json")
 print("wrote", made)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/prof_r05.sh [parts = "cfg4 b1 mid enc"]   (GPU box, from the repo root) -- round-5 rocprofv3 evidence -> gpurun_out/r05_prof/
+# usage: tools/prof_r06.sh [parts = "cfg4 b1 mid enc"]   (GPU box, from the repo root) -- round-6 rocprofv3 evidence -> gpurun_out/r06_prof/
 #   cfg4  the default line's search half (207 M, incl. the recall-0.95 point): --kernel-trace --stats; FETCH_SIZE / WRITE_SIZE passes of
 #         scan / re-rank / selection with the refine point's (nprobe, k_factor) sweep pinned to the timed shape (BENCH_REFINE_NPROBES /
 #         BENCH_REFINE_KFS), so that a kernel's mean is over launches of ONE shape
@@ -7,11 +7,11 @@
 #   mid   the few-hundred-token encoder (bench.py's 16 queries, 570 tokens): stats + FETCH_SIZE + WRITE_SIZE of every kernel of the pass
 #   mid256  the same for bench.py's 256 queries (8 097 tokens)
 #   enc   encode (cfg3): stats, a plain run, FETCH_SIZE / WRITE_SIZE of its GEMM kernels
-# Counters always in their own passes with --kernel-trace only.  tools/pmc_json_r05.py turns the summaries into the stamped
-# profiles/r05_*_pmc.json files bench.py reads for `roofline.traffic`.
+# Counters always in their own passes with --kernel-trace only.  tools/pmc_json_r06.py turns the summaries into the stamped
+# profiles/r06_*_pmc.json files bench.py reads for `roofline.traffic`.
 parts=${1:-"cfg4 b1 mid enc"}
 R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/r05_prof
+out=$R/gpurun_out/r06_prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 stats() { # tag, command...
@@ -30,7 +30,11 @@ for part in $parts; do case $part in
 cfg4)
   B="python $R/bench.py --no-encode --no-cpu-baseline --streams 1"
   stats cfg4 $B
-  export BENCH_REFINE_NPROBES=8 BENCH_REFINE_KFS=512
+  # the refine point the run above chose (held-out batch): the counter passes pin the sweep to it
+  KF=$(python -c "import json,sys; d=json.loads([l for l in open('$out/cfg4_under_stats.out') if l.startswith('{')][-1]); a=d['at_recall_095']; print(a['nprobe'], a['k_factor_rf'])")
+  set -- $KF
+  export BENCH_REFINE_NPROBES=$1 BENCH_REFINE_KFS=$2
+  echo "refine point: nprobe $1 k_factor $2"
   for c in FETCH_SIZE WRITE_SIZE; do pmc cfg4 $c "scan_kernel|rerank_sq8|select_pairs" $B --no-recall --steps 10; done
   unset BENCH_REFINE_NPROBES BENCH_REFINE_KFS ;;
 b1)
@@ -52,7 +56,7 @@ mid256)
   for c in FETCH_SIZE WRITE_SIZE; do pmc mid256 $c "mienc" $Q; done
   unset ENC_NQ ENC_REPS ;;
 enc)
-  E="python $R/bench.py --workload encode --steps 4 --warmup 1 --no-cpu-baseline"
+  E="python $R/bench.py --workload encode --steps 4 --warmup 1 --no-cpu-baseline --no-full"
   stats encode $E; cp $out/encode_under_stats.out $out/encode_under_stats.json
   timeout 600 $E > $out/encode_plain.json 2> $out/encode_plain.err
   for c in FETCH_SIZE WRITE_SIZE; do pmc encode_gemm $c "gemm_bf16_(ring|slab)" $E; done ;;
