@@ -708,29 +708,37 @@ class IndexIVFPQ:
         if rc:
             _check(rc)
 
-    def coarse_slice(self, x, nprobe: int, list_lo: int, list_hi: int):
+    def coarse_slice(self, x, nprobe: int, list_lo: int, list_hi: int, D_out=None):
         """quantizer.search restricted to centroids [list_lo, list_hi) with global
-        list numbers -> (coarse_I int32, coarse_D f32) CUDA tensors [nq, nprobe]."""
+        list numbers -> (coarse_I int32, coarse_D f32) CUDA tensors [nq, nprobe].
+        D_out: a contiguous f32 [nq, nprobe] CUDA tensor the scores are written into (the sharded search's send buffer)."""
         import torch
         x = _as_f32(x, self.d)
         nq = x.shape[0]
         cI = torch.empty((nq, nprobe), dtype=torch.int32, device=x.device)
-        cD = torch.empty((nq, nprobe), dtype=torch.float32, device=x.device)
+        if D_out is not None:
+            assert D_out.is_cuda and D_out.dtype == torch.float32 and D_out.is_contiguous() and tuple(D_out.shape) == (nq, nprobe)
+        cD = D_out if D_out is not None else torch.empty((nq, nprobe), dtype=torch.float32, device=x.device)
         _check(_Lib.get().mi_index_coarse_slice(self._h, nq, _ptr(x), int(nprobe), int(list_lo), int(list_hi),
                                                 _ptr(cI), _ptr(cD), _current_stream()))
         return cI, cD
 
-    def search_preassigned(self, x, k: int, coarse_I, coarse_D):
+    def search_preassigned(self, x, k: int, coarse_I, coarse_D, D=None, I=None):
         """faiss IndexIVF.search_preassigned (CUDA tensors): search with a given
-        coarse assignment [nq, nprobe] (int32 list numbers, -1 = none)."""
+        coarse assignment [nq, nprobe] (int32 list numbers, -1 = none).  D / I: contiguous f32 / int64 [nq, k] CUDA
+        tensors to write into (the sharded search's send buffer) instead of fresh ones."""
         import torch
         x = _as_f32(x, self.d)
         nq = x.shape[0]
         coarse_I = coarse_I.to(torch.int32).contiguous()
         coarse_D = coarse_D.to(torch.float32).contiguous()
         assert coarse_I.shape == coarse_D.shape and coarse_I.shape[0] == nq
-        D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
-        I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+        if D is None:
+            D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+        else:
+            assert I is not None and D.is_cuda and I.is_cuda and D.dtype == torch.float32 and I.dtype == torch.int64
+            assert D.is_contiguous() and I.is_contiguous() and tuple(D.shape) == (nq, k) and tuple(I.shape) == (nq, k)
         _check(_Lib.get().mi_index_search_preassigned(self._h, nq, _ptr(x), k, coarse_I.shape[1], _ptr(coarse_I),
                                                       _ptr(coarse_D), _ptr(D), _ptr(I), _current_stream()))
         return D, I

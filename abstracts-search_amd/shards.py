@@ -54,6 +54,7 @@ class ShardedIndex:
         # split by centroid range; the per-rank top-nprobe lists take the same
         # exchange + merge (same total order => the same probe list as the full search)
         self.shard_coarse = shard_coarse
+        self._native_coarse = local_coarse is None and local_search_pre is None   # the HIP index: results straight into the send buffers
         self._local_coarse = local_coarse or (lambda q, nprobe, lo, hi: self.index.coarse_slice(q, nprobe, lo, hi))
         self._local_search_pre = local_search_pre or (lambda q, k, cI, cD: self.index.search_preassigned(q, k, cI, cD))
         self._nlist = nlist if nlist is not None else getattr(index, "nlist", None)
@@ -118,13 +119,18 @@ class ShardedIndex:
             for what, t in marks:
                 if prev is not None:
                     dt = prev[1].elapsed_time(t) if cuda else (t - prev[1]) * 1e3
+                    direct = self.shard_coarse and self._native_coarse and self._id_map is None   # slice / scan write the send buffers themselves
                     if what == "begin":
                         n_ex += 1
                         name = ("coarse_slice" if n_ex == 1 else "scan_preassigned") if self.shard_coarse else "setup"
+                        if direct:
+                            name = "coarse_setup" if n_ex == 1 else "scan_setup"
                     else:
                         name = {"local": "pack" if self.shard_coarse else "local_search", "exchange": "all_gather", "merge": "merge"}[what]
                         if self.shard_coarse:
                             name = ("coarse_" if n_ex == 1 else "scan_") + name
+                        if direct and what == "local":
+                            name = "coarse_slice" if n_ex == 1 else "scan_preassigned"
                     acc[name + "_ms"] = acc.get(name + "_ms", 0.0) + dt / reps
                 prev = (what, t)
         return {k2: round(v, 4) for k2, v in acc.items()}
@@ -211,7 +217,12 @@ class ShardedIndex:
     def _search_all(self, qall, k, q_lo, nq_out):
         nq = qall.shape[0]
         self._mark("start")
-        if self.shard_coarse:
+        if self.shard_coarse and self._native_coarse and self._id_map is None:
+            mD, mI = self._merged_probe_lists(qall)
+
+            def fill(Dv, Iv):                                       # the scan writes the send buffer (no pack copies)
+                self.index.search_preassigned(qall, k, mI, mD, Dv, Iv)
+        elif self.shard_coarse:
             Dl, Il = self._search_sharded_coarse(qall, k)
 
             def fill(Dv, Iv):
@@ -248,6 +259,12 @@ class ShardedIndex:
         return self._search_all(qall, k, self.rank * b, b)       # this shard, all queries; own slice merged
 
     def _search_sharded_coarse(self, qall, k):
+        mD, mI = self._merged_probe_lists(qall)
+        return self._local_search_pre(qall, k, mI, mD)
+
+    def _merged_probe_lists(self, qall):
+        """this rank's slice of the coarse quantiser, exchanged and merged: the global top-nprobe lists (f32 scores, int32 list
+        numbers) every rank then scans its shard of"""
         import torch
         nprobe = min(int(self._nprobe if self._nprobe is not None else self.index.nprobe), self._nlist)
         per = (self._nlist + self.mworld - 1) // self.mworld
@@ -268,18 +285,19 @@ class ShardedIndex:
                     peers[p - 1, :nq * nprobe * 4].view(torch.float32).view(nq, nprobe).copy_(pD)
                     peers[p - 1, dbytes:].view(torch.int64).view(nq, nprobe).copy_(pI)
                 self._emu_peer[key] = peers
-        if hi > lo:
-            cI, cD = self._local_coarse(qall, nprobe, lo, hi)
-        else:
-            cI = torch.full((nq, nprobe), -1, dtype=torch.int32, device=qall.device)
-            cD = torch.full((nq, nprobe), -torch.finfo(torch.float32).max, device=qall.device)
-
         def fill(Dv, Iv):
-            Dv.copy_(cD)
+            if hi > lo and self._native_coarse:
+                cI, _ = self.index.coarse_slice(qall, nprobe, lo, hi, D_out=Dv)   # the scores straight into the send buffer
+            elif hi > lo:
+                cI, cD = self._local_coarse(qall, nprobe, lo, hi)
+                Dv.copy_(cD)
+            else:
+                cI = torch.full((nq, nprobe), -1, dtype=torch.int32, device=qall.device)
+                Dv.fill_(-torch.finfo(torch.float32).max)
             Iv.copy_(cI)                                            # int32 -> int64
 
         mD, mI = self._exchange_merge(nq, nprobe, qall.device, fill, peers=peers)   # global top-nprobe lists
-        return self._local_search_pre(qall, k, mI.to(torch.int32), mD)
+        return mD, mI.to(torch.int32)
 
     def search_into(self, q_local, k, D, I):
         Dm, Im = self.search(q_local, k)

@@ -58,7 +58,10 @@ def test_clustering_parameters_mirror_faiss_defaults():
     assert (cp.niter, cp.nredo, cp.max_points_per_centroid, cp.min_points_per_centroid, cp.seed) == (25, 1, 256, 39, 1234)
     assert not (cp.spherical or cp.int_centroids or cp.update_index or cp.frozen_centroids or cp.verbose)
     cp.check_supported("x")
-    for field in ("spherical", "int_centroids", "update_index", "frozen_centroids"):
+    c2 = faiss.ClusteringParameters()
+    c2.spherical = True                                           # implemented for the coarse quantiser (round 6): accepted
+    c2.check_supported("train")
+    for field in ("int_centroids", "update_index", "frozen_centroids"):
         c2 = faiss.ClusteringParameters()
         setattr(c2, field, True)
         with pytest.raises(NotImplementedError, match=field):
