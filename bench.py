@@ -193,7 +193,7 @@ def self_launch(n):
 def rank_census(torch, dist, world, dev, ntotal):
     """What the collective library itself sees: the ranks an all-reduce on the job's backend reaches and every rank's
     share of the index (one all-gather) -- so that the line shows N ranks took part, not N copies of rank 0."""
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():
         return {"backend": None, "ranks": 1, "index_vectors_per_rank": [int(ntotal)]}
     one = torch.ones(1, device=dev, dtype=torch.int64)
     dist.all_reduce(one)

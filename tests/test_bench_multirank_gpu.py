@@ -120,3 +120,26 @@ def test_cfg4_line_two_ranks_subshard_refine_point():
     out = _run(2, SMALL, BENCH_FORCE_SUBSHARD="1")
     a = out["at_recall_095"]
     assert a is not None and a["recall_at_10"] > 0.8 and "1/8 sub-shard" in a["scope"] and a["qps"] > 0
+
+
+@pytest.mark.gpu
+def test_cfg4_line_emulating_rank_0_of_8(one_gpu_line):
+    """`python bench.py --emulate-rank-of 8` (round 6): one process, one GPU, RCCL at world size 1 -- rank 0's shard (rows i = 0
+    mod 8), its 1/8 slice of the coarse quantiser, 8-block exchanges, 8-way merges.  The line is labelled a rehearsal, names
+    every stage of the step, and scans an eighth of the bytes the whole index's step scans (the merged probe lists are the real
+    job's: the absent ranks' TRUE coarse lists stand behind the collective)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emulate-rank-of", "8", "--steps", "3", "--warmup", "1"] + SMALL,
+                       cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["rehearsal"] is True and out["emulation"]["rank_of"] == 8 and out["n_gpus"] == 1
+    assert out["emulation"]["index_vectors"] == 2 * 1048576 // 8 and out["config"]["shard_coarse"] is True
+    assert out["config"]["rccl_ranks"] == 1 and out["config"]["collective_backend"] == "nccl"
+    sp = out["step_split"]["per_rank"][0]
+    for key in ("coarse_slice_ms", "coarse_all_gather_ms", "coarse_merge_ms", "scan_preassigned_ms", "scan_all_gather_ms", "scan_merge_ms"):
+        assert sp[key] >= 0, key
+    whole = one_gpu_line["roofline"]["bytes_per_launch"]
+    assert 0.08 * whole < sp["scan_bytes"] < 0.18 * whole, (sp["scan_bytes"], whole)   # the same lists, an eighth of every one
+    assert out["recall_at_10"] is None and out["at_recall_095"] is None and "encode" not in out

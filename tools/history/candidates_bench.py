@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Time of the first stage of a refine search (mi_index_search_candidates) at a whole-index-like shape: ~25 k pairs per
 query, the best 5120 kept (CAND_KC); run under rocprofv3 --kernel-trace --stats for the per-kernel split."""
 import os, sys, time

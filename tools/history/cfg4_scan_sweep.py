@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Builds the full cfg4 index (207 M x 1024, IVF65536,PQ64) once on one MI355X and times the
 batch-1024 search + the scan kernel under launch variants (MI_NSLICE, MI_SCAN_NW, nprobe).
 GPU box; ~2.5 min.  usage: python tools/cfg4_scan_sweep.py [N]"""

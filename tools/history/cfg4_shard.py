@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """One shard of BASELINE.json configs[3] on one MI355X: 207M x 1024 IVF65536,PQ64
 sharded by vector over 8 GPUs = 25.9M vectors per GPU, every GPU searching all
 queries (batch 1024) over its shard.  Builds the shard from the synthetic

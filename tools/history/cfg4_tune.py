@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """The `tune` step on one shard of BASELINE.json configs[3] (207M x 1024, IVF65536,PQ64 over
 8 GPUs = 25.9M vectors on this GPU) with a flat refine stage over the shard's raw vectors
 (106 GB of the 288 GB HBM): which (nprobe, k_factor_rf) reaches recall@10 >= 0.95 against

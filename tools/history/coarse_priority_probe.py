@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Does a high-priority stream for the coarse stage hide it behind the previous batch's scan?  207 M index (or PROBE_N),
 batch 1024, nprobe 64: (a) whole searches round-robin on 2 streams (bench.py's loop); (b) coarse quantiser of batch i+1
 on a high-priority stream, LUT + scan (search_preassigned) on a normal one, chained by events."""

@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Encoder throughput on synthetic abstracts (cfg3 shape: stella_en_1.5B_v5
 architecture, random-init bf16 weights, clipped log-normal lengths).  GPU box."""
 import os, sys, time

@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """IndexFlatIP.rerank (gather GEMM + candidate merge) on random candidates: 1024 queries x kc
 rows of an n-row store, f32 or half store -- is the gather bound by bytes or by rows (TLB reach /
 scattered-row rate)?  Candidates: uniformly random over the store, or clustered into `nreg`

@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """bf16 GEMM time at the encoder's shapes for few-hundred- to few-thousand-token batches (cfg5's batch 16 / 256),
 per tile configuration (MI_GEMM_TILE): which existing kernel is the best starting point for the mid-batch path."""
 import os, subprocess, sys

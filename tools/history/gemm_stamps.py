@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """In-kernel phase stamps of the 256x256 GEMM kernels (MI_GEMM_TS=1): where a tile's time goes -- pipeline fill, K loop,
 epilogue, store drain, and (slab kernel) the gap between consecutive workgroups of a CU.
 usage: [ZERO=1] [M=32768] python tools/gemm_stamps.py   (GPU box; prints to stderr)"""

@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Kernel-time sweep of the exact-f32 score GEMM (run under tools/prof_cmd.sh).
 
 IndexFlatIP.search = ip_gemm_kernel + select_kernel; sweeping d at fixed

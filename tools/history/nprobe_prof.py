@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Search steps at a large nprobe on the cfg2 index (per-kernel profile target: run under
 tools/prof_cmd.sh).  usage: python tools/nprobe_prof.py [nprobe[,nprobe...]] [k] [batch] [reps]"""
 import os, sys, time

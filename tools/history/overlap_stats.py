@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Concurrency statistics from a rocprofv3 kernel_trace.csv of the multi-stream bench:
 per kernel the duration under overlap, plus how long 1, 2, 3... kernels ran at once.
 usage: python tools/overlap_stats.py <kernel_trace.csv> [last_n_dispatches]"""

@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORY (rounds 1-3): kept for the record; NOT maintained -- knobs it sets may no longer exist (silent no-ops), paths may have moved.
 # usage: tools_prof.sh <tag> <bench args...>   (run on the GPU box from the repo root)
 # rocprofv3 kernel trace + stats of bench.py, bounded by timeout; CSV summaries land in gpurun_out/<tag>/
 tag=$1; shift

@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORY (rounds 1-3): kept for the record; NOT maintained -- knobs it sets may no longer exist (silent no-ops), paths may have moved.
 # usage: tools/prof_attn_pmc.sh <tag>   (GPU box) -- SQ counters of the encoder's attention kernel (one --pmc pass)
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag

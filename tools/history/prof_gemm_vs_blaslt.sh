@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORY (rounds 1-3): kept for the record; NOT maintained -- knobs it sets may no longer exist (silent no-ops), paths may have moved.
 # L2-miss traffic and kernel names of the slab GEMM against hipBLASLt on the encoder's shapes (GPU box) -> gpurun_out/r03_blaslt/
 out=$GRAFT_REPO_ROOT/gpurun_out/r03_blaslt
 mkdir -p $out

@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORY (rounds 1-3): kept for the record; NOT maintained -- knobs it sets may no longer exist (silent no-ops), paths may have moved.
 # usage: tools/prof_r03.sh   (GPU box, from the repo root) -- round-3 rocprofv3 evidence in one go:
 #   encode (cfg3 shape): --kernel-trace --stats; one SQ-counter pass; FETCH_SIZE and WRITE_SIZE passes (GEMM kernels only)
 #   cfg4 (207 M): --kernel-trace --stats of the default line (with the whole-index refine point); FETCH / WRITE passes of the scan kernel

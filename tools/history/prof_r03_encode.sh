@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORY (rounds 1-3): kept for the record; NOT maintained -- knobs it sets may no longer exist (silent no-ops), paths may have moved.
 # the encode half of tools/prof_r03.sh (GPU box): kernel stats + FETCH / WRITE passes -> gpurun_out/r03_prof/
 out=$GRAFT_REPO_ROOT/gpurun_out/r03_prof
 mkdir -p $out

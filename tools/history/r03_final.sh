@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORY (rounds 1-3): kept for the record; NOT maintained -- knobs it sets may no longer exist (silent no-ops), paths may have moved.
 # round-3 closing run (GPU box): the whole GPU suite, then the default bench line
 mkdir -p gpurun_out
 timeout 2000 python -m pytest tests -m gpu -q -rf 2>&1 | grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" | tail -8 | tee gpurun_out/r03_gputest_final.log

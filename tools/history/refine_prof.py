@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """The recall >= 0.95 operating point on one cfg4 sub-shard (25.9 M vectors, IVF65536,PQ64 + refine
 store), timed per configuration; run under tools/prof_cmd.sh for the per-kernel split.
 usage: python tools/refine_prof.py [f16|f32] [nprobe] [k_factor] [N]"""

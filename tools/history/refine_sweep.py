@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Recall@10 and step time of IVF4096,PQ64 + RFlat (IndexRefineFlat) on the bench corpus:
 k_factor x nprobe sweep against exact search.  GPU box."""
 import os, sys, time

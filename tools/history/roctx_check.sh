@@ -1,3 +1,4 @@
+# HISTORY (rounds 1-3): kept for the record; NOT maintained -- knobs it sets may no longer exist (silent no-ops), paths may have moved.
 # do the stage ranges reach a rocprofv3 --marker-trace summary?  (GPU box)
 cd /tmp && export TMPDIR=/tmp
 for mode in auto forced; do

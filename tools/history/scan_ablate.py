@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Ablation / tuning harness for the scan kernel (GPU box): builds cfg2 once and
 times scan_kernel (HIP events inside the library) under MI_NSLICE / MI_SCAN_DEBUG."""
 import os, sys, time

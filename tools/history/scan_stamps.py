@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """In-kernel phase timing of the scan kernel at cfg2 (GPU box): MI_SCAN_TS=1 makes
 mi_index_profile_scan replay the last scan once with s_memtime stamps and print the
 per-phase statistics (stderr)."""

@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Durations of the coarse-selection kernel per search step from a rocprofv3 kernel trace
 (steps are recognised by the small-batch score GEMM in front of it), grouped by nprobe run.
 usage: python tools/select_from_trace.py <kernel_trace.csv> <steps_per_run>"""

@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """select_refine_kernel at the cfg4 coarse size (1024 queries x 65536 centroids): time by nprobe, with and without
 the exact chains (MI_REFINE_DEBUG=1), through mi_index_coarse (GPU box)."""
 import os, sys, time

@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Per-phase kernel durations from a rocprofv3 kernel_trace.csv.
 usage: python tools/trace_groups.py <trace.csv> <kernel-substring> <launches-per-group>
 Prints the median duration of every consecutive group of launches of that kernel."""

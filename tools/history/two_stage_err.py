@@ -1,3 +1,5 @@
+"""HISTORY (rounds 1-3): kept for the record of how a number in DESIGN_HISTORY.md / profiles/ was produced.  NOT maintained: knobs it
+sets may no longer exist (MI_RERANK, MI_REFINE_DEBUG, MI_SCAN_DEBUG ... are silent no-ops now) and paths may have moved."""
 """Empirical |approximate - exact| of the two-stage coarse quantiser's first stage against the
 margin its second stage assumes (eps_rel |q| max|c|).  MI_REFINE_DEBUG=1 makes the second stage
 report the approximate scores of the selected centroids instead of their exact ones.  GPU box."""
