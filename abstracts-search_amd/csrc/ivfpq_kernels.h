@@ -2178,8 +2178,10 @@ __device__ __forceinline__ int wave_rank(unsigned key, int64_t id, int n, int la
 
 // Reduce a wave's candidate buffer (cnt <= 128 entries) to its exact top-k
 // under (score desc, id asc); returns the new count and the k-th score.
+// (ids: null, or the lists' id array when the buffer holds POSITIONS in it instead of ids -- scan_kernel's lazy mode: only the
+// rare tie path below compares ids, and fetches them then)
 __device__ __forceinline__ void wave_compress(float *buf_s, int64_t *buf_id, int lane, int k, int &cnt,
-                                              float &thr) {
+                                              float &thr, const int64_t *ids = nullptr) {
     const bool va = lane < cnt, vb = lane + 64 < cnt;
     const float sa = va ? buf_s[lane] : 0.f, sb = vb ? buf_s[lane + 64] : 0.f;
     const int64_t ia = va ? buf_id[lane] : 0, ib = vb ? buf_id[lane + 64] : 0;
@@ -2191,7 +2193,8 @@ __device__ __forceinline__ void wave_compress(float *buf_s, int64_t *buf_id, int
     const int ties = __popcll(__ballot(ea)) + __popcll(__ballot(eb));
     bool keep_a = ga || ea, keep_b = gb || eb;
     if (ties > need) {  // rare: keep the `need` smallest ids among the tied entries
-        const unsigned long long ua = (unsigned long long)ia ^ (1ull << 63), ub = (unsigned long long)ib ^ (1ull << 63);
+        const int64_t ra = (ids && ea) ? ids[ia] : ia, rb = (ids && eb) ? ids[ib] : ib;
+        const unsigned long long ua = (unsigned long long)ra ^ (1ull << 63), ub = (unsigned long long)rb ^ (1ull << 63);
         unsigned long long pref = 0;
         for (int bit = 63; bit >= 0; --bit) {
             const unsigned long long t = pref | (1ull << bit);
@@ -2324,6 +2327,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
     const int end = (int)(((int64_t)G * (slice + 1)) / a.nslice);
 
     const bool has_bound = a.bound_s != nullptr;
+    const bool lazy_ids = !ALL && !has_bound && !(a.debug & 16);   // (debug 16: the eager id loads, for A/B runs)
     float bs = 0.f;
     int64_t bid = 0;
     if (has_bound) {
@@ -2334,7 +2338,10 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
     int cnt = 0;
     float thr = MI_NEG_INF;
 
-    // work items = 64-code groups [beg, end), dealt round-robin to the waves
+    // work items = 64-code groups [beg, end), dealt round-robin to the waves.  (Taking them from a workgroup counter instead --
+    // the waves of a slice finish up to 60 k cycles apart and the tail's barrier waits for the slowest -- removes that wait and
+    // lengthens the main loop by as much: the workgroup is bound by what it streams, not by its slowest wave.  Measured in
+    // round 6, not kept: profiles/r06_scan_lazy_ids_ab.txt.)
     int t = beg + w;
     int p = 0;
     if (!reg_tab && !wide_tab && t < end) {  // smallest p with prefix[p+1] > t
@@ -2382,7 +2389,12 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         const uint4 *gp = reinterpret_cast<const uint4 *>(a.codes + (size_t)gg * (NCH * 1024)) + lane;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) g.c[ch] = gp[ch * 64];
-        if (!ALL || a.all_id) g.id = a.ids[(size_t)gg * 64 + lane];
+        // lazy ids (top-k mode without an extraction bound): a code's id is only ever COMPARED when two scores tie at a cut, and
+        // only the <= 3 k survivors of the workgroup are published -- so the candidates carry their POSITION in the id array
+        // (group x 64 + lane: no load) and the ids of the survivors are fetched in the selection tail.  The eager load was 8 of
+        // the 72 bytes the scan moved per code.
+        if (lazy_ids) g.id = (int64_t)gg * 64 + lane;
+        else if (!ALL || a.all_id) g.id = a.ids[(size_t)gg * 64 + lane];
         if constexpr (L2) g.t = a.tnorm[(size_t)gg * 64 + lane];
     };
     // Two groups per wave are requested before the LUT barrier (most of a cfg2-sized
@@ -2438,7 +2450,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
             const unsigned long long mask = __ballot(pf);
             if (mask) {
                 if (cnt > 64) {  // make room: reduce the buffer to the wave's top k, tighten the threshold
-                    wave_compress(buf_s, buf_id, lane, k, cnt, thr);
+                    wave_compress(buf_s, buf_id, lane, k, cnt, thr, lazy_ids ? a.ids : nullptr);
                     if (thr > wthr && lane == 0) atomicMax(wg_thr, f2o(thr));
                 }
                 if (pf) {
@@ -2519,20 +2531,27 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
             int o = 0;
             if (lane == 0) o = atomicAdd(c_total, tot);
             o = uniform_i(o);
+            // (lazy ids: the survivors' ids now, all of a lane's loads in flight together)
+            int64_t ra = ia, rb = ib, rc = last_id;
+            if (lazy_ids) {
+                if (pa) ra = a.ids[ia];
+                if (pb) rb = a.ids[ib];
+                if (pc) rc = a.ids[last_id];
+            }
             if (pa) {
                 const int x = o + lane_prefix_count(ma);
                 g_s[x] = sa;
-                g_id[x] = ia;
+                g_id[x] = ra;
             }
             if (pb) {
                 const int x = o + na + lane_prefix_count(mb);
                 g_s[x] = sb;
-                g_id[x] = ib;
+                g_id[x] = rb;
             }
             if (pc) {
                 const int x = o + na + nb2 + lane_prefix_count(mc);
                 g_s[x] = last_s;
-                g_id[x] = last_id;
+                g_id[x] = rc;
             }
         }
     }

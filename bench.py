@@ -594,7 +594,14 @@ def cfg4_workload(args, ctx):
     roofline = {"kernel": "scan_kernel<64,8,false>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_launch": int(scan_bytes), "avg_launch_ms": round(scan_ms, 5),
-                "algorithmic_bytes": "codes of the probed lists x (64 B code + 8 B id), device-counted"}
+                "algorithmic_bytes": "codes of the probed lists x (64 B code + 8 B id), device-counted: SURVEY 8(d)'s per-code figure (what "
+                                     "the reference's scan reads)",
+                # since round 6 the kernel reads the id of a code only if the code survives its workgroup's selection: what it
+                # MOVES is the code bytes -- below the algorithmic figure, which `traffic` (PMC) shows
+                "bytes_moved_per_launch": int(scan_bytes * 64 // 72),
+                "frac_of_bytes_moved": round(scan_bytes * 64 / 72 / (scan_ms * 1e-3) / 1e9 / 8000.0, 4) if scan_ms > 0 else None,
+                "bytes_moved_note": "64 B per code (ids are fetched for the <= 3 k survivors of a workgroup only): the kernel is bound by its "
+                                    "LDS gather (64 table reads per code, random banks) at about this rate"}
 
     # ---- recall >= 0.95 operating point: IVF-PQ proposes k * k_factor candidates, exact re-ranking
     at095 = None
