@@ -296,6 +296,9 @@ void prepare_cent16(const float *c, int64_t nc, int d, DevBuf &c16, DevBuf &stat
 // than it saves.  MI_TWO_STAGE=0 / 1 forces it off / on (tests).
 bool two_stage_wanted(int64_t nq, int64_t nc, int d, int K) {
     bool on = nq >= 256 && nc >= 8192 && nq * nc >= ((int64_t)1 << 24) && (K <= 128 || nq * nc >= ((int64_t)1 << 26));   // (1024 x 65536, K 256: 2.68 -> 2.16 ms)
+    // the 8 192-centroid slice a rank of the 8-GPU job quantises against (sharded coarse quantiser, batch 1024): 0.181 -> 0.139 ms,
+    // the rank's rehearsed step 0.536 -> 0.478 ms (bench.py --emulate-rank-of 8, MI_TWO_STAGE unset / 1 alternating)
+    on = on || (nq >= 1024 && nc >= 8192 && K <= 128);
     if (knobs().two_stage >= 0) on = knobs().two_stage != 0;
     return on && d % 128 == 0 && d <= 4096 && nc % 4 == 0 && K <= 1024 && nc < ((int64_t)1 << 31);
 }
