@@ -124,6 +124,9 @@ void launch_rerank_scores(const float *q, int nq, const TB *base, int64_t nb, in
     launch_gemm_gather<TB>(q, nq, base, nb, d, idx, kc, S, ldS, st);
 }
 
+#ifndef MI_RERANK_SQ8_NST
+#define MI_RERANK_SQ8_NST 3                 // ring stages of rerank_sq8_kernel (2 and 4 measured: profiles/r06_rerank_sq8_stages_ab.txt)
+#endif
 // the same over a QT_8bit store: the per-query table of the asymmetric score (w | A, in `tab`), then rerank_sq8_kernel (rows
 // that are not whole 128-byte pieces: one thread per candidate)
 void launch_rerank_sq8(const float *q, int nq, const uint8_t *base, int64_t nb, int d, const float *trained,
@@ -136,7 +139,7 @@ void launch_rerank_sq8(const float *q, int nq, const uint8_t *base, int64_t nb, 
     const int tiles = (kc + 63) / 64;
     if (d % 128 == 0 && (int64_t)nq * tiles < ((int64_t)1 << 31)) {
         const unsigned grid = (unsigned)((int64_t)nq * tiles);
-        hipLaunchKernelGGL((rerank_sq8_kernel<3>), dim3(grid), dim3(64), 0, st, wq, Aq, base, nb, d, idx, kc, S, ldS, tiles);
+        hipLaunchKernelGGL((rerank_sq8_kernel<MI_RERANK_SQ8_NST>), dim3(grid), dim3(64), 0, st, wq, Aq, base, nb, d, idx, kc, S, ldS, tiles);
         MI_HIP(hipGetLastError());
         return;
     }
