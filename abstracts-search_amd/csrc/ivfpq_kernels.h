@@ -2824,25 +2824,49 @@ __global__ void __launch_bounds__(256) topk_rows_kernel(const float *__restrict_
         id[j] = t;
         key[j] = (c < kc && t >= 0 && v == v) ? f2o(v) : 0u;
     }
-    for (int r = 0; r < k; ++r) {
-        // this round's best under (key desc, id asc, position asc): the position only separates a caller's duplicate ids
-        unsigned bk = 0u;
-        long long bi = 0x7fffffffffffffffll;
-        int bp = 0x7fffffff;
+    // a thread's best under (key desc, id asc, position asc) is kept between the rounds: only the thread whose entry left
+    // looks at its VPT_ values again (every thread rescanning every round was 20 three-word compares x 10 rounds x 16 waves
+    // a CU: the kernel was VALU-bound at 43 us for 1024 x 4 640, three times its bytes' time)
+    unsigned lk;
+    long long li;
+    int lp;
+    auto rescan = [&]() {
+        lk = 0u;
+        li = 0x7fffffffffffffffll;
+        lp = 0x7fffffff;
 #pragma unroll
         for (int j = 0; j < VPT_; ++j) {
-            const bool better = key[j] > bk || (key[j] == bk && key[j] != 0u && id[j] < bi);   // (positions ascend with j)
-            if (better) { bk = key[j]; bi = id[j]; bp = j * 256 + tid; }
+            const bool better = key[j] > lk || (key[j] == lk && key[j] != 0u && id[j] < li);   // (positions ascend with j)
+            if (better) { lk = key[j]; li = id[j]; lp = j * 256 + tid; }
         }
+    };
+    rescan();
+    for (int r = 0; r < k; ++r) {
+        unsigned bk = lk;
+        long long bi = li;
+        int bp = lp;
         auto take = [&](unsigned ok, long long oi, int op) {
             if (ok > bk || (ok == bk && (oi < bi || (oi == bi && op < bp)))) { bk = ok; bi = oi; bp = op; }
         };
+        // the wave's best: the largest key alone decides unless two lanes hold it (tied exact scores: rare) -- one word
+        // through the butterfly, the winner's id and position read from its lane
+        unsigned mk = lk;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned ok = (unsigned)__shfl_xor((int)bk, off);
-            const long long oi = ((long long)__shfl_xor((int)(bi >> 32), off) << 32) | (unsigned)__shfl_xor((int)bi, off);
-            const int op = __shfl_xor(bp, off);
-            take(ok, oi, op);
+        for (int off = 32; off > 0; off >>= 1) mk = max(mk, (unsigned)__shfl_xor((int)mk, off));
+        const unsigned long long tie = __ballot(lk == mk);
+        if (__popcll(tie) == 1) {                                // (wave-uniform)
+            const int src = (int)__ffsll((long long)tie) - 1;
+            bk = mk;
+            bi = ((long long)__builtin_amdgcn_readlane((int)(li >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)li, src);
+            bp = __builtin_amdgcn_readlane(lp, src);
+        } else {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned ok = (unsigned)__shfl_xor((int)bk, off);
+                const long long oi = ((long long)__shfl_xor((int)(bi >> 32), off) << 32) | (unsigned)__shfl_xor((int)bi, off);
+                const int op = __shfl_xor(bp, off);
+                take(ok, oi, op);
+            }
         }
         if (lane == 0) { wk[r & 1][w] = bk; wi[r & 1][w] = bi; wp[r & 1][w] = bp; }
         __syncthreads();
@@ -2857,6 +2881,7 @@ __global__ void __launch_bounds__(256) topk_rows_kernel(const float *__restrict_
 #pragma unroll
             for (int j = 0; j < VPT_; ++j)
                 if (j == (bp >> 8)) key[j] = 0u;             // the winner leaves
+            rescan();
         }
     }
 }
