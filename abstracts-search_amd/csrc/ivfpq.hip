@@ -52,6 +52,10 @@ struct Knobs {
     bool no_sliced_select;   // MI_NO_SLICED_SELECT=1: one workgroup per row for a few long rows too
     bool no_topk_rows;    // MI_NO_TOPK_ROWS=1: the re-rank's final top-k through the general merge
     bool scan_ts;         // MI_SCAN_TS=1: mi_index_profile_scan prints in-kernel phase stamps
+    bool scan_prune;      // MI_SCAN_PRUNE=0: no exact list pruning (every probed list is scanned, as faiss does)
+    int prune_mode;       // MI_SCAN_PRUNE_MODE=1: the two-phase form only; 2: the in-kernel early stop only (0: early stop where it applies, else two phases)
+    int prune_p1;         // MI_SCAN_PRUNE_P1: lists per query scanned before the others are tested (0: nprobe / 32, 1..8)
+    int64_t prune_min_groups;   // MI_SCAN_PRUNE_MIN_GROUPS: smallest scan (64-code groups of all probed lists of the call) that is pruned
     void load() {
         auto num = [](const char *n, int dflt) { const char *e = std::getenv(n); return e && *e ? std::atoi(e) : dflt; };
         auto set = [](const char *n) { return std::getenv(n) != nullptr; };
@@ -67,6 +71,10 @@ struct Knobs {
         no_topk_rows = set("MI_NO_TOPK_ROWS");
         no_sliced_select = set("MI_NO_SLICED_SELECT");
         scan_ts = set("MI_SCAN_TS");
+        scan_prune = num("MI_SCAN_PRUNE", 1) != 0;
+        prune_mode = num("MI_SCAN_PRUNE_MODE", 0);
+        prune_p1 = num("MI_SCAN_PRUNE_P1", 0);
+        prune_min_groups = num("MI_SCAN_PRUNE_MIN_GROUPS", 200000);
     }
 };
 Knobs &knobs_mut() {
@@ -562,6 +570,7 @@ struct SearchWS {
     std::mutex mu;   // held by the one call that is enqueuing work through this set (two host threads on one stream take turns)
     DevBuf selsc;   // the sliced selection's per-slice results (launch_select)
     DevBuf q, scores, cidx, cdis, lut, ps, pid, bs, bid, D, I, pgoff, plen, pprefix, counters, all_s, all_id, q16, qscale, rstats, qaug, qn, cscan;
+    DevBuf plen1, ppre1, plen2, ppre2, comb_s, comb_id, pruneA;   // exact list pruning: the two phases' probe tables, their results side by side; the early stop's A[q]
     size_t counters_zeroed = 0;  // bytes of `counters` known to be zero
     // most recent scan launch on this stream (mi_index_profile_scan replays it)
     ScanArgs last_scan{};
@@ -610,6 +619,9 @@ struct mi_index {
     std::mutex mu;
     // add()/encode() workspaces
     DevBuf ws_scores, ws_x, ws_assign, ws_codes, ws_ids, ws_count, ws_x16, ws_xscale, ws_rstats;
+    // exact list pruning (search_chunk): {groups scanned, groups of all probed lists, queries} summed over the pruned calls
+    DevBuf prune_stats;
+    bool prune_stats_ok = false;
 
     int nch() const { return (M + 15) / 16; }
 };
@@ -1191,15 +1203,17 @@ int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_a
         unsigned long long *cnt = h->ws_count.as<unsigned long long>(1);
         MI_HIP(hipMemsetAsync(cnt, 0, 8, st));
         const int64_t n = w.last_nq * w.last_nprobe;
-        hipLaunchKernelGGL(count_codes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           w.cidx.get<int32_t>(), n, h->d_len.get<int32_t>(), cnt);
+        // (the launch's own table of list lengths: a pruned search replays its first phase, whose other probes have length 0)
+        hipLaunchKernelGGL(sum_len_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.last_scan.p_len, n, cnt);
         MI_HIP(hipGetLastError());
         hipEvent_t e0, e1;
         MI_HIP(hipEventCreate(&e0));
         MI_HIP(hipEventCreate(&e1));
-        launch_scan(h->M, w.last_scan, st);  // warm
+        ScanArgs replay = w.last_scan;
+        replay.prune_stats = nullptr;        // (the replays are not searches)
+        launch_scan(h->M, replay, st);  // warm
         MI_HIP(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) launch_scan(h->M, w.last_scan, st);
+        for (int i = 0; i < reps; ++i) launch_scan(h->M, replay, st);
         MI_HIP(hipEventRecord(e1, st));
         MI_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -1213,7 +1227,7 @@ int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_a
             DevBuf tsb;
             unsigned long long *dts = tsb.as<unsigned long long>(nb * SCAN_TS);
             MI_HIP(hipMemsetAsync(dts, 0, nb * SCAN_TS * 8, st));
-            ScanArgs sa = w.last_scan;
+            ScanArgs sa = replay;
             sa.ts = dts;
             launch_scan(h->M, sa, st);
             std::vector<unsigned long long> hts(nb * SCAN_TS);
@@ -1246,8 +1260,34 @@ int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_a
         }
         unsigned long long c = 0;
         MI_HIP(hipMemcpy(&c, cnt, 8, hipMemcpyDeviceToHost));
+        if (replay.prune_A) {
+            // an early-stop launch reads only the groups its waves reach: counted by one more replay (whole 64-code groups)
+            DevBuf tmp;
+            unsigned long long *t3 = tmp.as<unsigned long long>(3);
+            MI_HIP(hipMemsetAsync(t3, 0, 24, st));
+            ScanArgs sa = replay;
+            sa.prune_stats = t3;
+            launch_scan(h->M, sa, st);
+            MI_HIP(hipStreamSynchronize(st));
+            unsigned long long g3[3] = {0, 0, 0};
+            MI_HIP(hipMemcpy(g3, t3, 24, hipMemcpyDeviceToHost));
+            c = std::min<unsigned long long>(c, g3[0] * 64ull);
+        }
         if (scan_ms_avg) *scan_ms_avg = (double)ms / reps;
         if (scan_bytes) *scan_bytes = (int64_t)c * (h->M + 8);
+    });
+}
+
+int mi_index_prune_stats(mi_index *h, unsigned long long *out3, int reset) {
+    return guard([&] {
+        MI_REQUIRE(h && out3, "bad argument");
+        DeviceGuard dg(h->device);
+        std::lock_guard<std::mutex> hl(h->mu);
+        out3[0] = out3[1] = out3[2] = 0;
+        if (!h->prune_stats_ok) return;
+        MI_HIP(hipDeviceSynchronize());
+        MI_HIP(hipMemcpy(out3, h->prune_stats.p, 24, hipMemcpyDeviceToHost));
+        if (reset) MI_HIP(hipMemset(h->prune_stats.p, 0, 24));
     });
 }
 
@@ -1353,7 +1393,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     stage.reset();
     stage = std::make_unique<Range>("mi_ivfpq:scan+topk");
 
-    const int nslice = choose_nslice(h, nq, nprobe, std::min(k, 64));
+    int nslice = choose_nslice(h, nq, nprobe, std::min(k, 64));
     const int npass = (k + 63) / 64;
     float *ps = w.ps.as<float>((size_t)nq * nslice * 64);
     int64_t *pid = w.pid.as<int64_t>((size_t)nq * nslice * 64);
@@ -1438,6 +1478,94 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         l2_finish();
         return;
     }
+    // ---- exact list pruning, two forms (ivfpq_kernels.h, above prune_tables_kernel).  By-residual inner product, k <= 64:
+    //  - early stop inside the scan kernel: the lists of a query come in descending coarse order, so do their bounds; a wave
+    //    stops at the first list whose bound is below a threshold it holds.  One launch more (lut_maxsum_kernel, ~5 us);
+    //    nprobe <= 64 (the probe tables in registers), lists from the library's own coarse quantiser (sorted);
+    //  - two phases (prune_tables_kernel): the P1 best lists of every query first, then only the lists whose bound reaches the
+    //    k-th score found there -- any nprobe, any list order, a threshold shared by all slices of a query; two more small
+    //    launches, a second scan launch and a merge: for scans large enough to pay for them (a query batch, not a query).
+    const double avg_groups_pr = h->nlist > 0 ? (double)h->ngroups / h->nlist : 0.0;
+    const bool prunable = knobs().scan_prune && !l2 && h->by_residual && npass == 1 && M <= 128;
+    // (a query's slices each hold their own thresholds, and only the first has the best lists: the early stop wants ONE workgroup
+    // per query -- batches that fill the chip that way; smaller ones take the two phases, whose threshold all slices share)
+    const bool early = prunable && knobs().prune_mode != 1 && nprobe <= 64 && !pre_I &&
+                       (knobs().prune_mode == 2 || (nq >= 512 && avg_groups_pr * nprobe * (double)nq >= 4096.0));
+    if (early && knobs().nslice <= 0 && nslice > 1) {
+        nslice = 1;
+        ps = w.ps.as<float>((size_t)nq * nslice * 64);
+        pid = w.pid.as<int64_t>((size_t)nq * nslice * 64);
+    }
+    unsigned long long *pstats = nullptr;
+    if (prunable) {
+        std::lock_guard<std::mutex> hl(h->mu);
+        pstats = h->prune_stats.as<unsigned long long>(3);
+        if (!h->prune_stats_ok) {
+            MI_HIP(hipMemsetAsync(pstats, 0, 24, st));
+            MI_HIP(hipStreamSynchronize(st));
+            h->prune_stats_ok = true;
+        }
+    }
+    float *pruneA = nullptr;
+    if (early) {
+        pruneA = w.pruneA.as<float>((size_t)nq);
+        hipLaunchKernelGGL(lut_maxsum_kernel, dim3((unsigned)nq), dim3(256), 0, st, lut, M, pruneA);
+        MI_HIP(hipGetLastError());
+    }
+    {
+        const bool prune = prunable && !early && knobs().prune_mode != 2 && nprobe >= 8 && Ddev &&
+                           avg_groups_pr * nprobe * (double)nq >= (double)knobs().prune_min_groups;
+        if (prune) {
+            const int kp = k;
+            const int P1 = std::max(1, std::min(knobs().prune_p1 > 0 ? knobs().prune_p1 : std::min(8, nprobe / 32), nprobe - 1));
+            unsigned long long *stats = pstats;
+            float *comb_s = w.comb_s.as<float>((size_t)nq * 2 * kp);
+            int64_t *comb_id = w.comb_id.as<int64_t>((size_t)nq * 2 * kp);
+            int32_t *len_ph[2] = {w.plen1.as<int32_t>((size_t)nq * nprobe), w.plen2.as<int32_t>((size_t)nq * nprobe)};
+            int32_t *pre_ph[2] = {w.ppre1.as<int32_t>((size_t)nq * (nprobe + 1)), w.ppre2.as<int32_t>((size_t)nq * (nprobe + 1))};
+            const int ns_ph[2] = {choose_nslice(h, nq, P1, kp), choose_nslice(h, nq, std::max(1, (nprobe - P1) / 8), kp)};
+            const int ns_max = std::max(ns_ph[0], ns_ph[1]);
+            float *pps = w.ps.as<float>((size_t)nq * ns_max * 64);
+            int64_t *ppid = w.pid.as<int64_t>((size_t)nq * ns_max * 64);
+            for (int ph = 0; ph < 2; ++ph) {
+                PruneArgs pa{};
+                pa.lut = lut; pa.coarse_dis = cscan; pa.p_len = pt.p_len; pa.p_prefix = pt.p_prefix;
+                pa.t_s = comb_s; pa.t_id = comb_id; pa.ld_t = 2 * kp; pa.k = kp; pa.nprobe = nprobe; pa.P1 = P1; pa.M = M; pa.mode = ph;
+                pa.len_out = len_ph[ph]; pa.prefix_out = pre_ph[ph]; pa.stats = ph ? stats : nullptr;
+                hipLaunchKernelGGL(prune_tables_kernel, dim3((unsigned)nq), dim3(256), 0, st, pa);
+                MI_HIP(hipGetLastError());
+                ScanArgs a{};
+                a.lut = lut; a.coarse_dis = cscan;
+                a.p_goff = pt.p_goff; a.p_len = len_ph[ph]; a.p_prefix = pre_ph[ph];
+                a.codes = h->d_codes.get<uint8_t>(); a.ids = h->d_ids.get<int64_t>();
+                a.part_s = pps; a.part_id = ppid;
+                a.nq = (int)nq; a.nprobe = nprobe; a.nslice = ns_ph[ph]; a.k = kp; a.by_residual = 1;
+                a.nw = 8;
+                if (knobs().scan_nw) a.nw = knobs().scan_nw == 16 ? 16 : 8;
+                const bool fuse = scan_fused_merge_bytes(a.nslice, kp) <= scan_lut_bytes(M, a.nw) && !knobs().no_fused_merge;
+                a.D = comb_s; a.I = comb_id; a.ldo = 2 * kp; a.out_off = ph * kp;
+                if (fuse) {
+                    unsigned *cnt = w.counters.as<unsigned>((size_t)nq);
+                    if (w.counters_zeroed < w.counters.cap) {
+                        MI_HIP(hipMemsetAsync(w.counters.p, 0, w.counters.cap, st));
+                        w.counters_zeroed = w.counters.cap;
+                    }
+                    a.counters = cnt;
+                }
+                launch_scan(M, a, st);
+                if (ph == 0) {
+                    w.last_scan = a;
+                    w.have_last_scan = true;
+                    w.last_nq = nq;
+                    w.last_nprobe = nprobe;
+                }
+                if (!fuse)
+                    launch_merge(pps, ppid, a.nslice, kp, (int64_t)a.nslice * kp, nq, kp, comb_s, comb_id, 2 * kp, ph * kp, nullptr, nullptr, st);
+            }
+            launch_merge(comb_s, comb_id, 2, kp, (int64_t)2 * kp, nq, kp, Ddev, Idev, k, 0, nullptr, nullptr, st);
+            return;
+        }
+    }
     for (int pass = 0; pass < npass; ++pass) {
         const int kp = std::min(64, k - pass * 64);
         ScanArgs a{};
@@ -1457,6 +1585,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
                           !knobs().no_fused_merge;
         a.counters = nullptr; a.D = Ddev; a.I = Idev; a.ldo = k; a.out_off = pass * 64;
         a.next_bound_s = npass > 1 ? bs : nullptr; a.next_bound_id = npass > 1 ? bid : nullptr;
+        a.prune_A = pruneA; a.prune_stats = pruneA ? pstats : nullptr;
         if (fuse) {
             const size_t cb = (size_t)nq * sizeof(unsigned);
             unsigned *cnt = w.counters.as<unsigned>((size_t)nq);

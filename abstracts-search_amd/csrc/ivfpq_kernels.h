@@ -2097,6 +2097,11 @@ struct ScanArgs {
     float *all_s;              // [nq][all_ld]
     int64_t *all_id;           // [nq][all_ld]
     int64_t all_ld;
+    // exact early stop (top-k mode, nprobe <= 64, lists in descending coarse order): prune_A[q] = the chain of the query's
+    // table-row maxima (lut_maxsum_kernel), so that lane p's U = dis0[p] + A bounds every code of probe p; a wave stops at the
+    // first list whose U is below a threshold it already holds (see "Exact list pruning" above prune_tables_kernel)
+    const float *prune_A;      // [nq] or null
+    unsigned long long *prune_stats;   // null, or [3] += {groups processed, groups of all probes, queries}
 };
 
 // LDS bytes the fused final merge needs inside the LUT region
@@ -2310,6 +2315,10 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // LDS tables visible (also drains the LUT DMA)
     }
+    // exact early stop: lane p's upper bound of every score of probe p (+inf: never below a threshold)
+    const bool early_stop = !ALL && !L2 && reg_tab && a.prune_A != nullptr && a.by_residual;
+    float r_U = __builtin_inff();
+    if (early_stop) r_U = r_dis + a.prune_A[q];
     // 64 < nprobe <= 256: the group -> probe search still runs on registers (lane p keeps
     // prefix[p+1], [p+65], [p+129], [p+193]: four ballots), only the four table values of
     // the located probe come from LDS, as independent reads.  The sequential walk with one
@@ -2337,6 +2346,8 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
 
     int cnt = 0;
     float thr = MI_NEG_INF;
+    float wthr_seen = MI_NEG_INF;   // the workgroup's threshold as this wave last read it
+    int my_end = end;               // early stop: the first group of a list that cannot hold a result (the lists' bounds descend)
 
     // work items = 64-code groups [beg, end), dealt round-robin to the waves.  (Taking them from a workgroup counter instead --
     // the waves of a slice finish up to 60 k cycles apart and the tail's barrier waits for the slowest -- removes that wait and
@@ -2365,6 +2376,10 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         if (reg_tab) {
             // probes whose group range ends at or before tt: prefix is non-decreasing
             const int pp = __popcll(__ballot(lane < nprobe && r_pre1 <= tt));
+            if (early_stop && readlane_f(r_U, pp) < fmaxf(thr, wthr_seen)) {   // (wave-uniform) k scores above this list's bound are held already
+                my_end = tt;
+                return;
+            }
             gi = tt - __builtin_amdgcn_readlane(r_pre0, pp);
             gg = __builtin_amdgcn_readlane(r_goff, pp) + gi;
             g.nvalid = min(64, __builtin_amdgcn_readlane(r_len, pp) - gi * 64);
@@ -2435,6 +2450,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         if (n_proc == 2) stamp(18);
 
         const float wthr = o2f(__hip_atomic_load(wg_thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        wthr_seen = wthr;
         const float thr_eff = fmaxf(thr, wthr);
         bool pf = (lane < g.nvalid) && (s >= thr_eff);
         if (has_bound) pf = pf && (s < bs || (s == bs && g.id > bid));
@@ -2467,20 +2483,28 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         ++n_proc;
     };
     Group g0{}, g1{};
-    if (t < end) locate_and_load(t, g0);
-    if (t + SCAN_NW < end) locate_and_load(t + SCAN_NW, g1);
+    if (t < my_end) locate_and_load(t, g0);
+    if (t + SCAN_NW < my_end) locate_and_load(t + SCAN_NW, g1);
     stamp(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own LUT rows (DMA) and the first code groups
     __syncthreads();  // every wave's LUT rows are in LDS
     stamp(2);
-    while (t < end) {
-        process(g0, t + SCAN_NW < end);
-        if (t + 2 * SCAN_NW < end) locate_and_load(t + 2 * SCAN_NW, g0);
+    // (my_end only ever moves to a group that was not requested yet: `more` below is decided when the next group was requested)
+    while (t < my_end) {
+        process(g0, t + SCAN_NW < my_end);
+        if (t + 2 * SCAN_NW < my_end) locate_and_load(t + 2 * SCAN_NW, g0);
         t += SCAN_NW;
-        if (t >= end) break;
-        process(g1, t + SCAN_NW < end);
-        if (t + 2 * SCAN_NW < end) locate_and_load(t + 2 * SCAN_NW, g1);
+        if (t >= my_end) break;
+        process(g1, t + SCAN_NW < my_end);
+        if (t + 2 * SCAN_NW < my_end) locate_and_load(t + 2 * SCAN_NW, g1);
         t += SCAN_NW;
+    }
+    if (!ALL && a.prune_stats) {
+        if (lane == 0 && n_proc) atomicAdd(a.prune_stats, (unsigned long long)n_proc);
+        if (tid == 0 && slice == 0) {
+            atomicAdd(a.prune_stats + 1, (unsigned long long)G);
+            atomicAdd(a.prune_stats + 2, 1ull);
+        }
     }
 
     if constexpr (ALL) return;
@@ -3040,19 +3064,137 @@ __global__ void __launch_bounds__(256)
     codes[(size_t)v * M + m] = (uint8_t)best;
 }
 
-// Σ over (q, probe) of the probed list lengths (profiling only).
-__global__ void count_codes_kernel(const int32_t *__restrict__ coarse_idx, int64_t n,
-                                   const int32_t *__restrict__ list_len,
-                                   unsigned long long *__restrict__ out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long v = 0;
-    if (i < n) {
-        int l = coarse_idx[i];
-        if (l >= 0) v = (unsigned long long)list_len[l];
+// ---------------------------------------------------------------------
+// Exact list pruning for a by-residual inner-product scan (large batches: ivfpq.hip, search_chunk).
+//
+// A code's score is s = dis0 + acc, acc = the f32 chain 0 + LUT[0][c_0] + LUT[1][c_1] + ... (m ascending), dis0 = <q, centroid>
+// of its list.  With mx_m = max_c LUT[m][c] and A = the SAME chain over the maxima, rounded addition being monotone in both
+// operands gives acc <= A and s <= U = fl(dis0 + A) for EVERY code of the list, in floating point, with no slack term.  So once
+// k scores >= T are known for the query (phase 1: the scan of its P1 best lists), a list with U < T cannot hold a result --
+// its codes are all strictly below the final k-th best (>= T), ties included -- and phase 2 scans only the lists that remain.
+// Results are bit-identical to the exhaustive scan; how much goes depends on the data (clustered corpora: the residual
+// tables are small against the spread of the coarse scores, and ~15 of 16 probed lists go).
+//
+// mode 0: the probe tables of phase 1 (probes [0, P1) keep their length, the others get length 0 and no groups);
+// mode 1: those of phase 2 (probes >= P1 that survive U >= T; T = the k-th result of phase 1, -inf when it found fewer).
+// One 256-thread workgroup per query; the group counts come from the full prefix table (a list's groups, not its length / 64).
+// ---------------------------------------------------------------------
+struct PruneArgs {
+    const float *lut;          // [nq][M*256]           (mode 1)
+    const float *coarse_dis;   // [nq][nprobe]          (mode 1)
+    const int32_t *p_len;      // [nq][nprobe]   full tables, in
+    const int32_t *p_prefix;   // [nq][nprobe+1]
+    const float *t_s;          // [nq][ld_t]: phase 1's results (mode 1); T = t_s[q][k-1] if t_id[q][k-1] >= 0
+    const int64_t *t_id;
+    int64_t ld_t;
+    int k, nprobe, P1, M, mode;
+    int32_t *len_out;          // [nq][nprobe]
+    int32_t *prefix_out;       // [nq][nprobe+1]
+    unsigned long long *stats; // null, or [3] += {groups this phase scans, groups of all probes, queries}
+};
+
+__global__ void __launch_bounds__(256) prune_tables_kernel(PruneArgs a) {
+    __shared__ float s_mx[128];
+    __shared__ int wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t q = blockIdx.x;
+    const int K = a.nprobe;
+    float A = 0.f, T = MI_NEG_INF;
+    if (a.mode == 1) {
+        // four threads per LUT row, 64 entries each, every load of a thread issued before the first is used (a wave per row,
+        // row after row, was 16 dependent round trips: 53 us of a 0.5 ms step)
+        for (int m0 = 0; m0 < a.M; m0 += 64) {
+            const int m = m0 + (tid >> 2);
+            float4 v[16];
+            if (m < a.M) {
+                const float4 *row = reinterpret_cast<const float4 *>(a.lut + ((size_t)q * a.M + m) * 256) + (tid & 3) * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = row[i];
+            }
+            float x = MI_NEG_INF;
+            if (m < a.M) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x = fmaxf(x, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+            }
+            x = fmaxf(x, __shfl_xor(x, 1));
+            x = fmaxf(x, __shfl_xor(x, 2));
+            if (m < a.M && (tid & 3) == 0) s_mx[m] = x;
+        }
+        __syncthreads();
+        for (int m = 0; m < a.M; ++m) A += s_mx[m];          // the scan's chain (0 + ..., m ascending) over the maxima
+        if (a.t_id[q * a.ld_t + a.k - 1] >= 0) T = a.t_s[q * a.ld_t + a.k - 1];
     }
+    auto groups_kept = [&](int p) -> int {
+        bool keep;
+        if (a.mode == 0) keep = p < a.P1;
+        else keep = p >= a.P1 && !(a.coarse_dis[q * K + p] + A < T);      // U < T: nothing in this list can be a result
+        return keep ? a.p_prefix[q * (K + 1) + p + 1] - a.p_prefix[q * (K + 1) + p] : -1;
+    };
+    const int per = (K + 255) / 256, b = tid * per;
+    int sum = 0;
+    for (int i = 0; i < per; ++i)
+        if (b + i < K) sum += max(groups_kept(b + i), 0);
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int ww = 0; ww < w; ++ww) run += wtot[ww];
+    for (int i = 0; i < per; ++i)
+        if (b + i < K) {
+            const int p = b + i, g = groups_kept(p);
+            a.len_out[q * K + p] = g >= 0 ? a.p_len[q * K + p] : 0;
+            a.prefix_out[q * (K + 1) + p] = run;
+            run += max(g, 0);
+            if (p == K - 1) a.prefix_out[q * (K + 1) + K] = run;
+        }
+    if (a.stats && tid == 0) {
+        atomicAdd(a.stats, (unsigned long long)(wtot[0] + wtot[1] + wtot[2] + wtot[3]));
+        atomicAdd(a.stats + 1, (unsigned long long)a.p_prefix[q * (K + 1) + K]);
+        atomicAdd(a.stats + 2, 1ull);
+    }
+}
+
+// A[q] = the scan's chain (0 + ..., m ascending) over the row maxima of the query's look-up tables: ScanArgs::prune_A
+__global__ void __launch_bounds__(256) lut_maxsum_kernel(const float *__restrict__ lut, int M, float *__restrict__ A) {
+    __shared__ float s_mx[128];
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    for (int m0 = 0; m0 < M; m0 += 64) {
+        const int m = m0 + (tid >> 2);
+        float x = MI_NEG_INF;
+        if (m < M) {
+            const float4 *row = reinterpret_cast<const float4 *>(lut + ((size_t)q * M + m) * 256) + (tid & 3) * 16;
+            float4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = row[i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x = fmaxf(x, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+        }
+        x = fmaxf(x, __shfl_xor(x, 1));
+        x = fmaxf(x, __shfl_xor(x, 2));
+        if (m < M && (tid & 3) == 0) s_mx[m] = x;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc += s_mx[m];
+        A[q] = acc;
+    }
+}
+
+// Σ of a table of list lengths (profiling only: the codes a scan launch reads)
+__global__ void sum_len_kernel(const int32_t *__restrict__ len, int64_t n, unsigned long long *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = i < n ? (unsigned long long)max(len[i], 0) : 0ull;
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
 }
+
 
 
 // ---------------------------------------------------------------------

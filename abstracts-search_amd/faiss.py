@@ -77,6 +77,7 @@ class _Lib:
                 "mi_index_search": [v, c_int64, v, c_int, c_int, v, v, v],
                 "mi_index_coarse_lut": [v, c_int64, v, c_int, v, v, v],
                 "mi_index_profile_scan": [v, c_int, v, POINTER(c_double), POINTER(c_int64)],
+                "mi_index_prune_stats": [v, v, c_int],
                 "mi_index_search_candidates": [v, c_int64, v, c_int, c_int, v, v],
                 "mi_index_coarse_slice": [v, c_int64, v, c_int, c_int, c_int, v, v, v],
                 "mi_index_search_preassigned": [v, c_int64, v, c_int, c_int, v, v, v, v, v],
@@ -757,6 +758,13 @@ class IndexIVFPQ:
         if self.metric_type == METRIC_L2:       # the library hands back -|q - c|^2; faiss reports squared distances
             cD = np.where(cI < 0, np.float32(np.finfo(np.float32).max), -cD)
         return cI, cD, lut
+
+    def prune_stats(self, reset: bool = False) -> dict:
+        """Exact list pruning (mi_ivfpq.h, mi_index_prune_stats): what the pruned searches since the last reset skipped."""
+        out = (ctypes.c_ulonglong * 3)()
+        _check(_Lib.get().mi_index_prune_stats(self._h, out, int(reset)))
+        g2, gall, nq = int(out[0]), int(out[1]), int(out[2])
+        return {"queries": nq, "groups_all_probes": gall, "groups_second_phase": g2}
 
     # -- scan-kernel timing (HIP events on the launch stream) ------------
     def profile_scan(self, reps: int = 50, stream: int | None = None):

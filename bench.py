@@ -549,8 +549,40 @@ def cfg4_workload(args, ctx):
             torch.cuda.synchronize()
 
     settle(step, args.settle_ms)
+    torch.cuda.synchronize()
+    index.prune_stats(reset=True)
     dt, blocks, t_issue = clock.measure(step, steps, warmup)
     qps = steps * batch * (world if replicas else 1) / dt
+    torch.cuda.synchronize()
+    pst = index.prune_stats(reset=True)
+
+    # ---- the same loop with the exact list pruning off (MI_SCAN_PRUNE=0): every probed list scanned, as faiss's
+    # IndexIVFPQ.search does -- the step the rounds before 6 timed, and the launch the scan kernel's roofline is quoted on
+    pruning, exhaustive = None, None
+    if pst["queries"] > 0 and not os.environ.get("BENCH_NO_EXHAUSTIVE"):   # (BENCH_NO_EXHAUSTIVE: kernel traces of the pruned step alone)
+        g_all, g_2 = pst["groups_all_probes"], pst["groups_second_phase"]
+        early = batch >= 512 and nprobe <= 64 and sharded is None and os.environ.get("MI_SCAN_PRUNE_MODE", "0") != "1"
+        pruning = {"exact": True, "form": "early stop inside the scan kernel (one workgroup per query)" if early else "two scan launches",
+                   "queries": pst["queries"], "groups_all_probes_per_query": round(g_all / pst["queries"], 1),
+                   ("groups_scanned_per_query" if early else "groups_second_launch_per_query"): round(g_2 / pst["queries"], 2),
+                   ("scanned_fraction" if early else "second_launch_fraction"): round(g_2 / max(1, g_all), 4),
+                   "what": "by-residual inner product: a code scores <q, centroid> + a chain of 64 table entries, so <q, centroid> + the same "
+                           "chain over the tables' row maxima bounds every code of a list (rounded addition is monotone: no slack term); a list "
+                           "whose bound is below a score k found codes already reach provably holds no result.  The lists of a query come in "
+                           "descending coarse order: a wave stops at the first such list (batches >= 512, nprobe <= 64), or -- caller-ordered "
+                           "lists, smaller batches -- a first launch scans the best lists and a second one only the lists that can still "
+                           "matter.  (D, I) are the exhaustive scan's bits (tests: test_exact_list_pruning_is_bit_identical; the whole index "
+                           "suite with the pruning forced on; parity_vs_oracle below runs on the pruned path).  How much goes depends on "
+                           "the data: this corpus is SURVEY 8(d)'s clustered one"}
+        os.environ["MI_SCAN_PRUNE"] = "0"
+        faiss.reload_env()
+        settle(step, args.settle_ms)
+        dt_x, blocks_x, _ = clock.measure(step, steps, warmup)
+        torch.cuda.synchronize()
+        exhaustive = {"queries_per_s": round(steps * batch * (world if replicas else 1) / dt_x, 1), "ms_per_step": round(dt_x / steps * 1e3, 5),
+                      "what": "MI_SCAN_PRUNE=0: the same K steps scanning all nprobe lists of every query"}
+        del os.environ["MI_SCAN_PRUNE"]
+        faiss.reload_env()
 
     # ---- the reference's own call shape, reported beside the metric and never as `value`: numpy queries in, numpy (D, I)
     # out through IndexIVFPQ.search, as a faiss caller writes it (the timed loop above hands over device tensors and keeps
@@ -584,9 +616,20 @@ def cfg4_workload(args, ctx):
     # ---- roofline of the dominant kernel (PQ-code scan): the library re-launches the scan of
     # the last step back to back between two HIP events recorded on the launch stream
     torch.cuda.synchronize()
+    prof_p1 = None
+    if exhaustive is not None:
+        # the pruned step's own first phase, then (knob off) the exhaustive launch the kernel's roofline is quoted on
+        index.search_into(my_q[0], k, Ds[0], Is[0], None, sptr[0])
+        prof_p1 = index.profile_scan(max(3, min(steps, 20)), sptr[0])
+        torch.cuda.synchronize()
+        os.environ["MI_SCAN_PRUNE"] = "0"
+        faiss.reload_env()
     index.search_into(my_q[0], k, Ds[0], Is[0], None, sptr[0])
     prof = index.profile_scan(max(3, min(steps, 20)), sptr[0])
     torch.cuda.synchronize()
+    if exhaustive is not None:
+        del os.environ["MI_SCAN_PRUNE"]
+        faiss.reload_env()
     scan_ms, scan_bytes = prof["scan_ms_avg"], prof["scan_bytes"]
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     pmc, traffic_src = committed_traffic("r06_cfg4_scan_pmc.json", lambda d: (N, nlist, batch, nprobe, k, nsh) == tuple(d["config"]))
@@ -602,6 +645,17 @@ def cfg4_workload(args, ctx):
                 "frac_of_bytes_moved": round(scan_bytes * 64 / 72 / (scan_ms * 1e-3) / 1e9 / 8000.0, 4) if scan_ms > 0 else None,
                 "bytes_moved_note": "64 B per code (ids are fetched for the <= 3 k survivors of a workgroup only): the kernel is bound by its "
                                     "LDS gather (64 table reads per code, random banks) at about this rate"}
+    if exhaustive is not None:
+        roofline["launch"] = ("the exhaustive launch (all nprobe lists of every query: `exhaustive_scan`) -- the kernel at the size SURVEY 8(d) prices; "
+                              "the timed step runs the same kernel on the lists that survive (`pruned_step_scan`)")
+        p1b, p1ms = prof_p1["scan_bytes"], prof_p1["scan_ms_avg"]
+        roofline["pruned_step_scan"] = {
+            "avg_launch_ms": round(p1ms, 5), "bytes_per_launch": int(p1b),
+            "achieved": round(p1b / (p1ms * 1e-3) / 1e9, 1) if p1ms > 0 else None, "unit": "GB/s",
+            "frac": round(p1b / (p1ms * 1e-3) / 1e9 / 8000.0, 4) if p1ms > 0 else None,
+            "note": "the (first) scan launch of the pruned step, one workgroup per query; bytes = the 64-code groups its waves reached x 72 B "
+                    "per code (device-counted); the 64 KiB table staging and the selection tail of a workgroup are spread over ~200 groups "
+                    "where a workgroup of the exhaustive launch has ~500"}
 
     # ---- recall >= 0.95 operating point: IVF-PQ proposes k * k_factor candidates, exact re-ranking
     at095 = None
@@ -662,7 +716,7 @@ def cfg4_workload(args, ctx):
                        "hbm_note": "after IndexIVFPQ.seal(): the append log the lists were built from is freed (an export / add rebuilds it from the scan image)"},
             "recall_at_10": None if recall is None else round(recall, 4),
             "recall_note": "against exact inner-product search over all %d rows, %d queries" % (N, batch),
-            "roofline": roofline, "host_io": host_io, "cpu_baseline": cpu, "parity_vs_oracle": parity,
+            "roofline": roofline, "pruning": pruning, "exhaustive_scan": exhaustive, "host_io": host_io, "cpu_baseline": cpu, "parity_vs_oracle": parity,
             "at_recall_095": at095, "step_split": split, "reference_oracles": reference_oracles(),
         }
         if emu:

@@ -175,6 +175,18 @@ int mi_index_search_preassigned(mi_index *h, int64_t nq, const float *q, int k, 
  * the algorithmic bytes of one launch (codes scanned x (M + 8)). */
 int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_avg,
                           int64_t *scan_bytes);
+/* Exact list pruning (replaces nothing in the reference: faiss's IndexIVFPQ::search scans every probed list; same (D, I)).
+ * A by-residual inner-product code scores <q, centroid> + the f32 chain of M table entries, so <q, centroid> + the same chain
+ * over the tables' row maxima bounds every code of a list (rounded addition is monotone: no slack term); a list whose bound is
+ * below a score that k found codes already reach provably holds no result.  mi_index_search uses it in two forms, k <= 64:
+ *  - batches of >= 512 queries, nprobe <= 64: inside the scan kernel -- one workgroup per query walks the lists in descending
+ *    coarse order and every wave stops at the first list whose bound is below a threshold it holds;
+ *  - other large scans (mi_index_search_preassigned's caller-ordered lists, nprobe > 64, 16..511 queries): two scan launches
+ *    -- the best nprobe/32 lists of every query, then only the lists whose bound reaches the k-th score found there.
+ * out3 = {64-code groups scanned (early stop) or scanned by the second launch (two phases), groups of all probed lists,
+ * queries}, summed over the pruned calls since the last reset.  MI_SCAN_PRUNE=0 turns the pruning off, MI_SCAN_PRUNE_MODE=1 / 2
+ * keeps one form (mi_ivfpq_reload_env).  mi_index_profile_scan replays the (first) scan launch of the last search. */
+int mi_index_prune_stats(mi_index *h, unsigned long long *out3, int reset);
 
 /* ---- exchange step ------------------------------------------------- */
 

@@ -804,6 +804,83 @@ def test_pretransform_apply_is_the_exact_gemm_and_the_file_round_trips(faiss, or
     assert np.array_equal(I, Ib) and np.array_equal(bits(D), bits(Db))
 
 
+@pytest.mark.parametrize("env", [{}, {"MI_SCAN_PRUNE_P1": "1"}, {"MI_SCAN_PRUNE_P1": "7"}, {"MI_NO_FUSED_MERGE": "1"}, {"MI_NSLICE": "3"},
+                                 {"MI_SCAN_PRUNE_MODE": "2"}, {"MI_SCAN_PRUNE_MODE": "2", "MI_NSLICE": "3"},
+                                 {"MI_SCAN_PRUNE_MODE": "2", "MI_NO_FUSED_MERGE": "1"}, {"MI_SCAN_PRUNE_MODE": "1"}])
+def test_exact_list_pruning_is_bit_identical(faiss, oracle, monkeypatch, env):
+    """Exact list pruning (mi_ivfpq.h: mi_index_prune_stats), both forms -- two scan launches (prune_tables_kernel: the best lists
+    of every query, then only the lists whose score bound reaches the k-th score found) and the early stop inside the scan
+    kernel (MI_SCAN_PRUNE_MODE=2 here: the default takes it from 512 queries up) -- must give the exhaustive scan's and the
+    oracle's bits, whatever P1, the merge route, the slicing or the probe-table path (nprobe <= 64, <= 256, > 256);
+    by_residual = False, k > 64 and METRIC_L2 keep the exhaustive scan.  The threshold that makes a batch 'large enough' for the
+    two launches is lowered to 0 here (the default only lets query batches through)."""
+    d, M, nlist, n, nq = 64, 8, 600, 24000, 37
+    cent, cb, x, q = random_problem(99, d, M, nlist, n, nq)
+    x[5000:5400] = x[5000]                                       # 400 identical vectors: ties at the cut, ids decide
+    idx = make_index(faiss, cent, cb)
+    idx.add(x)
+    flat = make_index(faiss, cent, cb, by_residual=False)
+    flat.add(x)
+    ln, codes = oracle.encode(x, cent, cb, True)
+    off, lc, li = oracle.build_lists(ln, codes, np.arange(n), nlist)
+    for nprobe, k in ((8, 1), (16, 10), (64, 10), (64, 64), (65, 10), (256, 10), (257, 33), (600, 64), (64, 100)):
+        idx.nprobe = flat.nprobe = nprobe
+        monkeypatch.setenv("MI_SCAN_PRUNE", "0")
+        D0, I0 = idx.search(q, k)
+        F0 = flat.search(q, k)
+        monkeypatch.setenv("MI_SCAN_PRUNE", "1")
+        monkeypatch.setenv("MI_SCAN_PRUNE_MIN_GROUPS", "0")
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        idx.prune_stats(reset=True)
+        D1, I1 = idx.search(q, k)
+        st = idx.prune_stats()
+        F1 = flat.search(q, k)
+        for key in list(env) + ["MI_SCAN_PRUNE_MIN_GROUPS"]:
+            monkeypatch.delenv(key)
+        assert np.array_equal(I0, I1), (env, nprobe, k, np.argwhere(I0 != I1)[:5])
+        assert np.array_equal(bits(D0), bits(D1)), (env, nprobe, k)
+        assert np.array_equal(F0[1], F1[1]) and np.array_equal(bits(F0[0]), bits(F1[0]))
+        De, Ie = oracle.search(q, cent, cb, off, lc, li, nprobe, k, True)
+        assert np.array_equal(I1, Ie) and np.array_equal(bits(D1), bits(De)), (env, nprobe, k)
+        mode = env.get("MI_SCAN_PRUNE_MODE", os.environ.get("MI_SCAN_PRUNE_MODE", "0"))
+        if k <= 64 and (mode != "2" or nprobe <= 64):   # (the early stop: probe tables in registers only)
+            # this corpus sits tightly around its centroids: nearly every list beyond the first few is provably out
+            assert st["queries"] == nq and 0 < st["groups_all_probes"], st
+            assert st["groups_second_phase"] <= st["groups_all_probes"], st
+            # (two launches; k = 64 > a list's 40 codes: the 64th score comes from another cluster and bounds little.  The early stop
+            # gives little HERE: a list is one group, a wave has a threshold after three and two more in flight)
+            if k <= 10 and nprobe >= 16 and mode != "2":
+                assert st["groups_second_phase"] < 0.5 * st["groups_all_probes"], (nprobe, k, st)
+        else:
+            assert st["queries"] == 0, st                        # k > 64: the all-scores path, not pruned
+    assert flat.prune_stats()["queries"] == 0                    # by_residual = False: dis0 = 0 for every list, nothing to bound
+    # the default dispatch of a large batch (>= 512 queries, nprobe <= 64): the early stop
+    if not env:
+        rng = np.random.default_rng(5)
+        qb = (x[rng.integers(0, n, 600)] + 0.05 * rng.standard_normal((600, d))).astype(np.float32)
+        idx.nprobe = 64
+        monkeypatch.setenv("MI_SCAN_PRUNE", "0")
+        Db0, Ib0 = idx.search(qb, 10)
+        monkeypatch.delenv("MI_SCAN_PRUNE")
+        idx.prune_stats(reset=True)
+        Db1, Ib1 = idx.search(qb, 10)
+        st = idx.prune_stats()
+        assert np.array_equal(Ib0, Ib1) and np.array_equal(bits(Db0), bits(Db1))
+        if os.environ.get("MI_SCAN_PRUNE_MODE", "0") == "0":     # (a run of the suite with one form forced: the dispatch differs)
+            assert st["queries"] == 600 and st["groups_second_phase"] < st["groups_all_probes"], st
+    # a query whose best lists hold fewer than k codes: no threshold, nothing pruned, same result
+    tiny = make_index(faiss, cent, cb)
+    tiny.add(x[:300])
+    tiny.nprobe = 64
+    monkeypatch.setenv("MI_SCAN_PRUNE", "0")
+    Dt0, It0 = tiny.search(q, 64)
+    monkeypatch.setenv("MI_SCAN_PRUNE", "1")
+    monkeypatch.setenv("MI_SCAN_PRUNE_MIN_GROUPS", "0")
+    Dt1, It1 = tiny.search(q, 64)
+    assert np.array_equal(It0, It1) and np.array_equal(bits(Dt0), bits(Dt1)) and (It1 == -1).any()
+
+
 @pytest.mark.parametrize("metric", ["ip", "l2"])
 def test_seal_frees_the_log_and_changes_nothing(faiss, tmp_path, metric):
     """IndexIVFPQ.seal() (mi_index_seal; bench.py calls it once the 207 M-vector index is filled: 16.6 GB of HBM back): searches
