@@ -1489,7 +1489,9 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     const bool prunable = knobs().scan_prune && !l2 && h->by_residual && npass == 1 && M <= 128;
     // (a query's slices each hold their own thresholds, and only the first has the best lists: the early stop wants ONE workgroup
     // per query -- batches that fill the chip that way; smaller ones take the two phases, whose threshold all slices share)
-    const bool early = prunable && knobs().prune_mode != 1 && nprobe <= 64 && !pre_I &&
+    // (caller-assigned lists -- mi_index_search_preassigned: ShardedIndex hands over the merged coarse result, in order -- are
+    // checked row by row on the device: a query whose lists are not in descending order is scanned in full)
+    const bool early = prunable && knobs().prune_mode != 1 && nprobe <= 64 &&
                        (knobs().prune_mode == 2 || (nq >= 512 && avg_groups_pr * nprobe * (double)nq >= 4096.0));
     if (early && knobs().nslice <= 0 && nslice > 1) {
         nslice = 1;
@@ -1507,10 +1509,16 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         }
     }
     float *pruneA = nullptr;
+    int32_t *prune_sorted = nullptr;
     if (early) {
-        pruneA = w.pruneA.as<float>((size_t)nq);
+        pruneA = w.pruneA.as<float>((size_t)nq * 2);
         hipLaunchKernelGGL(lut_maxsum_kernel, dim3((unsigned)nq), dim3(256), 0, st, lut, M, pruneA);
         MI_HIP(hipGetLastError());
+        if (pre_I) {
+            prune_sorted = reinterpret_cast<int32_t *>(pruneA + nq);
+            hipLaunchKernelGGL(rows_descending_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, cscan, nq, nprobe, prune_sorted);
+            MI_HIP(hipGetLastError());
+        }
     }
     {
         const bool prune = prunable && !early && knobs().prune_mode != 2 && nprobe >= 8 && Ddev &&
@@ -1585,7 +1593,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
                           !knobs().no_fused_merge;
         a.counters = nullptr; a.D = Ddev; a.I = Idev; a.ldo = k; a.out_off = pass * 64;
         a.next_bound_s = npass > 1 ? bs : nullptr; a.next_bound_id = npass > 1 ? bid : nullptr;
-        a.prune_A = pruneA; a.prune_stats = pruneA ? pstats : nullptr;
+        a.prune_A = pruneA; a.prune_sorted = prune_sorted; a.prune_stats = pruneA ? pstats : nullptr;
         if (fuse) {
             const size_t cb = (size_t)nq * sizeof(unsigned);
             unsigned *cnt = w.counters.as<unsigned>((size_t)nq);

@@ -2101,6 +2101,8 @@ struct ScanArgs {
     // table-row maxima (lut_maxsum_kernel), so that lane p's U = dis0[p] + A bounds every code of probe p; a wave stops at the
     // first list whose U is below a threshold it already holds (see "Exact list pruning" above prune_tables_kernel)
     const float *prune_A;      // [nq] or null
+    const int32_t *prune_sorted;   // null, or [nq]: 0 = this query's lists are NOT in descending coarse order (caller-assigned lists):
+                                   // no early stop for it
     unsigned long long *prune_stats;   // null, or [3] += {groups processed, groups of all probes, queries}
 };
 
@@ -2316,7 +2318,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         __syncthreads();   // LDS tables visible (also drains the LUT DMA)
     }
     // exact early stop: lane p's upper bound of every score of probe p (+inf: never below a threshold)
-    const bool early_stop = !ALL && !L2 && reg_tab && a.prune_A != nullptr && a.by_residual;
+    const bool early_stop = !ALL && !L2 && reg_tab && a.prune_A != nullptr && a.by_residual && (!a.prune_sorted || a.prune_sorted[q] != 0);
     float r_U = __builtin_inff();
     if (early_stop) r_U = r_dis + a.prune_A[q];
     // 64 < nprobe <= 256: the group -> probe search still runs on registers (lane p keeps
@@ -3079,6 +3081,32 @@ __global__ void __launch_bounds__(256)
 // mode 1: those of phase 2 (probes >= P1 that survive U >= T; T = the k-th result of phase 1, -inf when it found fewer).
 // One 256-thread workgroup per query; the group counts come from the full prefix table (a list's groups, not its length / 64).
 // ---------------------------------------------------------------------
+// s_mx[m] = max_c LUT[q][m][c]: a wave per row and round (one coalesced KiB per instruction), every load of a thread issued before
+// the first is used; 256-thread workgroup, M <= 128.  Ends with a barrier.
+__device__ __forceinline__ void lut_row_maxima(const float *__restrict__ lutq, int M, float *s_mx) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int R = 16;                                  // rounds of 4 rows kept in flight together
+    for (int m0 = 0; m0 < M; m0 += 4 * R) {
+        float4 v[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int m = m0 + i * 4 + w;
+            if (m < M) v[i] = reinterpret_cast<const float4 *>(lutq + (size_t)m * 256)[lane];
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int m = m0 + i * 4 + w;
+            if (m < M) {                                   // (wave-uniform)
+                float x = fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w));
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off));
+                if (lane == 0) s_mx[m] = x;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 struct PruneArgs {
     const float *lut;          // [nq][M*256]           (mode 1)
     const float *coarse_dis;   // [nq][nprobe]          (mode 1)
@@ -3101,26 +3129,7 @@ __global__ void __launch_bounds__(256) prune_tables_kernel(PruneArgs a) {
     const int K = a.nprobe;
     float A = 0.f, T = MI_NEG_INF;
     if (a.mode == 1) {
-        // four threads per LUT row, 64 entries each, every load of a thread issued before the first is used (a wave per row,
-        // row after row, was 16 dependent round trips: 53 us of a 0.5 ms step)
-        for (int m0 = 0; m0 < a.M; m0 += 64) {
-            const int m = m0 + (tid >> 2);
-            float4 v[16];
-            if (m < a.M) {
-                const float4 *row = reinterpret_cast<const float4 *>(a.lut + ((size_t)q * a.M + m) * 256) + (tid & 3) * 16;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = row[i];
-            }
-            float x = MI_NEG_INF;
-            if (m < a.M) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) x = fmaxf(x, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
-            }
-            x = fmaxf(x, __shfl_xor(x, 1));
-            x = fmaxf(x, __shfl_xor(x, 2));
-            if (m < a.M && (tid & 3) == 0) s_mx[m] = x;
-        }
-        __syncthreads();
+        lut_row_maxima(a.lut + (size_t)q * a.M * 256, a.M, s_mx);
         for (int m = 0; m < a.M; ++m) A += s_mx[m];          // the scan's chain (0 + ..., m ascending) over the maxima
         if (a.t_id[q * a.ld_t + a.k - 1] >= 0) T = a.t_s[q * a.ld_t + a.k - 1];
     }
@@ -3164,27 +3173,23 @@ __global__ void __launch_bounds__(256) lut_maxsum_kernel(const float *__restrict
     __shared__ float s_mx[128];
     const int tid = threadIdx.x;
     const int64_t q = blockIdx.x;
-    for (int m0 = 0; m0 < M; m0 += 64) {
-        const int m = m0 + (tid >> 2);
-        float x = MI_NEG_INF;
-        if (m < M) {
-            const float4 *row = reinterpret_cast<const float4 *>(lut + ((size_t)q * M + m) * 256) + (tid & 3) * 16;
-            float4 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = row[i];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) x = fmaxf(x, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
-        }
-        x = fmaxf(x, __shfl_xor(x, 1));
-        x = fmaxf(x, __shfl_xor(x, 2));
-        if (m < M && (tid & 3) == 0) s_mx[m] = x;
-    }
-    __syncthreads();
+    lut_row_maxima(lut + (size_t)q * M * 256, M, s_mx);
     if (tid == 0) {
         float acc = 0.f;
         for (int m = 0; m < M; ++m) acc += s_mx[m];
         A[q] = acc;
     }
+}
+
+// sorted[q] = 1 when the coarse scores of row q never ascend (caller-assigned lists: mi_index_search_preassigned); NaN = not sorted
+__global__ void __launch_bounds__(256) rows_descending_kernel(const float *__restrict__ dis, int64_t nq, int nprobe, int32_t *__restrict__ sorted) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const float *r = dis + q * nprobe;
+    int ok = 1;
+    for (int p = 1; p < nprobe; ++p) ok &= (r[p] <= r[p - 1]) ? 1 : 0;
+    if (nprobe > 0 && !(r[0] == r[0])) ok = 0;
+    sorted[q] = ok;
 }
 
 // Σ of a table of list lengths (profiling only: the codes a scan launch reads)

@@ -261,7 +261,7 @@ def main():
                          "nq*nprobe*12 bytes per rank, ~50 us; every rank then multiplies 1/N of the 65536 centroids). "
                          "Default: on from 4 ranks (a replicated coarse stage is 0.34 of a 0.65 ms step at N = 8), off below")
     ap.add_argument("--streams", type=int, default=None,
-                    help="HIP streams the steps are issued round-robin on (default: 2 cfg4, 4 cfg2)")
+                    help="HIP streams the steps are issued round-robin on (default: cfg4 4 on one GPU and 2 sharded, 4 cfg2)")
     args = ap.parse_args()
     if args.workload == "search":
         args.workload = "cfg2"
@@ -303,8 +303,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("BENCH_FORCE_SHARDED"):
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
+        for name, val in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(name, val)           # (one process playing a rank: whatever the launcher did not set)
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -516,7 +516,9 @@ def cfg4_workload(args, ctx):
     # batches are independent: 2 streams, also on the sharded path (the exchange of one batch and the coarse stage of
     # the next overlap the other's scan; ShardedIndex keeps a buffer set per stream, torch.distributed orders the
     # collectives by issue order on every rank).  BENCH_SHARD_STREAMS=1 issues the sharded steps on one stream.
-    S = max(1, 2 if args.streams is None else args.streams)
+    # (round 6: 4 on one GPU -- with the exact list pruning a step is four short stages of different bounds (MFMA GEMM, HBM-bound
+    # chains, LDS-bound scan): 2 / 3 / 4 streams 0.472 / 0.452 / 0.447 ms, profiles/r06_exact_list_pruning_ab.txt)
+    S = max(1, (4 if not use_shards else 2) if args.streams is None else args.streams)
     if sharded is not None:
         S = max(1, int(os.environ.get("BENCH_SHARD_STREAMS", "0")) or S)
         # (the native exchange keeps a buffer set per stream too -- mi_shards::Bufs -- and RCCL orders the collectives of one
@@ -561,7 +563,7 @@ def cfg4_workload(args, ctx):
     pruning, exhaustive = None, None
     if pst["queries"] > 0 and not os.environ.get("BENCH_NO_EXHAUSTIVE"):   # (BENCH_NO_EXHAUSTIVE: kernel traces of the pruned step alone)
         g_all, g_2 = pst["groups_all_probes"], pst["groups_second_phase"]
-        early = batch >= 512 and nprobe <= 64 and sharded is None and os.environ.get("MI_SCAN_PRUNE_MODE", "0") != "1"
+        early = batch >= 512 and nprobe <= 64 and os.environ.get("MI_SCAN_PRUNE_MODE", "0") != "1"
         pruning = {"exact": True, "form": "early stop inside the scan kernel (one workgroup per query)" if early else "two scan launches",
                    "queries": pst["queries"], "groups_all_probes_per_query": round(g_all / pst["queries"], 1),
                    ("groups_scanned_per_query" if early else "groups_second_launch_per_query"): round(g_2 / pst["queries"], 2),

@@ -869,6 +869,26 @@ def test_exact_list_pruning_is_bit_identical(faiss, oracle, monkeypatch, env):
         assert np.array_equal(Ib0, Ib1) and np.array_equal(bits(Db0), bits(Db1))
         if os.environ.get("MI_SCAN_PRUNE_MODE", "0") == "0":     # (a run of the suite with one form forced: the dispatch differs)
             assert st["queries"] == 600 and st["groups_second_phase"] < st["groups_all_probes"], st
+    # caller-assigned lists (search_preassigned): in coarse order the early stop runs, shuffled the per-row check turns it off --
+    # the same k best either way (and through the two launches when the early stop is not forced)
+    import torch
+    idx.nprobe = 33
+    Dn, In = idx.search(q, 10)
+    cI, cD, _ = idx.coarse_and_lut(q, 33, want_lut=False)
+    perm = np.random.default_rng(3).permutation(33)
+    qd = torch.from_numpy(q).cuda()
+    for force in ("2", None):
+        if force:
+            monkeypatch.setenv("MI_SCAN_PRUNE_MODE", force)
+        monkeypatch.setenv("MI_SCAN_PRUNE_MIN_GROUPS", "0")
+        for ci, cd in ((cI, cD), (cI[:, perm], cD[:, perm])):
+            idx.prune_stats(reset=True)
+            Dp, Ip = idx.search_preassigned(qd, 10, torch.from_numpy(np.ascontiguousarray(ci)).cuda(), torch.from_numpy(np.ascontiguousarray(cd)).cuda())
+            assert np.array_equal(Ip.cpu().numpy(), In) and np.array_equal(bits(Dp.cpu().numpy()), bits(Dn)), force
+            assert idx.prune_stats()["queries"] == nq
+        if force:
+            monkeypatch.delenv("MI_SCAN_PRUNE_MODE")
+        monkeypatch.delenv("MI_SCAN_PRUNE_MIN_GROUPS")
     # a query whose best lists hold fewer than k codes: no threshold, nothing pruned, same result
     tiny = make_index(faiss, cent, cb)
     tiny.add(x[:300])

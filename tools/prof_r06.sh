@@ -29,6 +29,11 @@ pmc() { # tag, counter, regex, command...
 for part in $parts; do case $part in
 cfg4)
   B="python $R/bench.py --no-encode --no-cpu-baseline --streams 1"
+  # the step as it runs by default (exact list pruning on; bench.py times the exhaustive step beside it): its kernels
+  stats cfg4_pruned $B --no-refine-point --no-recall
+  # everything below on the EXHAUSTIVE scan (MI_SCAN_PRUNE=0) -- the launch the scan kernel's roofline is quoted on: with the
+  # pruning on, the timed step's launches of the same kernel read a sixteenth of the lists and would share every mean
+  export MI_SCAN_PRUNE=0
   stats cfg4 $B
   # the refine point the run above chose (held-out batch): the counter passes pin the sweep to it
   KF=$(python -c "import json,sys; d=json.loads([l for l in open('$out/cfg4_under_stats.out') if l.startswith('{')][-1]); a=d['at_recall_095']; print(a['nprobe'], a['k_factor_rf'])")
@@ -36,7 +41,7 @@ cfg4)
   export BENCH_REFINE_NPROBES=$1 BENCH_REFINE_KFS=$2
   echo "refine point: nprobe $1 k_factor $2"
   for c in FETCH_SIZE WRITE_SIZE; do pmc cfg4 $c "scan_kernel|rerank_sq8|select_pairs" $B --no-recall --steps 10; done
-  unset BENCH_REFINE_NPROBES BENCH_REFINE_KFS ;;
+  unset BENCH_REFINE_NPROBES BENCH_REFINE_KFS MI_SCAN_PRUNE ;;
 b1)
   Q="python $R/tools/encode_b1.py 31 40 1"
   stats b1 $Q; timeout 300 $Q > $out/b1_plain.out 2>/dev/null
