@@ -4,6 +4,7 @@
 // device every entry point fails with an error.
 #include "../../include/mi_ivfpq.h"
 
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -620,8 +621,16 @@ struct mi_index {
     // add()/encode() workspaces
     DevBuf ws_scores, ws_x, ws_assign, ws_codes, ws_ids, ws_count, ws_x16, ws_xscale, ws_rstats;
     // exact list pruning (search_chunk): {groups scanned, groups of all probed lists, queries} summed over the pruned calls
+    // The device counters only grow; mi_index_prune_stats reports them against `prune_base` (its reset moves the base).  A copy
+    // lands in pinned host memory every few pruned calls, asynchronously: the NEXT calls read from it whether this index's data
+    // prunes at all -- when most of the probed groups are scanned anyway the early stop keeps the balanced slices of the
+    // exhaustive launch instead of one workgroup per query (no synchronisation on a search path; a stale or torn read only
+    // picks the other, equally exact, launch shape).
     DevBuf prune_stats;
     bool prune_stats_ok = false;
+    unsigned long long prune_base[3] = {0, 0, 0};
+    unsigned long long *prune_seen = nullptr;   // pinned, [3]
+    std::atomic<unsigned> prune_calls{0};
 
     int nch() const { return (M + 15) / 16; }
 };
@@ -944,6 +953,10 @@ int mi_index_destroy(mi_index *h) {
     return guard([&] {
         if (!h) return;
         DeviceGuard dg(h->device);
+        if (h->prune_seen) {
+            (void)hipDeviceSynchronize();      // an asynchronous copy of the counters may still be on its way
+            (void)hipHostFree(h->prune_seen);
+        }
         delete h;
     });
 }
@@ -1286,8 +1299,12 @@ int mi_index_prune_stats(mi_index *h, unsigned long long *out3, int reset) {
         out3[0] = out3[1] = out3[2] = 0;
         if (!h->prune_stats_ok) return;
         MI_HIP(hipDeviceSynchronize());
-        MI_HIP(hipMemcpy(out3, h->prune_stats.p, 24, hipMemcpyDeviceToHost));
-        if (reset) MI_HIP(hipMemset(h->prune_stats.p, 0, 24));
+        unsigned long long life[3];
+        MI_HIP(hipMemcpy(life, h->prune_stats.p, 24, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 3; ++i) {
+            out3[i] = life[i] - h->prune_base[i];
+            if (reset) h->prune_base[i] = life[i];
+        }
     });
 }
 
@@ -1488,16 +1505,12 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     const double avg_groups_pr = h->nlist > 0 ? (double)h->ngroups / h->nlist : 0.0;
     const bool prunable = knobs().scan_prune && !l2 && h->by_residual && npass == 1 && M <= 128;
     // (a query's slices each hold their own thresholds, and only the first has the best lists: the early stop wants ONE workgroup
-    // per query -- batches that fill the chip that way; smaller ones take the two phases, whose threshold all slices share)
+    // per query -- batches that fill the chip that way; smaller ones take the two phases, whose threshold all slices share.  One
+    // workgroup per query gives up the balanced rounds of the sliced launch: only while the index's earlier calls did prune)
     // (caller-assigned lists -- mi_index_search_preassigned: ShardedIndex hands over the merged coarse result, in order -- are
     // checked row by row on the device: a query whose lists are not in descending order is scanned in full)
     const bool early = prunable && knobs().prune_mode != 1 && nprobe <= 64 &&
                        (knobs().prune_mode == 2 || (nq >= 512 && avg_groups_pr * nprobe * (double)nq >= 4096.0));
-    if (early && knobs().nslice <= 0 && nslice > 1) {
-        nslice = 1;
-        ps = w.ps.as<float>((size_t)nq * nslice * 64);
-        pid = w.pid.as<int64_t>((size_t)nq * nslice * 64);
-    }
     unsigned long long *pstats = nullptr;
     if (prunable) {
         std::lock_guard<std::mutex> hl(h->mu);
@@ -1505,8 +1518,22 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         if (!h->prune_stats_ok) {
             MI_HIP(hipMemsetAsync(pstats, 0, 24, st));
             MI_HIP(hipStreamSynchronize(st));
+            MI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->prune_seen), 24, hipHostMallocDefault));
+            h->prune_seen[0] = h->prune_seen[1] = h->prune_seen[2] = 0;
             h->prune_stats_ok = true;
         }
+    }
+    // does this index's data prune?  (counters of earlier calls, as last copied to the host; nothing seen yet: assume it does)
+    bool prunes_well = true;
+    if (prunable && h->prune_seen) {
+        const unsigned long long g_scanned = reinterpret_cast<volatile unsigned long long *>(h->prune_seen)[0],
+                                 g_all = reinterpret_cast<volatile unsigned long long *>(h->prune_seen)[1];
+        if (g_all >= 100000 && g_scanned <= g_all) prunes_well = (double)g_scanned < 0.5 * (double)g_all;
+    }
+    if (early && knobs().nslice <= 0 && nslice > 1 && prunes_well) {
+        nslice = 1;
+        ps = w.ps.as<float>((size_t)nq * nslice * 64);
+        pid = w.pid.as<int64_t>((size_t)nq * nslice * 64);
     }
     float *pruneA = nullptr;
     int32_t *prune_sorted = nullptr;
@@ -1571,6 +1598,8 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
                     launch_merge(pps, ppid, a.nslice, kp, (int64_t)a.nslice * kp, nq, kp, comb_s, comb_id, 2 * kp, ph * kp, nullptr, nullptr, st);
             }
             launch_merge(comb_s, comb_id, 2, kp, (int64_t)2 * kp, nq, kp, Ddev, Idev, k, 0, nullptr, nullptr, st);
+            if ((h->prune_calls.fetch_add(1, std::memory_order_relaxed) & 3u) == 0)
+                MI_HIP(hipMemcpyAsync(h->prune_seen, pstats, 24, hipMemcpyDeviceToHost, st));
             return;
         }
     }
@@ -1605,6 +1634,8 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
             a.counters = cnt;
         }
         launch_scan(M, a, st);
+        if (a.prune_stats && (h->prune_calls.fetch_add(1, std::memory_order_relaxed) & 3u) == 0)
+            MI_HIP(hipMemcpyAsync(h->prune_seen, pstats, 24, hipMemcpyDeviceToHost, st));
         if (pass == 0) {
             w.last_scan = a;
             w.have_last_scan = true;
