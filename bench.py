@@ -561,7 +561,12 @@ def cfg4_workload(args, ctx):
     # ---- the same loop with the exact list pruning off (MI_SCAN_PRUNE=0): every probed list scanned, as faiss's
     # IndexIVFPQ.search does -- the step the rounds before 6 timed, and the launch the scan kernel's roofline is quoted on
     pruning, exhaustive = None, None
-    if pst["queries"] > 0 and not os.environ.get("BENCH_NO_EXHAUSTIVE"):   # (BENCH_NO_EXHAUSTIVE: kernel traces of the pruned step alone)
+    pruned_here = pst["queries"] > 0
+    if world > 1 and dist.is_initialized():                  # (every rank takes the same legs: the steps below hold collectives)
+        t = torch.tensor([1 if pruned_here else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        pruned_here = bool(t.item())
+    if pruned_here and not os.environ.get("BENCH_NO_EXHAUSTIVE"):   # (BENCH_NO_EXHAUSTIVE: kernel traces of the pruned step alone)
         g_all, g_2 = pst["groups_all_probes"], pst["groups_second_phase"]
         early = batch >= 512 and nprobe <= 64 and os.environ.get("MI_SCAN_PRUNE_MODE", "0") != "1"
         pruning = {"exact": True, "form": "early stop inside the scan kernel (one workgroup per query)" if early else "two scan launches",

@@ -1,5 +1,5 @@
 timeout 300 python -m pytest tests/test_ivfpq_gpu.py -x -q -k "exact_list_pruning or search_matches_oracle" 2>&1 | tail -1
-for st in 2 3 4; do
+for st in ${PRUNE_STREAMS:-2 3 4}; do
 timeout 600 python bench.py --no-encode --no-cpu-baseline --no-refine-point --streams $st 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; p=d['pruning']; x=d['exhaustive_scan']; f=r['pruned_step_scan']
