@@ -629,7 +629,7 @@ struct mi_index {
     DevBuf prune_stats;
     bool prune_stats_ok = false;
     unsigned long long prune_base[3] = {0, 0, 0};
-    unsigned long long *prune_seen = nullptr;   // pinned, [3]
+    unsigned long long *prune_seen = nullptr;   // pinned, [PRUNE_SLOTS][3]
     std::atomic<unsigned> prune_calls{0};
 
     int nch() const { return (M + 15) / 16; }
@@ -1276,15 +1276,16 @@ int mi_index_profile_scan(mi_index *h, int reps, void *stream, double *scan_ms_a
         if (replay.prune_A) {
             // an early-stop launch reads only the groups its waves reach: counted by one more replay (whole 64-code groups)
             DevBuf tmp;
-            unsigned long long *t3 = tmp.as<unsigned long long>(3);
-            MI_HIP(hipMemsetAsync(t3, 0, 24, st));
+            unsigned long long *t3 = tmp.as<unsigned long long>(PRUNE_SLOTS * 3);
+            MI_HIP(hipMemsetAsync(t3, 0, PRUNE_SLOTS * 24, st));
             ScanArgs sa = replay;
             sa.prune_stats = t3;
             launch_scan(h->M, sa, st);
             MI_HIP(hipStreamSynchronize(st));
-            unsigned long long g3[3] = {0, 0, 0};
-            MI_HIP(hipMemcpy(g3, t3, 24, hipMemcpyDeviceToHost));
-            c = std::min<unsigned long long>(c, g3[0] * 64ull);
+            unsigned long long g3[PRUNE_SLOTS * 3], groups = 0;
+            MI_HIP(hipMemcpy(g3, t3, sizeof(g3), hipMemcpyDeviceToHost));
+            for (int sl = 0; sl < PRUNE_SLOTS; ++sl) groups += g3[sl * 3];
+            c = std::min<unsigned long long>(c, groups * 64ull);
         }
         if (scan_ms_avg) *scan_ms_avg = (double)ms / reps;
         if (scan_bytes) *scan_bytes = (int64_t)c * (h->M + 8);
@@ -1299,8 +1300,10 @@ int mi_index_prune_stats(mi_index *h, unsigned long long *out3, int reset) {
         out3[0] = out3[1] = out3[2] = 0;
         if (!h->prune_stats_ok) return;
         MI_HIP(hipDeviceSynchronize());
-        unsigned long long life[3];
-        MI_HIP(hipMemcpy(life, h->prune_stats.p, 24, hipMemcpyDeviceToHost));
+        unsigned long long slots[PRUNE_SLOTS * 3], life[3] = {0, 0, 0};
+        MI_HIP(hipMemcpy(slots, h->prune_stats.p, sizeof(slots), hipMemcpyDeviceToHost));
+        for (int sl = 0; sl < PRUNE_SLOTS; ++sl)
+            for (int i = 0; i < 3; ++i) life[i] += slots[sl * 3 + i];
         for (int i = 0; i < 3; ++i) {
             out3[i] = life[i] - h->prune_base[i];
             if (reset) h->prune_base[i] = life[i];
@@ -1514,20 +1517,23 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
     unsigned long long *pstats = nullptr;
     if (prunable) {
         std::lock_guard<std::mutex> hl(h->mu);
-        pstats = h->prune_stats.as<unsigned long long>(3);
+        pstats = h->prune_stats.as<unsigned long long>(PRUNE_SLOTS * 3);
         if (!h->prune_stats_ok) {
-            MI_HIP(hipMemsetAsync(pstats, 0, 24, st));
+            MI_HIP(hipMemsetAsync(pstats, 0, PRUNE_SLOTS * 24, st));
             MI_HIP(hipStreamSynchronize(st));
-            MI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->prune_seen), 24, hipHostMallocDefault));
-            h->prune_seen[0] = h->prune_seen[1] = h->prune_seen[2] = 0;
+            MI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->prune_seen), PRUNE_SLOTS * 24, hipHostMallocDefault));
+            std::memset(h->prune_seen, 0, PRUNE_SLOTS * 24);
             h->prune_stats_ok = true;
         }
     }
     // does this index's data prune?  (counters of earlier calls, as last copied to the host; nothing seen yet: assume it does)
     bool prunes_well = true;
     if (prunable && h->prune_seen) {
-        const unsigned long long g_scanned = reinterpret_cast<volatile unsigned long long *>(h->prune_seen)[0],
-                                 g_all = reinterpret_cast<volatile unsigned long long *>(h->prune_seen)[1];
+        unsigned long long g_scanned = 0, g_all = 0;
+        for (int sl = 0; sl < PRUNE_SLOTS; ++sl) {
+            g_scanned += reinterpret_cast<volatile unsigned long long *>(h->prune_seen)[sl * 3];
+            g_all += reinterpret_cast<volatile unsigned long long *>(h->prune_seen)[sl * 3 + 1];
+        }
         if (g_all >= 100000 && g_scanned <= g_all) prunes_well = (double)g_scanned < 0.5 * (double)g_all;
     }
     if (early && knobs().nslice <= 0 && nslice > 1 && prunes_well) {
@@ -1599,7 +1605,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
             }
             launch_merge(comb_s, comb_id, 2, kp, (int64_t)2 * kp, nq, kp, Ddev, Idev, k, 0, nullptr, nullptr, st);
             if ((h->prune_calls.fetch_add(1, std::memory_order_relaxed) & 3u) == 0)
-                MI_HIP(hipMemcpyAsync(h->prune_seen, pstats, 24, hipMemcpyDeviceToHost, st));
+                MI_HIP(hipMemcpyAsync(h->prune_seen, pstats, PRUNE_SLOTS * 24, hipMemcpyDeviceToHost, st));
             return;
         }
     }
@@ -1635,7 +1641,7 @@ static void search_chunk(mi_index *h, SearchWS &w, int64_t nq, const float *qdev
         }
         launch_scan(M, a, st);
         if (a.prune_stats && (h->prune_calls.fetch_add(1, std::memory_order_relaxed) & 3u) == 0)
-            MI_HIP(hipMemcpyAsync(h->prune_seen, pstats, 24, hipMemcpyDeviceToHost, st));
+            MI_HIP(hipMemcpyAsync(h->prune_seen, pstats, PRUNE_SLOTS * 24, hipMemcpyDeviceToHost, st));
         if (pass == 0) {
             w.last_scan = a;
             w.have_last_scan = true;

@@ -2103,8 +2103,11 @@ struct ScanArgs {
     const float *prune_A;      // [nq] or null
     const int32_t *prune_sorted;   // null, or [nq]: 0 = this query's lists are NOT in descending coarse order (caller-assigned lists):
                                    // no early stop for it
-    unsigned long long *prune_stats;   // null, or [3] += {groups processed, groups of all probes, queries}
+    unsigned long long *prune_stats;   // null, or [PRUNE_SLOTS][3] += {groups processed, groups of all probes, queries}; one atomic
+                                       // triple per WORKGROUP, spread over the slots (one per wave on one address: 10 k serialised
+                                       // atomics, 50 us of a 245 us launch)
 };
+constexpr int PRUNE_SLOTS = 64;
 
 // LDS bytes the fused final merge needs inside the LUT region
 __host__ __device__ inline size_t scan_fused_merge_bytes(int nslice, int k) {
@@ -2312,6 +2315,7 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
     if (tid == 0) {
         *wg_thr = f2o(MI_NEG_INF);
         *c_total = 0;
+        c_total[1] = 0;    // groups this workgroup processed (prune_stats)
     }
     if (!reg_tab) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2501,13 +2505,8 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
         if (t + 2 * SCAN_NW < my_end) locate_and_load(t + 2 * SCAN_NW, g1);
         t += SCAN_NW;
     }
-    if (!ALL && a.prune_stats) {
-        if (lane == 0 && n_proc) atomicAdd(a.prune_stats, (unsigned long long)n_proc);
-        if (tid == 0 && slice == 0) {
-            atomicAdd(a.prune_stats + 1, (unsigned long long)G);
-            atomicAdd(a.prune_stats + 2, 1ull);
-        }
-    }
+    int *c_groups = c_total + 1;    // (a spare word of the carve's last 16 bytes)
+    if (!ALL && a.prune_stats && lane == 0 && n_proc) atomicAdd(c_groups, n_proc);
 
     if constexpr (ALL) return;
     stamp(4);
@@ -2520,6 +2519,14 @@ __global__ void __launch_bounds__(NW * 64, 4) scan_kernel(ScanArgs a) {   // 4 w
     tmax[w * SCAN_WBUF + lane] = max(max(ka, kb), kc3);
     __syncthreads();  // every wave is done with the LUT: its LDS is reused below
     stamp(5);
+    if (a.prune_stats && tid == 0) {
+        unsigned long long *ps3 = a.prune_stats + (size_t)(blockIdx.x & (PRUNE_SLOTS - 1)) * 3;
+        atomicAdd(ps3, (unsigned long long)*c_groups);
+        if (slice == 0) {
+            atomicAdd(ps3 + 1, (unsigned long long)G);
+            atomicAdd(ps3 + 2, 1ull);
+        }
+    }
     // Any k distinct candidates bound the k-th largest from below, so for small k the
     // 512 thread maxima are first folded to 64 (k <= 16) or 128 (k <= 64) column maxima:
     // the descent then costs one or two ballots per step instead of eight.
@@ -3118,7 +3125,7 @@ struct PruneArgs {
     int k, nprobe, P1, M, mode;
     int32_t *len_out;          // [nq][nprobe]
     int32_t *prefix_out;       // [nq][nprobe+1]
-    unsigned long long *stats; // null, or [3] += {groups this phase scans, groups of all probes, queries}
+    unsigned long long *stats; // null, or [PRUNE_SLOTS][3] += {groups this phase scans, groups of all probes, queries} (slot = workgroup % PRUNE_SLOTS)
 };
 
 __global__ void __launch_bounds__(256) prune_tables_kernel(PruneArgs a) {
@@ -3162,9 +3169,10 @@ __global__ void __launch_bounds__(256) prune_tables_kernel(PruneArgs a) {
             if (p == K - 1) a.prefix_out[q * (K + 1) + K] = run;
         }
     if (a.stats && tid == 0) {
-        atomicAdd(a.stats, (unsigned long long)(wtot[0] + wtot[1] + wtot[2] + wtot[3]));
-        atomicAdd(a.stats + 1, (unsigned long long)a.p_prefix[q * (K + 1) + K]);
-        atomicAdd(a.stats + 2, 1ull);
+        unsigned long long *ps3 = a.stats + (size_t)(blockIdx.x & (PRUNE_SLOTS - 1)) * 3;
+        atomicAdd(ps3, (unsigned long long)(wtot[0] + wtot[1] + wtot[2] + wtot[3]));
+        atomicAdd(ps3 + 1, (unsigned long long)a.p_prefix[q * (K + 1) + K]);
+        atomicAdd(ps3 + 2, 1ull);
     }
 }
 

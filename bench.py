@@ -620,49 +620,64 @@ def cfg4_workload(args, ctx):
             _, Ia = sharded.search_replicated(q_gt, k)
         recall = recall_at_k(Ia, gt[1][:batch])
 
-    # ---- roofline of the dominant kernel (PQ-code scan): the library re-launches the scan of
-    # the last step back to back between two HIP events recorded on the launch stream
+    # ---- roofline of the dominant kernel (PQ-code scan): the library re-launches the scan of the last step back to back between
+    # two HIP events recorded on the launch stream.  With the exact list pruning the timed step's launch reads what its waves
+    # reach (device-counted); the exhaustive launch -- the kernel at the size SURVEY 8(d) prices -- is profiled beside it.
     torch.cuda.synchronize()
-    prof_p1 = None
-    if exhaustive is not None:
-        # the pruned step's own first phase, then (knob off) the exhaustive launch the kernel's roofline is quoted on
+    reps_p = max(3, min(steps, 20))
+    prof_p = prof_x = None
+    if pruned_here:
         index.search_into(my_q[0], k, Ds[0], Is[0], None, sptr[0])
-        prof_p1 = index.profile_scan(max(3, min(steps, 20)), sptr[0])
+        prof_p = index.profile_scan(reps_p, sptr[0])
         torch.cuda.synchronize()
-        os.environ["MI_SCAN_PRUNE"] = "0"
-        faiss.reload_env()
-    index.search_into(my_q[0], k, Ds[0], Is[0], None, sptr[0])
-    prof = index.profile_scan(max(3, min(steps, 20)), sptr[0])
-    torch.cuda.synchronize()
-    if exhaustive is not None:
-        del os.environ["MI_SCAN_PRUNE"]
-        faiss.reload_env()
-    scan_ms, scan_bytes = prof["scan_ms_avg"], prof["scan_bytes"]
-    achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    pmc, traffic_src = committed_traffic("r06_cfg4_scan_pmc.json", lambda d: (N, nlist, batch, nprobe, k, nsh) == tuple(d["config"]))
-    traffic = int(pmc["corrected_bytes_per_launch"]) if pmc else None
-    roofline = {"kernel": "scan_kernel<64,8,false>", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "bytes_per_launch": int(scan_bytes), "avg_launch_ms": round(scan_ms, 5),
-                "algorithmic_bytes": "codes of the probed lists x (64 B code + 8 B id), device-counted: SURVEY 8(d)'s per-code figure (what "
-                                     "the reference's scan reads)",
-                # since round 6 the kernel reads the id of a code only if the code survives its workgroup's selection: what it
-                # MOVES is the code bytes -- below the algorithmic figure, which `traffic` (PMC) shows
-                "bytes_moved_per_launch": int(scan_bytes * 64 // 72),
-                "frac_of_bytes_moved": round(scan_bytes * 64 / 72 / (scan_ms * 1e-3) / 1e9 / 8000.0, 4) if scan_ms > 0 else None,
-                "bytes_moved_note": "64 B per code (ids are fetched for the <= 3 k survivors of a workgroup only): the kernel is bound by its "
-                                    "LDS gather (64 table reads per code, random banks) at about this rate"}
-    if exhaustive is not None:
-        roofline["launch"] = ("the exhaustive launch (all nprobe lists of every query: `exhaustive_scan`) -- the kernel at the size SURVEY 8(d) prices; "
-                              "the timed step runs the same kernel on the lists that survive (`pruned_step_scan`)")
-        p1b, p1ms = prof_p1["scan_bytes"], prof_p1["scan_ms_avg"]
-        roofline["pruned_step_scan"] = {
-            "avg_launch_ms": round(p1ms, 5), "bytes_per_launch": int(p1b),
-            "achieved": round(p1b / (p1ms * 1e-3) / 1e9, 1) if p1ms > 0 else None, "unit": "GB/s",
-            "frac": round(p1b / (p1ms * 1e-3) / 1e9 / 8000.0, 4) if p1ms > 0 else None,
-            "note": "the (first) scan launch of the pruned step, one workgroup per query; bytes = the 64-code groups its waves reached x 72 B "
-                    "per code (device-counted); the 64 KiB table staging and the selection tail of a workgroup are spread over ~200 groups "
-                    "where a workgroup of the exhaustive launch has ~500"}
+    if not pruned_here or exhaustive is not None:
+        if pruned_here:
+            os.environ["MI_SCAN_PRUNE"] = "0"
+            faiss.reload_env()
+        index.search_into(my_q[0], k, Ds[0], Is[0], None, sptr[0])
+        prof_x = index.profile_scan(reps_p, sptr[0])
+        torch.cuda.synchronize()
+        if pruned_here:
+            del os.environ["MI_SCAN_PRUNE"]
+            faiss.reload_env()
+    cfg_key = (N, nlist, batch, nprobe, k, nsh)
+
+    def scan_roofline(prof, pmc_file, pruned_launch):
+        ms, nbytes = prof["scan_ms_avg"], prof["scan_bytes"]
+        ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        pmc, src = committed_traffic(pmc_file, lambda d_: cfg_key == tuple(d_["config"]))
+        out = {"kernel": "scan_kernel<64,8,false>", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0,
+               "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": int(pmc["corrected_bytes_per_launch"]) if pmc else None,
+               "traffic_source": src, "bytes_per_launch": int(nbytes), "avg_launch_ms": round(ms, 5),
+               # since round 6 the kernel reads the id of a code only if the code survives its workgroup's selection: what it
+               # MOVES is the code bytes -- below the algorithmic figure, which `traffic` (PMC) shows
+               "bytes_moved_per_launch": int(nbytes * 64 // 72),
+               "frac_of_bytes_moved": round(nbytes * 64 / 72 / (ms * 1e-3) / 1e9 / 8000.0, 4) if ms > 0 else None}
+        if pruned_launch:
+            out["launch"] = ("the timed step's scan launch: exact list pruning on, one workgroup per query walks the probed lists in coarse order "
+                             "and every wave stops at the first list that provably holds no result (`pruning`)")
+            out["algorithmic_bytes"] = ("the 64-code groups the waves reached (device-counted) x 64 codes x (64 B code + 8 B id): SURVEY 8(d)'s per-code "
+                                        "figure on the codes this launch reads; PMC traffic adds the 64 KiB look-up table every workgroup stages")
+            out["note"] = ("a workgroup's table staging and selection tail are spread over ~200 groups where a workgroup of the exhaustive launch "
+                           "has ~500: the rate on this launch is lower than on `exhaustive_launch`, the step 5-6 x shorter")
+        else:
+            out["algorithmic_bytes"] = ("codes of the probed lists x (64 B code + 8 B id), device-counted: SURVEY 8(d)'s per-code figure (what "
+                                        "the reference's scan reads)")
+            out["bytes_moved_note"] = ("64 B per code (ids are fetched for the <= 3 k survivors of a workgroup only): the kernel is bound by its "
+                                       "LDS gather (64 table reads per code, random banks) at about this rate")
+        return out
+
+    if prof_p is not None:
+        roofline = scan_roofline(prof_p, "r06_cfg4_pruned_scan_pmc.json", True)
+        if prof_x is not None:
+            roofline["exhaustive_launch"] = dict(scan_roofline(prof_x, "r06_cfg4_scan_pmc.json", False),
+                                                 launch="MI_SCAN_PRUNE=0: all nprobe lists of every query (`exhaustive_scan`) -- the kernel at the size "
+                                                        "SURVEY 8(d) prices, the launch rounds 1-5 quoted")
+    else:
+        roofline = scan_roofline(prof_x, "r06_cfg4_scan_pmc.json", False)
+    # (what the per-rank split and the scaling model below are written in: the exhaustive launch when it was measured)
+    prof_m = prof_x if prof_x is not None else prof_p
+    scan_ms, scan_bytes = prof_m["scan_ms_avg"], prof_m["scan_bytes"]
 
     # ---- recall >= 0.95 operating point: IVF-PQ proposes k * k_factor candidates, exact re-ranking
     at095 = None

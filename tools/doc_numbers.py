@@ -5,7 +5,9 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
 d = json.loads(open(src).read().strip().splitlines()[-1])
-a, e, c5, r = d["at_recall_095"], d["encode"], d["cfg5"]["curve"], d["roofline"]
+a, e, c5 = d["at_recall_095"], d["encode"], d["cfg5"]["curve"]
+ps = d["roofline"] if "exhaustive_launch" in d["roofline"] else {}        # the timed (pruned) step's scan launch
+r = d["roofline"].get("exhaustive_launch", d["roofline"])                 # the exhaustive launch: SURVEY 8(d)'s size
 k = lambda v: f"{v / 1e3:.1f} k"
 sp = lambda v: f"{v:,.0f}".replace(",", " ")
 traffic = (r.get("traffic") or 0) / 1e9
@@ -14,14 +16,15 @@ c5lat = " / ".join(f"{c['latency_ms_p50']:.2f}" for c in c5)
 c5enc = " / ".join(f"{c['encode_alone_ms']:.2f}" for c in c5)
 cpu = f"{d['cpu_baseline']['value']:.0f}" if d.get("cpu_baseline") else "n/a"
 M = lambda v: f"{v / 1e6:.2f} M"
-pr, xs, ps = d.get("pruning") or {}, d.get("exhaustive_scan") or {}, r.get("pruned_step_scan") or {}
+pr, xs = d.get("pruning") or {}, d.get("exhaustive_scan") or {}
+ptraffic = (ps.get("traffic") or 0) / 1e9
 frac_scanned = pr.get("scanned_fraction", pr.get("second_launch_fraction", 0.0))
 rel = os.path.relpath(src, ROOT)
 
 design_rows = f"""| what | value | roofline / evidence |
 |---|---|---|
-| cfg4 headline: 207 M × 1024, IVF65536,PQ64, batch 1024, nprobe 64, k 10, queries and results resident in HBM | **{M(d['value'])} queries/s**, {d['ms_per_step']:.3f} ms/step — exact list pruning on (the default; same `(D, I)` bits): the scan reads **{frac_scanned:.3f}** of the probed lists' codes | `pruning` / `roofline.pruned_step_scan` of the line: its scan launch {ps.get('avg_launch_ms', 0):.3f} ms, {ps.get('frac', 0):.2f} of the HBM peak on the bytes it reads; §4 “Exact list pruning”, `profiles/r06_exact_list_pruning_ab.txt` |
-| the same step scanning every probed list, as faiss does (`exhaustive_scan`, MI_SCAN_PRUNE=0: the step of rounds 1–5) | {k(xs.get('queries_per_s', 0))} queries/s, {xs.get('ms_per_step', 0):.3f} ms/step | `scan_kernel<64,8,false,false>` {r['avg_launch_ms']:.2f} ms per launch: {r['achieved'] / 1e3:.2f} TB/s = **{r['frac']:.3f}** of 8 TB/s by SURVEY §8(d)'s (64 + 8) B per code; bytes actually moved (ids only for survivors) {r['frac_of_bytes_moved']:.3f}; PMC traffic {traffic:.2f} GB = {ratio:.3f} × algorithmic (`profiles/r06_cfg4_scan_pmc.json`) |
+| cfg4 headline: 207 M × 1024, IVF65536,PQ64, batch 1024, nprobe 64, k 10, queries and results resident in HBM | **{M(d['value'])} queries/s**, {d['ms_per_step']:.3f} ms/step — exact list pruning on (the default; same `(D, I)` bits): the scan reads **{frac_scanned:.3f}** of the probed lists' codes | `roofline` of the line = this step's scan launch: {ps.get('avg_launch_ms', 0):.3f} ms, {ps.get('bytes_per_launch', 0) / 1e9:.2f} GB of codes reached = **{ps.get('frac', 0):.3f}** of 8 TB/s, PMC traffic {ptraffic:.2f} GB (`profiles/r06_cfg4_pruned_scan_pmc.json`); §4 “Exact list pruning”, `profiles/r06_exact_list_pruning_ab.txt` |
+| the same step scanning every probed list, as faiss does (`exhaustive_scan`, MI_SCAN_PRUNE=0: the step of rounds 1–5) | {k(xs.get('queries_per_s', 0))} queries/s, {xs.get('ms_per_step', 0):.3f} ms/step | `roofline.exhaustive_launch`: `scan_kernel<64,8,false,false>` {r['avg_launch_ms']:.2f} ms per launch: {r['achieved'] / 1e3:.2f} TB/s = **{r['frac']:.3f}** of 8 TB/s by SURVEY §8(d)'s (64 + 8) B per code; bytes actually moved (ids only for survivors) {r['frac_of_bytes_moved']:.3f}; PMC traffic {traffic:.2f} GB = {ratio:.3f} × algorithmic (`profiles/r06_cfg4_scan_pmc.json`) |
 | the same steps as faiss callers write them (`host_io`: numpy in, numpy `(D, I)` out) | {M(d['host_io']['queries_per_s'])} queries/s, {d['host_io']['ms_per_step']:.3f} ms/step | never `value`; PCIe both ways + a host sync per call |
 | recall@10 ≥ 0.95 point: `IVF65536,PQ64,Refine(SQ8)`, all 207 M rows on one GPU, (nprobe, k_factor) chosen on a held-out batch | recall **{a['recall_at_10']:.4f}** (selection batch {a['recall_at_10_selection_batch']:.4f}) at **{k(a['qps'])} queries/s**, {a['ms_per_step']:.3f} ms/step, (nprobe {a['nprobe']}, k_factor {a['k_factor_rf']}) | re-rank stage {a['roofline']['frac']:.2f} of HBM peak, PMC 1.03 × algorithmic (`profiles/r06_cfg4_refine_pmc.json`); ids and score bits equal the oracle at the timed shape |
 | encode (cfg3), 128 abstracts / 27 958 tokens per step | **{sp(e['abstracts_per_s'])} abstracts/s**, {e['ms_per_step']:.1f} ms/step | GEMM replay frac **{e['roofline']['frac']:.3f}** of 2.5 PF bf16; L2-miss traffic 2.56 × algorithmic |

@@ -86,6 +86,28 @@ if F and W:
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction (profiles/r06_cfg4_refine_pmc.json)",
                "kernel_source": [kernel_stamp.stamp("ivfpq_kernels.h", "rerank_sq8_kernel")]}
         json.dump(doc, open(prof + "/r06_cfg4_refine_pmc.json", "w"), indent=1); made.append("r06_cfg4_refine_pmc.json")
+# ---- cfg4 with the exact list pruning on: the timed step's own scan launch (BENCH_NO_EXHAUSTIVE=1 passes: every dispatch is of that kind)
+Fp, Wp, stp = parse(src + "/cfg4_pruned_FETCH_SIZE.txt"), parse(src + "/cfg4_pruned_WRITE_SIZE.txt"), stats(src + "/cfg4_pruned_kernel_stats.csv")
+if Fp and Wp:
+    for suf in ("_kernel_stats.csv", "_FETCH_SIZE.txt", "_WRITE_SIZE.txt"):
+        f = os.path.join(src, "cfg4_pruned" + suf)
+        if os.path.exists(f):
+            open(os.path.join(prof, "r06_cfg4_pruned_step" + suf.replace("_kernel_stats", "_kernel_stats_" + VER).replace("_SIZE.txt", "_SIZE_" + VER + ".txt")), "w").write(open(f).read())
+    line = json.loads([l for l in open(src + "/cfg4_pruned_under_FETCH_SIZE.out") if l.startswith("{")][-1])
+    cfg, rl = line["config"], line["roofline"]
+    kf = [n for n in Fp if "scan_kernel<64, 8, false, false>" in n][0]
+    kw = [n for n in Wp if "scan_kernel<64, 8, false, false>" in n][0]
+    corrected = int(Fp[kf]["FETCH_SIZE"][1] * 2048 + Wp[kw]["WRITE_SIZE"][1] * 1024)
+    doc = {"kernel": kf, "dispatches": Fp[kf]["FETCH_SIZE"][0], "FETCH_SIZE_KiB_mean": Fp[kf]["FETCH_SIZE"][1], "WRITE_SIZE_KiB_mean": Wp[kw]["WRITE_SIZE"][1],
+           "corrected_bytes_per_launch": corrected, "config": [cfg["corpus"], cfg["nlist"], cfg["global_batch"], cfg["nprobe"], cfg["k"], 1],
+           "config_text": "cfg4 with the exact list pruning on (the default): the timed step's scan launch -- one workgroup per query, every wave stops at the first list that provably holds no result",
+           "how": "two separate rocprofv3 --pmc passes (tools/prof_r06.sh cfg4: FETCH_SIZE, then WRITE_SIZE; --kernel-trace only, --kernel-include-regex 'scan_kernel') of `BENCH_NO_EXHAUSTIVE=1 bench.py --no-encode --no-cpu-baseline --streams 1 --no-refine-point --no-recall --steps 10`: no exhaustive launch in the process; means over the dispatches of this kernel (profiles/r06_cfg4_pruned_step_FETCH_SIZE_v1.txt, _WRITE_SIZE_v1.txt)",
+           "correction": CORR, "algorithmic_bytes_per_launch": rl["bytes_per_launch"], "traffic_over_algorithmic": round(corrected / rl["bytes_per_launch"], 4),
+           "what_the_difference_is": "every workgroup stages its query's 64 KiB look-up table (1024 x 64 KiB = 67 MB) and reads whole code groups two ahead of the stop",
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction (profiles/r06_cfg4_pruned_scan_pmc.json)",
+           "kernel_trace_same_command": {"scan_avg_ms_batch1024": round((avg_us(stp, "scan_kernel<64, 8, false, false>") or 0) / 1e3, 4), "file": "profiles/r06_cfg4_pruned_step_kernel_stats_v1.csv"},
+           "kernel_source": [kernel_stamp.stamp("ivfpq_kernels.h", "scan_kernel")]}
+    json.dump(doc, open(prof + "/r06_cfg4_pruned_scan_pmc.json", "w"), indent=1); made.append("r06_cfg4_pruned_scan_pmc.json")
 # ---- bulk encode
 if os.path.exists(src + "/encode_gemm_FETCH_SIZE.txt"):
     keep("encode"); keep("encode_gemm")

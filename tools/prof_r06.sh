@@ -30,7 +30,10 @@ for part in $parts; do case $part in
 cfg4)
   B="python $R/bench.py --no-encode --no-cpu-baseline --streams 1"
   # the step as it runs by default (exact list pruning on; bench.py times the exhaustive step beside it): its kernels
+  export BENCH_NO_EXHAUSTIVE=1    # (only the pruned step's launches of the scan kernel in these three passes)
   stats cfg4_pruned $B --no-refine-point --no-recall
+  for c in FETCH_SIZE WRITE_SIZE; do pmc cfg4_pruned $c "scan_kernel" $B --no-refine-point --no-recall --steps 10; done
+  unset BENCH_NO_EXHAUSTIVE
   # everything below on the EXHAUSTIVE scan (MI_SCAN_PRUNE=0) -- the launch the scan kernel's roofline is quoted on: with the
   # pruning on, the timed step's launches of the same kernel read a sixteenth of the lists and would share every mean
   export MI_SCAN_PRUNE=0
