@@ -221,3 +221,34 @@ def test_sq8_restatement_against_float64_and_the_documented_formulas(oracle):
     cand[1, 4:] = -1
     D, I = oracle.rerank_sq8(q, allc, tr, cand, k)
     assert (I[1][4:] == -1).all() and (D[1][4:] == -np.finfo(np.float32).max).all() and (I[1][:4] >= 0).all()
+
+
+@given(seed=st.integers(0, 2**31 - 1), M=st.sampled_from([4, 16, 64]), spread=st.sampled_from([1e-3, 1.0, 1e4, 1e20]),
+       dis_scale=st.sampled_from([0.0, 1.0, 1e6, 1e-30]))
+@settings(max_examples=60, deadline=None)
+def test_chain_of_row_maxima_bounds_every_code_in_floating_point(seed, M, spread, dis_scale):
+    """The exactness argument of the exact list pruning (csrc/ivfpq_kernels.h above prune_tables_kernel), on the oracle's
+    arithmetic: a code scores fl(dis0 + acc), acc = the f32 chain 0 + LUT[0][c0] + LUT[1][c1] + ... (m ascending: ivfpq_oracle.c,
+    "ADC sum"); with A = the same chain over the row maxima, acc <= A and fl(dis0 + acc) <= fl(dis0 + A) for the COMPUTED values,
+    because rounded addition is monotone in both operands -- no slack term, whatever the magnitudes (mixed signs, a dynamic range
+    that makes most additions inexact, subnormals)."""
+    rng = np.random.default_rng(seed)
+    lut = (rng.standard_normal((M, 256)) * spread * 10.0 ** rng.integers(-8, 8, (M, 1))).astype(np.float32)
+    if seed % 3 == 0:
+        lut[rng.integers(0, M), rng.integers(0, 256)] = np.float32(1e-42)      # a subnormal entry
+    codes = rng.integers(0, 256, (500, M))
+    dis0 = np.float32(rng.standard_normal() * dis_scale)
+    acc = np.zeros(500, np.float32)
+    A = np.float32(0.0)
+    for m in range(M):                                                          # one rounded addition per step, as the kernel does
+        acc = (acc + lut[m, codes[:, m]]).astype(np.float32)
+        A = np.float32(A + lut[m].max())
+        assert (acc <= A).all()
+    s, U = (dis0 + acc).astype(np.float32), np.float32(dis0 + A)
+    assert (s <= U).all()
+    # and the bound is attained by the code that takes every row's maximum: nothing tighter holds for a whole list
+    best = lut.argmax(axis=1)
+    accb = np.float32(0.0)
+    for m in range(M):
+        accb = np.float32(accb + lut[m, best[m]])
+    assert np.float32(dis0 + accb) == U
